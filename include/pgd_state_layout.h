@@ -1,0 +1,48 @@
+/*
+ * pgd_state_layout.h — field order of the struct-of-arrays simulation state exchanged through
+ * pgd_get_state / pgd_set_state (checkpoint / resume; BaseVehicle.get_state/set_state, base_vehicle.py:683-698).
+ *
+ * Float fields are [PGD_NF][N*V], int fields [PGD_NI][N*V] (index env*V + slot), env ints [PGD_NEI][N].
+ */
+#ifndef PGD_STATE_LAYOUT_H
+#define PGD_STATE_LAYOUT_H
+
+enum {
+  SF_X = 0, SF_Y, SF_THETA,   /* position, heading_theta [rad]          base_vehicle.py:390-416 */
+  SF_SPEED,                   /* [m/s] (speed property is km/h)         base_vehicle.py:394-401 */
+  SF_STEER, SF_THROTTLE,      /* last applied action                    base_vehicle.py:343-349 */
+  SF_LASTX, SF_LASTY,         /* last_position                          base_vehicle.py:246 */
+  SF_LASTHX, SF_LASTHY,       /* last_heading_dir                       base_vehicle.py:247 */
+  SF_ACT0S, SF_ACT0T,         /* last_current_action[0] (older)         base_vehicle.py:171,248 */
+  SF_ACT1S, SF_ACT1T,         /* last_current_action[1] (newer) */
+  SF_PID_HP, SF_PID_HI,       /* IDM heading PID p_error, i_error       PID_controller.py:1-17 */
+  SF_PID_LP, SF_PID_LI,       /* IDM lateral PID */
+  SF_TARGET_SPEED,            /* IDMPolicy.target_speed [km/h]          idm_policy.py:182 */
+  SF_ENERGY,                  /* energy_consumption                     base_vehicle.py:278-290 */
+  SF_DIST_LEFT, SF_DIST_RIGHT,/* dist_to_left_side / right_side         base_vehicle.py:380-388 */
+  SF_EP_REWARD,               /* episode_rewards                        base_env.py:335-339 */
+  SF_SPARE,
+  PGD_NF
+};
+enum {
+  SI_STATUS = 0,              /* ST_* */
+  SI_LANE,                    /* vehicle.lane (map-local id) */
+  SI_CK0, SI_CK1,             /* Navigation._target_checkpoints_index   navigation.py:132 */
+  SI_RLANE,                   /* IDMPolicy.routing_target_lane (-1 = None) */
+  SI_TIMER,                   /* IDMPolicy.overtake_timer */
+  SI_VFLAGS,                  /* PGD_F_* vehicle state bits */
+  SI_SPARE,
+  PGD_NI
+};
+enum {
+  EI_SCEN = 0,                /* scenario id of the running episode */
+  EI_NEXT_GROUP,              /* next traffic trigger group             traffic_manager.py:78-85 */
+  EI_EP_STEPS,                /* episode_steps                          base_env.py:185 */
+  EI_EPISODES,                /* auto-reset count (RNG counter) */
+  EI_STEPS_TOTAL,             /* steps since pgd_reset (RNG counter) */
+  EI_SPARE0, EI_SPARE1, EI_SPARE2,
+  PGD_NEI
+};
+enum { ST_EMPTY = 0, ST_PENDING = 1, ST_ACTIVE = 2, ST_REMOVED = 3 };
+
+#endif

@@ -1,0 +1,198 @@
+/*
+ * pgdrive_hip.h — C ABI of the MI355X-native batched PGDrive step engine.
+ *
+ * The reference (decisionforce/pgdrive v0.1.4) has no FFI/plugin layer for env.step(); its boundary is the Python
+ * gym.Env surface (pgdrive/envs/base_env.py:184-193 step, :269-290 reset, :403-425 spaces).  This header re-states that
+ * surface batched over N environments x V vehicle slots behind plain C entry points (no torch / C++ types), so a Python
+ * VecEnv (pgdrive_amd/vec_env.py, ctypes) or any other host can bind it.  Each entry point cites what it replaces.
+ *
+ * Conventions: int status codes (0 = PGD_OK); the caller owns every buffer; pointers named d_* are DEVICE pointers,
+ * h_* are HOST pointers; all work is enqueued on the hipStream_t given at creation (passed as void* so this header
+ * needs no HIP include); no hidden global state; one handle may be driven by one host thread at a time.
+ *
+ * Geometry contract (all float32, PGDrive coordinates: x forward, y left->right as in the reference, angles in rad):
+ *   pgd_lane  : StraightLane / CircularLane closed forms  (component/lane/straight_lane.py:13-67, circular_lane.py:11-67)
+ *   pgd_road  : RoadNetwork.graph[from][to] -> lanes     (component/road/road_network.py:20)
+ *   pgd_box   : every box the reference hands to Bullet   (component/blocks/base_block.py:286-464): lane-surface boxes
+ *               (kind 0), white/yellow continuous and broken line ghosts (1,2,3), sidewalk bodies (4)
+ *   uniform grid per map: cell -> ascending list of box ids (creation order == the reference's Bullet insertion order)
+ */
+#ifndef PGDRIVE_HIP_H
+#define PGDRIVE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGD_OK 0
+#define PGD_ERR_ARG 1
+#define PGD_ERR_HIP 2
+#define PGD_ERR_STATE 3
+
+#define PGD_MAX_SUCC 8       /* successor lanes stored inline per lane */
+#define PGD_MAX_CKPT 32      /* max nodes of a route (Navigation.checkpoints, navigation.py:131) */
+#define PGD_NAVI_DIM 10      /* Navigation.navigation_info_dim (navigation.py:23) */
+#define PGD_STATE_DIM 8      /* ego floats of StateObservation.vehicle_state at default config (state_obs.py:58-106) */
+
+/* box kinds (constants.py:55-63 BodyName) */
+#define PGD_BOX_LANE 0
+#define PGD_BOX_WHITE 1
+#define PGD_BOX_YELLOW 2
+#define PGD_BOX_BROKEN 3
+#define PGD_BOX_SIDEWALK 4
+
+/* per-agent flag bits returned by pgd_step (constants.py:15-22 TerminationState + BaseVehicleState) */
+#define PGD_F_ARRIVE        (1u << 0)   /* arrive_dest          base_vehicle.py:738-745 */
+#define PGD_F_OUT_OF_ROAD   (1u << 1)   /* out_of_road          pgdrive_env.py:209-216 */
+#define PGD_F_CRASH_VEHICLE (1u << 2)   /* crash_vehicle        collision_callback.py:7-36 */
+#define PGD_F_CRASH_OBJECT  (1u << 3)   /* crash_object (no objects in this build: always 0) */
+#define PGD_F_CRASH_BUILDING (1u << 4)  /* crash_building (InvisibleWall/TollGate: always 0 on PG maps) */
+#define PGD_F_MAX_STEP      (1u << 5)   /* max_step / horizon   base_env.py:190-192 */
+#define PGD_F_ON_YELLOW     (1u << 8)   /* on_yellow_continuous_line  base_vehicle.py:615-636 */
+#define PGD_F_ON_WHITE      (1u << 9)   /* on_white_continuous_line */
+#define PGD_F_ON_BROKEN     (1u << 10)  /* on_broken_line */
+#define PGD_F_CRASH_SIDEWALK (1u << 11) /* crash_sidewalk        base_vehicle.py:638-643 */
+#define PGD_F_OFF_LANE      (1u << 12)  /* not on_lane           navigation.py:158-160 */
+#define PGD_F_OUT_OF_ROUTE  (1u << 13)  /* out_of_route          base_vehicle.py:274-276 */
+#define PGD_F_RESET         (1u << 16)  /* this env was auto-reset at the end of the step (obs is the new episode's) */
+
+typedef struct pgd_lane {   /* 64 B */
+  float ax, ay;             /* straight: start point; circular: centre */
+  float bx, by;             /* straight: unit direction; circular: (radius, start_phase) */
+  float c;                  /* straight: heading; circular: end_phase */
+  float dir;                /* 0 = straight; +1/-1 = CircularLane.direction */
+  float length, width;
+  float ex, ey;             /* lane end point = position(length, 0) */
+  int16_t road;             /* map-local road id */
+  int16_t index;            /* lane index inside its road (0 = left-most) */
+  int16_t n_succ;
+  int16_t pad;
+  int16_t succ[PGD_MAX_SUCC]; /* map-local lane ids L2 with |end - L2.start| < 0.1 (abs_lane.py:114-119) */
+} pgd_lane;
+
+typedef struct pgd_road {   /* 16 B */
+  int16_t from, to;         /* node ids */
+  int16_t first_lane, n_lanes;
+  uint8_t negative;         /* Road.is_negative_road (road.py:33-34) */
+  uint8_t block_id;         /* Road.block_ID char (road.py:46-51) */
+  uint8_t valid;            /* 0 for the decoration road */
+  uint8_t pad0;
+  int32_t pad1;
+} pgd_road;
+
+typedef struct pgd_box {    /* 32 B */
+  float cx, cy;             /* centre */
+  float ux, uy;             /* unit vector of the long axis */
+  float hl, hw;             /* half extents along / across */
+  int32_t kind;             /* PGD_BOX_* */
+  int32_t lane;             /* map-local lane id for PGD_BOX_LANE, else -1 */
+} pgd_box;
+
+typedef struct pgd_map {    /* per-map header; offsets index the bank-wide arrays */
+  int32_t lane_off, n_lanes;
+  int32_t road_off, n_roads;
+  int32_t box_off, n_boxes;
+  int32_t cell_off;         /* into cell_start[] (gx*gy+1 entries for this map) */
+  int32_t item_off;         /* into cell_items[] */
+  int32_t gx, gy;
+  float ox, oy, cell;       /* grid origin and cell size [m] */
+  float lane_width;         /* map config lane_width (Navigation.get_current_lane_width, navigation.py:322-323) */
+  int32_t pad[2];
+} pgd_map;
+
+/* One vehicle slot of a scenario (spawn state + static parameters).  Slots [0,A) are controlled agents, the rest are
+ * IDM traffic (manager/traffic_manager.py:239-290).  A slot with lane < 0 is unused. */
+typedef struct pgd_spawn {  /* 64 B + route */
+  float x, y, heading;      /* spawn pose: lane.position(long, lat), lane.heading_at(long)  (base_vehicle.py:304-309) */
+  float length, width;      /* vehicle_type.py:7-74 */
+  float wheelbase;          /* FRONT_WHEELBASE + REAR_WHEELBASE */
+  float mass;
+  float max_engine_force, max_brake_force, friction; /* utils/space.py:219-255 */
+  float max_steer;          /* [rad] */
+  float max_speed;          /* [km/h] */
+  int16_t lane;             /* spawn lane (map-local); <0 = empty slot */
+  int16_t group;            /* trigger group (block order); -1 = active from the start (agents) */
+  int16_t n_ckpt;           /* route length in nodes */
+  int16_t timer0;           /* IDMPolicy.overtake_timer initial value (idm_policy.py:185) */
+  int16_t dest_lane;        /* Navigation.final_lane (navigation.py:138-140) */
+  int16_t pad[3];
+  int16_t ckpt[PGD_MAX_CKPT];       /* route as node ids (Navigation.checkpoints) */
+  int16_t ckpt_road[PGD_MAX_CKPT];  /* road id of (ckpt[k], ckpt[k+1]); -1 past the end */
+} pgd_spawn;
+
+typedef struct pgd_scenario {
+  int32_t map;              /* index into the map table */
+  int32_t n_groups;         /* number of traffic trigger groups */
+  int16_t trigger_road[16]; /* BlockVehicles.trigger_road per group, in activation order (traffic_manager.py:283-288) */
+} pgd_scenario;
+
+typedef struct pgd_config {
+  int32_t num_envs;         /* N */
+  int32_t num_agents;       /* A  controlled agents per env (1 = PGDriveEnv; >1 = MARL) */
+  int32_t num_traffic;      /* T  IDM traffic slots per env; V = A + T */
+  int32_t num_lasers;       /* lidar beams (pgdrive_env.py:63; 0 disables the lidar block of the obs) */
+  int32_t num_others;       /* neighbour-info vehicles (lidar.num_others, 4) */
+  float lidar_dist;         /* 50 m */
+  float dt;                 /* physics_world_step_size 0.02 (base_env.py:70) */
+  int32_t decision_repeat;  /* 5 (base_env.py:33) */
+  int32_t auto_reset;       /* 1: envs whose agent is done are reset inside pgd_step */
+  int32_t resample_scenario;/* 1: on auto-reset draw a new scenario (base_env.py:451-458), else keep env's scenario */
+  int32_t horizon;          /* 0 = none (base_env.py:190-192) */
+  uint32_t seed;            /* seed of the device-side counter RNG used for scenario resampling */
+  /* reward scheme (pgdrive_env.py:91-101) */
+  float success_reward, out_of_road_penalty, crash_vehicle_penalty, crash_object_penalty;
+  float driving_reward, speed_reward;
+  int32_t use_lateral;
+  int32_t out_of_route_done;
+  int32_t traffic_ghost;    /* reserved */
+  int32_t pad[3];
+} pgd_config;
+
+typedef struct pgd_engine* pgd_handle;
+
+/* Size of one observation row D = 8 + 10 + 4*num_others + num_lasers (obs/state_obs.py:17-23,124-130). */
+int pgd_obs_dim(const pgd_config* cfg);
+
+/* Replaces PGDriveEnv.__init__ / lazy_init (envs/base_env.py:100-178): allocates device state for N x V slots. */
+int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* out);
+
+/* Replaces MapManager.update_map + block._create_in_world (manager/map_manager.py:98-155, blocks/base_block.py:142-179):
+ * uploads immutable geometry for a bank of maps.  All pointers are HOST arrays; they are copied. */
+int pgd_upload_maps(pgd_handle h, const pgd_map* h_maps, int n_maps, const pgd_lane* h_lanes, int n_lanes,
+                    const pgd_road* h_roads, int n_roads, const pgd_box* h_boxes, int n_boxes,
+                    const int32_t* h_cell_start, int n_cell_start, const int32_t* h_cell_items, int n_cell_items);
+
+/* Replaces AgentManager.reset + TrafficManager.reset spawn tables (manager/agent_manager.py:91-132,
+ * traffic_manager.py:48-69,239-290): a bank of scenarios, each with V spawn slots.  HOST arrays, copied. */
+int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* h_scen, int n_scen, const pgd_spawn* h_spawns /*[n_scen*V]*/);
+
+/* Replaces env.reset(force_seed) (envs/base_env.py:269-301) for the listed envs (h_env_ids == NULL -> all):
+ * env e starts scenario h_scen_ids[i]; writes the first observation.  d_obs may be NULL. */
+int pgd_reset(pgd_handle h, const int32_t* h_env_ids, const int32_t* h_scen_ids, int n, float* d_obs /*[N,A,D]*/);
+
+/* Replaces env.step(action) (envs/base_env.py:184-224, 303-344) for all N envs.  Asynchronous on the stream. */
+int pgd_step(pgd_handle h, const float* d_actions /*[N,A,2]*/, float* d_obs /*[N,A,D]*/, float* d_reward /*[N,A]*/,
+             uint8_t* d_done /*[N,A]*/, uint32_t* d_flags /*[N,A]*/);
+
+/* Checkpoint / resume (BaseVehicle.get_state/set_state, base_vehicle.py:683-698): raw SoA state blobs.
+ * Layout: nf float fields then ni int fields, each [N*V]; query sizes with pgd_state_dims. HOST buffers. */
+int pgd_state_dims(pgd_handle h, int* n_float_fields, int* n_int_fields, int* n_env_int_fields);
+int pgd_get_state(pgd_handle h, float* h_f, int32_t* h_i, int32_t* h_env_i);
+int pgd_set_state(pgd_handle h, const float* h_f, const int32_t* h_i, const int32_t* h_env_i);
+/* Recompute localisation + observation from the current state without stepping (engine.after_step + observe,
+ * base_env.py:295-301). */
+int pgd_observe(pgd_handle h, float* d_obs);
+
+/* Timing helper for bench.py: HIP-event time [ms] of the last `k` pgd_step launches on the engine stream. */
+int pgd_last_step_ms(pgd_handle h, float* ms);
+
+int pgd_sync(pgd_handle h);
+int pgd_destroy(pgd_handle h);
+const char* pgd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

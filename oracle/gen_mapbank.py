@@ -1,0 +1,43 @@
+"""Generate the map-description bank with the REFERENCE's BIG generator (runs only in the build container).
+
+    PYTHONHASHSEED=0 python oracle/gen_mapbank.py
+
+Output: pgdrive_amd/assets/pg_bank_v0.json.gz — data only (lane geometry, roads, block metadata) for the
+`PGDrive-v0` seed range 1000..1099 (pgdrive/register.py:14-17; map=3, lane_num=3, lane_width=3.5, exit_length=50,
+pgdrive/envs/pgdrive_env.py:31-37).  Also writes tests/golden/boxes_seed*.npz: the boxes the reference's block code
+registered in (stubbed) Bullet for a few seeds — the golden for pgdrive_amd.mapdata.build_boxes.
+"""
+import gzip
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import ref_export  # noqa: E402
+
+
+def strip(m):
+    return {k: v for k, v in m.items() if k not in ("net", "big", "boxes")}
+
+
+def main():
+    root = os.path.dirname(HERE)
+    descs = []
+    for seed in range(1000, 1100):
+        m = ref_export.generate(seed, block_num=3)
+        descs.append(strip(m))
+        if seed in (1000, 1003, 1017, 1042, 1099):
+            np.savez_compressed(os.path.join(root, "tests", "golden", "boxes_seed%d.npz" % seed), boxes=m["boxes"])
+    out = os.path.join(root, "pgdrive_amd", "assets", "pg_bank_v0.json.gz")
+    with gzip.GzipFile(out, "wb", mtime=0) as f:
+        f.write(json.dumps(dict(version=0, source="decisionforce/pgdrive v0.1.4 BIG, seeds 1000..1099, map=3",
+                                maps=descs), separators=(",", ":")).encode())
+    print("wrote", out, os.path.getsize(out))
+
+
+if __name__ == "__main__":
+    main()

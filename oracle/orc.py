@@ -1,0 +1,135 @@
+"""ctypes wrapper of the CPU oracle liborc.so (TEST INFRASTRUCTURE: tests/, smoke(), bench cpu_baseline only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pgdrive_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborc.so")
+    src = os.path.join(_HERE, "pgd_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liborc.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(_abi.PgdConfig)]
+        for name in ("orc_wrap_to_pi", "orc_not_zero", "orc_norm", "orc_clip", "orc_lane_heading", "orc_lane_distance",
+                     "orc_pid", "orc_ray_box", "orc_idm_acc", "orc_heading_diff"):
+            getattr(L, name).restype = C.c_double
+        L.orc_wrap_to_pi.argtypes = [C.c_double]
+        L.orc_not_zero.argtypes = [C.c_double, C.c_double]
+        L.orc_norm.argtypes = [C.c_double, C.c_double]
+        L.orc_clip.argtypes = [C.c_double] * 3
+        L.orc_lane_heading.argtypes = [C.c_void_p, C.c_double]
+        L.orc_lane_distance.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_lane_local.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.orc_lane_position.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.orc_pid.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_projection.argtypes = [C.c_double] * 4 + [C.c_void_p]
+        L.orc_ray_box.argtypes = [C.c_double] * 9
+        L.orc_obb_overlap.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_bicycle.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_idm_acc.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_navi_info.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_heading_diff.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_localize.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_state_check.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_state_check.restype = C.c_uint
+        L.orc_idm_act.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_find_front_back.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_step_range.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.orc_rng.restype = C.c_uint32
+        L.orc_rng.argtypes = [C.c_uint32] * 4
+        for name in ("orc_upload_maps", "orc_upload_scenarios", "orc_destroy", "orc_get_state", "orc_set_state",
+                     "orc_reset", "orc_observe", "orc_refresh", "orc_step"):
+            getattr(L, name).argtypes = None
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Oracle:
+    """Same call surface as pgdrive_amd.engine.Engine, float64 on the CPU."""
+    def __init__(self, cfg, bank, scen):
+        self.L = lib()
+        self.cfg = cfg
+        self.N, self.A, self.V = cfg.num_envs, cfg.num_agents, cfg.num_agents + cfg.num_traffic
+        self.D = _abi.obs_dim(cfg)
+        self.h = C.c_void_p(self.L.orc_create(C.byref(cfg)))
+        self.bank, self.scen = bank, scen
+        assert scen.V == self.V
+        self.L.orc_upload_maps(
+            self.h, _p(bank.maps), len(bank.maps), _p(bank.lanes), len(bank.lanes), _p(bank.roads), len(bank.roads),
+            _p(bank.boxes), len(bank.boxes), _p(bank.cell_start), len(bank.cell_start), _p(bank.cell_items),
+            len(bank.cell_items)
+        )
+        self.L.orc_upload_scenarios(self.h, _p(scen.scenarios), len(scen.scenarios), _p(scen.spawns))
+
+    def reset(self, scen_ids, env_ids=None):
+        scen_ids = np.ascontiguousarray(scen_ids, dtype=np.int32)
+        env_ids = None if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
+        obs = np.zeros((self.N, self.A, self.D), dtype=np.float64)
+        self.L.orc_reset(self.h, _p(env_ids), _p(scen_ids), C.c_int(len(scen_ids)), _p(obs))
+        return obs
+
+    def observe(self):
+        obs = np.zeros((self.N, self.A, self.D), dtype=np.float64)
+        self.L.orc_observe(self.h, _p(obs))
+        return obs
+
+    def refresh(self):
+        self.L.orc_refresh(self.h)
+
+    def step(self, actions, env_range=None):
+        actions = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.N, self.A, 2)
+        obs = np.zeros((self.N, self.A, self.D), dtype=np.float64)
+        rew = np.zeros((self.N, self.A), dtype=np.float64)
+        done = np.zeros((self.N, self.A), dtype=np.uint8)
+        flags = np.zeros((self.N, self.A), dtype=np.uint32)
+        if env_range is None:
+            self.L.orc_step(self.h, _p(actions), _p(obs), _p(rew), _p(done), _p(flags))
+        else:
+            self.L.orc_step_range(self.h, env_range[0], env_range[1], _p(actions), _p(obs), _p(rew), _p(done), _p(flags))
+        return obs, rew, done, flags
+
+    def get_state(self):
+        f = np.zeros((_abi.NF, self.N, self.V), dtype=np.float64)
+        i = np.zeros((_abi.NI, self.N, self.V), dtype=np.int32)
+        ei = np.zeros((_abi.NEI, self.N), dtype=np.int32)
+        self.L.orc_get_state(self.h, _p(f), _p(i), _p(ei))
+        return f, i, ei
+
+    def set_state(self, f, i, ei):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        i = np.ascontiguousarray(i, dtype=np.int32)
+        ei = np.ascontiguousarray(ei, dtype=np.int32)
+        self.L.orc_set_state(self.h, _p(f), _p(i), _p(ei))
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,49 @@
+"""ctypes mirror of the plain-C structs in include/pgdrive_hip.h (kept in lock-step by tests/test_abi.py)."""
+import ctypes as C
+
+
+class PgdConfig(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int32), ("num_agents", C.c_int32), ("num_traffic", C.c_int32), ("num_lasers", C.c_int32),
+        ("num_others", C.c_int32), ("lidar_dist", C.c_float), ("dt", C.c_float), ("decision_repeat", C.c_int32),
+        ("auto_reset", C.c_int32), ("resample_scenario", C.c_int32), ("horizon", C.c_int32), ("seed", C.c_uint32),
+        ("success_reward", C.c_float), ("out_of_road_penalty", C.c_float), ("crash_vehicle_penalty", C.c_float),
+        ("crash_object_penalty", C.c_float), ("driving_reward", C.c_float), ("speed_reward", C.c_float),
+        ("use_lateral", C.c_int32), ("out_of_route_done", C.c_int32), ("traffic_ghost", C.c_int32),
+        ("pad", C.c_int32 * 3),
+    ]
+
+
+def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_others=4, lidar_dist=50.0, dt=0.02,
+                decision_repeat=5, auto_reset=1, resample_scenario=0, horizon=0, seed=0, success_reward=10.0,
+                out_of_road_penalty=5.0, crash_vehicle_penalty=5.0, crash_object_penalty=5.0, driving_reward=1.0,
+                speed_reward=0.1, use_lateral=False, out_of_route_done=False):
+    """Defaults mirror PGDriveEnv_DEFAULT_CONFIG / BASE_DEFAULT_CONFIG (pgdrive_env.py:22-109, base_env.py:19-90)."""
+    c = PgdConfig()
+    c.num_envs, c.num_agents, c.num_traffic = num_envs, num_agents, num_traffic
+    c.num_lasers, c.num_others, c.lidar_dist = num_lasers, (num_others if num_lasers > 0 else 0), lidar_dist
+    c.dt, c.decision_repeat = dt, decision_repeat
+    c.auto_reset, c.resample_scenario, c.horizon, c.seed = int(auto_reset), int(resample_scenario), int(horizon or 0), seed
+    c.success_reward, c.out_of_road_penalty = success_reward, out_of_road_penalty
+    c.crash_vehicle_penalty, c.crash_object_penalty = crash_vehicle_penalty, crash_object_penalty
+    c.driving_reward, c.speed_reward = driving_reward, speed_reward
+    c.use_lateral, c.out_of_route_done = int(bool(use_lateral)), int(bool(out_of_route_done))
+    return c
+
+
+def obs_dim(cfg):
+    return 8 + 10 + 4 * cfg.num_others + cfg.num_lasers
+
+
+# state layout (include/pgd_state_layout.h)
+SF = dict(X=0, Y=1, THETA=2, SPEED=3, STEER=4, THROTTLE=5, LASTX=6, LASTY=7, LASTHX=8, LASTHY=9, ACT0S=10, ACT0T=11,
+          ACT1S=12, ACT1T=13, PID_HP=14, PID_HI=15, PID_LP=16, PID_LI=17, TARGET_SPEED=18, ENERGY=19, DIST_LEFT=20,
+          DIST_RIGHT=21, EP_REWARD=22, SPARE=23)
+SI = dict(STATUS=0, LANE=1, CK0=2, CK1=3, RLANE=4, TIMER=5, VFLAGS=6, SPARE=7)
+EI = dict(SCEN=0, NEXT_GROUP=1, EP_STEPS=2, EPISODES=3, STEPS_TOTAL=4)
+NF, NI, NEI = 24, 8, 8
+ST_EMPTY, ST_PENDING, ST_ACTIVE, ST_REMOVED = 0, 1, 2, 3
+
+F_ARRIVE, F_OUT_OF_ROAD, F_CRASH_VEHICLE, F_CRASH_OBJECT, F_CRASH_BUILDING, F_MAX_STEP = 1, 2, 4, 8, 16, 32
+F_ON_YELLOW, F_ON_WHITE, F_ON_BROKEN, F_CRASH_SIDEWALK, F_OFF_LANE, F_OUT_OF_ROUTE = 256, 512, 1024, 2048, 4096, 8192
+F_RESET = 1 << 16

@@ -1,0 +1,262 @@
+"""Host-side episode set-up: ego spawn, destination + route, traffic spawn table (one *scenario* per map seed).
+
+Restates, on flat map descriptions, what the reference does once per `env.reset()`:
+
+* seeding                     pgdrive/utils/random_utils.py:14-50, base_class/randomizable.py:4-21
+* ego spawn                   pgdrive/envs/pgdrive_env.py:77-79, component/vehicle/base_vehicle.py:292-339
+* destination + BFS route     component/vehicle_module/navigation.py:99-153
+* traffic spawn (trigger mode) manager/traffic_manager.py:239-290,311-314
+* vehicle parameter sampling  base_class/base_runnable.py:81-88, utils/space.py:219-255, vehicle/vehicle_type.py:7-86
+* IDM overtake timer          policy/idm_policy.py:185
+
+The result is packed into `pgd_scenario` / `pgd_spawn` records (include/pgdrive_hip.h) and uploaded once.
+"""
+import hashlib
+import math
+import struct
+
+import numpy as np
+
+from . import mapdata
+
+MAX_CKPT = mapdata.MAX_CKPT
+MAX_GROUPS = 16
+
+SPAWN_DT = np.dtype(
+    [
+        ("x", "<f4"), ("y", "<f4"), ("heading", "<f4"), ("length", "<f4"), ("width", "<f4"), ("wheelbase", "<f4"),
+        ("mass", "<f4"), ("max_engine_force", "<f4"), ("max_brake_force", "<f4"), ("friction", "<f4"),
+        ("max_steer", "<f4"), ("max_speed", "<f4"), ("lane", "<i2"), ("group", "<i2"), ("n_ckpt", "<i2"),
+        ("timer0", "<i2"), ("dest_lane", "<i2"), ("pad", "<i2", (3, )), ("ckpt", "<i2", (MAX_CKPT, )),
+        ("ckpt_road", "<i2", (MAX_CKPT, ))
+    ]
+)
+SCEN_DT = np.dtype([("map", "<i4"), ("n_groups", "<i4"), ("trigger_road", "<i2", (MAX_GROUPS, ))])
+assert SPAWN_DT.itemsize == 64 + 4 * MAX_CKPT and SCEN_DT.itemsize == 8 + 2 * MAX_GROUPS
+
+# vehicle_type.py:7-74 (L, W, front+rear wheelbase, mass) and utils/space.py:219-255
+# parameter tuples are (first, second) positional args of the reference's BoxSpace namedtuple("max min").
+VEHICLE_TYPES = {
+    "default": dict(length=4.51, width=1.852, wheelbase=1.05234 + 1.4166, mass=1100.0, friction=0.9,
+                    engine=(750, 850), brake=(80, 180), max_steering=40.0, max_speed=80.0),
+    "s": dict(length=4.25, width=1.7, wheelbase=1.4126 + 1.07, mass=800.0, friction=0.9, engine=(350, 550),
+              brake=(35, 80), max_steering=50.0, max_speed=80.0),
+    "m": dict(length=4.4, width=1.85, wheelbase=1.285 + 1.203, mass=1200.0, friction=0.75, engine=(650, 850),
+              brake=(60, 150), max_steering=45.0, max_speed=80.0),
+    "l": dict(length=4.5, width=1.86, wheelbase=1.391 + 1.10751, mass=1300.0, friction=0.8, engine=(450, 650),
+              brake=(60, 120), max_steering=40.0, max_speed=80.0),
+    "xl": dict(length=5.8, width=2.3, wheelbase=1.726 + 1.075, mass=1600.0, friction=0.7, engine=(500, 700),
+               brake=(50, 100), max_steering=35.0, max_speed=80.0),
+}
+TYPE_KEYS = ["s", "m", "l", "xl", "default"]  # dict order of vehicle_type (vehicle_type.py:78)
+TRAFFIC_TYPE_PROB = [0.2, 0.3, 0.3, 0.2, 0]  # traffic_manager.py:313
+VEHICLE_GAP = 10  # traffic_manager.py:31
+MAX_RAND_INT = 65536  # randomizable.py:10
+
+
+def get_np_random(seed):
+    """RandomState seeded with the first 8 bytes of sha512(str(seed)) (random_utils.py:14-50, 60-83)."""
+    seed = int(seed) % 2**64
+    h = hashlib.sha512(str(seed).encode("utf8")).digest()[:8]
+    b = h + b"\0" * (4 - len(h) % 4)  # the reference always pads (even when already aligned)
+    words = struct.unpack("{}I".format(len(b) // 4), b)
+    big = sum(2**(32 * i) * w for i, w in enumerate(words))
+    ints = []
+    if big == 0:
+        ints = [0]
+    while big > 0:
+        big, mod = divmod(big, 2**32)
+        ints.append(mod)
+    rng = np.random.RandomState()
+    rng.seed(ints)
+    return rng
+
+
+def sample_vehicle_params(vtype, object_seed):
+    """BaseRunnable.sample_parameters (base_runnable.py:81-88): every Box of the ParameterSpace is seeded with the same
+    integer, so each draws the same first uniform; values are cast to float32 (Box dtype)."""
+    t = VEHICLE_TYPES[vtype]
+    rng = get_np_random(object_seed)
+    ps_seed = rng.randint(low=0, high=int(1e6))
+
+    def box(first, second):  # BoxSpace(first, second) -> max=first, min=second -> Box(low=second, high=first)
+        r = get_np_random(ps_seed)
+        return float(np.float32(r.uniform(low=np.float32(second), high=np.float32(first))))
+
+    return dict(
+        length=t["length"], width=t["width"], wheelbase=t["wheelbase"], mass=t["mass"], friction=t["friction"],
+        max_engine_force=box(*t["engine"]), max_brake_force=box(*t["brake"]),
+        max_steer=math.radians(t["max_steering"]), max_speed=t["max_speed"], vtype=vtype,
+    )
+
+
+def choose_destination(desc, seed, start_node, negative=False):
+    """Navigation.update (navigation.py:99-121): a socket of the last block, chosen with get_np_random(seed)."""
+    block = desc["blocks"][0] if negative else desc["blocks"][-1]
+    sockets = list(block["sockets"])
+    rng = get_np_random(seed)
+    socket = sockets[rng.choice(len(sockets))]
+    while True:
+        is_socket_node = start_node in (socket["pos"][0], socket["pos"][1], socket["neg"][0], socket["neg"][1])
+        if not is_socket_node or len(sockets) == 1:
+            break
+        sockets.remove(socket)
+        if len(sockets) == 0:
+            raise ValueError("Can not set a destination!")
+    return socket["neg"][1] if negative else socket["pos"][1]
+
+
+def make_route(desc, lane_id, final_node):
+    """Navigation.set_route (navigation.py:123-148) -> (ckpt nodes, road per leg, final lane id)."""
+    rl = mapdata.road_lookup(desc)
+    lane = desc["lanes"][lane_id]
+    road = desc["roads"][lane["road"]]
+    ckpt = mapdata.shortest_path(desc, road["frm"], final_node)
+    if len(ckpt) <= 2:
+        ckpt = [road["frm"], road["to"]]
+        single = True
+    else:
+        single = False
+    roads = [rl[(ckpt[k], ckpt[k + 1])] for k in range(len(ckpt) - 1)]
+    final_road = desc["roads"][roads[-1]]
+    final_lane = final_road["first_lane"] + final_road["n_lanes"] - 1  # final_lanes[-1]
+    return ckpt, roads, final_lane, single
+
+
+def _fill_route(rec, desc, lane_id, final_node):
+    ckpt, roads, final_lane, single = make_route(desc, lane_id, final_node)
+    if len(ckpt) > MAX_CKPT:
+        raise ValueError("route with %d nodes exceeds PGD_MAX_CKPT" % len(ckpt))
+    rec["n_ckpt"] = len(ckpt)
+    rec["ckpt"][:] = -1
+    rec["ckpt_road"][:] = -1
+    rec["ckpt"][:len(ckpt)] = ckpt
+    rec["ckpt_road"][:len(roads)] = roads
+    rec["dest_lane"] = final_lane
+    return single
+
+
+def _fill_vehicle(rec, desc, lane_id, longitude, lateral, params):
+    l = desc["lanes"][lane_id]
+    x, y = mapdata.lane_position(l, longitude, lateral)
+    rec["x"], rec["y"] = x, y
+    rec["heading"] = mapdata.lane_heading_at(l, longitude)
+    for k in ("length", "width", "wheelbase", "mass", "max_engine_force", "max_brake_force", "friction", "max_steer",
+              "max_speed"):
+        rec[k] = params[k]
+    rec["lane"] = lane_id
+
+
+def propose_traffic(desc, seed, density):
+    """TrafficManager._create_vehicles_once (traffic_manager.py:239-290) -> list of groups
+    [{trigger_road, vehicles:[{lane, long, vtype, policy_seed}]}] in *block* order, consuming the manager RNG exactly
+    like the reference (shuffle, then per vehicle: type choice, policy seed)."""
+    rng = get_np_random(seed)  # BaseManager seeds np_random with the global seed (base_manager.py:14)
+    rl = mapdata.road_lookup(desc)
+    groups = []
+    if abs(density) < 1e-2:
+        return groups
+    for block in desc["blocks"][1:]:
+        cands = []
+        total_length = 0.0
+        for lanes in block["spawn_lanes"]:
+            for lid in lanes:
+                l = desc["lanes"][lid]
+                total_length += l["length"]
+                for i in range(int(l["length"] / VEHICLE_GAP)):
+                    cands.append((lid, float(i * VEHICLE_GAP)))
+        total_spawn_points = int(math.floor(total_length / VEHICLE_GAP))
+        total_vehicles = int(math.floor(total_spawn_points * density))
+        order = list(range(len(cands)))
+        rng.shuffle(order)
+        selected = [cands[i] for i in order[:min(total_vehicles, len(cands))]]
+        vehicles = []
+        for lid, lg in selected:
+            vtype = TYPE_KEYS[int(rng.choice(len(TYPE_KEYS), p=TRAFFIC_TYPE_PROB))]
+            policy_seed = int(rng.randint(0, MAX_RAND_INT))
+            vehicles.append(dict(lane=lid, long=lg, vtype=vtype, policy_seed=policy_seed))
+        tr = block["trigger_road"]
+        groups.append(dict(trigger_road=rl[(tr[0], tr[1])], vehicles=vehicles))
+    return groups
+
+
+def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=0.1, spawn_lane=None,
+                   spawn_longitude=5.0, spawn_lateral=0.0, vehicle_model="default", agent_spawns=None):
+    """One scenario = V = num_agents + num_traffic spawn slots for map `desc` under global seed `seed`."""
+    V = num_agents + num_traffic
+    scen = np.zeros((), dtype=SCEN_DT)
+    spawns = np.zeros(V, dtype=SPAWN_DT)
+    spawns["lane"] = -1
+    spawns["group"] = -1
+    scen["map"] = map_index
+    scen["trigger_road"][:] = -1
+
+    engine_rng = get_np_random(seed)  # BaseEngine.seed -> Randomizable.seed (base_engine.py:300-304)
+    rl = mapdata.road_lookup(desc)
+
+    # ---- agents (agent_manager.py:63-83: spawn_object -> engine.generate_seed()) ----
+    if agent_spawns is None:
+        if spawn_lane is None:
+            r = desc["roads"][rl[(desc["nodes"].index(">"), desc["nodes"].index(">>"))]]
+            spawn_lane = r["first_lane"] + 0
+        agent_spawns = [dict(lane=spawn_lane, long=spawn_longitude, lat=spawn_lateral, dest=None)] * num_agents
+    for a in range(num_agents):
+        sp = agent_spawns[a]
+        obj_seed = int(engine_rng.randint(0, MAX_RAND_INT))
+        params = sample_vehicle_params(vehicle_model, obj_seed)
+        _fill_vehicle(spawns[a], desc, sp["lane"], sp["long"], sp["lat"], params)
+        road = desc["roads"][desc["lanes"][sp["lane"]]["road"]]
+        dest = sp.get("dest")
+        if dest is None:
+            dest = choose_destination(desc, seed, road["frm"], negative=road["negative"])
+        _fill_route(spawns[a], desc, sp["lane"], dest)
+        spawns[a]["group"] = -1
+        spawns[a]["timer0"] = 0
+
+    # ---- traffic (traffic_manager.py:239-290) ----
+    groups = propose_traffic(desc, seed, density) if num_traffic > 0 else []
+    slot = num_agents
+    n_groups = 0
+    dropped = 0
+    for g in groups:
+        if n_groups >= MAX_GROUPS:
+            break
+        scen["trigger_road"][n_groups] = g["trigger_road"]
+        for v in g["vehicles"]:
+            obj_seed = int(engine_rng.randint(0, MAX_RAND_INT))  # consumed even if the slot cap drops the vehicle
+            if slot >= V:
+                dropped += 1
+                continue
+            params = sample_vehicle_params(v["vtype"], obj_seed)
+            _fill_vehicle(spawns[slot], desc, v["lane"], v["long"], 0.0, params)
+            road = desc["roads"][desc["lanes"][v["lane"]]["road"]]
+            dest = choose_destination(desc, seed, road["frm"], negative=road["negative"])
+            try:
+                _fill_route(spawns[slot], desc, v["lane"], dest)
+            except (KeyError, ValueError):
+                # no route from this lane (e.g. dead-end ramp part): keep the lane's own road as route
+                spawns[slot]["n_ckpt"] = 2
+                spawns[slot]["ckpt"][:] = -1
+                spawns[slot]["ckpt_road"][:] = -1
+                spawns[slot]["ckpt"][:2] = [road["frm"], road["to"]]
+                spawns[slot]["ckpt_road"][0] = desc["lanes"][v["lane"]]["road"]
+                spawns[slot]["dest_lane"] = road["first_lane"] + road["n_lanes"] - 1
+            spawns[slot]["group"] = n_groups
+            spawns[slot]["timer0"] = int(get_np_random(v["policy_seed"]).randint(0, 50))  # idm_policy.py:185
+            slot += 1
+        n_groups += 1
+    scen["n_groups"] = n_groups
+    return scen, spawns, dict(dropped=dropped, n_traffic=slot - num_agents)
+
+
+class ScenarioBank:
+    def __init__(self, descs, seeds, num_agents=1, num_traffic=16, density=0.1, **kw):
+        scens, spawns, self.info = [], [], []
+        for m, (d, s) in enumerate(zip(descs, seeds)):
+            sc, sp, info = build_scenario(d, m, s, num_agents, num_traffic, density, **kw)
+            scens.append(sc)
+            spawns.append(sp)
+            self.info.append(info)
+        self.scenarios = np.array(scens, dtype=SCEN_DT)
+        self.spawns = np.concatenate(spawns)
+        self.V = num_agents + num_traffic
