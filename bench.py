@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""bench.py — env-steps/sec of the batched PGDrive step engine (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 2000 --warmup 200
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = pgd_step over all local environments: every agent and traffic vehicle advanced 0.1 s + (obs, reward, done)
+written.  Workload = BASELINE config C3: 4096 envs/GPU x (1 ego + 16 IDM traffic slots) x 240 lidar beams, PGDrive-v0
+maps (seeds 1000..1099, env e -> scenario e mod 100), actions uniform(-1,1) from numpy default_rng(0), pre-generated
+on the device, auto-reset on done.  Weak scaling: each rank owns 4096 envs; with N>1 ranks one RCCL all_gather of
+(obs, reward, done) per step over xGMI is inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic HBM bytes per env-step for this build's record layout:
+#   state r/w   2 * V * (23 f32 + 7 i32) * 4 B  + env ints 2*5*4
+#   actions 8*A, spawn params read V*48, obs write 4*A*D, reward/done/flags 9*A,
+#   k_observe re-read of 7 floats/vehicle
+def algorithmic_bytes(A, T, D):
+    V = A + T
+    k_step = 2 * V * (23 + 7) * 4 + 40 + 8 * A + V * 48 + 9 * A
+    k_obs = V * (5 * 4 + 8) + 4 * A * D + A * 12 * 4
+    return k_step, k_obs
+
+
+def cpu_baseline(descs, args, seconds=12.0):
+    """Oracle (scalar C restatement, 1 thread) on a bounded sample of the same workload."""
+    from oracle import orc
+    from pgdrive_amd import _abi, mapdata, scenario
+    n = 256
+    sel = descs[:16]
+    mb = mapdata.MapBank(sel)
+    sb = scenario.ScenarioBank(sel, [d["seed"] for d in sel], num_agents=1, num_traffic=args.traffic)
+    cfg = _abi.make_config(n, num_agents=1, num_traffic=args.traffic, num_lasers=args.lasers)
+    o = orc.Oracle(cfg, mb, sb)
+    o.reset(np.arange(n) % len(sel))
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, size=(32, n, 1, 2)).astype(np.float32)
+    o.step(acts[0])
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < seconds:
+        o.step(acts[k % 32])
+        k += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n * k / dt, unit="env-steps/s", cores=1, kind="port",
+                sample="%d envs x %d steps of the C3 workload (16 maps), oracle/pgd_oracle.c fp64, 1 thread" % (n, k))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--traffic", type=int, default=16)
+    ap.add_argument("--lasers", type=int, default=240)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="replicas only: skip the per-step RCCL gather")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pgdrive_amd import _abi, bank, mapdata, scenario
+    from pgdrive_amd.engine import Engine
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    descs = bank.load_descriptions()
+    mb = mapdata.MapBank(descs)
+    sb = scenario.ScenarioBank(descs, [d["seed"] for d in descs], num_agents=1, num_traffic=args.traffic)
+    N, A = args.envs, 1
+    cfg = _abi.make_config(N, num_agents=A, num_traffic=args.traffic, num_lasers=args.lasers, auto_reset=1,
+                           seed=1234 + rank)
+    eng = Engine(cfg, mb, sb, device=local_rank)
+    D = eng.D
+    eng.reset((np.arange(N) + rank * N) % len(descs))
+
+    rng = np.random.default_rng(rank)  # rank 0 == default_rng(0)
+    CYC = 64
+    actions = torch.from_numpy(rng.uniform(-1, 1, size=(CYC, N, A, 2)).astype(np.float32)).to(dev)
+
+    gather = world > 1 and not args.no_gather
+    if gather:
+        # one exchange per step: obs | reward | done packed into a single fp32 row per env
+        pack = torch.empty((N, A * (D + 2)), dtype=torch.float32, device=dev)
+        gathered = torch.empty((world * N, A * (D + 2)), dtype=torch.float32, device=dev)
+
+    def one_step(k):
+        obs, rew, done, flags = eng.step(actions[k % CYC])
+        if gather:
+            pack[:, :A * D] = obs.view(N, A * D)
+            pack[:, A * D:A * D + A] = rew
+            pack[:, A * D + A:] = done.to(torch.float32)
+            dist.all_gather_into_tensor(gathered, pack)
+
+    with torch.cuda.stream(eng.stream):
+        for k in range(args.warmup):
+            one_step(k)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        eng.profile_begin(args.steps)
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            one_step(args.warmup + k)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        prof = eng.profile_end()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_env_steps = float(N) * world * args.steps
+        value = total_env_steps / elapsed
+        b_step, b_obs = algorithmic_bytes(A, args.traffic, D)
+        dom = "k_observe" if prof["k_observe_ms"] >= prof["k_step_ms"] else "k_step"
+        dom_ms = max(prof["k_observe_ms"], prof["k_step_ms"])
+        dom_bytes = (b_obs if dom == "k_observe" else b_step) * N
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (whole node) at 4096 envs x 240 lidar beams",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "C3: %d envs/GPU x (1 ego + %d IDM traffic slots) x %d lidar beams, PGDrive-v0 maps "
+                            "seeds 1000-1099, uniform(-1,1) actions, auto-reset" % (N, args.traffic, args.lasers),
+                "envs_per_gpu": N, "global_envs": N * world, "obs_dim": D,
+                "parallelism": "env-sharded dp%d%s" % (world, " + RCCL all_gather(obs,reward,done)/step" if gather else ""),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                "frac": achieved / 8000.0, "traffic": None,
+                "bytes_per_env_step": {"k_step": b_step, "k_observe": b_obs},
+                "k_step_ms": prof["k_step_ms"], "k_observe_ms": prof["k_observe_ms"], "events": prof["count"],
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(descs, args)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

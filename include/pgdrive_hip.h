@@ -188,6 +188,11 @@ int pgd_observe(pgd_handle h, float* d_obs);
 /* Timing helper for bench.py: HIP-event time [ms] of the last `k` pgd_step launches on the engine stream. */
 int pgd_last_step_ms(pgd_handle h, float* ms);
 
+/* Per-kernel HIP-event profile: between begin and end every pgd_step records events around its two kernels on the
+ * engine stream (up to `capacity` steps); end synchronises and returns the average duration of each kernel. */
+int pgd_profile_begin(pgd_handle h, int capacity);
+int pgd_profile_end(pgd_handle h, float* k_step_ms, float* k_observe_ms, int* count);
+
 int pgd_sync(pgd_handle h);
 int pgd_destroy(pgd_handle h);
 const char* pgd_version(void);

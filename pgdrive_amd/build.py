@@ -1,0 +1,39 @@
+"""Builds libpgdrive_hip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "pgd_engine.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "pgd_device.h"), os.path.join(HERE, "..", "include", "pgdrive_hip.h"),
+        os.path.join(HERE, "..", "include", "pgd_state_layout.h")]
+LIB = os.path.join(HERE, "libpgdrive_hip.so")
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP engine cannot be built")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False, extra=()):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC] + list(extra)
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    build(force=True, verbose=True, extra=sys.argv[1:])

@@ -1,0 +1,183 @@
+// pgd_device.h — fp32 device routines of the batched PGDrive step engine (gfx950 / CDNA4, wave64).
+//
+// Every routine cites the reference code whose behaviour it reproduces (paths relative to pgdrive/ in
+// decisionforce/pgdrive v0.1.4).  Bullet queries of the reference are evaluated as exact 2-D geometry on the boxes the
+// reference registers in Bullet (uploaded by pgd_upload_maps); see DESIGN.md for the data layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pgd_state_layout.h"
+#include "../../include/pgdrive_hip.h"
+
+#define PGD_PI 3.14159265358979323846f
+#define DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------------------------------
+// device-side view of the engine
+// ---------------------------------------------------------------------------------------------------------------------
+struct PgdDev {
+  pgd_config cfg;
+  int N, A, T, V, D, NV;
+  int epw;  // envs per wave in k_step
+  const pgd_map* maps;
+  const pgd_lane* lanes;
+  const pgd_road* roads;
+  const pgd_box* boxes;
+  const int32_t* cell_start;
+  const int32_t* cell_items;
+  const pgd_scenario* scen;
+  const pgd_spawn* spawns;
+  int n_scen;
+  float* f;     // [PGD_NF][NV]
+  int32_t* i;   // [PGD_NI][NV]
+  int32_t* ei;  // [PGD_NEI][N]
+};
+
+struct MapView {
+  const pgd_map* m;
+  const pgd_lane* lanes;
+  const pgd_road* roads;
+  const pgd_box* boxes;
+  const int32_t* cstart;
+  const int32_t* citems;
+};
+
+DEV MapView map_view(const PgdDev& d, int map) {
+  MapView v;
+  v.m = d.maps + map;
+  v.lanes = d.lanes + v.m->lane_off;
+  v.roads = d.roads + v.m->road_off;
+  v.boxes = d.boxes + v.m->box_off;
+  v.cstart = d.cell_start + v.m->cell_off;
+  v.citems = d.cell_items + v.m->item_off;
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// scalar helpers: utils/math_utils.py:32-94, cutils.pyx:147-154
+// ---------------------------------------------------------------------------------------------------------------------
+DEV float clipf(float a, float lo, float hi) { return fminf(fmaxf(a, lo), hi); }
+DEV float norm2(float x, float y) { return sqrtf(x * x + y * y); }
+DEV float wrap_to_pi(float x) {  // ((x + pi) % (2 pi)) - pi with Python's sign-of-divisor modulo
+  float r = fmodf(x + PGD_PI, 2.0f * PGD_PI);
+  if (r < 0.0f) r += 2.0f * PGD_PI;
+  return r - PGD_PI;
+}
+DEV float not_zero(float x, float eps) { return fabsf(x) > eps ? x : (x > 0.0f ? eps : -eps); }
+
+// counter RNG (IDM timer reseed idm_policy.py:239, scenario resampling base_env.py:451-458)
+DEV uint32_t pcg_hash(uint32_t x) {
+  uint32_t state = x * 747796405u + 2891336453u;
+  uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+  return (word >> 22u) ^ word;
+}
+DEV uint32_t pgd_rng(uint32_t seed, uint32_t a, uint32_t b, uint32_t c) {
+  return pcg_hash(seed ^ pcg_hash(a ^ pcg_hash(b ^ pcg_hash(c + 0x9e3779b9u))));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// lanes: component/lane/straight_lane.py:53-67, circular_lane.py:41-67
+// ---------------------------------------------------------------------------------------------------------------------
+DEV void lane_local(const pgd_lane& l, float px, float py, float& lon, float& lat) {
+  float dx = px - l.ax, dy = py - l.ay;
+  if (l.dir == 0.0f) {
+    lon = dx * l.bx + dy * l.by;
+    lat = dy * l.bx - dx * l.by;
+  } else {
+    float R = l.bx, p0 = l.by;
+    float phi = p0 + wrap_to_pi(atan2f(dy, dx) - p0);
+    lon = l.dir * (phi - p0) * R;
+    lat = l.dir * (R - norm2(dx, dy));
+  }
+}
+DEV void lane_position(const pgd_lane& l, float lon, float lat, float& x, float& y) {
+  if (l.dir == 0.0f) {
+    x = l.ax + lon * l.bx - lat * l.by;
+    y = l.ay + lon * l.by + lat * l.bx;
+  } else {
+    float phi = l.dir * lon / l.bx + l.by;
+    float r = l.bx - lat * l.dir;
+    float s, c;
+    sincosf(phi, &s, &c);
+    x = l.ax + r * c;
+    y = l.ay + r * s;
+  }
+}
+DEV float lane_heading_at(const pgd_lane& l, float lon) {
+  if (l.dir == 0.0f) return l.c;
+  return l.dir * lon / l.bx + l.by + 0.5f * PGD_PI * l.dir;
+}
+DEV bool lane_is_prev_of(const pgd_lane& a, int b) {  // abs_lane.py:114-119 via the successor table
+  bool r = false;
+#pragma unroll
+  for (int k = 0; k < PGD_MAX_SUCC; ++k) r = r || (k < a.n_succ && a.succ[k] == b);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// oriented boxes
+// ---------------------------------------------------------------------------------------------------------------------
+struct Obb {
+  float cx, cy, ux, uy, hl, hw;
+};
+DEV Obb obb_of(const pgd_box& b) { return Obb{b.cx, b.cy, b.ux, b.uy, b.hl, b.hw}; }
+DEV bool point_in_obb(const Obb& o, float px, float py) {
+  float dx = px - o.cx, dy = py - o.cy;
+  return fabsf(dx * o.ux + dy * o.uy) <= o.hl && fabsf(dy * o.ux - dx * o.uy) <= o.hw;
+}
+DEV bool obb_overlap(const Obb& A, const Obb& B) {  // separating axis test, closed rectangles
+  float dx = B.cx - A.cx, dy = B.cy - A.cy;
+  float ac = fabsf(A.ux * B.ux + A.uy * B.uy), as = fabsf(A.ux * B.uy - A.uy * B.ux);
+  if (fabsf(dx * A.ux + dy * A.uy) > A.hl + B.hl * ac + B.hw * as) return false;
+  if (fabsf(dy * A.ux - dx * A.uy) > A.hw + B.hl * as + B.hw * ac) return false;
+  if (fabsf(dx * B.ux + dy * B.uy) > B.hl + A.hl * ac + A.hw * as) return false;
+  if (fabsf(dy * B.ux - dx * B.uy) > B.hw + A.hl * as + A.hw * ac) return false;
+  return true;
+}
+DEV float point_obb_dist(const Obb& o, float px, float py) {  // lidar broad phase (lidar.py:109-124)
+  float dx = px - o.cx, dy = py - o.cy;
+  float a = fmaxf(fabsf(dx * o.ux + dy * o.uy) - o.hl, 0.0f), c = fmaxf(fabsf(dy * o.ux - dx * o.uy) - o.hw, 0.0f);
+  return sqrtf(a * a + c * c);
+}
+// nearest hit fraction of the segment p + t d, t in [0,1]; 1 = miss (cutils.pyx:60-142 rayTestClosest)
+DEV float ray_obb(const Obb& o, float px, float py, float dx, float dy) {
+  float rx = px - o.cx, ry = py - o.cy;
+  float ox = rx * o.ux + ry * o.uy, oy = ry * o.ux - rx * o.uy;
+  float vx = dx * o.ux + dy * o.uy, vy = dy * o.ux - dx * o.uy;
+  float t0 = 0.0f, t1 = 1.0f;
+  if (fabsf(vx) < 1e-12f) {
+    if (fabsf(ox) > o.hl) return 1.0f;
+  } else {
+    float inv = 1.0f / vx;
+    float a = (-o.hl - ox) * inv, b = (o.hl - ox) * inv;
+    t0 = fmaxf(t0, fminf(a, b));
+    t1 = fminf(t1, fmaxf(a, b));
+    if (t0 > t1) return 1.0f;
+  }
+  if (fabsf(vy) < 1e-12f) {
+    if (fabsf(oy) > o.hw) return 1.0f;
+  } else {
+    float inv = 1.0f / vy;
+    float a = (-o.hw - oy) * inv, b = (o.hw - oy) * inv;
+    t0 = fmaxf(t0, fminf(a, b));
+    t1 = fminf(t1, fmaxf(a, b));
+    if (t0 > t1) return 1.0f;
+  }
+  return t0;
+}
+
+// BaseVehicle.projection (base_vehicle.py:460-475)
+DEV void projection(float hx, float hy, float vx, float vy, float& ph, float& ps) {
+  float l = norm2(hx, hy);
+  ph = (vx * hx + vy * hy) / (l + 1e-6f);
+  float sx = -hy / l, sy = hx / l;
+  ps = (vx * sx + vy * sy) / (norm2(sx, sy) + 1e-6f);
+}
+
+DEV float pid_update(float& p, float& i, float kp, float ki, float kd, float err) {  // PID_controller.py:10-17
+  i += err;
+  float dd = err - p;
+  p = err;
+  return -kp * p - ki * i - kd * dd;
+}

@@ -1,0 +1,1044 @@
+// pgd_engine.hip — kernels + C ABI (include/pgdrive_hip.h) of the MI355X-native batched PGDrive step engine.
+//
+// Execution model (gfx950, wave64):
+//   k_step     one 64-lane wave per block; lane = one vehicle slot, a wave carries floor(64/V) whole environments.
+//              IDM neighbour search, crash test and trigger logic read the env's vehicle snapshot from LDS;
+//              localisation / line / sidewalk tests walk the per-map uniform grid (L2-resident, immutable).
+//              Reward, done and auto-reset are fused at the end, so one launch advances every vehicle 0.1 s.
+//   k_observe  one 256-thread block per (env, agent): vehicle boxes of the env are compacted into LDS with a wave
+//              ballot, one lidar beam per thread (min over LDS-broadcast boxes), 274-float row written coalesced.
+// The reference call stack this replaces: envs/base_env.py:184-224,303-344.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "pgd_device.h"
+
+#define HIPCHK(x)                                                                              \
+  do {                                                                                         \
+    hipError_t _e = (x);                                                                       \
+    if (_e != hipSuccess) {                                                                    \
+      fprintf(stderr, "[pgdrive_hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return PGD_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+#define WAVE 64
+#define MAXV 64
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per-lane vehicle registers
+// ---------------------------------------------------------------------------------------------------------------------
+struct Veh {
+  float x, y, th, v, steer, thr, lastx, lasty, lasthx, lasthy, a0s, a0t, a1s, a1t, php, phi, plp, pli, target, energy,
+      dl, dr, eprew;
+  int status, lane, ck0, ck1, rlane, timer, vflags;
+};
+
+DEV void load_veh(const PgdDev& d, int idx, Veh& r) {
+  const float* f = d.f;
+  const int NV = d.NV;
+  r.x = f[SF_X * NV + idx]; r.y = f[SF_Y * NV + idx]; r.th = f[SF_THETA * NV + idx]; r.v = f[SF_SPEED * NV + idx];
+  r.steer = f[SF_STEER * NV + idx]; r.thr = f[SF_THROTTLE * NV + idx];
+  r.lastx = f[SF_LASTX * NV + idx]; r.lasty = f[SF_LASTY * NV + idx];
+  r.lasthx = f[SF_LASTHX * NV + idx]; r.lasthy = f[SF_LASTHY * NV + idx];
+  r.a0s = f[SF_ACT0S * NV + idx]; r.a0t = f[SF_ACT0T * NV + idx];
+  r.a1s = f[SF_ACT1S * NV + idx]; r.a1t = f[SF_ACT1T * NV + idx];
+  r.php = f[SF_PID_HP * NV + idx]; r.phi = f[SF_PID_HI * NV + idx];
+  r.plp = f[SF_PID_LP * NV + idx]; r.pli = f[SF_PID_LI * NV + idx];
+  r.target = f[SF_TARGET_SPEED * NV + idx]; r.energy = f[SF_ENERGY * NV + idx];
+  r.dl = f[SF_DIST_LEFT * NV + idx]; r.dr = f[SF_DIST_RIGHT * NV + idx]; r.eprew = f[SF_EP_REWARD * NV + idx];
+  const int32_t* i = d.i;
+  r.status = i[SI_STATUS * NV + idx]; r.lane = i[SI_LANE * NV + idx]; r.ck0 = i[SI_CK0 * NV + idx];
+  r.ck1 = i[SI_CK1 * NV + idx]; r.rlane = i[SI_RLANE * NV + idx]; r.timer = i[SI_TIMER * NV + idx];
+  r.vflags = i[SI_VFLAGS * NV + idx];
+}
+DEV void store_veh(const PgdDev& d, int idx, const Veh& r) {
+  float* f = d.f;
+  const int NV = d.NV;
+  f[SF_X * NV + idx] = r.x; f[SF_Y * NV + idx] = r.y; f[SF_THETA * NV + idx] = r.th; f[SF_SPEED * NV + idx] = r.v;
+  f[SF_STEER * NV + idx] = r.steer; f[SF_THROTTLE * NV + idx] = r.thr;
+  f[SF_LASTX * NV + idx] = r.lastx; f[SF_LASTY * NV + idx] = r.lasty;
+  f[SF_LASTHX * NV + idx] = r.lasthx; f[SF_LASTHY * NV + idx] = r.lasthy;
+  f[SF_ACT0S * NV + idx] = r.a0s; f[SF_ACT0T * NV + idx] = r.a0t;
+  f[SF_ACT1S * NV + idx] = r.a1s; f[SF_ACT1T * NV + idx] = r.a1t;
+  f[SF_PID_HP * NV + idx] = r.php; f[SF_PID_HI * NV + idx] = r.phi;
+  f[SF_PID_LP * NV + idx] = r.plp; f[SF_PID_LI * NV + idx] = r.pli;
+  f[SF_TARGET_SPEED * NV + idx] = r.target; f[SF_ENERGY * NV + idx] = r.energy;
+  f[SF_DIST_LEFT * NV + idx] = r.dl; f[SF_DIST_RIGHT * NV + idx] = r.dr; f[SF_EP_REWARD * NV + idx] = r.eprew;
+  int32_t* i = d.i;
+  i[SI_STATUS * NV + idx] = r.status; i[SI_LANE * NV + idx] = r.lane; i[SI_CK0 * NV + idx] = r.ck0;
+  i[SI_CK1 * NV + idx] = r.ck1; i[SI_RLANE * NV + idx] = r.rlane; i[SI_TIMER * NV + idx] = r.timer;
+  i[SI_VFLAGS * NV + idx] = r.vflags;
+}
+
+DEV float speed_kmh(float v) { return clipf(v * 3.6f, 0.0f, 100000.0f); }  // base_vehicle.py:394-401
+
+// env snapshot in LDS (one entry per lane of the wave)
+struct Snap {
+  float x[WAVE], y[WAVE], ux[WAVE], uy[WAVE], spd[WAVE], hl[WAVE], hw[WAVE];
+  int lane[WAVE], present[WAVE];
+};
+DEV Obb snap_obb(const Snap& S, int k) { return Obb{S.x[k], S.y[k], S.ux[k], S.uy[k], S.hl[k], S.hw[k]}; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// localisation: utils/scene_utils.py:138-185 + navigation.py:328-344.  "First hit" = smallest box id (Bullet insertion
+// order); cell lists are ascending so the first match per class in the cell is the answer.
+// ---------------------------------------------------------------------------------------------------------------------
+DEV int get_current_lane(const MapView& mv, float px, float py, float hx, float hy, int road_cur, int road_next) {
+  const pgd_map& m = *mv.m;
+  int cx = (int)floorf((px - m.ox) / m.cell), cy = (int)floorf((py - m.oy) / m.cell);
+  if (cx < 0 || cy < 0 || cx >= m.gx || cy >= m.gy) return -1;
+  int cell = cy * m.gx + cx;
+  int k0 = mv.cstart[cell], k1 = mv.cstart[cell + 1];
+  int best_cur = -1, best_next = -1, best_any = -1;
+  for (int k = k0; k < k1; ++k) {
+    const pgd_box& b = mv.boxes[mv.citems[k]];
+    if (b.kind != PGD_BOX_LANE) continue;
+    if (!point_in_obb(obb_of(b), px, py)) continue;
+    const pgd_lane& l = mv.lanes[b.lane];
+    if (best_cur >= 0) break;
+    bool want = (best_any < 0) || (l.road == road_cur) || (best_next < 0 && l.road == road_next);
+    if (!want) continue;
+    float lon, lat;
+    lane_local(l, px, py, lon, lat);
+    float lh = lane_heading_at(l, lon);
+    float s, c;
+    sincosf(lh, &s, &c);
+    float cosangle = (c * hx + s * hy) / (norm2(c, s) * norm2(hx, hy));
+    if (!(cosangle > 0.0f)) continue;
+    if (best_any < 0) best_any = b.lane;
+    if (l.road == road_cur) best_cur = b.lane;
+    else if (l.road == road_next && best_next < 0) best_next = b.lane;
+  }
+  if (best_cur >= 0) return best_cur;
+  if (road_next < 0) return best_any;
+  if (best_next >= 0) return best_next;
+  return best_any;
+}
+
+// Navigation._update_target_checkpoints (navigation.py:262-282)
+DEV void update_checkpoints(const MapView& mv, const pgd_spawn& sp, Veh& r, float lon) {
+  if (r.ck0 == r.ck1) return;
+  if (!(lon < 5.0f)) return;
+  int n = sp.n_ckpt;
+  int start_node = mv.roads[mv.lanes[r.lane].road].from;
+  bool in_tail = false;
+  int idx = -1;
+  for (int k = r.ck1; k < n; ++k) {
+    if (sp.ckpt[k] == start_node) {
+      in_tail = true;
+      if (idx < 0 && k < n - 1) idx = k;
+    }
+  }
+  if (!in_tail || idx < 0) return;
+  r.ck0 = idx;
+  r.ck1 = (idx + 1 == n - 1) ? idx : idx + 1;
+}
+
+// Navigation.update_localization (navigation.py:155-183)
+DEV void update_localization(const MapView& mv, const pgd_spawn& sp, Veh& r) {
+  float s, c;
+  sincosf(r.th, &s, &c);
+  int road_cur = sp.ckpt_road[r.ck0];
+  int road_next = (r.ck0 == r.ck1) ? -1 : sp.ckpt_road[r.ck1];
+  int lane = get_current_lane(mv, r.x, r.y, c, s, road_cur, road_next);
+  bool on_lane = lane >= 0;
+  if (!on_lane) lane = r.lane;
+  r.lane = lane;
+  float lon, lat;
+  lane_local(mv.lanes[lane], r.x, r.y, lon, lat);
+  update_checkpoints(mv, sp, r, lon);
+  r.vflags = on_lane ? (r.vflags & ~PGD_F_OFF_LANE) : (r.vflags | PGD_F_OFF_LANE);
+}
+
+// BaseVehicle._state_check (base_vehicle.py:615-644)
+DEV unsigned state_check(const MapView& mv, const Obb& car) {
+  const pgd_map& m = *mv.m;
+  float ex = fabsf(car.ux) * car.hl + fabsf(car.uy) * car.hw, ey = fabsf(car.uy) * car.hl + fabsf(car.ux) * car.hw;
+  int cx0 = max((int)floorf((car.cx - ex - m.ox) / m.cell), 0), cx1 = min((int)floorf((car.cx + ex - m.ox) / m.cell), m.gx - 1);
+  int cy0 = max((int)floorf((car.cy - ey - m.oy) / m.cell), 0), cy1 = min((int)floorf((car.cy + ey - m.oy) / m.cell), m.gy - 1);
+  unsigned fl = 0;
+  for (int cy = cy0; cy <= cy1; ++cy)
+    for (int cx = cx0; cx <= cx1; ++cx) {
+      int cell = cy * m.gx + cx;
+      int k1 = mv.cstart[cell + 1];
+      for (int k = mv.cstart[cell]; k < k1; ++k) {
+        const pgd_box& b = mv.boxes[mv.citems[k]];
+        if (b.kind == PGD_BOX_LANE) continue;
+        unsigned bit = b.kind == PGD_BOX_WHITE ? PGD_F_ON_WHITE
+                       : b.kind == PGD_BOX_YELLOW ? PGD_F_ON_YELLOW
+                       : b.kind == PGD_BOX_BROKEN ? PGD_F_ON_BROKEN : PGD_F_CRASH_SIDEWALK;
+        if (fl & bit) continue;
+        if (obb_overlap(car, obb_of(b))) fl |= bit;
+      }
+    }
+  return fl;
+}
+
+// BaseVehicle.after_step (base_vehicle.py:255-290)
+DEV void after_step_vehicle(const MapView& mv, const pgd_spawn& sp, Veh& r, bool is_agent) {
+  update_localization(mv, sp, r);
+  if (is_agent) {
+    unsigned fl = (unsigned)r.vflags;
+    fl &= ~(PGD_F_ON_WHITE | PGD_F_ON_YELLOW | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OUT_OF_ROUTE);
+    float s, c;
+    sincosf(r.th, &s, &c);
+    fl |= state_check(mv, Obb{r.x, r.y, c, s, 0.5f * sp.length, 0.5f * sp.width});
+    const pgd_road& cr = mv.roads[sp.ckpt_road[r.ck0]];
+    float lon, lat;
+    lane_local(mv.lanes[cr.first_lane], r.x, r.y, lon, lat);
+    float w = mv.m->lane_width;
+    r.dl = lat + w * 0.5f;
+    r.dr = w * cr.n_lanes - r.dl;
+    if (r.dr < 0.0f || r.dl < 0.0f) fl |= PGD_F_OUT_OF_ROUTE;
+    r.vflags = (int)fl;
+    float dist = norm2(r.lastx - r.x, r.lasty - r.y) / 1000.0f;
+    r.energy += 3.25f * expf(0.01f * speed_kmh(r.v)) * dist / 100.0f * 1000.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// IDM: policy/idm_policy.py:82-133 (FrontBackObjects), :190-353 (act, lane change), :244-271 (PID + IDM law)
+// ---------------------------------------------------------------------------------------------------------------------
+struct Fbo {
+  int front[3], back[3];
+  float fd[3], bd[3];
+  bool exist[3];
+};
+
+DEV void find_front_back(const MapView& mv, const Snap& S, int base, int V, int self, unsigned long long objs, int lane,
+                         float max_dist, bool with_ref, Fbo& r) {
+  const pgd_lane& L = mv.lanes[lane];
+  const pgd_road& road = mv.roads[L.road];
+  int idx = L.index;
+  int lanes[3];
+  lanes[0] = (with_ref && idx > 0) ? road.first_lane + idx - 1 : -1;
+  lanes[1] = lane;
+  lanes[2] = (with_ref && idx + 1 < road.n_lanes) ? road.first_lane + idx + 1 : -1;
+  float px = S.x[base + self], py = S.y[base + self];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    r.front[i] = r.back[i] = -1;
+    r.exist[i] = lanes[i] >= 0;
+    r.fd[i] = r.bd[i] = max_dist;
+    if (lanes[i] < 0) continue;
+    const pgd_lane& li = mv.lanes[lanes[i]];
+    float cur, lat;
+    lane_local(li, px, py, cur, lat);
+    float left_long = li.length - cur;
+    bool found_f = false, found_b = false;
+    for (int o = 0; o < V; ++o) {  // objects on this very lane
+      if (!((objs >> o) & 1ull) || S.lane[base + o] != lanes[i]) continue;
+      float lo, la;
+      lane_local(li, S.x[base + o], S.y[base + o], lo, la);
+      float lg = lo - cur;
+      if (r.fd[i] > lg && lg > 0.0f) { r.fd[i] = lg; r.front[i] = o; found_f = true; }
+      if (lg < 0.0f && fabsf(lg) < r.bd[i]) { r.bd[i] = fabsf(lg); r.back[i] = o; found_b = true; }
+    }
+    for (int o = 0; o < V; ++o) {  // successor / predecessor lanes
+      if (!((objs >> o) & 1ull)) continue;
+      int ol = S.lane[base + o];
+      if (ol == lanes[i]) continue;
+      const pgd_lane& OL = mv.lanes[ol];
+      if (!found_f && lane_is_prev_of(li, ol)) {
+        float lo, la;
+        lane_local(OL, S.x[base + o], S.y[base + o], lo, la);
+        float lg = lo + left_long;
+        if (r.fd[i] > lg && lg > 0.0f) { r.fd[i] = lg; r.front[i] = o; }
+      } else if (!found_b && lane_is_prev_of(OL, lanes[i])) {
+        float lo, la;
+        lane_local(OL, S.x[base + o], S.y[base + o], lo, la);
+        float lg = OL.length - lo + cur;
+        if (r.bd[i] > lg) { r.bd[i] = lg; r.back[i] = o; }
+      }
+    }
+  }
+}
+
+DEV void idm_act(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const Snap& S, int base, int V, int s, int e,
+                 uint32_t step_count, Veh& r, float& out_steer, float& out_acc) {
+  const float NORMAL = 30.0f, CREEP = 5.0f, SAFE = 15.0f, MAXD = 30.0f;
+  int cur_road = sp.ckpt_road[r.ck0];
+  const pgd_road& CR = mv.roads[cur_road];
+  int vlane = r.lane;
+  int rt = r.rlane;
+  bool success;
+  // move_to_next_road (idm_policy.py:222-242)
+  if (rt < 0) {
+    rt = vlane;
+    success = mv.lanes[rt].road == cur_road;
+  } else if (mv.lanes[rt].road != cur_road) {
+    success = false;
+    const pgd_lane& RT = mv.lanes[rt];
+    for (int k = 0; k < CR.n_lanes; ++k)
+      if (lane_is_prev_of(RT, CR.first_lane + k)) { rt = CR.first_lane + k; success = true; break; }
+  } else if (mv.lanes[vlane].road == cur_road && rt != vlane) {
+    rt = vlane;
+    r.timer = (int)(pgd_rng(d.cfg.seed, (uint32_t)e, (uint32_t)s, step_count) % 25u);
+    success = true;
+  } else success = true;
+  r.rlane = rt;
+
+  // Lidar.get_surrounding_objects (lidar.py:109-124)
+  float px = S.x[base + s], py = S.y[base + s];
+  unsigned long long objs = 0ull;
+  for (int o = 0; o < V; ++o) {
+    if (o == s || !S.present[base + o]) continue;
+    if (point_obb_dist(snap_obb(S, base + o), px, py) <= 50.0f) objs |= 1ull << o;
+  }
+
+  int front_obj = -1;
+  float front_dist = 5.0f;
+  int steer_lane = rt;
+  float speed = S.spd[base + s];
+  if (success) {
+    if (mv.lanes[rt].road == cur_road) {
+      Fbo fb;
+      find_front_back(mv, S, base, V, s, objs, rt, MAXD, true, fb);
+      int idx = mv.lanes[rt].index;
+      int n_cur = CR.n_lanes;
+      int avail_lo = 0, avail_hi = n_cur - 1;
+      bool decided = false;
+      if (r.ck0 != r.ck1) {
+        const pgd_road& NR = mv.roads[sp.ckpt_road[r.ck1]];
+        int diff = n_cur - NR.n_lanes;
+        if (diff > 0) {
+          if (lane_is_prev_of(mv.lanes[CR.first_lane], NR.first_lane)) { avail_lo = 0; avail_hi = NR.n_lanes - 1; }
+          else { avail_lo = diff; avail_hi = n_cur - 1; }
+          if (idx < avail_lo || idx > avail_hi) {
+            int side = idx > avail_hi ? 0 : 2;  // 0: change to left, 2: change to right
+            if (fb.bd[side] < SAFE || fb.fd[side] < 5.0f) {
+              r.target = CREEP;
+              front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
+            } else {
+              r.target = NORMAL;
+              front_obj = fb.front[side]; front_dist = fb.fd[side];
+              steer_lane = CR.first_lane + idx + (side == 0 ? -1 : 1);
+            }
+            decided = true;
+          }
+        }
+      }
+      if (!decided) {
+        if (fabsf(speed - NORMAL) > 3.0f && fb.front[1] >= 0 && fabsf(S.spd[base + fb.front[1]] - NORMAL) > 3.0f &&
+            r.timer > 50) {
+          float fs = S.spd[base + fb.front[1]];
+          bool has_r = false, has_l = false;
+          float rs = 0.0f, ls = 0.0f;
+          if (fb.front[2] >= 0) { has_r = true; rs = S.spd[base + fb.front[2]]; }
+          else if (fb.exist[2] && fb.fd[2] > SAFE && fb.bd[2] > SAFE) { has_r = true; rs = 100.0f; }
+          if (fb.front[0] >= 0) { has_l = true; ls = S.spd[base + fb.front[0]]; }
+          else if (fb.exist[0] && fb.fd[0] > SAFE && fb.bd[0] > SAFE) { has_l = true; ls = 100.0f; }
+          if (has_l && ls - fs > 10.0f) {
+            int ex = idx - 1;
+            if (ex >= avail_lo && ex <= avail_hi) {
+              front_obj = fb.front[0]; front_dist = fb.fd[0]; steer_lane = CR.first_lane + ex; decided = true;
+            }
+          }
+          if (!decided && has_r && rs - fs > 10.0f) {
+            int ex = idx + 1;
+            if (ex >= avail_lo && ex <= avail_hi) {
+              front_obj = fb.front[2]; front_dist = fb.fd[2]; steer_lane = CR.first_lane + ex; decided = true;
+            }
+          }
+        }
+        if (!decided) {
+          r.target = NORMAL;
+          r.timer += 1;
+          front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
+        }
+      }
+    }  // else: reference's assert fails -> except branch: no front object, dist 5
+  } else {
+    Fbo fb;
+    find_front_back(mv, S, base, V, s, objs, rt, MAXD, false, fb);
+    front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
+  }
+
+  // steering_control (idm_policy.py:244-252)
+  const pgd_lane& SL = mv.lanes[steer_lane];
+  float lon, lat;
+  lane_local(SL, px, py, lon, lat);
+  float lane_heading = lane_heading_at(SL, lon + 1.0f);
+  float steering = pid_update(r.php, r.phi, 1.7f, 0.01f, 3.5f, wrap_to_pi(lane_heading - r.th));
+  steering += pid_update(r.plp, r.pli, 0.3f, 0.002f, 0.05f, -lat);
+  // acceleration / desired_gap (idm_policy.py:254-271)
+  float ratio = fmaxf(speed, 0.0f) / not_zero(r.target, 0.0f);
+  float r2 = ratio * ratio, r4 = r2 * r2, r8 = r4 * r4;
+  float acc = 1.0f - r8 * r2;
+  if (front_obj >= 0) {
+    float hx = S.ux[base + s], hy = S.uy[base + s];
+    float fsp = S.spd[base + front_obj];
+    float dvx = speed * hx - fsp * S.ux[base + front_obj], dvy = speed * hy - fsp * S.uy[base + front_obj];
+    float dv = dvx * hx + dvy * hy;
+    float d_star = 10.0f + speed * 1.5f + speed * dv / (2.0f * 2.2360679774997896f);
+    float sd = d_star / not_zero(front_dist, 1e-2f);
+    acc -= sd * sd;
+  }
+  out_steer = steering;
+  out_acc = acc;
+}
+
+// kinematic bicycle (component/highway_vehicle/kinematics.py:134-156) driven by the reference's action -> force mapping
+// (base_vehicle.py:343-376); see DESIGN.md §3 for the substitution of Bullet's raycast vehicle.
+DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r) {
+  float dt = d.cfg.dt;
+  float force = 0.0f, brake;
+  if (r.thr >= 0.0f) {
+    brake = 2.0f;
+    force = (r.v * 3.6f > p.max_speed) ? 0.0f : p.max_engine_force * r.thr;
+  } else {
+    brake = fabsf(r.thr) * p.max_brake_force;
+  }
+  float delta = -clipf(r.steer, -1.0f, 1.0f) * p.max_steer;
+  float beta = atanf(0.5f * tanf(delta));
+  float sb = sinf(beta);
+  float inv_half_base = 2.0f / p.wheelbase;
+  float dv_brake = fminf(4.0f * brake / p.mass, p.friction * 9.81f * dt);
+  float dv_engine = 4.0f * force / p.mass * dt;
+  for (int k = 0; k < d.cfg.decision_repeat; ++k) {
+    float s, c;
+    sincosf(r.th + beta, &s, &c);
+    r.x += r.v * c * dt;
+    r.y += r.v * s * dt;
+    r.th += r.v * sb * inv_half_base * dt;
+    if (force != 0.0f) r.v += dv_engine;
+    else r.v = fmaxf(0.0f, r.v - dv_brake);
+    r.v = fmaxf(r.v, 0.0f);
+  }
+}
+
+DEV void reset_vehicle(const pgd_spawn& p, Veh& r) {  // base_vehicle.py:292-339 + idm_policy.py:180-188
+  memset(&r, 0, sizeof(Veh));
+  r.rlane = -1;
+  if (p.lane < 0) { r.status = ST_EMPTY; return; }
+  r.status = p.group < 0 ? ST_ACTIVE : ST_PENDING;
+  r.x = p.x; r.y = p.y; r.th = p.heading;
+  r.lastx = p.x; r.lasty = p.y;
+  sincosf(p.heading, &r.lasthy, &r.lasthx);
+  r.target = 30.0f;
+  r.lane = p.lane;
+  r.ck0 = 0;
+  r.ck1 = p.n_ckpt > 2 ? 1 : 0;
+  r.timer = p.timer0;
+}
+
+// reward / done: envs/pgdrive_env.py:162-258, base_vehicle.py:738-745
+DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const Veh& r, unsigned& flags_out,
+                      bool& done_out) {
+  const pgd_config& g = d.cfg;
+  unsigned vf = (unsigned)r.vflags;
+  int cur_road = sp.ckpt_road[r.ck0];
+  const pgd_road& CR = mv.roads[cur_road];
+  const pgd_lane& VL = mv.lanes[r.lane];
+  bool in_ref = VL.road == cur_road;
+  const pgd_lane& cl = in_ref ? VL : mv.lanes[CR.first_lane];
+  float positive = in_ref ? 1.0f : (mv.roads[VL.road].negative ? -1.0f : 1.0f);
+  float l0, t0, l1, t1;
+  lane_local(cl, r.lastx, r.lasty, l0, t0);
+  lane_local(cl, r.x, r.y, l1, t1);
+  float w = mv.m->lane_width;
+  float lateral_factor = g.use_lateral ? clipf(1.0f - 2.0f * fabsf(t1) / w, 0.0f, 1.0f) : 1.0f;
+  float reward = g.driving_reward * (l1 - l0) * lateral_factor * positive;
+  reward += g.speed_reward * (speed_kmh(r.v) / sp.max_speed) * positive;
+  unsigned out = vf & (PGD_F_ON_YELLOW | PGD_F_ON_WHITE | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OFF_LANE |
+                       PGD_F_OUT_OF_ROUTE | PGD_F_CRASH_VEHICLE);
+  const pgd_lane& fl = mv.lanes[sp.dest_lane];
+  float lon, lat;
+  lane_local(fl, r.x, r.y, lon, lat);
+  bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - CR.n_lanes) * w);
+  bool oor = (vf & (PGD_F_ON_YELLOW | PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK)) != 0;
+  if (g.out_of_route_done) oor = oor || (vf & PGD_F_OUT_OF_ROUTE);
+  bool crash = (vf & PGD_F_CRASH_VEHICLE) != 0;
+  if (arrive) out |= PGD_F_ARRIVE;
+  if (oor) out |= PGD_F_OUT_OF_ROAD;
+  if (arrive) reward = g.success_reward;
+  else if (oor) reward = -g.out_of_road_penalty;
+  else if (crash) reward = -g.crash_vehicle_penalty;
+  flags_out = out;
+  done_out = arrive || oor || crash;
+  return reward;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_step: one env.step() for every environment (base_env.py:184-224)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
+                                                uint8_t* __restrict__ done, uint32_t* __restrict__ flags) {
+  __shared__ Snap S;
+  __shared__ int s_flag[WAVE];
+  const int V = d.V, A = d.A, N = d.N;
+  const int lane = threadIdx.x;
+  const int el = lane / V, s = lane - el * V;
+  const int e = blockIdx.x * d.epw + el;
+  const bool valid = (el < d.epw) && (e < N);
+  const int base = el * V;
+  const int idx = e * V + s;
+
+  Veh r;
+  MapView mv;
+  const pgd_spawn* sp = nullptr;
+  const pgd_scenario* sc = nullptr;
+  int ng = 0, ep_steps = 0;
+  uint32_t steps_total = 0;
+  S.present[lane] = 0;
+  s_flag[lane] = 0;
+  if (valid) {
+    load_veh(d, idx, r);
+    int scen = d.ei[EI_SCEN * N + e];
+    sc = d.scen + scen;
+    sp = d.spawns + (size_t)scen * V + s;
+    mv = map_view(d, sc->map);
+    ng = d.ei[EI_NEXT_GROUP * N + e];
+    ep_steps = d.ei[EI_EP_STEPS * N + e];
+    steps_total = (uint32_t)d.ei[EI_STEPS_TOTAL * N + e];
+    // (1) TrafficManager.before_step trigger (traffic_manager.py:76-85)
+    if (s < A && r.status == ST_ACTIVE && ng < sc->n_groups && mv.lanes[r.lane].road == sc->trigger_road[ng]) s_flag[el] = 1;
+  }
+  __syncthreads();
+  const bool trig = valid && s_flag[el] != 0;
+  if (trig && r.status == ST_PENDING && sp->group == ng) r.status = ST_ACTIVE;
+  if (trig) ng += 1;  // every lane of the env keeps the same copy
+  // snapshot of the world before physics
+  if (valid) {
+    float sn, cs;
+    sincosf(r.th, &sn, &cs);
+    S.x[lane] = r.x; S.y[lane] = r.y; S.ux[lane] = cs; S.uy[lane] = sn;
+    S.spd[lane] = speed_kmh(r.v);
+    S.hl[lane] = 0.5f * sp->length; S.hw[lane] = 0.5f * sp->width;
+    S.lane[lane] = r.lane;
+    S.present[lane] = (r.status == ST_PENDING || r.status == ST_ACTIVE) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool acting = valid && r.status == ST_ACTIVE;
+  // (2) policies
+  if (acting) {
+    float st, tb;
+    if (s < A) {  // EnvInputPolicy.act (env_input_policy.py:17-26); NaN made harmless (test_ego_vehicle.py:78-84)
+      float a0 = act[((size_t)e * A + s) * 2 + 0], a1 = act[((size_t)e * A + s) * 2 + 1];
+      if (a0 != a0) a0 = 0.0f;
+      if (a1 != a1) a1 = 0.0f;
+      st = clipf(a0, -1.0f, 1.0f);
+      tb = clipf(a1, -1.0f, 1.0f);
+    } else {
+      idm_act(d, mv, *sp, S, base, V, s, e, steps_total, r, st, tb);
+    }
+    // (3) BaseVehicle.before_step (base_vehicle.py:238-253)
+    r.vflags &= ~PGD_F_CRASH_VEHICLE;
+    r.lastx = r.x; r.lasty = r.y;
+    r.lasthx = S.ux[lane]; r.lasthy = S.uy[lane];
+    r.a0s = r.a1s; r.a0t = r.a1t;
+    r.a1s = st; r.a1t = tb;
+    r.steer = st; r.thr = tb;
+    // (4) physics
+    dynamics(d, *sp, r);
+  }
+  __syncthreads();
+  if (acting) {
+    float sn, cs;
+    sincosf(r.th, &sn, &cs);
+    S.x[lane] = r.x; S.y[lane] = r.y; S.ux[lane] = cs; S.uy[lane] = sn;
+  }
+  __syncthreads();
+  // (5) vehicle-vehicle contacts on the post-physics poses (collision_callback.py:7-36)
+  if (acting && s < A) {
+    Obb me = snap_obb(S, lane);
+    bool hit = false;
+    for (int o = 0; o < V; ++o) {
+      if (o == s || !S.present[base + o]) continue;
+      hit = hit || obb_overlap(me, snap_obb(S, base + o));
+    }
+    if (hit) r.vflags |= PGD_F_CRASH_VEHICLE;
+  }
+  // (6) after_step; traffic off the lanes is removed (traffic_manager.py:91-109)
+  if (acting) {
+    after_step_vehicle(mv, *sp, r, s < A);
+    if (s >= A && (r.vflags & PGD_F_OFF_LANE)) r.status = ST_REMOVED;
+  }
+  ep_steps += 1;
+  steps_total += 1;
+  // (7) reward / done (base_env.py:303-344)
+  s_flag[lane] = 0;
+  __syncthreads();
+  if (valid && s < A) {
+    unsigned fl = 0;
+    bool dn = false;
+    float rew = 0.0f;
+    if (r.status == ST_ACTIVE) rew = reward_done(d, mv, *sp, r, fl, dn);
+    if (d.cfg.horizon > 0 && ep_steps >= d.cfg.horizon) { dn = true; fl |= PGD_F_MAX_STEP; }
+    r.eprew += rew;
+    bool will_reset = dn && d.cfg.auto_reset && A == 1;
+    if (will_reset) { fl |= PGD_F_RESET; s_flag[el] = 1; }
+    size_t k = (size_t)e * A + s;
+    reward[k] = rew;
+    done[k] = dn ? 1 : 0;
+    flags[k] = fl;
+  }
+  __syncthreads();
+  // (8) auto reset (base_env.py:269-301): the whole env restarts from its (possibly re-drawn) scenario
+  int episodes = 0;
+  if (valid && s_flag[el]) {
+    int scen = d.ei[EI_SCEN * N + e];
+    episodes = d.ei[EI_EPISODES * N + e] + 1;
+    if (d.cfg.resample_scenario)
+      scen = (int)(pgd_rng(d.cfg.seed, (uint32_t)e, 0x5ce9a210u, (uint32_t)episodes) % (uint32_t)d.n_scen);
+    sc = d.scen + scen;
+    sp = d.spawns + (size_t)scen * V + s;
+    mv = map_view(d, sc->map);
+    reset_vehicle(*sp, r);
+    if (r.status != ST_EMPTY) after_step_vehicle(mv, *sp, r, s < A);
+    ng = 0;
+    ep_steps = 0;
+    if (s == 0) {
+      d.ei[EI_SCEN * N + e] = scen;
+      d.ei[EI_EPISODES * N + e] = episodes;
+    }
+  }
+  if (valid) {
+    store_veh(d, idx, r);
+    if (s == 0) {
+      d.ei[EI_NEXT_GROUP * N + e] = ng;
+      d.ei[EI_EP_STEPS * N + e] = ep_steps;
+      d.ei[EI_STEPS_TOTAL * N + e] = (int)steps_total;
+    }
+  }
+}
+
+// reset of selected envs (base_env.py:269-301); grid = envs, one wave per floor(64/V) envs like k_step
+__global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restrict__ env_ids,
+                                                 const int32_t* __restrict__ scen_ids, int n) {
+  const int V = d.V, A = d.A, N = d.N;
+  const int lane = threadIdx.x;
+  const int el = lane / V, s = lane - el * V;
+  const int k = blockIdx.x * d.epw + el;
+  if (el >= d.epw || k >= n) return;
+  const int e = env_ids ? env_ids[k] : k;
+  const int scen = scen_ids[k];
+  const pgd_scenario* sc = d.scen + scen;
+  const pgd_spawn* sp = d.spawns + (size_t)scen * V + s;
+  MapView mv = map_view(d, sc->map);
+  Veh r;
+  reset_vehicle(*sp, r);
+  if (r.status != ST_EMPTY) after_step_vehicle(mv, *sp, r, s < A);
+  store_veh(d, e * V + s, r);
+  if (s == 0) {
+    d.ei[EI_SCEN * N + e] = scen;
+    d.ei[EI_NEXT_GROUP * N + e] = 0;
+    d.ei[EI_EP_STEPS * N + e] = 0;
+    d.ei[EI_EPISODES * N + e] = 0;
+    d.ei[EI_STEPS_TOTAL * N + e] = 0;
+  }
+}
+
+// engine.after_step on the current state (used after pgd_set_state)
+__global__ __launch_bounds__(WAVE) void k_refresh(PgdDev d) {
+  const int V = d.V, A = d.A, N = d.N;
+  const int lane = threadIdx.x;
+  const int el = lane / V, s = lane - el * V;
+  const int e = blockIdx.x * d.epw + el;
+  if (el >= d.epw || e >= N) return;
+  Veh r;
+  load_veh(d, e * V + s, r);
+  if (r.status != ST_ACTIVE && r.status != ST_PENDING) return;
+  int scen = d.ei[EI_SCEN * N + e];
+  MapView mv = map_view(d, d.scen[scen].map);
+  after_step_vehicle(mv, d.spawns[(size_t)scen * V + s], r, s < A);
+  store_veh(d, e * V + s, r);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_observe: LidarStateObservation.observe (obs/state_obs.py:132-170) for every (env, agent)
+// ---------------------------------------------------------------------------------------------------------------------
+DEV void navi_info_for(const MapView& mv, int road, int n_cur, float px, float py, float hx, float hy, float* out) {
+  // Navigation._get_info_for_checkpoint (navigation.py:213-260)
+  const pgd_lane& ref = mv.lanes[mv.roads[road].first_lane];
+  float w = mv.m->lane_width;
+  float later_middle = ((float)n_cur * 0.5f - 0.5f) * w;
+  float cx, cy;
+  lane_position(ref, ref.length, later_middle, cx, cy);
+  float dx = cx - px, dy = cy - py;
+  float dn = norm2(dx, dy);
+  if (dn > 50.0f) { dx = dx / dn * 50.0f; dy = dy / dn * 50.0f; }
+  float ph, ps;
+  projection(hx, hy, dx, dy, ph, ps);
+  float bend = 0.0f, dir = 0.0f, angle = 0.0f;
+  if (ref.dir != 0.0f) {
+    bend = ref.bx / (60.0f + n_cur * w);
+    dir = ref.dir;
+    angle = dir == 1.0f ? ref.c - ref.by : ref.by - ref.c;
+  }
+  out[0] = clipf((ph / 50.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
+  out[1] = clipf((ps / 50.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
+  out[2] = clipf(bend, 0.0f, 1.0f);
+  out[3] = clipf((dir + 1.0f) * 0.5f, 0.0f, 1.0f);
+  out[4] = clipf((angle * (180.0f / PGD_PI) / 135.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
+}
+
+DEV float heading_diff(const pgd_lane& l, float px, float py, float fx, float fy) {  // base_vehicle.py:433-458
+  float lx, ly;
+  if (l.dir == 0.0f) { lx = -l.by; ly = l.bx; }
+  else if (l.dir < 0.0f) { lx = px - l.ax; ly = py - l.ay; }
+  else { lx = l.ax - px; ly = l.ay - py; }
+  float ln = norm2(lx, ly), fn = norm2(fx, fy);
+  if (ln * fn == 0.0f) return 0.0f;
+  return clipf((fx * lx + fy * ly) / (ln * fn), -1.0f, 1.0f) * 0.5f + 0.5f;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__ obs) {
+  __shared__ float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV], bdist[MAXV];
+  __shared__ int s_n;
+  const int V = d.V, A = d.A, N = d.N, NV = d.NV, D = d.D;
+  const int e = blockIdx.x / A, a = blockIdx.x - e * A;
+  const int tid = threadIdx.x;
+  const int me = e * V + a;
+  const float* f = d.f;
+  const float px = f[SF_X * NV + me], py = f[SF_Y * NV + me], th = f[SF_THETA * NV + me];
+  float hy, hx;
+  sincosf(th, &hy, &hx);
+  const int scen = d.ei[EI_SCEN * N + e];
+  const pgd_spawn* spb = d.spawns + (size_t)scen * V;
+  const float R = d.cfg.lidar_dist;
+  float* row = obs + ((size_t)e * A + a) * D;
+  const int NL = d.cfg.num_lasers;
+
+  // wave 0: compact the vehicles inside the r = R broad phase (lidar.py:109-124) into LDS
+  if (tid < WAVE) {
+    bool in = false;
+    float x = 0, y = 0, ux = 1, uy = 0, hl = 0, hw = 0, spd = 0, dist = 0;
+    if (tid < V && tid != a && NL > 0) {
+      int st = d.i[SI_STATUS * NV + e * V + tid];
+      if (st == ST_PENDING || st == ST_ACTIVE) {
+        x = f[SF_X * NV + e * V + tid]; y = f[SF_Y * NV + e * V + tid];
+        float t = f[SF_THETA * NV + e * V + tid];
+        sincosf(t, &uy, &ux);
+        hl = 0.5f * spb[tid].length; hw = 0.5f * spb[tid].width;
+        spd = speed_kmh(f[SF_SPEED * NV + e * V + tid]);
+        in = point_obb_dist(Obb{x, y, ux, uy, hl, hw}, px, py) <= R;
+        dist = norm2(px - x, py - y);
+      }
+    }
+    unsigned long long m = __ballot(in);
+    if (in) {
+      int k = __popcll(m & ((1ull << tid) - 1ull));
+      bx[k] = x; by[k] = y; bux[k] = ux; buy[k] = uy; bhl[k] = hl; bhw[k] = hw; bspd[k] = spd; bdist[k] = dist;
+    }
+    if (tid == 0) s_n = __popcll(m);
+  }
+  __syncthreads();
+  const int n = s_n;
+
+  // StateObservation.vehicle_state (state_obs.py:58-106): 8 floats, one lane each
+  if (tid < 8 + 10) {
+    const pgd_spawn& sp = spb[a];
+    MapView mv = map_view(d, d.scen[scen].map);
+    int ck0 = d.i[SI_CK0 * NV + me], ck1 = d.i[SI_CK1 * NV + me];
+    const pgd_road& CR = mv.roads[sp.ckpt_road[ck0]];
+    float v = 0.0f;
+    if (tid == 0) v = clipf(f[SF_DIST_LEFT * NV + me] / 18.0f, 0.0f, 1.0f);        // (MAX_LANE_NUM+1)*MAX_LANE_WIDTH
+    else if (tid == 1) v = clipf(f[SF_DIST_RIGHT * NV + me] / 18.0f, 0.0f, 1.0f);
+    else if (tid == 2) v = heading_diff(mv.lanes[CR.first_lane + CR.n_lanes - 1], px, py, hx, hy);
+    else if (tid == 3) v = clipf((speed_kmh(f[SF_SPEED * NV + me]) + 1.0f) / (sp.max_speed + 1.0f), 0.0f, 1.0f);
+    else if (tid == 4) v = clipf((f[SF_STEER * NV + me] / 60.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
+    else if (tid == 5) v = clipf((f[SF_ACT0S * NV + me] + 1.0f) * 0.5f, 0.0f, 1.0f);
+    else if (tid == 6) v = clipf((f[SF_ACT0T * NV + me] + 1.0f) * 0.5f, 0.0f, 1.0f);
+    else if (tid == 7) {
+      float lhx = f[SF_LASTHX * NV + me], lhy = f[SF_LASTHY * NV + me];
+      // acos(clip(cos_beta, 0, 1)) (state_obs.py:87-92) evaluated as atan2(|cross|, dot): identical for unit vectors,
+      // but well-conditioned in fp32 near beta = 0 where 1 - cos(beta) underflows the mantissa
+      float dot = hx * lhx + hy * lhy, cross = hx * lhy - hy * lhx;
+      float beta = dot <= 0.0f ? 0.5f * PGD_PI : atan2f(fabsf(cross), dot);
+      v = clipf(beta / 0.1f, 0.0f, 1.0f);
+    } else {  // navi info: lanes 8..12 -> checkpoint 1, 13..17 -> checkpoint 2 (navigation.py:185-197)
+      int which = (tid - 8) / 5, comp = (tid - 8) - which * 5;
+      float out[5];
+      navi_info_for(mv, sp.ckpt_road[which == 0 ? ck0 : ck1], CR.n_lanes, px, py, hx, hy, out);
+      v = out[comp];
+    }
+    row[tid] = v;
+  }
+  if (NL <= 0) return;
+
+  // get_surrounding_vehicles_info (lidar.py:55-77): rank by centre distance (stable), 4 floats per neighbour
+  const int NO = d.cfg.num_others;
+  if (tid >= WAVE && tid < WAVE + MAXV) {
+    int k = tid - WAVE;
+    if (k < n) {
+      int rank = 0;
+      float dk = bdist[k];
+      for (int j = 0; j < n; ++j) rank += (bdist[j] < dk || (bdist[j] == dk && j < k)) ? 1 : 0;
+      if (rank < NO) {
+        float ph, ps;
+        float ms = spb[a].max_speed;
+        float sp_me = speed_kmh(f[SF_SPEED * NV + me]);
+        projection(hx, hy, bx[k] - px, by[k] - py, ph, ps);
+        float* o = row + 18 + rank * 4;
+        o[0] = clipf((ph / R + 1.0f) * 0.5f, 0.0f, 1.0f);
+        o[1] = clipf((ps / R + 1.0f) * 0.5f, 0.0f, 1.0f);
+        projection(hx, hy, bspd[k] * bux[k] - sp_me * hx, bspd[k] * buy[k] - sp_me * hy, ph, ps);
+        o[2] = clipf((ph / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
+        o[3] = clipf((ps / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
+      }
+    } else if (k < NO) {
+      float* o = row + 18 + k * 4;
+      o[0] = o[1] = o[2] = o[3] = 0.0f;
+    }
+  }
+
+  // lidar (distance_detector.py:65-94, cutils.pyx:60-142): beam i at theta + i*2pi/N, nearest hit fraction
+  const float unit = 2.0f * PGD_PI / (float)NL;
+  for (int i = tid; i < NL; i += BLOCK) {
+    float ang = (float)i * unit + th;
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    float dx = R * cs, dy = R * sn;
+    float best = 1.0f;
+    for (int k = 0; k < n; ++k) best = fminf(best, ray_obb(Obb{bx[k], by[k], bux[k], buy[k], bhl[k], bhw[k]}, px, py, dx, dy));
+    row[18 + 4 * NO + i] = best;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+struct pgd_engine {
+  PgdDev d;
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  hipEvent_t ev0, ev1;
+  bool ev_valid;
+  pgd_map* maps; pgd_lane* lanes; pgd_road* roads; pgd_box* boxes; int32_t* cell_start; int32_t* cell_items;
+  pgd_scenario* scen; pgd_spawn* spawns;
+  int32_t* d_ids;  // scratch [2N]
+  bool have_maps, have_scen;
+  // per-kernel HIP-event profile of pgd_step launches (bench.py roofline numbers)
+  std::vector<hipEvent_t>* prof_ev;  // 3 events per recorded step
+  int prof_cap, prof_n;
+};
+
+template <typename T>
+static int upload(T** dst, const T* src, size_t n, hipStream_t st) {
+  if (*dst) { HIPCHK(hipFree(*dst)); *dst = nullptr; }
+  HIPCHK(hipMalloc(dst, sizeof(T) * (n ? n : 1)));
+  if (n) HIPCHK(hipMemcpyAsync(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return PGD_OK;
+}
+
+extern "C" {
+
+const char* pgd_version(void) { return "pgdrive_hip 0.1 (gfx950)"; }
+
+int pgd_obs_dim(const pgd_config* c) { return PGD_STATE_DIM + PGD_NAVI_DIM + 4 * c->num_others + c->num_lasers; }
+
+int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* out) {
+  if (!cfg || !out) return PGD_ERR_ARG;
+  int V = cfg->num_agents + cfg->num_traffic;
+  if (cfg->num_envs <= 0 || cfg->num_agents <= 0 || V > MAXV || cfg->num_others > 16 || cfg->num_lasers < 0) return PGD_ERR_ARG;
+  HIPCHK(hipSetDevice(device));
+  pgd_engine* h = (pgd_engine*)calloc(1, sizeof(pgd_engine));
+  h->device = device;
+  h->d.cfg = *cfg;
+  h->d.N = cfg->num_envs; h->d.A = cfg->num_agents; h->d.T = cfg->num_traffic; h->d.V = V;
+  h->d.D = pgd_obs_dim(cfg);
+  h->d.NV = h->d.N * V;
+  h->d.epw = WAVE / V;
+  if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }
+  else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+  HIPCHK(hipEventCreate(&h->ev0));
+  HIPCHK(hipEventCreate(&h->ev1));
+  size_t nv = (size_t)h->d.NV;
+  HIPCHK(hipMalloc(&h->d.f, sizeof(float) * nv * PGD_NF));
+  HIPCHK(hipMalloc(&h->d.i, sizeof(int32_t) * nv * PGD_NI));
+  HIPCHK(hipMalloc(&h->d.ei, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI));
+  HIPCHK(hipMalloc(&h->d_ids, sizeof(int32_t) * (size_t)h->d.N * 2));
+  HIPCHK(hipMemsetAsync(h->d.f, 0, sizeof(float) * nv * PGD_NF, h->stream));
+  HIPCHK(hipMemsetAsync(h->d.i, 0, sizeof(int32_t) * nv * PGD_NI, h->stream));
+  HIPCHK(hipMemsetAsync(h->d.ei, 0, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI, h->stream));
+  *out = h;
+  return PGD_OK;
+}
+
+int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lane* lanes, int n_lanes,
+                    const pgd_road* roads, int n_roads, const pgd_box* boxes, int n_boxes, const int32_t* cs, int n_cs,
+                    const int32_t* ci, int n_ci) {
+  if (!h || !maps || n_maps <= 0) return PGD_ERR_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  int rc;
+  if ((rc = upload(&h->maps, maps, n_maps, h->stream))) return rc;
+  if ((rc = upload(&h->lanes, lanes, n_lanes, h->stream))) return rc;
+  if ((rc = upload(&h->roads, roads, n_roads, h->stream))) return rc;
+  if ((rc = upload(&h->boxes, boxes, n_boxes, h->stream))) return rc;
+  if ((rc = upload(&h->cell_start, cs, n_cs, h->stream))) return rc;
+  if ((rc = upload(&h->cell_items, ci, n_ci, h->stream))) return rc;
+  h->d.maps = h->maps; h->d.lanes = h->lanes; h->d.roads = h->roads; h->d.boxes = h->boxes;
+  h->d.cell_start = h->cell_start; h->d.cell_items = h->cell_items;
+  h->have_maps = true;
+  return PGD_OK;
+}
+
+int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, const pgd_spawn* spawns) {
+  if (!h || !scen || n_scen <= 0 || !spawns) return PGD_ERR_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  int rc;
+  if ((rc = upload(&h->scen, scen, n_scen, h->stream))) return rc;
+  if ((rc = upload(&h->spawns, spawns, (size_t)n_scen * h->d.V, h->stream))) return rc;
+  h->d.scen = h->scen; h->d.spawns = h->spawns; h->d.n_scen = n_scen;
+  h->have_scen = true;
+  return PGD_OK;
+}
+
+static int launch_observe(pgd_handle h, float* d_obs) {
+  int blocks = h->d.N * h->d.A;
+  if (h->d.cfg.num_lasers > 0) hipLaunchKernelGGL(k_observe<256>, dim3(blocks), dim3(256), 0, h->stream, h->d, d_obs);
+  else hipLaunchKernelGGL(k_observe<64>, dim3(blocks), dim3(64), 0, h->stream, h->d, d_obs);
+  HIPCHK(hipGetLastError());
+  return PGD_OK;
+}
+
+int pgd_reset(pgd_handle h, const int32_t* env_ids, const int32_t* scen_ids, int n, float* d_obs) {
+  if (!h || !scen_ids || n <= 0 || n > h->d.N) return PGD_ERR_ARG;
+  if (!h->have_maps || !h->have_scen) return PGD_ERR_STATE;
+  HIPCHK(hipSetDevice(h->device));
+  for (int k = 0; k < n; ++k) {
+    if (scen_ids[k] < 0 || scen_ids[k] >= h->d.n_scen) return PGD_ERR_ARG;
+    if (env_ids && (env_ids[k] < 0 || env_ids[k] >= h->d.N)) return PGD_ERR_ARG;
+  }
+  int32_t* d_env = nullptr;
+  if (env_ids) {
+    HIPCHK(hipMemcpyAsync(h->d_ids, env_ids, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+    d_env = h->d_ids;
+  }
+  HIPCHK(hipMemcpyAsync(h->d_ids + h->d.N, scen_ids, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+  int blocks = (n + h->d.epw - 1) / h->d.epw;
+  hipLaunchKernelGGL(k_reset, dim3(blocks), dim3(WAVE), 0, h->stream, h->d, d_env, h->d_ids + h->d.N, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));  // host id buffers may be reused by the caller
+  if (d_obs) return launch_observe(h, d_obs);
+  return PGD_OK;
+}
+
+int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done, uint32_t* d_flags) {
+  if (!h || !d_actions || !d_reward || !d_done || !d_flags) return PGD_ERR_ARG;
+  if (!h->have_maps || !h->have_scen) return PGD_ERR_STATE;
+  const bool prof = h->prof_ev && h->prof_n < h->prof_cap;
+  hipEvent_t* pe = prof ? &(*h->prof_ev)[(size_t)h->prof_n * 3] : nullptr;
+  HIPCHK(hipEventRecord(prof ? pe[0] : h->ev0, h->stream));
+  int blocks = (h->d.N + h->d.epw - 1) / h->d.epw;
+  hipLaunchKernelGGL(k_step, dim3(blocks), dim3(WAVE), 0, h->stream, h->d, d_actions, d_reward, d_done, d_flags);
+  HIPCHK(hipGetLastError());
+  if (prof) HIPCHK(hipEventRecord(pe[1], h->stream));
+  if (d_obs) {
+    int rc = launch_observe(h, d_obs);
+    if (rc) return rc;
+  }
+  HIPCHK(hipEventRecord(prof ? pe[2] : h->ev1, h->stream));
+  if (prof) h->prof_n += 1;
+  else h->ev_valid = true;
+  return PGD_OK;
+}
+
+int pgd_observe(pgd_handle h, float* d_obs) {
+  if (!h || !d_obs) return PGD_ERR_ARG;
+  if (!h->have_maps || !h->have_scen) return PGD_ERR_STATE;
+  int blocks = (h->d.N + h->d.epw - 1) / h->d.epw;
+  hipLaunchKernelGGL(k_refresh, dim3(blocks), dim3(WAVE), 0, h->stream, h->d);
+  HIPCHK(hipGetLastError());
+  return launch_observe(h, d_obs);
+}
+
+int pgd_state_dims(pgd_handle h, int* nf, int* ni, int* nei) {
+  (void)h;
+  if (nf) *nf = PGD_NF;
+  if (ni) *ni = PGD_NI;
+  if (nei) *nei = PGD_NEI;
+  return PGD_OK;
+}
+int pgd_get_state(pgd_handle h, float* f, int32_t* i, int32_t* ei) {
+  if (!h || !f || !i || !ei) return PGD_ERR_ARG;
+  size_t nv = (size_t)h->d.NV;
+  HIPCHK(hipMemcpyAsync(f, h->d.f, sizeof(float) * nv * PGD_NF, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(i, h->d.i, sizeof(int32_t) * nv * PGD_NI, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(ei, h->d.ei, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return PGD_OK;
+}
+int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, const int32_t* ei) {
+  if (!h || !f || !i || !ei) return PGD_ERR_ARG;
+  size_t nv = (size_t)h->d.NV;
+  HIPCHK(hipMemcpyAsync(h->d.f, f, sizeof(float) * nv * PGD_NF, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d.i, i, sizeof(int32_t) * nv * PGD_NI, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d.ei, ei, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return PGD_OK;
+}
+
+int pgd_last_step_ms(pgd_handle h, float* ms) {
+  if (!h || !ms || !h->ev_valid) return PGD_ERR_ARG;
+  HIPCHK(hipEventSynchronize(h->ev1));
+  HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return PGD_OK;
+}
+
+int pgd_profile_begin(pgd_handle h, int capacity) {
+  if (!h || capacity <= 0) return PGD_ERR_ARG;
+  if (!h->prof_ev) h->prof_ev = new std::vector<hipEvent_t>();
+  while ((int)h->prof_ev->size() < capacity * 3) {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreate(&ev));
+    h->prof_ev->push_back(ev);
+  }
+  h->prof_cap = capacity;
+  h->prof_n = 0;
+  return PGD_OK;
+}
+
+int pgd_profile_end(pgd_handle h, float* k_step_ms, float* k_observe_ms, int* count) {
+  if (!h || !h->prof_ev || !k_step_ms || !k_observe_ms || !count) return PGD_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < h->prof_n; ++k) {
+    float t0 = 0.f, t1 = 0.f;
+    HIPCHK(hipEventElapsedTime(&t0, (*h->prof_ev)[(size_t)k * 3], (*h->prof_ev)[(size_t)k * 3 + 1]));
+    HIPCHK(hipEventElapsedTime(&t1, (*h->prof_ev)[(size_t)k * 3 + 1], (*h->prof_ev)[(size_t)k * 3 + 2]));
+    a += t0;
+    b += t1;
+  }
+  *count = h->prof_n;
+  *k_step_ms = h->prof_n ? (float)(a / h->prof_n) : 0.f;
+  *k_observe_ms = h->prof_n ? (float)(b / h->prof_n) : 0.f;
+  h->prof_cap = 0;
+  h->prof_n = 0;
+  return PGD_OK;
+}
+
+int pgd_sync(pgd_handle h) {
+  if (!h) return PGD_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return PGD_OK;
+}
+
+int pgd_destroy(pgd_handle h) {
+  if (!h) return PGD_ERR_ARG;
+  (void)hipStreamSynchronize(h->stream);
+  void* bufs[] = {h->d.f, h->d.i, h->d.ei, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
+                  h->cell_items, h->scen, h->spawns};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  (void)hipEventDestroy(h->ev0);
+  (void)hipEventDestroy(h->ev1);
+  if (h->prof_ev) {
+    for (hipEvent_t ev : *h->prof_ev) (void)hipEventDestroy(ev);
+    delete h->prof_ev;
+  }
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  free(h);
+  return PGD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+"""ctypes binding of libpgdrive_hip.so (C ABI in include/pgdrive_hip.h) + torch buffers for device memory.
+
+PyTorch is plumbing here (device allocation, streams, torch.distributed); all simulation runs in the HIP library.
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, constructing an Engine raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+from .build import LIB, build
+
+_LIBH = None
+
+_SIGS = {
+    "pgd_obs_dim": (C.c_int, [C.POINTER(_abi.PgdConfig)]),
+    "pgd_create": (C.c_int, [C.POINTER(_abi.PgdConfig), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pgd_upload_maps": (C.c_int, [C.c_void_p] + [C.c_void_p, C.c_int] * 6),
+    "pgd_upload_scenarios": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pgd_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pgd_step": (C.c_int, [C.c_void_p] * 6),
+    "pgd_state_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pgd_get_state": (C.c_int, [C.c_void_p] * 4),
+    "pgd_set_state": (C.c_int, [C.c_void_p] * 4),
+    "pgd_observe": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pgd_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "pgd_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "pgd_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "pgd_sync": (C.c_int, [C.c_void_p]),
+    "pgd_destroy": (C.c_int, [C.c_void_p]),
+    "pgd_version": (C.c_char_p, []),
+}
+EXPORTS = tuple(_SIGS.keys())
+
+
+def load_library(path=None):
+    """dlopen the HIP engine; fails loudly when it has not been built (no fallback path exists)."""
+    global _LIBH
+    if _LIBH is not None and path is None:
+        return _LIBH
+    # torch bundles its own HIP runtime: import it first so this library binds to the same libamdhip64 (two runtimes
+    # in one process do not see each other's devices / streams)
+    import torch  # noqa: F401
+    p = path or LIB
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "pgdrive_amd: %s is missing — build it with `python -m pgdrive_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the step engine." % p
+        )
+    L = C.CDLL(p)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _LIBH = L
+    return L
+
+
+def _np_p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class PgdError(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise PgdError("%s failed with status %d" % (what, rc))
+
+
+class Engine:
+    """One simulation handle on one GPU: N envs x (A agents + T traffic slots)."""
+    def __init__(self, cfg, bank, scen, device=0, stream=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("pgdrive_amd.Engine needs a GPU (MI355X); no CPU fallback exists")
+        self.torch = torch
+        self.L = load_library()
+        self.cfg = cfg
+        self.N, self.A, self.T = cfg.num_envs, cfg.num_agents, cfg.num_traffic
+        self.V = self.A + self.T
+        self.D = _abi.obs_dim(cfg)
+        assert scen.V == self.V, "scenario bank built for V=%d, engine has V=%d" % (scen.V, self.V)
+        self.device = torch.device("cuda", device)
+        self.bank, self.scen = bank, scen
+        h = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        # the engine enqueues on its own torch stream; step() orders it after / before the caller's current stream
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        sptr = C.c_void_p(self.stream.cuda_stream)
+        _chk(self.L.pgd_create(C.byref(cfg), device, sptr, C.byref(h)), "pgd_create")
+        self.h = h
+        _chk(
+            self.L.pgd_upload_maps(
+                self.h, _np_p(bank.maps), len(bank.maps), _np_p(bank.lanes), len(bank.lanes), _np_p(bank.roads),
+                len(bank.roads), _np_p(bank.boxes), len(bank.boxes), _np_p(bank.cell_start), len(bank.cell_start),
+                _np_p(bank.cell_items), len(bank.cell_items)
+            ), "pgd_upload_maps"
+        )
+        _chk(self.L.pgd_upload_scenarios(self.h, _np_p(scen.scenarios), len(scen.scenarios), _np_p(scen.spawns)),
+             "pgd_upload_scenarios")
+        dev = self.device
+        self.obs = torch.zeros((self.N, self.A, self.D), dtype=torch.float32, device=dev)
+        self.reward = torch.zeros((self.N, self.A), dtype=torch.float32, device=dev)
+        self.done = torch.zeros((self.N, self.A), dtype=torch.uint8, device=dev)
+        self.flags = torch.zeros((self.N, self.A), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+
+    # -- reference surface ------------------------------------------------------------------------------------------
+    def reset(self, scen_ids, env_ids=None):
+        scen_ids = np.ascontiguousarray(scen_ids, dtype=np.int32)
+        env_ids = None if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
+        self.torch.cuda.synchronize(self.device)
+        _chk(self.L.pgd_reset(self.h, _np_p(env_ids), _np_p(scen_ids), len(scen_ids), C.c_void_p(self.obs.data_ptr())),
+             "pgd_reset")
+        self.sync()
+        return self.obs
+
+    def step(self, actions, want_obs=True):
+        """actions: float32 cuda tensor [N, A, 2] (contiguous). Asynchronous on the engine stream."""
+        assert actions.is_cuda and actions.dtype == self.torch.float32 and actions.is_contiguous()
+        assert actions.numel() == self.N * self.A * 2
+        cur = self.torch.cuda.current_stream(self.device)
+        foreign = cur != self.stream
+        if foreign:
+            self.stream.wait_stream(cur)
+        _chk(
+            self.L.pgd_step(
+                self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()) if want_obs else None,
+                C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()), C.c_void_p(self.flags.data_ptr())
+            ), "pgd_step"
+        )
+        if foreign:
+            cur.wait_stream(self.stream)
+        return self.obs, self.reward, self.done, self.flags
+
+    def observe(self):
+        _chk(self.L.pgd_observe(self.h, C.c_void_p(self.obs.data_ptr())), "pgd_observe")
+        self.sync()
+        return self.obs
+
+    def sync(self):
+        _chk(self.L.pgd_sync(self.h), "pgd_sync")
+
+    def last_step_ms(self):
+        ms = C.c_float()
+        _chk(self.L.pgd_last_step_ms(self.h, C.byref(ms)), "pgd_last_step_ms")
+        return ms.value
+
+    def profile_begin(self, capacity):
+        _chk(self.L.pgd_profile_begin(self.h, int(capacity)), "pgd_profile_begin")
+
+    def profile_end(self):
+        a, b, n = C.c_float(), C.c_float(), C.c_int()
+        _chk(self.L.pgd_profile_end(self.h, C.byref(a), C.byref(b), C.byref(n)), "pgd_profile_end")
+        return dict(k_step_ms=a.value, k_observe_ms=b.value, count=n.value)
+
+    # -- checkpoint / resume ------------------------------------------------------------------------------------------
+    def get_state(self):
+        f = np.zeros((_abi.NF, self.N, self.V), dtype=np.float32)
+        i = np.zeros((_abi.NI, self.N, self.V), dtype=np.int32)
+        ei = np.zeros((_abi.NEI, self.N), dtype=np.int32)
+        _chk(self.L.pgd_get_state(self.h, _np_p(f), _np_p(i), _np_p(ei)), "pgd_get_state")
+        return f, i, ei
+
+    def set_state(self, f, i, ei):
+        f = np.ascontiguousarray(f, dtype=np.float32)
+        i = np.ascontiguousarray(i, dtype=np.int32)
+        ei = np.ascontiguousarray(ei, dtype=np.int32)
+        assert f.shape == (_abi.NF, self.N, self.V) and i.shape == (_abi.NI, self.N, self.V)
+        _chk(self.L.pgd_set_state(self.h, _np_p(f), _np_p(i), _np_p(ei)), "pgd_set_state")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pgd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
