@@ -1,0 +1,519 @@
+"""Generate golden vectors by importing the REFERENCE's own Python (runs only in the build container).
+
+    PYTHONHASHSEED=0 python oracle/gen_golden.py
+
+Writes tests/golden/routines_v0.npz (+ scenes_v0.json).  Every array is the output of a reference function
+(`/root/reference/pgdrive/...`, imported under the stubs of oracle/refstub.py) on seeded inputs; the CPU oracle
+(oracle/pgd_oracle.c) is pinned against them by tests/test_oracle_golden.py.  Nothing here is shipped or imported at
+test time; only the data files travel.
+"""
+import ast
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_export  # noqa: E402  (installs the stubs)
+
+from pgdrive.component.highway_vehicle.kinematics import Vehicle as KinVehicle  # noqa: E402
+from pgdrive.component.lane.circular_lane import CircularLane  # noqa: E402
+from pgdrive.component.vehicle.base_vehicle import BaseVehicle  # noqa: E402
+from pgdrive.component.vehicle_module.PID_controller import PIDController  # noqa: E402
+from pgdrive.component.vehicle_module.lidar import Lidar  # noqa: E402
+from pgdrive.component.vehicle_module.navigation import Navigation  # noqa: E402
+from pgdrive.envs.pgdrive_env import PGDriveEnv, PGDriveEnv_DEFAULT_CONFIG  # noqa: E402
+from pgdrive.obs.state_obs import StateObservation  # noqa: E402
+from pgdrive.policy.idm_policy import FrontBackObjects, IDMPolicy  # noqa: E402
+from pgdrive.utils import math_utils  # noqa: E402
+from pgdrive.utils.math_utils import Vector  # noqa: E402
+from pgdrive.utils.random_utils import get_np_random  # noqa: E402
+from pgdrive.utils.space import ParameterSpace, VehicleParameterSpace  # noqa: E402
+
+from pgdrive_amd import scenario as my_scenario  # noqa: E402  (only for the seed tables compared below)
+
+
+def _load_function(path, name):
+    """exec a single top-level function of a reference file (used for test helpers whose module imports panda3d)."""
+    src = open(path).read()
+    tree = ast.parse(src)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            mod = ast.Module(body=[node], type_ignores=[])
+            ns = {"math": math, "np": np}
+            exec(compile(mod, path, "exec"), ns)
+            return ns[name]
+    raise KeyError(name)
+
+
+line_intersect = _load_function("/root/reference/pgdrive/tests/test_component/test_detector_mask.py", "_line_intersect")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class FakeMap:
+    MAX_LANE_NUM = 3
+    MAX_LANE_WIDTH = 4.5
+    LANE_WIDTH = "lane_width"
+
+    def __init__(self, m):
+        self._config = {"lane_width": m["lane_width"]}
+        self.road_network = m["net"]
+        self.blocks = m["big"].blocks
+
+
+class FakeLidar:
+    """Only the pure-math methods of Lidar are used (bound below); get_surrounding_objects is supplied by the scene."""
+    perceive_distance = 50
+    num_lasers = 240
+    angle_delta = 360 / 240
+    available = True
+    get_surrounding_vehicles_info = Lidar.get_surrounding_vehicles_info
+    get_surrounding_vehicles = staticmethod(lambda detected: set(detected))
+    _get_lidar_mask = Lidar._get_lidar_mask
+    _mark_this_range = Lidar._mark_this_range
+
+    def __init__(self):
+        self.objs = set()
+
+    def get_surrounding_objects(self, vehicle):
+        """Stand-in for Bullet's contactTest of the r=50 m ghost cylinder (lidar.py:109-124): chassis boxes whose
+        distance to the vehicle centre is <= 50 m.  Scenes keep every vehicle >0.5 m away from that boundary."""
+        out = set()
+        for o in self.objs:
+            if o is vehicle:
+                continue
+            d = _point_box_dist(vehicle.position, o)
+            assert abs(d - 50.0) > 0.5, "scene too close to the broad-phase boundary"
+            if d <= 50.0:
+                out.add(o)
+        return out
+
+
+def _point_box_dist(p, o):
+    c, s_ = math.cos(o.heading_theta), math.sin(o.heading_theta)
+    dx, dy = p[0] - o.position[0], p[1] - o.position[1]
+    a = max(abs(dx * c + dy * s_) - o.LENGTH / 2, 0.0)
+    b = max(abs(-dx * s_ + dy * c) - o.WIDTH / 2, 0.0)
+    return math.hypot(a, b)
+
+
+class FakeDetector:
+    available = False
+
+
+class FakeVehicle:
+    """Duck-typed BaseVehicle: state attributes are plain data, every derived quantity is the reference's own method."""
+    MAX_STEERING = BaseVehicle.MAX_STEERING
+    MAX_LENGTH = BaseVehicle.MAX_LENGTH
+    MAX_WIDTH = BaseVehicle.MAX_WIDTH
+    heading_diff = BaseVehicle.heading_diff
+    projection = BaseVehicle.projection
+    _dist_to_route_left_right = BaseVehicle._dist_to_route_left_right
+    update_dist_to_left_right = BaseVehicle.update_dist_to_left_right
+    _out_of_route = BaseVehicle._out_of_route
+    arrive_destination = BaseVehicle.arrive_destination
+    current_road = BaseVehicle.current_road
+
+    def __init__(self, x, y, theta, speed_kmh, length, width, max_speed=80.0):
+        self.position = Vector((x, y))
+        self.heading_theta = theta
+        self.speed = speed_kmh
+        self.LENGTH, self.WIDTH = length, width
+        self.max_speed = max_speed
+        self.steering = 0.0
+        self.throttle_brake = 0.0
+        self.last_current_action = [(0.0, 0.0), (0.0, 0.0)]
+        self.last_heading_dir = self.heading
+        self.last_position = self.position
+        self.lane = None
+        self.lane_index = None
+        self.navigation = None
+        self.lidar = FakeLidar()
+        self.side_detector = FakeDetector()
+        self.lane_line_detector = FakeDetector()
+        self.engine = None
+        self.on_lane = True
+        self.crash_vehicle = self.crash_object = self.crash_building = self.crash_sidewalk = False
+        self.on_yellow_continuous_line = self.on_white_continuous_line = self.on_broken_line = False
+        self.out_of_route = False
+
+    @property
+    def heading(self):
+        return Vector((math.cos(self.heading_theta), math.sin(self.heading_theta)))
+
+    @property
+    def velocity(self):
+        return self.speed * np.asarray([math.cos(self.heading_theta), math.sin(self.heading_theta)])
+
+
+def make_navigation(fmap, checkpoints, idx):
+    nav = Navigation.__new__(Navigation)
+    nav.map = fmap
+    nav.checkpoints = list(checkpoints)
+    nav._target_checkpoints_index = list(idx)
+    nav._navi_info = np.zeros((10, ))
+    nav._show_navi_info = False
+    nav.FORCE_CALCULATE = False
+    g = fmap.road_network.graph
+    nav.current_ref_lanes = g[checkpoints[idx[0]]][checkpoints[idx[0] + 1]]
+    if idx[0] == idx[1]:
+        nav.next_ref_lanes = None
+        nav.next_road = None
+    else:
+        nav.next_ref_lanes = g[checkpoints[idx[1]]][checkpoints[idx[1] + 1]]
+        nav.next_road = True
+    from pgdrive.component.road.road import Road
+    nav.current_road = Road(checkpoints[idx[0]], checkpoints[idx[0] + 1])
+    nav.final_road = Road(checkpoints[-2], checkpoints[-1])
+    nav.final_lane = nav.final_road.get_lanes(fmap.road_network)[-1]
+    return nav
+
+
+def ref_navi_info(nav, v):
+    """Navigation.update_localization lines 167-197 with the Bullet localisation result given (lane already known)."""
+    ck = nav.checkpoints
+    i0, i1 = nav._target_checkpoints_index
+    g = nav.map.road_network.graph
+    lanes1 = g[ck[i0]][ck[i0 + 1]]
+    lanes2 = g[ck[i1]][ck[i1 + 1]]
+    nav.current_ref_lanes = lanes1
+    out = np.zeros(10)
+    out[:5], _, _ = nav._get_info_for_checkpoint(lanes_id=0, lanes=lanes1, ego_vehicle=v)
+    out[5:], _, _ = nav._get_info_for_checkpoint(lanes_id=1, lanes=lanes2, ego_vehicle=v)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def gen_scalar(rng, out):
+    x = np.concatenate([rng.uniform(-20, 20, 200), [math.pi, -math.pi, 3 * math.pi, 0.0, 2 * math.pi, -3 * math.pi]])
+    out["wrap_x"] = x
+    out["wrap_y"] = np.array([math_utils.wrap_to_pi(v) for v in x])
+    z = np.concatenate([rng.uniform(-0.05, 0.05, 50), [0.0, 0.01, -0.01, 1e-2 + 1e-9]])
+    out["nz_x"] = z
+    out["nz_y"] = np.array([math_utils.not_zero(v) for v in z])
+    out["nz0_y"] = np.array([math_utils.not_zero(v, 0) for v in z])
+    a = rng.uniform(-5, 5, (100, 2))
+    out["norm_x"] = a
+    out["norm_y"] = np.array([math_utils.norm(p[0], p[1]) for p in a])
+    out["clip_x"] = rng.uniform(-3, 3, 100)
+    out["clip_y"] = np.array([math_utils.clip(v, -1.0, 1.0) for v in out["clip_x"]])
+
+
+def gen_lanes(rng, m, out, tag):
+    lanes = ref_lanes_in_order(m)
+    pts, res = [], []
+    for lid, l in enumerate(lanes):
+        for _ in range(6):
+            lon = rng.uniform(-5, l.length + 5)
+            lat = rng.uniform(-6, 6)
+            p = l.position(lon, lat)
+            lc = l.local_coordinates(p)
+            q = (p[0] + rng.uniform(-8, 8), p[1] + rng.uniform(-8, 8))
+            lq = l.local_coordinates(q)
+            pts.append([lid, lon, lat, q[0], q[1]])
+            res.append([p[0], p[1], lc[0], lc[1], l.heading_at(lon), lq[0], lq[1], l.distance(q)])
+    out["lane_%s_in" % tag] = np.array(pts)
+    out["lane_%s_out" % tag] = np.array(res)
+
+
+def ref_lanes_in_order(m):
+    lanes = []
+    for _f, td in m["net"].graph.items():
+        for _t, ls in td.items():
+            lanes.extend(ls)
+    return lanes
+
+
+def gen_pid(rng, out):
+    for name, gains in (("h", (1.7, 0.01, 3.5)), ("l", (0.3, 0.002, 0.05))):
+        pid = PIDController(*gains)
+        errs = rng.normal(0, 0.3, 60)
+        out["pid_%s_err" % name] = errs
+        out["pid_%s_out" % name] = np.array([pid.get_result(e) for e in errs])
+
+
+def gen_idm_law(rng, out):
+    pol = IDMPolicy.__new__(IDMPolicy)
+    rows, res = [], []
+    for k in range(200):
+        ego = FakeVehicle(0, 0, rng.uniform(-3, 3), rng.uniform(0, 60), 4.5, 1.8)
+        front = FakeVehicle(10, 0, rng.uniform(-3, 3), rng.uniform(0, 60), 4.5, 1.8)
+        pol.control_object = ego
+        pol.target_speed = 30 if k % 3 else 5
+        has_front = k % 4 != 0
+        dist = rng.uniform(-0.02, 30) if k % 7 else 0.0
+        acc = pol.acceleration(front if has_front else None, dist)
+        rows.append([ego.speed, pol.target_speed, float(has_front), dist, ego.heading_theta, front.speed,
+                     front.heading_theta])
+        res.append(acc)
+    out["idm_in"] = np.array(rows)
+    out["idm_out"] = np.array(res)
+
+
+def gen_bicycle(rng, out):
+    class TM:
+        np_random = np.random.RandomState(0)
+    trajs, acts = [], []
+    for k in range(6):
+        v = KinVehicle.__new__(KinVehicle)
+        v._position = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5)])
+        v.heading = rng.uniform(-3, 3)
+        v.speed = rng.uniform(0, 20)
+        v.crashed = False
+        v.LENGTH = 2.46894
+        v.MAX_SPEED = 40
+        tr = [[v._position[0], v._position[1], v.heading, v.speed]]
+        ac = []
+        for t in range(50):
+            a = {"steering": rng.uniform(-0.6, 0.6), "acceleration": rng.uniform(-3, 3)}
+            ac.append([a["steering"], a["acceleration"]])
+            v.step(0.02, a)
+            tr.append([v._position[0], v._position[1], v.heading, v.speed])
+        trajs.append(tr)
+        acts.append(ac)
+    out["bike_traj"] = np.array(trajs)
+    out["bike_act"] = np.array(acts)
+
+
+def box_corners(cx, cy, th, hl, hw):
+    c, s = math.cos(th), math.sin(th)
+    pts = []
+    for a, b in ((hl, hw), (hl, -hw), (-hl, -hw), (-hl, hw)):
+        pts.append((cx + a * c - b * s, cy + a * s + b * c))
+    return pts
+
+
+def exact_lidar(px, py, theta, boxes, n=240, dist=50.0):
+    """Beam fan of DistanceDetector (distance_detector.py:42-44, cutils.pyx:51-54) cast against box edges with the
+    reference test's exact intersector (_line_intersect, test_detector_mask.py:132-154)."""
+    res = np.ones(n)
+    for i in range(n):
+        ang = i * 2 * np.pi / n + theta
+        best = 1e9
+        for (cx, cy, th, hl, hw) in boxes:
+            cs = box_corners(cx, cy, th, hl, hw)
+            for k in range(4):
+                r = line_intersect(ang, (px, py), cs[k], cs[(k + 1) % 4], maximum=1e9)
+                best = min(best, r)
+        res[i] = min(best / dist, 1.0)
+    return res
+
+
+def gen_scenes(rng, maps, out_json):
+    """Full scenes on real maps: ego + traffic vehicles on lanes; golden = reference navi info, state obs, neighbour
+    info, exact lidar, IDM front/back search + action, reward/done."""
+    scenes = []
+    for m in maps:
+        fmap = FakeMap(m)
+        lanes = ref_lanes_in_order(m)
+        lane_ids = {id(l): k for k, l in enumerate(lanes)}
+        nodes = m["nodes"]
+        net = m["net"]
+        # ego route exactly as scenario.build_scenario computes it (we store the node names so the test re-derives ids)
+        dest = my_scenario.choose_destination(m, m["seed"], nodes.index(">"))
+        ckpt_ids, _, _, _ = my_scenario.make_route(m, 0, dest)
+        ckpt = [nodes[i] for i in ckpt_ids]
+        for rep in range(6):
+            # pick ego somewhere along its route
+            k0 = int(rng.integers(0, len(ckpt) - 1))
+            idx = [k0, k0 + 1] if k0 + 1 < len(ckpt) - 1 else [k0, k0]
+            cur = net.graph[ckpt[k0]][ckpt[k0 + 1]]
+            el = cur[int(rng.integers(0, len(cur)))]
+            lon = rng.uniform(1.0, max(el.length - 1.0, 1.5))
+            lat = rng.uniform(-1.2, 1.2)
+            p = el.position(lon, lat)
+            ego = FakeVehicle(p[0], p[1], el.heading_at(lon) + rng.normal(0, 0.1), rng.uniform(0, 80), 4.51, 1.852)
+            ego.lane = el
+            ego.lane_index = el.index
+            ego.steering = rng.uniform(-1, 1)
+            ego.last_current_action = [(rng.uniform(-1, 1), rng.uniform(-1, 1)), (0.3, 0.2)]
+            lth = ego.heading_theta - rng.normal(0, 0.02)
+            ego.last_heading_dir = Vector((math.cos(lth), math.sin(lth)))
+            ego.last_position = Vector((p[0] - 0.8 * math.cos(lth), p[1] - 0.8 * math.sin(lth)))
+            ego.navigation = make_navigation(fmap, ckpt, idx)
+            # traffic around the ego: same road lanes, successor road lanes, elsewhere
+            cands = list(cur)
+            if idx[0] != idx[1]:
+                cands += list(net.graph[ckpt[idx[1]]][ckpt[idx[1] + 1]])
+            if k0 > 0:
+                cands += list(net.graph[ckpt[k0 - 1]][ckpt[k0]])
+            others = []
+            for j in range(int(rng.integers(3, 9))):
+                tl = cands[int(rng.integers(0, len(cands)))]
+                tlon = rng.uniform(0.5, max(tl.length - 0.5, 1.0))
+                tp = tl.position(tlon, rng.uniform(-0.5, 0.5))
+                L, W = [(4.25, 1.7), (4.4, 1.85), (4.5, 1.86), (5.8, 2.3)][int(rng.integers(0, 4))]
+                tv = FakeVehicle(tp[0], tp[1], tl.heading_at(tlon) + rng.normal(0, 0.05), rng.uniform(0, 50), L, W)
+                tv.lane, tv.lane_index = tl, tl.index
+                # keep vehicles from overlapping the ego so lidar start is outside every box
+                if math.hypot(tp[0] - p[0], tp[1] - p[1]) < 6.5:
+                    continue
+                # traffic vehicle navigation: route from its road start to the same destination
+                try:
+                    tck_ids, _, _, _ = my_scenario.make_route(m, lane_ids[id(tl)], dest)
+                    tck = [nodes[i] for i in tck_ids]
+                except Exception:
+                    continue
+                tidx = [0, 1] if len(tck) > 2 else [0, 0]
+                tv.navigation = make_navigation(fmap, tck, tidx)
+                others.append(tv)
+            allv = [ego] + others
+            for v in allv:
+                v.lidar.objs = set(allv)
+            # drop vehicles that sit on the 50 m broad-phase boundary of any other vehicle
+            def _ok(v):
+                return all(abs(_point_box_dist(w.position, v) - 50.0) > 0.6 and abs(_point_box_dist(v.position, w) - 50.0) > 0.6
+                           for w in allv if w is not v)
+            others = [v for v in others if _ok(v)]
+            allv = [ego] + others
+            for v in allv:
+                v.lidar.objs = set(allv)
+            # ---- reference outputs ----
+            ego.update_dist_to_left_right = types.MethodType(BaseVehicle.update_dist_to_left_right, ego)
+            ego.engine = None
+            left, right = BaseVehicle._dist_to_route_left_right(ego)
+            ego.dist_to_left_side, ego.dist_to_right_side = left, right
+            navi = ref_navi_info(ego.navigation, ego)
+            ego.navigation._navi_info = navi
+            sobs = StateObservation.__new__(StateObservation)
+            sobs.config = {"random_agent_model": False}
+            state = np.array(StateObservation.vehicle_state(sobs, ego), dtype=np.float64)
+            mask, objs = ego.lidar._get_lidar_mask(ego)
+            info = np.array(ego.lidar.get_surrounding_vehicles_info(ego, objs, 4), dtype=np.float64)
+            cloud = exact_lidar(p[0], p[1], ego.heading_theta,
+                                [(o.position[0], o.position[1], o.heading_theta, o.LENGTH / 2, o.WIDTH / 2) for o in others])
+            assert all(mask[i] or cloud[i] == 1.0 for i in range(240)), "reference mask must cover every hit beam"
+            # reward / done with the scene's flags (Bullet-derived flags are inputs here)
+            env = types.SimpleNamespace(vehicles={"a": ego}, config=dict(PGDriveEnv_DEFAULT_CONFIG))
+            env._is_out_of_road = types.MethodType(PGDriveEnv._is_out_of_road, env)
+            rewards = []
+            for combo in range(8):
+                ego.on_yellow_continuous_line = bool(combo & 1)
+                ego.crash_vehicle = bool(combo & 2)
+                ego.crash_sidewalk = bool(combo & 4)
+                r, _ = PGDriveEnv.reward_function(env, "a")
+                d, dinfo = PGDriveEnv.done_function(env, "a")
+                rewards.append([combo, r, float(d), float(dinfo["arrive_dest"]), float(dinfo["out_of_road"]),
+                                float(dinfo["crash_vehicle"])])
+            ego.on_yellow_continuous_line = ego.crash_vehicle = ego.crash_sidewalk = False
+            # IDM: front/back search + full act() for every traffic vehicle
+            idm = []
+            for tv in others:
+                pol = IDMPolicy.__new__(IDMPolicy)
+                pol.control_object = tv
+                pol.target_speed = 30
+                pol.routing_target_lane = None
+                pol.available_routing_index_range = None
+                pol.overtake_timer = int(rng.integers(0, 70))
+                pol.np_random = np.random.RandomState(0)
+                pol.heading_pid = PIDController(1.7, 0.01, 3.5)
+                pol.lateral_pid = PIDController(0.3, .002, 0.05)
+                timer0 = pol.overtake_timer
+                in_ref = tv.lane in tv.navigation.current_ref_lanes
+                fb = FrontBackObjects.get_find_front_back_objs(
+                    tv.lidar.get_surrounding_objects(tv), tv.lane, tv.position, 30,
+                    tv.navigation.current_ref_lanes if in_ref else None
+                )
+                fobj = [allv.index(o) if o is not None else -1 for o in fb.front_objs]
+                bobj = [allv.index(o) if o is not None else -1 for o in fb.back_objs]
+                fd = [d if d is not None else -1.0 for d in fb.front_dist]
+                bd = [d if d is not None else -1.0 for d in fb.back_dist]
+                import io
+                import contextlib
+                with contextlib.redirect_stdout(io.StringIO()) as buf:
+                    act = pol.act()
+                idm.append(dict(slot=allv.index(tv), in_ref=bool(in_ref), front=fobj, back=bobj, fd=fd, bd=bd,
+                                act=[float(act[0]), float(act[1])], timer0=timer0, timer1=int(pol.overtake_timer),
+                                target=float(pol.target_speed), fallback="IDM bug" in buf.getvalue(),
+                                rlane=lane_ids[id(pol.routing_target_lane)]))
+            scenes.append(dict(
+                seed=m["seed"],
+                vehicles=[dict(x=v.position[0], y=v.position[1], theta=v.heading_theta, speed_kmh=v.speed,
+                               length=v.LENGTH, width=v.WIDTH, lane=lane_ids[id(v.lane)],
+                               ckpt=[nodes.index(n) for n in v.navigation.checkpoints],
+                               idx=list(v.navigation._target_checkpoints_index)) for v in allv],
+                ego=dict(steering=ego.steering, act0=list(ego.last_current_action[0]),
+                         last_heading=[ego.last_heading_dir[0], ego.last_heading_dir[1]],
+                         last_position=[ego.last_position[0], ego.last_position[1]]),
+                left=left, right=right, navi=navi.tolist(), state=state.tolist(), others=info.tolist(),
+                cloud=cloud.tolist(), rewards=rewards, idm=idm,
+            ))
+    out_json["scenes"] = scenes
+
+
+def gen_checkpoints(rng, maps, out_json):
+    """Navigation._update_target_checkpoints (navigation.py:262-282) on real routes."""
+    rows = []
+    for m in maps:
+        fmap = FakeMap(m)
+        nodes = m["nodes"]
+        dest = my_scenario.choose_destination(m, m["seed"], nodes.index(">"))
+        ckpt_ids, _, _, _ = my_scenario.make_route(m, 0, dest)
+        ckpt = [nodes[i] for i in ckpt_ids]
+        lanes = ref_lanes_in_order(m)
+        for _ in range(60):
+            k0 = int(rng.integers(0, len(ckpt) - 1))
+            idx = [k0, k0 + 1] if k0 + 1 < len(ckpt) - 1 else [k0, k0]
+            nav = make_navigation(fmap, ckpt, idx)
+            lid = int(rng.integers(0, len(lanes)))
+            if lanes[lid].index is None:  # arcs shorter than one 4 m chord get no surface box, hence no index
+                continue
+            lon = float(rng.uniform(0, 10))
+            nav._update_target_checkpoints(lanes[lid].index, lon)
+            rows.append(dict(seed=m["seed"], ckpt=ckpt_ids, idx=idx, lane=lid, lon=lon,
+                             out=list(nav._target_checkpoints_index)))
+    out_json["checkpoints"] = rows
+
+
+def gen_seeding(out_json):
+    """Seeded host tables: get_np_random stream, vehicle parameter sampling (base_runnable.py:81-88, space.py:219-255)."""
+    rows = []
+    for seed in (0, 5, 1000, 1042, 65535, 123456789):
+        r = get_np_random(seed)
+        rows.append(dict(seed=seed, randint=[int(r.randint(0, 65536)) for _ in range(4)], uniform=float(r.uniform())))
+    out_json["np_random"] = rows
+    spaces = {"default": VehicleParameterSpace.DEFAULT_VEHICLE, "s": VehicleParameterSpace.S_VEHICLE,
+              "m": VehicleParameterSpace.M_VEHICLE, "l": VehicleParameterSpace.L_VEHICLE,
+              "xl": VehicleParameterSpace.XL_VEHICLE}
+    params = []
+    for vt, sp in spaces.items():
+        for seed in (3, 4242, 60000):
+            ps = ParameterSpace(sp)
+            rng = get_np_random(seed)
+            ps.seed(rng.randint(low=0, high=int(1e6)))
+            s = ps.sample()
+            params.append(dict(vtype=vt, seed=seed, max_engine_force=float(s["max_engine_force"][0]),
+                               max_brake_force=float(s["max_brake_force"][0]), max_steering=float(s["max_steering"][0]),
+                               wheel_friction=float(s["wheel_friction"][0]), max_speed=float(s["max_speed"][0])))
+    out_json["vehicle_params"] = params
+
+
+def main():
+    rng = np.random.default_rng(20240927)
+    out = {}
+    out_json = {}
+    gen_scalar(rng, out)
+    maps = [ref_export.generate(s, block_num=3) for s in (1000, 1003, 1017)]
+    for m in maps[:2]:
+        gen_lanes(rng, m, out, str(m["seed"]))
+    gen_pid(rng, out)
+    gen_idm_law(rng, out)
+    gen_bicycle(rng, out)
+    gen_scenes(rng, maps, out_json)
+    gen_checkpoints(rng, maps, out_json)
+    gen_seeding(out_json)
+    gd = os.path.join(ROOT, "tests", "golden")
+    np.savez_compressed(os.path.join(gd, "routines_v0.npz"), **out)
+    with open(os.path.join(gd, "scenes_v0.json"), "w") as f:
+        json.dump(out_json, f)
+    print("wrote goldens:", {k: v.shape for k, v in out.items()}, "scenes", len(out_json["scenes"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,9 @@ def lib():
         L.orc_state_check.restype = C.c_uint
         L.orc_idm_act.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_find_front_back.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_dist_left_right.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_reward_done.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_update_checkpoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
         L.orc_step_range.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.orc_rng.restype = C.c_uint32
         L.orc_rng.argtypes = [C.c_uint32] * 4

@@ -1,0 +1,19 @@
+"""pgdrive_amd — MI355X-native batched PGDrive step engine (HIP kernels behind a C ABI).
+
+Importing the package does not touch the GPU; `PGDriveVecEnv` / `PGDriveEnv` / `Engine` need libpgdrive_hip.so
+(built in-tree by `python -m pgdrive_amd.build`) and an MI355X — there is no CPU fallback.
+"""
+__version__ = "0.1.0"
+
+
+def __getattr__(name):
+    if name == "PGDriveVecEnv":
+        from .vec_env import PGDriveVecEnv
+        return PGDriveVecEnv
+    if name in ("PGDriveEnv", "make"):
+        from . import env
+        return getattr(env, name)
+    if name == "Engine":
+        from .engine import Engine
+        return Engine
+    raise AttributeError(name)

@@ -1,0 +1,89 @@
+"""Single-environment, numpy-in / numpy-out wrapper with the reference's exact gym.Env call shapes.
+
+    env = PGDriveEnv(dict(start_seed=1000, environment_num=100))
+    o = env.reset(); o, r, d, info = env.step([0.0, 1.0])
+
+Mirrors pgdrive/envs/pgdrive_env.py (PGDriveEnv) on top of the batched engine with N = 1 and auto_reset off, so the
+terminal observation is returned and the user calls reset() — exactly the reference's episode protocol
+(envs/base_env.py:184-193, 269-344).  Gym ids -> seed ranges follow pgdrive/register.py:5-38.
+"""
+import numpy as np
+
+from . import _abi
+from .vec_env import PGDriveVecEnv
+
+# register.py:5-38
+ENV_IDS = {
+    "PGDrive-test-v0": dict(start_seed=0, environment_num=200),
+    "PGDrive-validation-v0": dict(start_seed=200, environment_num=800),
+    "PGDrive-v0": dict(start_seed=1000, environment_num=100),
+    "PGDrive-10envs-v0": dict(start_seed=1000, environment_num=10),
+    "PGDrive-1000envs-v0": dict(start_seed=1000, environment_num=1000),
+    "PGDrive-training0-v0": dict(start_seed=3000, environment_num=1000),
+    "PGDrive-training1-v0": dict(start_seed=5000, environment_num=1000),
+    "PGDrive-training2-v0": dict(start_seed=7000, environment_num=1000),
+}
+
+
+class PGDriveEnv:
+    metadata = {"render.modes": []}
+
+    def __init__(self, config=None):
+        cfg = dict(config or {})
+        cfg["num_envs"] = 1
+        cfg.setdefault("auto_reset", False)
+        cfg.setdefault("resample_scenario", False)
+        self.vec = PGDriveVecEnv(cfg)
+        self.config = self.vec.config
+        self.observation_space = self.vec.single_observation_space
+        self.action_space = self.vec.single_action_space
+        self.episode_steps = 0
+        self.episode_reward = 0.0
+        self._done = False
+        import torch
+        self._torch = torch
+
+    def reset(self, episode_data=None, force_seed=None):
+        assert episode_data is None, "episode replay is not built"
+        obs = self.vec.reset(force_seed=force_seed)
+        self.episode_steps = 0
+        self.episode_reward = 0.0
+        self._done = False
+        return obs[0].cpu().numpy()
+
+    def step(self, action):
+        a = self._torch.as_tensor(np.asarray(action, dtype=np.float32).reshape(1, 2), device=self.vec.engine.device)
+        obs, rew, done, flags = self.vec.step(a)
+        self.vec.engine.sync()
+        self.episode_steps += 1
+        r = float(rew[0].item())
+        d = bool(done[0].item()) or self._done  # sticky done (base_env.py:318-319)
+        self._done = d
+        self.episode_reward += r
+        fl = int(flags[0].item()) & 0xFFFFFFFF
+        f, i, _ = self.vec.engine.get_state()
+        info = {k: bool(v) for k, v in self.vec.info_from_flags(np.array([fl])).items()}
+        info = {k: bool(np.asarray(v).reshape(-1)[0]) for k, v in self.vec.info_from_flags(np.array([fl])).items()}
+        cost = 0.0  # cost_function (pgdrive_env.py:197-207)
+        if info["out_of_road"]:
+            cost = 1.0
+        elif info["crash_vehicle"]:
+            cost = 1.0
+        info.update(
+            cost=cost, velocity=float(f[_abi.SF["SPEED"], 0, 0] * 3.6), steering=float(f[_abi.SF["STEER"], 0, 0]),
+            acceleration=float(f[_abi.SF["THROTTLE"], 0, 0]), step_reward=r, episode_reward=self.episode_reward,
+            episode_length=self.episode_steps, episode_energy=float(f[_abi.SF["ENERGY"], 0, 0]),
+        )
+        return obs[0].cpu().numpy(), r, d, info
+
+    def seed(self, seed=None):
+        self.vec.seed(seed)
+
+    def close(self):
+        self.vec.close()
+
+
+def make(env_id, **kw):
+    cfg = dict(ENV_IDS[env_id])
+    cfg.update(kw)
+    return PGDriveEnv(cfg)

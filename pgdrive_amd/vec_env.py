@@ -1,0 +1,149 @@
+"""Batched gym-style surface over the HIP step engine.
+
+`PGDriveVecEnv` mirrors the reference's env surface (pgdrive/envs/base_env.py:184-193 step, :269-290 reset,
+:403-425 spaces; defaults pgdrive/envs/pgdrive_env.py:22-109) for N environments at once: observations keep the
+reference layout (obs/state_obs.py), config keys keep the reference names, unknown keys raise
+KeyError like Config.update(allow_add_new_key=False) (utils/config.py:115-125).
+"""
+import copy
+
+import numpy as np
+
+from . import _abi, bank, mapdata, scenario
+from .spaces import Box
+
+# Reference defaults this build honours (pgdrive_env.py:22-109, base_env.py:19-90)
+DEFAULT_CONFIG = dict(
+    num_envs=1,
+    start_seed=1000,  # PGDrive-v0 (register.py:14-17)
+    environment_num=100,
+    map=3,
+    map_config=dict(lane_width=3.5, lane_num=3, exit_length=50),
+    traffic_density=0.1,
+    traffic_mode="trigger",
+    max_traffic_vehicles=16,  # slot cap per env (the reference has no cap)
+    decision_repeat=5,
+    physics_world_step_size=2e-2,
+    horizon=None,
+    vehicle_config=dict(
+        lidar=dict(num_lasers=240, distance=50, num_others=4, gaussian_noise=0.0, dropout_prob=0.0),
+        side_detector=dict(num_lasers=0, distance=50, gaussian_noise=0.0, dropout_prob=0.0),
+        lane_line_detector=dict(num_lasers=0, distance=20, gaussian_noise=0.0, dropout_prob=0.0),
+        spawn_longitude=5.0,
+        spawn_lateral=0.0,
+        vehicle_model="default",
+    ),
+    success_reward=10.0,
+    out_of_road_penalty=5.0,
+    crash_vehicle_penalty=5.0,
+    crash_object_penalty=5.0,
+    driving_reward=1.0,
+    speed_reward=0.1,
+    use_lateral=False,
+    out_of_route_done=False,
+    auto_reset=True,
+    resample_scenario=True,  # a new seed per episode like _reset_global_seed (base_env.py:451-458)
+    device=0,
+    seed=0,
+    map_bank=None,  # path of a description bank; None -> shipped PGDrive-v0 bank
+)
+
+
+def merge_config(default, user, path=""):
+    """Nested update that rejects unknown keys (utils/config.py:115-125)."""
+    out = copy.deepcopy(default)
+    for k, v in (user or {}).items():
+        if k not in out:
+            raise KeyError("'{}' does not exist in existing config. Please use config.update(...) with known keys "
+                           "only: {}".format(path + k, sorted(out.keys())))
+        if isinstance(out[k], dict) and isinstance(v, dict):
+            out[k] = merge_config(out[k], v, path + k + ".")
+        else:
+            out[k] = v
+    return out
+
+
+class PGDriveVecEnv:
+    """N independent PGDrive environments stepped by one HIP launch pair per step."""
+    def __init__(self, config=None):
+        self.config = merge_config(DEFAULT_CONFIG, config)
+        c = self.config
+        vc = c["vehicle_config"]
+        if vc["side_detector"]["num_lasers"] or vc["lane_line_detector"]["num_lasers"]:
+            raise NotImplementedError("side / lane-line detectors are not built yet (0 lasers is the reference default)")
+        if c["traffic_mode"] != "trigger":
+            raise NotImplementedError("only TrafficMode.Trigger (the reference default) is built")
+        if c["map"] != 3 or c["map_config"] != DEFAULT_CONFIG["map_config"]:
+            if c["map_bank"] is None:
+                raise NotImplementedError("only the shipped map bank (map=3, lane_num=3, lane_width=3.5) is available; "
+                                          "pass map_bank=<path> for other maps")
+        descs = bank.load_descriptions(c["map_bank"] or bank.DEFAULT_BANK)
+        by_seed = {d["seed"]: d for d in descs}
+        seeds = list(range(c["start_seed"], c["start_seed"] + c["environment_num"]))
+        missing = [s for s in seeds if s not in by_seed]
+        if missing:
+            raise KeyError("map seeds %s..%s are not in the map bank" % (missing[0], missing[-1]))
+        self.seeds = seeds
+        sel = [by_seed[s] for s in seeds]
+        self.num_envs = int(c["num_envs"])
+        T = int(c["max_traffic_vehicles"]) if abs(c["traffic_density"]) >= 1e-2 else 0
+        self.map_bank = mapdata.MapBank(sel)
+        self.scen_bank = scenario.ScenarioBank(
+            sel, seeds, num_agents=1, num_traffic=T, density=c["traffic_density"],
+            spawn_longitude=vc["spawn_longitude"], spawn_lateral=vc["spawn_lateral"], vehicle_model=vc["vehicle_model"]
+        )
+        lid = vc["lidar"]
+        nl = lid["num_lasers"] if lid["distance"] > 0 else 0
+        self.cfg = _abi.make_config(
+            self.num_envs, num_agents=1, num_traffic=T, num_lasers=nl, num_others=lid["num_others"],
+            lidar_dist=lid["distance"], dt=c["physics_world_step_size"], decision_repeat=c["decision_repeat"],
+            auto_reset=c["auto_reset"], resample_scenario=c["resample_scenario"], horizon=c["horizon"] or 0,
+            seed=c["seed"], success_reward=c["success_reward"], out_of_road_penalty=c["out_of_road_penalty"],
+            crash_vehicle_penalty=c["crash_vehicle_penalty"], crash_object_penalty=c["crash_object_penalty"],
+            driving_reward=c["driving_reward"], speed_reward=c["speed_reward"], use_lateral=c["use_lateral"],
+            out_of_route_done=c["out_of_route_done"]
+        )
+        from .engine import Engine
+        self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])
+        self.obs_dim = self.engine.D
+        # spaces (base_vehicle.py:720-727, state_obs.py:124-130)
+        self.single_observation_space = Box(-0.0, 1.0, (self.obs_dim, ), np.float32)
+        self.single_action_space = Box(-1.0, 1.0, (2, ), np.float32)
+        self.observation_space = self.single_observation_space
+        self.action_space = self.single_action_space
+        self._rng = np.random.RandomState(c["seed"])
+
+    def reset(self, force_seed=None):
+        """Reset every env; `force_seed` (int or array) pins the map seed(s), else seeds are drawn uniformly from
+        [start_seed, start_seed + environment_num) (base_env.py:451-458).  Returns a cuda float32 tensor [N, D]."""
+        if force_seed is None:
+            ids = self._rng.randint(0, len(self.seeds), size=self.num_envs)
+        else:
+            fs = np.broadcast_to(np.asarray(force_seed), (self.num_envs, ))
+            ids = np.array([self.seeds.index(int(s)) for s in fs])
+        obs = self.engine.reset(ids.astype(np.int32))
+        return obs.view(self.num_envs, self.obs_dim)
+
+    def step(self, actions):
+        """actions: cuda float32 tensor [N, 2] -> (obs [N,D], reward [N], done [N] uint8, flags [N] int32) on the GPU."""
+        obs, rew, done, flags = self.engine.step(actions.contiguous().view(self.num_envs, 1, 2))
+        return obs.view(self.num_envs, self.obs_dim), rew.view(-1), done.view(-1), flags.view(-1)
+
+    def info_from_flags(self, flags):
+        """Host-side decode of the flag bit-field into the reference's info keys (pgdrive_env.py:165-194)."""
+        fl = np.asarray(flags.cpu() if hasattr(flags, "cpu") else flags).astype(np.uint32)
+        return dict(
+            arrive_dest=(fl & _abi.F_ARRIVE) != 0, out_of_road=(fl & _abi.F_OUT_OF_ROAD) != 0,
+            crash_vehicle=(fl & _abi.F_CRASH_VEHICLE) != 0, crash_object=(fl & _abi.F_CRASH_OBJECT) != 0,
+            crash_building=(fl & _abi.F_CRASH_BUILDING) != 0, max_step=(fl & _abi.F_MAX_STEP) != 0,
+            crash=(fl & (_abi.F_CRASH_VEHICLE | _abi.F_CRASH_OBJECT | _abi.F_CRASH_BUILDING)) != 0,
+        )
+
+    def seed(self, seed=None):
+        if seed is not None:
+            self._rng = np.random.RandomState(seed)
+
+    def close(self):
+        if getattr(self, "engine", None) is not None:
+            self.engine.close()
+            self.engine = None

@@ -1,0 +1,54 @@
+"""Host-side mirror of the reference's env surface that does not need a GPU: config merging, spaces, gym ids, sharding."""
+import numpy as np
+import pytest
+
+from pgdrive_amd import dist as pdist
+from pgdrive_amd import env as penv
+from pgdrive_amd import spaces, vec_env
+
+
+def test_unknown_config_key_raises_like_reference():
+    """Config.update(allow_add_new_key=False) raises KeyError on unknown keys (utils/config.py:115-125)."""
+    with pytest.raises(KeyError):
+        vec_env.merge_config(vec_env.DEFAULT_CONFIG, dict(not_a_key=1))
+    with pytest.raises(KeyError):
+        vec_env.merge_config(vec_env.DEFAULT_CONFIG, dict(vehicle_config=dict(lidar=dict(beams=3))))
+    c = vec_env.merge_config(vec_env.DEFAULT_CONFIG, dict(vehicle_config=dict(lidar=dict(num_lasers=72))))
+    assert c["vehicle_config"]["lidar"]["num_lasers"] == 72 and c["vehicle_config"]["lidar"]["distance"] == 50
+    assert vec_env.DEFAULT_CONFIG["vehicle_config"]["lidar"]["num_lasers"] == 240  # defaults untouched
+
+
+def test_default_config_mirrors_reference_values():
+    c = vec_env.DEFAULT_CONFIG
+    assert c["decision_repeat"] == 5 and c["physics_world_step_size"] == 2e-2  # base_env.py:33,70
+    assert c["traffic_density"] == 0.1 and c["traffic_mode"] == "trigger"  # pgdrive_env.py:47-48
+    assert (c["success_reward"], c["out_of_road_penalty"], c["crash_vehicle_penalty"], c["driving_reward"],
+            c["speed_reward"]) == (10.0, 5.0, 5.0, 1.0, 0.1)  # pgdrive_env.py:91-101
+    assert c["vehicle_config"]["lidar"] == dict(num_lasers=240, distance=50, num_others=4, gaussian_noise=0.0,
+                                                dropout_prob=0.0)
+
+
+def test_spaces():
+    b = spaces.Box(-1.0, 1.0, (2, ), np.float32)
+    assert b.contains(np.array([0.3, -1.0], dtype=np.float32)) and not b.contains(np.array([1.5, 0.0]))
+    assert b.sample().shape == (2, ) and b.contains(b.sample())
+    o = spaces.Box(-0.0, 1.0, (274, ), np.float32)
+    assert o.contains(np.zeros(274, dtype=np.float32)) and not o.contains(np.zeros(273))
+
+
+def test_gym_id_table():
+    """register.py:5-38"""
+    assert penv.ENV_IDS["PGDrive-v0"] == dict(start_seed=1000, environment_num=100)
+    assert penv.ENV_IDS["PGDrive-test-v0"] == dict(start_seed=0, environment_num=200)
+    assert len(penv.ENV_IDS) == 8
+
+
+def test_shard_ranges_partition_envs():
+    for n, w in ((32768, 8), (4096, 1), (10, 4), (7, 8)):
+        got = []
+        for r in range(w):
+            lo, hi = pdist.shard_range(n, r, w)
+            got.extend(range(lo, hi))
+        assert got == list(range(n))
+    ids = np.concatenate([pdist.scenario_ids_for(*pdist.shard_range(1000, r, 4), 100) for r in range(4)])
+    assert (ids == np.arange(1000) % 100).all()  # env -> scenario mapping does not depend on the world size

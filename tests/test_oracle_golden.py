@@ -1,0 +1,258 @@
+"""Pins the CPU oracle (oracle/pgd_oracle.c) against golden vectors produced by the reference's own Python
+(oracle/gen_golden.py -> tests/golden/routines_v0.npz, scenes_v0.json).  fp64 oracle vs fp64 reference: 1e-9 abs
+(SURVEY.md §8c); lane tables travel through float32, so geometry-dependent values are compared at 1e-4 m / 2e-6."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pgdrive_amd import _abi, mapdata, scenario
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from oracle import orc
+    orc.build()
+    return orc.lib()
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "routines_v0.npz"))
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    with open(os.path.join(GOLD, "scenes_v0.json")) as f:
+        return json.load(f)
+
+
+def test_scalar_helpers(L, gold):
+    """math_utils.wrap_to_pi / not_zero / norm / clip (utils/math_utils.py:32-94, cutils.pyx:147-154)."""
+    y = np.array([L.orc_wrap_to_pi(float(v)) for v in gold["wrap_x"]])
+    assert np.abs(y - gold["wrap_y"]).max() < 1e-12
+    y = np.array([L.orc_not_zero(float(v), 1e-2) for v in gold["nz_x"]])
+    assert (y == gold["nz_y"]).all()
+    y = np.array([L.orc_not_zero(float(v), 0.0) for v in gold["nz_x"]])
+    assert (y == gold["nz0_y"]).all()
+    y = np.array([L.orc_norm(float(a), float(b)) for a, b in gold["norm_x"]])
+    assert np.abs(y - gold["norm_y"]).max() < 1e-12
+    y = np.array([L.orc_clip(float(v), -1.0, 1.0) for v in gold["clip_x"]])
+    assert (y == gold["clip_y"]).all()
+
+
+@pytest.mark.parametrize("seed", [1000, 1003])
+def test_lane_closed_forms(L, gold, descs, seed):
+    """StraightLane / CircularLane position, local_coordinates, heading_at, distance on every lane of two maps."""
+    d = [m for m in descs if m["seed"] == seed][0]
+    lanes = mapdata.pack_lanes(d, mapdata.build_successors(d))
+    gin, gout = gold["lane_%d_in" % seed], gold["lane_%d_out" % seed]
+    buf = (C.c_double * 2)()
+    worst = 0.0
+    for row, ref in zip(gin, gout):
+        lp = lanes[int(row[0]):int(row[0]) + 1].ctypes.data_as(C.c_void_p)
+        L.orc_lane_position(lp, float(row[1]), float(row[2]), buf)
+        worst = max(worst, abs(buf[0] - ref[0]), abs(buf[1] - ref[1]))
+        L.orc_lane_local(lp, float(ref[0]), float(ref[1]), buf)
+        worst = max(worst, abs(buf[0] - ref[2]), abs(buf[1] - ref[3]))
+        h = L.orc_lane_heading(lp, float(row[1]))
+        worst = max(worst, abs(h - ref[4]))
+        L.orc_lane_local(lp, float(row[3]), float(row[4]), buf)
+        worst = max(worst, abs(buf[0] - ref[5]), abs(buf[1] - ref[6]))
+        worst = max(worst, abs(L.orc_lane_distance(lp, float(row[3]), float(row[4])) - ref[7]))
+    # lane records are float32: 500 m * 2^-24 = 3e-5 m
+    assert worst < 1e-4, worst
+
+
+def test_pid(L, gold):
+    """PIDController.get_result (vehicle_module/PID_controller.py:10-17) with the IDM gains (idm_policy.py:187-188)."""
+    for name, gains in (("h", (1.7, 0.01, 3.5)), ("l", (0.3, 0.002, 0.05))):
+        st = (C.c_double * 2)(0.0, 0.0)
+        y = np.array([L.orc_pid(st, gains[0], gains[1], gains[2], float(e)) for e in gold["pid_%s_err" % name]])
+        assert np.abs(y - gold["pid_%s_out" % name]).max() < 1e-12
+
+
+def test_idm_law(L, gold):
+    """IDMPolicy.acceleration / desired_gap (policy/idm_policy.py:254-271)."""
+    y = np.array([L.orc_idm_acc(r[0], r[1], int(r[2]), r[3], r[4], r[5], r[6]) for r in gold["idm_in"]])
+    ref = gold["idm_out"]
+    assert np.abs(y - ref).max() / max(1.0, np.abs(ref).max()) < 1e-12
+    assert np.allclose(y, ref, rtol=1e-10, atol=1e-9)
+
+
+def test_bicycle(L, gold):
+    """highway_vehicle.kinematics.Vehicle.step (kinematics.py:134-156): the dynamics oracle."""
+    for traj, acts in zip(gold["bike_traj"], gold["bike_act"]):
+        s = (C.c_double * 4)(*traj[0])
+        for t, a in enumerate(acts):
+            L.orc_bicycle(s, float(a[0]), float(a[1]), 2.46894, 0.02)
+            assert np.abs(np.array(s[:]) - traj[t + 1]).max() < 1e-9
+
+
+def test_ray_box_known_answers(L):
+    """SURVEY §8c known answers: empty -> 1.0; a box straight ahead at distance d -> (d - L_other/2)/50 on beam 0."""
+    f = L.orc_ray_box(20.0, 0.0, 0.0, 2.25, 0.9, 0.0, 0.0, 50.0, 0.0)
+    assert abs(f - (20.0 - 2.25) / 50.0) < 1e-12
+    assert L.orc_ray_box(20.0, 0.0, 0.0, 2.25, 0.9, 0.0, 0.0, 0.0, 50.0) == 1.0  # perpendicular beam misses
+    assert L.orc_ray_box(20.0, 0.0, 0.0, 2.25, 0.9, 0.0, 0.0, -50.0, 0.0) == 1.0  # behind
+    assert L.orc_ray_box(100.0, 0.0, 0.0, 2.25, 0.9, 0.0, 0.0, 50.0, 0.0) == 1.0  # out of range
+    assert L.orc_ray_box(1.0, 0.0, 0.3, 2.25, 0.9, 0.0, 0.0, 50.0, 0.0) == 0.0  # origin inside the box
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# full scenes
+# ----------------------------------------------------------------------------------------------------------------------
+def _scene_engine(descs, sc):
+    """Oracle holding exactly the scene's vehicles (slot 0 = ego) with their routes; state overwritten from the scene."""
+    from oracle import orc
+    d = [m for m in descs if m["seed"] == sc["seed"]][0]
+    mb = mapdata.MapBank([d])
+    V = len(sc["vehicles"])
+    spawns = np.zeros(V, dtype=scenario.SPAWN_DT)
+    rl = mapdata.road_lookup(d)
+    for k, v in enumerate(sc["vehicles"]):
+        r = spawns[k]
+        r["x"], r["y"], r["heading"] = v["x"], v["y"], v["theta"]
+        r["length"], r["width"] = v["length"], v["width"]
+        r["wheelbase"], r["mass"], r["max_engine_force"], r["max_brake_force"] = 2.46894, 1100, 800, 130
+        r["friction"], r["max_steer"], r["max_speed"] = 0.9, np.deg2rad(40), 80
+        r["lane"], r["group"], r["n_ckpt"] = v["lane"], -1, len(v["ckpt"])
+        r["ckpt"][:] = -1
+        r["ckpt_road"][:] = -1
+        r["ckpt"][:len(v["ckpt"])] = v["ckpt"]
+        roads = [rl[(v["ckpt"][j], v["ckpt"][j + 1])] for j in range(len(v["ckpt"]) - 1)]
+        r["ckpt_road"][:len(roads)] = roads
+        fr = d["roads"][roads[-1]]
+        r["dest_lane"] = fr["first_lane"] + fr["n_lanes"] - 1
+    sb = scenario.ScenarioBank.__new__(scenario.ScenarioBank)
+    scen = np.zeros(1, dtype=scenario.SCEN_DT)
+    scen["trigger_road"][:] = -1
+    sb.scenarios, sb.spawns, sb.V, sb.info = scen, spawns, V, []
+    cfg = _abi.make_config(1, num_agents=1, num_traffic=V - 1)
+    o = orc.Oracle(cfg, mb, sb)
+    o.reset(np.zeros(1, dtype=np.int32))
+    f, i, ei = o.get_state()
+    SF, SI = _abi.SF, _abi.SI
+    for k, v in enumerate(sc["vehicles"]):
+        f[SF["X"], 0, k], f[SF["Y"], 0, k], f[SF["THETA"], 0, k] = v["x"], v["y"], v["theta"]
+        f[SF["SPEED"], 0, k] = v["speed_kmh"] / 3.6
+        i[SI["STATUS"], 0, k] = _abi.ST_ACTIVE
+        i[SI["LANE"], 0, k] = v["lane"]
+        i[SI["CK0"], 0, k], i[SI["CK1"], 0, k] = v["idx"]
+        i[SI["RLANE"], 0, k] = -1
+        f[SF["TARGET_SPEED"], 0, k] = 30.0
+    e = sc["ego"]
+    f[SF["STEER"], 0, 0] = e["steering"]
+    f[SF["ACT0S"], 0, 0], f[SF["ACT0T"], 0, 0] = e["act0"]
+    f[SF["LASTHX"], 0, 0], f[SF["LASTHY"], 0, 0] = e["last_heading"]
+    f[SF["LASTX"], 0, 0], f[SF["LASTY"], 0, 0] = e["last_position"]
+    return o, f, i, ei, d
+
+
+def test_scene_observation(L, descs, scenes):
+    """navi info (navigation.py:213-260), vehicle_state (state_obs.py:58-106), neighbour info (lidar.py:55-77) and the
+    240-beam fan cast with the reference test's exact intersector (test_detector_mask.py:132-154)."""
+    SF = _abi.SF
+    worst = dict(lr=0.0, state=0.0, navi=0.0, others=0.0, lidar=0.0)
+    flips = 0
+    for sc in scenes["scenes"]:
+        o, f, i, ei, d = _scene_engine(descs, sc)
+        o.set_state(f, i, ei)
+        lr = (C.c_double * 2)()
+        L.orc_dist_left_right(o.h, 0, 0, lr)
+        worst["lr"] = max(worst["lr"], abs(lr[0] - sc["left"]), abs(lr[1] - sc["right"]))
+        f[SF["DIST_LEFT"], 0, 0], f[SF["DIST_RIGHT"], 0, 0] = lr[0], lr[1]
+        o.set_state(f, i, ei)
+        obs = o.observe()[0, 0]
+        worst["state"] = max(worst["state"], np.abs(obs[:8] - np.array(sc["state"])).max())
+        worst["navi"] = max(worst["navi"], np.abs(obs[8:18] - np.array(sc["navi"])).max())
+        worst["others"] = max(worst["others"], np.abs(obs[18:34] - np.array(sc["others"])).max())
+        dl = np.abs(obs[34:] - np.array(sc["cloud"]))
+        flips += int((dl > 1e-6).sum())  # a beam through a box corner may differ (the reference helper pads edges by 1e-5)
+        worst["lidar"] = max(worst["lidar"], float(dl[dl <= 1e-6].max()))
+        o.close()
+    print(worst, "corner beams", flips)
+    assert worst["lr"] < 1e-4 and worst["state"] < 2e-6 and worst["navi"] < 2e-6 and worst["others"] < 2e-6
+    assert worst["lidar"] < 1e-6 and flips <= 3
+
+
+def test_scene_reward_done(L, descs, scenes):
+    """PGDriveEnv.reward_function / done_function (envs/pgdrive_env.py:162-258) over 8 flag combinations per scene."""
+    SI = _abi.SI
+    bits = {1: _abi.F_ON_YELLOW, 2: _abi.F_CRASH_VEHICLE, 4: _abi.F_CRASH_SIDEWALK}
+    worst = 0.0
+    for sc in scenes["scenes"]:
+        o, f, i, ei, d = _scene_engine(descs, sc)
+        for combo, r_ref, d_ref, arrive, oor, crash in sc["rewards"]:
+            fl = 0
+            for b, m in bits.items():
+                if int(combo) & b:
+                    fl |= m
+            i[SI["VFLAGS"], 0, 0] = fl
+            o.set_state(f, i, ei)
+            out = (C.c_double * 3)()
+            L.orc_reward_done(o.h, 0, 0, out)
+            worst = max(worst, abs(out[0] - r_ref))
+            assert int(out[1]) == int(d_ref)
+            fo = int(out[2])
+            assert bool(fo & _abi.F_ARRIVE) == bool(arrive)
+            assert bool(fo & _abi.F_OUT_OF_ROAD) == bool(oor)
+            assert bool(fo & _abi.F_CRASH_VEHICLE) == bool(crash)
+        o.close()
+    assert worst < 1e-4, worst
+
+
+def test_scene_idm(L, descs, scenes):
+    """FrontBackObjects.get_find_front_back_objs (idm_policy.py:82-133) and the full IDMPolicy.act (idm_policy.py:190-353:
+    move_to_next_road, lane_change_policy, steering PIDs, IDM law) for every traffic vehicle of every scene."""
+    SI, SF = _abi.SI, _abi.SF
+    n_checked = 0
+    worst = 0.0
+    for sc in scenes["scenes"]:
+        for rec in sc["idm"]:
+            o, f, i, ei, d = _scene_engine(descs, sc)
+            s = rec["slot"]
+            i[SI["TIMER"], 0, s] = rec["timer0"]
+            o.set_state(f, i, ei)
+            objs = (C.c_int * 6)()
+            dist = (C.c_double * 6)()
+            L.orc_find_front_back(o.h, 0, s, sc["vehicles"][s]["lane"], 1 if rec["in_ref"] else 0, objs, dist)
+            assert list(objs[:3]) == rec["front"] and list(objs[3:]) == rec["back"], (sc["seed"], s)
+            ref_d = np.array(rec["fd"] + rec["bd"])
+            assert np.abs(np.array(dist[:]) - ref_d).max() < 1e-4
+            out = (C.c_double * 2)()
+            L.orc_idm_act(o.h, 0, s, out)
+            assert not rec["fallback"]
+            worst = max(worst, abs(out[0] - rec["act"][0]), abs(out[1] - rec["act"][1]) / max(1.0, abs(rec["act"][1])))
+            f2, i2, _ = o.get_state()
+            assert i2[SI["RLANE"], 0, s] == rec["rlane"]
+            assert i2[SI["TIMER"], 0, s] == rec["timer1"]
+            assert f2[SF["TARGET_SPEED"], 0, s] == rec["target"]
+            n_checked += 1
+            o.close()
+    print("idm vehicles checked:", n_checked, "worst", worst)
+    assert n_checked > 50 and worst < 1e-4
+
+
+def test_checkpoint_update(L, descs, scenes):
+    """Navigation._update_target_checkpoints (navigation.py:262-282)."""
+    SI = _abi.SI
+    by_seed = {}
+    for row in scenes["checkpoints"]:
+        by_seed.setdefault(row["seed"], []).append(row)
+    for seed, rows in by_seed.items():
+        sc = dict(seed=seed, vehicles=[dict(x=0, y=0, theta=0, speed_kmh=0, length=4.5, width=1.8, lane=0,
+                                            ckpt=rows[0]["ckpt"], idx=[0, 0])],
+                  ego=dict(steering=0, act0=[0, 0], last_heading=[1, 0], last_position=[0, 0]))
+        o, f, i, ei, d = _scene_engine(descs, sc)
+        for row in rows:
+            i[SI["CK0"], 0, 0], i[SI["CK1"], 0, 0] = row["idx"]
+            o.set_state(f, i, ei)
+            L.orc_update_checkpoints(o.h, 0, 0, row["lane"], float(row["lon"]))
+            _, i2, _ = o.get_state()
+            assert [int(i2[SI["CK0"], 0, 0]), int(i2[SI["CK1"], 0, 0])] == row["out"], row
+        o.close()

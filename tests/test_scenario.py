@@ -1,0 +1,82 @@
+"""Seeded host tables vs the reference's own RNG plumbing (goldens from oracle/gen_golden.py:gen_seeding) and the
+traffic spawn rule (manager/traffic_manager.py:239-290)."""
+import json
+import math
+import os
+
+import numpy as np
+
+from pgdrive_amd import mapdata, scenario
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _gold():
+    with open(os.path.join(GOLD, "scenes_v0.json")) as f:
+        return json.load(f)
+
+
+def test_get_np_random_matches_reference():
+    """utils/random_utils.py:14-50: sha512-hashed RandomState seeding."""
+    for row in _gold()["np_random"]:
+        r = scenario.get_np_random(row["seed"])
+        assert [int(r.randint(0, 65536)) for _ in range(4)] == row["randint"]
+        assert abs(float(r.uniform()) - row["uniform"]) < 1e-15
+
+
+def test_vehicle_parameter_sampling_matches_reference():
+    """BaseRunnable.sample_parameters + ParameterSpace (base_runnable.py:81-88, utils/space.py:152-255)."""
+    for row in _gold()["vehicle_params"]:
+        p = scenario.sample_vehicle_params(row["vtype"], row["seed"])
+        assert abs(p["max_engine_force"] - row["max_engine_force"]) < 1e-4
+        assert abs(p["max_brake_force"] - row["max_brake_force"]) < 1e-4
+        assert abs(math.degrees(p["max_steer"]) - row["max_steering"]) < 1e-4
+        assert abs(p["friction"] - row["wheel_friction"]) < 1e-6 and p["max_speed"] == row["max_speed"]
+
+
+def test_traffic_spawn_rule(descs):
+    """floor(floor(sum len / 10 m) * density) vehicles per block on a 10 m grid, types from [.2,.3,.3,.2,0]."""
+    d = descs[0]
+    groups = scenario.propose_traffic(d, d["seed"], 0.1)
+    assert len(groups) == len(d["blocks"]) - 1
+    for g, b in zip(groups, d["blocks"][1:]):
+        total = sum(d["lanes"][l]["length"] for lanes in b["spawn_lanes"] for l in lanes)
+        assert len(g["vehicles"]) == int(math.floor(math.floor(total / 10) * 0.1))
+        for v in g["vehicles"]:
+            assert v["long"] % 10 == 0 and v["long"] < d["lanes"][v["lane"]]["length"]
+            assert v["vtype"] in ("s", "m", "l", "xl")
+    again = scenario.propose_traffic(d, d["seed"], 0.1)
+    assert again == groups  # same seed -> same traffic (test_random_engine.py:6-188)
+    assert scenario.propose_traffic(d, d["seed"], 0.0) == []
+
+
+def test_scenario_records(descs):
+    sb = scenario.ScenarioBank(descs[:5], [d["seed"] for d in descs[:5]], num_agents=1, num_traffic=16)
+    assert sb.spawns.shape == (5 * 17, )
+    for k, d in enumerate(descs[:5]):
+        sp = sb.spawns[k * 17:(k + 1) * 17]
+        ego = sp[0]
+        assert ego["lane"] == 0 and ego["group"] == -1
+        assert abs(ego["x"] - 5.0) < 1e-6 and abs(ego["y"]) < 1e-6 and ego["heading"] == 0.0  # spawn long 5 on ('>','>>',0)
+        assert 750 <= ego["max_engine_force"] <= 850 and 80 <= ego["max_brake_force"] <= 180
+        n = ego["n_ckpt"]
+        assert d["nodes"][ego["ckpt"][0]] == ">" and n >= 3
+        # every leg of the route is a road of the map, the destination lane is the right-most lane of the last road
+        for j in range(n - 1):
+            r = d["roads"][ego["ckpt_road"][j]]
+            assert r["frm"] == ego["ckpt"][j] and r["to"] == ego["ckpt"][j + 1]
+        last = d["roads"][ego["ckpt_road"][n - 2]]
+        assert ego["dest_lane"] == last["first_lane"] + last["n_lanes"] - 1
+        used = sp[1:][sp[1:]["lane"] >= 0]
+        assert (used["group"] >= 0).all() and (used["timer0"] >= 0).all() and (used["timer0"] < 50).all()
+        assert sb.scenarios[k]["n_groups"] == len(d["blocks"]) - 1
+
+
+def test_empty_and_capped_slots(descs):
+    """density 0 -> no traffic slots used; a tiny cap drops vehicles but keeps the RNG stream aligned."""
+    sc, sp, info = scenario.build_scenario(descs[2], 0, descs[2]["seed"], num_traffic=16, density=0.0)
+    assert (sp[1:]["lane"] < 0).all() and info["n_traffic"] == 0
+    sc2, sp2, info2 = scenario.build_scenario(descs[2], 0, descs[2]["seed"], num_traffic=2, density=0.3)
+    sc3, sp3, info3 = scenario.build_scenario(descs[2], 0, descs[2]["seed"], num_traffic=40, density=0.3)
+    assert info2["dropped"] > 0 and info3["dropped"] == 0
+    assert (sp2[1:3]["lane"] == sp3[1:3]["lane"]).all() and (sp2[1:3]["max_engine_force"] == sp3[1:3]["max_engine_force"]).all()
