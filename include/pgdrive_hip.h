@@ -58,7 +58,7 @@ extern "C" {
 #define PGD_F_OUT_OF_ROUTE  (1u << 13)  /* out_of_route          base_vehicle.py:274-276 */
 #define PGD_F_RESET         (1u << 16)  /* this env was auto-reset at the end of the step (obs is the new episode's) */
 
-typedef struct pgd_lane {   /* 64 B */
+typedef struct __attribute__((aligned(16))) pgd_lane {   /* 64 B */
   float ax, ay;             /* straight: start point; circular: centre */
   float bx, by;             /* straight: unit direction; circular: (radius, start_phase) */
   float c;                  /* straight: heading; circular: end_phase */
@@ -72,7 +72,7 @@ typedef struct pgd_lane {   /* 64 B */
   int16_t succ[PGD_MAX_SUCC]; /* map-local lane ids L2 with |end - L2.start| < 0.1 (abs_lane.py:114-119) */
 } pgd_lane;
 
-typedef struct pgd_road {   /* 16 B */
+typedef struct __attribute__((aligned(16))) pgd_road {   /* 16 B */
   int16_t from, to;         /* node ids */
   int16_t first_lane, n_lanes;
   uint8_t negative;         /* Road.is_negative_road (road.py:33-34) */
@@ -82,7 +82,7 @@ typedef struct pgd_road {   /* 16 B */
   int32_t pad1;
 } pgd_road;
 
-typedef struct pgd_box {    /* 32 B */
+typedef struct __attribute__((aligned(16))) pgd_box {    /* 32 B */
   float cx, cy;             /* centre */
   float ux, uy;             /* unit vector of the long axis */
   float hl, hw;             /* half extents along / across */

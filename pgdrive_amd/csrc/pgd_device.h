@@ -19,14 +19,18 @@
 struct PgdDev {
   pgd_config cfg;
   int N, A, T, V, D, NV;
-  int epw;  // envs per wave in k_step
+  int epw;        // whole environments per wave in k_step
+  int sub;        // sub-lanes cooperating on one vehicle
+  int lds_bytes;  // dynamic LDS of k_step for the staged lane/road tables (0 = tables read from global memory)
   const pgd_map* maps;
   const pgd_lane* lanes;
   const pgd_road* roads;
   const pgd_box* boxes;
   const int32_t* cell_start;
   const int32_t* cell_items;
+  const pgd_box* cell_boxes;  // cell-major copies: cell_boxes[item_off + k] == boxes[box_off + cell_items[item_off + k]]
   const pgd_scenario* scen;
+  const pgd_map* scen_map;    // [n_scen] copy of each scenario's map header
   const pgd_spawn* spawns;
   int n_scen;
   float* f;     // [PGD_NF][NV]
@@ -41,8 +45,20 @@ struct MapView {
   const pgd_box* boxes;
   const int32_t* cstart;
   const int32_t* citems;
+  const pgd_box* cbox;
 };
 
+DEV MapView map_view_of(const PgdDev& d, const pgd_map* m) {
+  MapView v;
+  v.m = m;
+  v.lanes = d.lanes + m->lane_off;
+  v.roads = d.roads + m->road_off;
+  v.boxes = d.boxes + m->box_off;
+  v.cstart = d.cell_start + m->cell_off;
+  v.citems = d.cell_items + m->item_off;
+  v.cbox = d.cell_boxes + m->item_off;
+  return v;
+}
 DEV MapView map_view(const PgdDev& d, int map) {
   MapView v;
   v.m = d.maps + map;
@@ -51,6 +67,7 @@ DEV MapView map_view(const PgdDev& d, int map) {
   v.boxes = d.boxes + v.m->box_off;
   v.cstart = d.cell_start + v.m->cell_off;
   v.citems = d.cell_items + v.m->item_off;
+  v.cbox = d.cell_boxes + v.m->item_off;
   return v;
 }
 
@@ -59,9 +76,10 @@ DEV MapView map_view(const PgdDev& d, int map) {
 // ---------------------------------------------------------------------------------------------------------------------
 DEV float clipf(float a, float lo, float hi) { return fminf(fmaxf(a, lo), hi); }
 DEV float norm2(float x, float y) { return sqrtf(x * x + y * y); }
-DEV float wrap_to_pi(float x) {  // ((x + pi) % (2 pi)) - pi with Python's sign-of-divisor modulo
-  float r = fmodf(x + PGD_PI, 2.0f * PGD_PI);
-  if (r < 0.0f) r += 2.0f * PGD_PI;
+DEV float wrap_to_pi(float x) {  // ((x + pi) % (2 pi)) - pi with Python's sign-of-divisor modulo: result in [-pi, pi)
+  float y = x + PGD_PI;
+  float r = y - 2.0f * PGD_PI * floorf(y * (0.5f / PGD_PI));
+  r = r < 0.0f ? r + 2.0f * PGD_PI : (r >= 2.0f * PGD_PI ? r - 2.0f * PGD_PI : r);
   return r - PGD_PI;
 }
 DEV float not_zero(float x, float eps) { return fabsf(x) > eps ? x : (x > 0.0f ? eps : -eps); }

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "pgd_device.h"
@@ -29,6 +30,27 @@
 #define WAVE 64
 #define MAXV 64
 
+// Optional per-phase cycle counters of k_step (build with -DPGD_PROF; never enabled in the shipped library)
+#ifdef PGD_PROF
+#define PROF_BLOCKS 8192
+__device__ unsigned long long g_phase_cycles[PROF_BLOCKS * 16];  // per block, no atomics (they would serialise)
+__shared__ long long s_prof_t0, s_prof_w0;
+#define PHASE_MARK(k)                                                                                      \
+  do {                                                                                                     \
+    if ((int)threadIdx.x == __builtin_ffsll((long long)__ballot(1)) - 1 && blockIdx.x < PROF_BLOCKS) {       \
+      long long _now = clock64();                                                                          \
+      g_phase_cycles[blockIdx.x * 16 + (k)] += (unsigned long long)(_now - s_prof_t0);                     \
+      s_prof_t0 = _now;                                                                                    \
+    }                                                                                                      \
+  } while (0)
+#define PHASE_INIT() do { if (threadIdx.x == 0) { s_prof_t0 = clock64(); s_prof_w0 = wall_clock64(); } } while (0)
+#define PHASE_END() do { if (threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS) g_phase_cycles[blockIdx.x * 16 + 15] += (unsigned long long)(wall_clock64() - s_prof_w0); } while (0)
+#else
+#define PHASE_MARK(k)
+#define PHASE_INIT()
+#define PHASE_END()
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // per-lane vehicle registers
 // ---------------------------------------------------------------------------------------------------------------------
@@ -36,43 +58,47 @@ struct Veh {
   float x, y, th, v, steer, thr, lastx, lasty, lasthx, lasthy, a0s, a0t, a1s, a1t, php, phi, plp, pli, target, energy,
       dl, dr, eprew;
   int status, lane, ck0, ck1, rlane, timer, vflags;
+  float hx, hy;  // unit heading (cos, sin of th): derived, kept in registers, never stored
 };
 
-DEV void load_veh(const PgdDev& d, int idx, Veh& r) {
-  const float* f = d.f;
-  const int NV = d.NV;
-  r.x = f[SF_X * NV + idx]; r.y = f[SF_Y * NV + idx]; r.th = f[SF_THETA * NV + idx]; r.v = f[SF_SPEED * NV + idx];
-  r.steer = f[SF_STEER * NV + idx]; r.thr = f[SF_THROTTLE * NV + idx];
-  r.lastx = f[SF_LASTX * NV + idx]; r.lasty = f[SF_LASTY * NV + idx];
-  r.lasthx = f[SF_LASTHX * NV + idx]; r.lasthy = f[SF_LASTHY * NV + idx];
-  r.a0s = f[SF_ACT0S * NV + idx]; r.a0t = f[SF_ACT0T * NV + idx];
-  r.a1s = f[SF_ACT1S * NV + idx]; r.a1t = f[SF_ACT1T * NV + idx];
-  r.php = f[SF_PID_HP * NV + idx]; r.phi = f[SF_PID_HI * NV + idx];
-  r.plp = f[SF_PID_LP * NV + idx]; r.pli = f[SF_PID_LI * NV + idx];
-  r.target = f[SF_TARGET_SPEED * NV + idx]; r.energy = f[SF_ENERGY * NV + idx];
-  r.dl = f[SF_DIST_LEFT * NV + idx]; r.dr = f[SF_DIST_RIGHT * NV + idx]; r.eprew = f[SF_EP_REWARD * NV + idx];
-  const int32_t* i = d.i;
-  r.status = i[SI_STATUS * NV + idx]; r.lane = i[SI_LANE * NV + idx]; r.ck0 = i[SI_CK0 * NV + idx];
-  r.ck1 = i[SI_CK1 * NV + idx]; r.rlane = i[SI_RLANE * NV + idx]; r.timer = i[SI_TIMER * NV + idx];
-  r.vflags = i[SI_VFLAGS * NV + idx];
+// device state is env-major: [env][field][slot] — the V slots of one field are contiguous and an env's whole state is one
+// 2 KB block (full cache lines for the one-env-per-wave kernels); pgd_get/set_state convert to the ABI's field-major order
+DEV void load_veh(const PgdDev& d, int e, int s, Veh& r) {
+  const float* f = d.f + (size_t)e * (PGD_NF * d.V) + s;
+  const int NV = d.V;
+  r.x = f[SF_X * NV]; r.y = f[SF_Y * NV]; r.th = f[SF_THETA * NV]; r.v = f[SF_SPEED * NV];
+  r.steer = f[SF_STEER * NV]; r.thr = f[SF_THROTTLE * NV];
+  r.lastx = f[SF_LASTX * NV]; r.lasty = f[SF_LASTY * NV];
+  r.lasthx = f[SF_LASTHX * NV]; r.lasthy = f[SF_LASTHY * NV];
+  r.a0s = f[SF_ACT0S * NV]; r.a0t = f[SF_ACT0T * NV];
+  r.a1s = f[SF_ACT1S * NV]; r.a1t = f[SF_ACT1T * NV];
+  r.php = f[SF_PID_HP * NV]; r.phi = f[SF_PID_HI * NV];
+  r.plp = f[SF_PID_LP * NV]; r.pli = f[SF_PID_LI * NV];
+  r.target = f[SF_TARGET_SPEED * NV]; r.energy = f[SF_ENERGY * NV];
+  r.dl = f[SF_DIST_LEFT * NV]; r.dr = f[SF_DIST_RIGHT * NV]; r.eprew = f[SF_EP_REWARD * NV];
+  const int32_t* i = d.i + (size_t)e * (PGD_NI * d.V) + s;
+  r.status = i[SI_STATUS * NV]; r.lane = i[SI_LANE * NV]; r.ck0 = i[SI_CK0 * NV];
+  r.ck1 = i[SI_CK1 * NV]; r.rlane = i[SI_RLANE * NV]; r.timer = i[SI_TIMER * NV];
+  r.vflags = i[SI_VFLAGS * NV];
+  sincosf(r.th, &r.hy, &r.hx);
 }
-DEV void store_veh(const PgdDev& d, int idx, const Veh& r) {
-  float* f = d.f;
-  const int NV = d.NV;
-  f[SF_X * NV + idx] = r.x; f[SF_Y * NV + idx] = r.y; f[SF_THETA * NV + idx] = r.th; f[SF_SPEED * NV + idx] = r.v;
-  f[SF_STEER * NV + idx] = r.steer; f[SF_THROTTLE * NV + idx] = r.thr;
-  f[SF_LASTX * NV + idx] = r.lastx; f[SF_LASTY * NV + idx] = r.lasty;
-  f[SF_LASTHX * NV + idx] = r.lasthx; f[SF_LASTHY * NV + idx] = r.lasthy;
-  f[SF_ACT0S * NV + idx] = r.a0s; f[SF_ACT0T * NV + idx] = r.a0t;
-  f[SF_ACT1S * NV + idx] = r.a1s; f[SF_ACT1T * NV + idx] = r.a1t;
-  f[SF_PID_HP * NV + idx] = r.php; f[SF_PID_HI * NV + idx] = r.phi;
-  f[SF_PID_LP * NV + idx] = r.plp; f[SF_PID_LI * NV + idx] = r.pli;
-  f[SF_TARGET_SPEED * NV + idx] = r.target; f[SF_ENERGY * NV + idx] = r.energy;
-  f[SF_DIST_LEFT * NV + idx] = r.dl; f[SF_DIST_RIGHT * NV + idx] = r.dr; f[SF_EP_REWARD * NV + idx] = r.eprew;
-  int32_t* i = d.i;
-  i[SI_STATUS * NV + idx] = r.status; i[SI_LANE * NV + idx] = r.lane; i[SI_CK0 * NV + idx] = r.ck0;
-  i[SI_CK1 * NV + idx] = r.ck1; i[SI_RLANE * NV + idx] = r.rlane; i[SI_TIMER * NV + idx] = r.timer;
-  i[SI_VFLAGS * NV + idx] = r.vflags;
+DEV void store_veh(const PgdDev& d, int e, int s, const Veh& r) {
+  float* f = d.f + (size_t)e * (PGD_NF * d.V) + s;
+  const int NV = d.V;
+  f[SF_X * NV] = r.x; f[SF_Y * NV] = r.y; f[SF_THETA * NV] = r.th; f[SF_SPEED * NV] = r.v;
+  f[SF_STEER * NV] = r.steer; f[SF_THROTTLE * NV] = r.thr;
+  f[SF_LASTX * NV] = r.lastx; f[SF_LASTY * NV] = r.lasty;
+  f[SF_LASTHX * NV] = r.lasthx; f[SF_LASTHY * NV] = r.lasthy;
+  f[SF_ACT0S * NV] = r.a0s; f[SF_ACT0T * NV] = r.a0t;
+  f[SF_ACT1S * NV] = r.a1s; f[SF_ACT1T * NV] = r.a1t;
+  f[SF_PID_HP * NV] = r.php; f[SF_PID_HI * NV] = r.phi;
+  f[SF_PID_LP * NV] = r.plp; f[SF_PID_LI * NV] = r.pli;
+  f[SF_TARGET_SPEED * NV] = r.target; f[SF_ENERGY * NV] = r.energy;
+  f[SF_DIST_LEFT * NV] = r.dl; f[SF_DIST_RIGHT * NV] = r.dr; f[SF_EP_REWARD * NV] = r.eprew;
+  int32_t* i = d.i + (size_t)e * (PGD_NI * d.V) + s;
+  i[SI_STATUS * NV] = r.status; i[SI_LANE * NV] = r.lane; i[SI_CK0 * NV] = r.ck0;
+  i[SI_CK1 * NV] = r.ck1; i[SI_RLANE * NV] = r.rlane; i[SI_TIMER * NV] = r.timer;
+  i[SI_VFLAGS * NV] = r.vflags;
 }
 
 DEV float speed_kmh(float v) { return clipf(v * 3.6f, 0.0f, 100000.0f); }  // base_vehicle.py:394-401
@@ -81,43 +107,87 @@ DEV float speed_kmh(float v) { return clipf(v * 3.6f, 0.0f, 100000.0f); }  // ba
 struct Snap {
   float x[WAVE], y[WAVE], ux[WAVE], uy[WAVE], spd[WAVE], hl[WAVE], hw[WAVE];
   int lane[WAVE], present[WAVE];
+  // for the IDM neighbour search: each vehicle's longitudinal coordinate on its own lane, that lane's length and
+  // successor list (8 x int16), so the O(V^2) search never touches the lane table
+  float lon[WAVE], llen[WAVE];
+  int4 succ[WAVE];
 };
+DEV bool succ_has(const int4& p, int id) {  // 8 packed int16 ids, unused entries are -1
+  unsigned u = (unsigned)id & 0xffffu;
+  unsigned a = (unsigned)p.x, b = (unsigned)p.y, c = (unsigned)p.z, d = (unsigned)p.w;
+  return (a & 0xffffu) == u || (a >> 16) == u || (b & 0xffffu) == u || (b >> 16) == u || (c & 0xffffu) == u ||
+         (c >> 16) == u || (d & 0xffffu) == u || (d >> 16) == u;
+}
 DEV Obb snap_obb(const Snap& S, int k) { return Obb{S.x[k], S.y[k], S.ux[k], S.uy[k], S.hl[k], S.hw[k]}; }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// localisation: utils/scene_utils.py:138-185 + navigation.py:328-344.  "First hit" = smallest box id (Bullet insertion
-// order); cell lists are ascending so the first match per class in the cell is the answer.
+// sub-lane cooperation: a vehicle is carried by SUB consecutive lanes that hold identical copies of its registers; the
+// heavy box / neighbour loops are split across them and recombined with wave shuffles (all lanes of a group are always
+// convergent because they execute on identical data).
 // ---------------------------------------------------------------------------------------------------------------------
-DEV int get_current_lane(const MapView& mv, float px, float py, float hx, float hy, int road_cur, int road_next) {
+struct Grp {
+  int sub, SUB, lead;
+};
+DEV unsigned group_min(unsigned v, const Grp& g) {
+  unsigned r = v;
+  for (int j = 0; j < g.SUB; ++j) r = min(r, (unsigned)__shfl((int)v, g.lead + j));
+  return r;
+}
+DEV unsigned group_or(unsigned v, const Grp& g) {
+  unsigned r = v;
+  for (int j = 0; j < g.SUB; ++j) r |= (unsigned)__shfl((int)v, g.lead + j);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// localisation: utils/scene_utils.py:138-185 + navigation.py:328-344.  "First hit" = smallest box id (Bullet insertion
+// order); the cell-major box copies keep that order, so the smallest list position per class is the answer.
+// key = (position in cell << 16) | lane id
+// ---------------------------------------------------------------------------------------------------------------------
+DEV int get_current_lane(const MapView& mv, const Grp& g, float px, float py, float hx, float hy, int road_cur,
+                         int road_next) {
   const pgd_map& m = *mv.m;
   int cx = (int)floorf((px - m.ox) / m.cell), cy = (int)floorf((py - m.oy) / m.cell);
-  if (cx < 0 || cy < 0 || cx >= m.gx || cy >= m.gy) return -1;
-  int cell = cy * m.gx + cx;
-  int k0 = mv.cstart[cell], k1 = mv.cstart[cell + 1];
-  int best_cur = -1, best_next = -1, best_any = -1;
-  for (int k = k0; k < k1; ++k) {
-    const pgd_box& b = mv.boxes[mv.citems[k]];
-    if (b.kind != PGD_BOX_LANE) continue;
-    if (!point_in_obb(obb_of(b), px, py)) continue;
-    const pgd_lane& l = mv.lanes[b.lane];
-    if (best_cur >= 0) break;
-    bool want = (best_any < 0) || (l.road == road_cur) || (best_next < 0 && l.road == road_next);
-    if (!want) continue;
-    float lon, lat;
-    lane_local(l, px, py, lon, lat);
-    float lh = lane_heading_at(l, lon);
-    float s, c;
-    sincosf(lh, &s, &c);
-    float cosangle = (c * hx + s * hy) / (norm2(c, s) * norm2(hx, hy));
-    if (!(cosangle > 0.0f)) continue;
-    if (best_any < 0) best_any = b.lane;
-    if (l.road == road_cur) best_cur = b.lane;
-    else if (l.road == road_next && best_next < 0) best_next = b.lane;
+  int k0 = 0, k1 = 0;
+  if (cx >= 0 && cy >= 0 && cx < m.gx && cy < m.gy) {
+    int cell = cy * m.gx + cx;
+    k0 = mv.cstart[cell];
+    k1 = mv.cstart[cell + 1];
   }
-  if (best_cur >= 0) return best_cur;
-  if (road_next < 0) return best_any;
-  if (best_next >= 0) return best_next;
-  return best_any;
+  unsigned best_cur = 0xffffffffu, best_next = 0xffffffffu, best_any = 0xffffffffu;
+  const int stride = g.SUB;
+  for (int k = k0 + g.sub; k < k1; k += 4 * stride) {
+    pgd_box b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int kk = k + j * stride;
+      b[j] = mv.cbox[kk < k1 ? kk : k];  // batch the independent loads
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int kk = k + j * stride;
+      if (kk >= k1 || b[j].kind != PGD_BOX_LANE) continue;
+      if (!point_in_obb(obb_of(b[j]), px, py)) continue;
+      const pgd_lane& l = mv.lanes[b[j].lane];
+      unsigned key = ((unsigned)(kk - k0) << 16) | (unsigned)b[j].lane;
+      bool is_cur = l.road == road_cur, is_next = l.road == road_next;
+      if (!(key < best_any || (is_cur && key < best_cur) || (is_next && key < best_next))) continue;
+      // cos(angle between lane heading at the point and vehicle heading) > 0 (scene_utils.py:158-172); only the sign is
+      // used, so the lane direction is taken in closed form: straight = unit dir; arc = dir * (-dy, dx) around the centre
+      float dirx, diry;
+      if (l.dir == 0.0f) { dirx = l.bx; diry = l.by; }
+      else { dirx = -l.dir * (py - l.ay); diry = l.dir * (px - l.ax); }
+      if (!(dirx * hx + diry * hy > 0.0f)) continue;
+      best_any = min(best_any, key);
+      if (is_cur) best_cur = min(best_cur, key);
+      if (is_next) best_next = min(best_next, key);
+    }
+  }
+  best_cur = group_min(best_cur, g);
+  best_next = group_min(best_next, g);
+  best_any = group_min(best_any, g);
+  unsigned pick = best_cur != 0xffffffffu ? best_cur : (road_next < 0 ? best_any : (best_next != 0xffffffffu ? best_next : best_any));
+  return pick == 0xffffffffu ? -1 : (int)(pick & 0xffffu);
 }
 
 // Navigation._update_target_checkpoints (navigation.py:262-282)
@@ -140,12 +210,11 @@ DEV void update_checkpoints(const MapView& mv, const pgd_spawn& sp, Veh& r, floa
 }
 
 // Navigation.update_localization (navigation.py:155-183)
-DEV void update_localization(const MapView& mv, const pgd_spawn& sp, Veh& r) {
-  float s, c;
-  sincosf(r.th, &s, &c);
+DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r) {
+  const float s = r.hy, c = r.hx;
   int road_cur = sp.ckpt_road[r.ck0];
   int road_next = (r.ck0 == r.ck1) ? -1 : sp.ckpt_road[r.ck1];
-  int lane = get_current_lane(mv, r.x, r.y, c, s, road_cur, road_next);
+  int lane = get_current_lane(mv, g, r.x, r.y, c, s, road_cur, road_next);
   bool on_lane = lane >= 0;
   if (!on_lane) lane = r.lane;
   r.lane = lane;
@@ -156,38 +225,48 @@ DEV void update_localization(const MapView& mv, const pgd_spawn& sp, Veh& r) {
 }
 
 // BaseVehicle._state_check (base_vehicle.py:615-644)
-DEV unsigned state_check(const MapView& mv, const Obb& car) {
+DEV unsigned state_check(const MapView& mv, const Grp& g, const Obb& car) {
   const pgd_map& m = *mv.m;
   float ex = fabsf(car.ux) * car.hl + fabsf(car.uy) * car.hw, ey = fabsf(car.uy) * car.hl + fabsf(car.ux) * car.hw;
   int cx0 = max((int)floorf((car.cx - ex - m.ox) / m.cell), 0), cx1 = min((int)floorf((car.cx + ex - m.ox) / m.cell), m.gx - 1);
   int cy0 = max((int)floorf((car.cy - ey - m.oy) / m.cell), 0), cy1 = min((int)floorf((car.cy + ey - m.oy) / m.cell), m.gy - 1);
   unsigned fl = 0;
+  const int stride = g.SUB;
   for (int cy = cy0; cy <= cy1; ++cy)
     for (int cx = cx0; cx <= cx1; ++cx) {
       int cell = cy * m.gx + cx;
-      int k1 = mv.cstart[cell + 1];
-      for (int k = mv.cstart[cell]; k < k1; ++k) {
-        const pgd_box& b = mv.boxes[mv.citems[k]];
-        if (b.kind == PGD_BOX_LANE) continue;
-        unsigned bit = b.kind == PGD_BOX_WHITE ? PGD_F_ON_WHITE
-                       : b.kind == PGD_BOX_YELLOW ? PGD_F_ON_YELLOW
-                       : b.kind == PGD_BOX_BROKEN ? PGD_F_ON_BROKEN : PGD_F_CRASH_SIDEWALK;
-        if (fl & bit) continue;
-        if (obb_overlap(car, obb_of(b))) fl |= bit;
+      int k0 = mv.cstart[cell], k1 = mv.cstart[cell + 1];
+      for (int k = k0 + g.sub; k < k1; k += 4 * stride) {
+        pgd_box b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int kk = k + j * stride;
+          b[j] = mv.cbox[kk < k1 ? kk : k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int kk = k + j * stride;
+          if (kk >= k1 || b[j].kind == PGD_BOX_LANE) continue;
+          unsigned bit = b[j].kind == PGD_BOX_WHITE ? PGD_F_ON_WHITE
+                         : b[j].kind == PGD_BOX_YELLOW ? PGD_F_ON_YELLOW
+                         : b[j].kind == PGD_BOX_BROKEN ? PGD_F_ON_BROKEN : PGD_F_CRASH_SIDEWALK;
+          if (fl & bit) continue;
+          if (obb_overlap(car, obb_of(b[j]))) fl |= bit;
+        }
       }
     }
-  return fl;
+  return group_or(fl, g);
 }
 
-// BaseVehicle.after_step (base_vehicle.py:255-290)
-DEV void after_step_vehicle(const MapView& mv, const pgd_spawn& sp, Veh& r, bool is_agent) {
-  update_localization(mv, sp, r);
+// BaseVehicle.after_step (base_vehicle.py:255-290).  `with_state_check` = false lets the caller run the line / sidewalk
+// test wave-cooperatively afterwards (k_step with one env per wave) and OR the result into vflags.
+DEV void after_step_vehicle(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, bool is_agent,
+                            bool with_state_check) {
+  update_localization(mv, g, sp, r);
   if (is_agent) {
     unsigned fl = (unsigned)r.vflags;
     fl &= ~(PGD_F_ON_WHITE | PGD_F_ON_YELLOW | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OUT_OF_ROUTE);
-    float s, c;
-    sincosf(r.th, &s, &c);
-    fl |= state_check(mv, Obb{r.x, r.y, c, s, 0.5f * sp.length, 0.5f * sp.width});
+    if (with_state_check) fl |= state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sp.length, 0.5f * sp.width});
     const pgd_road& cr = mv.roads[sp.ckpt_road[r.ck0]];
     float lon, lat;
     lane_local(mv.lanes[cr.first_lane], r.x, r.y, lon, lat);
@@ -201,6 +280,46 @@ DEV void after_step_vehicle(const MapView& mv, const pgd_spawn& sp, Veh& r, bool
   }
 }
 
+// the same test with the whole wave on one car: the (<= 2x2) grid cells under the car are flattened into one index range
+DEV unsigned state_check_wave(const MapView& mv, const Obb& car) {
+  const pgd_map& m = *mv.m;
+  const int lane = threadIdx.x;
+  float ex = fabsf(car.ux) * car.hl + fabsf(car.uy) * car.hw, ey = fabsf(car.uy) * car.hl + fabsf(car.ux) * car.hw;
+  int cx0 = max((int)floorf((car.cx - ex - m.ox) / m.cell), 0), cx1 = min((int)floorf((car.cx + ex - m.ox) / m.cell), m.gx - 1);
+  int cy0 = max((int)floorf((car.cy - ey - m.oy) / m.cell), 0), cy1 = min((int)floorf((car.cy + ey - m.oy) / m.cell), m.gy - 1);
+  unsigned fl = 0;
+  for (int cyb = cy0; cyb <= cy1; cyb += 2)
+    for (int cxb = cx0; cxb <= cx1; cxb += 2) {  // blocks of up to 2x2 cells (a car spans at most 2 cells per axis)
+      int k0[4], pre[5];
+      pre[0] = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int cx = cxb + (q & 1), cy = cyb + (q >> 1);
+        bool in = cx <= cx1 && cy <= cy1;
+        int cell = in ? cy * m.gx + cx : 0;
+        int a = mv.cstart[cell], b = mv.cstart[cell + 1];
+        k0[q] = a;
+        pre[q + 1] = pre[q] + (in ? b - a : 0);
+      }
+      for (int f = lane; f < pre[4]; f += WAVE) {
+        int q = (f >= pre[1]) + (f >= pre[2]) + (f >= pre[3]);
+        int kk = (q == 0 ? k0[0] : q == 1 ? k0[1] : q == 2 ? k0[2] : k0[3]) + f - (q == 0 ? pre[0] : q == 1 ? pre[1] : q == 2 ? pre[2] : pre[3]);
+        pgd_box b = mv.cbox[kk];
+        if (b.kind == PGD_BOX_LANE) continue;
+        unsigned bit = b.kind == PGD_BOX_WHITE ? PGD_F_ON_WHITE
+                       : b.kind == PGD_BOX_YELLOW ? PGD_F_ON_YELLOW
+                       : b.kind == PGD_BOX_BROKEN ? PGD_F_ON_BROKEN : PGD_F_CRASH_SIDEWALK;
+        if (obb_overlap(car, obb_of(b))) fl |= bit;
+      }
+    }
+  unsigned out = 0;
+  if (__ballot((fl & PGD_F_ON_WHITE) != 0)) out |= PGD_F_ON_WHITE;
+  if (__ballot((fl & PGD_F_ON_YELLOW) != 0)) out |= PGD_F_ON_YELLOW;
+  if (__ballot((fl & PGD_F_ON_BROKEN) != 0)) out |= PGD_F_ON_BROKEN;
+  if (__ballot((fl & PGD_F_CRASH_SIDEWALK) != 0)) out |= PGD_F_CRASH_SIDEWALK;
+  return out;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // IDM: policy/idm_policy.py:82-133 (FrontBackObjects), :190-353 (act, lane change), :244-271 (PID + IDM law)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -210,57 +329,80 @@ struct Fbo {
   bool exist[3];
 };
 
-DEV void find_front_back(const MapView& mv, const Snap& S, int base, int V, int self, unsigned long long objs, int lane,
-                         float max_dist, bool with_ref, Fbo& r) {
+DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int base, int V, int self, unsigned long long objs,
+                         int lane, float max_dist, bool with_ref, Fbo& r) {
   const pgd_lane& L = mv.lanes[lane];
   const pgd_road& road = mv.roads[L.road];
-  int idx = L.index;
-  int lanes[3];
-  lanes[0] = (with_ref && idx > 0) ? road.first_lane + idx - 1 : -1;
-  lanes[1] = lane;
-  lanes[2] = (with_ref && idx + 1 < road.n_lanes) ? road.first_lane + idx + 1 : -1;
-  float px = S.x[base + self], py = S.y[base + self];
+  const int idx = L.index;
+  const int l0 = (with_ref && idx > 0) ? road.first_lane + idx - 1 : -1;
+  const int l2 = (with_ref && idx + 1 < road.n_lanes) ? road.first_lane + idx + 1 : -1;
+  const float px = S.x[base + self], py = S.y[base + self];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     r.front[i] = r.back[i] = -1;
-    r.exist[i] = lanes[i] >= 0;
     r.fd[i] = r.bd[i] = max_dist;
-    if (lanes[i] < 0) continue;
-    const pgd_lane& li = mv.lanes[lanes[i]];
+  }
+  r.exist[0] = l0 >= 0; r.exist[1] = true; r.exist[2] = l2 >= 0;
+  // target lane t (0 left, 1 own, 2 right) is searched by sub-lane t mod SUB; t is a per-lane runtime value so the
+  // sub-lanes run the same instructions on different target lanes (no serialisation across targets)
+  for (int t = g.sub; t < 3; t += g.SUB) {
+    const int tl = t == 0 ? l0 : (t == 1 ? lane : l2);
+    if (tl < 0) continue;
+    const pgd_lane& li = mv.lanes[tl];
     float cur, lat;
     lane_local(li, px, py, cur, lat);
-    float left_long = li.length - cur;
+    const float left_long = li.length - cur;
+    const int4 lsucc = *reinterpret_cast<const int4*>(li.succ);
+    // one pass, five running minima (FrontBackObjects.get_find_front_back_objs, idm_policy.py:107-131):
+    //   same lane front/back; successor-lane front; predecessor-lane back (all / excluding successor-lane objects)
+    float same_f = max_dist, same_b = max_dist, succ_f = max_dist, pred_b = max_dist, pred_bx = max_dist;
+    int o_same_f = -1, o_same_b = -1, o_succ_f = -1, o_pred_b = -1, o_pred_bx = -1;
     bool found_f = false, found_b = false;
-    for (int o = 0; o < V; ++o) {  // objects on this very lane
-      if (!((objs >> o) & 1ull) || S.lane[base + o] != lanes[i]) continue;
-      float lo, la;
-      lane_local(li, S.x[base + o], S.y[base + o], lo, la);
-      float lg = lo - cur;
-      if (r.fd[i] > lg && lg > 0.0f) { r.fd[i] = lg; r.front[i] = o; found_f = true; }
-      if (lg < 0.0f && fabsf(lg) < r.bd[i]) { r.bd[i] = fabsf(lg); r.back[i] = o; found_b = true; }
-    }
-    for (int o = 0; o < V; ++o) {  // successor / predecessor lanes
+#pragma unroll 4
+    for (int o = 0; o < V; ++o) {
+      const int ol = S.lane[base + o];
+      const float olon = S.lon[base + o], ollen = S.llen[base + o];
+      const int4 osucc = S.succ[base + o];
       if (!((objs >> o) & 1ull)) continue;
-      int ol = S.lane[base + o];
-      if (ol == lanes[i]) continue;
-      const pgd_lane& OL = mv.lanes[ol];
-      if (!found_f && lane_is_prev_of(li, ol)) {
-        float lo, la;
-        lane_local(OL, S.x[base + o], S.y[base + o], lo, la);
-        float lg = lo + left_long;
-        if (r.fd[i] > lg && lg > 0.0f) { r.fd[i] = lg; r.front[i] = o; }
-      } else if (!found_b && lane_is_prev_of(OL, lanes[i])) {
-        float lo, la;
-        lane_local(OL, S.x[base + o], S.y[base + o], lo, la);
-        float lg = OL.length - lo + cur;
-        if (r.bd[i] > lg) { r.bd[i] = lg; r.back[i] = o; }
+      if (ol == tl) {
+        float lg = olon - cur;
+        if (same_f > lg && lg > 0.0f) { same_f = lg; o_same_f = o; found_f = true; }
+        if (lg < 0.0f && fabsf(lg) < same_b) { same_b = fabsf(lg); o_same_b = o; found_b = true; }
+      } else {
+        const bool is_succ = succ_has(lsucc, ol);
+        if (is_succ) {
+          float lg = olon + left_long;
+          if (succ_f > lg && lg > 0.0f) { succ_f = lg; o_succ_f = o; }
+        }
+        if (succ_has(osucc, tl)) {
+          float lg = ollen - olon + cur;
+          if (pred_b > lg) { pred_b = lg; o_pred_b = o; }
+          if (!is_succ && pred_bx > lg) { pred_bx = lg; o_pred_bx = o; }
+        }
       }
     }
+    // objects on the lane itself take precedence; an object on a successor lane is only a "front" candidate while no
+    // same-lane front object exists, and only then is it barred from being a "back" candidate (the reference's elif)
+    const float fd = found_f ? same_f : succ_f;
+    const int fo = found_f ? o_same_f : o_succ_f;
+    const float bd = found_b ? same_b : (found_f ? pred_b : pred_bx);
+    const int bo = found_b ? o_same_b : (found_f ? o_pred_b : o_pred_bx);
+    if (t == 0) { r.fd[0] = fd; r.front[0] = fo; r.bd[0] = bd; r.back[0] = bo; }
+    else if (t == 1) { r.fd[1] = fd; r.front[1] = fo; r.bd[1] = bd; r.back[1] = bo; }
+    else { r.fd[2] = fd; r.front[2] = fo; r.bd[2] = bd; r.back[2] = bo; }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {  // every sub-lane gets every target lane's result
+    int src = g.lead + (i % g.SUB);
+    r.front[i] = __shfl(r.front[i], src);
+    r.back[i] = __shfl(r.back[i], src);
+    r.fd[i] = __shfl(r.fd[i], src);
+    r.bd[i] = __shfl(r.bd[i], src);
   }
 }
 
-DEV void idm_act(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const Snap& S, int base, int V, int s, int e,
-                 uint32_t step_count, Veh& r, float& out_steer, float& out_acc) {
+DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spawn& sp, const Snap& S, int base, int V,
+                 int s, int e, uint32_t step_count, Veh& r, float& out_steer, float& out_acc) {
   const float NORMAL = 30.0f, CREEP = 5.0f, SAFE = 15.0f, MAXD = 30.0f;
   int cur_road = sp.ckpt_road[r.ck0];
   const pgd_road& CR = mv.roads[cur_road];
@@ -286,78 +428,84 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const 
   // Lidar.get_surrounding_objects (lidar.py:109-124)
   float px = S.x[base + s], py = S.y[base + s];
   unsigned long long objs = 0ull;
+#pragma unroll 4
   for (int o = 0; o < V; ++o) {
-    if (o == s || !S.present[base + o]) continue;
-    if (point_obb_dist(snap_obb(S, base + o), px, py) <= 50.0f) objs |= 1ull << o;
+    const Obb ob = snap_obb(S, base + o);
+    const bool in = o != s && S.present[base + o] && point_obb_dist(ob, px, py) <= 50.0f;
+    objs |= in ? (1ull << o) : 0ull;
   }
 
+  PHASE_MARK(9);  // idm: routing + broad phase
   int front_obj = -1;
   float front_dist = 5.0f;
   int steer_lane = rt;
   float speed = S.spd[base + s];
-  if (success) {
-    if (mv.lanes[rt].road == cur_road) {
-      Fbo fb;
-      find_front_back(mv, S, base, V, s, objs, rt, MAXD, true, fb);
-      int idx = mv.lanes[rt].index;
-      int n_cur = CR.n_lanes;
-      int avail_lo = 0, avail_hi = n_cur - 1;
-      bool decided = false;
-      if (r.ck0 != r.ck1) {
-        const pgd_road& NR = mv.roads[sp.ckpt_road[r.ck1]];
-        int diff = n_cur - NR.n_lanes;
-        if (diff > 0) {
-          if (lane_is_prev_of(mv.lanes[CR.first_lane], NR.first_lane)) { avail_lo = 0; avail_hi = NR.n_lanes - 1; }
-          else { avail_lo = diff; avail_hi = n_cur - 1; }
-          if (idx < avail_lo || idx > avail_hi) {
-            int side = idx > avail_hi ? 0 : 2;  // 0: change to left, 2: change to right
-            if (fb.bd[side] < SAFE || fb.fd[side] < 5.0f) {
-              r.target = CREEP;
-              front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
-            } else {
-              r.target = NORMAL;
-              front_obj = fb.front[side]; front_dist = fb.fd[side];
-              steer_lane = CR.first_lane + idx + (side == 0 ? -1 : 1);
-            }
-            decided = true;
+  // one neighbour search for both branches of IDMPolicy.act (idm_policy.py:195-208): with the reference lanes when the
+  // routing lane is on the current road, on the routing lane alone otherwise; the reference's failed assert (routing lane
+  // not in ref lanes although move_to_next_road succeeded) falls back to "no front object, distance 5"
+  const bool in_cur = mv.lanes[rt].road == cur_road;
+  const bool search = !success || in_cur;
+  Fbo fb;
+  if (search) find_front_back(mv, g, S, base, V, s, objs, rt, MAXD, success, fb);
+  PHASE_MARK(10);  // idm: front/back search
+  if (success && in_cur) {
+    int idx = mv.lanes[rt].index;
+    int n_cur = CR.n_lanes;
+    int avail_lo = 0, avail_hi = n_cur - 1;
+    bool decided = false;
+    if (r.ck0 != r.ck1) {
+      const pgd_road& NR = mv.roads[sp.ckpt_road[r.ck1]];
+      int diff = n_cur - NR.n_lanes;
+      if (diff > 0) {
+        if (lane_is_prev_of(mv.lanes[CR.first_lane], NR.first_lane)) { avail_lo = 0; avail_hi = NR.n_lanes - 1; }
+        else { avail_lo = diff; avail_hi = n_cur - 1; }
+        if (idx < avail_lo || idx > avail_hi) {
+          int side = idx > avail_hi ? 0 : 2;  // 0: change to left, 2: change to right
+          if (fb.bd[side] < SAFE || fb.fd[side] < 5.0f) {
+            r.target = CREEP;
+            front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
+          } else {
+            r.target = NORMAL;
+            front_obj = fb.front[side]; front_dist = fb.fd[side];
+            steer_lane = CR.first_lane + idx + (side == 0 ? -1 : 1);
+          }
+          decided = true;
+        }
+      }
+    }
+    if (!decided) {
+      if (fabsf(speed - NORMAL) > 3.0f && fb.front[1] >= 0 && fabsf(S.spd[base + fb.front[1]] - NORMAL) > 3.0f &&
+          r.timer > 50) {
+        float fs = S.spd[base + fb.front[1]];
+        bool has_r = false, has_l = false;
+        float rs = 0.0f, ls = 0.0f;
+        if (fb.front[2] >= 0) { has_r = true; rs = S.spd[base + fb.front[2]]; }
+        else if (fb.exist[2] && fb.fd[2] > SAFE && fb.bd[2] > SAFE) { has_r = true; rs = 100.0f; }
+        if (fb.front[0] >= 0) { has_l = true; ls = S.spd[base + fb.front[0]]; }
+        else if (fb.exist[0] && fb.fd[0] > SAFE && fb.bd[0] > SAFE) { has_l = true; ls = 100.0f; }
+        if (has_l && ls - fs > 10.0f) {
+          int ex = idx - 1;
+          if (ex >= avail_lo && ex <= avail_hi) {
+            front_obj = fb.front[0]; front_dist = fb.fd[0]; steer_lane = CR.first_lane + ex; decided = true;
+          }
+        }
+        if (!decided && has_r && rs - fs > 10.0f) {
+          int ex = idx + 1;
+          if (ex >= avail_lo && ex <= avail_hi) {
+            front_obj = fb.front[2]; front_dist = fb.fd[2]; steer_lane = CR.first_lane + ex; decided = true;
           }
         }
       }
       if (!decided) {
-        if (fabsf(speed - NORMAL) > 3.0f && fb.front[1] >= 0 && fabsf(S.spd[base + fb.front[1]] - NORMAL) > 3.0f &&
-            r.timer > 50) {
-          float fs = S.spd[base + fb.front[1]];
-          bool has_r = false, has_l = false;
-          float rs = 0.0f, ls = 0.0f;
-          if (fb.front[2] >= 0) { has_r = true; rs = S.spd[base + fb.front[2]]; }
-          else if (fb.exist[2] && fb.fd[2] > SAFE && fb.bd[2] > SAFE) { has_r = true; rs = 100.0f; }
-          if (fb.front[0] >= 0) { has_l = true; ls = S.spd[base + fb.front[0]]; }
-          else if (fb.exist[0] && fb.fd[0] > SAFE && fb.bd[0] > SAFE) { has_l = true; ls = 100.0f; }
-          if (has_l && ls - fs > 10.0f) {
-            int ex = idx - 1;
-            if (ex >= avail_lo && ex <= avail_hi) {
-              front_obj = fb.front[0]; front_dist = fb.fd[0]; steer_lane = CR.first_lane + ex; decided = true;
-            }
-          }
-          if (!decided && has_r && rs - fs > 10.0f) {
-            int ex = idx + 1;
-            if (ex >= avail_lo && ex <= avail_hi) {
-              front_obj = fb.front[2]; front_dist = fb.fd[2]; steer_lane = CR.first_lane + ex; decided = true;
-            }
-          }
-        }
-        if (!decided) {
-          r.target = NORMAL;
-          r.timer += 1;
-          front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
-        }
+        r.target = NORMAL;
+        r.timer += 1;
+        front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
       }
-    }  // else: reference's assert fails -> except branch: no front object, dist 5
-  } else {
-    Fbo fb;
-    find_front_back(mv, S, base, V, s, objs, rt, MAXD, false, fb);
+    }
+  } else if (!success) {
     front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
   }
+  PHASE_MARK(11);  // idm: lane-change logic
 
   // steering_control (idm_policy.py:244-252)
   const pgd_lane& SL = mv.lanes[steer_lane];
@@ -381,6 +529,7 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const 
   }
   out_steer = steering;
   out_acc = acc;
+  PHASE_MARK(12);  // idm: PID + IDM law
 }
 
 // kinematic bicycle (component/highway_vehicle/kinematics.py:134-156) driven by the reference's action -> force mapping
@@ -395,21 +544,34 @@ DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r) {
     brake = fabsf(r.thr) * p.max_brake_force;
   }
   float delta = -clipf(r.steer, -1.0f, 1.0f) * p.max_steer;
-  float beta = atanf(0.5f * tanf(delta));
-  float sb = sinf(beta);
+  // beta = atan(t), t = tan(delta)/2  ->  cos(beta) = 1/sqrt(1+t^2), sin(beta) = t/sqrt(1+t^2)
+  float t = 0.5f * tanf(delta);
+  float cb = 1.0f / sqrtf(1.0f + t * t), sb = t * cb;
+  // unit vector of the motion direction th + beta, advanced by exact small-angle rotations instead of sincos per sub-step
+  float cd = r.hx * cb - r.hy * sb, sd = r.hy * cb + r.hx * sb;
   float inv_half_base = 2.0f / p.wheelbase;
   float dv_brake = fminf(4.0f * brake / p.mass, p.friction * 9.81f * dt);
   float dv_engine = 4.0f * force / p.mass * dt;
   for (int k = 0; k < d.cfg.decision_repeat; ++k) {
-    float s, c;
-    sincosf(r.th + beta, &s, &c);
-    r.x += r.v * c * dt;
-    r.y += r.v * s * dt;
-    r.th += r.v * sb * inv_half_base * dt;
+    r.x += r.v * cd * dt;
+    r.y += r.v * sd * dt;
+    float dth = r.v * sb * inv_half_base * dt;  // |dth| < 0.25 rad at 80 km/h and full lock
+    r.th += dth;
+    float q = dth * dth;
+    float sn = dth * (1.0f + q * (-1.0f / 6.0f + q * (1.0f / 120.0f + q * (-1.0f / 5040.0f))));
+    float cs = 1.0f + q * (-0.5f + q * (1.0f / 24.0f + q * (-1.0f / 720.0f + q * (1.0f / 40320.0f))));
+    float ncd = cd * cs - sd * sn;
+    sd = sd * cs + cd * sn;
+    cd = ncd;
     if (force != 0.0f) r.v += dv_engine;
     else r.v = fmaxf(0.0f, r.v - dv_brake);
     r.v = fmaxf(r.v, 0.0f);
   }
+  // heading unit vector = motion direction rotated back by beta, renormalised
+  float hx = cd * cb + sd * sb, hy = sd * cb - cd * sb;
+  float inv = 1.0f / sqrtf(hx * hx + hy * hy);
+  r.hx = hx * inv;
+  r.hy = hy * inv;
 }
 
 DEV void reset_vehicle(const pgd_spawn& p, Veh& r) {  // base_vehicle.py:292-339 + idm_policy.py:180-188
@@ -420,6 +582,7 @@ DEV void reset_vehicle(const pgd_spawn& p, Veh& r) {  // base_vehicle.py:292-339
   r.x = p.x; r.y = p.y; r.th = p.heading;
   r.lastx = p.x; r.lasty = p.y;
   sincosf(p.heading, &r.lasthy, &r.lasthx);
+  r.hx = r.lasthx; r.hy = r.lasthy;
   r.target = 30.0f;
   r.lane = p.lane;
   r.ck0 = 0;
@@ -466,19 +629,43 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_step: one env.step() for every environment (base_env.py:184-224)
+// lane -> (group g = lane / SUB, sub-lane); group g -> (env-local el = g / V, slot s = g % V)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
+struct LaneMap {
+  int sub, lead, el, s, e, idx, base;
+  bool valid;
+};
+DEV LaneMap lane_map(const PgdDev& d, int unit, int n_units) {
+  LaneMap m;
+  int lane = threadIdx.x;
+  int g = lane / d.sub;
+  m.sub = lane - g * d.sub;
+  m.lead = g * d.sub;
+  m.el = g / d.V;
+  m.s = g - m.el * d.V;
+  m.e = unit * d.epw + m.el;
+  m.valid = (m.el < d.epw) && (m.e < n_units);
+  m.base = m.el * d.V;
+  m.idx = m.e * d.V + m.s;
+  return m;
+}
+
+extern __shared__ __align__(16) unsigned char s_dyn[];  // [lanes | roads] of the block's map when epw == 1
+
+__global__ __launch_bounds__(WAVE, 4) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags) {
   __shared__ Snap S;
   __shared__ int s_flag[WAVE];
+  __shared__ int s_hit[WAVE];  // per snapshot slot: an agent's chassis overlaps another vehicle
   const int V = d.V, A = d.A, N = d.N;
   const int lane = threadIdx.x;
-  const int el = lane / V, s = lane - el * V;
-  const int e = blockIdx.x * d.epw + el;
-  const bool valid = (el < d.epw) && (e < N);
-  const int base = el * V;
-  const int idx = e * V + s;
+  const LaneMap lm = lane_map(d, blockIdx.x, N);
+  const int el = lm.el, s = lm.s, e = lm.e, base = lm.base;
+  const bool valid = lm.valid, leader = lm.sub == 0;
+  const Grp g{lm.sub, d.sub, lm.lead};
+  const int slot = base + s;  // my entry of the LDS snapshot
 
+  PHASE_INIT();
   Veh r;
   MapView mv;
   const pgd_spawn* sp = nullptr;
@@ -487,33 +674,79 @@ __global__ __launch_bounds__(WAVE) void k_step(PgdDev d, const float* __restrict
   uint32_t steps_total = 0;
   S.present[lane] = 0;
   s_flag[lane] = 0;
-  if (valid) {
-    load_veh(d, idx, r);
-    int scen = d.ei[EI_SCEN * N + e];
+  s_hit[lane] = 0;
+  const bool one_env = d.epw == 1;  // every lane of the wave works on env blockIdx.x
+  int scen = 0;
+  if (one_env || valid) {
+    scen = d.ei[(size_t)((one_env ? (int)blockIdx.x : e)) * PGD_NEI + EI_SCEN];
     sc = d.scen + scen;
+    mv = map_view_of(d, d.scen_map + scen);
+  }
+  if (one_env && d.lds_bytes > 0) {
+    // stage the env's lane + road tables in LDS (coalesced 16 B loads by all 64 lanes)
+    const pgd_map* bm = mv.m;
+    const int nl16 = bm->n_lanes * 4, nr16 = bm->n_roads;  // 16-byte units
+    if ((nl16 + nr16) * 16 <= d.lds_bytes) {
+      const uint4* gl = reinterpret_cast<const uint4*>(mv.lanes);
+      const uint4* gr = reinterpret_cast<const uint4*>(mv.roads);
+      uint4* sl = reinterpret_cast<uint4*>(s_dyn);
+      const int n16 = nl16 + nr16;  // roads follow the lanes in LDS; both source ranges are 16 B aligned
+      for (int k = lane; k < n16; k += 4 * WAVE) {
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int kk = k + j * WAVE;
+          if (kk < n16) v[j] = kk < nl16 ? gl[kk] : gr[kk - nl16];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int kk = k + j * WAVE;
+          if (kk < n16) sl[kk] = v[j];
+        }
+      }
+      mv.lanes = reinterpret_cast<const pgd_lane*>(s_dyn);
+      mv.roads = reinterpret_cast<const pgd_road*>(s_dyn + (size_t)bm->n_lanes * sizeof(pgd_lane));
+    }
+  }
+  PHASE_MARK(13);  // load: scenario + table staging
+  if (valid) {
+    load_veh(d, e, s, r);
     sp = d.spawns + (size_t)scen * V + s;
-    mv = map_view(d, sc->map);
-    ng = d.ei[EI_NEXT_GROUP * N + e];
-    ep_steps = d.ei[EI_EP_STEPS * N + e];
-    steps_total = (uint32_t)d.ei[EI_STEPS_TOTAL * N + e];
+    ng = d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP];
+    ep_steps = d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS];
+    steps_total = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
+  }
+  __syncthreads();
+  if (valid) {
     // (1) TrafficManager.before_step trigger (traffic_manager.py:76-85)
     if (s < A && r.status == ST_ACTIVE && ng < sc->n_groups && mv.lanes[r.lane].road == sc->trigger_road[ng]) s_flag[el] = 1;
   }
   __syncthreads();
+  PHASE_MARK(0);  // load
   const bool trig = valid && s_flag[el] != 0;
   if (trig && r.status == ST_PENDING && sp->group == ng) r.status = ST_ACTIVE;
   if (trig) ng += 1;  // every lane of the env keeps the same copy
   // snapshot of the world before physics
   if (valid) {
-    float sn, cs;
-    sincosf(r.th, &sn, &cs);
-    S.x[lane] = r.x; S.y[lane] = r.y; S.ux[lane] = cs; S.uy[lane] = sn;
-    S.spd[lane] = speed_kmh(r.v);
-    S.hl[lane] = 0.5f * sp->length; S.hw[lane] = 0.5f * sp->width;
-    S.lane[lane] = r.lane;
-    S.present[lane] = (r.status == ST_PENDING || r.status == ST_ACTIVE) ? 1 : 0;
+    if (leader) {
+      S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
+      S.spd[slot] = speed_kmh(r.v);
+      S.hl[slot] = 0.5f * sp->length; S.hw[slot] = 0.5f * sp->width;
+      S.lane[slot] = r.lane;
+      const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE;
+      S.present[slot] = present ? 1 : 0;
+      if (present && V > A) {
+        const pgd_lane& ml = mv.lanes[r.lane];
+        float lo, la;
+        lane_local(ml, r.x, r.y, lo, la);
+        S.lon[slot] = lo;
+        S.llen[slot] = ml.length;
+        S.succ[slot] = *reinterpret_cast<const int4*>(ml.succ);
+      }
+    }
   }
   __syncthreads();
+  PHASE_MARK(1);  // trigger + snapshot
   const bool acting = valid && r.status == ST_ACTIVE;
   // (2) policies
   if (acting) {
@@ -525,40 +758,48 @@ __global__ __launch_bounds__(WAVE) void k_step(PgdDev d, const float* __restrict
       st = clipf(a0, -1.0f, 1.0f);
       tb = clipf(a1, -1.0f, 1.0f);
     } else {
-      idm_act(d, mv, *sp, S, base, V, s, e, steps_total, r, st, tb);
+      idm_act(d, mv, g, *sp, S, base, V, s, e, steps_total, r, st, tb);
     }
+    PHASE_MARK(2);  // policy (IDM)
     // (3) BaseVehicle.before_step (base_vehicle.py:238-253)
     r.vflags &= ~PGD_F_CRASH_VEHICLE;
     r.lastx = r.x; r.lasty = r.y;
-    r.lasthx = S.ux[lane]; r.lasthy = S.uy[lane];
+    r.lasthx = r.hx; r.lasthy = r.hy;
     r.a0s = r.a1s; r.a0t = r.a1t;
     r.a1s = st; r.a1t = tb;
     r.steer = st; r.thr = tb;
     // (4) physics
     dynamics(d, *sp, r);
+    PHASE_MARK(3);  // dynamics
   }
   __syncthreads();
-  if (acting) {
-    float sn, cs;
-    sincosf(r.th, &sn, &cs);
-    S.x[lane] = r.x; S.y[lane] = r.y; S.ux[lane] = cs; S.uy[lane] = sn;
+  if (acting && leader) { S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy; }
+  __syncthreads();
+  // (5) vehicle-vehicle contacts on the post-physics poses (collision_callback.py:7-36): every body in the world tests
+  // itself against each agent of its env, so the A x V pair tests run in parallel lanes
+  if (valid && leader && S.present[slot]) {
+    Obb me = snap_obb(S, slot);
+    for (int a = 0; a < A; ++a)
+      if (a != s && obb_overlap(snap_obb(S, base + a), me)) s_hit[base + a] = 1;
   }
   __syncthreads();
-  // (5) vehicle-vehicle contacts on the post-physics poses (collision_callback.py:7-36)
-  if (acting && s < A) {
-    Obb me = snap_obb(S, lane);
-    bool hit = false;
-    for (int o = 0; o < V; ++o) {
-      if (o == s || !S.present[base + o]) continue;
-      hit = hit || obb_overlap(me, snap_obb(S, base + o));
-    }
-    if (hit) r.vflags |= PGD_F_CRASH_VEHICLE;
-  }
+  if (acting && s < A && s_hit[slot]) r.vflags |= PGD_F_CRASH_VEHICLE;
+  PHASE_MARK(4);  // crash
   // (6) after_step; traffic off the lanes is removed (traffic_manager.py:91-109)
   if (acting) {
-    after_step_vehicle(mv, *sp, r, s < A);
+    after_step_vehicle(mv, g, *sp, r, s < A, !one_env);
     if (s >= A && (r.vflags & PGD_F_OFF_LANE)) r.status = ST_REMOVED;
   }
+  if (one_env) {  // line / sidewalk test of each agent by the whole wave (base_vehicle.py:615-644)
+    if (leader && valid && s < A) s_flag[A + s] = acting ? 1 : 0;
+    __syncthreads();
+    for (int a = 0; a < A; ++a) {
+      if (!s_flag[A + a]) continue;
+      unsigned fl = state_check_wave(mv, snap_obb(S, a));
+      if (valid && s == a) r.vflags |= (int)fl;
+    }
+  }
+  PHASE_MARK(5);  // after_step
   ep_steps += 1;
   steps_total += 1;
   // (7) reward / done (base_env.py:303-344)
@@ -573,49 +814,54 @@ __global__ __launch_bounds__(WAVE) void k_step(PgdDev d, const float* __restrict
     r.eprew += rew;
     bool will_reset = dn && d.cfg.auto_reset && A == 1;
     if (will_reset) { fl |= PGD_F_RESET; s_flag[el] = 1; }
-    size_t k = (size_t)e * A + s;
-    reward[k] = rew;
-    done[k] = dn ? 1 : 0;
-    flags[k] = fl;
+    if (leader) {
+      size_t k = (size_t)e * A + s;
+      reward[k] = rew;
+      done[k] = dn ? 1 : 0;
+      flags[k] = fl;
+    }
   }
   __syncthreads();
+  PHASE_MARK(6);  // reward/done
   // (8) auto reset (base_env.py:269-301): the whole env restarts from its (possibly re-drawn) scenario
   int episodes = 0;
   if (valid && s_flag[el]) {
-    int scen = d.ei[EI_SCEN * N + e];
-    episodes = d.ei[EI_EPISODES * N + e] + 1;
+    episodes = d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] + 1;
     if (d.cfg.resample_scenario)
       scen = (int)(pgd_rng(d.cfg.seed, (uint32_t)e, 0x5ce9a210u, (uint32_t)episodes) % (uint32_t)d.n_scen);
     sc = d.scen + scen;
     sp = d.spawns + (size_t)scen * V + s;
-    mv = map_view(d, sc->map);
+    mv = map_view(d, sc->map);  // global tables: the staged map may not be the new one
     reset_vehicle(*sp, r);
-    if (r.status != ST_EMPTY) after_step_vehicle(mv, *sp, r, s < A);
+    if (r.status != ST_EMPTY) after_step_vehicle(mv, g, *sp, r, s < A, true);
     ng = 0;
     ep_steps = 0;
-    if (s == 0) {
-      d.ei[EI_SCEN * N + e] = scen;
-      d.ei[EI_EPISODES * N + e] = episodes;
+    if (s == 0 && leader) {
+      d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
+      d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] = episodes;
     }
   }
-  if (valid) {
-    store_veh(d, idx, r);
+  PHASE_MARK(7);  // reset
+  if (valid && leader) {
+    store_veh(d, e, s, r);
     if (s == 0) {
-      d.ei[EI_NEXT_GROUP * N + e] = ng;
-      d.ei[EI_EP_STEPS * N + e] = ep_steps;
-      d.ei[EI_STEPS_TOTAL * N + e] = (int)steps_total;
+      d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP] = ng;
+      d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS] = ep_steps;
+      d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL] = (int)steps_total;
     }
   }
+  PHASE_MARK(8);  // store
+  PHASE_END();
 }
 
-// reset of selected envs (base_env.py:269-301); grid = envs, one wave per floor(64/V) envs like k_step
+// reset of selected envs (base_env.py:269-301); same lane mapping as k_step, unit = position in the id list
 __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restrict__ env_ids,
                                                  const int32_t* __restrict__ scen_ids, int n) {
   const int V = d.V, A = d.A, N = d.N;
-  const int lane = threadIdx.x;
-  const int el = lane / V, s = lane - el * V;
-  const int k = blockIdx.x * d.epw + el;
-  if (el >= d.epw || k >= n) return;
+  const LaneMap lm = lane_map(d, blockIdx.x, n);
+  if (!lm.valid) return;
+  const Grp g{lm.sub, d.sub, lm.lead};
+  const int k = lm.e, s = lm.s;
   const int e = env_ids ? env_ids[k] : k;
   const int scen = scen_ids[k];
   const pgd_scenario* sc = d.scen + scen;
@@ -623,31 +869,32 @@ __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restr
   MapView mv = map_view(d, sc->map);
   Veh r;
   reset_vehicle(*sp, r);
-  if (r.status != ST_EMPTY) after_step_vehicle(mv, *sp, r, s < A);
-  store_veh(d, e * V + s, r);
+  if (r.status != ST_EMPTY) after_step_vehicle(mv, g, *sp, r, s < A, true);
+  if (lm.sub != 0) return;
+  store_veh(d, e, s, r);
   if (s == 0) {
-    d.ei[EI_SCEN * N + e] = scen;
-    d.ei[EI_NEXT_GROUP * N + e] = 0;
-    d.ei[EI_EP_STEPS * N + e] = 0;
-    d.ei[EI_EPISODES * N + e] = 0;
-    d.ei[EI_STEPS_TOTAL * N + e] = 0;
+    d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
+    d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP] = 0;
+    d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS] = 0;
+    d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] = 0;
+    d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL] = 0;
   }
 }
 
 // engine.after_step on the current state (used after pgd_set_state)
 __global__ __launch_bounds__(WAVE) void k_refresh(PgdDev d) {
   const int V = d.V, A = d.A, N = d.N;
-  const int lane = threadIdx.x;
-  const int el = lane / V, s = lane - el * V;
-  const int e = blockIdx.x * d.epw + el;
-  if (el >= d.epw || e >= N) return;
+  const LaneMap lm = lane_map(d, blockIdx.x, N);
+  if (!lm.valid) return;
+  const Grp g{lm.sub, d.sub, lm.lead};
+  const int e = lm.e, s = lm.s;
   Veh r;
-  load_veh(d, e * V + s, r);
+  load_veh(d, e, s, r);
   if (r.status != ST_ACTIVE && r.status != ST_PENDING) return;
-  int scen = d.ei[EI_SCEN * N + e];
+  int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
   MapView mv = map_view(d, d.scen[scen].map);
-  after_step_vehicle(mv, d.spawns[(size_t)scen * V + s], r, s < A);
-  store_veh(d, e * V + s, r);
+  after_step_vehicle(mv, g, d.spawns[(size_t)scen * V + s], r, s < A, true);
+  if (lm.sub == 0) store_veh(d, e, s, r);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -692,15 +939,16 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__ obs) {
   __shared__ float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV], bdist[MAXV];
   __shared__ int s_n;
-  const int V = d.V, A = d.A, N = d.N, NV = d.NV, D = d.D;
+  const int V = d.V, A = d.A, NV = d.V, D = d.D;
   const int e = blockIdx.x / A, a = blockIdx.x - e * A;
   const int tid = threadIdx.x;
-  const int me = e * V + a;
-  const float* f = d.f;
+  const int me = a;  // slot of the observing agent inside its env block
+  const float* f = d.f + (size_t)e * (PGD_NF * V);
+  const int32_t* ii = d.i + (size_t)e * (PGD_NI * V);
   const float px = f[SF_X * NV + me], py = f[SF_Y * NV + me], th = f[SF_THETA * NV + me];
   float hy, hx;
   sincosf(th, &hy, &hx);
-  const int scen = d.ei[EI_SCEN * N + e];
+  const int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
   const pgd_spawn* spb = d.spawns + (size_t)scen * V;
   const float R = d.cfg.lidar_dist;
   float* row = obs + ((size_t)e * A + a) * D;
@@ -711,13 +959,13 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
     bool in = false;
     float x = 0, y = 0, ux = 1, uy = 0, hl = 0, hw = 0, spd = 0, dist = 0;
     if (tid < V && tid != a && NL > 0) {
-      int st = d.i[SI_STATUS * NV + e * V + tid];
+      int st = ii[SI_STATUS * NV + tid];
       if (st == ST_PENDING || st == ST_ACTIVE) {
-        x = f[SF_X * NV + e * V + tid]; y = f[SF_Y * NV + e * V + tid];
-        float t = f[SF_THETA * NV + e * V + tid];
+        x = f[SF_X * NV + tid]; y = f[SF_Y * NV + tid];
+        float t = f[SF_THETA * NV + tid];
         sincosf(t, &uy, &ux);
         hl = 0.5f * spb[tid].length; hw = 0.5f * spb[tid].width;
-        spd = speed_kmh(f[SF_SPEED * NV + e * V + tid]);
+        spd = speed_kmh(f[SF_SPEED * NV + tid]);
         in = point_obb_dist(Obb{x, y, ux, uy, hl, hw}, px, py) <= R;
         dist = norm2(px - x, py - y);
       }
@@ -736,7 +984,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
   if (tid < 8 + 10) {
     const pgd_spawn& sp = spb[a];
     MapView mv = map_view(d, d.scen[scen].map);
-    int ck0 = d.i[SI_CK0 * NV + me], ck1 = d.i[SI_CK1 * NV + me];
+    int ck0 = ii[SI_CK0 * NV + me], ck1 = ii[SI_CK1 * NV + me];
     const pgd_road& CR = mv.roads[sp.ckpt_road[ck0]];
     float v = 0.0f;
     if (tid == 0) v = clipf(f[SF_DIST_LEFT * NV + me] / 18.0f, 0.0f, 1.0f);        // (MAX_LANE_NUM+1)*MAX_LANE_WIDTH
@@ -813,6 +1061,10 @@ struct pgd_engine {
   hipEvent_t ev0, ev1;
   bool ev_valid;
   pgd_map* maps; pgd_lane* lanes; pgd_road* roads; pgd_box* boxes; int32_t* cell_start; int32_t* cell_items;
+  pgd_box* cell_boxes;
+  pgd_map* scen_map;  // per scenario: copy of its map header (saves one dependent load per block)
+  std::vector<pgd_map>* h_maps;
+  std::vector<pgd_scenario>* h_scen;
   pgd_scenario* scen; pgd_spawn* spawns;
   int32_t* d_ids;  // scratch [2N]
   bool have_maps, have_scen;
@@ -827,6 +1079,20 @@ static int upload(T** dst, const T* src, size_t n, hipStream_t st) {
   HIPCHK(hipMalloc(dst, sizeof(T) * (n ? n : 1)));
   if (n) HIPCHK(hipMemcpyAsync(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
+  return PGD_OK;
+}
+
+static int build_scen_map(pgd_engine* h) {
+  if (!h->h_maps || !h->h_scen) return PGD_OK;
+  std::vector<pgd_map> sm(h->h_scen->size());
+  for (size_t k = 0; k < sm.size(); ++k) {
+    int m = (*h->h_scen)[k].map;
+    if (m < 0 || m >= (int)h->h_maps->size()) return PGD_ERR_ARG;
+    sm[k] = (*h->h_maps)[m];
+  }
+  int rc = upload(&h->scen_map, sm.data(), sm.size(), h->stream);
+  if (rc) return rc;
+  h->d.scen_map = h->scen_map;
   return PGD_OK;
 }
 
@@ -847,7 +1113,8 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->d.N = cfg->num_envs; h->d.A = cfg->num_agents; h->d.T = cfg->num_traffic; h->d.V = V;
   h->d.D = pgd_obs_dim(cfg);
   h->d.NV = h->d.N * V;
-  h->d.epw = WAVE / V;
+  h->d.sub = WAVE / V < 16 ? WAVE / V : 16;  // sub-lanes per vehicle
+  h->d.epw = WAVE / (V * h->d.sub);          // whole environments per wave
   if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }
   else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
   HIPCHK(hipEventCreate(&h->ev0));
@@ -876,8 +1143,30 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
   if ((rc = upload(&h->boxes, boxes, n_boxes, h->stream))) return rc;
   if ((rc = upload(&h->cell_start, cs, n_cs, h->stream))) return rc;
   if ((rc = upload(&h->cell_items, ci, n_ci, h->stream))) return rc;
+  // cell-major copies of the boxes: cell_boxes[item_off + k] = boxes[box_off + cell_items[item_off + k]] — one dependent
+  // load less per box in the grid walks, and a cell's boxes are contiguous (coalesced across sub-lanes)
+  {
+    std::vector<pgd_box> cb((size_t)(n_ci > 0 ? n_ci : 1));
+    int max_lanes = 0, max_roads = 0;
+    for (int m = 0; m < n_maps; ++m) {
+      const pgd_map& M = maps[m];
+      int n_items = cs[M.cell_off + M.gx * M.gy];
+      for (int k = 0; k < n_items; ++k) cb[(size_t)M.item_off + k] = boxes[M.box_off + ci[M.item_off + k]];
+      if (M.n_lanes > max_lanes) max_lanes = M.n_lanes;
+      if (M.n_roads > max_roads) max_roads = M.n_roads;
+    }
+    if ((rc = upload(&h->cell_boxes, cb.data(), (size_t)n_ci, h->stream))) return rc;
+    size_t need = (size_t)max_lanes * sizeof(pgd_lane) + (size_t)max_roads * sizeof(pgd_road);
+    h->d.lds_bytes = (h->d.epw == 1 && need <= 40 * 1024) ? (int)need : 0;  // else: tables stay in global memory
+    // Measured (profiles/r01_notes.md): staging costs a 36 MB L2 burst per step and loses to plain global reads once the
+    // IDM search stopped touching the lane table (58 vs 49 M env-steps/s); kept as an opt-in for larger-V experiments.
+    if (!getenv("PGD_LDS_TABLES")) h->d.lds_bytes = 0;
+  }
   h->d.maps = h->maps; h->d.lanes = h->lanes; h->d.roads = h->roads; h->d.boxes = h->boxes;
-  h->d.cell_start = h->cell_start; h->d.cell_items = h->cell_items;
+  h->d.cell_start = h->cell_start; h->d.cell_items = h->cell_items; h->d.cell_boxes = h->cell_boxes;
+  if (!h->h_maps) h->h_maps = new std::vector<pgd_map>();
+  h->h_maps->assign(maps, maps + n_maps);
+  if ((rc = build_scen_map(h))) return rc;
   h->have_maps = true;
   return PGD_OK;
 }
@@ -889,6 +1178,9 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   if ((rc = upload(&h->scen, scen, n_scen, h->stream))) return rc;
   if ((rc = upload(&h->spawns, spawns, (size_t)n_scen * h->d.V, h->stream))) return rc;
   h->d.scen = h->scen; h->d.spawns = h->spawns; h->d.n_scen = n_scen;
+  if (!h->h_scen) h->h_scen = new std::vector<pgd_scenario>();
+  h->h_scen->assign(scen, scen + n_scen);
+  if ((rc = build_scen_map(h))) return rc;
   h->have_scen = true;
   return PGD_OK;
 }
@@ -930,7 +1222,8 @@ int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward
   hipEvent_t* pe = prof ? &(*h->prof_ev)[(size_t)h->prof_n * 3] : nullptr;
   HIPCHK(hipEventRecord(prof ? pe[0] : h->ev0, h->stream));
   int blocks = (h->d.N + h->d.epw - 1) / h->d.epw;
-  hipLaunchKernelGGL(k_step, dim3(blocks), dim3(WAVE), 0, h->stream, h->d, d_actions, d_reward, d_done, d_flags);
+  hipLaunchKernelGGL(k_step, dim3(blocks), dim3(WAVE), (size_t)h->d.lds_bytes, h->stream, h->d, d_actions, d_reward, d_done,
+                     d_flags);
   HIPCHK(hipGetLastError());
   if (prof) HIPCHK(hipEventRecord(pe[1], h->stream));
   if (d_obs) {
@@ -959,25 +1252,54 @@ int pgd_state_dims(pgd_handle h, int* nf, int* ni, int* nei) {
   if (nei) *nei = PGD_NEI;
   return PGD_OK;
 }
-int pgd_get_state(pgd_handle h, float* f, int32_t* i, int32_t* ei) {
+}  // extern "C" (state conversion helpers are C++ templates)
+
+// ABI order is field-major ([field][env*V + slot], [field][env]); the device keeps env-major blocks — convert on the host
+template <typename T>
+static void to_abi(const T* dev, T* abi, int n_env, int n_fields, int v) {
+  for (int e = 0; e < n_env; ++e)
+    for (int f = 0; f < n_fields; ++f)
+      for (int s = 0; s < v; ++s) abi[((size_t)f * n_env + e) * v + s] = dev[((size_t)e * n_fields + f) * v + s];
+}
+template <typename T>
+static void from_abi(const T* abi, T* dev, int n_env, int n_fields, int v) {
+  for (int e = 0; e < n_env; ++e)
+    for (int f = 0; f < n_fields; ++f)
+      for (int s = 0; s < v; ++s) dev[((size_t)e * n_fields + f) * v + s] = abi[((size_t)f * n_env + e) * v + s];
+}
+
+extern "C" int pgd_get_state(pgd_handle h, float* f, int32_t* i, int32_t* ei) {
   if (!h || !f || !i || !ei) return PGD_ERR_ARG;
-  size_t nv = (size_t)h->d.NV;
-  HIPCHK(hipMemcpyAsync(f, h->d.f, sizeof(float) * nv * PGD_NF, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(i, h->d.i, sizeof(int32_t) * nv * PGD_NI, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(ei, h->d.ei, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI, hipMemcpyDeviceToHost, h->stream));
+  const size_t nv = (size_t)h->d.NV;
+  const int N = h->d.N, V = h->d.V;
+  std::vector<float> tf(nv * PGD_NF);
+  std::vector<int32_t> ti(nv * PGD_NI), te((size_t)N * PGD_NEI);
+  HIPCHK(hipMemcpyAsync(tf.data(), h->d.f, sizeof(float) * tf.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(ti.data(), h->d.i, sizeof(int32_t) * ti.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(te.data(), h->d.ei, sizeof(int32_t) * te.size(), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  to_abi(tf.data(), f, N, PGD_NF, V);
+  to_abi(ti.data(), i, N, PGD_NI, V);
+  to_abi(te.data(), ei, N, PGD_NEI, 1);
   return PGD_OK;
 }
-int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, const int32_t* ei) {
+extern "C" int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, const int32_t* ei) {
   if (!h || !f || !i || !ei) return PGD_ERR_ARG;
-  size_t nv = (size_t)h->d.NV;
-  HIPCHK(hipMemcpyAsync(h->d.f, f, sizeof(float) * nv * PGD_NF, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d.i, i, sizeof(int32_t) * nv * PGD_NI, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d.ei, ei, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI, hipMemcpyHostToDevice, h->stream));
+  const size_t nv = (size_t)h->d.NV;
+  const int N = h->d.N, V = h->d.V;
+  std::vector<float> tf(nv * PGD_NF);
+  std::vector<int32_t> ti(nv * PGD_NI), te((size_t)N * PGD_NEI);
+  from_abi(f, tf.data(), N, PGD_NF, V);
+  from_abi(i, ti.data(), N, PGD_NI, V);
+  from_abi(ei, te.data(), N, PGD_NEI, 1);
+  HIPCHK(hipMemcpyAsync(h->d.f, tf.data(), sizeof(float) * tf.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d.i, ti.data(), sizeof(int32_t) * ti.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d.ei, te.data(), sizeof(int32_t) * te.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return PGD_OK;
 }
 
+extern "C" {
 int pgd_last_step_ms(pgd_handle h, float* ms) {
   if (!h || !ms || !h->ev_valid) return PGD_ERR_ARG;
   HIPCHK(hipEventSynchronize(h->ev1));
@@ -1017,6 +1339,25 @@ int pgd_profile_end(pgd_handle h, float* k_step_ms, float* k_observe_ms, int* co
   return PGD_OK;
 }
 
+#ifdef PGD_PROF
+int pgd_debug_phase_cycles(pgd_handle h, unsigned long long* out16, int reset) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::vector<unsigned long long> all((size_t)PROF_BLOCKS * 16);
+  HIPCHK(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * all.size()));
+  for (int k = 0; k < 32; ++k) out16[k] = 0;  // [0,16): sums over blocks, [16,32): max over blocks
+  for (size_t b = 0; b < PROF_BLOCKS; ++b)
+    for (int k = 0; k < 16; ++k) {
+      out16[k] += all[b * 16 + k];
+      if (all[b * 16 + k] > out16[16 + k]) out16[16 + k] = all[b * 16 + k];
+    }
+  if (reset) {
+    std::fill(all.begin(), all.end(), 0ull);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), all.data(), sizeof(unsigned long long) * all.size()));
+  }
+  return PGD_OK;
+}
+#endif
+
 int pgd_sync(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1027,7 +1368,7 @@ int pgd_destroy(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->d.f, h->d.i, h->d.ei, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
-                  h->cell_items, h->scen, h->spawns};
+                  h->cell_items, h->cell_boxes, h->scen_map, h->scen, h->spawns};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   (void)hipEventDestroy(h->ev0);
@@ -1036,6 +1377,8 @@ int pgd_destroy(pgd_handle h) {
     for (hipEvent_t ev : *h->prof_ev) (void)hipEventDestroy(ev);
     delete h->prof_ev;
   }
+  delete h->h_maps;
+  delete h->h_scen;
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   free(h);
   return PGD_OK;
