@@ -30,7 +30,20 @@ def algorithmic_bytes(A, T, D):
     V = A + T
     k_step = 2 * V * (23 + 7) * 4 + 40 + 8 * A + V * 48 + 9 * A
     k_obs = V * (5 * 4 + 8) + 4 * A * D + A * 12 * 4
-    return k_step, k_obs
+    fused = k_step + 4 * A * D  # observation fused into k_step: no re-read of the vehicle records, obs row written once
+    return k_step, k_obs, fused
+
+
+def load_traffic(N, args):
+    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate
+    runs of this same command, profiles/r01_pmc_traffic.json); null when the workload differs from the profiled one."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(p):
+        return None
+    t = json.load(open(p))
+    if (t.get("envs"), t.get("traffic"), t.get("lasers")) != (N, args.traffic, args.lasers):
+        return None
+    return t.get("bytes_per_launch")
 
 
 def cpu_baseline(descs, args, seconds=12.0):
@@ -138,7 +151,10 @@ def main():
     if rank == 0:
         total_env_steps = float(N) * world * args.steps
         value = total_env_steps / elapsed
-        b_step, b_obs = algorithmic_bytes(A, args.traffic, D)
+        b_step, b_obs, b_fused = algorithmic_bytes(A, args.traffic, D)
+        fused = prof["k_observe_ms"] == 0.0  # pgd_step ran the observation inside k_step (one env per wave)
+        if fused:
+            b_step, b_obs = b_fused, 0
         dom = "k_observe" if prof["k_observe_ms"] >= prof["k_step_ms"] else "k_step"
         dom_ms = max(prof["k_observe_ms"], prof["k_step_ms"])
         dom_bytes = (b_obs if dom == "k_observe" else b_step) * N
@@ -155,8 +171,8 @@ def main():
                 "parallelism": "env-sharded dp%d%s" % (world, " + RCCL all_gather(obs,reward,done)/step" if gather else ""),
             },
             "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": None,
+                "bound": "hbm", "kernel": dom + (" (observation fused)" if fused else ""), "achieved": achieved,
+                "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": load_traffic(N, args),
                 "bytes_per_env_step": {"k_step": b_step, "k_observe": b_obs},
                 "k_step_ms": prof["k_step_ms"], "k_observe_ms": prof["k_observe_ms"], "events": prof["count"],
             },

@@ -33,10 +33,17 @@ struct PgdDev {
   const pgd_map* scen_map;    // [n_scen] copy of each scenario's map header
   const pgd_spawn* spawns;
   int n_scen;
-  float* f;     // [PGD_NF][NV]
-  int32_t* i;   // [PGD_NI][NV]
-  int32_t* ei;  // [PGD_NEI][N]
+  struct VehRec* rec;  // [N*V] one 128-byte record per vehicle slot (device layout; the ABI blobs are field-major)
+  int32_t* ei;         // [N][PGD_NEI]
 };
+
+// Device-side vehicle record: the PGD_NF float fields followed by the PGD_NI int fields of include/pgd_state_layout.h.
+// 128 B = one cache line per vehicle: a lane loads / stores its vehicle with 8 dwordx4 transactions, full-line writes.
+struct __attribute__((aligned(16))) VehRec {
+  float f[PGD_NF];
+  int32_t i[PGD_NI];
+};
+static_assert(sizeof(VehRec) == 128, "vehicle record must be exactly one 128-byte line");
 
 struct MapView {
   const pgd_map* m;

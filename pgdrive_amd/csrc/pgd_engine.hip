@@ -61,44 +61,38 @@ struct Veh {
   float hx, hy;  // unit heading (cos, sin of th): derived, kept in registers, never stored
 };
 
-// device state is env-major: [env][field][slot] — the V slots of one field are contiguous and an env's whole state is one
-// 2 KB block (full cache lines for the one-env-per-wave kernels); pgd_get/set_state convert to the ABI's field-major order
 DEV void load_veh(const PgdDev& d, int e, int s, Veh& r) {
-  const float* f = d.f + (size_t)e * (PGD_NF * d.V) + s;
-  const int NV = d.V;
-  r.x = f[SF_X * NV]; r.y = f[SF_Y * NV]; r.th = f[SF_THETA * NV]; r.v = f[SF_SPEED * NV];
-  r.steer = f[SF_STEER * NV]; r.thr = f[SF_THROTTLE * NV];
-  r.lastx = f[SF_LASTX * NV]; r.lasty = f[SF_LASTY * NV];
-  r.lasthx = f[SF_LASTHX * NV]; r.lasthy = f[SF_LASTHY * NV];
-  r.a0s = f[SF_ACT0S * NV]; r.a0t = f[SF_ACT0T * NV];
-  r.a1s = f[SF_ACT1S * NV]; r.a1t = f[SF_ACT1T * NV];
-  r.php = f[SF_PID_HP * NV]; r.phi = f[SF_PID_HI * NV];
-  r.plp = f[SF_PID_LP * NV]; r.pli = f[SF_PID_LI * NV];
-  r.target = f[SF_TARGET_SPEED * NV]; r.energy = f[SF_ENERGY * NV];
-  r.dl = f[SF_DIST_LEFT * NV]; r.dr = f[SF_DIST_RIGHT * NV]; r.eprew = f[SF_EP_REWARD * NV];
-  const int32_t* i = d.i + (size_t)e * (PGD_NI * d.V) + s;
-  r.status = i[SI_STATUS * NV]; r.lane = i[SI_LANE * NV]; r.ck0 = i[SI_CK0 * NV];
-  r.ck1 = i[SI_CK1 * NV]; r.rlane = i[SI_RLANE * NV]; r.timer = i[SI_TIMER * NV];
-  r.vflags = i[SI_VFLAGS * NV];
+  VehRec t;
+  const uint4* src = reinterpret_cast<const uint4*>(d.rec + (size_t)e * d.V + s);
+  uint4* dst = reinterpret_cast<uint4*>(&t);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dst[k] = src[k];
+  r.x = t.f[SF_X]; r.y = t.f[SF_Y]; r.th = t.f[SF_THETA]; r.v = t.f[SF_SPEED];
+  r.steer = t.f[SF_STEER]; r.thr = t.f[SF_THROTTLE];
+  r.lastx = t.f[SF_LASTX]; r.lasty = t.f[SF_LASTY]; r.lasthx = t.f[SF_LASTHX]; r.lasthy = t.f[SF_LASTHY];
+  r.a0s = t.f[SF_ACT0S]; r.a0t = t.f[SF_ACT0T]; r.a1s = t.f[SF_ACT1S]; r.a1t = t.f[SF_ACT1T];
+  r.php = t.f[SF_PID_HP]; r.phi = t.f[SF_PID_HI]; r.plp = t.f[SF_PID_LP]; r.pli = t.f[SF_PID_LI];
+  r.target = t.f[SF_TARGET_SPEED]; r.energy = t.f[SF_ENERGY];
+  r.dl = t.f[SF_DIST_LEFT]; r.dr = t.f[SF_DIST_RIGHT]; r.eprew = t.f[SF_EP_REWARD];
+  r.status = t.i[SI_STATUS]; r.lane = t.i[SI_LANE]; r.ck0 = t.i[SI_CK0]; r.ck1 = t.i[SI_CK1];
+  r.rlane = t.i[SI_RLANE]; r.timer = t.i[SI_TIMER]; r.vflags = t.i[SI_VFLAGS];
   sincosf(r.th, &r.hy, &r.hx);
 }
 DEV void store_veh(const PgdDev& d, int e, int s, const Veh& r) {
-  float* f = d.f + (size_t)e * (PGD_NF * d.V) + s;
-  const int NV = d.V;
-  f[SF_X * NV] = r.x; f[SF_Y * NV] = r.y; f[SF_THETA * NV] = r.th; f[SF_SPEED * NV] = r.v;
-  f[SF_STEER * NV] = r.steer; f[SF_THROTTLE * NV] = r.thr;
-  f[SF_LASTX * NV] = r.lastx; f[SF_LASTY * NV] = r.lasty;
-  f[SF_LASTHX * NV] = r.lasthx; f[SF_LASTHY * NV] = r.lasthy;
-  f[SF_ACT0S * NV] = r.a0s; f[SF_ACT0T * NV] = r.a0t;
-  f[SF_ACT1S * NV] = r.a1s; f[SF_ACT1T * NV] = r.a1t;
-  f[SF_PID_HP * NV] = r.php; f[SF_PID_HI * NV] = r.phi;
-  f[SF_PID_LP * NV] = r.plp; f[SF_PID_LI * NV] = r.pli;
-  f[SF_TARGET_SPEED * NV] = r.target; f[SF_ENERGY * NV] = r.energy;
-  f[SF_DIST_LEFT * NV] = r.dl; f[SF_DIST_RIGHT * NV] = r.dr; f[SF_EP_REWARD * NV] = r.eprew;
-  int32_t* i = d.i + (size_t)e * (PGD_NI * d.V) + s;
-  i[SI_STATUS * NV] = r.status; i[SI_LANE * NV] = r.lane; i[SI_CK0 * NV] = r.ck0;
-  i[SI_CK1 * NV] = r.ck1; i[SI_RLANE * NV] = r.rlane; i[SI_TIMER * NV] = r.timer;
-  i[SI_VFLAGS * NV] = r.vflags;
+  VehRec t;
+  t.f[SF_X] = r.x; t.f[SF_Y] = r.y; t.f[SF_THETA] = r.th; t.f[SF_SPEED] = r.v;
+  t.f[SF_STEER] = r.steer; t.f[SF_THROTTLE] = r.thr;
+  t.f[SF_LASTX] = r.lastx; t.f[SF_LASTY] = r.lasty; t.f[SF_LASTHX] = r.lasthx; t.f[SF_LASTHY] = r.lasthy;
+  t.f[SF_ACT0S] = r.a0s; t.f[SF_ACT0T] = r.a0t; t.f[SF_ACT1S] = r.a1s; t.f[SF_ACT1T] = r.a1t;
+  t.f[SF_PID_HP] = r.php; t.f[SF_PID_HI] = r.phi; t.f[SF_PID_LP] = r.plp; t.f[SF_PID_LI] = r.pli;
+  t.f[SF_TARGET_SPEED] = r.target; t.f[SF_ENERGY] = r.energy;
+  t.f[SF_DIST_LEFT] = r.dl; t.f[SF_DIST_RIGHT] = r.dr; t.f[SF_EP_REWARD] = r.eprew; t.f[SF_SPARE] = 0.0f;
+  t.i[SI_STATUS] = r.status; t.i[SI_LANE] = r.lane; t.i[SI_CK0] = r.ck0; t.i[SI_CK1] = r.ck1;
+  t.i[SI_RLANE] = r.rlane; t.i[SI_TIMER] = r.timer; t.i[SI_VFLAGS] = r.vflags; t.i[SI_SPARE] = 0;
+  uint4* dst = reinterpret_cast<uint4*>(d.rec + (size_t)e * d.V + s);
+  const uint4* src = reinterpret_cast<const uint4*>(&t);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dst[k] = src[k];
 }
 
 DEV float speed_kmh(float v) { return clipf(v * 3.6f, 0.0f, 100000.0f); }  // base_vehicle.py:394-401
@@ -628,6 +622,138 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// observation: LidarStateObservation.observe (obs/state_obs.py:132-170) for one (env, agent)
+// ---------------------------------------------------------------------------------------------------------------------
+DEV void navi_info_for(const MapView& mv, int road, int n_cur, float px, float py, float hx, float hy, float* out) {
+  // Navigation._get_info_for_checkpoint (navigation.py:213-260)
+  const pgd_lane& ref = mv.lanes[mv.roads[road].first_lane];
+  float w = mv.m->lane_width;
+  float later_middle = ((float)n_cur * 0.5f - 0.5f) * w;
+  float cx, cy;
+  lane_position(ref, ref.length, later_middle, cx, cy);
+  float dx = cx - px, dy = cy - py;
+  float dn = norm2(dx, dy);
+  if (dn > 50.0f) { dx = dx / dn * 50.0f; dy = dy / dn * 50.0f; }
+  float ph, ps;
+  projection(hx, hy, dx, dy, ph, ps);
+  float bend = 0.0f, dir = 0.0f, angle = 0.0f;
+  if (ref.dir != 0.0f) {
+    bend = ref.bx / (60.0f + n_cur * w);
+    dir = ref.dir;
+    angle = dir == 1.0f ? ref.c - ref.by : ref.by - ref.c;
+  }
+  out[0] = clipf((ph / 50.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
+  out[1] = clipf((ps / 50.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
+  out[2] = clipf(bend, 0.0f, 1.0f);
+  out[3] = clipf((dir + 1.0f) * 0.5f, 0.0f, 1.0f);
+  out[4] = clipf((angle * (180.0f / PGD_PI) / 135.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
+}
+
+DEV float heading_diff(const pgd_lane& l, float px, float py, float fx, float fy) {  // base_vehicle.py:433-458
+  float lx, ly;
+  if (l.dir == 0.0f) { lx = -l.by; ly = l.bx; }
+  else if (l.dir < 0.0f) { lx = px - l.ax; ly = py - l.ay; }
+  else { lx = l.ax - px; ly = l.ay - py; }
+  float ln = norm2(lx, ly), fn = norm2(fx, fy);
+  if (ln * fn == 0.0f) return 0.0f;
+  return clipf((fx * lx + fy * ly) / (ln * fn), -1.0f, 1.0f) * 0.5f + 0.5f;
+}
+
+struct ObsLds {  // vehicles inside the lidar broad phase of the observing agent, compacted
+  float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV], bdist[MAXV];
+  int n;
+};
+struct AgentView {  // what the observation needs from the observing vehicle
+  float x, y, th, hx, hy, dl, dr, v, steer, a0s, a0t, lhx, lhy;
+  int ck0, ck1;
+};
+
+// one wave compacts the candidates: lane `o` brings vehicle o of the env (present = in the physics world)
+DEV void obs_compact(ObsLds& L, int o, int a, bool present, float x, float y, float ux, float uy, float hl, float hw,
+                     float spd, float px, float py, float R) {
+  bool in = present && o != a && point_obb_dist(Obb{x, y, ux, uy, hl, hw}, px, py) <= R;
+  unsigned long long m = __ballot(in);
+  if (in) {
+    int k = __popcll(m & ((1ull << o) - 1ull));
+    L.bx[k] = x; L.by[k] = y; L.bux[k] = ux; L.buy[k] = uy; L.bhl[k] = hl; L.bhw[k] = hw; L.bspd[k] = spd;
+    L.bdist[k] = norm2(px - x, py - y);
+  }
+  if (o == 0) L.n = __popcll(m);
+}
+
+// writes the D floats of one agent's row with `nt` cooperating threads (tid in [0, nt))
+DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const AgentView& ag, const ObsLds& L,
+                       float* __restrict__ row, int tid, int nt) {
+  const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
+  const float R = d.cfg.lidar_dist;
+  const int NL = d.cfg.num_lasers;
+  // StateObservation.vehicle_state (state_obs.py:58-106) + navi info (navigation.py:185-197): one lane per float
+  if (tid < 8 + 10) {
+    const pgd_road& CR = mv.roads[sp.ckpt_road[ag.ck0]];
+    float v = 0.0f;
+    if (tid == 0) v = clipf(ag.dl / 18.0f, 0.0f, 1.0f);  // (MAX_LANE_NUM+1)*MAX_LANE_WIDTH (pg_map.py:13-15)
+    else if (tid == 1) v = clipf(ag.dr / 18.0f, 0.0f, 1.0f);
+    else if (tid == 2) v = heading_diff(mv.lanes[CR.first_lane + CR.n_lanes - 1], px, py, hx, hy);
+    else if (tid == 3) v = clipf((speed_kmh(ag.v) + 1.0f) / (sp.max_speed + 1.0f), 0.0f, 1.0f);
+    else if (tid == 4) v = clipf((ag.steer / 60.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
+    else if (tid == 5) v = clipf((ag.a0s + 1.0f) * 0.5f, 0.0f, 1.0f);
+    else if (tid == 6) v = clipf((ag.a0t + 1.0f) * 0.5f, 0.0f, 1.0f);
+    else if (tid == 7) {
+      // acos(clip(cos_beta, 0, 1)) (state_obs.py:87-92) evaluated as atan2(|cross|, dot): identical for unit vectors,
+      // but well-conditioned in fp32 near beta = 0 where 1 - cos(beta) underflows the mantissa
+      float dot = hx * ag.lhx + hy * ag.lhy, cross = hx * ag.lhy - hy * ag.lhx;
+      float beta = dot <= 0.0f ? 0.5f * PGD_PI : atan2f(fabsf(cross), dot);
+      v = clipf(beta / 0.1f, 0.0f, 1.0f);
+    } else {  // lanes 8..12 -> checkpoint 1, 13..17 -> checkpoint 2
+      int which = (tid - 8) / 5, comp = (tid - 8) - which * 5;
+      float out[5];
+      navi_info_for(mv, sp.ckpt_road[which == 0 ? ag.ck0 : ag.ck1], CR.n_lanes, px, py, hx, hy, out);
+      v = out[comp];
+    }
+    row[tid] = v;
+  }
+  if (NL <= 0) return;
+  // get_surrounding_vehicles_info (lidar.py:55-77): rank by centre distance (stable), 4 floats per neighbour; the last
+  // threads take this part so that it overlaps the state block of the first ones
+  const int NO = d.cfg.num_others;
+  const int n = L.n;
+  for (int k = nt - 1 - tid; k < (n > NO ? n : NO); k += nt) {
+    if (k < n) {
+      int rank = 0;
+      float dk = L.bdist[k];
+      for (int j = 0; j < n; ++j) rank += (L.bdist[j] < dk || (L.bdist[j] == dk && j < k)) ? 1 : 0;
+      if (rank < NO) {
+        float ph, ps;
+        float ms = sp.max_speed;
+        float sp_me = speed_kmh(ag.v);
+        projection(hx, hy, L.bx[k] - px, L.by[k] - py, ph, ps);
+        float* o = row + 18 + rank * 4;
+        o[0] = clipf((ph / R + 1.0f) * 0.5f, 0.0f, 1.0f);
+        o[1] = clipf((ps / R + 1.0f) * 0.5f, 0.0f, 1.0f);
+        projection(hx, hy, L.bspd[k] * L.bux[k] - sp_me * hx, L.bspd[k] * L.buy[k] - sp_me * hy, ph, ps);
+        o[2] = clipf((ph / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
+        o[3] = clipf((ps / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
+      }
+    } else {  // k in [n, NO): absent neighbour -> zeros
+      float* o = row + 18 + k * 4;
+      o[0] = o[1] = o[2] = o[3] = 0.0f;
+    }
+  }
+  // lidar (distance_detector.py:65-94, cutils.pyx:60-142): beam i at theta + i*2pi/N, nearest hit fraction
+  const float unit = 2.0f * PGD_PI / (float)NL;
+  for (int i = tid; i < NL; i += nt) {
+    float ang = (float)i * unit + ag.th;
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    float dx = R * cs, dy = R * sn;
+    float best = 1.0f;
+    for (int k = 0; k < n; ++k)
+      best = fminf(best, ray_obb(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
+    row[18 + 4 * NO + i] = best;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_step: one env.step() for every environment (base_env.py:184-224)
 // lane -> (group g = lane / SUB, sub-lane); group g -> (env-local el = g / V, slot s = g % V)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -652,9 +778,16 @@ DEV LaneMap lane_map(const PgdDev& d, int unit, int n_units) {
 
 extern __shared__ __align__(16) unsigned char s_dyn[];  // [lanes | roads] of the block's map when epw == 1
 
-__global__ __launch_bounds__(WAVE, 4) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
-                                                uint8_t* __restrict__ done, uint32_t* __restrict__ flags) {
+#define FUSE_MAX_AGENTS 8
+#ifndef PGD_WAVES_PER_SIMD
+#define PGD_WAVES_PER_SIMD 3  // <=168 VGPRs: measured 71.4 (3) vs 66.6 (4, 113 spilled VGPRs) M env-steps/s at 4096 envs
+#endif
+__global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
+                                                uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
+                                                float* __restrict__ obs) {
   __shared__ Snap S;
+  __shared__ ObsLds OL;
+  __shared__ AgentView s_ag[FUSE_MAX_AGENTS];
   __shared__ int s_flag[WAVE];
   __shared__ int s_hit[WAVE];  // per snapshot slot: an agent's chassis overlaps another vehicle
   const int V = d.V, A = d.A, N = d.N;
@@ -851,6 +984,37 @@ __global__ __launch_bounds__(WAVE, 4) void k_step(PgdDev d, const float* __restr
     }
   }
   PHASE_MARK(8);  // store
+  // (9) observation of the new state, fused: the wave already holds every vehicle of the env (obs/state_obs.py:132-170)
+  if (obs != nullptr) {  // host passes obs only when one_env && A <= FUSE_MAX_AGENTS
+    __syncthreads();
+    if (valid && leader) {
+      const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE;
+      S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
+      S.spd[slot] = speed_kmh(r.v);
+      S.hl[slot] = 0.5f * sp->length; S.hw[slot] = 0.5f * sp->width;  // the scenario may have changed on reset
+      S.present[slot] = present ? 1 : 0;
+      if (s < A) {
+        AgentView& ag = s_ag[s];
+        ag.x = r.x; ag.y = r.y; ag.th = r.th; ag.hx = r.hx; ag.hy = r.hy; ag.dl = r.dl; ag.dr = r.dr; ag.v = r.v;
+        ag.steer = r.steer; ag.a0s = r.a0s; ag.a0t = r.a0t; ag.lhx = r.lasthx; ag.lhy = r.lasthy;
+        ag.ck0 = r.ck0; ag.ck1 = r.ck1;
+      }
+    }
+    if (lane == 0) s_flag[0] = d.ei[(size_t)blockIdx.x * PGD_NEI + EI_SCEN];  // scenario after a possible reset
+    __syncthreads();
+    const int scen_now = s_flag[0];
+    const MapView mvo = map_view_of(d, d.scen_map + scen_now);
+    for (int a = 0; a < A; ++a) {
+      const AgentView ag = s_ag[a];
+      const bool have = lane < V && d.cfg.num_lasers > 0;
+      obs_compact(OL, lane, a, have && S.present[lane], S.x[lane], S.y[lane], S.ux[lane], S.uy[lane], S.hl[lane], S.hw[lane],
+                  S.spd[lane], ag.x, ag.y, d.cfg.lidar_dist);
+      __syncthreads();
+      observe_agent(d, mvo, d.spawns[(size_t)scen_now * V + a], ag, OL, obs + ((size_t)blockIdx.x * A + a) * d.D, lane, WAVE);
+      __syncthreads();
+    }
+  }
+  PHASE_MARK(14);  // fused observation
   PHASE_END();
 }
 
@@ -898,156 +1062,41 @@ __global__ __launch_bounds__(WAVE) void k_refresh(PgdDev d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_observe: LidarStateObservation.observe (obs/state_obs.py:132-170) for every (env, agent)
+// k_observe: stand-alone observation kernel, one block per (env, agent).  pgd_step fuses the observation into k_step when
+// a wave carries exactly one env; this kernel serves pgd_reset / pgd_observe and the configurations that do not fuse.
 // ---------------------------------------------------------------------------------------------------------------------
-DEV void navi_info_for(const MapView& mv, int road, int n_cur, float px, float py, float hx, float hy, float* out) {
-  // Navigation._get_info_for_checkpoint (navigation.py:213-260)
-  const pgd_lane& ref = mv.lanes[mv.roads[road].first_lane];
-  float w = mv.m->lane_width;
-  float later_middle = ((float)n_cur * 0.5f - 0.5f) * w;
-  float cx, cy;
-  lane_position(ref, ref.length, later_middle, cx, cy);
-  float dx = cx - px, dy = cy - py;
-  float dn = norm2(dx, dy);
-  if (dn > 50.0f) { dx = dx / dn * 50.0f; dy = dy / dn * 50.0f; }
-  float ph, ps;
-  projection(hx, hy, dx, dy, ph, ps);
-  float bend = 0.0f, dir = 0.0f, angle = 0.0f;
-  if (ref.dir != 0.0f) {
-    bend = ref.bx / (60.0f + n_cur * w);
-    dir = ref.dir;
-    angle = dir == 1.0f ? ref.c - ref.by : ref.by - ref.c;
-  }
-  out[0] = clipf((ph / 50.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
-  out[1] = clipf((ps / 50.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
-  out[2] = clipf(bend, 0.0f, 1.0f);
-  out[3] = clipf((dir + 1.0f) * 0.5f, 0.0f, 1.0f);
-  out[4] = clipf((angle * (180.0f / PGD_PI) / 135.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
-}
-
-DEV float heading_diff(const pgd_lane& l, float px, float py, float fx, float fy) {  // base_vehicle.py:433-458
-  float lx, ly;
-  if (l.dir == 0.0f) { lx = -l.by; ly = l.bx; }
-  else if (l.dir < 0.0f) { lx = px - l.ax; ly = py - l.ay; }
-  else { lx = l.ax - px; ly = l.ay - py; }
-  float ln = norm2(lx, ly), fn = norm2(fx, fy);
-  if (ln * fn == 0.0f) return 0.0f;
-  return clipf((fx * lx + fy * ly) / (ln * fn), -1.0f, 1.0f) * 0.5f + 0.5f;
-}
-
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__ obs) {
-  __shared__ float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV], bdist[MAXV];
-  __shared__ int s_n;
-  const int V = d.V, A = d.A, NV = d.V, D = d.D;
+  __shared__ ObsLds L;
+  const int V = d.V, A = d.A, D = d.D;
   const int e = blockIdx.x / A, a = blockIdx.x - e * A;
   const int tid = threadIdx.x;
-  const int me = a;  // slot of the observing agent inside its env block
-  const float* f = d.f + (size_t)e * (PGD_NF * V);
-  const int32_t* ii = d.i + (size_t)e * (PGD_NI * V);
-  const float px = f[SF_X * NV + me], py = f[SF_Y * NV + me], th = f[SF_THETA * NV + me];
-  float hy, hx;
-  sincosf(th, &hy, &hx);
+  const VehRec* recs = d.rec + (size_t)e * V;  // the env's vehicle records
+  const VehRec& mine = recs[a];
+  AgentView ag;
+  ag.x = mine.f[SF_X]; ag.y = mine.f[SF_Y]; ag.th = mine.f[SF_THETA];
+  sincosf(ag.th, &ag.hy, &ag.hx);
+  ag.dl = mine.f[SF_DIST_LEFT]; ag.dr = mine.f[SF_DIST_RIGHT]; ag.v = mine.f[SF_SPEED]; ag.steer = mine.f[SF_STEER];
+  ag.a0s = mine.f[SF_ACT0S]; ag.a0t = mine.f[SF_ACT0T]; ag.lhx = mine.f[SF_LASTHX]; ag.lhy = mine.f[SF_LASTHY];
+  ag.ck0 = mine.i[SI_CK0]; ag.ck1 = mine.i[SI_CK1];
   const int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
   const pgd_spawn* spb = d.spawns + (size_t)scen * V;
-  const float R = d.cfg.lidar_dist;
-  float* row = obs + ((size_t)e * A + a) * D;
-  const int NL = d.cfg.num_lasers;
-
-  // wave 0: compact the vehicles inside the r = R broad phase (lidar.py:109-124) into LDS
-  if (tid < WAVE) {
-    bool in = false;
-    float x = 0, y = 0, ux = 1, uy = 0, hl = 0, hw = 0, spd = 0, dist = 0;
-    if (tid < V && tid != a && NL > 0) {
-      int st = ii[SI_STATUS * NV + tid];
-      if (st == ST_PENDING || st == ST_ACTIVE) {
-        x = f[SF_X * NV + tid]; y = f[SF_Y * NV + tid];
-        float t = f[SF_THETA * NV + tid];
-        sincosf(t, &uy, &ux);
-        hl = 0.5f * spb[tid].length; hw = 0.5f * spb[tid].width;
-        spd = speed_kmh(f[SF_SPEED * NV + tid]);
-        in = point_obb_dist(Obb{x, y, ux, uy, hl, hw}, px, py) <= R;
-        dist = norm2(px - x, py - y);
-      }
+  if (tid < WAVE) {  // wave 0: broad phase r = lidar distance (lidar.py:109-124), compacted into LDS
+    bool present = false;
+    float x = 0, y = 0, ux = 1, uy = 0, hl = 0, hw = 0, spd = 0;
+    if (tid < V && d.cfg.num_lasers > 0) {
+      int st = recs[tid].i[SI_STATUS];
+      present = st == ST_PENDING || st == ST_ACTIVE;
+      x = recs[tid].f[SF_X]; y = recs[tid].f[SF_Y];
+      sincosf(recs[tid].f[SF_THETA], &uy, &ux);
+      hl = 0.5f * spb[tid].length; hw = 0.5f * spb[tid].width;
+      spd = speed_kmh(recs[tid].f[SF_SPEED]);
     }
-    unsigned long long m = __ballot(in);
-    if (in) {
-      int k = __popcll(m & ((1ull << tid) - 1ull));
-      bx[k] = x; by[k] = y; bux[k] = ux; buy[k] = uy; bhl[k] = hl; bhw[k] = hw; bspd[k] = spd; bdist[k] = dist;
-    }
-    if (tid == 0) s_n = __popcll(m);
+    obs_compact(L, tid, a, present, x, y, ux, uy, hl, hw, spd, ag.x, ag.y, d.cfg.lidar_dist);
   }
   __syncthreads();
-  const int n = s_n;
-
-  // StateObservation.vehicle_state (state_obs.py:58-106): 8 floats, one lane each
-  if (tid < 8 + 10) {
-    const pgd_spawn& sp = spb[a];
-    MapView mv = map_view(d, d.scen[scen].map);
-    int ck0 = ii[SI_CK0 * NV + me], ck1 = ii[SI_CK1 * NV + me];
-    const pgd_road& CR = mv.roads[sp.ckpt_road[ck0]];
-    float v = 0.0f;
-    if (tid == 0) v = clipf(f[SF_DIST_LEFT * NV + me] / 18.0f, 0.0f, 1.0f);        // (MAX_LANE_NUM+1)*MAX_LANE_WIDTH
-    else if (tid == 1) v = clipf(f[SF_DIST_RIGHT * NV + me] / 18.0f, 0.0f, 1.0f);
-    else if (tid == 2) v = heading_diff(mv.lanes[CR.first_lane + CR.n_lanes - 1], px, py, hx, hy);
-    else if (tid == 3) v = clipf((speed_kmh(f[SF_SPEED * NV + me]) + 1.0f) / (sp.max_speed + 1.0f), 0.0f, 1.0f);
-    else if (tid == 4) v = clipf((f[SF_STEER * NV + me] / 60.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
-    else if (tid == 5) v = clipf((f[SF_ACT0S * NV + me] + 1.0f) * 0.5f, 0.0f, 1.0f);
-    else if (tid == 6) v = clipf((f[SF_ACT0T * NV + me] + 1.0f) * 0.5f, 0.0f, 1.0f);
-    else if (tid == 7) {
-      float lhx = f[SF_LASTHX * NV + me], lhy = f[SF_LASTHY * NV + me];
-      // acos(clip(cos_beta, 0, 1)) (state_obs.py:87-92) evaluated as atan2(|cross|, dot): identical for unit vectors,
-      // but well-conditioned in fp32 near beta = 0 where 1 - cos(beta) underflows the mantissa
-      float dot = hx * lhx + hy * lhy, cross = hx * lhy - hy * lhx;
-      float beta = dot <= 0.0f ? 0.5f * PGD_PI : atan2f(fabsf(cross), dot);
-      v = clipf(beta / 0.1f, 0.0f, 1.0f);
-    } else {  // navi info: lanes 8..12 -> checkpoint 1, 13..17 -> checkpoint 2 (navigation.py:185-197)
-      int which = (tid - 8) / 5, comp = (tid - 8) - which * 5;
-      float out[5];
-      navi_info_for(mv, sp.ckpt_road[which == 0 ? ck0 : ck1], CR.n_lanes, px, py, hx, hy, out);
-      v = out[comp];
-    }
-    row[tid] = v;
-  }
-  if (NL <= 0) return;
-
-  // get_surrounding_vehicles_info (lidar.py:55-77): rank by centre distance (stable), 4 floats per neighbour
-  const int NO = d.cfg.num_others;
-  if (tid >= WAVE && tid < WAVE + MAXV) {
-    int k = tid - WAVE;
-    if (k < n) {
-      int rank = 0;
-      float dk = bdist[k];
-      for (int j = 0; j < n; ++j) rank += (bdist[j] < dk || (bdist[j] == dk && j < k)) ? 1 : 0;
-      if (rank < NO) {
-        float ph, ps;
-        float ms = spb[a].max_speed;
-        float sp_me = speed_kmh(f[SF_SPEED * NV + me]);
-        projection(hx, hy, bx[k] - px, by[k] - py, ph, ps);
-        float* o = row + 18 + rank * 4;
-        o[0] = clipf((ph / R + 1.0f) * 0.5f, 0.0f, 1.0f);
-        o[1] = clipf((ps / R + 1.0f) * 0.5f, 0.0f, 1.0f);
-        projection(hx, hy, bspd[k] * bux[k] - sp_me * hx, bspd[k] * buy[k] - sp_me * hy, ph, ps);
-        o[2] = clipf((ph / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
-        o[3] = clipf((ps / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
-      }
-    } else if (k < NO) {
-      float* o = row + 18 + k * 4;
-      o[0] = o[1] = o[2] = o[3] = 0.0f;
-    }
-  }
-
-  // lidar (distance_detector.py:65-94, cutils.pyx:60-142): beam i at theta + i*2pi/N, nearest hit fraction
-  const float unit = 2.0f * PGD_PI / (float)NL;
-  for (int i = tid; i < NL; i += BLOCK) {
-    float ang = (float)i * unit + th;
-    float sn, cs;
-    sincosf(ang, &sn, &cs);
-    float dx = R * cs, dy = R * sn;
-    float best = 1.0f;
-    for (int k = 0; k < n; ++k) best = fminf(best, ray_obb(Obb{bx[k], by[k], bux[k], buy[k], bhl[k], bhw[k]}, px, py, dx, dy));
-    row[18 + 4 * NO + i] = best;
-  }
+  MapView mv = map_view_of(d, d.scen_map + scen);
+  observe_agent(d, mv, spb[a], ag, L, obs + ((size_t)e * A + a) * D, tid, BLOCK);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1071,6 +1120,7 @@ struct pgd_engine {
   // per-kernel HIP-event profile of pgd_step launches (bench.py roofline numbers)
   std::vector<hipEvent_t>* prof_ev;  // 3 events per recorded step
   int prof_cap, prof_n;
+  bool prof_fused;
 };
 
 template <typename T>
@@ -1120,12 +1170,10 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipEventCreate(&h->ev1));
   size_t nv = (size_t)h->d.NV;
-  HIPCHK(hipMalloc(&h->d.f, sizeof(float) * nv * PGD_NF));
-  HIPCHK(hipMalloc(&h->d.i, sizeof(int32_t) * nv * PGD_NI));
+  HIPCHK(hipMalloc(&h->d.rec, sizeof(VehRec) * nv));
   HIPCHK(hipMalloc(&h->d.ei, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI));
   HIPCHK(hipMalloc(&h->d_ids, sizeof(int32_t) * (size_t)h->d.N * 2));
-  HIPCHK(hipMemsetAsync(h->d.f, 0, sizeof(float) * nv * PGD_NF, h->stream));
-  HIPCHK(hipMemsetAsync(h->d.i, 0, sizeof(int32_t) * nv * PGD_NI, h->stream));
+  HIPCHK(hipMemsetAsync(h->d.rec, 0, sizeof(VehRec) * nv, h->stream));
   HIPCHK(hipMemsetAsync(h->d.ei, 0, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI, h->stream));
   *out = h;
   return PGD_OK;
@@ -1222,15 +1270,17 @@ int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward
   hipEvent_t* pe = prof ? &(*h->prof_ev)[(size_t)h->prof_n * 3] : nullptr;
   HIPCHK(hipEventRecord(prof ? pe[0] : h->ev0, h->stream));
   int blocks = (h->d.N + h->d.epw - 1) / h->d.epw;
+  const bool fuse = d_obs && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !getenv("PGD_NO_FUSE");
   hipLaunchKernelGGL(k_step, dim3(blocks), dim3(WAVE), (size_t)h->d.lds_bytes, h->stream, h->d, d_actions, d_reward, d_done,
-                     d_flags);
+                     d_flags, fuse ? d_obs : (float*)nullptr);
   HIPCHK(hipGetLastError());
   if (prof) HIPCHK(hipEventRecord(pe[1], h->stream));
-  if (d_obs) {
+  if (d_obs && !fuse) {
     int rc = launch_observe(h, d_obs);
     if (rc) return rc;
   }
-  HIPCHK(hipEventRecord(prof ? pe[2] : h->ev1, h->stream));
+  h->prof_fused = fuse;
+  if (!(prof && fuse)) HIPCHK(hipEventRecord(prof ? pe[2] : h->ev1, h->stream));  // fused: [0],[1] bracket the only kernel
   if (prof) h->prof_n += 1;
   else h->ev_valid = true;
   return PGD_OK;
@@ -1254,46 +1304,38 @@ int pgd_state_dims(pgd_handle h, int* nf, int* ni, int* nei) {
 }
 }  // extern "C" (state conversion helpers are C++ templates)
 
-// ABI order is field-major ([field][env*V + slot], [field][env]); the device keeps env-major blocks — convert on the host
-template <typename T>
-static void to_abi(const T* dev, T* abi, int n_env, int n_fields, int v) {
-  for (int e = 0; e < n_env; ++e)
-    for (int f = 0; f < n_fields; ++f)
-      for (int s = 0; s < v; ++s) abi[((size_t)f * n_env + e) * v + s] = dev[((size_t)e * n_fields + f) * v + s];
-}
-template <typename T>
-static void from_abi(const T* abi, T* dev, int n_env, int n_fields, int v) {
-  for (int e = 0; e < n_env; ++e)
-    for (int f = 0; f < n_fields; ++f)
-      for (int s = 0; s < v; ++s) dev[((size_t)e * n_fields + f) * v + s] = abi[((size_t)f * n_env + e) * v + s];
-}
-
+// ABI order is field-major ([field][env*V + slot], [field][env]); the device keeps one 128 B record per vehicle and one
+// PGD_NEI-int row per env — converted on the host
 extern "C" int pgd_get_state(pgd_handle h, float* f, int32_t* i, int32_t* ei) {
   if (!h || !f || !i || !ei) return PGD_ERR_ARG;
   const size_t nv = (size_t)h->d.NV;
-  const int N = h->d.N, V = h->d.V;
-  std::vector<float> tf(nv * PGD_NF);
-  std::vector<int32_t> ti(nv * PGD_NI), te((size_t)N * PGD_NEI);
-  HIPCHK(hipMemcpyAsync(tf.data(), h->d.f, sizeof(float) * tf.size(), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(ti.data(), h->d.i, sizeof(int32_t) * ti.size(), hipMemcpyDeviceToHost, h->stream));
+  const int N = h->d.N;
+  std::vector<VehRec> tr(nv);
+  std::vector<int32_t> te((size_t)N * PGD_NEI);
+  HIPCHK(hipMemcpyAsync(tr.data(), h->d.rec, sizeof(VehRec) * nv, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(te.data(), h->d.ei, sizeof(int32_t) * te.size(), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  to_abi(tf.data(), f, N, PGD_NF, V);
-  to_abi(ti.data(), i, N, PGD_NI, V);
-  to_abi(te.data(), ei, N, PGD_NEI, 1);
+  for (size_t k = 0; k < nv; ++k) {
+    for (int q = 0; q < PGD_NF; ++q) f[(size_t)q * nv + k] = tr[k].f[q];
+    for (int q = 0; q < PGD_NI; ++q) i[(size_t)q * nv + k] = tr[k].i[q];
+  }
+  for (int e = 0; e < N; ++e)
+    for (int q = 0; q < PGD_NEI; ++q) ei[(size_t)q * N + e] = te[(size_t)e * PGD_NEI + q];
   return PGD_OK;
 }
 extern "C" int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, const int32_t* ei) {
   if (!h || !f || !i || !ei) return PGD_ERR_ARG;
   const size_t nv = (size_t)h->d.NV;
-  const int N = h->d.N, V = h->d.V;
-  std::vector<float> tf(nv * PGD_NF);
-  std::vector<int32_t> ti(nv * PGD_NI), te((size_t)N * PGD_NEI);
-  from_abi(f, tf.data(), N, PGD_NF, V);
-  from_abi(i, ti.data(), N, PGD_NI, V);
-  from_abi(ei, te.data(), N, PGD_NEI, 1);
-  HIPCHK(hipMemcpyAsync(h->d.f, tf.data(), sizeof(float) * tf.size(), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d.i, ti.data(), sizeof(int32_t) * ti.size(), hipMemcpyHostToDevice, h->stream));
+  const int N = h->d.N;
+  std::vector<VehRec> tr(nv);
+  std::vector<int32_t> te((size_t)N * PGD_NEI);
+  for (size_t k = 0; k < nv; ++k) {
+    for (int q = 0; q < PGD_NF; ++q) tr[k].f[q] = f[(size_t)q * nv + k];
+    for (int q = 0; q < PGD_NI; ++q) tr[k].i[q] = i[(size_t)q * nv + k];
+  }
+  for (int e = 0; e < N; ++e)
+    for (int q = 0; q < PGD_NEI; ++q) te[(size_t)e * PGD_NEI + q] = ei[(size_t)q * N + e];
+  HIPCHK(hipMemcpyAsync(h->d.rec, tr.data(), sizeof(VehRec) * nv, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d.ei, te.data(), sizeof(int32_t) * te.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return PGD_OK;
@@ -1327,7 +1369,7 @@ int pgd_profile_end(pgd_handle h, float* k_step_ms, float* k_observe_ms, int* co
   for (int k = 0; k < h->prof_n; ++k) {
     float t0 = 0.f, t1 = 0.f;
     HIPCHK(hipEventElapsedTime(&t0, (*h->prof_ev)[(size_t)k * 3], (*h->prof_ev)[(size_t)k * 3 + 1]));
-    HIPCHK(hipEventElapsedTime(&t1, (*h->prof_ev)[(size_t)k * 3 + 1], (*h->prof_ev)[(size_t)k * 3 + 2]));
+    if (!h->prof_fused) HIPCHK(hipEventElapsedTime(&t1, (*h->prof_ev)[(size_t)k * 3 + 1], (*h->prof_ev)[(size_t)k * 3 + 2]));
     a += t0;
     b += t1;
   }
@@ -1367,7 +1409,7 @@ int pgd_sync(pgd_handle h) {
 int pgd_destroy(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   (void)hipStreamSynchronize(h->stream);
-  void* bufs[] = {h->d.f, h->d.i, h->d.ei, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
+  void* bufs[] = {h->d.rec, h->d.ei, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
                   h->cell_items, h->cell_boxes, h->scen_map, h->scen, h->spawns};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
