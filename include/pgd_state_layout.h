@@ -21,17 +21,17 @@ enum {
   SF_ENERGY,                  /* energy_consumption                     base_vehicle.py:278-290 */
   SF_DIST_LEFT, SF_DIST_RIGHT,/* dist_to_left_side / right_side         base_vehicle.py:380-388 */
   SF_EP_REWARD,               /* episode_rewards                        base_env.py:335-339 */
-  SF_SPARE,
+  SF_AGENT_ID,                /* multi-agent: k of "agent{k}" (integer-valued)  agent_manager.py:154-175 */
   PGD_NF
 };
 enum {
   SI_STATUS = 0,              /* ST_* */
   SI_LANE,                    /* vehicle.lane (map-local id) */
   SI_CK0, SI_CK1,             /* Navigation._target_checkpoints_index   navigation.py:132 */
-  SI_RLANE,                   /* IDMPolicy.routing_target_lane (-1 = None) */
-  SI_TIMER,                   /* IDMPolicy.overtake_timer */
+  SI_RLANE,                   /* traffic: IDMPolicy.routing_target_lane (-1 = None); agents: episode_length (base_env.py:338) */
+  SI_TIMER,                   /* traffic: IDMPolicy.overtake_timer; dying agents: delay-done countdown (agent_manager.py:191-199) */
   SI_VFLAGS,                  /* PGD_F_* vehicle state bits */
-  SI_SPARE,
+  SI_SPAWN,                   /* index of the slot's pgd_spawn record inside its scenario (slot id, or a respawn record) */
   PGD_NI
 };
 enum {
@@ -40,9 +40,10 @@ enum {
   EI_EP_STEPS,                /* episode_steps                          base_env.py:185 */
   EI_EPISODES,                /* auto-reset count (RNG counter) */
   EI_STEPS_TOTAL,             /* steps since pgd_reset (RNG counter) */
-  EI_SPARE0, EI_SPARE1, EI_SPARE2,
+  EI_NEXT_AGENT,              /* next "agent{k}" id (AgentManager.next_agent_count) */
+  EI_SPARE1, EI_SPARE2,
   PGD_NEI
 };
-enum { ST_EMPTY = 0, ST_PENDING = 1, ST_ACTIVE = 2, ST_REMOVED = 3 };
+enum { ST_EMPTY = 0, ST_PENDING = 1, ST_ACTIVE = 2, ST_REMOVED = 3, ST_DYING = 4 /* finished agent, static, counting down */ };
 
 #endif

@@ -57,6 +57,9 @@ extern "C" {
 #define PGD_F_OFF_LANE      (1u << 12)  /* not on_lane           navigation.py:158-160 */
 #define PGD_F_OUT_OF_ROUTE  (1u << 13)  /* out_of_route          base_vehicle.py:274-276 */
 #define PGD_F_RESET         (1u << 16)  /* this env was auto-reset at the end of the step (obs is the new episode's) */
+#define PGD_F_REPORT        (1u << 17)  /* multi-agent: the slot held an active agent this step: obs/reward/done are valid */
+#define PGD_F_NEW           (1u << 18)  /* multi-agent: an agent was (re)spawned into this slot: obs valid, reward 0 */
+#define PGD_F_ALL_DONE      (1u << 19)  /* multi-agent: done["__all__"] (multi_agent_pgdrive.py:142-148) */
 
 typedef struct __attribute__((aligned(16))) pgd_lane {   /* 64 B */
   float ax, ay;             /* straight: start point; circular: centre */
@@ -146,9 +149,19 @@ typedef struct pgd_config {
   float driving_reward, speed_reward;
   int32_t use_lateral;
   int32_t out_of_route_done;
-  int32_t traffic_ghost;    /* reserved */
-  int32_t pad[3];
+  /* multi-agent (envs/marl_envs/multi_agent_pgdrive.py:12-55); all zero for the single-agent PGDriveEnv */
+  int32_t marl_flags;       /* PGD_MA_* bits */
+  int32_t delay_done;       /* steps a finished agent stays as a static obstacle (25) */
+  int32_t agent_limit;      /* num_agents of the reference: respawn only while active + dying < agent_limit */
+  int32_t respawn_places;   /* P safe spawn places (SpawnManager.safe_spawn_places, spawn_manager.py:114-155) */
+  int32_t respawn_dests;    /* Dn destinations; every scenario carries P*Dn extra pgd_spawn records after its V slots */
+  int32_t pad;
 } pgd_config;
+
+#define PGD_MA_ENABLED        1  /* MultiAgentPGDrive semantics: per-agent done, delay-done queue, respawn, __all__ */
+#define PGD_MA_CRASH_DONE     2  /* crash_done       (multi_agent_pgdrive.py:21) */
+#define PGD_MA_OUT_ROAD_DONE  4  /* out_of_road_done (multi_agent_pgdrive.py:22) */
+#define PGD_MA_ALLOW_RESPAWN  8  /* allow_respawn    (multi_agent_pgdrive.py:26) */
 
 typedef struct pgd_engine* pgd_handle;
 

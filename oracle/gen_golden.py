@@ -494,6 +494,37 @@ def gen_seeding(out_json):
     out_json["vehicle_params"] = params
 
 
+def gen_marl(out_json):
+    """Multi-agent roundabout: spawn slot table from the reference's own Road / lane objects
+    (SpawnManager._auto_fill_spawn_roads_randomly, spawn_manager.py:114-155; MARoundaboutConfig.spawn_roads,
+    marl_inout_roundabout.py:15-28) and the destination node of every negated spawn road."""
+    from pgdrive.component.blocks.first_block import FirstPGBlock
+    from pgdrive.component.blocks.roundabout import Roundabout
+    from pgdrive.component.road.road import Road
+    m = ref_export.generate_ma_roundabout()
+    net = m["net"]
+    spawn_roads = [
+        Road(FirstPGBlock.NODE_2, FirstPGBlock.NODE_3),
+        -Road(Roundabout.node(1, 0, 2), Roundabout.node(1, 0, 3)),
+        -Road(Roundabout.node(1, 1, 2), Roundabout.node(1, 1, 3)),
+        -Road(Roundabout.node(1, 2, 2), Roundabout.node(1, 2, 3)),
+    ]
+    exit_length = 60 - FirstPGBlock.ENTRANCE_LENGTH
+    num_slots = int(math.floor(exit_length / 8.0))
+    rows = []
+    for road in spawn_roads:
+        lanes = road.get_lanes(net)
+        for lane_idx in range(2):
+            for j in range(num_slots):
+                long = 4.0 + j * 8.0
+                p = lanes[lane_idx].position(long, 0)
+                rows.append(dict(road=[road.start_node, road.end_node], lane_idx=lane_idx, j=j, long=long,
+                                 x=float(p[0]), y=float(p[1]), heading=float(lanes[lane_idx].heading_at(long))))
+    out_json["marl_slots"] = rows
+    out_json["marl_dest_nodes"] = [(-r).end_node for r in spawn_roads]
+    out_json["marl_capacity"] = 2 * len(spawn_roads) * num_slots
+
+
 def main():
     rng = np.random.default_rng(20240927)
     out = {}
@@ -508,6 +539,7 @@ def main():
     gen_scenes(rng, maps, out_json)
     gen_checkpoints(rng, maps, out_json)
     gen_seeding(out_json)
+    gen_marl(out_json)
     gd = os.path.join(ROOT, "tests", "golden")
     np.savez_compressed(os.path.join(gd, "routines_v0.npz"), **out)
     with open(os.path.join(gd, "scenes_v0.json"), "w") as f:

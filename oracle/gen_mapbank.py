@@ -39,5 +39,22 @@ def main():
     print("wrote", out, os.path.getsize(out))
 
 
+def main_marl():
+    """MARoundaboutMap (envs/marl_envs/marl_inout_roundabout.py:30-63) -> pgdrive_amd/assets/ma_roundabout_v0.json.gz
+    + tests/golden/boxes_ma_roundabout.npz"""
+    root = os.path.dirname(HERE)
+    m = ref_export.generate_ma_roundabout()
+    np.savez_compressed(os.path.join(root, "tests", "golden", "boxes_ma_roundabout.npz"), boxes=m["boxes"])
+    out = os.path.join(root, "pgdrive_amd", "assets", "ma_roundabout_v0.json.gz")
+    with gzip.GzipFile(out, "wb", mtime=0) as f:
+        f.write(json.dumps(dict(version=0, source="decisionforce/pgdrive v0.1.4 MARoundaboutMap (lane_num=2, "
+                                "exit_length=60, exit_radius=10, inner_radius=30, angle=70)", maps=[strip(m)]),
+                           separators=(",", ":")).encode())
+    print("wrote", out, os.path.getsize(out))
+
+
 if __name__ == "__main__":
-    main()
+    if "--marl" in sys.argv:
+        main_marl()
+    else:
+        main()

@@ -69,14 +69,37 @@ def _color_code(c):
     return 1 if tuple(c) == tuple(LineColor.YELLOW) else 0
 
 
-def generate(seed, lane_num=3, lane_width=3.5, exit_length=50, block_num=None, block_seq=None):
-    """Run the reference BIG and flatten the result into plain python/numpy data."""
+class _Blocks:
+    def __init__(self, blocks):
+        self.blocks = blocks
+
+
+def generate_ma_roundabout(lane_num=2, lane_width=3.5, exit_length=60):
+    """MARoundaboutMap._generate (envs/marl_envs/marl_inout_roundabout.py:30-63): first block + one roundabout with
+    exit_radius 10, inner_radius 30, angle 70."""
+    from pgdrive.component.blocks.first_block import FirstPGBlock
+    from pgdrive.component.blocks.roundabout import Roundabout
     net = RoadNetwork()
-    big = BIG(lane_num, lane_width, net, None, refstub.FakePhysicsWorld(), exit_length=exit_length, random_seed=seed)
-    if block_seq is not None:
-        big.generate(BigGenerateMethod.BLOCK_SEQUENCE, block_seq)
+    pw = refstub.FakePhysicsWorld()
+    first = FirstPGBlock(net, lane_width, lane_num, None, pw, length=exit_length)
+    Roundabout.EXIT_PART_LENGTH = exit_length
+    rb = Roundabout(1, first.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    ok = rb.construct_block(None, pw, extra_config={"exit_radius": 10, "inner_radius": 30, "angle": 70})
+    assert ok
+    return generate(0, lane_num, lane_width, exit_length, prebuilt=(net, _Blocks([first, rb])))
+
+
+def generate(seed, lane_num=3, lane_width=3.5, exit_length=50, block_num=None, block_seq=None, prebuilt=None):
+    """Run the reference BIG and flatten the result into plain python/numpy data."""
+    if prebuilt is not None:
+        net, big = prebuilt
     else:
-        big.generate(BigGenerateMethod.BLOCK_NUM, block_num)
+        net = RoadNetwork()
+        big = BIG(lane_num, lane_width, net, None, refstub.FakePhysicsWorld(), exit_length=exit_length, random_seed=seed)
+        if block_seq is not None:
+            big.generate(BigGenerateMethod.BLOCK_SEQUENCE, block_seq)
+        else:
+            big.generate(BigGenerateMethod.BLOCK_NUM, block_num)
     net.after_init()
 
     nodes = []  # node names in first-seen order

@@ -9,15 +9,18 @@ class PgdConfig(C.Structure):
         ("auto_reset", C.c_int32), ("resample_scenario", C.c_int32), ("horizon", C.c_int32), ("seed", C.c_uint32),
         ("success_reward", C.c_float), ("out_of_road_penalty", C.c_float), ("crash_vehicle_penalty", C.c_float),
         ("crash_object_penalty", C.c_float), ("driving_reward", C.c_float), ("speed_reward", C.c_float),
-        ("use_lateral", C.c_int32), ("out_of_route_done", C.c_int32), ("traffic_ghost", C.c_int32),
-        ("pad", C.c_int32 * 3),
+        ("use_lateral", C.c_int32), ("out_of_route_done", C.c_int32), ("marl_flags", C.c_int32),
+        ("delay_done", C.c_int32), ("agent_limit", C.c_int32), ("respawn_places", C.c_int32),
+        ("respawn_dests", C.c_int32), ("pad", C.c_int32),
     ]
 
 
 def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_others=4, lidar_dist=50.0, dt=0.02,
                 decision_repeat=5, auto_reset=1, resample_scenario=0, horizon=0, seed=0, success_reward=10.0,
                 out_of_road_penalty=5.0, crash_vehicle_penalty=5.0, crash_object_penalty=5.0, driving_reward=1.0,
-                speed_reward=0.1, use_lateral=False, out_of_route_done=False):
+                speed_reward=0.1, use_lateral=False, out_of_route_done=False, multi_agent=False, crash_done=True,
+                out_of_road_done=True, allow_respawn=True, delay_done=25, agent_limit=0, respawn_places=0,
+                respawn_dests=0):
     """Defaults mirror PGDriveEnv_DEFAULT_CONFIG / BASE_DEFAULT_CONFIG (pgdrive_env.py:22-109, base_env.py:19-90)."""
     c = PgdConfig()
     c.num_envs, c.num_agents, c.num_traffic = num_envs, num_agents, num_traffic
@@ -28,6 +31,11 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
     c.crash_vehicle_penalty, c.crash_object_penalty = crash_vehicle_penalty, crash_object_penalty
     c.driving_reward, c.speed_reward = driving_reward, speed_reward
     c.use_lateral, c.out_of_route_done = int(bool(use_lateral)), int(bool(out_of_route_done))
+    if multi_agent:
+        c.marl_flags = MA_ENABLED | (MA_CRASH_DONE if crash_done else 0) | (MA_OUT_ROAD_DONE if out_of_road_done else 0) | \
+            (MA_ALLOW_RESPAWN if allow_respawn else 0)
+        c.delay_done, c.agent_limit = int(delay_done), int(agent_limit or num_agents)
+        c.respawn_places, c.respawn_dests = int(respawn_places), int(respawn_dests)
     return c
 
 
@@ -38,12 +46,13 @@ def obs_dim(cfg):
 # state layout (include/pgd_state_layout.h)
 SF = dict(X=0, Y=1, THETA=2, SPEED=3, STEER=4, THROTTLE=5, LASTX=6, LASTY=7, LASTHX=8, LASTHY=9, ACT0S=10, ACT0T=11,
           ACT1S=12, ACT1T=13, PID_HP=14, PID_HI=15, PID_LP=16, PID_LI=17, TARGET_SPEED=18, ENERGY=19, DIST_LEFT=20,
-          DIST_RIGHT=21, EP_REWARD=22, SPARE=23)
-SI = dict(STATUS=0, LANE=1, CK0=2, CK1=3, RLANE=4, TIMER=5, VFLAGS=6, SPARE=7)
-EI = dict(SCEN=0, NEXT_GROUP=1, EP_STEPS=2, EPISODES=3, STEPS_TOTAL=4)
+          DIST_RIGHT=21, EP_REWARD=22, AGENT_ID=23)
+SI = dict(STATUS=0, LANE=1, CK0=2, CK1=3, RLANE=4, TIMER=5, VFLAGS=6, SPAWN=7)
+EI = dict(SCEN=0, NEXT_GROUP=1, EP_STEPS=2, EPISODES=3, STEPS_TOTAL=4, NEXT_AGENT=5)
 NF, NI, NEI = 24, 8, 8
-ST_EMPTY, ST_PENDING, ST_ACTIVE, ST_REMOVED = 0, 1, 2, 3
+ST_EMPTY, ST_PENDING, ST_ACTIVE, ST_REMOVED, ST_DYING = 0, 1, 2, 3, 4
+MA_ENABLED, MA_CRASH_DONE, MA_OUT_ROAD_DONE, MA_ALLOW_RESPAWN = 1, 2, 4, 8
 
 F_ARRIVE, F_OUT_OF_ROAD, F_CRASH_VEHICLE, F_CRASH_OBJECT, F_CRASH_BUILDING, F_MAX_STEP = 1, 2, 4, 8, 16, 32
 F_ON_YELLOW, F_ON_WHITE, F_ON_BROKEN, F_CRASH_SIDEWALK, F_OFF_LANE, F_OUT_OF_ROUTE = 256, 512, 1024, 2048, 4096, 8192
-F_RESET = 1 << 16
+F_RESET, F_REPORT, F_NEW, F_ALL_DONE = 1 << 16, 1 << 17, 1 << 18, 1 << 19

@@ -6,6 +6,7 @@ import os
 
 _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 DEFAULT_BANK = os.path.join(_ASSETS, "pg_bank_v0.json.gz")
+MA_ROUNDABOUT_BANK = os.path.join(_ASSETS, "ma_roundabout_v0.json.gz")  # MARoundaboutMap (marl_inout_roundabout.py:30-63)
 
 
 def load_descriptions(path=DEFAULT_BANK):

@@ -22,6 +22,7 @@ struct PgdDev {
   int epw;        // whole environments per wave in k_step
   int sub;        // sub-lanes cooperating on one vehicle
   int lds_bytes;  // dynamic LDS of k_step for the staged lane/road tables (0 = tables read from global memory)
+  int sstride;    // pgd_spawn records per scenario: V slots + respawn_places * respawn_dests (multi-agent)
   const pgd_map* maps;
   const pgd_lane* lanes;
   const pgd_road* roads;

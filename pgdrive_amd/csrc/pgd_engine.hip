@@ -57,7 +57,8 @@ __shared__ long long s_prof_t0, s_prof_w0;
 struct Veh {
   float x, y, th, v, steer, thr, lastx, lasty, lasthx, lasthy, a0s, a0t, a1s, a1t, php, phi, plp, pli, target, energy,
       dl, dr, eprew;
-  int status, lane, ck0, ck1, rlane, timer, vflags;
+  int status, lane, ck0, ck1, rlane, timer, vflags, spawn;
+  float agent_id;
   float hx, hy;  // unit heading (cos, sin of th): derived, kept in registers, never stored
 };
 
@@ -75,7 +76,8 @@ DEV void load_veh(const PgdDev& d, int e, int s, Veh& r) {
   r.target = t.f[SF_TARGET_SPEED]; r.energy = t.f[SF_ENERGY];
   r.dl = t.f[SF_DIST_LEFT]; r.dr = t.f[SF_DIST_RIGHT]; r.eprew = t.f[SF_EP_REWARD];
   r.status = t.i[SI_STATUS]; r.lane = t.i[SI_LANE]; r.ck0 = t.i[SI_CK0]; r.ck1 = t.i[SI_CK1];
-  r.rlane = t.i[SI_RLANE]; r.timer = t.i[SI_TIMER]; r.vflags = t.i[SI_VFLAGS];
+  r.rlane = t.i[SI_RLANE]; r.timer = t.i[SI_TIMER]; r.vflags = t.i[SI_VFLAGS]; r.spawn = t.i[SI_SPAWN];
+  r.agent_id = t.f[SF_AGENT_ID];
   sincosf(r.th, &r.hy, &r.hx);
 }
 DEV void store_veh(const PgdDev& d, int e, int s, const Veh& r) {
@@ -86,9 +88,9 @@ DEV void store_veh(const PgdDev& d, int e, int s, const Veh& r) {
   t.f[SF_ACT0S] = r.a0s; t.f[SF_ACT0T] = r.a0t; t.f[SF_ACT1S] = r.a1s; t.f[SF_ACT1T] = r.a1t;
   t.f[SF_PID_HP] = r.php; t.f[SF_PID_HI] = r.phi; t.f[SF_PID_LP] = r.plp; t.f[SF_PID_LI] = r.pli;
   t.f[SF_TARGET_SPEED] = r.target; t.f[SF_ENERGY] = r.energy;
-  t.f[SF_DIST_LEFT] = r.dl; t.f[SF_DIST_RIGHT] = r.dr; t.f[SF_EP_REWARD] = r.eprew; t.f[SF_SPARE] = 0.0f;
+  t.f[SF_DIST_LEFT] = r.dl; t.f[SF_DIST_RIGHT] = r.dr; t.f[SF_EP_REWARD] = r.eprew; t.f[SF_AGENT_ID] = r.agent_id;
   t.i[SI_STATUS] = r.status; t.i[SI_LANE] = r.lane; t.i[SI_CK0] = r.ck0; t.i[SI_CK1] = r.ck1;
-  t.i[SI_RLANE] = r.rlane; t.i[SI_TIMER] = r.timer; t.i[SI_VFLAGS] = r.vflags; t.i[SI_SPARE] = 0;
+  t.i[SI_RLANE] = r.rlane; t.i[SI_TIMER] = r.timer; t.i[SI_VFLAGS] = r.vflags; t.i[SI_SPAWN] = r.spawn;
   uint4* dst = reinterpret_cast<uint4*>(d.rec + (size_t)e * d.V + s);
   const uint4* src = reinterpret_cast<const uint4*>(&t);
 #pragma unroll
@@ -568,9 +570,11 @@ DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r) {
   r.hy = hy * inv;
 }
 
-DEV void reset_vehicle(const pgd_spawn& p, Veh& r) {  // base_vehicle.py:292-339 + idm_policy.py:180-188
+DEV void reset_vehicle(const pgd_spawn& p, Veh& r, int spawn_index, bool is_agent) {  // base_vehicle.py:292-339
   memset(&r, 0, sizeof(Veh));
-  r.rlane = -1;
+  r.spawn = spawn_index;
+  r.rlane = is_agent ? 0 : -1;  // agents: episode length; traffic: IDMPolicy.routing_target_lane = None
+  r.hx = 1.0f;
   if (p.lane < 0) { r.status = ST_EMPTY; return; }
   r.status = p.group < 0 ? ST_ACTIVE : ST_PENDING;
   r.x = p.x; r.y = p.y; r.th = p.heading;
@@ -809,6 +813,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   s_flag[lane] = 0;
   s_hit[lane] = 0;
   const bool one_env = d.epw == 1;  // every lane of the wave works on env blockIdx.x
+  const bool marl = (d.cfg.marl_flags & PGD_MA_ENABLED) != 0;
   int scen = 0;
   if (one_env || valid) {
     scen = d.ei[(size_t)((one_env ? (int)blockIdx.x : e)) * PGD_NEI + EI_SCEN];
@@ -844,7 +849,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_MARK(13);  // load: scenario + table staging
   if (valid) {
     load_veh(d, e, s, r);
-    sp = d.spawns + (size_t)scen * V + s;
+    sp = d.spawns + (size_t)scen * d.sstride + r.spawn;
+    // (0) AgentManager.before_step (agent_manager.py:191-199): finished agents count down, then leave the world
+    if (marl && r.status == ST_DYING && --r.timer == 0) r.status = ST_EMPTY;
     ng = d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP];
     ep_steps = d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS];
     steps_total = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
@@ -866,7 +873,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       S.spd[slot] = speed_kmh(r.v);
       S.hl[slot] = 0.5f * sp->length; S.hw[slot] = 0.5f * sp->width;
       S.lane[slot] = r.lane;
-      const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE;
+      const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
       S.present[slot] = present ? 1 : 0;
       if (present && V > A) {
         const pgd_lane& ml = mv.lanes[r.lane];
@@ -938,21 +945,88 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // (7) reward / done (base_env.py:303-344)
   s_flag[lane] = 0;
   __syncthreads();
-  if (valid && s < A) {
-    unsigned fl = 0;
-    bool dn = false;
-    float rew = 0.0f;
-    if (r.status == ST_ACTIVE) rew = reward_done(d, mv, *sp, r, fl, dn);
-    if (d.cfg.horizon > 0 && ep_steps >= d.cfg.horizon) { dn = true; fl |= PGD_F_MAX_STEP; }
-    r.eprew += rew;
-    bool will_reset = dn && d.cfg.auto_reset && A == 1;
-    if (will_reset) { fl |= PGD_F_RESET; s_flag[el] = 1; }
-    if (leader) {
-      size_t k = (size_t)e * A + s;
-      reward[k] = rew;
-      done[k] = dn ? 1 : 0;
-      flags[k] = fl;
+  unsigned my_fl = 0;
+  bool my_dn = false;
+  float my_rew = 0.0f;
+  const bool was_active = acting;  // status at the start of the step (after the delay-done countdown)
+  if (valid && s < A && !marl) {
+    if (r.status == ST_ACTIVE) my_rew = reward_done(d, mv, *sp, r, my_fl, my_dn);
+    if (d.cfg.horizon > 0 && ep_steps >= d.cfg.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
+    r.eprew += my_rew;
+    bool will_reset = my_dn && d.cfg.auto_reset && A == 1;
+    if (will_reset) { my_fl |= PGD_F_RESET; s_flag[el] = 1; }
+  }
+  if (marl && one_env) {
+    // ---- multi-agent tail: multi_agent_pgdrive.py:109-213, agent_manager.py:134-175, spawn_manager.py:160-215 ----
+    const pgd_config& gcf = d.cfg;
+    if (valid && s < A && was_active) {
+      my_rew = reward_done(d, mv, *sp, r, my_fl, my_dn);
+      const bool arrive = my_fl & PGD_F_ARRIVE, oor = my_fl & PGD_F_OUT_OF_ROAD, crash = my_fl & PGD_F_CRASH_VEHICLE;
+      if (crash && !(gcf.marl_flags & PGD_MA_CRASH_DONE) && !(arrive || oor)) my_dn = false;
+      if (oor && !(gcf.marl_flags & PGD_MA_OUT_ROAD_DONE) && !arrive) my_dn = false;
+      r.rlane += 1;  // episode_length
+      if (gcf.horizon > 0 && r.rlane >= gcf.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
+      r.eprew += my_rew;
+      my_fl |= PGD_F_REPORT;
+      if (my_dn) {  // AgentManager.finish
+        if (arrive || gcf.delay_done <= 0) r.status = ST_EMPTY;
+        else { r.status = ST_DYING; r.timer = gcf.delay_done; }
+      }
     }
+    // the world after the finishes (leaders publish, everybody reads)
+    __syncthreads();
+    if (valid && leader) {
+      S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
+      S.hl[slot] = 0.5f * sp->length; S.hw[slot] = 0.5f * sp->width;
+      S.present[slot] = (r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool is_lead_agent = valid && leader && s < A;
+    int alive = __popcll(__ballot(is_lead_agent && (r.status == ST_ACTIVE || r.status == ST_DYING)));
+    int next_agent = d.ei[(size_t)blockIdx.x * PGD_NEI + EI_NEXT_AGENT];
+    const bool allow = (gcf.marl_flags & PGD_MA_ALLOW_RESPAWN) && !(gcf.horizon > 0 && ep_steps >= gcf.horizon) &&
+                       alive < gcf.agent_limit;
+    if (allow) {
+      const pgd_spawn* rbase = d.spawns + (size_t)scen * d.sstride + V;
+      for (int p = 0; p < gcf.respawn_places; ++p) {
+        const pgd_spawn& place = rbase[p * gcf.respawn_dests];
+        float ps, pc;
+        sincosf(place.heading, &ps, &pc);
+        const Obb region{place.x, place.y, pc, ps, 4.0f, 1.5f};  // RESPAWN_REGION 8 m x 3 m (spawn_manager.py:27-28)
+        const bool blocks = lane < V && S.present[lane] && obb_overlap(region, snap_obb(S, lane));
+        if (__ballot(blocks) != 0ull) continue;
+        // lowest empty slot that did not report this step (its terminal row must survive)
+        unsigned long long em = __ballot(is_lead_agent && r.status == ST_EMPTY && !(my_fl & PGD_F_REPORT));
+        if (em == 0ull) break;
+        const int src = __builtin_ffsll((long long)em) - 1;
+        const int tslot = (src / d.sub) % V;
+        const int dest = (int)(pgd_rng(gcf.seed, (uint32_t)blockIdx.x, 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
+                               (uint32_t)gcf.respawn_dests);
+        if (valid && s == tslot) {
+          const int sidx = V + p * gcf.respawn_dests + dest;
+          sp = d.spawns + (size_t)scen * d.sstride + sidx;
+          reset_vehicle(*sp, r, sidx, true);
+          r.agent_id = (float)next_agent;
+          after_step_vehicle(mv, g, *sp, r, true, true);
+          my_fl |= PGD_F_NEW;
+          if (leader) {
+            S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
+            S.hl[slot] = 0.5f * sp->length; S.hw[slot] = 0.5f * sp->width;
+            S.present[slot] = 1;
+          }
+        }
+        next_agent += 1;
+        __syncthreads();
+      }
+    }
+    // d["__all__"] (multi_agent_pgdrive.py:142-148)
+    const int n_active = __popcll(__ballot(is_lead_agent && r.status == ST_ACTIVE));
+    const bool all_done = n_active == 0 || (gcf.horizon > 0 && ep_steps >= 5 * gcf.horizon);
+    if (all_done) {
+      my_fl |= PGD_F_ALL_DONE;
+      if (gcf.auto_reset) { my_fl |= PGD_F_RESET; s_flag[el] = 1; }
+    }
+    if (lane == 0) d.ei[(size_t)blockIdx.x * PGD_NEI + EI_NEXT_AGENT] = next_agent;
   }
   __syncthreads();
   PHASE_MARK(6);  // reward/done
@@ -963,16 +1037,29 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (d.cfg.resample_scenario)
       scen = (int)(pgd_rng(d.cfg.seed, (uint32_t)e, 0x5ce9a210u, (uint32_t)episodes) % (uint32_t)d.n_scen);
     sc = d.scen + scen;
-    sp = d.spawns + (size_t)scen * V + s;
+    sp = d.spawns + (size_t)scen * d.sstride + s;
     mv = map_view(d, sc->map);  // global tables: the staged map may not be the new one
-    reset_vehicle(*sp, r);
+    reset_vehicle(*sp, r, s, s < A);
     if (r.status != ST_EMPTY) after_step_vehicle(mv, g, *sp, r, s < A, true);
+    // agent ids restart at 0: id = number of spawned agent slots below this one (agent_manager.py:91-132)
+    const unsigned long long am = __ballot(leader && s < A && r.status == ST_ACTIVE);
+    if (s < A && r.status == ST_ACTIVE) {
+      r.agent_id = A == 1 ? 0.0f : (float)__popcll(am & ((1ull << lm.lead) - 1ull));  // A > 1 implies one env per wave
+      if (marl) my_fl |= PGD_F_NEW;
+    }
     ng = 0;
     ep_steps = 0;
     if (s == 0 && leader) {
       d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
       d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] = episodes;
+      d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_AGENT] = A == 1 ? 1 : __popcll(am);
     }
+  }
+  if (valid && leader && s < A) {
+    size_t k = (size_t)e * A + s;
+    reward[k] = my_rew;
+    done[k] = my_dn ? 1 : 0;
+    flags[k] = my_fl;
   }
   PHASE_MARK(7);  // reset
   if (valid && leader) {
@@ -988,9 +1075,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (obs != nullptr) {  // host passes obs only when one_env && A <= FUSE_MAX_AGENTS
     __syncthreads();
     if (valid && leader) {
-      const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE;
+      const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
       S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
-      S.spd[slot] = speed_kmh(r.v);
+      S.spd[slot] = r.status == ST_DYING ? 0.0f : speed_kmh(r.v);
       S.hl[slot] = 0.5f * sp->length; S.hw[slot] = 0.5f * sp->width;  // the scenario may have changed on reset
       S.present[slot] = present ? 1 : 0;
       if (s < A) {
@@ -1010,7 +1097,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       obs_compact(OL, lane, a, have && S.present[lane], S.x[lane], S.y[lane], S.ux[lane], S.uy[lane], S.hl[lane], S.hw[lane],
                   S.spd[lane], ag.x, ag.y, d.cfg.lidar_dist);
       __syncthreads();
-      observe_agent(d, mvo, d.spawns[(size_t)scen_now * V + a], ag, OL, obs + ((size_t)blockIdx.x * A + a) * d.D, lane, WAVE);
+      observe_agent(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + ((size_t)blockIdx.x * A + a) * d.D, lane,
+                    WAVE);
       __syncthreads();
     }
   }
@@ -1029,14 +1117,17 @@ __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restr
   const int e = env_ids ? env_ids[k] : k;
   const int scen = scen_ids[k];
   const pgd_scenario* sc = d.scen + scen;
-  const pgd_spawn* sp = d.spawns + (size_t)scen * V + s;
+  const pgd_spawn* sp = d.spawns + (size_t)scen * d.sstride + s;
   MapView mv = map_view(d, sc->map);
   Veh r;
-  reset_vehicle(*sp, r);
+  reset_vehicle(*sp, r, s, s < A);
   if (r.status != ST_EMPTY) after_step_vehicle(mv, g, *sp, r, s < A, true);
+  const unsigned long long am = __ballot(lm.sub == 0 && s < A && r.status == ST_ACTIVE);  // epw == 1 whenever A > 1
+  if (s < A && r.status == ST_ACTIVE) r.agent_id = A == 1 ? 0.0f : (float)__popcll(am & ((1ull << lm.lead) - 1ull));
   if (lm.sub != 0) return;
   store_veh(d, e, s, r);
   if (s == 0) {
+    d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_AGENT] = A == 1 ? 1 : __popcll(am);
     d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
     d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP] = 0;
     d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS] = 0;
@@ -1054,10 +1145,10 @@ __global__ __launch_bounds__(WAVE) void k_refresh(PgdDev d) {
   const int e = lm.e, s = lm.s;
   Veh r;
   load_veh(d, e, s, r);
-  if (r.status != ST_ACTIVE && r.status != ST_PENDING) return;
+  if (r.status != ST_ACTIVE && r.status != ST_PENDING && r.status != ST_DYING) return;
   int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
   MapView mv = map_view(d, d.scen[scen].map);
-  after_step_vehicle(mv, g, d.spawns[(size_t)scen * V + s], r, s < A, true);
+  after_step_vehicle(mv, g, d.spawns[(size_t)scen * d.sstride + r.spawn], r, s < A, true);
   if (lm.sub == 0) store_veh(d, e, s, r);
 }
 
@@ -1066,13 +1157,24 @@ __global__ __launch_bounds__(WAVE) void k_refresh(PgdDev d) {
 // a wave carries exactly one env; this kernel serves pgd_reset / pgd_observe and the configurations that do not fuse.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__ obs) {
+__global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags) {
   __shared__ ObsLds L;
   const int V = d.V, A = d.A, D = d.D;
   const int e = blockIdx.x / A, a = blockIdx.x - e * A;
   const int tid = threadIdx.x;
   const VehRec* recs = d.rec + (size_t)e * V;  // the env's vehicle records
   const VehRec& mine = recs[a];
+  float* row = obs + ((size_t)e * A + a) * D;
+  // which slots get a row: after a multi-agent step the ones that reported or were (re)spawned, else the active ones
+  bool want = mine.i[SI_STATUS] == ST_ACTIVE;
+  if (flags) {
+    const uint32_t fa = flags[(size_t)e * A + a];
+    want = (fa & PGD_F_RESET) ? want : (fa & (PGD_F_REPORT | PGD_F_NEW)) != 0;  // after a reset only the new episode counts
+  }
+  if (!want) {
+    for (int k = tid; k < D; k += BLOCK) row[k] = 0.0f;
+    return;
+  }
   AgentView ag;
   ag.x = mine.f[SF_X]; ag.y = mine.f[SF_Y]; ag.th = mine.f[SF_THETA];
   sincosf(ag.th, &ag.hy, &ag.hx);
@@ -1080,23 +1182,38 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
   ag.a0s = mine.f[SF_ACT0S]; ag.a0t = mine.f[SF_ACT0T]; ag.lhx = mine.f[SF_LASTHX]; ag.lhy = mine.f[SF_LASTHY];
   ag.ck0 = mine.i[SI_CK0]; ag.ck1 = mine.i[SI_CK1];
   const int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
-  const pgd_spawn* spb = d.spawns + (size_t)scen * V;
+  const pgd_spawn* spb = d.spawns + (size_t)scen * d.sstride;
   if (tid < WAVE) {  // wave 0: broad phase r = lidar distance (lidar.py:109-124), compacted into LDS
     bool present = false;
     float x = 0, y = 0, ux = 1, uy = 0, hl = 0, hw = 0, spd = 0;
     if (tid < V && d.cfg.num_lasers > 0) {
       int st = recs[tid].i[SI_STATUS];
-      present = st == ST_PENDING || st == ST_ACTIVE;
+      present = st == ST_PENDING || st == ST_ACTIVE || st == ST_DYING;
+      bool still = st == ST_DYING;  // a finished agent is a static body (zero velocity)
+      if (flags && tid < A) {
+        // multi-agent step: rows of agents that drove this step show the world before the finishes / respawns
+        // (base_env.py:303-344 runs before multi_agent_pgdrive.py:128-141); an agent spawned this step sees the world at
+        // its spawn time, i.e. the earlier spawns of the step only
+        const uint32_t fa = flags[(size_t)e * A + a], fo = flags[(size_t)e * A + tid];
+        if (fa & PGD_F_RESET) {
+        } else if (fa & PGD_F_NEW) {
+          present = present && (!(fo & PGD_F_NEW) || recs[tid].f[SF_AGENT_ID] < mine.f[SF_AGENT_ID]);
+        } else {
+          present = (fo & PGD_F_REPORT) || (present && !(fo & PGD_F_NEW));
+          still = still && !(fo & PGD_F_REPORT);
+        }
+      }
       x = recs[tid].f[SF_X]; y = recs[tid].f[SF_Y];
       sincosf(recs[tid].f[SF_THETA], &uy, &ux);
-      hl = 0.5f * spb[tid].length; hw = 0.5f * spb[tid].width;
-      spd = speed_kmh(recs[tid].f[SF_SPEED]);
+      const pgd_spawn& so = spb[recs[tid].i[SI_SPAWN]];
+      hl = 0.5f * so.length; hw = 0.5f * so.width;
+      spd = still ? 0.0f : speed_kmh(recs[tid].f[SF_SPEED]);
     }
     obs_compact(L, tid, a, present, x, y, ux, uy, hl, hw, spd, ag.x, ag.y, d.cfg.lidar_dist);
   }
   __syncthreads();
   MapView mv = map_view_of(d, d.scen_map + scen);
-  observe_agent(d, mv, spb[a], ag, L, obs + ((size_t)e * A + a) * D, tid, BLOCK);
+  observe_agent(d, mv, spb[mine.i[SI_SPAWN]], ag, L, row, tid, BLOCK);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1163,6 +1280,9 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->d.N = cfg->num_envs; h->d.A = cfg->num_agents; h->d.T = cfg->num_traffic; h->d.V = V;
   h->d.D = pgd_obs_dim(cfg);
   h->d.NV = h->d.N * V;
+  const bool marl = (cfg->marl_flags & PGD_MA_ENABLED) != 0;
+  if (marl && (cfg->respawn_places < 0 || cfg->respawn_dests < 0 || cfg->num_traffic != 0)) return PGD_ERR_ARG;
+  h->d.sstride = V + (marl ? cfg->respawn_places * cfg->respawn_dests : 0);
   h->d.sub = WAVE / V < 16 ? WAVE / V : 16;  // sub-lanes per vehicle
   h->d.epw = WAVE / (V * h->d.sub);          // whole environments per wave
   if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }
@@ -1224,7 +1344,7 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   HIPCHK(hipSetDevice(h->device));
   int rc;
   if ((rc = upload(&h->scen, scen, n_scen, h->stream))) return rc;
-  if ((rc = upload(&h->spawns, spawns, (size_t)n_scen * h->d.V, h->stream))) return rc;
+  if ((rc = upload(&h->spawns, spawns, (size_t)n_scen * h->d.sstride, h->stream))) return rc;
   h->d.scen = h->scen; h->d.spawns = h->spawns; h->d.n_scen = n_scen;
   if (!h->h_scen) h->h_scen = new std::vector<pgd_scenario>();
   h->h_scen->assign(scen, scen + n_scen);
@@ -1233,10 +1353,11 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   return PGD_OK;
 }
 
-static int launch_observe(pgd_handle h, float* d_obs) {
+static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags) {
   int blocks = h->d.N * h->d.A;
-  if (h->d.cfg.num_lasers > 0) hipLaunchKernelGGL(k_observe<256>, dim3(blocks), dim3(256), 0, h->stream, h->d, d_obs);
-  else hipLaunchKernelGGL(k_observe<64>, dim3(blocks), dim3(64), 0, h->stream, h->d, d_obs);
+  if (h->d.cfg.num_lasers > 64)
+    hipLaunchKernelGGL(k_observe<256>, dim3(blocks), dim3(256), 0, h->stream, h->d, d_obs, d_flags);
+  else hipLaunchKernelGGL(k_observe<64>, dim3(blocks), dim3(64), 0, h->stream, h->d, d_obs, d_flags);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }
@@ -1259,7 +1380,7 @@ int pgd_reset(pgd_handle h, const int32_t* env_ids, const int32_t* scen_ids, int
   hipLaunchKernelGGL(k_reset, dim3(blocks), dim3(WAVE), 0, h->stream, h->d, d_env, h->d_ids + h->d.N, n);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));  // host id buffers may be reused by the caller
-  if (d_obs) return launch_observe(h, d_obs);
+  if (d_obs) return launch_observe(h, d_obs, nullptr);
   return PGD_OK;
 }
 
@@ -1270,13 +1391,15 @@ int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward
   hipEvent_t* pe = prof ? &(*h->prof_ev)[(size_t)h->prof_n * 3] : nullptr;
   HIPCHK(hipEventRecord(prof ? pe[0] : h->ev0, h->stream));
   int blocks = (h->d.N + h->d.epw - 1) / h->d.epw;
-  const bool fuse = d_obs && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !getenv("PGD_NO_FUSE");
+  const bool marl = (h->d.cfg.marl_flags & PGD_MA_ENABLED) != 0;
+  if (marl && h->d.epw != 1) return PGD_ERR_STATE;  // the multi-agent tail needs the env in one wave (V >= 33 or SUB split)
+  const bool fuse = d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !getenv("PGD_NO_FUSE");
   hipLaunchKernelGGL(k_step, dim3(blocks), dim3(WAVE), (size_t)h->d.lds_bytes, h->stream, h->d, d_actions, d_reward, d_done,
                      d_flags, fuse ? d_obs : (float*)nullptr);
   HIPCHK(hipGetLastError());
   if (prof) HIPCHK(hipEventRecord(pe[1], h->stream));
   if (d_obs && !fuse) {
-    int rc = launch_observe(h, d_obs);
+    int rc = launch_observe(h, d_obs, marl ? d_flags : (const uint32_t*)nullptr);
     if (rc) return rc;
   }
   h->prof_fused = fuse;
@@ -1292,7 +1415,7 @@ int pgd_observe(pgd_handle h, float* d_obs) {
   int blocks = (h->d.N + h->d.epw - 1) / h->d.epw;
   hipLaunchKernelGGL(k_refresh, dim3(blocks), dim3(WAVE), 0, h->stream, h->d);
   HIPCHK(hipGetLastError());
-  return launch_observe(h, d_obs);
+  return launch_observe(h, d_obs, nullptr);
 }
 
 int pgd_state_dims(pgd_handle h, int* nf, int* ni, int* nei) {

@@ -1,0 +1,160 @@
+"""Multi-agent roundabout on the HIP engine (BASELINE config 5).
+
+Mirrors `MultiAgentRoundaboutEnv` (pgdrive/envs/marl_envs/marl_inout_roundabout.py:133-153) on top of
+`MultiAgentPGDrive` (pgdrive/envs/marl_envs/multi_agent_pgdrive.py:58-213): per-agent termination, finished agents stay
+`delay_done` steps as static obstacles, new agents ("agent{k}", ever increasing k) are respawned into free 8 m x 3 m
+places at the road starts while fewer than `num_agents` are alive and the episode is younger than `horizon`;
+`done["__all__"]` ends the episode.
+
+`MultiAgentRoundaboutVecEnv` — N envs, slot-indexed cuda tensors `[N, A, ...]` + flag bits (PGD_F_REPORT / NEW / ALL_DONE).
+`MultiAgentRoundaboutEnv`    — one env, the reference's dict-in / dict-out protocol.
+"""
+import numpy as np
+
+from . import _abi, bank, mapdata, scenario
+from .spaces import Box, Dict
+from .vec_env import merge_config
+
+# MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG + MARoundaboutConfig (multi_agent_pgdrive.py:12-55, marl_inout_roundabout.py:15-28)
+MA_DEFAULT_CONFIG = dict(
+    num_envs=1,
+    num_agents=40,
+    max_agents=None,  # slot capacity per env (default: num_agents); the reference has no cap
+    crash_done=True,
+    out_of_road_done=True,
+    delay_done=25,
+    allow_respawn=True,
+    horizon=1000,
+    vehicle_config=dict(lidar=dict(num_lasers=72, distance=40, num_others=0)),
+    success_reward=10.0,
+    out_of_road_penalty=10,
+    crash_vehicle_penalty=10,
+    crash_object_penalty=10,
+    driving_reward=1.0,
+    speed_reward=0.1,
+    use_lateral=False,
+    decision_repeat=5,
+    physics_world_step_size=2e-2,
+    spawn_variants=16,  # number of pre-drawn initial placements (SpawnManager.reset draws afresh every episode)
+    auto_reset=True,
+    device=0,
+    seed=0,
+)
+
+
+class MultiAgentRoundaboutVecEnv:
+    def __init__(self, config=None):
+        self.config = c = merge_config(MA_DEFAULT_CONFIG, config)
+        lid = c["vehicle_config"]["lidar"]
+        if lid["num_others"] != 0:
+            raise NotImplementedError("LidarStateObservationMARound with num_others > 0 is not built (reference default 0)")
+        self.desc = bank.load_descriptions(bank.MA_ROUNDABOUT_BANK)[0]
+        self.map_bank = mapdata.MapBank([self.desc])
+        cap = c["max_agents"] or c["num_agents"]
+        self.scen_bank = scenario.MarlScenarioBank(self.desc, c["num_agents"], capacity=cap,
+                                                   n_variants=c["spawn_variants"], seed=c["seed"])
+        self.num_envs, self.A = int(c["num_envs"]), cap
+        self.cfg = _abi.make_config(
+            self.num_envs, num_agents=cap, num_traffic=0, num_lasers=lid["num_lasers"], num_others=0,
+            lidar_dist=lid["distance"], dt=c["physics_world_step_size"], decision_repeat=c["decision_repeat"],
+            auto_reset=c["auto_reset"], resample_scenario=1, horizon=c["horizon"] or 0, seed=c["seed"],
+            success_reward=c["success_reward"], out_of_road_penalty=c["out_of_road_penalty"],
+            crash_vehicle_penalty=c["crash_vehicle_penalty"], crash_object_penalty=c["crash_object_penalty"],
+            driving_reward=c["driving_reward"], speed_reward=c["speed_reward"], use_lateral=c["use_lateral"],
+            multi_agent=True, crash_done=c["crash_done"], out_of_road_done=c["out_of_road_done"],
+            allow_respawn=c["allow_respawn"], delay_done=c["delay_done"], agent_limit=c["num_agents"],
+            respawn_places=self.scen_bank.P, respawn_dests=self.scen_bank.Dn
+        )
+        from .engine import Engine
+        self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])
+        self.obs_dim = self.engine.D
+        self.single_observation_space = Box(-0.0, 1.0, (self.obs_dim, ), np.float32)
+        self.single_action_space = Box(-1.0, 1.0, (2, ), np.float32)
+        self._rng = np.random.RandomState(c["seed"])
+
+    def reset(self):
+        ids = self._rng.randint(0, len(self.scen_bank.scenarios), size=self.num_envs).astype(np.int32)
+        return self.engine.reset(ids)  # [N, A, D]; rows of empty slots are zero
+
+    def step(self, actions):
+        """actions [N, A, 2] cuda float32 (rows of slots without an active agent are ignored)."""
+        return self.engine.step(actions.contiguous())
+
+    def slot_table(self):
+        """Host copy of (status, agent id) per slot: ([N, A] int, [N, A] int)."""
+        f, i, _ = self.engine.get_state()
+        return i[_abi.SI["STATUS"]], f[_abi.SF["AGENT_ID"]].astype(np.int64)
+
+    def close(self):
+        if getattr(self, "engine", None) is not None:
+            self.engine.close()
+            self.engine = None
+
+
+class MultiAgentRoundaboutEnv:
+    """Dict protocol of the reference: keys "agent{k}"; done has "__all__" (multi_agent_pgdrive.py:126-150)."""
+    def __init__(self, config=None):
+        cfg = dict(config or {})
+        cfg["num_envs"] = 1
+        cfg.setdefault("auto_reset", False)
+        self.vec = MultiAgentRoundaboutVecEnv(cfg)
+        self.config = self.vec.config
+        import torch
+        self._torch = torch
+        self._slots = {}  # agent name -> slot
+        self.episode_steps = 0
+
+    @property
+    def observation_space(self):
+        return Dict({k: self.vec.single_observation_space for k in self._slots})
+
+    @property
+    def action_space(self):
+        return Dict({k: self.vec.single_action_space for k in self._slots})
+
+    def _refresh_slots(self):
+        status, ids = self.vec.slot_table()
+        self._slots = {"agent%d" % ids[0, s]: s for s in range(self.vec.A) if status[0, s] == _abi.ST_ACTIVE}
+
+    def reset(self):
+        obs = self.vec.reset()[0].cpu().numpy()
+        self._refresh_slots()
+        self.episode_steps = 0
+        return {k: obs[s] for k, s in self._slots.items()}
+
+    def step(self, actions):
+        a = np.zeros((1, self.vec.A, 2), dtype=np.float32)
+        for k, s in self._slots.items():  # extra keys are ignored like base_env.py:205-212
+            if k in actions:
+                a[0, s] = np.asarray(actions[k], dtype=np.float32)
+        obs, rew, done, flags = self.vec.step(self._torch.from_numpy(a).to(self.vec.engine.device))
+        self.vec.engine.sync()
+        obs, rew, done = obs[0].cpu().numpy(), rew[0].cpu().numpy(), done[0].cpu().numpy()
+        fl = flags[0].cpu().numpy().astype(np.uint32)
+        self.episode_steps += 1
+        o, r, d, info = {}, {}, {}, {}
+        for k, s in self._slots.items():  # agents that acted this step
+            assert fl[s] & _abi.F_REPORT
+            o[k], r[k], d[k] = obs[s], float(rew[s]), bool(done[s])
+            info[k] = dict(
+                arrive_dest=bool(fl[s] & _abi.F_ARRIVE), out_of_road=bool(fl[s] & _abi.F_OUT_OF_ROAD),
+                crash_vehicle=bool(fl[s] & _abi.F_CRASH_VEHICLE), crash=bool(fl[s] & _abi.F_CRASH_VEHICLE),
+                max_step=bool(fl[s] & _abi.F_MAX_STEP), step_reward=float(rew[s]),
+                cost=1 if (fl[s] & _abi.F_CRASH_VEHICLE and not fl[s] & _abi.F_OUT_OF_ROAD) else 0,
+            )
+        all_done = bool(fl[0] & _abi.F_ALL_DONE)
+        self._refresh_slots()
+        if not all_done:
+            status, ids = self.vec.slot_table()
+            for s in range(self.vec.A):  # respawned agents: obs of the newcomer, reward 0, not done
+                if fl[s] & _abi.F_NEW and not fl[s] & _abi.F_REPORT:
+                    k = "agent%d" % ids[0, s]
+                    o[k], r[k], d[k], info[k] = obs[s], 0.0, False, {}
+        d["__all__"] = all_done
+        if all_done:
+            for k in list(d.keys()):
+                d[k] = True
+        return o, r, d, info
+
+    def close(self):
+        self.vec.close()

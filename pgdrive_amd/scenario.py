@@ -260,3 +260,105 @@ class ScenarioBank:
         self.scenarios = np.array(scens, dtype=SCEN_DT)
         self.spawns = np.concatenate(spawns)
         self.V = num_agents + num_traffic
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# multi-agent (envs/marl_envs/multi_agent_pgdrive.py, marl_inout_roundabout.py, manager/spawn_manager.py)
+# ----------------------------------------------------------------------------------------------------------------------
+RESPAWN_REGION_LONGITUDE = 8.0  # spawn_manager.py:27
+RESPAWN_REGION_LATERAL = 3.0  # spawn_manager.py:28
+MAX_VEHICLE_LENGTH, MAX_VEHICLE_WIDTH = 10.0, 2.5  # base_vehicle.py:83-84
+ENTRANCE_LENGTH = 10  # first_block.py:21
+
+
+def neg_road(desc, frm, to):
+    """Road.__neg__ on node names (road.py:26-31)."""
+    nodes = desc["nodes"]
+    a, b = nodes[frm], nodes[to]
+    if b.find("-") == -1:
+        na, nb = "-" + b, "-" + a
+    else:
+        na, nb = b[b.find("-") + 1:], a[a.find("-") + 1:]
+    return nodes.index(na), nodes.index(nb)
+
+
+def roundabout_spawn_roads(desc):
+    """MARoundaboutConfig.spawn_roads (marl_inout_roundabout.py:15-28): '>>'->'>>>' and the three exits, negated."""
+    n = desc["nodes"]
+    roads = [(n.index(">>"), n.index(">>>"))]
+    for k in range(3):
+        roads.append(neg_road(desc, n.index("1O%d_2_" % k), n.index("1O%d_3_" % k)))
+    return roads
+
+
+def spawn_slots(desc, spawn_roads):
+    """SpawnManager._auto_fill_spawn_roads_randomly (spawn_manager.py:114-155): (road, lane, slot j) -> longitude;
+    the j == 0 slots are the safe respawn places."""
+    rl = mapdata.road_lookup(desc)
+    exit_length = desc["exit_length"] - ENTRANCE_LENGTH
+    num_slots = int(math.floor(exit_length / RESPAWN_REGION_LONGITUDE))
+    slots, safe = [], []
+    for (frm, to) in spawn_roads:
+        road = desc["roads"][rl[(frm, to)]]
+        for lane_idx in range(desc["lane_num"]):
+            for j in range(num_slots):
+                cfg = dict(lane=road["first_lane"] + lane_idx, long=0.5 * RESPAWN_REGION_LONGITUDE + j * RESPAWN_REGION_LONGITUDE,
+                           lat=0.0, road=(frm, to))
+                slots.append(cfg)
+                if j == 0:
+                    safe.append(cfg)
+    return slots, safe
+
+
+def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle_model="default"):
+    """SpawnManager.reset (spawn_manager.py:68-101): `num_agents` of the spawn slots without replacement, jittered inside
+    the slot, each with a random destination (RoundaboutSpawnManager.update_destination_for,
+    marl_inout_roundabout.py:125-130); followed by the respawn table [safe place][destination].
+    `rng` is a numpy RandomState (the reference leaves this manager unseeded)."""
+    A = capacity or num_agents
+    spawn_roads = roundabout_spawn_roads(desc)
+    slots, safe = spawn_slots(desc, spawn_roads)
+    if num_agents > len(slots):
+        raise ValueError("Too many agents! We only accept %d agents" % len(slots))
+    dests = [neg_road(desc, *r)[1] for r in spawn_roads]  # end node of the negated spawn road
+    P, Dn = len(safe), len(dests)
+    recs = np.zeros(A + P * Dn, dtype=SPAWN_DT)
+    recs["lane"] = -1
+    recs["group"] = -1
+    pick = rng.choice(len(slots), num_agents, replace=False)
+    lo, la = RESPAWN_REGION_LONGITUDE - MAX_VEHICLE_LENGTH, RESPAWN_REGION_LATERAL - MAX_VEHICLE_WIDTH
+    for a, idx in enumerate(pick):
+        c = slots[int(idx)]
+        lon = c["long"] + rng.uniform(-lo / 2, lo / 2)
+        lat = c["lat"] + rng.uniform(-la / 2, la / 2)
+        params = sample_vehicle_params(vehicle_model, int(rng.randint(0, MAX_RAND_INT)))
+        _fill_vehicle(recs[a], desc, c["lane"], lon, lat, params)
+        _fill_route(recs[a], desc, c["lane"], dests[int(rng.randint(0, Dn))])
+    for p, c in enumerate(safe):
+        for dn, dest in enumerate(dests):
+            r = recs[A + p * Dn + dn]
+            params = sample_vehicle_params(vehicle_model, int(rng.randint(0, MAX_RAND_INT)))
+            _fill_vehicle(r, desc, c["lane"], c["long"], c["lat"], params)
+            _fill_route(r, desc, c["lane"], dest)
+    scen = np.zeros((), dtype=SCEN_DT)
+    scen["map"] = map_index
+    scen["trigger_road"][:] = -1
+    return scen, recs, P, Dn
+
+
+class MarlScenarioBank:
+    """`n_variants` random initial placements over one multi-agent map (scenarios differ only in spawn choice)."""
+    def __init__(self, desc, num_agents, capacity=None, n_variants=16, seed=0):
+        rng = np.random.RandomState(seed)
+        scens, recs = [], []
+        for _ in range(n_variants):
+            sc, rc, self.P, self.Dn = build_marl_scenario(desc, 0, rng, num_agents, capacity)
+            scens.append(sc)
+            recs.append(rc)
+        self.scenarios = np.array(scens, dtype=SCEN_DT)
+        self.spawns = np.concatenate(recs)
+        self.A = capacity or num_agents
+        self.V = self.A
+        self.num_agents = num_agents
+        self.stride = self.A + self.P * self.Dn
+        self.info = []

@@ -107,3 +107,37 @@ def test_checkpoint_resume_roundtrip():
             assert torch.equal(x, y)
     finally:
         env.close()
+
+
+def test_marl_dict_protocol():
+    """Key-set invariants of the reference's MARL tests (tests/test_env/test_ma_roundabout_env.py:73-200,
+    test_marl_reborn.py:6-60): obs/reward/done/info share keys, finished agents disappear, newcomers get fresh
+    increasing ids, -penalty => done, __all__ ends the episode."""
+    from pgdrive_amd.marl_env import MultiAgentRoundaboutEnv
+    env = MultiAgentRoundaboutEnv(dict(num_agents=8, horizon=150, seed=2))
+    try:
+        o = env.reset()
+        assert len(o) == 8 and all(v.shape == (90, ) for v in o.values())
+        assert sorted(o) == ["agent%d" % k for k in range(8)]
+        max_id = 7
+        seen_new = False
+        for t in range(400):
+            # even ids floor it (crash / leave the road), odd ids creep: the episode stays alive and slots get re-used
+            act = {k: ([0.0, 1.0] if int(k[5:]) % 2 == 0 else [0.0, 0.12]) for k in o}
+            o, r, d, i = env.step(act)
+            keys = set(o)
+            assert keys == set(r) == set(i) == set(d) - {"__all__"}
+            for k in keys:
+                assert env.vec.single_observation_space.contains(o[k])
+                if r[k] == -10.0:
+                    assert d[k] and (i[k]["out_of_road"] or i[k]["crash_vehicle"])
+                kid = int(k[5:])
+                if kid > max_id:
+                    seen_new, max_id = True, kid
+            if d["__all__"]:
+                assert all(d.values())
+                break
+            o = {k: v for k, v in o.items() if not d[k]}
+        assert d["__all__"] and seen_new and t >= 149
+    finally:
+        env.close()

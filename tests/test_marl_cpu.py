@@ -1,0 +1,98 @@
+"""Multi-agent roundabout, CPU side: map boxes + spawn-slot table vs reference goldens, and the oracle's episode protocol
+(multi_agent_pgdrive.py:109-213) — no GPU needed."""
+import json
+import os
+
+import numpy as np
+
+from pgdrive_amd import _abi, bank, mapdata, scenario
+from tests import util
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _desc():
+    return bank.load_descriptions(bank.MA_ROUNDABOUT_BANK)[0]
+
+
+def test_roundabout_boxes_match_reference():
+    d = _desc()
+    ref = np.load(os.path.join(GOLD, "boxes_ma_roundabout.npz"))["boxes"]
+    mine = mapdata.build_boxes(d)
+    assert ref.shape == mine.shape == (704, 7)
+    assert (ref[:, 0] == mine[:, 0]).all() and (ref[:, 6] == mine[:, 6]).all()
+    assert np.abs(ref[:, [1, 2, 4, 5]] - mine[:, [1, 2, 4, 5]]).max() < 1e-9
+    assert len(d["lanes"]) == 52
+
+
+def test_spawn_slots_match_reference():
+    """SpawnManager slot table (spawn_manager.py:114-155) on MARoundaboutConfig.spawn_roads (marl_inout_roundabout.py:15-28)."""
+    with open(os.path.join(GOLD, "scenes_v0.json")) as f:
+        g = json.load(f)
+    d = _desc()
+    roads = scenario.roundabout_spawn_roads(d)
+    slots, safe = scenario.spawn_slots(d, roads)
+    assert len(slots) == g["marl_capacity"] == 48 and len(safe) == 8
+    for mine, ref in zip(slots, g["marl_slots"]):
+        assert [d["nodes"][mine["road"][0]], d["nodes"][mine["road"][1]]] == ref["road"]
+        lane = d["lanes"][mine["lane"]]
+        assert lane["index"] == ref["lane_idx"] and mine["long"] == ref["long"]
+        x, y = mapdata.lane_position(lane, mine["long"], 0.0)
+        assert abs(x - ref["x"]) < 1e-9 and abs(y - ref["y"]) < 1e-9
+        assert abs(mapdata.lane_heading_at(lane, mine["long"]) - ref["heading"]) < 1e-12
+    dests = [d["nodes"][scenario.neg_road(d, *r)[1]] for r in roads]
+    assert dests == g["marl_dest_nodes"]
+    import pytest
+    with pytest.raises(ValueError, match="Too many agents"):
+        scenario.MarlScenarioBank(d, num_agents=49, n_variants=1)
+
+
+def test_oracle_marl_episode_protocol():
+    """delay-done queue, respawn ids, horizon, __all__ + auto-reset on the CPU oracle."""
+    from oracle import orc
+    d, mb, sb = util.make_marl_banks(num_agents=8, n_variants=4)
+    n = 4
+    cfg = util.marl_config(n, sb, horizon=80)
+    o = orc.Oracle(cfg, mb, sb)
+    obs = o.reset(np.arange(n) % 4)
+    assert obs.shape == (n, 8, 90)
+    rng = np.random.default_rng(0)
+    SI, SF, EI = _abi.SI, _abi.SF, _abi.EI
+    max_id = np.full(n, 7)
+    n_all = 0
+    prev_status = o.get_state()[1][SI["STATUS"]].copy()
+    dying_age = np.zeros((n, 8), dtype=int)
+    for t in range(300):
+        act = util.marl_actions(rng, n, 8)
+        obs, rew, done, fl = o.step(act)
+        f, i, ei = o.get_state()
+        st = i[SI["STATUS"]]
+        report = (fl & _abi.F_REPORT) != 0
+        new = (fl & _abi.F_NEW) != 0
+        reset = (fl & _abi.F_RESET) != 0
+        # only agents that were active at the start of the step report
+        assert (report == (prev_status == _abi.ST_ACTIVE)).all()
+        assert (done[~report] == 0).all() and (rew[~report] == 0).all()
+        # a finished agent either leaves at once (arrival) or becomes a static dying body for delay_done steps
+        fin = report & (done == 1) & ~reset
+        assert ((st[fin] == _abi.ST_DYING) | (st[fin] == _abi.ST_EMPTY)).all()
+        assert (i[SI["TIMER"]][fin & (st == _abi.ST_DYING)] == 25).all()
+        dying_age = np.where(st == _abi.ST_DYING, dying_age + 1, 0)
+        assert dying_age.max() <= 25
+        # newcomers carry fresh, increasing ids; NEXT_AGENT counts them
+        ids = f[SF["AGENT_ID"]].astype(int)
+        for e in range(n):
+            if reset[e].any():
+                assert (ei[EI["EP_STEPS"], e] == 0) and ei[EI["NEXT_AGENT"], e] == 8
+                max_id[e] = 7
+                n_all += 1
+                continue
+            for s in np.nonzero(new[e])[0]:
+                assert ids[e, s] > max_id[e]
+                max_id[e] = ids[e, s]
+            assert ei[EI["NEXT_AGENT"], e] == max_id[e] + 1
+            alive = ((st[e] == _abi.ST_ACTIVE) | (st[e] == _abi.ST_DYING)).sum()
+            assert alive <= 8
+        assert np.isfinite(obs).all() and obs.min() >= 0 and obs.max() <= 1
+        prev_status = st.copy()
+    assert n_all >= n  # every env finished at least one episode (horizon 80 -> __all__ soon after)

@@ -22,3 +22,27 @@ def driving_actions(rng, n, a=1):
 
 def round_state_f32(f):
     return np.asarray(f, dtype=np.float32).astype(np.float64)
+
+
+def make_marl_banks(num_agents=8, n_variants=8, seed=1, capacity=None):
+    from pgdrive_amd import bank
+    d = bank.load_descriptions(bank.MA_ROUNDABOUT_BANK)[0]
+    mb = mapdata.MapBank([d])
+    sb = scenario.MarlScenarioBank(d, num_agents=num_agents, capacity=capacity, n_variants=n_variants, seed=seed)
+    return d, mb, sb
+
+
+def marl_config(n_envs, sb, **kw):
+    """MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG (multi_agent_pgdrive.py:12-55): 72 beams / 40 m / 0 others, penalties 10."""
+    args = dict(num_agents=sb.A, num_traffic=0, num_lasers=72, num_others=0, lidar_dist=40.0, multi_agent=True, horizon=1000,
+                agent_limit=sb.num_agents, respawn_places=sb.P, respawn_dests=sb.Dn, out_of_road_penalty=10.0,
+                crash_vehicle_penalty=10.0, crash_object_penalty=10.0, delay_done=25, auto_reset=1)
+    args.update(kw)
+    return _abi.make_config(n_envs, **args)
+
+
+def marl_actions(rng, n, a):
+    act = np.zeros((n, a, 2), dtype=np.float32)
+    act[..., 0] = np.clip(rng.normal(0, 0.25, size=(n, a)), -1, 1)
+    act[..., 1] = np.clip(rng.normal(0.6, 0.4, size=(n, a)), -1, 1)
+    return act
