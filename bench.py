@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--lasers", type=int, default=240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="replicas only: skip the per-step RCCL gather")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     args = ap.parse_args()
 
     import torch
@@ -93,7 +94,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+    local_rank = local_rank % torch.cuda.device_count()  # plumbing tests may oversubscribe one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -113,21 +115,38 @@ def main():
 
     gather = world > 1 and not args.no_gather
     if gather:
-        # one exchange per step: obs | reward | done packed into a single fp32 row per env
-        pack = torch.empty((N, A * (D + 2)), dtype=torch.float32, device=dev)
-        gathered = torch.empty((world * N, A * (D + 2)), dtype=torch.float32, device=dev)
+        # one exchange per step: obs | reward | done packed into a single fp32 row per env, double-buffered:
+        # the all_gather of step t (RCCL's own stream) overlaps the kernels of step t+1; buffer b is re-used at step t+2
+        # only after its gather has completed
+        bufs = [eng.make_outputs() for _ in range(2)]
+        packs = [torch.empty((N, A * (D + 2)), dtype=torch.float32, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world * N, A * (D + 2)), dtype=torch.float32, device=dev) for _ in range(2)]
+        pending = [None, None]
 
     def one_step(k):
-        obs, rew, done, flags = eng.step(actions[k % CYC])
+        if not gather:
+            eng.step(actions[k % CYC])
+            return
+        b = k % 2
+        if pending[b] is not None:
+            pending[b].wait()  # stream-level wait: step k may overwrite what the gather of step k-2 was reading
+        obs, rew, done, flags = eng.step(actions[k % CYC], out=bufs[b])
+        pack = packs[b]
+        pack[:, :A * D] = obs.view(N, A * D)
+        pack[:, A * D:A * D + A] = rew
+        pack[:, A * D + A:] = done.to(torch.float32)
+        pending[b] = dist.all_gather_into_tensor(gathered[b], pack, async_op=True)
+
+    def drain():
         if gather:
-            pack[:, :A * D] = obs.view(N, A * D)
-            pack[:, A * D:A * D + A] = rew
-            pack[:, A * D + A:] = done.to(torch.float32)
-            dist.all_gather_into_tensor(gathered, pack)
+            for w in pending:
+                if w is not None:
+                    w.wait()
 
     with torch.cuda.stream(eng.stream):
         for k in range(args.warmup):
             one_step(k)
+        drain()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -136,6 +155,7 @@ def main():
         t0 = time.perf_counter()
         for k in range(args.steps):
             one_step(args.warmup + k)
+        drain()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -168,7 +188,7 @@ def main():
                 "workload": "C3: %d envs/GPU x (1 ego + %d IDM traffic slots) x %d lidar beams, PGDrive-v0 maps "
                             "seeds 1000-1099, uniform(-1,1) actions, auto-reset" % (N, args.traffic, args.lasers),
                 "envs_per_gpu": N, "global_envs": N * world, "obs_dim": D,
-                "parallelism": "env-sharded dp%d%s" % (world, " + RCCL all_gather(obs,reward,done)/step" if gather else ""),
+                "parallelism": "env-sharded dp%d%s" % (world, " + 1 RCCL all_gather(obs,reward,done)/step, double-buffered" if gather else ""),
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom + (" (observation fused)" if fused else ""), "achieved": achieved,

@@ -119,23 +119,33 @@ class Engine:
         self.sync()
         return self.obs
 
-    def step(self, actions, want_obs=True):
-        """actions: float32 cuda tensor [N, A, 2] (contiguous). Asynchronous on the engine stream."""
+    def make_outputs(self):
+        """A second set of output buffers (double buffering of the per-step gather, pgdrive_amd/dist.py)."""
+        t, dev = self.torch, self.device
+        return (t.zeros((self.N, self.A, self.D), dtype=t.float32, device=dev),
+                t.zeros((self.N, self.A), dtype=t.float32, device=dev),
+                t.zeros((self.N, self.A), dtype=t.uint8, device=dev),
+                t.zeros((self.N, self.A), dtype=t.int32, device=dev))
+
+    def step(self, actions, want_obs=True, out=None):
+        """actions: float32 cuda tensor [N, A, 2] (contiguous). Asynchronous on the engine stream.
+        `out` = (obs, reward, done, flags) tensors to write instead of the engine's own buffers."""
         assert actions.is_cuda and actions.dtype == self.torch.float32 and actions.is_contiguous()
         assert actions.numel() == self.N * self.A * 2
+        obs, reward, done, flags = out if out is not None else (self.obs, self.reward, self.done, self.flags)
         cur = self.torch.cuda.current_stream(self.device)
         foreign = cur != self.stream
         if foreign:
             self.stream.wait_stream(cur)
         _chk(
             self.L.pgd_step(
-                self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()) if want_obs else None,
-                C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()), C.c_void_p(self.flags.data_ptr())
+                self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()) if want_obs else None,
+                C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(flags.data_ptr())
             ), "pgd_step"
         )
         if foreign:
             cur.wait_stream(self.stream)
-        return self.obs, self.reward, self.done, self.flags
+        return obs, reward, done, flags
 
     def observe(self):
         _chk(self.L.pgd_observe(self.h, C.c_void_p(self.obs.data_ptr())), "pgd_observe")
