@@ -51,7 +51,7 @@ def cpu_baseline(descs, args, seconds=12.0):
     from oracle import orc
     from pgdrive_amd import _abi, mapdata, scenario
     n = 256
-    sel = descs[:16]
+    sel = list(descs[:16])
     mb = mapdata.MapBank(sel)
     sb = scenario.ScenarioBank(sel, [d["seed"] for d in sel], num_agents=1, num_traffic=args.traffic)
     cfg = _abi.make_config(n, num_agents=1, num_traffic=args.traffic, num_lasers=args.lasers)
@@ -99,7 +99,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    descs = bank.load_descriptions()
+    descs = bank.get_descriptions(range(1000, 1100))  # generated on the host by our own BIG (pgdrive_amd/mapgen.py)
     mb = mapdata.MapBank(descs)
     sb = scenario.ScenarioBank(descs, [d["seed"] for d in descs], num_agents=1, num_traffic=args.traffic)
     N, A = args.envs, 1

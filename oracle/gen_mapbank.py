@@ -53,8 +53,29 @@ def main_marl():
     print("wrote", out, os.path.getsize(out))
 
 
+def main_mapgen_goldens():
+    """Extra goldens for pgdrive_amd/mapgen.py beyond the 100-seed bank: other block counts, lane counts / widths and
+    explicit block sequences through every block type -> tests/golden/mapgen_v0.json.gz"""
+    root = os.path.dirname(HERE)
+    cases = []
+    for seed, kw in [(0, dict(block_num=7)), (1, dict(block_num=7)), (2, dict(block_num=5)), (3, dict(block_num=1)),
+                     (11, dict(block_num=4, lane_num=2)), (12, dict(block_num=4, lane_num=2, lane_width=3.0)),
+                     (13, dict(block_num=3, lane_num=3, lane_width=4.5, exit_length=60)),
+                     (5, dict(block_seq="SCS")), (6, dict(block_seq="XTO")), (7, dict(block_seq="rRC")),
+                     (8, dict(block_seq="OOO")), (9, dict(block_seq="TTT")), (10, dict(block_seq="CrXRTOS")),
+                     (4242, dict(block_num=10))]:
+        m = ref_export.generate(seed, **kw)
+        cases.append(dict(seed=seed, kw=kw, desc=strip(m)))
+    out = os.path.join(root, "tests", "golden", "mapgen_v0.json.gz")
+    with gzip.GzipFile(out, "wb", mtime=0) as f:
+        f.write(json.dumps(dict(cases=cases), separators=(",", ":")).encode())
+    print("wrote", out, os.path.getsize(out))
+
+
 if __name__ == "__main__":
     if "--marl" in sys.argv:
         main_marl()
+    elif "--mapgen" in sys.argv:
+        main_mapgen_goldens()
     else:
         main()

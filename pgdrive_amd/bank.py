@@ -18,3 +18,19 @@ def load_descriptions(path=DEFAULT_BANK):
 def save_descriptions(descs, path, source="pgdrive_amd"):
     with gzip.GzipFile(path, "wb", mtime=0) as f:
         f.write(json.dumps(dict(version=0, source=source, maps=descs), separators=(",", ":")).encode())
+
+
+_CACHE = {}
+
+
+def get_descriptions(seeds, lane_num=3, lane_width=3.5, exit_length=50, block_num=3, block_seq=None):
+    """Map descriptions for `seeds`, generated on the host by our own BIG (pgdrive_amd/mapgen.py) and cached per process
+    (MapManager's per-seed PGMap cache, manager/map_manager.py:98-155)."""
+    from . import mapgen
+    out = []
+    for s in seeds:
+        key = (int(s), lane_num, lane_width, exit_length, block_num, block_seq)
+        if key not in _CACHE:
+            _CACHE[key] = mapgen.generate_map(int(s), lane_num, lane_width, exit_length, block_num, block_seq)
+        out.append(_CACHE[key])
+    return out

@@ -19,6 +19,7 @@ from .vec_env import merge_config
 MA_DEFAULT_CONFIG = dict(
     num_envs=1,
     num_agents=40,
+    map_config=dict(exit_length=60, lane_num=2, lane_width=3.5),  # marl_inout_roundabout.py:23
     max_agents=None,  # slot capacity per env (default: num_agents); the reference has no cap
     crash_done=True,
     out_of_road_done=True,
@@ -48,7 +49,9 @@ class MultiAgentRoundaboutVecEnv:
         lid = c["vehicle_config"]["lidar"]
         if lid["num_others"] != 0:
             raise NotImplementedError("LidarStateObservationMARound with num_others > 0 is not built (reference default 0)")
-        self.desc = bank.load_descriptions(bank.MA_ROUNDABOUT_BANK)[0]
+        from . import mapgen
+        mc = c["map_config"]
+        self.desc = mapgen.generate_ma_roundabout(mc["lane_num"], mc["lane_width"], mc["exit_length"])
         self.map_bank = mapdata.MapBank([self.desc])
         cap = c["max_agents"] or c["num_agents"]
         self.scen_bank = scenario.MarlScenarioBank(self.desc, c["num_agents"], capacity=cap,

@@ -45,7 +45,7 @@ DEFAULT_CONFIG = dict(
     resample_scenario=True,  # a new seed per episode like _reset_global_seed (base_env.py:451-458)
     device=0,
     seed=0,
-    map_bank=None,  # path of a description bank; None -> shipped PGDrive-v0 bank
+    map_bank=None,  # path of a pre-generated description bank; None -> generate with our BIG (pgdrive_amd/mapgen.py)
 )
 
 
@@ -73,16 +73,18 @@ class PGDriveVecEnv:
             raise NotImplementedError("side / lane-line detectors are not built yet (0 lasers is the reference default)")
         if c["traffic_mode"] != "trigger":
             raise NotImplementedError("only TrafficMode.Trigger (the reference default) is built")
-        if c["map"] != 3 or c["map_config"] != DEFAULT_CONFIG["map_config"]:
-            if c["map_bank"] is None:
-                raise NotImplementedError("only the shipped map bank (map=3, lane_num=3, lane_width=3.5) is available; "
-                                          "pass map_bank=<path> for other maps")
-        descs = bank.load_descriptions(c["map_bank"] or bank.DEFAULT_BANK)
-        by_seed = {d["seed"]: d for d in descs}
+        mc = c["map_config"]
         seeds = list(range(c["start_seed"], c["start_seed"] + c["environment_num"]))
-        missing = [s for s in seeds if s not in by_seed]
-        if missing:
-            raise KeyError("map seeds %s..%s are not in the map bank" % (missing[0], missing[-1]))
+        if c["map_bank"] is not None:  # pre-generated descriptions (load_map_from_json, pgdrive_env.py:38-39)
+            by_seed = {d["seed"]: d for d in bank.load_descriptions(c["map_bank"])}
+            missing = [s for s in seeds if s not in by_seed]
+            if missing:
+                raise KeyError("map seeds %s..%s are not in the map bank" % (missing[0], missing[-1]))
+        else:  # BIG on the host: `map` is a block count (int) or a block sequence (str) (base_map.py:16-35)
+            m = c["map"]
+            kw = dict(block_num=m) if isinstance(m, int) else dict(block_seq=m, block_num=None)
+            by_seed = {d["seed"]: d for d in bank.get_descriptions(seeds, mc["lane_num"], mc["lane_width"],
+                                                                   mc["exit_length"], **kw)}
         self.seeds = seeds
         sel = [by_seed[s] for s in seeds]
         self.num_envs = int(c["num_envs"])

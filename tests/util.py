@@ -25,8 +25,8 @@ def round_state_f32(f):
 
 
 def make_marl_banks(num_agents=8, n_variants=8, seed=1, capacity=None):
-    from pgdrive_amd import bank
-    d = bank.load_descriptions(bank.MA_ROUNDABOUT_BANK)[0]
+    from pgdrive_amd import mapgen
+    d = mapgen.generate_ma_roundabout()
     mb = mapdata.MapBank([d])
     sb = scenario.MarlScenarioBank(d, num_agents=num_agents, capacity=capacity, n_variants=n_variants, seed=seed)
     return d, mb, sb
