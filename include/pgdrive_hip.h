@@ -155,6 +155,12 @@ typedef struct pgd_config {
   int32_t agent_limit;      /* num_agents of the reference: respawn only while active + dying < agent_limit */
   int32_t respawn_places;   /* P safe spawn places (SpawnManager.safe_spawn_places, spawn_manager.py:114-155) */
   int32_t respawn_dests;    /* Dn destinations; every scenario carries P*Dn extra pgd_spawn records after its V slots */
+  /* SideDetector / LaneLineDetector ray fans against lane-line boxes (vehicle_module/distance_detector.py:137-152);
+   * 0 lasers (the reference default, pgdrive_env.py:64-65) keeps the two lateral-distance floats of state_obs.py:66-71 */
+  int32_t side_lasers;      /* k: rays vs continuous (white / yellow / side) line boxes; replace obs[0:2] when > 0 */
+  float side_dist;          /* 50 m */
+  int32_t lane_line_lasers; /* m: rays vs continuous + broken line boxes; inserted after the yaw-rate float when > 0 */
+  float lane_line_dist;     /* 20 m */
   int32_t pad;
 } pgd_config;
 
@@ -165,7 +171,8 @@ typedef struct pgd_config {
 
 typedef struct pgd_engine* pgd_handle;
 
-/* Size of one observation row D = 8 + 10 + 4*num_others + num_lasers (obs/state_obs.py:17-23,124-130). */
+/* Size of one observation row D = (side_lasers or 2) + 6 + lane_line_lasers + 10 + 4*num_others + num_lasers
+ * (obs/state_obs.py:17-23,108-114,124-130); 274 at the defaults. */
 int pgd_obs_dim(const pgd_config* cfg);
 
 /* Replaces PGDriveEnv.__init__ / lazy_init (envs/base_env.py:100-178): allocates device state for N x V slots. */

@@ -447,6 +447,98 @@ def gen_scenes(rng, maps, out_json):
     out_json["scenes"] = scenes
 
 
+def _make_detector(cls, n, dist):
+    """Instantiate the reference's SideDetector / LaneLineDetector (distance_detector.py:137-152) with a stub render
+    root, so that beam angles (`_lidar_range`), range and collision mask are the reference's own values."""
+    from pgdrive.component.vehicle_module import distance_detector as dd
+    from panda3d.core import NodePath
+    dd.get_engine = lambda: types.SimpleNamespace(render=NodePath("render"))
+    return cls(n, dist, enable_show=False)
+
+
+def exact_fan(det, px, py, theta, boxes):
+    """cutils_perceive (cutils.pyx:60-142) against the static line boxes: beam i points at _lidar_range[i] + theta, the
+    closest hit among boxes whose into-mask (base_block.py:301,348) meets the detector's mask; a box that contains the
+    ray origin is not hit (Bullet's convex ray cast reports no hit from inside)."""
+    from pgdrive.constants import CollisionGroup
+    into = {1: CollisionGroup.ContinuousLaneLine, 2: CollisionGroup.ContinuousLaneLine, 3: CollisionGroup.BrokenLaneLine}
+    res = []
+    for i in range(det.num_lasers):
+        ang = det._lidar_range[i] + theta
+        best = 1e9
+        for (kind, cx, cy, th, hl, hw, _lane) in boxes:
+            kind = int(kind)
+            if kind not in into or not int(det.mask & into[kind]):
+                continue
+            c, s_ = math.cos(th), math.sin(th)
+            dx, dy = px - cx, py - cy
+            if abs(dx * c + dy * s_) <= hl and abs(-dx * s_ + dy * c) <= hw:
+                continue
+            if math.hypot(dx, dy) > det.perceive_distance + hl + hw:
+                continue
+            cs = box_corners(cx, cy, th, hl, hw)
+            for k in range(4):
+                best = min(best, line_intersect(ang, (px, py), cs[k], cs[(k + 1) % 4], maximum=1e9))
+        res.append(min(best / det.perceive_distance, 1.0))
+    return res
+
+
+def gen_detectors(maps):
+    """SideDetector / LaneLineDetector fans inside StateObservation.vehicle_state (state_obs.py:64-71,96-105)."""
+    from pgdrive.component.vehicle_module.distance_detector import LaneLineDetector, SideDetector
+    rng = np.random.default_rng(20240928)
+    cases = []
+    configs = [(2, 50.0, 2, 50.0), (12, 50.0, 6, 20.0), (7, 50.0, 0, 20.0), (0, 50.0, 5, 20.0), (32, 30.0, 16, 20.0)]
+    for m in maps:
+        fmap = FakeMap(m)
+        lanes = ref_lanes_in_order(m)
+        lane_ids = {id(l): k for k, l in enumerate(lanes)}
+        nodes, net = m["nodes"], m["net"]
+        dest = my_scenario.choose_destination(m, m["seed"], nodes.index(">"))
+        ckpt_ids, _, _, _ = my_scenario.make_route(m, 0, dest)
+        ckpt = [nodes[i] for i in ckpt_ids]
+        for rep in range(10):
+            ks, ds, km, dm = configs[rep % len(configs)]
+            k0 = int(rng.integers(0, len(ckpt) - 1))
+            idx = [k0, k0 + 1] if k0 + 1 < len(ckpt) - 1 else [k0, k0]
+            cur = net.graph[ckpt[k0]][ckpt[k0 + 1]]
+            el = cur[int(rng.integers(0, len(cur)))]
+            lon = rng.uniform(1.0, max(el.length - 1.0, 1.5))
+            lat = rng.uniform(-1.7, 1.7)
+            p = el.position(lon, lat)
+            ego = FakeVehicle(p[0], p[1], el.heading_at(lon) + rng.normal(0, 0.15), rng.uniform(0, 80), 4.51, 1.852)
+            ego.lane, ego.lane_index = el, el.index
+            ego.steering = rng.uniform(-1, 1)
+            ego.last_current_action = [(rng.uniform(-1, 1), rng.uniform(-1, 1)), (0.3, 0.2)]
+            lth = ego.heading_theta - rng.normal(0, 0.02)
+            ego.last_heading_dir = Vector((math.cos(lth), math.sin(lth)))
+            ego.last_position = Vector((p[0] - 0.8 * math.cos(lth), p[1] - 0.8 * math.sin(lth)))
+            ego.navigation = make_navigation(fmap, ckpt, idx)
+            ego.engine = types.SimpleNamespace(physics_world=types.SimpleNamespace(static_world=None))
+            left, right = BaseVehicle._dist_to_route_left_right(ego)
+            ego.dist_to_left_side, ego.dist_to_right_side = left, right
+            for det_cls, attr, n, dist in ((SideDetector, "side_detector", ks, ds), (LaneLineDetector, "lane_line_detector", km, dm)):
+                det = _make_detector(det_cls, n, dist)
+                det.perceive = (lambda det_: lambda v, world, detector_mask=None: types.SimpleNamespace(
+                    cloud_points=exact_fan(det_, v.position[0], v.position[1], v.heading_theta, m["boxes"])))(det)
+                setattr(ego, attr, det)
+            sobs = StateObservation.__new__(StateObservation)
+            sobs.config = {"random_agent_model": False}
+            state = [float(x) for x in StateObservation.vehicle_state(sobs, ego)]
+            assert len(state) == (ks or 2) + 6 + km
+            cases.append(dict(
+                seed=m["seed"], side=[ks, ds], lane_line=[km, dm], state=state, left=left, right=right,
+                vehicles=[dict(x=p[0], y=p[1], theta=ego.heading_theta, speed_kmh=ego.speed, length=4.51, width=1.852,
+                               lane=lane_ids[id(el)], ckpt=[nodes.index(n) for n in ckpt], idx=idx)],
+                ego=dict(steering=ego.steering, act0=list(ego.last_current_action[0]),
+                         last_heading=[ego.last_heading_dir[0], ego.last_heading_dir[1]],
+                         last_position=[ego.last_position[0], ego.last_position[1]]),
+            ))
+    with open(os.path.join(ROOT, "tests", "golden", "detectors_v0.json"), "w") as f:
+        json.dump(dict(cases=cases), f)
+    print("wrote detector goldens:", len(cases))
+
+
 def gen_checkpoints(rng, maps, out_json):
     """Navigation._update_target_checkpoints (navigation.py:262-282) on real routes."""
     rows = []
@@ -529,8 +621,11 @@ def main():
     rng = np.random.default_rng(20240927)
     out = {}
     out_json = {}
-    gen_scalar(rng, out)
     maps = [ref_export.generate(s, block_num=3) for s in (1000, 1003, 1017)]
+    gen_detectors(maps)  # own rng and own file: does not disturb the vectors below
+    if "--detectors-only" in sys.argv:
+        return
+    gen_scalar(rng, out)
     for m in maps[:2]:
         gen_lanes(rng, m, out, str(m["seed"]))
     gen_pid(rng, out)

@@ -11,7 +11,8 @@ class PgdConfig(C.Structure):
         ("crash_object_penalty", C.c_float), ("driving_reward", C.c_float), ("speed_reward", C.c_float),
         ("use_lateral", C.c_int32), ("out_of_route_done", C.c_int32), ("marl_flags", C.c_int32),
         ("delay_done", C.c_int32), ("agent_limit", C.c_int32), ("respawn_places", C.c_int32),
-        ("respawn_dests", C.c_int32), ("pad", C.c_int32),
+        ("respawn_dests", C.c_int32), ("side_lasers", C.c_int32), ("side_dist", C.c_float),
+        ("lane_line_lasers", C.c_int32), ("lane_line_dist", C.c_float), ("pad", C.c_int32),
     ]
 
 
@@ -20,7 +21,7 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
                 out_of_road_penalty=5.0, crash_vehicle_penalty=5.0, crash_object_penalty=5.0, driving_reward=1.0,
                 speed_reward=0.1, use_lateral=False, out_of_route_done=False, multi_agent=False, crash_done=True,
                 out_of_road_done=True, allow_respawn=True, delay_done=25, agent_limit=0, respawn_places=0,
-                respawn_dests=0):
+                respawn_dests=0, side_lasers=0, side_dist=50.0, lane_line_lasers=0, lane_line_dist=20.0):
     """Defaults mirror PGDriveEnv_DEFAULT_CONFIG / BASE_DEFAULT_CONFIG (pgdrive_env.py:22-109, base_env.py:19-90)."""
     c = PgdConfig()
     c.num_envs, c.num_agents, c.num_traffic = num_envs, num_agents, num_traffic
@@ -31,6 +32,8 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
     c.crash_vehicle_penalty, c.crash_object_penalty = crash_vehicle_penalty, crash_object_penalty
     c.driving_reward, c.speed_reward = driving_reward, speed_reward
     c.use_lateral, c.out_of_route_done = int(bool(use_lateral)), int(bool(out_of_route_done))
+    c.side_lasers, c.side_dist = int(side_lasers), float(side_dist)
+    c.lane_line_lasers, c.lane_line_dist = int(lane_line_lasers), float(lane_line_dist)
     if multi_agent:
         c.marl_flags = MA_ENABLED | (MA_CRASH_DONE if crash_done else 0) | (MA_OUT_ROAD_DONE if out_of_road_done else 0) | \
             (MA_ALLOW_RESPAWN if allow_respawn else 0)
@@ -40,7 +43,7 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
 
 
 def obs_dim(cfg):
-    return 8 + 10 + 4 * cfg.num_others + cfg.num_lasers
+    return (cfg.side_lasers or 2) + 6 + cfg.lane_line_lasers + 10 + 4 * cfg.num_others + cfg.num_lasers
 
 
 # state layout (include/pgd_state_layout.h)

@@ -190,7 +190,7 @@ DEV float ray_obb(const Obb& o, float px, float py, float dx, float dy) {
     t1 = fminf(t1, fmaxf(a, b));
     if (t0 > t1) return 1.0f;
   }
-  return t0;
+  return t0 > 0.0f ? t0 : 1.0f;  // origin inside the box: no hit (Bullet's convex ray cast semantics)
 }
 
 // BaseVehicle.projection (base_vehicle.py:460-475)

@@ -663,6 +663,38 @@ DEV float heading_diff(const pgd_lane& l, float px, float py, float fx, float fy
   return clipf((fx * lx + fy * ly) / (ln * fn), -1.0f, 1.0f) * 0.5f + 0.5f;
 }
 
+// nearest hit fraction of the segment p + t d (t in [0,1]) against the map's boxes whose kind is in `kinds`: Amanatides-Woo
+// walk over the uniform grid; a cell is skipped once its entry parameter is beyond the best hit so far
+DEV float ray_grid(const MapView& mv, float px, float py, float dx, float dy, unsigned kinds) {
+  const pgd_map& m = *mv.m;
+  const float inv = 1.0f / m.cell;
+  int ix = (int)floorf((px - m.ox) * inv), iy = (int)floorf((py - m.oy) * inv);
+  const int sx = dx > 0.0f ? 1 : -1, sy = dy > 0.0f ? 1 : -1;
+  const float big = 3.0e38f;
+  const float tdx = dx != 0.0f ? fabsf(m.cell / dx) : big, tdy = dy != 0.0f ? fabsf(m.cell / dy) : big;
+  float tmx = dx != 0.0f ? ((m.ox + (ix + (dx > 0.0f ? 1 : 0)) * m.cell) - px) / dx : big;
+  float tmy = dy != 0.0f ? ((m.oy + (iy + (dy > 0.0f ? 1 : 0)) * m.cell) - py) / dy : big;
+  float best = 1.0f, t_enter = 0.0f;
+  for (int it = 0; it < 64; ++it) {
+    if (t_enter > best + 0.02f) break;  // boxes are registered with a 5 cm margin: keep a little slack
+    if (ix >= 0 && iy >= 0 && ix < m.gx && iy < m.gy) {
+      const int cell = iy * m.gx + ix;
+      const int k1 = mv.cstart[cell + 1];
+      for (int k = mv.cstart[cell]; k < k1; ++k) {
+        const pgd_box b = mv.cbox[k];
+        if (!((1u << b.kind) & kinds)) continue;
+        best = fminf(best, ray_obb(obb_of(b), px, py, dx, dy));
+      }
+    } else if ((sx > 0 ? ix >= m.gx : ix < 0) || (sy > 0 ? iy >= m.gy : iy < 0)) {
+      break;  // left the grid for good
+    }
+    if (tmx < tmy) { t_enter = tmx; tmx += tdx; ix += sx; }
+    else { t_enter = tmy; tmy += tdy; iy += sy; }
+    if (t_enter > 1.0f) break;
+  }
+  return best;
+}
+
 struct ObsLds {  // vehicles inside the lidar broad phase of the observing agent, compacted
   float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV], bdist[MAXV];
   int n;
@@ -691,30 +723,48 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
   const float R = d.cfg.lidar_dist;
   const int NL = d.cfg.num_lasers;
-  // StateObservation.vehicle_state (state_obs.py:58-106) + navi info (navigation.py:185-197): one lane per float
-  if (tid < 8 + 10) {
+  // StateObservation.vehicle_state (state_obs.py:58-106) + navi info (navigation.py:185-197): one lane per float.
+  // Row layout: [side fan k | 2 lateral distances][6 ego floats][lane-line fan m][10 navi][4*NO neighbours][NL beams]
+  const int KS = d.cfg.side_lasers, KM = d.cfg.lane_line_lasers;
+  const int o_ego = KS > 0 ? KS : 2, o_navi = o_ego + 6 + KM, o_oth = o_navi + 10;
+  if (tid < 18) {
     const pgd_road& CR = mv.roads[sp.ckpt_road[ag.ck0]];
     float v = 0.0f;
-    if (tid == 0) v = clipf(ag.dl / 18.0f, 0.0f, 1.0f);  // (MAX_LANE_NUM+1)*MAX_LANE_WIDTH (pg_map.py:13-15)
-    else if (tid == 1) v = clipf(ag.dr / 18.0f, 0.0f, 1.0f);
-    else if (tid == 2) v = heading_diff(mv.lanes[CR.first_lane + CR.n_lanes - 1], px, py, hx, hy);
-    else if (tid == 3) v = clipf((speed_kmh(ag.v) + 1.0f) / (sp.max_speed + 1.0f), 0.0f, 1.0f);
-    else if (tid == 4) v = clipf((ag.steer / 60.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
-    else if (tid == 5) v = clipf((ag.a0s + 1.0f) * 0.5f, 0.0f, 1.0f);
-    else if (tid == 6) v = clipf((ag.a0t + 1.0f) * 0.5f, 0.0f, 1.0f);
+    int col = -1;
+    if (tid == 0) { v = clipf(ag.dl / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 0; }  // (MAX_LANE_NUM+1)*MAX_LANE_WIDTH
+    else if (tid == 1) { v = clipf(ag.dr / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 1; }
+    else if (tid == 2) { v = heading_diff(mv.lanes[CR.first_lane + CR.n_lanes - 1], px, py, hx, hy); col = o_ego; }
+    else if (tid == 3) { v = clipf((speed_kmh(ag.v) + 1.0f) / (sp.max_speed + 1.0f), 0.0f, 1.0f); col = o_ego + 1; }
+    else if (tid == 4) { v = clipf((ag.steer / 60.0f + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 2; }
+    else if (tid == 5) { v = clipf((ag.a0s + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 3; }
+    else if (tid == 6) { v = clipf((ag.a0t + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 4; }
     else if (tid == 7) {
       // acos(clip(cos_beta, 0, 1)) (state_obs.py:87-92) evaluated as atan2(|cross|, dot): identical for unit vectors,
       // but well-conditioned in fp32 near beta = 0 where 1 - cos(beta) underflows the mantissa
       float dot = hx * ag.lhx + hy * ag.lhy, cross = hx * ag.lhy - hy * ag.lhx;
       float beta = dot <= 0.0f ? 0.5f * PGD_PI : atan2f(fabsf(cross), dot);
       v = clipf(beta / 0.1f, 0.0f, 1.0f);
+      col = o_ego + 5;
     } else {  // lanes 8..12 -> checkpoint 1, 13..17 -> checkpoint 2
       int which = (tid - 8) / 5, comp = (tid - 8) - which * 5;
       float out[5];
       navi_info_for(mv, sp.ckpt_road[which == 0 ? ag.ck0 : ag.ck1], CR.n_lanes, px, py, hx, hy, out);
       v = out[comp];
+      col = o_navi + (tid - 8);
     }
-    row[tid] = v;
+    if (col >= 0) row[col] = v;
+  }
+  // SideDetector / LaneLineDetector fans (distance_detector.py:137-152): beam i at theta + i*2pi/n + 90 deg, cast through
+  // the map grid against the line boxes of the wanted kinds
+  for (int q = tid; q < KS + KM; q += nt) {
+    const bool side = q < KS;
+    const int i = side ? q : q - KS, n = side ? KS : KM;
+    const float dist = side ? d.cfg.side_dist : d.cfg.lane_line_dist;
+    const unsigned kinds = side ? ((1u << PGD_BOX_WHITE) | (1u << PGD_BOX_YELLOW))
+                                : ((1u << PGD_BOX_WHITE) | (1u << PGD_BOX_YELLOW) | (1u << PGD_BOX_BROKEN));
+    float sn, cs;
+    sincosf((float)i * (2.0f * PGD_PI / (float)n) + 0.5f * PGD_PI + ag.th, &sn, &cs);
+    row[side ? i : o_ego + 6 + i] = ray_grid(mv, px, py, dist * cs, dist * sn, kinds);
   }
   if (NL <= 0) return;
   // get_surrounding_vehicles_info (lidar.py:55-77): rank by centre distance (stable), 4 floats per neighbour; the last
@@ -731,7 +781,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
         float ms = sp.max_speed;
         float sp_me = speed_kmh(ag.v);
         projection(hx, hy, L.bx[k] - px, L.by[k] - py, ph, ps);
-        float* o = row + 18 + rank * 4;
+        float* o = row + o_oth + rank * 4;
         o[0] = clipf((ph / R + 1.0f) * 0.5f, 0.0f, 1.0f);
         o[1] = clipf((ps / R + 1.0f) * 0.5f, 0.0f, 1.0f);
         projection(hx, hy, L.bspd[k] * L.bux[k] - sp_me * hx, L.bspd[k] * L.buy[k] - sp_me * hy, ph, ps);
@@ -739,7 +789,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
         o[3] = clipf((ps / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
       }
     } else {  // k in [n, NO): absent neighbour -> zeros
-      float* o = row + 18 + k * 4;
+      float* o = row + o_oth + k * 4;
       o[0] = o[1] = o[2] = o[3] = 0.0f;
     }
   }
@@ -753,7 +803,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
     float best = 1.0f;
     for (int k = 0; k < n; ++k)
       best = fminf(best, ray_obb(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
-    row[18 + 4 * NO + i] = best;
+    row[o_oth + 4 * NO + i] = best;
   }
 }
 
@@ -1267,7 +1317,9 @@ extern "C" {
 
 const char* pgd_version(void) { return "pgdrive_hip 0.1 (gfx950)"; }
 
-int pgd_obs_dim(const pgd_config* c) { return PGD_STATE_DIM + PGD_NAVI_DIM + 4 * c->num_others + c->num_lasers; }
+int pgd_obs_dim(const pgd_config* c) {
+  return (c->side_lasers > 0 ? c->side_lasers : 2) + 6 + c->lane_line_lasers + PGD_NAVI_DIM + 4 * c->num_others + c->num_lasers;
+}
 
 int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* out) {
   if (!cfg || !out) return PGD_ERR_ARG;

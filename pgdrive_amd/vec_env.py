@@ -69,8 +69,9 @@ class PGDriveVecEnv:
         self.config = merge_config(DEFAULT_CONFIG, config)
         c = self.config
         vc = c["vehicle_config"]
-        if vc["side_detector"]["num_lasers"] or vc["lane_line_detector"]["num_lasers"]:
-            raise NotImplementedError("side / lane-line detectors are not built yet (0 lasers is the reference default)")
+        for det in ("lidar", "side_detector", "lane_line_detector"):
+            if vc[det]["gaussian_noise"] or vc[det]["dropout_prob"]:
+                raise NotImplementedError(det + " noise / dropout (0 in the reference defaults) is not built")
         if c["traffic_mode"] != "trigger":
             raise NotImplementedError("only TrafficMode.Trigger (the reference default) is built")
         mc = c["map_config"]
@@ -94,7 +95,7 @@ class PGDriveVecEnv:
             sel, seeds, num_agents=1, num_traffic=T, density=c["traffic_density"],
             spawn_longitude=vc["spawn_longitude"], spawn_lateral=vc["spawn_lateral"], vehicle_model=vc["vehicle_model"]
         )
-        lid = vc["lidar"]
+        lid, sd, ld = vc["lidar"], vc["side_detector"], vc["lane_line_detector"]
         nl = lid["num_lasers"] if lid["distance"] > 0 else 0
         self.cfg = _abi.make_config(
             self.num_envs, num_agents=1, num_traffic=T, num_lasers=nl, num_others=lid["num_others"],
@@ -103,7 +104,9 @@ class PGDriveVecEnv:
             seed=c["seed"], success_reward=c["success_reward"], out_of_road_penalty=c["out_of_road_penalty"],
             crash_vehicle_penalty=c["crash_vehicle_penalty"], crash_object_penalty=c["crash_object_penalty"],
             driving_reward=c["driving_reward"], speed_reward=c["speed_reward"], use_lateral=c["use_lateral"],
-            out_of_route_done=c["out_of_route_done"]
+            out_of_route_done=c["out_of_route_done"],
+            side_lasers=sd["num_lasers"] if sd["distance"] > 0 else 0, side_dist=sd["distance"],
+            lane_line_lasers=ld["num_lasers"] if ld["distance"] > 0 else 0, lane_line_dist=ld["distance"]
         )
         from .engine import Engine
         self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])

@@ -100,13 +100,13 @@ def test_ray_box_known_answers(L):
     assert L.orc_ray_box(20.0, 0.0, 0.0, 2.25, 0.9, 0.0, 0.0, 0.0, 50.0) == 1.0  # perpendicular beam misses
     assert L.orc_ray_box(20.0, 0.0, 0.0, 2.25, 0.9, 0.0, 0.0, -50.0, 0.0) == 1.0  # behind
     assert L.orc_ray_box(100.0, 0.0, 0.0, 2.25, 0.9, 0.0, 0.0, 50.0, 0.0) == 1.0  # out of range
-    assert L.orc_ray_box(1.0, 0.0, 0.3, 2.25, 0.9, 0.0, 0.0, 50.0, 0.0) == 0.0  # origin inside the box
+    assert L.orc_ray_box(1.0, 0.0, 0.3, 2.25, 0.9, 0.0, 0.0, 50.0, 0.0) == 1.0  # origin inside the box: no hit, as Bullet's convex ray cast
 
 
 # ----------------------------------------------------------------------------------------------------------------------
 # full scenes
 # ----------------------------------------------------------------------------------------------------------------------
-def _scene_engine(descs, sc):
+def _scene_engine(descs, sc, **cfg_kw):
     """Oracle holding exactly the scene's vehicles (slot 0 = ego) with their routes; state overwritten from the scene."""
     from oracle import orc
     d = [m for m in descs if m["seed"] == sc["seed"]][0]
@@ -132,7 +132,7 @@ def _scene_engine(descs, sc):
     scen = np.zeros(1, dtype=scenario.SCEN_DT)
     scen["trigger_road"][:] = -1
     sb.scenarios, sb.spawns, sb.V, sb.info = scen, spawns, V, []
-    cfg = _abi.make_config(1, num_agents=1, num_traffic=V - 1)
+    cfg = _abi.make_config(1, num_agents=1, num_traffic=V - 1, **cfg_kw)
     o = orc.Oracle(cfg, mb, sb)
     o.reset(np.zeros(1, dtype=np.int32))
     f, i, ei = o.get_state()
@@ -178,6 +178,30 @@ def test_scene_observation(L, descs, scenes):
     print(worst, "corner beams", flips)
     assert worst["lr"] < 1e-4 and worst["state"] < 2e-6 and worst["navi"] < 2e-6 and worst["others"] < 2e-6
     assert worst["lidar"] < 1e-6 and flips <= 3
+
+
+def test_side_and_lane_line_detectors(L, descs):
+    """SideDetector / LaneLineDetector fans spliced into vehicle_state by the reference's own StateObservation
+    (state_obs.py:64-71,96-105; distance_detector.py:137-152), cast against the reference-recorded line boxes."""
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "detectors_v0.json")))["cases"]
+    SF = _abi.SF
+    worst, flips, total = 0.0, 0, 0
+    for sc in cases:
+        (ks, ds), (km, dm) = sc["side"], sc["lane_line"]
+        o, f, i, ei, d = _scene_engine(descs, sc, side_lasers=ks, side_dist=ds, lane_line_lasers=km, lane_line_dist=dm)
+        f[SF["DIST_LEFT"], 0, 0], f[SF["DIST_RIGHT"], 0, 0] = sc["left"], sc["right"]
+        o.set_state(f, i, ei)
+        obs = o.observe()[0, 0]
+        n = (ks or 2) + 6 + km
+        assert obs.shape[0] == n + 10 + 16 + 240 and len(sc["state"]) == n
+        dl = np.abs(obs[:n] - np.array(sc["state"]))
+        bad = dl > 2e-6
+        flips += int(bad.sum())  # a beam through a box corner (the reference helper pads edges by 1e-5)
+        total += n
+        worst = max(worst, float(dl[~bad].max()))
+        o.close()
+    print("detector floats", total, "worst", worst, "corner beams", flips)
+    assert worst < 2e-6 and flips <= 3
 
 
 def test_scene_reward_done(L, descs, scenes):

@@ -22,7 +22,9 @@ def _engines(descs, n_envs, n_maps=8, **kw):
     from pgdrive_amd.engine import Engine
     mb, sb = util.make_banks(descs, n_maps=n_maps, **{k: v for k, v in kw.items() if k in ("num_agents", "num_traffic", "density")})
     cfg = _abi.make_config(n_envs, num_agents=kw.get("num_agents", 1), num_traffic=kw.get("num_traffic", 16),
-                           num_lasers=kw.get("num_lasers", 240), auto_reset=kw.get("auto_reset", 1))
+                           num_lasers=kw.get("num_lasers", 240), auto_reset=kw.get("auto_reset", 1),
+                           side_lasers=kw.get("side_lasers", 0), side_dist=kw.get("side_dist", 50.0),
+                           lane_line_lasers=kw.get("lane_line_lasers", 0), lane_line_dist=kw.get("lane_line_dist", 20.0))
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
     return torch, eng, ora, cfg
@@ -43,8 +45,20 @@ def _compare_step(torch, eng, ora, act, stats):
     if same.any():
         d = np.abs(g_obs - o_obs)[same]
         nl = eng.cfg.num_lasers
-        head = d[:, :d.shape[1] - nl]
-        stats["obs"] = max(stats["obs"], float(head.max()))
+        ks, km = eng.cfg.side_lasers, eng.cfg.lane_line_lasers
+        fan = np.zeros(d.shape[1], dtype=bool)  # ray-cast columns: side fan, lane-line fan, lidar
+        fan[:ks] = True
+        fan[(ks or 2) + 6:(ks or 2) + 6 + km] = True
+        if nl:
+            fan[-nl:] = True
+        stats["obs"] = max(stats["obs"], float(d[:, ~fan].max()))
+        if ks + km:  # same treatment as the lidar beams below, plus origin-on-a-line-edge flips
+            beams = d[:, fan][:, :ks + km]
+            graze = beams > OBS_TOL
+            stats["det_beams"] = stats.get("det_beams", 0) + beams.size
+            stats["det_grazing"] = stats.get("det_grazing", 0) + int(graze.sum())
+            if (~graze).any():
+                stats["obs"] = max(stats["obs"], float(beams[~graze].max()))
         if nl:
             # a beam grazing a box corner can flip hit <-> miss between fp32 and fp64 (the slab test compares two
             # nearly equal parameters); such flips are counted and bounded, every other beam must agree to OBS_TOL
@@ -86,6 +100,35 @@ def test_teacher_forced_parity(descs, num_traffic, num_lasers):
     print("teacher-forced parity:", stats, "pose", pose)
     assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and pose < 1e-3
     assert stats["flag_mismatch"] <= 1e-3 * stats["steps"]
+    assert stats.get("grazing", 0) <= 1e-5 * stats.get("beams", 1) + 2
+
+
+@pytest.mark.parametrize("side,lane_line,num_lasers", [((12, 50.0), (6, 20.0), 240), ((2, 50.0), (2, 50.0), 0),
+                                                       ((0, 50.0), (33, 20.0), 16), ((70, 30.0), (0, 20.0), 0)])
+def test_side_and_lane_line_detector_parity(descs, side, lane_line, num_lasers):
+    """SideDetector / LaneLineDetector fans (distance_detector.py:137-152) spliced into the state block
+    (state_obs.py:64-71,96-105): device grid walk vs the oracle's brute force over every line box."""
+    n_envs = 64
+    torch, eng, ora, cfg = _engines(descs, n_envs, num_lasers=num_lasers, side_lasers=side[0], side_dist=side[1],
+                                    lane_line_lasers=lane_line[0], lane_line_dist=lane_line[1])
+    assert eng.D == (side[0] or 2) + 6 + lane_line[0] + 10 + 4 * cfg.num_others + num_lasers
+    scen_ids = np.arange(n_envs) % 8
+    o0 = ora.reset(scen_ids)
+    g0 = eng.reset(scen_ids).cpu().numpy()
+    assert (np.abs(g0 - o0) > OBS_TOL).sum() <= 2
+    rng = np.random.default_rng(5)
+    stats = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
+    for t in range(150):
+        act = util.driving_actions(rng, n_envs)
+        _compare_step(torch, eng, ora, act, stats)
+        f, i, ei = ora.get_state()
+        f32 = util.round_state_f32(f)
+        ora.set_state(f32, i, ei)
+        eng.set_state(f32, i, ei)
+    print("detector parity:", stats)
+    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL
+    assert stats["flag_mismatch"] <= 1e-3 * stats["steps"]
+    assert stats["det_grazing"] <= 1e-4 * stats["det_beams"] + 2
     assert stats.get("grazing", 0) <= 1e-5 * stats.get("beams", 1) + 2
 
 
