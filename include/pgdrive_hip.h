@@ -129,6 +129,8 @@ typedef struct pgd_scenario {
   int32_t map;              /* index into the map table */
   int32_t n_groups;         /* number of traffic trigger groups */
   int16_t trigger_road[16]; /* BlockVehicles.trigger_road per group, in activation order (traffic_manager.py:283-288) */
+  int32_t max_steps;        /* auto_termination: 250 * map.num_blocks (base_env.py:318); 0 = off */
+  int32_t pad;
 } pgd_scenario;
 
 typedef struct pgd_config {
@@ -161,6 +163,11 @@ typedef struct pgd_config {
   float side_dist;          /* 50 m */
   int32_t lane_line_lasers; /* m: rays vs continuous + broken line boxes; inserted after the yaw-rate float when > 0 */
   float lane_line_dist;     /* 20 m */
+  /* action pre-processing of the controlled agents */
+  int32_t discrete_action;  /* 1: EnvInputPolicy.convert_to_continuous_action (env_input_policy.py:28-31), applied AFTER the
+                               clip to [-1,1] exactly as the reference does */
+  int32_t discrete_steering_dim, discrete_throttle_dim; /* 5, 5 (base_env.py:35-36) */
+  int32_t increment_steering; /* 1: steering += a0 * 0.05, clipped (base_vehicle.py:351-358) */
   int32_t pad;
 } pgd_config;
 

@@ -539,6 +539,51 @@ def gen_detectors(maps):
     print("wrote detector goldens:", len(cases))
 
 
+def gen_traffic(maps):
+    """TrafficManager._create_vehicles_once / _create_respawn_vehicles (traffic_manager.py:188-309) run on the reference's
+    own block objects with spawn_object / IDMPolicy replaced by recorders: the manager RNG stream (shuffle, vehicle type,
+    policy seed) is the reference's, vehicle by vehicle."""
+    from pgdrive.component.vehicle import vehicle_type as vt_mod
+    from pgdrive.manager.traffic_manager import TrafficManager
+    from pgdrive.policy import idm_policy as idm_mod
+    names = {cls: k for k, cls in vt_mod.vehicle_type.items()}
+    out = []
+    real_idm = idm_mod.IDMPolicy
+    try:
+        idm_mod.IDMPolicy = lambda v, seed: setattr(v, "policy_seed", int(seed))
+        for m in maps:
+            lanes = ref_lanes_in_order(m)
+            lane_ids = {id(l): k for k, l in enumerate(lanes)}
+            fmap = FakeMap(m)
+            row = dict(seed=m["seed"])
+            for density in (0.1, 0.3):
+                for mode in ("trigger", "respawn"):
+                    tm = TrafficManager.__new__(TrafficManager)
+                    tm.np_random = get_np_random(m["seed"])  # BaseManager -> Randomizable.seed(global seed)
+                    tm.engine = types.SimpleNamespace(add_policy=lambda *a: None)
+                    tm._traffic_vehicles, tm.block_triggered_vehicles = [], []
+                    tm.spawn_object = lambda cls, vehicle_config: types.SimpleNamespace(
+                        id=0, vtype=names[cls], long=float(vehicle_config["spawn_longitude"]),
+                        lane=[k for k, l in enumerate(lanes) if l.index == vehicle_config["spawn_lane_index"]][0])
+                    if mode == "trigger":
+                        tm._create_vehicles_once(fmap, density)
+                        groups = [dict(trigger=[m["nodes"].index(bv.trigger_road.start_node),
+                                                m["nodes"].index(bv.trigger_road.end_node)],
+                                       vehicles=[[v.lane, v.long, v.vtype, v.policy_seed] for v in bv.vehicles])
+                                  for bv in reversed(tm.block_triggered_vehicles)]  # block order
+                        row["trigger_%g" % density] = groups
+                    else:
+                        tm._create_respawn_vehicles(fmap, density)
+                        row["respawn_%g" % density] = [[v.lane, v.long, v.vtype, v.policy_seed] for v in tm._traffic_vehicles]
+            out.append(row)
+    finally:
+        idm_mod.IDMPolicy = real_idm
+    with open(os.path.join(ROOT, "tests", "golden", "traffic_v0.json"), "w") as f:
+        json.dump(dict(maps=out), f)
+    print("wrote traffic goldens:", [(r["seed"], len(r["respawn_0.1"]), sum(len(g["vehicles"]) for g in r["trigger_0.1"]))
+                                     for r in out])
+
+
 def gen_checkpoints(rng, maps, out_json):
     """Navigation._update_target_checkpoints (navigation.py:262-282) on real routes."""
     rows = []
@@ -623,7 +668,8 @@ def main():
     out_json = {}
     maps = [ref_export.generate(s, block_num=3) for s in (1000, 1003, 1017)]
     gen_detectors(maps)  # own rng and own file: does not disturb the vectors below
-    if "--detectors-only" in sys.argv:
+    gen_traffic(maps + [ref_export.generate(s, block_num=3) for s in (1042, 1077)])
+    if "--detectors-only" in sys.argv or "--side-files-only" in sys.argv:
         return
     gen_scalar(rng, out)
     for m in maps[:2]:

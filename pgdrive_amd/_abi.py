@@ -12,7 +12,9 @@ class PgdConfig(C.Structure):
         ("use_lateral", C.c_int32), ("out_of_route_done", C.c_int32), ("marl_flags", C.c_int32),
         ("delay_done", C.c_int32), ("agent_limit", C.c_int32), ("respawn_places", C.c_int32),
         ("respawn_dests", C.c_int32), ("side_lasers", C.c_int32), ("side_dist", C.c_float),
-        ("lane_line_lasers", C.c_int32), ("lane_line_dist", C.c_float), ("pad", C.c_int32),
+        ("lane_line_lasers", C.c_int32), ("lane_line_dist", C.c_float), ("discrete_action", C.c_int32),
+        ("discrete_steering_dim", C.c_int32), ("discrete_throttle_dim", C.c_int32), ("increment_steering", C.c_int32),
+        ("pad", C.c_int32),
     ]
 
 
@@ -21,7 +23,8 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
                 out_of_road_penalty=5.0, crash_vehicle_penalty=5.0, crash_object_penalty=5.0, driving_reward=1.0,
                 speed_reward=0.1, use_lateral=False, out_of_route_done=False, multi_agent=False, crash_done=True,
                 out_of_road_done=True, allow_respawn=True, delay_done=25, agent_limit=0, respawn_places=0,
-                respawn_dests=0, side_lasers=0, side_dist=50.0, lane_line_lasers=0, lane_line_dist=20.0):
+                respawn_dests=0, side_lasers=0, side_dist=50.0, lane_line_lasers=0, lane_line_dist=20.0,
+                discrete_action=False, discrete_steering_dim=5, discrete_throttle_dim=5, increment_steering=False):
     """Defaults mirror PGDriveEnv_DEFAULT_CONFIG / BASE_DEFAULT_CONFIG (pgdrive_env.py:22-109, base_env.py:19-90)."""
     c = PgdConfig()
     c.num_envs, c.num_agents, c.num_traffic = num_envs, num_agents, num_traffic
@@ -34,6 +37,8 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
     c.use_lateral, c.out_of_route_done = int(bool(use_lateral)), int(bool(out_of_route_done))
     c.side_lasers, c.side_dist = int(side_lasers), float(side_dist)
     c.lane_line_lasers, c.lane_line_dist = int(lane_line_lasers), float(lane_line_dist)
+    c.discrete_action, c.increment_steering = int(bool(discrete_action)), int(bool(increment_steering))
+    c.discrete_steering_dim, c.discrete_throttle_dim = int(discrete_steering_dim), int(discrete_throttle_dim)
     if multi_agent:
         c.marl_flags = MA_ENABLED | (MA_CRASH_DONE if crash_done else 0) | (MA_OUT_ROAD_DONE if out_of_road_done else 0) | \
             (MA_ALLOW_RESPAWN if allow_respawn else 0)

@@ -947,6 +947,10 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       if (a1 != a1) a1 = 0.0f;
       st = clipf(a0, -1.0f, 1.0f);
       tb = clipf(a1, -1.0f, 1.0f);
+      if (d.cfg.discrete_action) {  // convert_to_continuous_action on the CLIPPED action (env_input_policy.py:17-31)
+        st = st * (2.0f / (float)(d.cfg.discrete_steering_dim - 1)) - 1.0f;
+        tb = tb * (2.0f / (float)(d.cfg.discrete_throttle_dim - 1)) - 1.0f;
+      }
     } else {
       idm_act(d, mv, g, *sp, S, base, V, s, e, steps_total, r, st, tb);
     }
@@ -957,7 +961,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     r.lasthx = r.hx; r.lasthy = r.hy;
     r.a0s = r.a1s; r.a0t = r.a1t;
     r.a1s = st; r.a1t = tb;
-    r.steer = st; r.thr = tb;
+    // _set_action / _set_incremental_action (base_vehicle.py:343-358)
+    r.steer = (s < A && d.cfg.increment_steering) ? clipf(r.steer + st * 0.05f, -1.0f, 1.0f) : st;
+    r.thr = tb;
     // (4) physics
     dynamics(d, *sp, r);
     PHASE_MARK(3);  // dynamics
@@ -1002,6 +1008,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (valid && s < A && !marl) {
     if (r.status == ST_ACTIVE) my_rew = reward_done(d, mv, *sp, r, my_fl, my_dn);
     if (d.cfg.horizon > 0 && ep_steps >= d.cfg.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
+    if (sc->max_steps > 0 && ep_steps >= sc->max_steps) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }  // auto_termination
     r.eprew += my_rew;
     bool will_reset = my_dn && d.cfg.auto_reset && A == 1;
     if (will_reset) { my_fl |= PGD_F_RESET; s_flag[el] = 1; }

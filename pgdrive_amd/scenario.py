@@ -31,8 +31,9 @@ SPAWN_DT = np.dtype(
         ("ckpt_road", "<i2", (MAX_CKPT, ))
     ]
 )
-SCEN_DT = np.dtype([("map", "<i4"), ("n_groups", "<i4"), ("trigger_road", "<i2", (MAX_GROUPS, ))])
-assert SPAWN_DT.itemsize == 64 + 4 * MAX_CKPT and SCEN_DT.itemsize == 8 + 2 * MAX_GROUPS
+SCEN_DT = np.dtype([("map", "<i4"), ("n_groups", "<i4"), ("trigger_road", "<i2", (MAX_GROUPS, )), ("max_steps", "<i4"),
+                    ("pad", "<i4")])
+assert SPAWN_DT.itemsize == 64 + 4 * MAX_CKPT and SCEN_DT.itemsize == 16 + 2 * MAX_GROUPS
 
 # vehicle_type.py:7-74 (L, W, front+rear wheelbase, mass) and utils/space.py:219-255
 # parameter tuples are (first, second) positional args of the reference's BoxSpace namedtuple("max min").
@@ -147,6 +148,35 @@ def _fill_vehicle(rec, desc, lane_id, longitude, lateral, params):
     rec["lane"] = lane_id
 
 
+def propose_respawn_traffic(desc, seed, density):
+    """TrafficMode.Respawn: TrafficManager._create_respawn_vehicles / _create_vehicles_on_lane / _get_available_respawn_lanes
+    (traffic_manager.py:188-222,236-239,292-309): one vehicle every 10 m on every lane of the map's respawn roads (a road
+    listed by two blocks cancels out), driving from the first step on.  The density draw is commented out upstream, so
+    every candidate spawns; vehicles leave for good when they run off the lanes (re-spawning is commented out too)."""
+    rng = get_np_random(seed)
+    if abs(density) < 1e-2:
+        return []
+    rl = mapdata.road_lookup(desc)
+    roads = []
+    for block in desc["blocks"]:
+        for r in block["respawn_roads"]:
+            r = tuple(r)
+            if r in roads:
+                roads.remove(r)
+            else:
+                roads.append(r)
+    vehicles = []
+    for r in roads:
+        road = desc["roads"][rl[r]]
+        for lid in range(road["first_lane"], road["first_lane"] + road["n_lanes"]):
+            longs = [float(i * VEHICLE_GAP) for i in range(int(desc["lanes"][lid]["length"] / VEHICLE_GAP))]
+            rng.shuffle(longs)
+            for lg in longs:
+                vtype = TYPE_KEYS[int(rng.choice(len(TYPE_KEYS), p=TRAFFIC_TYPE_PROB))]
+                vehicles.append(dict(lane=lid, long=lg, vtype=vtype, policy_seed=int(rng.randint(0, MAX_RAND_INT))))
+    return [dict(trigger_road=-1, vehicles=vehicles)]
+
+
 def propose_traffic(desc, seed, density):
     """TrafficManager._create_vehicles_once (traffic_manager.py:239-290) -> list of groups
     [{trigger_road, vehicles:[{lane, long, vtype, policy_seed}]}] in *block* order, consuming the manager RNG exactly
@@ -181,7 +211,8 @@ def propose_traffic(desc, seed, density):
 
 
 def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=0.1, spawn_lane=None,
-                   spawn_longitude=5.0, spawn_lateral=0.0, vehicle_model="default", agent_spawns=None):
+                   spawn_longitude=5.0, spawn_lateral=0.0, vehicle_model="default", agent_spawns=None,
+                   traffic_mode="trigger", traffic_seed=None, auto_termination=False):
     """One scenario = V = num_agents + num_traffic spawn slots for map `desc` under global seed `seed`."""
     V = num_agents + num_traffic
     scen = np.zeros((), dtype=SCEN_DT)
@@ -190,6 +221,7 @@ def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=
     spawns["group"] = -1
     scen["map"] = map_index
     scen["trigger_road"][:] = -1
+    scen["max_steps"] = 250 * len(desc["blocks"]) if auto_termination else 0  # base_env.py:318, map.num_blocks
 
     engine_rng = get_np_random(seed)  # BaseEngine.seed -> Randomizable.seed (base_engine.py:300-304)
     rl = mapdata.road_lookup(desc)
@@ -214,14 +246,20 @@ def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=
         spawns[a]["timer0"] = 0
 
     # ---- traffic (traffic_manager.py:239-290) ----
-    groups = propose_traffic(desc, seed, density) if num_traffic > 0 else []
+    # the manager RNG is re-seeded with the episode seed unless random_traffic (traffic_manager.py:348-350)
+    tseed = seed if traffic_seed is None else traffic_seed
+    if traffic_mode not in ("trigger", "hybrid", "respawn"):
+        raise ValueError("No such mode named {}".format(traffic_mode))  # traffic_manager.py:68
+    respawn = traffic_mode == "respawn"
+    groups = (propose_respawn_traffic if respawn else propose_traffic)(desc, tseed, density) if num_traffic > 0 else []
     slot = num_agents
     n_groups = 0
     dropped = 0
     for g in groups:
         if n_groups >= MAX_GROUPS:
             break
-        scen["trigger_road"][n_groups] = g["trigger_road"]
+        if not respawn:
+            scen["trigger_road"][n_groups] = g["trigger_road"]
         for v in g["vehicles"]:
             obj_seed = int(engine_rng.randint(0, MAX_RAND_INT))  # consumed even if the slot cap drops the vehicle
             if slot >= V:
@@ -241,19 +279,20 @@ def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=
                 spawns[slot]["ckpt"][:2] = [road["frm"], road["to"]]
                 spawns[slot]["ckpt_road"][0] = desc["lanes"][v["lane"]]["road"]
                 spawns[slot]["dest_lane"] = road["first_lane"] + road["n_lanes"] - 1
-            spawns[slot]["group"] = n_groups
+            spawns[slot]["group"] = -1 if respawn else n_groups  # respawn-mode vehicles drive from the first step
             spawns[slot]["timer0"] = int(get_np_random(v["policy_seed"]).randint(0, 50))  # idm_policy.py:185
             slot += 1
-        n_groups += 1
+        n_groups += 0 if respawn else 1
     scen["n_groups"] = n_groups
     return scen, spawns, dict(dropped=dropped, n_traffic=slot - num_agents)
 
 
 class ScenarioBank:
-    def __init__(self, descs, seeds, num_agents=1, num_traffic=16, density=0.1, **kw):
+    def __init__(self, descs, seeds, num_agents=1, num_traffic=16, density=0.1, traffic_seeds=None, **kw):
         scens, spawns, self.info = [], [], []
         for m, (d, s) in enumerate(zip(descs, seeds)):
-            sc, sp, info = build_scenario(d, m, s, num_agents, num_traffic, density, **kw)
+            ts = None if traffic_seeds is None else int(traffic_seeds[m])
+            sc, sp, info = build_scenario(d, m, s, num_agents, num_traffic, density, traffic_seed=ts, **kw)
             scens.append(sc)
             spawns.append(sp)
             self.info.append(info)

@@ -10,7 +10,7 @@ import copy
 import numpy as np
 
 from . import _abi, bank, mapdata, scenario
-from .spaces import Box
+from .spaces import Box, MultiDiscrete
 
 # Reference defaults this build honours (pgdrive_env.py:22-109, base_env.py:19-90)
 DEFAULT_CONFIG = dict(
@@ -20,7 +20,12 @@ DEFAULT_CONFIG = dict(
     map=3,
     map_config=dict(lane_width=3.5, lane_num=3, exit_length=50),
     traffic_density=0.1,
-    traffic_mode="trigger",
+    traffic_mode="trigger",  # "trigger" | "hybrid" (same as trigger upstream) | "respawn" (traffic_manager.py:19-27)
+    random_traffic=False,  # True: traffic layout drawn from the env seed instead of the map seed (traffic_manager.py:348-350)
+    auto_termination=False,  # done after 250 * num_blocks steps (base_env.py:318)
+    discrete_action=False,
+    discrete_steering_dim=5,
+    discrete_throttle_dim=5,
     max_traffic_vehicles=16,  # slot cap per env (the reference has no cap)
     decision_repeat=5,
     physics_world_step_size=2e-2,
@@ -32,6 +37,7 @@ DEFAULT_CONFIG = dict(
         spawn_longitude=5.0,
         spawn_lateral=0.0,
         vehicle_model="default",
+        increment_steering=False,
     ),
     success_reward=10.0,
     out_of_road_penalty=5.0,
@@ -72,8 +78,6 @@ class PGDriveVecEnv:
         for det in ("lidar", "side_detector", "lane_line_detector"):
             if vc[det]["gaussian_noise"] or vc[det]["dropout_prob"]:
                 raise NotImplementedError(det + " noise / dropout (0 in the reference defaults) is not built")
-        if c["traffic_mode"] != "trigger":
-            raise NotImplementedError("only TrafficMode.Trigger (the reference default) is built")
         mc = c["map_config"]
         seeds = list(range(c["start_seed"], c["start_seed"] + c["environment_num"]))
         if c["map_bank"] is not None:  # pre-generated descriptions (load_map_from_json, pgdrive_env.py:38-39)
@@ -93,7 +97,10 @@ class PGDriveVecEnv:
         self.map_bank = mapdata.MapBank(sel)
         self.scen_bank = scenario.ScenarioBank(
             sel, seeds, num_agents=1, num_traffic=T, density=c["traffic_density"],
-            spawn_longitude=vc["spawn_longitude"], spawn_lateral=vc["spawn_lateral"], vehicle_model=vc["vehicle_model"]
+            spawn_longitude=vc["spawn_longitude"], spawn_lateral=vc["spawn_lateral"], vehicle_model=vc["vehicle_model"],
+            traffic_mode=c["traffic_mode"], auto_termination=c["auto_termination"],
+            traffic_seeds=np.random.RandomState(c["seed"]).randint(0, scenario.MAX_RAND_INT, len(seeds))
+            if c["random_traffic"] else None
         )
         lid, sd, ld = vc["lidar"], vc["side_detector"], vc["lane_line_detector"]
         nl = lid["num_lasers"] if lid["distance"] > 0 else 0
@@ -106,14 +113,17 @@ class PGDriveVecEnv:
             driving_reward=c["driving_reward"], speed_reward=c["speed_reward"], use_lateral=c["use_lateral"],
             out_of_route_done=c["out_of_route_done"],
             side_lasers=sd["num_lasers"] if sd["distance"] > 0 else 0, side_dist=sd["distance"],
-            lane_line_lasers=ld["num_lasers"] if ld["distance"] > 0 else 0, lane_line_dist=ld["distance"]
+            lane_line_lasers=ld["num_lasers"] if ld["distance"] > 0 else 0, lane_line_dist=ld["distance"],
+            discrete_action=c["discrete_action"], discrete_steering_dim=c["discrete_steering_dim"],
+            discrete_throttle_dim=c["discrete_throttle_dim"], increment_steering=vc["increment_steering"]
         )
         from .engine import Engine
         self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])
         self.obs_dim = self.engine.D
         # spaces (base_vehicle.py:720-727, state_obs.py:124-130)
         self.single_observation_space = Box(-0.0, 1.0, (self.obs_dim, ), np.float32)
-        self.single_action_space = Box(-1.0, 1.0, (2, ), np.float32)
+        self.single_action_space = MultiDiscrete([c["discrete_steering_dim"], c["discrete_throttle_dim"]]) \
+            if c["discrete_action"] else Box(-1.0, 1.0, (2, ), np.float32)
         self.observation_space = self.single_observation_space
         self.action_space = self.single_action_space
         self._rng = np.random.RandomState(c["seed"])

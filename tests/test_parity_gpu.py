@@ -20,11 +20,14 @@ def _engines(descs, n_envs, n_maps=8, **kw):
     import torch
     from oracle import orc
     from pgdrive_amd.engine import Engine
-    mb, sb = util.make_banks(descs, n_maps=n_maps, **{k: v for k, v in kw.items() if k in ("num_agents", "num_traffic", "density")})
+    mb, sb = util.make_banks(descs, n_maps=n_maps, **{k: v for k, v in kw.items() if k in (
+        "num_agents", "num_traffic", "density", "traffic_mode", "auto_termination")})
     cfg = _abi.make_config(n_envs, num_agents=kw.get("num_agents", 1), num_traffic=kw.get("num_traffic", 16),
                            num_lasers=kw.get("num_lasers", 240), auto_reset=kw.get("auto_reset", 1),
                            side_lasers=kw.get("side_lasers", 0), side_dist=kw.get("side_dist", 50.0),
-                           lane_line_lasers=kw.get("lane_line_lasers", 0), lane_line_dist=kw.get("lane_line_dist", 20.0))
+                           lane_line_lasers=kw.get("lane_line_lasers", 0), lane_line_dist=kw.get("lane_line_dist", 20.0),
+                           discrete_action=kw.get("discrete_action", False),
+                           increment_steering=kw.get("increment_steering", False), horizon=kw.get("horizon", 0))
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
     return torch, eng, ora, cfg
@@ -130,6 +133,53 @@ def test_side_and_lane_line_detector_parity(descs, side, lane_line, num_lasers):
     assert stats["flag_mismatch"] <= 1e-3 * stats["steps"]
     assert stats["det_grazing"] <= 1e-4 * stats["det_beams"] + 2
     assert stats.get("grazing", 0) <= 1e-5 * stats.get("beams", 1) + 2
+
+
+@pytest.mark.parametrize("discrete", [True, False])
+def test_action_modes_respawn_traffic_auto_termination(descs, discrete):
+    """discrete_action (env_input_policy.py:17-31, converted after the clip as upstream), increment_steering
+    (base_vehicle.py:351-358), TrafficMode.Respawn (traffic_manager.py:236-239) and auto_termination (base_env.py:318)."""
+    n_envs = 64
+    torch, eng, ora, cfg = _engines(descs, n_envs, discrete_action=discrete, increment_steering=True,
+                                    traffic_mode="respawn", auto_termination=True, num_lasers=60)
+    scen_ids = np.arange(n_envs) % 8
+    o0 = ora.reset(scen_ids)
+    g0 = eng.reset(scen_ids).cpu().numpy()
+    assert np.abs(g0 - o0).max() < OBS_TOL
+    f, i, ei = ora.get_state()
+    assert (i[_abi.SI["STATUS"]][:, 1:] == _abi.ST_ACTIVE).sum() > 8 * n_envs  # respawn-mode traffic drives from step 0
+    # jump half of the envs close to their auto-termination step (250 * num_blocks = 1000 for 3-block maps)
+    ei[_abi.EI["EP_STEPS"], ::2] = 995
+    ora.set_state(f, i, ei)
+    eng.set_state(util.round_state_f32(f), i, ei)
+    rng = np.random.default_rng(11)
+    stats = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
+    n_max_step = 0
+    for t in range(120):
+        if discrete:  # MultiDiscrete([5, 5]) samples; upstream clips them to [-1, 1] BEFORE the conversion, so the
+            # car only ever brakes (steering / throttle in {-1, -0.5}) -- reproduced as is
+            act = rng.integers(0, 5, size=(n_envs, 1, 2)).astype(np.float32)
+            act[::7] = rng.uniform(-2, 2, size=act[::7].shape).astype(np.float32)  # and a few stray floats
+        else:
+            act = util.driving_actions(rng, n_envs)
+            act[..., 0] *= 4.0  # incremental steering: 0.05 per unit action
+        o_obs, o_rew, o_done, o_flags = ora.step(act)
+        n_max_step += int(((o_flags & _abi.F_MAX_STEP) != 0).sum())
+        g_obs, g_rew, g_done, g_flags = eng.step(torch.from_numpy(act).to(eng.device))
+        eng.sync()
+        same = (g_flags.cpu().numpy().astype(np.uint32) == o_flags) & (g_done.cpu().numpy() == o_done)
+        stats["steps"] += same.size
+        stats["flag_mismatch"] += int((~same).sum())
+        d = np.abs(g_obs.cpu().numpy().astype(np.float64) - o_obs)[same]
+        stats["obs"] = max(stats["obs"], float(d[:, :-60].max()))
+        stats["rew"] = max(stats["rew"], float(np.abs(g_rew.cpu().numpy() - o_rew)[same].max()))
+        f, i, ei = ora.get_state()
+        f32 = util.round_state_f32(f)
+        ora.set_state(f32, i, ei)
+        eng.set_state(f32, i, ei)
+    print("action modes parity:", stats, "max_step flags", n_max_step)
+    assert n_max_step >= n_envs // 4  # the jumped envs hit 250 * num_blocks unless they crashed before
+    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] <= 1e-3 * stats["steps"]
 
 
 def test_free_running_rollout(descs):

@@ -80,3 +80,45 @@ def test_empty_and_capped_slots(descs):
     sc3, sp3, info3 = scenario.build_scenario(descs[2], 0, descs[2]["seed"], num_traffic=40, density=0.3)
     assert info2["dropped"] > 0 and info3["dropped"] == 0
     assert (sp2[1:3]["lane"] == sp3[1:3]["lane"]).all() and (sp2[1:3]["max_engine_force"] == sp3[1:3]["max_engine_force"]).all()
+
+
+def test_traffic_proposals_match_reference_manager():
+    """The reference's own TrafficManager._create_vehicles_once / _create_respawn_vehicles (traffic_manager.py:188-309), run
+    on its block objects with recorders in place of spawn_object / IDMPolicy (oracle/gen_golden.py:gen_traffic): same
+    lanes, longitudes, vehicle types and policy seeds, vehicle by vehicle, for trigger and respawn modes."""
+    from pgdrive_amd import bank
+    with open(os.path.join(GOLD, "traffic_v0.json")) as f:
+        gold = json.load(f)["maps"]
+    descs = {d["seed"]: d for d in bank.get_descriptions([g["seed"] for g in gold])}
+    n = 0
+    for g in gold:
+        d = descs[g["seed"]]
+        rl = mapdata.road_lookup(d)
+        for density in (0.1, 0.3):
+            mine = scenario.propose_traffic(d, d["seed"], density)
+            ref = g["trigger_%g" % density]
+            assert len(mine) == len(ref)
+            for a, b in zip(mine, ref):
+                assert a["trigger_road"] == rl[tuple(b["trigger"])]
+                assert [[v["lane"], v["long"], v["vtype"], v["policy_seed"]] for v in a["vehicles"]] == b["vehicles"]
+                n += len(b["vehicles"])
+            mine = scenario.propose_respawn_traffic(d, d["seed"], density)
+            ref = g["respawn_%g" % density]
+            assert [[v["lane"], v["long"], v["vtype"], v["policy_seed"]] for v in mine[0]["vehicles"]] == ref
+            n += len(ref)
+    assert n > 300
+
+
+def test_respawn_mode_and_auto_termination_scenarios(descs):
+    d = descs[0]
+    sc, sp, info = scenario.build_scenario(d, 0, d["seed"], 1, 16, 0.1, traffic_mode="respawn", auto_termination=True)
+    assert sc["n_groups"] == 0 and sc["max_steps"] == 250 * len(d["blocks"])
+    assert (sp["group"][1:][sp["lane"][1:] >= 0] == -1).all() and info["n_traffic"] == 16
+    sc, sp, info = scenario.build_scenario(d, 0, d["seed"], 1, 16, 0.1, traffic_mode="hybrid")
+    sc2, sp2, _ = scenario.build_scenario(d, 0, d["seed"], 1, 16, 0.1)
+    assert sc.tobytes() == sc2.tobytes() and sp.tobytes() == sp2.tobytes() and sc["max_steps"] == 0
+    sc3, sp3, _ = scenario.build_scenario(d, 0, d["seed"], 1, 16, 0.1, traffic_seed=7)
+    assert sp3.tobytes() != sp2.tobytes() and sp3[0].tobytes() == sp2[0].tobytes()  # only the traffic moves
+    import pytest
+    with pytest.raises(ValueError):
+        scenario.build_scenario(d, 0, d["seed"], 1, 16, 0.1, traffic_mode="nope")

@@ -4,11 +4,11 @@ import numpy as np
 from pgdrive_amd import _abi, mapdata, scenario
 
 
-def make_banks(descs, n_maps=8, num_agents=1, num_traffic=16, density=0.1, first=0):
+def make_banks(descs, n_maps=8, num_agents=1, num_traffic=16, density=0.1, first=0, **kw):
     sel = descs[first:first + n_maps]
     mb = mapdata.MapBank(sel)
     sb = scenario.ScenarioBank(sel, [d["seed"] for d in sel], num_agents=num_agents, num_traffic=num_traffic,
-                               density=density)
+                               density=density, **kw)
     return mb, sb
 
 
