@@ -46,8 +46,9 @@ def load_traffic(N, args):
     return t.get("bytes_per_launch")
 
 
-def cpu_baseline(descs, args, seconds=12.0):
-    """Oracle (scalar C restatement, 1 thread) on a bounded sample of the same workload."""
+def cpu_baseline(descs, args, seconds=10.0):
+    """Oracle (scalar C restatement) on a bounded sample of the same workload: 1 thread (the reported baseline) and, in
+    `all_cores`, OpenMP over envs on every host core."""
     from oracle import orc
     from pgdrive_amd import _abi, mapdata, scenario
     n = 256
@@ -66,8 +67,30 @@ def cpu_baseline(descs, args, seconds=12.0):
         o.step(acts[k % 32])
         k += 1
     dt = time.perf_counter() - t0
+    o.close()
+    # all host cores: the full 4096-env workload, OpenMP over envs inside one parallel region
+    cores = min(len(os.sched_getaffinity(0)), 128)
+    allc = None
+    if cores > 1:
+        n2 = args.envs
+        cfg2 = _abi.make_config(n2, num_agents=1, num_traffic=args.traffic, num_lasers=args.lasers)
+        o2 = orc.Oracle(cfg2, mb, sb)
+        o2.reset(np.arange(n2) % len(sel))
+        ring = rng.uniform(-1, 1, size=(8, n2, 1, 2)).astype(np.float32)
+        o2.run(ring, 2, cores)
+        t1 = time.perf_counter()
+        k2 = 0
+        while time.perf_counter() - t1 < seconds / 2:
+            o2.run(ring, 8, cores)
+            k2 += 8
+        dt2 = time.perf_counter() - t1
+        o2.close()
+        allc = dict(value=n2 * k2 / dt2, unit="env-steps/s", cores=cores,
+                    sample="%d envs x %d steps, OpenMP static over envs" % (n2, k2))
     return dict(value=n * k / dt, unit="env-steps/s", cores=1, kind="port",
-                sample="%d envs x %d steps of the C3 workload (16 maps), oracle/pgd_oracle.c fp64, 1 thread" % (n, k))
+                sample="%d envs x %d steps of the C3 workload (16 maps), oracle/pgd_oracle.c fp64 (bicycle restatement, "
+                       "not Bullet), 1 thread" % (n, k),
+                all_cores=allc)
 
 
 def main():

@@ -56,6 +56,8 @@ def lib():
         L.orc_reward_done.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_update_checkpoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
         L.orc_step_range.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.orc_step_mt.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.orc_run_mt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 4
         L.orc_rng.restype = C.c_uint32
         L.orc_rng.argtypes = [C.c_uint32] * 4
         for name in ("orc_upload_maps", "orc_upload_scenarios", "orc_destroy", "orc_get_state", "orc_set_state",
@@ -101,16 +103,28 @@ class Oracle:
     def refresh(self):
         self.L.orc_refresh(self.h)
 
-    def step(self, actions, env_range=None):
+    def step(self, actions, env_range=None, threads=1):
         actions = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.N, self.A, 2)
         obs = np.zeros((self.N, self.A, self.D), dtype=np.float64)
         rew = np.zeros((self.N, self.A), dtype=np.float64)
         done = np.zeros((self.N, self.A), dtype=np.uint8)
         flags = np.zeros((self.N, self.A), dtype=np.uint32)
-        if env_range is None:
+        if threads > 1:
+            self.L.orc_step_mt(self.h, int(threads), _p(actions), _p(obs), _p(rew), _p(done), _p(flags))
+        elif env_range is None:
             self.L.orc_step(self.h, _p(actions), _p(obs), _p(rew), _p(done), _p(flags))
         else:
             self.L.orc_step_range(self.h, env_range[0], env_range[1], _p(actions), _p(obs), _p(rew), _p(done), _p(flags))
+        return obs, rew, done, flags
+
+    def run(self, action_ring, steps, threads):
+        """`steps` steps inside one OpenMP region (bench.py all-cores baseline); returns the last step's outputs."""
+        ring = np.ascontiguousarray(action_ring, dtype=np.float32).reshape(-1, self.N, self.A, 2)
+        obs = np.zeros((self.N, self.A, self.D), dtype=np.float64)
+        rew = np.zeros((self.N, self.A), dtype=np.float64)
+        done = np.zeros((self.N, self.A), dtype=np.uint8)
+        flags = np.zeros((self.N, self.A), dtype=np.uint32)
+        self.L.orc_run_mt(self.h, int(threads), int(steps), _p(ring), ring.shape[0], _p(obs), _p(rew), _p(done), _p(flags))
         return obs, rew, done, flags
 
     def get_state(self):

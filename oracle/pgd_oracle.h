@@ -26,6 +26,9 @@ int orc_reset(orc_handle h, const int32_t* env_ids, const int32_t* scen_ids, int
 int orc_observe(orc_handle h, double* obs);
 int orc_refresh(orc_handle h);
 int orc_step(orc_handle h, const float* actions, double* obs, double* reward, uint8_t* done, uint32_t* flags);
+int orc_step_mt(orc_handle h, int threads, const float* actions, double* obs, double* reward, uint8_t* done, uint32_t* flags);
+int orc_run_mt(orc_handle h, int threads, int steps, const float* actions, int n_ring, double* obs, double* reward,
+               uint8_t* done, uint32_t* flags);
 int orc_step_range(orc_handle h, int e0, int e1, const float* actions, double* obs, double* reward, uint8_t* done,
                    uint32_t* flags);
 uint32_t orc_rng(uint32_t seed, uint32_t a, uint32_t b, uint32_t c);

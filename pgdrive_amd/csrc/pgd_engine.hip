@@ -457,12 +457,15 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
         else { avail_lo = diff; avail_hi = n_cur - 1; }
         if (idx < avail_lo || idx > avail_hi) {
           int side = idx > avail_hi ? 0 : 2;  // 0: change to left, 2: change to right
-          if (fb.bd[side] < SAFE || fb.fd[side] < 5.0f) {
+          // static indices only: a runtime index would push the whole Fbo into scratch memory
+          const float side_bd = side == 0 ? fb.bd[0] : fb.bd[2], side_fd = side == 0 ? fb.fd[0] : fb.fd[2];
+          const int side_front = side == 0 ? fb.front[0] : fb.front[2];
+          if (side_bd < SAFE || side_fd < 5.0f) {
             r.target = CREEP;
             front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
           } else {
             r.target = NORMAL;
-            front_obj = fb.front[side]; front_dist = fb.fd[side];
+            front_obj = side_front; front_dist = side_fd;
             steer_lane = CR.first_lane + idx + (side == 0 ? -1 : 1);
           }
           decided = true;
@@ -749,7 +752,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
       int which = (tid - 8) / 5, comp = (tid - 8) - which * 5;
       float out[5];
       navi_info_for(mv, sp.ckpt_road[which == 0 ? ag.ck0 : ag.ck1], CR.n_lanes, px, py, hx, hy, out);
-      v = out[comp];
+      v = comp == 0 ? out[0] : comp == 1 ? out[1] : comp == 2 ? out[2] : comp == 3 ? out[3] : out[4];
       col = o_navi + (tid - 8);
     }
     if (col >= 0) row[col] = v;
@@ -836,6 +839,10 @@ extern __shared__ __align__(16) unsigned char s_dyn[];  // [lanes | roads] of th
 #ifndef PGD_WAVES_PER_SIMD
 #define PGD_WAVES_PER_SIMD 3  // <=168 VGPRs: measured 71.4 (3) vs 66.6 (4, 113 spilled VGPRs) M env-steps/s at 4096 envs
 #endif
+// ONE_ENV (epw == 1: every lane of the wave works on env blockIdx.x) is a compile-time switch: the env index, its
+// scenario, the map view (7 table pointers) and the env counters are then wave-uniform and live in SGPRs instead of
+// occupying ~20 VGPRs per lane for the whole kernel.
+template <bool ONE_ENV>
 __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
                                                 float* __restrict__ obs) {
@@ -847,7 +854,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   const int V = d.V, A = d.A, N = d.N;
   const int lane = threadIdx.x;
   const LaneMap lm = lane_map(d, blockIdx.x, N);
-  const int el = lm.el, s = lm.s, e = lm.e, base = lm.base;
+  const int el = ONE_ENV ? 0 : lm.el, s = lm.s, e = ONE_ENV ? (int)blockIdx.x : lm.e, base = ONE_ENV ? 0 : lm.base;
   const bool valid = lm.valid, leader = lm.sub == 0;
   const Grp g{lm.sub, d.sub, lm.lead};
   const int slot = base + s;  // my entry of the LDS snapshot
@@ -862,13 +869,16 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   S.present[lane] = 0;
   s_flag[lane] = 0;
   s_hit[lane] = 0;
-  const bool one_env = d.epw == 1;  // every lane of the wave works on env blockIdx.x
+  constexpr bool one_env = ONE_ENV;
   const bool marl = (d.cfg.marl_flags & PGD_MA_ENABLED) != 0;
   int scen = 0;
   if (one_env || valid) {
-    scen = d.ei[(size_t)((one_env ? (int)blockIdx.x : e)) * PGD_NEI + EI_SCEN];
+    scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
     sc = d.scen + scen;
     mv = map_view_of(d, d.scen_map + scen);
+    ng = d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP];
+    ep_steps = d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS];
+    steps_total = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
   }
   if (one_env && d.lds_bytes > 0) {
     // stage the env's lane + road tables in LDS (coalesced 16 B loads by all 64 lanes)
@@ -902,9 +912,6 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     sp = d.spawns + (size_t)scen * d.sstride + r.spawn;
     // (0) AgentManager.before_step (agent_manager.py:191-199): finished agents count down, then leave the world
     if (marl && r.status == ST_DYING && --r.timer == 0) r.status = ST_EMPTY;
-    ng = d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP];
-    ep_steps = d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS];
-    steps_total = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
   }
   __syncthreads();
   if (valid) {
@@ -913,8 +920,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   __syncthreads();
   PHASE_MARK(0);  // load
-  const bool trig = valid && s_flag[el] != 0;
-  if (trig && r.status == ST_PENDING && sp->group == ng) r.status = ST_ACTIVE;
+  const bool trig = ONE_ENV ? (__ballot(s_flag[0] != 0) != 0ull) : (valid && s_flag[el] != 0);
+  if (valid && trig && r.status == ST_PENDING && sp->group == ng) r.status = ST_ACTIVE;
   if (trig) ng += 1;  // every lane of the env keeps the same copy
   // snapshot of the world before physics
   if (valid) {
@@ -1089,13 +1096,19 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_MARK(6);  // reward/done
   // (8) auto reset (base_env.py:269-301): the whole env restarts from its (possibly re-drawn) scenario
   int episodes = 0;
-  if (valid && s_flag[el]) {
+  // ONE_ENV: s_flag[0] is the env's reset flag, the same for every lane: a scalar branch keeps scen / mv in SGPRs
+  const bool resetting = ONE_ENV ? (__ballot(s_flag[0] != 0) != 0ull) : (valid && s_flag[el]);
+  if (resetting) {
     episodes = d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] + 1;
     if (d.cfg.resample_scenario)
       scen = (int)(pgd_rng(d.cfg.seed, (uint32_t)e, 0x5ce9a210u, (uint32_t)episodes) % (uint32_t)d.n_scen);
     sc = d.scen + scen;
-    sp = d.spawns + (size_t)scen * d.sstride + s;
     mv = map_view(d, sc->map);  // global tables: the staged map may not be the new one
+    ng = 0;
+    ep_steps = 0;
+  }
+  if (valid && resetting) {
+    sp = d.spawns + (size_t)scen * d.sstride + s;
     reset_vehicle(*sp, r, s, s < A);
     if (r.status != ST_EMPTY) after_step_vehicle(mv, g, *sp, r, s < A, true);
     // agent ids restart at 0: id = number of spawned agent slots below this one (agent_manager.py:91-132)
@@ -1104,8 +1117,6 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       r.agent_id = A == 1 ? 0.0f : (float)__popcll(am & ((1ull << lm.lead) - 1ull));  // A > 1 implies one env per wave
       if (marl) my_fl |= PGD_F_NEW;
     }
-    ng = 0;
-    ep_steps = 0;
     if (s == 0 && leader) {
       d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
       d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] = episodes;
@@ -1453,7 +1464,7 @@ int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward
   const bool marl = (h->d.cfg.marl_flags & PGD_MA_ENABLED) != 0;
   if (marl && h->d.epw != 1) return PGD_ERR_STATE;  // the multi-agent tail needs the env in one wave (V >= 33 or SUB split)
   const bool fuse = d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !getenv("PGD_NO_FUSE");
-  hipLaunchKernelGGL(k_step, dim3(blocks), dim3(WAVE), (size_t)h->d.lds_bytes, h->stream, h->d, d_actions, d_reward, d_done,
+  hipLaunchKernelGGL(h->d.epw == 1 ? k_step<true> : k_step<false>, dim3(blocks), dim3(WAVE), (size_t)h->d.lds_bytes, h->stream, h->d, d_actions, d_reward, d_done,
                      d_flags, fuse ? d_obs : (float*)nullptr);
   HIPCHK(hipGetLastError());
   if (prof) HIPCHK(hipEventRecord(pe[1], h->stream));

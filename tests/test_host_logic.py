@@ -4,7 +4,7 @@ import pytest
 
 from pgdrive_amd import dist as pdist
 from pgdrive_amd import env as penv
-from pgdrive_amd import spaces, vec_env
+from pgdrive_amd import _abi, spaces, vec_env
 
 
 def test_unknown_config_key_raises_like_reference():
@@ -52,3 +52,23 @@ def test_shard_ranges_partition_envs():
         assert got == list(range(n))
     ids = np.concatenate([pdist.scenario_ids_for(*pdist.shard_range(1000, r, 4), 100) for r in range(4)])
     assert (ids == np.arange(1000) % 100).all()  # env -> scenario mapping does not depend on the world size
+
+
+def test_oracle_multithreaded_step_is_identical(descs):
+    """orc_step_mt (OpenMP over envs; the all-cores CPU baseline of bench.py) returns exactly what orc_step returns."""
+    from oracle import orc
+    from tests import util
+    mb, sb = util.make_banks(descs, n_maps=4)
+    cfg = _abi.make_config(32, num_agents=1, num_traffic=16, num_lasers=30)
+    a, b = orc.Oracle(cfg, mb, sb), orc.Oracle(cfg, mb, sb)
+    ids = np.arange(32) % 4
+    a.reset(ids)
+    b.reset(ids)
+    rng = np.random.default_rng(3)
+    for t in range(40):
+        act = util.driving_actions(rng, 32)
+        ra, rb = a.step(act), b.step(act, threads=4)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y)
+    a.close()
+    b.close()
