@@ -263,21 +263,37 @@ DEV unsigned state_check(const MapView& mv, const Grp& g, const Obb& car) {
   return group_or(fl, g);
 }
 
+// What the later phases need from the agent's route position (Navigation.current_ref_lanes / next_ref_lanes,
+// navigation.py:155-183): looked up once per step after the checkpoint update, then reused by the side distances, the
+// reward and the observation instead of re-walking spawn record -> road table each time.
+struct RouteCtx {
+  int road_cur;    // road id of checkpoints[ck0] -> checkpoints[ck0 + 1]
+  int cur_first;   // its first lane (current_ref_lanes[0]) ...
+  int cur_n;       // ... and lane count
+  int next_first;  // first lane of the next checkpoint road (== cur_first on the last road)
+};
+DEV RouteCtx route_ctx(const MapView& mv, const pgd_spawn& sp, int ck0, int ck1) {
+  const int rc = sp.ckpt_road[ck0], rn = sp.ckpt_road[ck1];
+  const pgd_road& CR = mv.roads[rc];
+  const pgd_road& NR = mv.roads[rn];
+  return RouteCtx{rc, CR.first_lane, CR.n_lanes, NR.first_lane};
+}
+
 // BaseVehicle.after_step (base_vehicle.py:255-290).  `with_state_check` = false lets the caller run the line / sidewalk
 // test wave-cooperatively afterwards (k_step with one env per wave) and OR the result into vflags.
 DEV void after_step_vehicle(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, bool is_agent,
-                            bool with_state_check) {
+                            bool with_state_check, RouteCtx& ctx) {
   update_localization(mv, g, sp, r);
   if (is_agent) {
+    ctx = route_ctx(mv, sp, r.ck0, r.ck1);
     unsigned fl = (unsigned)r.vflags;
     fl &= ~(PGD_F_ON_WHITE | PGD_F_ON_YELLOW | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OUT_OF_ROUTE);
     if (with_state_check) fl |= state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sp.length, 0.5f * sp.width});
-    const pgd_road& cr = mv.roads[sp.ckpt_road[r.ck0]];
     float lon, lat;
-    lane_local(mv.lanes[cr.first_lane], r.x, r.y, lon, lat);
+    lane_local(mv.lanes[ctx.cur_first], r.x, r.y, lon, lat);
     float w = mv.m->lane_width;
     r.dl = lat + w * 0.5f;
-    r.dr = w * cr.n_lanes - r.dl;
+    r.dr = w * ctx.cur_n - r.dl;
     if (r.dr < 0.0f || r.dl < 0.0f) fl |= PGD_F_OUT_OF_ROUTE;
     r.vflags = (int)fl;
     float dist = norm2(r.lastx - r.x, r.lasty - r.y) / 1000.0f;
@@ -601,15 +617,13 @@ DEV void reset_vehicle(const pgd_spawn& p, Veh& r, int spawn_index, bool is_agen
 }
 
 // reward / done: envs/pgdrive_env.py:162-258, base_vehicle.py:738-745
-DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const Veh& r, unsigned& flags_out,
-                      bool& done_out) {
+DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const Veh& r, const RouteCtx& ctx,
+                      unsigned& flags_out, bool& done_out) {
   const pgd_config& g = d.cfg;
   unsigned vf = (unsigned)r.vflags;
-  int cur_road = sp.ckpt_road[r.ck0];
-  const pgd_road& CR = mv.roads[cur_road];
   const pgd_lane& VL = mv.lanes[r.lane];
-  bool in_ref = VL.road == cur_road;
-  const pgd_lane& cl = in_ref ? VL : mv.lanes[CR.first_lane];
+  bool in_ref = VL.road == ctx.road_cur;
+  const pgd_lane& cl = in_ref ? VL : mv.lanes[ctx.cur_first];
   float positive = in_ref ? 1.0f : (mv.roads[VL.road].negative ? -1.0f : 1.0f);
   float l0, t0, l1, t1;
   lane_local(cl, r.lastx, r.lasty, l0, t0);
@@ -623,7 +637,7 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
   const pgd_lane& fl = mv.lanes[sp.dest_lane];
   float lon, lat;
   lane_local(fl, r.x, r.y, lon, lat);
-  bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - CR.n_lanes) * w);
+  bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - ctx.cur_n) * w);
   bool oor = (vf & (PGD_F_ON_YELLOW | PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK)) != 0;
   if (g.out_of_route_done) oor = oor || (vf & PGD_F_OUT_OF_ROUTE);
   bool crash = (vf & PGD_F_CRASH_VEHICLE) != 0;
@@ -640,9 +654,9 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
 // ---------------------------------------------------------------------------------------------------------------------
 // observation: LidarStateObservation.observe (obs/state_obs.py:132-170) for one (env, agent)
 // ---------------------------------------------------------------------------------------------------------------------
-DEV void navi_info_for(const MapView& mv, int road, int n_cur, float px, float py, float hx, float hy, float* out) {
-  // Navigation._get_info_for_checkpoint (navigation.py:213-260)
-  const pgd_lane& ref = mv.lanes[mv.roads[road].first_lane];
+DEV void navi_info_for(const MapView& mv, int first_lane, int n_cur, float px, float py, float hx, float hy, float* out) {
+  // Navigation._get_info_for_checkpoint (navigation.py:213-260); first_lane = ref_lanes[0] of the checkpoint's road
+  const pgd_lane& ref = mv.lanes[first_lane];
   float w = mv.m->lane_width;
   float later_middle = ((float)n_cur * 0.5f - 0.5f) * w;
   float cx, cy;
@@ -713,7 +727,7 @@ struct ObsLds {  // vehicles inside the lidar broad phase of the observing agent
 };
 struct AgentView {  // what the observation needs from the observing vehicle
   float x, y, th, hx, hy, dl, dr, v, steer, a0s, a0t, lhx, lhy;
-  int ck0, ck1;
+  int cur_first, cur_n, next_first;  // RouteCtx of the vehicle
 };
 
 // one wave compacts the candidates: lane `o` brings vehicle o of the env (present = in the physics world)
@@ -740,12 +754,11 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   const int KS = d.cfg.side_lasers, KM = d.cfg.lane_line_lasers;
   const int o_ego = KS > 0 ? KS : 2, o_navi = o_ego + 6 + KM, o_oth = o_navi + 10;
   if (tid < 18) {
-    const pgd_road& CR = mv.roads[sp.ckpt_road[ag.ck0]];
     float v = 0.0f;
     int col = -1;
     if (tid == 0) { v = clipf(ag.dl / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 0; }  // (MAX_LANE_NUM+1)*MAX_LANE_WIDTH
     else if (tid == 1) { v = clipf(ag.dr / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 1; }
-    else if (tid == 2) { v = heading_diff(mv.lanes[CR.first_lane + CR.n_lanes - 1], px, py, hx, hy); col = o_ego; }
+    else if (tid == 2) { v = heading_diff(mv.lanes[ag.cur_first + ag.cur_n - 1], px, py, hx, hy); col = o_ego; }
     else if (tid == 3) { v = clipf((speed_kmh(ag.v) + 1.0f) / (sp.max_speed + 1.0f), 0.0f, 1.0f); col = o_ego + 1; }
     else if (tid == 4) { v = clipf((ag.steer / 60.0f + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 2; }
     else if (tid == 5) { v = clipf((ag.a0s + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 3; }
@@ -760,7 +773,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
     } else {  // lanes 8..12 -> checkpoint 1, 13..17 -> checkpoint 2
       int which = (tid - 8) / 5, comp = (tid - 8) - which * 5;
       float out[5];
-      navi_info_for(mv, sp.ckpt_road[which == 0 ? ag.ck0 : ag.ck1], CR.n_lanes, px, py, hx, hy, out);
+      navi_info_for(mv, which == 0 ? ag.cur_first : ag.next_first, ag.cur_n, px, py, hx, hy, out);
       v = comp == 0 ? out[0] : comp == 1 ? out[1] : comp == 2 ? out[2] : comp == 3 ? out[3] : out[4];
       col = o_navi + (tid - 8);
     }
@@ -880,6 +893,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
 
   PHASE_INIT();
   Veh r;
+  RouteCtx ctx{0, 0, 1, 0};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
   MapView mv;
   const pgd_spawn* sp = nullptr;
   const pgd_scenario* sc = nullptr;
@@ -1025,7 +1039,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_MARK(4);  // crash
   // (6) after_step; traffic off the lanes is removed (traffic_manager.py:91-109)
   if (acting) {
-    after_step_vehicle(mv, g, *sp, r, s < A, !one_env);
+    after_step_vehicle(mv, g, *sp, r, s < A, !one_env, ctx);
     if (s >= A && (r.vflags & PGD_F_OFF_LANE)) r.status = ST_REMOVED;
   }
   if (one_env) {  // line / sidewalk test of each agent by the whole wave (base_vehicle.py:615-644)
@@ -1048,7 +1062,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   float my_rew = 0.0f;
   const bool was_active = acting;  // status at the start of the step (after the delay-done countdown)
   if (valid && s < A && !marl) {
-    if (r.status == ST_ACTIVE) my_rew = reward_done(d, mv, *sp, r, my_fl, my_dn);
+    if (r.status == ST_ACTIVE) my_rew = reward_done(d, mv, *sp, r, ctx, my_fl, my_dn);
     if (d.cfg.horizon > 0 && ep_steps >= d.cfg.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
     if (sc->max_steps > 0 && ep_steps >= sc->max_steps) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }  // auto_termination
     r.eprew += my_rew;
@@ -1059,7 +1073,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // ---- multi-agent tail: multi_agent_pgdrive.py:109-213, agent_manager.py:134-175, spawn_manager.py:160-215 ----
     const pgd_config& gcf = d.cfg;
     if (valid && s < A && was_active) {
-      my_rew = reward_done(d, mv, *sp, r, my_fl, my_dn);
+      my_rew = reward_done(d, mv, *sp, r, ctx, my_fl, my_dn);
       const bool arrive = my_fl & PGD_F_ARRIVE, oor = my_fl & PGD_F_OUT_OF_ROAD, crash = my_fl & PGD_F_CRASH_VEHICLE;
       if (crash && !(gcf.marl_flags & PGD_MA_CRASH_DONE) && !(arrive || oor)) my_dn = false;
       if (oor && !(gcf.marl_flags & PGD_MA_OUT_ROAD_DONE) && !arrive) my_dn = false;
@@ -1106,7 +1120,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
           sp = d.spawns + (size_t)scen * d.sstride + sidx;
           reset_vehicle(*sp, r, sidx, true);
           r.agent_id = (float)next_agent;
-          after_step_vehicle(mv, g, *sp, r, true, true);
+          after_step_vehicle(mv, g, *sp, r, true, true, ctx);
           my_fl |= PGD_F_NEW;
           if (leader) {
             S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
@@ -1145,7 +1159,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (valid && resetting) {
     sp = d.spawns + (size_t)scen * d.sstride + s;
     reset_vehicle(*sp, r, s, s < A);
-    if (r.status != ST_EMPTY) after_step_vehicle(mv, g, *sp, r, s < A, true);
+    if (r.status != ST_EMPTY) after_step_vehicle(mv, g, *sp, r, s < A, true, ctx);
     // agent ids restart at 0: id = number of spawned agent slots below this one (agent_manager.py:91-132)
     const unsigned long long am = __ballot(leader && s < A && r.status == ST_ACTIVE);
     if (s < A && r.status == ST_ACTIVE) {
@@ -1187,7 +1201,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         AgentView& ag = s_ag[s];
         ag.x = r.x; ag.y = r.y; ag.th = r.th; ag.hx = r.hx; ag.hy = r.hy; ag.dl = r.dl; ag.dr = r.dr; ag.v = r.v;
         ag.steer = r.steer; ag.a0s = r.a0s; ag.a0t = r.a0t; ag.lhx = r.lasthx; ag.lhy = r.lasthy;
-        ag.ck0 = r.ck0; ag.ck1 = r.ck1;
+        ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
       }
     }
     __syncthreads();
@@ -1226,7 +1240,8 @@ __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restr
   MapView mv = map_view(d, sc->map);
   Veh r;
   reset_vehicle(*sp, r, s, s < A);
-  if (r.status != ST_EMPTY) after_step_vehicle(mv, g, *sp, r, s < A, true);
+  RouteCtx ctx;
+  if (r.status != ST_EMPTY) after_step_vehicle(mv, g, *sp, r, s < A, true, ctx);
   const unsigned long long am = __ballot(lm.sub == 0 && s < A && r.status == ST_ACTIVE);  // epw == 1 whenever A > 1
   if (s < A && r.status == ST_ACTIVE) r.agent_id = A == 1 ? 0.0f : (float)__popcll(am & ((1ull << lm.lead) - 1ull));
   if (lm.sub != 0) return;
@@ -1253,7 +1268,8 @@ __global__ __launch_bounds__(WAVE) void k_refresh(PgdDev d) {
   if (r.status != ST_ACTIVE && r.status != ST_PENDING && r.status != ST_DYING) return;
   int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
   MapView mv = map_view(d, d.scen[scen].map);
-  after_step_vehicle(mv, g, d.spawns[(size_t)scen * d.sstride + r.spawn], r, s < A, true);
+  RouteCtx ctx;
+  after_step_vehicle(mv, g, d.spawns[(size_t)scen * d.sstride + r.spawn], r, s < A, true, ctx);
   if (lm.sub == 0) store_veh(d, e, s, r);
 }
 
@@ -1285,7 +1301,6 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
   sincosf(ag.th, &ag.hy, &ag.hx);
   ag.dl = mine.f[SF_DIST_LEFT]; ag.dr = mine.f[SF_DIST_RIGHT]; ag.v = mine.f[SF_SPEED]; ag.steer = mine.f[SF_STEER];
   ag.a0s = mine.f[SF_ACT0S]; ag.a0t = mine.f[SF_ACT0T]; ag.lhx = mine.f[SF_LASTHX]; ag.lhy = mine.f[SF_LASTHY];
-  ag.ck0 = mine.i[SI_CK0]; ag.ck1 = mine.i[SI_CK1];
   const int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
   const pgd_spawn* spb = d.spawns + (size_t)scen * d.sstride;
   if (tid < WAVE) {  // wave 0: broad phase r = lidar distance (lidar.py:109-124), compacted into LDS
@@ -1318,7 +1333,10 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
   }
   __syncthreads();
   MapView mv = map_view_of(d, d.scen_map + scen);
-  observe_agent(d, mv, spb[mine.i[SI_SPAWN]], ag, L, row, tid, BLOCK);
+  const pgd_spawn& msp = spb[mine.i[SI_SPAWN]];
+  const RouteCtx ctx = route_ctx(mv, msp, mine.i[SI_CK0], mine.i[SI_CK1]);
+  ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
+  observe_agent(d, mv, msp, ag, L, row, tid, BLOCK);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
