@@ -29,7 +29,8 @@ struct PgdDev {
   const pgd_box* boxes;
   const int32_t* cell_start;
   const int32_t* cell_items;
-  const pgd_box* cell_boxes;  // cell-major copies: cell_boxes[item_off + k] == boxes[box_off + cell_items[item_off + k]]
+  const pgd_box* cell_boxes;  // cell-major copies of the boxes, lane boxes first inside each cell (pgd_upload_maps)
+  const struct LaneExt* cell_ext;  // same indexing: what localisation needs from the lane of a lane box
   const pgd_scenario* scen;
   const pgd_map* scen_map;    // [n_scen] copy of each scenario's map header
   const pgd_spawn* spawns;
@@ -46,13 +47,21 @@ struct __attribute__((aligned(16))) VehRec {
 };
 static_assert(sizeof(VehRec) == 128, "vehicle record must be exactly one 128-byte line");
 
+// Per lane-box extract of its lane (device-private, built on upload): the heading test and the road preference of
+// ray_localization (scene_utils.py:158-172, navigation.py:328-344) then need no dependent read of the 64-byte lane record.
+struct __attribute__((aligned(16))) LaneExt {
+  float ax, ay;  // straight lane: unit direction; arc: centre
+  float dir;     // 0 = straight, +-1 = CircularLane.direction
+  int32_t road;  // map-local road id of the lane
+};
+
 struct MapView {
   const pgd_map* m;
   const pgd_lane* lanes;
   const pgd_road* roads;
   const pgd_box* boxes;
   const int32_t* cstart;
-  const int32_t* citems;
+  const LaneExt* cext;
   const pgd_box* cbox;
 };
 
@@ -63,7 +72,7 @@ DEV MapView map_view_of(const PgdDev& d, const pgd_map* m) {
   v.roads = d.roads + m->road_off;
   v.boxes = d.boxes + m->box_off;
   v.cstart = d.cell_start + m->cell_off;
-  v.citems = d.cell_items + m->item_off;
+  v.cext = d.cell_ext + m->item_off;
   v.cbox = d.cell_boxes + m->item_off;
   return v;
 }
@@ -74,7 +83,7 @@ DEV MapView map_view(const PgdDev& d, int map) {
   v.roads = d.roads + v.m->road_off;
   v.boxes = d.boxes + v.m->box_off;
   v.cstart = d.cell_start + v.m->cell_off;
-  v.citems = d.cell_items + v.m->item_off;
+  v.cext = d.cell_ext + v.m->item_off;
   v.cbox = d.cell_boxes + v.m->item_off;
   return v;
 }

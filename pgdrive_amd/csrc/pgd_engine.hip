@@ -158,27 +158,30 @@ DEV int get_current_lane(const MapView& mv, const Grp& g, float px, float py, fl
   }
   unsigned best_cur = 0xffffffffu, best_next = 0xffffffffu, best_any = 0xffffffffu;
   const int stride = g.SUB;
-  for (int k = k0 + g.sub; k < k1; k += 4 * stride) {
-    pgd_box b[4];
+  constexpr int NB = 3;  // boxes per sub-lane and round: a cell holds 3-9 lane boxes, so one round is the rule
+  for (int k = k0 + g.sub; k < k1; k += NB * stride) {
+    pgd_box b[NB];
+    LaneExt x[NB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NB; ++j) {
       int kk = k + j * stride;
-      b[j] = mv.cbox[kk < k1 ? kk : k];  // batch the independent loads
+      kk = kk < k1 ? kk : k;
+      b[j] = mv.cbox[kk];  // batch the independent loads
+      x[j] = mv.cext[kk];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NB; ++j) {
       int kk = k + j * stride;
       if (kk >= k1) continue;
       if (!point_in_obb(obb_of(b[j]), px, py)) continue;
-      const pgd_lane& l = mv.lanes[b[j].lane];
       unsigned key = ((unsigned)(kk - k0) << 16) | (unsigned)b[j].lane;
-      bool is_cur = l.road == road_cur, is_next = l.road == road_next;
+      bool is_cur = x[j].road == road_cur, is_next = x[j].road == road_next;
       if (!(key < best_any || (is_cur && key < best_cur) || (is_next && key < best_next))) continue;
       // cos(angle between lane heading at the point and vehicle heading) > 0 (scene_utils.py:158-172); only the sign is
       // used, so the lane direction is taken in closed form: straight = unit dir; arc = dir * (-dy, dx) around the centre
       float dirx, diry;
-      if (l.dir == 0.0f) { dirx = l.bx; diry = l.by; }
-      else { dirx = -l.dir * (py - l.ay); diry = l.dir * (px - l.ax); }
+      if (x[j].dir == 0.0f) { dirx = x[j].ax; diry = x[j].ay; }
+      else { dirx = -x[j].dir * (py - x[j].ay); diry = x[j].dir * (px - x[j].ax); }
       if (!(dirx * hx + diry * hy > 0.0f)) continue;
       best_any = min(best_any, key);
       if (is_cur) best_cur = min(best_cur, key);
@@ -654,10 +657,8 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
 // ---------------------------------------------------------------------------------------------------------------------
 // observation: LidarStateObservation.observe (obs/state_obs.py:132-170) for one (env, agent)
 // ---------------------------------------------------------------------------------------------------------------------
-DEV void navi_info_for(const MapView& mv, int first_lane, int n_cur, float px, float py, float hx, float hy, float* out) {
-  // Navigation._get_info_for_checkpoint (navigation.py:213-260); first_lane = ref_lanes[0] of the checkpoint's road
-  const pgd_lane& ref = mv.lanes[first_lane];
-  float w = mv.m->lane_width;
+DEV void navi_info_for(const pgd_lane& ref, float w, int n_cur, float px, float py, float hx, float hy, float* out) {
+  // Navigation._get_info_for_checkpoint (navigation.py:213-260); ref = ref_lanes[0] of the checkpoint's road
   float later_middle = ((float)n_cur * 0.5f - 0.5f) * w;
   float cx, cy;
   lane_position(ref, ref.length, later_middle, cx, cy);
@@ -754,12 +755,17 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   const int KS = d.cfg.side_lasers, KM = d.cfg.lane_line_lasers;
   const int o_ego = KS > 0 ? KS : 2, o_navi = o_ego + 6 + KM, o_oth = o_navi + 10;
   if (tid < 18) {
+    // every lane fetches the one lane record its float needs BEFORE the branch ladder, so the reads overlap instead of
+    // queueing behind each other branch by branch: heading_diff -> last lane of the current road; navi -> first lanes
+    const int lid = tid < 8 ? ag.cur_first + ag.cur_n - 1 : (tid < 13 ? ag.cur_first : ag.next_first);
+    const pgd_lane ml = mv.lanes[lid];
+    const float max_speed = sp.max_speed;
     float v = 0.0f;
     int col = -1;
     if (tid == 0) { v = clipf(ag.dl / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 0; }  // (MAX_LANE_NUM+1)*MAX_LANE_WIDTH
     else if (tid == 1) { v = clipf(ag.dr / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 1; }
-    else if (tid == 2) { v = heading_diff(mv.lanes[ag.cur_first + ag.cur_n - 1], px, py, hx, hy); col = o_ego; }
-    else if (tid == 3) { v = clipf((speed_kmh(ag.v) + 1.0f) / (sp.max_speed + 1.0f), 0.0f, 1.0f); col = o_ego + 1; }
+    else if (tid == 2) { v = heading_diff(ml, px, py, hx, hy); col = o_ego; }
+    else if (tid == 3) { v = clipf((speed_kmh(ag.v) + 1.0f) / (max_speed + 1.0f), 0.0f, 1.0f); col = o_ego + 1; }
     else if (tid == 4) { v = clipf((ag.steer / 60.0f + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 2; }
     else if (tid == 5) { v = clipf((ag.a0s + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 3; }
     else if (tid == 6) { v = clipf((ag.a0t + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 4; }
@@ -773,7 +779,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
     } else {  // lanes 8..12 -> checkpoint 1, 13..17 -> checkpoint 2
       int which = (tid - 8) / 5, comp = (tid - 8) - which * 5;
       float out[5];
-      navi_info_for(mv, which == 0 ? ag.cur_first : ag.next_first, ag.cur_n, px, py, hx, hy, out);
+      navi_info_for(ml, mv.m->lane_width, ag.cur_n, px, py, hx, hy, out);
       v = comp == 0 ? out[0] : comp == 1 ? out[1] : comp == 2 ? out[2] : comp == 3 ? out[3] : out[4];
       col = o_navi + (tid - 8);
     }
@@ -1351,6 +1357,7 @@ struct pgd_engine {
   bool ev_valid;
   pgd_map* maps; pgd_lane* lanes; pgd_road* roads; pgd_box* boxes; int32_t* cell_start; int32_t* cell_items;
   pgd_box* cell_boxes;
+  LaneExt* cell_ext;
   pgd_map* scen_map;  // per scenario: copy of its map header (saves one dependent load per block)
   std::vector<pgd_map>* h_maps;
   std::vector<pgd_scenario>* h_scen;
@@ -1441,6 +1448,7 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
     // Inside each cell the lane-surface boxes are moved to the front (stable), and the device copy of cell_start packs
     // the number of lane boxes into the top byte (see cell_first / cell_mid).
     std::vector<pgd_box> cb((size_t)(n_ci > 0 ? n_ci : 1));
+    std::vector<LaneExt> cx((size_t)(n_ci > 0 ? n_ci : 1), LaneExt{0.f, 0.f, 0.f, -1});
     std::vector<int32_t> cs2(cs, cs + n_cs);
     int max_lanes = 0, max_roads = 0;
     for (int m = 0; m < n_maps; ++m) {
@@ -1453,7 +1461,14 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
         for (int pass = 0; pass < 2; ++pass)
           for (int k = a; k < b; ++k) {
             const pgd_box& bx = boxes[M.box_off + ci[M.item_off + k]];
-            if ((bx.kind == PGD_BOX_LANE) == (pass == 0)) cb[(size_t)M.item_off + w++] = bx;
+            if ((bx.kind == PGD_BOX_LANE) == (pass == 0)) {
+              if (pass == 0) {
+                if (bx.lane < 0 || bx.lane >= M.n_lanes) return PGD_ERR_ARG;
+                const pgd_lane& L = lanes[M.lane_off + bx.lane];
+                cx[(size_t)M.item_off + w] = L.dir == 0.0f ? LaneExt{L.bx, L.by, 0.0f, L.road} : LaneExt{L.ax, L.ay, L.dir, L.road};
+              }
+              cb[(size_t)M.item_off + w++] = bx;
+            }
             if (pass == 0 && k == b - 1) {
               const int n_lane_boxes = w - a;
               if (n_lane_boxes > 255) return PGD_ERR_ARG;
@@ -1465,6 +1480,7 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
       if (M.n_roads > max_roads) max_roads = M.n_roads;
     }
     if ((rc = upload(&h->cell_boxes, cb.data(), (size_t)n_ci, h->stream))) return rc;
+    if ((rc = upload(&h->cell_ext, cx.data(), (size_t)n_ci, h->stream))) return rc;
     if ((rc = upload(&h->cell_start, cs2.data(), n_cs, h->stream))) return rc;
     size_t need = (size_t)max_lanes * sizeof(pgd_lane) + (size_t)max_roads * sizeof(pgd_road);
     h->d.lds_bytes = (h->d.epw == 1 && need <= 40 * 1024) ? (int)need : 0;  // else: tables stay in global memory
@@ -1473,7 +1489,7 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
     if (!getenv("PGD_LDS_TABLES")) h->d.lds_bytes = 0;
   }
   h->d.maps = h->maps; h->d.lanes = h->lanes; h->d.roads = h->roads; h->d.boxes = h->boxes;
-  h->d.cell_start = h->cell_start; h->d.cell_items = h->cell_items; h->d.cell_boxes = h->cell_boxes;
+  h->d.cell_start = h->cell_start; h->d.cell_items = h->cell_items; h->d.cell_boxes = h->cell_boxes; h->d.cell_ext = h->cell_ext;
   if (!h->h_maps) h->h_maps = new std::vector<pgd_map>();
   h->h_maps->assign(maps, maps + n_maps);
   if ((rc = build_scen_map(h))) return rc;
@@ -1675,7 +1691,7 @@ int pgd_destroy(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->d.rec, h->d.ei, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
-                  h->cell_items, h->cell_boxes, h->scen_map, h->scen, h->spawns};
+                  h->cell_items, h->cell_boxes, h->cell_ext, h->scen_map, h->scen, h->spawns};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   (void)hipEventDestroy(h->ev0);
