@@ -356,10 +356,9 @@ struct Fbo {
 DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int base, int V, int self, unsigned long long objs,
                          int lane, float max_dist, bool with_ref, Fbo& r) {
   const pgd_lane& L = mv.lanes[lane];
-  const pgd_road& road = mv.roads[L.road];
-  const int idx = L.index;
-  const int l0 = (with_ref && idx > 0) ? road.first_lane + idx - 1 : -1;
-  const int l2 = (with_ref && idx + 1 < road.n_lanes) ? road.first_lane + idx + 1 : -1;
+  const int idx = L.index;  // the lanes of a road are consecutive; the device copy of the lane carries its road's lane count
+  const int l0 = (with_ref && idx > 0) ? lane - 1 : -1;
+  const int l2 = (with_ref && idx + 1 < L.pad) ? lane + 1 : -1;
   const float px = S.x[base + self], py = S.y[base + self];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -382,12 +381,12 @@ DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int bas
     float same_f = max_dist, same_b = max_dist, succ_f = max_dist, pred_b = max_dist, pred_bx = max_dist;
     int o_same_f = -1, o_same_b = -1, o_succ_f = -1, o_pred_b = -1, o_pred_bx = -1;
     bool found_f = false, found_b = false;
-#pragma unroll 4
-    for (int o = 0; o < V; ++o) {
+    // only the vehicles inside the broad phase, in slot order (ties keep the first one like the reference's loop)
+    for (unsigned long long m = objs; m != 0ull; m &= m - 1ull) {
+      const int o = __builtin_ctzll(m);
       const int ol = S.lane[base + o];
       const float olon = S.lon[base + o], ollen = S.llen[base + o];
       const int4 osucc = S.succ[base + o];
-      if (!((objs >> o) & 1ull)) continue;
       if (ol == tl) {
         float lg = olon - cur;
         if (same_f > lg && lg > 0.0f) { same_f = lg; o_same_f = o; found_f = true; }
@@ -426,36 +425,43 @@ DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int bas
 }
 
 DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spawn& sp, const Snap& S, int base, int V,
-                 int s, int e, uint32_t step_count, Veh& r, float& out_steer, float& out_acc) {
+                 int s, int e, uint32_t step_count, unsigned long long pmask, Veh& r, float& out_steer, float& out_acc) {
   const float NORMAL = 30.0f, CREEP = 5.0f, SAFE = 15.0f, MAXD = 30.0f;
-  int cur_road = sp.ckpt_road[r.ck0];
-  const pgd_road& CR = mv.roads[cur_road];
-  int vlane = r.lane;
+  const int vlane = r.lane;
   int rt = r.rlane;
+  // the three reads the routing decision needs are independent of each other: issue them together
+  const int cur_road = sp.ckpt_road[r.ck0];
+  const int vl_road = mv.lanes[vlane].road;
+  const int rt_road = rt < 0 ? vl_road : (int)mv.lanes[rt].road;
+  const pgd_road& CR = mv.roads[cur_road];
   bool success;
   // move_to_next_road (idm_policy.py:222-242)
   if (rt < 0) {
     rt = vlane;
-    success = mv.lanes[rt].road == cur_road;
-  } else if (mv.lanes[rt].road != cur_road) {
+    success = vl_road == cur_road;
+  } else if (rt_road != cur_road) {
     success = false;
     const pgd_lane& RT = mv.lanes[rt];
     for (int k = 0; k < CR.n_lanes; ++k)
       if (lane_is_prev_of(RT, CR.first_lane + k)) { rt = CR.first_lane + k; success = true; break; }
-  } else if (mv.lanes[vlane].road == cur_road && rt != vlane) {
+  } else if (vl_road == cur_road && rt != vlane) {
     rt = vlane;
     r.timer = (int)(pgd_rng(d.cfg.seed, (uint32_t)e, (uint32_t)s, step_count) % 25u);
     success = true;
   } else success = true;
+  // is the (new) routing lane on the current road?  first case: the vehicle lane's road; second: only a found lane of
+  // CR; third and fourth: established by the branch conditions
+  const bool in_cur = r.rlane < 0 ? (vl_road == cur_road) : (rt_road != cur_road ? success : true);
   r.rlane = rt;
 
   // Lidar.get_surrounding_objects (lidar.py:109-124)
   float px = S.x[base + s], py = S.y[base + s];
   unsigned long long objs = 0ull;
-#pragma unroll 4
-  for (int o = 0; o < V; ++o) {
+  // pmask = slots whose vehicle is in the physics world (wave-uniform with one env per wave: a scalar loop)
+  for (unsigned long long m = pmask & ~(1ull << s); m != 0ull; m &= m - 1ull) {
+    const int o = __builtin_ctzll(m);
     const Obb ob = snap_obb(S, base + o);
-    const bool in = o != s && S.present[base + o] && point_obb_dist(ob, px, py) <= 50.0f;
+    const bool in = S.present[base + o] && point_obb_dist(ob, px, py) <= 50.0f;
     objs |= in ? (1ull << o) : 0ull;
   }
 
@@ -467,7 +473,6 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
   // one neighbour search for both branches of IDMPolicy.act (idm_policy.py:195-208): with the reference lanes when the
   // routing lane is on the current road, on the routing lane alone otherwise; the reference's failed assert (routing lane
   // not in ref lanes although move_to_next_road succeeded) falls back to "no front object, distance 5"
-  const bool in_cur = mv.lanes[rt].road == cur_road;
   const bool search = !success || in_cur;
   Fbo fb;
   if (search) find_front_back(mv, g, S, base, V, s, objs, rt, MAXD, success, fb);
@@ -874,12 +879,13 @@ extern __shared__ __align__(16) unsigned char s_dyn[];  // [lanes | roads] of th
 
 #define FUSE_MAX_AGENTS 8
 #ifndef PGD_WAVES_PER_SIMD
-#define PGD_WAVES_PER_SIMD 3  // <=168 VGPRs: measured 71.4 (3) vs 66.6 (4, 113 spilled VGPRs) M env-steps/s at 4096 envs
+#define PGD_WAVES_PER_SIMD 4  // <=128 VGPRs: 4096 envs = 4096 waves are then all resident at once (16 per CU)
 #endif
 // ONE_ENV (epw == 1: every lane of the wave works on env blockIdx.x) is a compile-time switch: the env index, its
 // scenario, the map view (7 table pointers) and the env counters are then wave-uniform and live in SGPRs instead of
 // occupying ~20 VGPRs per lane for the whole kernel.
-template <bool ONE_ENV>
+// MARL (multi-agent tail: delay-done, respawn, __all__) is compiled in only for the multi-agent engine.
+template <bool ONE_ENV, bool MARL>
 __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
                                                 float* __restrict__ obs) {
@@ -909,8 +915,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   s_flag[lane] = 0;
   s_hit[lane] = 0;
   constexpr bool one_env = ONE_ENV;
-  const bool marl = (d.cfg.marl_flags & PGD_MA_ENABLED) != 0;
+  constexpr bool marl = MARL;
   int scen = 0;
+  // the vehicle record does not depend on the scenario: its 8 x 16 B reads go out first and overlap the scalar chain
+  // env counters -> scenario -> map header -> table pointers below
+  if (valid) load_veh(d, e, s, r);
   if (one_env || valid) {
     scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
     sc = d.scen + scen;
@@ -963,7 +972,6 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
 #endif
   PHASE_MARK(13);  // load: scenario + table staging
   if (valid) {
-    load_veh(d, e, s, r);
     sp = d.spawns + (size_t)scen * d.sstride + r.spawn;
     // (0) AgentManager.before_step (agent_manager.py:191-199): finished agents count down, then leave the world
     if (marl && r.status == ST_DYING && --r.timer == 0) r.status = ST_EMPTY;
@@ -999,6 +1007,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   __syncthreads();
   PHASE_MARK(1);  // trigger + snapshot
+  // slots present in the world: one ballot when the wave carries one env (lane o reads slot o), else "all, test later"
+  const unsigned long long pmask = ONE_ENV ? __ballot(lane < V && S.present[lane] != 0) : ((V >= 64 ? 0ull : (1ull << V)) - 1ull);
   const bool acting = valid && r.status == ST_ACTIVE;
   // (2) policies
   if (acting) {
@@ -1014,7 +1024,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         tb = tb * (2.0f / (float)(d.cfg.discrete_throttle_dim - 1)) - 1.0f;
       }
     } else {
-      idm_act(d, mv, g, *sp, S, base, V, s, e, steps_total, r, st, tb);
+      idm_act(d, mv, g, *sp, S, base, V, s, e, steps_total, pmask, r, st, tb);
     }
     PHASE_MARK(2);  // policy (IDM)
     // (3) BaseVehicle.before_step (base_vehicle.py:238-253)
@@ -1438,7 +1448,20 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
   HIPCHK(hipSetDevice(h->device));
   int rc;
   if ((rc = upload(&h->maps, maps, n_maps, h->stream))) return rc;
-  if ((rc = upload(&h->lanes, lanes, n_lanes, h->stream))) return rc;
+  {
+    // device copy of the lane table: `pad` carries the lane count of the lane's road (the lanes of a road are consecutive,
+    // so neighbour lanes follow from the lane id alone: no road-record read in the IDM neighbour search)
+    std::vector<pgd_lane> dl(lanes, lanes + n_lanes);
+    for (int m = 0; m < n_maps; ++m)
+      for (int k = 0; k < maps[m].n_lanes; ++k) {
+        pgd_lane& L = dl[(size_t)maps[m].lane_off + k];
+        if (L.road < 0 || L.road >= maps[m].n_roads) return PGD_ERR_ARG;
+        const pgd_road& R = roads[maps[m].road_off + L.road];
+        if (R.first_lane + L.index != k) return PGD_ERR_ARG;
+        L.pad = R.n_lanes;
+      }
+    if ((rc = upload(&h->lanes, dl.data(), n_lanes, h->stream))) return rc;
+  }
   if ((rc = upload(&h->roads, roads, n_roads, h->stream))) return rc;
   if ((rc = upload(&h->boxes, boxes, n_boxes, h->stream))) return rc;
   if ((rc = upload(&h->cell_items, ci, n_ci, h->stream))) return rc;
@@ -1552,7 +1575,10 @@ int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward
   const bool marl = (h->d.cfg.marl_flags & PGD_MA_ENABLED) != 0;
   if (marl && h->d.epw != 1) return PGD_ERR_STATE;  // the multi-agent tail needs the env in one wave (V >= 33 or SUB split)
   const bool fuse = d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !getenv("PGD_NO_FUSE");
-  hipLaunchKernelGGL(h->d.epw == 1 ? k_step<true> : k_step<false>, dim3(blocks), dim3(WAVE), (size_t)h->d.lds_bytes, h->stream, h->d, d_actions, d_reward, d_done,
+  void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*) = k_step<false, false>;
+  if (marl) kern = k_step<true, true>;
+  else if (h->d.epw == 1) kern = k_step<true, false>;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), (size_t)h->d.lds_bytes, h->stream, h->d, d_actions, d_reward, d_done,
                      d_flags, fuse ? d_obs : (float*)nullptr);
   HIPCHK(hipGetLastError());
   if (prof) HIPCHK(hipEventRecord(pe[1], h->stream));
