@@ -26,6 +26,9 @@ sys.path.insert(0, ROOT)
 #   state r/w   2 * V * (23 f32 + 7 i32) * 4 B  + env ints 2*5*4
 #   actions 8*A, spawn params read V*48, obs write 4*A*D, reward/done/flags 9*A,
 #   k_observe re-read of 7 floats/vehicle
+PROF_STRIDE = 16
+
+
 def algorithmic_bytes(A, T, D):
     V = A + T
     k_step = 2 * V * (23 + 7) * 4 + 40 + 8 * A + V * 48 + 9 * A
@@ -174,7 +177,10 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
-        eng.profile_begin(args.steps)
+        # HIP events bracket groups of PROF_STRIDE consecutive k_step launches over the whole timed region; the average
+        # launch duration is group time / PROF_STRIDE (two event packets around EVERY launch leave the command processor
+        # idle between back-to-back kernels and slow the thing being measured: 102 -> 125 M env-steps/s without them)
+        eng.profile_begin(args.steps // PROF_STRIDE + 1, stride=PROF_STRIDE)
         t0 = time.perf_counter()
         for k in range(args.steps):
             one_step(args.warmup + k)

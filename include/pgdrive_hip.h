@@ -212,12 +212,19 @@ int pgd_set_state(pgd_handle h, const float* h_f, const int32_t* h_i, const int3
  * base_env.py:295-301). */
 int pgd_observe(pgd_handle h, float* d_obs);
 
-/* Timing helper for bench.py: HIP-event time [ms] of the last `k` pgd_step launches on the engine stream. */
+/* Timing helper: HIP-event time [ms] of the last pgd_step on the engine stream.  Off by default (two event packets per
+ * step leave idle gaps between back-to-back launches); switch it on with pgd_enable_step_timing(h, 1). */
+int pgd_enable_step_timing(pgd_handle h, int on);
 int pgd_last_step_ms(pgd_handle h, float* ms);
 
 /* Per-kernel HIP-event profile: between begin and end every pgd_step records events around its two kernels on the
  * engine stream (up to `capacity` steps); end synchronises and returns the average duration of each kernel. */
 int pgd_profile_begin(pgd_handle h, int capacity);
+/* Strided variant for bench.py.  When pgd_step is a single kernel (observation fused) the two events bracket GROUPS of
+ * `stride` consecutive launches and pgd_profile_end reports group time / stride, i.e. the average launch duration with
+ * the launches left back to back; `count` is then the number of complete groups.  Otherwise every stride-th step is
+ * bracketed on its own. */
+int pgd_profile_begin_strided(pgd_handle h, int capacity, int stride);
 int pgd_profile_end(pgd_handle h, float* k_step_ms, float* k_observe_ms, int* count);
 
 int pgd_sync(pgd_handle h);

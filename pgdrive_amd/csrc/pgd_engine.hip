@@ -1376,7 +1376,10 @@ struct pgd_engine {
   bool have_maps, have_scen;
   // per-kernel HIP-event profile of pgd_step launches (bench.py roofline numbers)
   std::vector<hipEvent_t>* prof_ev;  // 3 events per recorded step
-  int prof_cap, prof_n;
+  int prof_cap, prof_n, prof_stride, prof_tick;
+  bool prof_grouped;
+  bool step_timing;  // record ev0 / ev1 around every step (pgd_last_step_ms)
+  bool no_fuse;      // PGD_NO_FUSE was set when the engine was created (debug: always run the stand-alone k_observe)
   bool prof_fused;
 };
 
@@ -1418,6 +1421,7 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   HIPCHK(hipSetDevice(device));
   pgd_engine* h = (pgd_engine*)calloc(1, sizeof(pgd_engine));
   h->device = device;
+  h->no_fuse = getenv("PGD_NO_FUSE") != nullptr;
   h->d.cfg = *cfg;
   h->d.N = cfg->num_envs; h->d.A = cfg->num_agents; h->d.T = cfg->num_traffic; h->d.V = V;
   h->d.D = pgd_obs_dim(cfg);
@@ -1568,28 +1572,40 @@ int pgd_reset(pgd_handle h, const int32_t* env_ids, const int32_t* scen_ids, int
 int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done, uint32_t* d_flags) {
   if (!h || !d_actions || !d_reward || !d_done || !d_flags) return PGD_ERR_ARG;
   if (!h->have_maps || !h->have_scen) return PGD_ERR_STATE;
-  const bool prof = h->prof_ev && h->prof_n < h->prof_cap;
-  hipEvent_t* pe = prof ? &(*h->prof_ev)[(size_t)h->prof_n * 3] : nullptr;
-  HIPCHK(hipEventRecord(prof ? pe[0] : h->ev0, h->stream));
-  int blocks = (h->d.N + h->d.epw - 1) / h->d.epw;
   const bool marl = (h->d.cfg.marl_flags & PGD_MA_ENABLED) != 0;
+  const bool fuse = d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse;
+  bool prof = h->prof_ev && h->prof_n < h->prof_cap;
+  // strided profile: with the observation fused (one kernel per step) events [0] / [1] bracket a GROUP of `stride`
+  // back-to-back launches and the group time is divided by the stride; otherwise every stride-th step is bracketed
+  const bool grouped = prof && h->prof_stride > 1 && fuse;
+  bool g_open = false, g_close = false;
+  if (prof && h->prof_stride > 1) {
+    const int ph = h->prof_tick++ % h->prof_stride;
+    if (grouped) { g_open = ph == 0; g_close = ph == h->prof_stride - 1; prof = false; }
+    else prof = ph == 0;
+  }
+  hipEvent_t* pe = (prof || g_open || g_close) ? &(*h->prof_ev)[(size_t)h->prof_n * 3] : nullptr;
+  const bool timing = h->step_timing && !prof && !grouped;
+  if (prof || timing || g_open) HIPCHK(hipEventRecord((prof || g_open) ? pe[0] : h->ev0, h->stream));
+  int blocks = (h->d.N + h->d.epw - 1) / h->d.epw;
   if (marl && h->d.epw != 1) return PGD_ERR_STATE;  // the multi-agent tail needs the env in one wave (V >= 33 or SUB split)
-  const bool fuse = d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !getenv("PGD_NO_FUSE");
   void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*) = k_step<false, false>;
   if (marl) kern = k_step<true, true>;
   else if (h->d.epw == 1) kern = k_step<true, false>;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), (size_t)h->d.lds_bytes, h->stream, h->d, d_actions, d_reward, d_done,
                      d_flags, fuse ? d_obs : (float*)nullptr);
   HIPCHK(hipGetLastError());
-  if (prof) HIPCHK(hipEventRecord(pe[1], h->stream));
+  if (prof || g_close) HIPCHK(hipEventRecord(pe[1], h->stream));
+  if (g_close) h->prof_n += 1;
   if (d_obs && !fuse) {
     int rc = launch_observe(h, d_obs, marl ? d_flags : (const uint32_t*)nullptr);
     if (rc) return rc;
   }
   h->prof_fused = fuse;
-  if (!(prof && fuse)) HIPCHK(hipEventRecord(prof ? pe[2] : h->ev1, h->stream));  // fused: [0],[1] bracket the only kernel
+  h->prof_grouped = grouped;
+  if ((prof && !fuse) || timing) HIPCHK(hipEventRecord(prof ? pe[2] : h->ev1, h->stream));  // fused: [0],[1] bracket the only kernel
   if (prof) h->prof_n += 1;
-  else h->ev_valid = true;
+  else if (timing) h->ev_valid = true;
   return PGD_OK;
 }
 
@@ -1649,15 +1665,27 @@ extern "C" int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, con
 }
 
 extern "C" {
+int pgd_enable_step_timing(pgd_handle h, int on) {
+  if (!h) return PGD_ERR_ARG;
+  h->step_timing = on != 0;
+  h->ev_valid = false;
+  return PGD_OK;
+}
+
 int pgd_last_step_ms(pgd_handle h, float* ms) {
-  if (!h || !ms || !h->ev_valid) return PGD_ERR_ARG;
+  if (!h || !ms) return PGD_ERR_ARG;
+  if (!h->ev_valid) return PGD_ERR_STATE;  // pgd_enable_step_timing(h, 1) and a step first
   HIPCHK(hipEventSynchronize(h->ev1));
   HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
   return PGD_OK;
 }
 
-int pgd_profile_begin(pgd_handle h, int capacity) {
-  if (!h || capacity <= 0) return PGD_ERR_ARG;
+int pgd_profile_begin(pgd_handle h, int capacity) { return pgd_profile_begin_strided(h, capacity, 1); }
+
+int pgd_profile_begin_strided(pgd_handle h, int capacity, int stride) {
+  if (!h || capacity <= 0 || stride <= 0) return PGD_ERR_ARG;
+  h->prof_stride = stride;
+  h->prof_tick = 0;
   if (!h->prof_ev) h->prof_ev = new std::vector<hipEvent_t>();
   while ((int)h->prof_ev->size() < capacity * 3) {
     hipEvent_t ev;
@@ -1677,7 +1705,7 @@ int pgd_profile_end(pgd_handle h, float* k_step_ms, float* k_observe_ms, int* co
     float t0 = 0.f, t1 = 0.f;
     HIPCHK(hipEventElapsedTime(&t0, (*h->prof_ev)[(size_t)k * 3], (*h->prof_ev)[(size_t)k * 3 + 1]));
     if (!h->prof_fused) HIPCHK(hipEventElapsedTime(&t1, (*h->prof_ev)[(size_t)k * 3 + 1], (*h->prof_ev)[(size_t)k * 3 + 2]));
-    a += t0;
+    a += h->prof_grouped ? t0 / (float)h->prof_stride : t0;
     b += t1;
   }
   *count = h->prof_n;

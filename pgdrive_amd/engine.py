@@ -26,6 +26,8 @@ _SIGS = {
     "pgd_observe": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pgd_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "pgd_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "pgd_profile_begin_strided": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "pgd_enable_step_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pgd_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "pgd_sync": (C.c_int, [C.c_void_p]),
     "pgd_destroy": (C.c_int, [C.c_void_p]),
@@ -155,13 +157,16 @@ class Engine:
     def sync(self):
         _chk(self.L.pgd_sync(self.h), "pgd_sync")
 
+    def enable_step_timing(self, on=True):
+        _chk(self.L.pgd_enable_step_timing(self.h, int(bool(on))), "pgd_enable_step_timing")
+
     def last_step_ms(self):
         ms = C.c_float()
         _chk(self.L.pgd_last_step_ms(self.h, C.byref(ms)), "pgd_last_step_ms")
         return ms.value
 
-    def profile_begin(self, capacity):
-        _chk(self.L.pgd_profile_begin(self.h, int(capacity)), "pgd_profile_begin")
+    def profile_begin(self, capacity, stride=1):
+        _chk(self.L.pgd_profile_begin_strided(self.h, int(capacity), int(stride)), "pgd_profile_begin_strided")
 
     def profile_end(self):
         a, b, n = C.c_float(), C.c_float(), C.c_int()
