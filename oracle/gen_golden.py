@@ -662,6 +662,32 @@ def gen_marl(out_json):
     out_json["marl_capacity"] = 2 * len(spawn_roads) * num_slots
 
 
+def gen_marl_intersection():
+    """Multi-agent intersection: spawn slot table and destination nodes from the reference's Road / lane objects
+    (MAIntersectionConfig.spawn_roads, marl_intersection.py:14-20; SpawnManager slots, spawn_manager.py:114-155)."""
+    from pgdrive.component.blocks.first_block import FirstPGBlock
+    from pgdrive.component.blocks.intersection import InterSection
+    from pgdrive.component.road.road import Road
+    m = ref_export.generate_ma_intersection()
+    net = m["net"]
+    spawn_roads = [Road(FirstPGBlock.NODE_2, FirstPGBlock.NODE_3)] + [
+        -Road(InterSection.node(1, k, 0), InterSection.node(1, k, 1)) for k in range(3)]
+    num_slots = int(math.floor((60 - FirstPGBlock.ENTRANCE_LENGTH) / 8.0))
+    rows = []
+    for road in spawn_roads:
+        lanes = road.get_lanes(net)
+        for lane_idx in range(2):
+            for j in range(num_slots):
+                long = 4.0 + j * 8.0
+                p = lanes[lane_idx].position(long, 0)
+                rows.append(dict(road=[road.start_node, road.end_node], lane_idx=lane_idx, j=j, long=long,
+                                 x=float(p[0]), y=float(p[1]), heading=float(lanes[lane_idx].heading_at(long))))
+    with open(os.path.join(ROOT, "tests", "golden", "marl_intersection_v0.json"), "w") as f:
+        json.dump(dict(slots=rows, dest_nodes=[(-r).end_node for r in spawn_roads],
+                       capacity=2 * len(spawn_roads) * num_slots), f)
+    print("wrote intersection slot goldens:", len(rows))
+
+
 def main():
     rng = np.random.default_rng(20240927)
     out = {}
@@ -669,6 +695,7 @@ def main():
     maps = [ref_export.generate(s, block_num=3) for s in (1000, 1003, 1017)]
     gen_detectors(maps)  # own rng and own file: does not disturb the vectors below
     gen_traffic(maps + [ref_export.generate(s, block_num=3) for s in (1042, 1077)])
+    gen_marl_intersection()
     if "--detectors-only" in sys.argv or "--side-files-only" in sys.argv:
         return
     gen_scalar(rng, out)

@@ -51,6 +51,14 @@ def main_marl():
                                 "exit_length=60, exit_radius=10, inner_radius=30, angle=70)", maps=[strip(m)]),
                            separators=(",", ":")).encode())
     print("wrote", out, os.path.getsize(out))
+    # MAIntersectionMap (envs/marl_envs/marl_intersection.py:29-54) -> tests/golden/ma_intersection_v0.json.gz (+ boxes)
+    m = ref_export.generate_ma_intersection()
+    np.savez_compressed(os.path.join(root, "tests", "golden", "boxes_ma_intersection.npz"), boxes=m["boxes"])
+    out = os.path.join(root, "tests", "golden", "ma_intersection_v0.json.gz")
+    with gzip.GzipFile(out, "wb", mtime=0) as f:
+        f.write(json.dumps(dict(version=0, source="decisionforce/pgdrive v0.1.4 MAIntersectionMap (lane_num=2, "
+                                "exit_length=60, u-turns)", maps=[strip(m)]), separators=(",", ":")).encode())
+    print("wrote", out, os.path.getsize(out))
 
 
 def main_mapgen_goldens():

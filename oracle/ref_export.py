@@ -89,6 +89,26 @@ def generate_ma_roundabout(lane_num=2, lane_width=3.5, exit_length=60):
     return generate(0, lane_num, lane_width, exit_length, prebuilt=(net, _Blocks([first, rb])))
 
 
+def generate_ma_intersection(lane_num=2, lane_width=3.5, exit_length=60):
+    """MAIntersectionMap._generate (envs/marl_envs/marl_intersection.py:29-54): first block + one intersection with
+    u-turns, exit parts as long as the entrance road."""
+    from pgdrive.component.blocks.first_block import FirstPGBlock
+    from pgdrive.component.blocks.intersection import InterSection
+    net = RoadNetwork()
+    pw = refstub.FakePhysicsWorld()
+    first = FirstPGBlock(net, lane_width, lane_num, None, pw, length=exit_length)
+    old = InterSection.EXIT_PART_LENGTH
+    InterSection.EXIT_PART_LENGTH = exit_length
+    try:
+        x = InterSection(1, first.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+        x.add_u_turn(True)
+        ok = x.construct_block(None, pw)
+        assert ok
+        return generate(0, lane_num, lane_width, exit_length, prebuilt=(net, _Blocks([first, x])))
+    finally:
+        InterSection.EXIT_PART_LENGTH = old
+
+
 def generate(seed, lane_num=3, lane_width=3.5, exit_length=50, block_num=None, block_seq=None, prebuilt=None):
     """Run the reference BIG and flatten the result into plain python/numpy data."""
     if prebuilt is not None:

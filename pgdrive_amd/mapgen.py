@@ -678,10 +678,14 @@ class Intersection(Block):
     """StdInterSection (intersection.py:15-238 with change_lane_num forced to 0, std_intersection.py:5-9)"""
     ID = "X"
     EXIT_PART_LENGTH = 30
+    enable_u_turn = False
 
     def build(self):
         self.config["change_lane_num"] = 0
         return self.build_x()
+
+    def add_u_turn(self, enable):
+        self.enable_u_turn = enable
 
     def build_x(self):
         p = self.config
@@ -715,6 +719,10 @@ class Intersection(Block):
         good = True
         left = attach_lanes[0]
         self._left_turn(radius, n, left, attach, nodes, part)
+        if self.enable_u_turn:  # InterSection._create_u_turn (intersection.py:207-230)
+            bend, _ = create_bend_straight(left, 0.1, self.lane_width / 2, np.deg2rad(180), False, left.width, (NONE, NONE))
+            self.rf(bend, len(attach_lanes), (attach[1], neg(attach)[0]), toward_smaller=False, center_line_type=NONE,
+                    side_type=NONE, inner_type=NONE)
         on_road = copy.deepcopy(attach_lanes)
         straight_len = 2 * radius + (2 * n - 1) * on_road[0].width
         for l in on_road:
@@ -979,6 +987,25 @@ def generate_map(seed, lane_num=3, lane_width=3.5, exit_length=50, block_num=3, 
     """PGMap._big_generate (component/map/pg_map.py:34-46) -> map description."""
     gnet, blocks = generate_blocks(seed, lane_num, lane_width, exit_length, None if block_seq else block_num, block_seq)
     return to_description(seed, gnet, blocks, lane_num, lane_width, exit_length)
+
+
+class FullIntersection(Intersection):
+    """InterSection proper (intersection.py:15-238): the lane-count change of the crossing road is sampled, not forced to 0."""
+    def build(self):
+        return self.build_x()
+
+
+def generate_ma_intersection(lane_num=2, lane_width=3.5, exit_length=60):
+    """MAIntersectionMap._generate (envs/marl_envs/marl_intersection.py:29-54): first block + one intersection (block
+    seed 1) with u-turns and exit parts as long as the entrance road."""
+    gnet = Net()
+    first = FirstBlock(gnet, lane_width, lane_num, exit_length)
+    x = FullIntersection(1, first.get_socket(0), gnet, 1)
+    x.EXIT_PART_LENGTH = exit_length
+    x.add_u_turn(True)
+    ok = x.construct()
+    assert ok
+    return to_description(0, gnet, [first, x], lane_num, lane_width, exit_length)
 
 
 def generate_ma_roundabout(lane_num=2, lane_width=3.5, exit_length=60):

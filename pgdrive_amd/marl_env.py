@@ -1,4 +1,4 @@
-"""Multi-agent roundabout on the HIP engine (BASELINE config 5).
+"""Multi-agent roundabout (BASELINE config 5) and intersection on the HIP engine.
 
 Mirrors `MultiAgentRoundaboutEnv` (pgdrive/envs/marl_envs/marl_inout_roundabout.py:133-153) on top of
 `MultiAgentPGDrive` (pgdrive/envs/marl_envs/multi_agent_pgdrive.py:58-213): per-agent termination, finished agents stay
@@ -8,6 +8,8 @@ places at the road starts while fewer than `num_agents` are alive and the episod
 
 `MultiAgentRoundaboutVecEnv` — N envs, slot-indexed cuda tensors `[N, A, ...]` + flag bits (PGD_F_REPORT / NEW / ALL_DONE).
 `MultiAgentRoundaboutEnv`    — one env, the reference's dict-in / dict-out protocol.
+`MultiAgentIntersectionVecEnv / MultiAgentIntersectionEnv` — the same machinery on `MAIntersectionMap`
+(pgdrive/envs/marl_envs/marl_intersection.py:14-109: first block + 4-way intersection with u-turns, 30 agents).
 """
 import numpy as np
 
@@ -44,18 +46,24 @@ MA_DEFAULT_CONFIG = dict(
 
 
 class MultiAgentRoundaboutVecEnv:
+    MAP_KIND = "roundabout"
+    DEFAULTS = MA_DEFAULT_CONFIG
+
+    @staticmethod
+    def _generate_map(mc):
+        from . import mapgen
+        return mapgen.generate_ma_roundabout(mc["lane_num"], mc["lane_width"], mc["exit_length"])
+
     def __init__(self, config=None):
-        self.config = c = merge_config(MA_DEFAULT_CONFIG, config)
+        self.config = c = merge_config(self.DEFAULTS, config)
         lid = c["vehicle_config"]["lidar"]
         if lid["num_others"] != 0:
             raise NotImplementedError("LidarStateObservationMARound with num_others > 0 is not built (reference default 0)")
-        from . import mapgen
-        mc = c["map_config"]
-        self.desc = mapgen.generate_ma_roundabout(mc["lane_num"], mc["lane_width"], mc["exit_length"])
+        self.desc = self._generate_map(c["map_config"])
         self.map_bank = mapdata.MapBank([self.desc])
         cap = c["max_agents"] or c["num_agents"]
         self.scen_bank = scenario.MarlScenarioBank(self.desc, c["num_agents"], capacity=cap,
-                                                   n_variants=c["spawn_variants"], seed=c["seed"])
+                                                   n_variants=c["spawn_variants"], seed=c["seed"], kind=self.MAP_KIND)
         self.num_envs, self.A = int(c["num_envs"]), cap
         self.cfg = _abi.make_config(
             self.num_envs, num_agents=cap, num_traffic=0, num_lasers=lid["num_lasers"], num_others=0,
@@ -94,13 +102,26 @@ class MultiAgentRoundaboutVecEnv:
             self.engine = None
 
 
+class MultiAgentIntersectionVecEnv(MultiAgentRoundaboutVecEnv):
+    """MultiAgentIntersectionEnv (marl_intersection.py:65-109) batched: MAIntersectionConfig = 30 agents, 2 lanes, exits 60 m."""
+    MAP_KIND = "intersection"
+    DEFAULTS = dict(MA_DEFAULT_CONFIG, num_agents=30)
+
+    @staticmethod
+    def _generate_map(mc):
+        from . import mapgen
+        return mapgen.generate_ma_intersection(mc["lane_num"], mc["lane_width"], mc["exit_length"])
+
+
 class MultiAgentRoundaboutEnv:
     """Dict protocol of the reference: keys "agent{k}"; done has "__all__" (multi_agent_pgdrive.py:126-150)."""
+    VEC = MultiAgentRoundaboutVecEnv
+
     def __init__(self, config=None):
         cfg = dict(config or {})
         cfg["num_envs"] = 1
         cfg.setdefault("auto_reset", False)
-        self.vec = MultiAgentRoundaboutVecEnv(cfg)
+        self.vec = self.VEC(cfg)
         self.config = self.vec.config
         import torch
         self._torch = torch
@@ -161,3 +182,8 @@ class MultiAgentRoundaboutEnv:
 
     def close(self):
         self.vec.close()
+
+
+class MultiAgentIntersectionEnv(MultiAgentRoundaboutEnv):
+    """Dict protocol on the intersection map (marl_intersection.py:65-109)."""
+    VEC = MultiAgentIntersectionVecEnv

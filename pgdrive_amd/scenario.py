@@ -330,6 +330,18 @@ def roundabout_spawn_roads(desc):
     return roads
 
 
+def intersection_spawn_roads(desc):
+    """MAIntersectionConfig.spawn_roads (marl_intersection.py:14-20): '>>'->'>>>' and the three exits, negated."""
+    n = desc["nodes"]
+    roads = [(n.index(">>"), n.index(">>>"))]
+    for k in range(3):
+        roads.append(neg_road(desc, n.index("1X%d_0_" % k), n.index("1X%d_1_" % k)))
+    return roads
+
+
+MARL_SPAWN_ROADS = {"roundabout": roundabout_spawn_roads, "intersection": intersection_spawn_roads}
+
+
 def spawn_slots(desc, spawn_roads):
     """SpawnManager._auto_fill_spawn_roads_randomly (spawn_manager.py:114-155): (road, lane, slot j) -> longitude;
     the j == 0 slots are the safe respawn places."""
@@ -349,13 +361,14 @@ def spawn_slots(desc, spawn_roads):
     return slots, safe
 
 
-def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle_model="default"):
+def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle_model="default", kind="roundabout"):
     """SpawnManager.reset (spawn_manager.py:68-101): `num_agents` of the spawn slots without replacement, jittered inside
     the slot, each with a random destination (RoundaboutSpawnManager.update_destination_for,
     marl_inout_roundabout.py:125-130); followed by the respawn table [safe place][destination].
-    `rng` is a numpy RandomState (the reference leaves this manager unseeded)."""
+    `rng` is a numpy RandomState (the reference leaves this manager unseeded).  `kind` selects the spawn roads; the
+    destination rule is the same on the intersection map (InterectionSpawnManager, marl_intersection.py:57-62)."""
     A = capacity or num_agents
-    spawn_roads = roundabout_spawn_roads(desc)
+    spawn_roads = MARL_SPAWN_ROADS[kind](desc)
     slots, safe = spawn_slots(desc, spawn_roads)
     if num_agents > len(slots):
         raise ValueError("Too many agents! We only accept %d agents" % len(slots))
@@ -387,11 +400,11 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
 
 class MarlScenarioBank:
     """`n_variants` random initial placements over one multi-agent map (scenarios differ only in spawn choice)."""
-    def __init__(self, desc, num_agents, capacity=None, n_variants=16, seed=0):
+    def __init__(self, desc, num_agents, capacity=None, n_variants=16, seed=0, kind="roundabout"):
         rng = np.random.RandomState(seed)
         scens, recs = [], []
         for _ in range(n_variants):
-            sc, rc, self.P, self.Dn = build_marl_scenario(desc, 0, rng, num_agents, capacity)
+            sc, rc, self.P, self.Dn = build_marl_scenario(desc, 0, rng, num_agents, capacity, kind=kind)
             scens.append(sc)
             recs.append(rc)
         self.scenarios = np.array(scens, dtype=SCEN_DT)

@@ -109,12 +109,14 @@ def test_checkpoint_resume_roundtrip():
         env.close()
 
 
-def test_marl_dict_protocol():
+@pytest.mark.parametrize("kind", ["roundabout", "intersection"])
+def test_marl_dict_protocol(kind):
     """Key-set invariants of the reference's MARL tests (tests/test_env/test_ma_roundabout_env.py:73-200,
     test_marl_reborn.py:6-60): obs/reward/done/info share keys, finished agents disappear, newcomers get fresh
     increasing ids, -penalty => done, __all__ ends the episode."""
-    from pgdrive_amd.marl_env import MultiAgentRoundaboutEnv
-    env = MultiAgentRoundaboutEnv(dict(num_agents=8, horizon=150, seed=2))
+    from pgdrive_amd import marl_env
+    cls = marl_env.MultiAgentRoundaboutEnv if kind == "roundabout" else marl_env.MultiAgentIntersectionEnv
+    env = cls(dict(num_agents=8, horizon=150, seed=2))
     try:
         o = env.reset()
         assert len(o) == 8 and all(v.shape == (90, ) for v in o.values())

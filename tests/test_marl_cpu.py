@@ -96,3 +96,50 @@ def test_oracle_marl_episode_protocol():
         assert np.isfinite(obs).all() and obs.min() >= 0 and obs.max() <= 1
         prev_status = st.copy()
     assert n_all >= n  # every env finished at least one episode (horizon 80 -> __all__ soon after)
+
+
+def test_intersection_map_and_slots_match_reference():
+    """MAIntersectionMap (marl_intersection.py:29-54) from our generator: boxes vs the reference's recorded Bullet boxes,
+    spawn slot table and destinations vs MAIntersectionConfig.spawn_roads (marl_intersection.py:14-20)."""
+    from pgdrive_amd import mapgen
+    d = mapgen.generate_ma_intersection()
+    ref = np.load(os.path.join(GOLD, "boxes_ma_intersection.npz"))["boxes"]
+    mine = mapdata.build_boxes(d)
+    assert ref.shape == mine.shape
+    assert (ref[:, 0] == mine[:, 0]).all() and (ref[:, 6] == mine[:, 6]).all()
+    assert np.abs(ref[:, [1, 2, 4, 5]] - mine[:, [1, 2, 4, 5]]).max() < 1e-9
+    with open(os.path.join(GOLD, "marl_intersection_v0.json")) as f:
+        g = json.load(f)
+    roads = scenario.intersection_spawn_roads(d)
+    slots, safe = scenario.spawn_slots(d, roads)
+    assert len(slots) == g["capacity"] == 48 and len(safe) == 8
+    for mine_s, r in zip(slots, g["slots"]):
+        assert [d["nodes"][mine_s["road"][0]], d["nodes"][mine_s["road"][1]]] == r["road"]
+        lane = d["lanes"][mine_s["lane"]]
+        assert lane["index"] == r["lane_idx"] and mine_s["long"] == r["long"]
+        x, y = mapdata.lane_position(lane, mine_s["long"], 0.0)
+        assert abs(x - r["x"]) < 1e-9 and abs(y - r["y"]) < 1e-9
+        assert abs(mapdata.lane_heading_at(lane, mine_s["long"]) - r["heading"]) < 1e-12
+    assert [d["nodes"][scenario.neg_road(d, *r)[1]] for r in roads] == g["dest_nodes"]
+    # every (safe place, destination) pair has a route, u-turn destinations included
+    sb = scenario.MarlScenarioBank(d, num_agents=30, n_variants=2, kind="intersection")
+    assert sb.P == 8 and sb.Dn == 4 and (sb.spawns["n_ckpt"][sb.spawns["lane"] >= 0] >= 2).all()
+
+
+def test_oracle_intersection_episode_runs():
+    from oracle import orc
+    d, mb, sb = util.make_marl_banks(num_agents=30, n_variants=2, kind="intersection")
+    cfg = util.marl_config(2, sb, horizon=60)
+    o = orc.Oracle(cfg, mb, sb)
+    obs = o.reset(np.arange(2) % 2)
+    assert obs.shape == (2, 30, 90)
+    rng = np.random.default_rng(0)
+    n_new = n_all = n_arrive = 0
+    for t in range(200):
+        obs, rew, done, fl = o.step(util.marl_actions(rng, 2, 30))
+        n_new += int(((fl & _abi.F_NEW) != 0).sum())
+        n_all += int(((fl & _abi.F_ALL_DONE) != 0).any(axis=1).sum())
+        n_arrive += int(((fl & _abi.F_ARRIVE) != 0).sum())
+        assert np.isfinite(obs).all() and obs.min() >= 0.0 and obs.max() <= 1.0
+    assert n_new > 10 and n_all >= 2
+    o.close()

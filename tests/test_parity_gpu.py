@@ -228,13 +228,13 @@ def test_empty_and_edge_slots(descs):
 
 
 @pytest.mark.parametrize("num_agents,capacity", [(8, 8), (12, 16), (40, 40)])
-def test_marl_roundabout_parity(num_agents, capacity):
+def test_marl_roundabout_parity(num_agents, capacity, kind="roundabout"):
     """BASELINE config 5: multi-agent roundabout (envs/marl_envs/marl_inout_roundabout.py) — per-agent done, delay-done
     queue, respawn into free 8 m x 3 m places, __all__, agent ids; teacher-forced against the oracle."""
     import torch
     from oracle import orc
     from pgdrive_amd.engine import Engine
-    d, mb, sb = util.make_marl_banks(num_agents=num_agents, capacity=capacity)
+    d, mb, sb = util.make_marl_banks(num_agents=num_agents, capacity=capacity, kind=kind)
     n_envs = 32
     cfg = util.marl_config(n_envs, sb, horizon=120)  # short horizon so that the episode end / reset path is exercised
     eng = Engine(cfg, mb, sb)
@@ -264,3 +264,8 @@ def test_marl_roundabout_parity(num_agents, capacity):
     assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL
     assert stats["flag_mismatch"] <= 2 and seen["int_mismatch"] <= 2 and seen["id_mismatch"] == 0
     assert seen["dying"] > 0 and stats["n_new"] > 0 and stats["n_all_done"] > 0 and stats["n_report"] > 1000
+
+
+def test_marl_intersection_parity():
+    """MultiAgentIntersectionEnv (envs/marl_envs/marl_intersection.py): 4-way intersection with u-turns, 30 agents."""
+    test_marl_roundabout_parity(30, 30, kind="intersection")

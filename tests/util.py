@@ -24,11 +24,11 @@ def round_state_f32(f):
     return np.asarray(f, dtype=np.float32).astype(np.float64)
 
 
-def make_marl_banks(num_agents=8, n_variants=8, seed=1, capacity=None):
+def make_marl_banks(num_agents=8, n_variants=8, seed=1, capacity=None, kind="roundabout"):
     from pgdrive_amd import mapgen
-    d = mapgen.generate_ma_roundabout()
+    d = mapgen.generate_ma_roundabout() if kind == "roundabout" else mapgen.generate_ma_intersection()
     mb = mapdata.MapBank([d])
-    sb = scenario.MarlScenarioBank(d, num_agents=num_agents, capacity=capacity, n_variants=n_variants, seed=seed)
+    sb = scenario.MarlScenarioBank(d, num_agents=num_agents, capacity=capacity, n_variants=n_variants, seed=seed, kind=kind)
     return d, mb, sb
 
 
