@@ -47,7 +47,7 @@ extern "C" {
 #define PGD_F_ARRIVE        (1u << 0)   /* arrive_dest          base_vehicle.py:738-745 */
 #define PGD_F_OUT_OF_ROAD   (1u << 1)   /* out_of_road          pgdrive_env.py:209-216 */
 #define PGD_F_CRASH_VEHICLE (1u << 2)   /* crash_vehicle        collision_callback.py:7-36 */
-#define PGD_F_CRASH_OBJECT  (1u << 3)   /* crash_object (no objects in this build: always 0) */
+#define PGD_F_CRASH_OBJECT  (1u << 3)   /* crash_object: first contact with a traffic object (collision_callback.py:27-32) */
 #define PGD_F_CRASH_BUILDING (1u << 4)  /* crash_building (InvisibleWall/TollGate: always 0 on PG maps) */
 #define PGD_F_MAX_STEP      (1u << 5)   /* max_step / horizon   base_env.py:190-192 */
 #define PGD_F_ON_YELLOW     (1u << 8)   /* on_yellow_continuous_line  base_vehicle.py:615-636 */
@@ -56,6 +56,8 @@ extern "C" {
 #define PGD_F_CRASH_SIDEWALK (1u << 11) /* crash_sidewalk        base_vehicle.py:638-643 */
 #define PGD_F_OFF_LANE      (1u << 12)  /* not on_lane           navigation.py:158-160 */
 #define PGD_F_OUT_OF_ROUTE  (1u << 13)  /* out_of_route          base_vehicle.py:274-276 */
+#define PGD_F_OBJECT_HIT    (1u << 14)  /* state bit of a traffic OBJECT's own slot: TrafficObject.crashed (COST_ONCE,
+                                           collision_callback.py:28-32); never reported for agents */
 #define PGD_F_RESET         (1u << 16)  /* this env was auto-reset at the end of the step (obs is the new episode's) */
 #define PGD_F_REPORT        (1u << 17)  /* multi-agent: the slot held an active agent this step: obs/reward/done are valid */
 #define PGD_F_NEW           (1u << 18)  /* multi-agent: an agent was (re)spawned into this slot: obs valid, reward 0 */
@@ -120,10 +122,19 @@ typedef struct pgd_spawn {  /* 64 B + route */
   int16_t n_ckpt;           /* route length in nodes */
   int16_t timer0;           /* IDMPolicy.overtake_timer initial value (idm_policy.py:185) */
   int16_t dest_lane;        /* Navigation.final_lane (navigation.py:138-140) */
-  int16_t pad[3];
+  int16_t kind;             /* PGD_OBJ_*: what occupies the slot */
+  int16_t pad[2];
   int16_t ckpt[PGD_MAX_CKPT];       /* route as node ids (Navigation.checkpoints) */
   int16_t ckpt_road[PGD_MAX_CKPT];  /* road id of (ckpt[k], ckpt[k+1]); -1 past the end */
 } pgd_spawn;
+
+/* pgd_spawn.kind.  Traffic objects (manager/object_manager.py, static_object/traffic_object.py) and broken-down vehicles
+ * occupy traffic slots with group = PGD_GROUP_NEVER: present in the world (contacts, lidar, IDM neighbour search), never
+ * driven.  Deliberate substitution: Bullet lets a hit cone fly away; here objects are static. */
+#define PGD_OBJ_VEHICLE  0  /* chassis box length x width */
+#define PGD_OBJ_CYLINDER 1  /* TrafficCone / TrafficWarning: circle of radius length / 2 (traffic_object.py:40,60) */
+#define PGD_OBJ_BOX      2  /* TrafficBarrier: box length x width at `heading` (traffic_object.py:80-96) */
+#define PGD_GROUP_NEVER (-2)
 
 typedef struct pgd_scenario {
   int32_t map;              /* index into the map table */
@@ -168,7 +179,8 @@ typedef struct pgd_config {
                                clip to [-1,1] exactly as the reference does */
   int32_t discrete_steering_dim, discrete_throttle_dim; /* 5, 5 (base_env.py:35-36) */
   int32_t increment_steering; /* 1: steering += a0 * 0.05, clipped (base_vehicle.py:351-358) */
-  int32_t pad;
+  int32_t safe_rl_env;      /* 1: SafePGDriveEnv.done_function (safe_pgdrive_env.py:49-56): a step with crash_vehicle, else
+                               crash_object, is never terminal */
 } pgd_config;
 
 #define PGD_MA_ENABLED        1  /* MultiAgentPGDrive semantics: per-agent done, delay-done queue, respawn, __all__ */

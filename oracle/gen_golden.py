@@ -662,6 +662,67 @@ def gen_marl(out_json):
     out_json["marl_capacity"] = 2 * len(spawn_roads) * num_slots
 
 
+def gen_objects():
+    """TrafficObjectManager.reset (object_manager.py:40-124) on the reference's own block objects with spawn_object replaced
+    by a recorder; the traffic manager that follows it (accident lanes skipped, vehicle types of broken-down vehicles
+    drawn from ITS stream first) is run as well."""
+    from pgdrive.component.vehicle import vehicle_type as vt_mod
+    from pgdrive.manager import object_manager as om
+    from pgdrive.manager.traffic_manager import TrafficManager
+    from pgdrive.policy import idm_policy as idm_mod
+    names = {cls: k for k, cls in vt_mod.vehicle_type.items()}
+    out = []
+    real_idm, real_get_engine = idm_mod.IDMPolicy, om.get_engine
+    try:
+        idm_mod.IDMPolicy = lambda v, seed: setattr(v, "policy_seed", int(seed))
+        for seed, kw in [(1000, dict(block_num=3)), (1003, dict(block_num=3)), (5, dict(block_seq="SCS")),
+                         (7, dict(block_seq="rRC")), (10, dict(block_seq="CrXRTOS")), (21, dict(block_seq="SSrRCC")),
+                         (22, dict(block_seq="CSRrSC")), (23, dict(block_seq="RRSSCC"))]:
+            m = ref_export.generate(seed, **kw)
+            lanes = ref_lanes_in_order(m)
+            lane_of = {l.index: k for k, l in enumerate(lanes)}
+            fmap = FakeMap(m)
+            fmap.config = fmap._config
+            for prob in (0.8, 1.0):
+                tm = TrafficManager.__new__(TrafficManager)
+                tm.np_random = get_np_random(seed)
+                tm._traffic_vehicles, tm.block_triggered_vehicles = [], []
+                tm.spawn_object = lambda cls, vehicle_config: types.SimpleNamespace(
+                    id=0, vtype=names[cls], long=float(vehicle_config["spawn_longitude"]),
+                    lane=lane_of[vehicle_config["spawn_lane_index"]])
+                mgr = om.TrafficObjectManager.__new__(om.TrafficObjectManager)
+                mgr.np_random = get_np_random(seed)
+                mgr.accident_prob = prob
+                rec = []
+
+                def spawn(cls, lane=None, longitude=None, lateral=None, vehicle_config=None):
+                    if vehicle_config is not None:
+                        rec.append(["vehicle", lane_of[vehicle_config["spawn_lane_index"]],
+                                    float(vehicle_config["spawn_longitude"]), 0.0, names[cls]])
+                        return types.SimpleNamespace(set_break_down=lambda: None)
+                    p = lane.position(longitude, lateral)
+                    rec.append([cls.__name__, lane_of[lane.index], float(longitude), float(lateral), float(p[0]), float(p[1]),
+                                float(lane.heading_at(longitude))])
+                    return None
+                mgr.spawn_object = spawn
+                engine = types.SimpleNamespace(current_map=fmap, traffic_manager=tm, add_policy=lambda *a: None,
+                                               object_manager=mgr)
+                mgr.engine = engine
+                tm.engine = engine
+                om.get_engine = lambda: engine
+                mgr.reset()
+                tm._create_vehicles_once(fmap, 0.2)
+                groups = [[[v.lane, v.long, v.vtype, v.policy_seed] for v in bv.vehicles]
+                          for bv in reversed(tm.block_triggered_vehicles)]
+                out.append(dict(seed=seed, kw=kw, prob=prob, objects=rec,
+                                accident_lanes=[lane_of[l.index] for l in mgr.accident_lanes], traffic_0_2=groups))
+    finally:
+        idm_mod.IDMPolicy, om.get_engine = real_idm, real_get_engine
+    with open(os.path.join(ROOT, "tests", "golden", "objects_v0.json"), "w") as f:
+        json.dump(dict(cases=out), f)
+    print("wrote object goldens:", [(c["seed"], c["prob"], len(c["objects"])) for c in out])
+
+
 def gen_marl_intersection():
     """Multi-agent intersection: spawn slot table and destination nodes from the reference's Road / lane objects
     (MAIntersectionConfig.spawn_roads, marl_intersection.py:14-20; SpawnManager slots, spawn_manager.py:114-155)."""
@@ -696,6 +757,7 @@ def main():
     gen_detectors(maps)  # own rng and own file: does not disturb the vectors below
     gen_traffic(maps + [ref_export.generate(s, block_num=3) for s in (1042, 1077)])
     gen_marl_intersection()
+    gen_objects()
     if "--detectors-only" in sys.argv or "--side-files-only" in sys.argv:
         return
     gen_scalar(rng, out)

@@ -14,7 +14,7 @@ class PgdConfig(C.Structure):
         ("respawn_dests", C.c_int32), ("side_lasers", C.c_int32), ("side_dist", C.c_float),
         ("lane_line_lasers", C.c_int32), ("lane_line_dist", C.c_float), ("discrete_action", C.c_int32),
         ("discrete_steering_dim", C.c_int32), ("discrete_throttle_dim", C.c_int32), ("increment_steering", C.c_int32),
-        ("pad", C.c_int32),
+        ("safe_rl_env", C.c_int32),
     ]
 
 
@@ -24,7 +24,8 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
                 speed_reward=0.1, use_lateral=False, out_of_route_done=False, multi_agent=False, crash_done=True,
                 out_of_road_done=True, allow_respawn=True, delay_done=25, agent_limit=0, respawn_places=0,
                 respawn_dests=0, side_lasers=0, side_dist=50.0, lane_line_lasers=0, lane_line_dist=20.0,
-                discrete_action=False, discrete_steering_dim=5, discrete_throttle_dim=5, increment_steering=False):
+                discrete_action=False, discrete_steering_dim=5, discrete_throttle_dim=5, increment_steering=False,
+                safe_rl_env=False):
     """Defaults mirror PGDriveEnv_DEFAULT_CONFIG / BASE_DEFAULT_CONFIG (pgdrive_env.py:22-109, base_env.py:19-90)."""
     c = PgdConfig()
     c.num_envs, c.num_agents, c.num_traffic = num_envs, num_agents, num_traffic
@@ -39,6 +40,7 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
     c.lane_line_lasers, c.lane_line_dist = int(lane_line_lasers), float(lane_line_dist)
     c.discrete_action, c.increment_steering = int(bool(discrete_action)), int(bool(increment_steering))
     c.discrete_steering_dim, c.discrete_throttle_dim = int(discrete_steering_dim), int(discrete_throttle_dim)
+    c.safe_rl_env = int(bool(safe_rl_env))
     if multi_agent:
         c.marl_flags = MA_ENABLED | (MA_CRASH_DONE if crash_done else 0) | (MA_OUT_ROAD_DONE if out_of_road_done else 0) | \
             (MA_ALLOW_RESPAWN if allow_respawn else 0)
@@ -63,4 +65,5 @@ MA_ENABLED, MA_CRASH_DONE, MA_OUT_ROAD_DONE, MA_ALLOW_RESPAWN = 1, 2, 4, 8
 
 F_ARRIVE, F_OUT_OF_ROAD, F_CRASH_VEHICLE, F_CRASH_OBJECT, F_CRASH_BUILDING, F_MAX_STEP = 1, 2, 4, 8, 16, 32
 F_ON_YELLOW, F_ON_WHITE, F_ON_BROKEN, F_CRASH_SIDEWALK, F_OFF_LANE, F_OUT_OF_ROUTE = 256, 512, 1024, 2048, 4096, 8192
+F_OBJECT_HIT = 1 << 14
 F_RESET, F_REPORT, F_NEW, F_ALL_DONE = 1 << 16, 1 << 17, 1 << 18, 1 << 19

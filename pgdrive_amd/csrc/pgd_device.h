@@ -175,6 +175,39 @@ DEV float point_obb_dist(const Obb& o, float px, float py) {  // lidar broad pha
   float a = fmaxf(fabsf(dx * o.ux + dy * o.uy) - o.hl, 0.0f), c = fmaxf(fabsf(dy * o.ux - dx * o.uy) - o.hw, 0.0f);
   return sqrtf(a * a + c * c);
 }
+DEV float ray_obb(const Obb& o, float px, float py, float dx, float dy);
+// Bodies of the world are chassis / barrier boxes or, for traffic cones and warning tripods (PGD_OBJ_CYLINDER), circles:
+// a circle is carried as an Obb with hw < 0 and radius hl.
+// OBJ is a compile-time switch: engines whose scenarios hold no traffic objects run kernels without the circle paths.
+template <bool OBJ>
+DEV bool shape_is_circle(const Obb& o) { return OBJ && o.hw < 0.0f; }
+template <bool OBJ>
+DEV bool shape_overlap(const Obb& box, const Obb& other) {
+  if (!shape_is_circle<OBJ>(other)) return obb_overlap(box, other);
+  return point_obb_dist(box, other.cx, other.cy) <= other.hl;
+}
+template <bool OBJ>
+DEV float shape_point_dist(const Obb& o, float px, float py) {
+  if (!shape_is_circle<OBJ>(o)) return point_obb_dist(o, px, py);
+  float dx = px - o.cx, dy = py - o.cy;
+  return fmaxf(sqrtf(dx * dx + dy * dy) - o.hl, 0.0f);
+}
+template <bool OBJ>
+DEV float shape_ray(const Obb& o, float px, float py, float dx, float dy) {
+  if (!shape_is_circle<OBJ>(o)) return ray_obb(o, px, py, dx, dy);
+  // |p + t d - c|^2 = r^2, smallest root in (0, 1]; a ray that starts inside does not hit (as for boxes).  Written with
+  // the unit direction u: offset of the centre across the ray = cross(f, u) (no cancellation, unlike b^2 - a c), along it
+  // = dot(f, u); hit distance = -dot - sqrt(r^2 - cross^2)
+  const float fx = px - o.cx, fy = py - o.cy;
+  const float len = sqrtf(dx * dx + dy * dy);
+  if (fx * fx + fy * fy <= o.hl * o.hl || len <= 0.0f) return 1.0f;
+  const float ux = dx / len, uy = dy / len;
+  const float along = fx * ux + fy * uy, across = fx * uy - fy * ux;
+  const float h2 = o.hl * o.hl - across * across;
+  if (h2 < 0.0f || along >= 0.0f) return 1.0f;
+  const float t = (-along - sqrtf(h2)) / len;
+  return (t > 0.0f && t <= 1.0f) ? t : 1.0f;
+}
 // nearest hit fraction of the segment p + t d, t in [0,1]; 1 = miss (cutils.pyx:60-142 rayTestClosest)
 DEV float ray_obb(const Obb& o, float px, float py, float dx, float dy) {
   float rx = px - o.cx, ry = py - o.cy;

@@ -424,6 +424,7 @@ DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int bas
   }
 }
 
+template <bool OBJ>
 DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spawn& sp, const Snap& S, int base, int V,
                  int s, int e, uint32_t step_count, unsigned long long pmask, Veh& r, float& out_steer, float& out_acc) {
   const float NORMAL = 30.0f, CREEP = 5.0f, SAFE = 15.0f, MAXD = 30.0f;
@@ -461,7 +462,7 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
   for (unsigned long long m = pmask & ~(1ull << s); m != 0ull; m &= m - 1ull) {
     const int o = __builtin_ctzll(m);
     const Obb ob = snap_obb(S, base + o);
-    const bool in = S.present[base + o] && point_obb_dist(ob, px, py) <= 50.0f;
+    const bool in = S.present[base + o] && shape_point_dist<OBJ>(ob, px, py) <= 50.0f;
     objs |= in ? (1ull << o) : 0ull;
   }
 
@@ -612,7 +613,7 @@ DEV void reset_vehicle(const pgd_spawn& p, Veh& r, int spawn_index, bool is_agen
   r.rlane = is_agent ? 0 : -1;  // agents: episode length; traffic: IDMPolicy.routing_target_lane = None
   r.hx = 1.0f;
   if (p.lane < 0) { r.status = ST_EMPTY; return; }
-  r.status = p.group < 0 ? ST_ACTIVE : ST_PENDING;
+  r.status = p.group == -1 ? ST_ACTIVE : ST_PENDING;  // PGD_GROUP_NEVER (-2): in the world, never driven
   r.x = p.x; r.y = p.y; r.th = p.heading;
   r.lastx = p.x; r.lasty = p.y;
   sincosf(p.heading, &r.lasthy, &r.lasthx);
@@ -641,21 +642,24 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
   float reward = g.driving_reward * (l1 - l0) * lateral_factor * positive;
   reward += g.speed_reward * (speed_kmh(r.v) / sp.max_speed) * positive;
   unsigned out = vf & (PGD_F_ON_YELLOW | PGD_F_ON_WHITE | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OFF_LANE |
-                       PGD_F_OUT_OF_ROUTE | PGD_F_CRASH_VEHICLE);
+                       PGD_F_OUT_OF_ROUTE | PGD_F_CRASH_VEHICLE | PGD_F_CRASH_OBJECT);
   const pgd_lane& fl = mv.lanes[sp.dest_lane];
   float lon, lat;
   lane_local(fl, r.x, r.y, lon, lat);
   bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - ctx.cur_n) * w);
   bool oor = (vf & (PGD_F_ON_YELLOW | PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK)) != 0;
   if (g.out_of_route_done) oor = oor || (vf & PGD_F_OUT_OF_ROUTE);
-  bool crash = (vf & PGD_F_CRASH_VEHICLE) != 0;
+  bool crash = (vf & PGD_F_CRASH_VEHICLE) != 0, crash_obj = (vf & PGD_F_CRASH_OBJECT) != 0;
   if (arrive) out |= PGD_F_ARRIVE;
   if (oor) out |= PGD_F_OUT_OF_ROAD;
   if (arrive) reward = g.success_reward;
   else if (oor) reward = -g.out_of_road_penalty;
   else if (crash) reward = -g.crash_vehicle_penalty;
+  else if (crash_obj) reward = -g.crash_object_penalty;
   flags_out = out;
-  done_out = arrive || oor || crash;
+  done_out = arrive || oor || crash || crash_obj;
+  // SafePGDriveEnv.done_function (safe_pgdrive_env.py:49-56): a step with crash_vehicle, else crash_object, is not terminal
+  if (g.safe_rl_env && (crash || crash_obj)) done_out = false;
   return reward;
 }
 
@@ -727,9 +731,10 @@ DEV float ray_grid(const MapView& mv, float px, float py, float dx, float dy, un
   return best;
 }
 
-struct ObsLds {  // vehicles inside the lidar broad phase of the observing agent, compacted
-  float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV], bdist[MAXV];
-  int n;
+struct ObsLds {  // bodies inside the lidar broad phase of the observing agent, compacted
+  float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV];
+  float bdist[MAXV];  // centre distance; +inf for traffic objects, which are never ranked as neighbour vehicles
+  int n, nveh;
 };
 struct AgentView {  // what the observation needs from the observing vehicle
   float x, y, th, hx, hy, dl, dr, v, steer, a0s, a0t, lhx, lhy;
@@ -737,19 +742,22 @@ struct AgentView {  // what the observation needs from the observing vehicle
 };
 
 // one wave compacts the candidates: lane `o` brings vehicle o of the env (present = in the physics world)
-DEV void obs_compact(ObsLds& L, int o, int a, bool present, float x, float y, float ux, float uy, float hl, float hw,
-                     float spd, float px, float py, float R) {
-  bool in = present && o != a && point_obb_dist(Obb{x, y, ux, uy, hl, hw}, px, py) <= R;
-  unsigned long long m = __ballot(in);
+template <bool OBJ>
+DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, float x, float y, float ux, float uy, float hl,
+                     float hw, float spd, float px, float py, float R) {
+  if (!OBJ) is_vehicle = true;
+  bool in = present && o != a && shape_point_dist<OBJ>(Obb{x, y, ux, uy, hl, hw}, px, py) <= R;
+  unsigned long long m = __ballot(in), mv_ = OBJ ? __ballot(in && is_vehicle) : m;
   if (in) {
     int k = __popcll(m & ((1ull << o) - 1ull));
     L.bx[k] = x; L.by[k] = y; L.bux[k] = ux; L.buy[k] = uy; L.bhl[k] = hl; L.bhw[k] = hw; L.bspd[k] = spd;
-    L.bdist[k] = norm2(px - x, py - y);
+    L.bdist[k] = is_vehicle ? norm2(px - x, py - y) : __builtin_inff();
   }
-  if (o == 0) L.n = __popcll(m);
+  if (o == 0) { L.n = __popcll(m); L.nveh = __popcll(mv_); }
 }
 
 // writes the D floats of one agent's row with `nt` cooperating threads (tid in [0, nt))
+template <bool OBJ>
 DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const AgentView& ag, const ObsLds& L,
                        float* __restrict__ row, int tid, int nt) {
   const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
@@ -807,13 +815,14 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   // get_surrounding_vehicles_info (lidar.py:55-77): rank by centre distance (stable), 4 floats per neighbour; the last
   // threads take this part so that it overlaps the state block of the first ones
   const int NO = d.cfg.num_others;
-  const int n = L.n;
-  for (int k = nt - 1 - tid; k < (n > NO ? n : NO); k += nt) {
+  const int n = L.n, nveh = OBJ ? L.nveh : n;
+  // with objects: indices [0, n) are the compacted bodies, [n, n + NO) the rank rows to zero-fill; without: [0, max(n, NO))
+  for (int k = nt - 1 - tid; k < (OBJ ? n + NO : (n > NO ? n : NO)); k += nt) {
     if (k < n) {
       int rank = 0;
       float dk = L.bdist[k];
       for (int j = 0; j < n; ++j) rank += (L.bdist[j] < dk || (L.bdist[j] == dk && j < k)) ? 1 : 0;
-      if (rank < NO) {
+      if (rank < NO && dk < __builtin_inff()) {
         float ph, ps;
         float ms = sp.max_speed;
         float sp_me = speed_kmh(ag.v);
@@ -825,8 +834,8 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
         o[2] = clipf((ph / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
         o[3] = clipf((ps / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
       }
-    } else {  // k in [n, NO): absent neighbour -> zeros
-      float* o = row + o_oth + k * 4;
+    } else if (!OBJ || k - n >= nveh) {  // ranks [nveh, NO): absent neighbour -> zeros
+      float* o = row + o_oth + (OBJ ? k - n : k) * 4;
       o[0] = o[1] = o[2] = o[3] = 0.0f;
     }
   }
@@ -840,7 +849,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
     float dx = R * cs, dy = R * sn;
     float best = 1.0f;
     for (int k = 0; k < n; ++k)
-      best = fminf(best, ray_obb(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
+      best = fminf(best, shape_ray<OBJ>(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
     row[o_oth + 4 * NO + i] = best;
   }
   PHASE_MARK(24);  // obs: lidar
@@ -885,7 +894,8 @@ extern __shared__ __align__(16) unsigned char s_dyn[];  // [lanes | roads] of th
 // scenario, the map view (7 table pointers) and the env counters are then wave-uniform and live in SGPRs instead of
 // occupying ~20 VGPRs per lane for the whole kernel.
 // MARL (multi-agent tail: delay-done, respawn, __all__) is compiled in only for the multi-agent engine.
-template <bool ONE_ENV, bool MARL>
+// OBJ: traffic objects present in some scenario (circle shapes, crash_object bookkeeping).
+template <bool ONE_ENV, bool MARL, bool OBJ>
 __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
                                                 float* __restrict__ obs) {
@@ -895,6 +905,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   __shared__ int s_flag[WAVE];
   __shared__ int s_hit[WAVE];  // per snapshot slot: an agent's chassis overlaps another vehicle
   __shared__ int s_pf[WAVE];   // landing zone of the warm-up loads
+  __shared__ int s_kind[WAVE]; // PGD_OBJ_* of every slot (fused observation: objects are lidar targets, not neighbours)
   const int V = d.V, A = d.A, N = d.N;
   const int lane = threadIdx.x;
   const LaneMap lm = lane_map(d, blockIdx.x, N);
@@ -991,7 +1002,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (leader) {
       S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
       S.spd[slot] = speed_kmh(r.v);
-      S.hl[slot] = 0.5f * sp->length; S.hw[slot] = 0.5f * sp->width;
+      const int kind = OBJ ? (int)sp->kind : PGD_OBJ_VEHICLE;
+      if (OBJ) s_kind[slot] = kind;
+      S.hl[slot] = 0.5f * sp->length; S.hw[slot] = kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * sp->width;
       S.lane[slot] = r.lane;
       const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
       S.present[slot] = present ? 1 : 0;
@@ -1024,11 +1037,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         tb = tb * (2.0f / (float)(d.cfg.discrete_throttle_dim - 1)) - 1.0f;
       }
     } else {
-      idm_act(d, mv, g, *sp, S, base, V, s, e, steps_total, pmask, r, st, tb);
+      idm_act<OBJ>(d, mv, g, *sp, S, base, V, s, e, steps_total, pmask, r, st, tb);
     }
     PHASE_MARK(2);  // policy (IDM)
     // (3) BaseVehicle.before_step (base_vehicle.py:238-253)
-    r.vflags &= ~PGD_F_CRASH_VEHICLE;
+    r.vflags &= ~(PGD_F_CRASH_VEHICLE | PGD_F_CRASH_OBJECT);
     r.lastx = r.x; r.lasty = r.y;
     r.lasthx = r.hx; r.lasthy = r.hy;
     r.a0s = r.a1s; r.a0t = r.a1t;
@@ -1045,13 +1058,33 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   __syncthreads();
   // (5) vehicle-vehicle contacts on the post-physics poses (collision_callback.py:7-36): every body in the world tests
   // itself against each agent of its env, so the A x V pair tests run in parallel lanes
-  if (valid && leader && S.present[slot]) {
-    Obb me = snap_obb(S, slot);
-    for (int a = 0; a < A; ++a)
-      if (a != s && obb_overlap(snap_obb(S, base + a), me)) s_hit[base + a] = 1;
+  if (!OBJ) {
+    if (valid && leader && S.present[slot]) {
+      Obb me = snap_obb(S, slot);
+      for (int a = 0; a < A; ++a)
+        if (a != s && obb_overlap(snap_obb(S, base + a), me)) s_hit[base + a] = 1;
+    }
+  } else {
+    const int my_kind = valid ? s_kind[slot] : PGD_OBJ_VEHICLE;
+    if (valid && S.present[slot] && (leader || my_kind != PGD_OBJ_VEHICLE)) {  // object sub-lanes all keep their copy of the bit
+      const Obb me = snap_obb(S, slot);
+      const int kind = my_kind;
+      // a traffic object reports only its first contact (TrafficObject.crashed / COST_ONCE, collision_callback.py:27-32)
+      const bool live = kind == PGD_OBJ_VEHICLE || !(r.vflags & (int)PGD_F_OBJECT_HIT);
+      bool touched = false;
+      for (int a = 0; a < A; ++a)
+        if (a != s && S.present[base + a] && shape_overlap<true>(snap_obb(S, base + a), me)) {
+          touched = true;
+          if (leader && live) atomicOr(&s_hit[base + a], kind == PGD_OBJ_VEHICLE ? 1 : 2);
+        }
+      if (touched && kind != PGD_OBJ_VEHICLE) r.vflags |= (int)PGD_F_OBJECT_HIT;  // every sub-lane keeps its copy in step
+    }
   }
   __syncthreads();
-  if (acting && s < A && s_hit[slot]) r.vflags |= PGD_F_CRASH_VEHICLE;
+  if (acting && s < A) {
+    if (s_hit[slot] & 1) r.vflags |= PGD_F_CRASH_VEHICLE;
+    if (OBJ && (s_hit[slot] & 2)) r.vflags |= PGD_F_CRASH_OBJECT;
+  }
   PHASE_MARK(4);  // crash
   // (6) after_step; traffic off the lanes is removed (traffic_manager.py:91-109)
   if (acting) {
@@ -1211,7 +1244,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
       S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
       S.spd[slot] = r.status == ST_DYING ? 0.0f : speed_kmh(r.v);
-      S.hl[slot] = 0.5f * sp->length; S.hw[slot] = 0.5f * sp->width;  // the scenario may have changed on reset
+      S.hl[slot] = 0.5f * sp->length;  // the scenario may have changed on reset
+      S.hw[slot] = (OBJ && sp->kind == PGD_OBJ_CYLINDER) ? -1.0f : 0.5f * sp->width;
+      if (OBJ) s_kind[slot] = sp->kind;
       S.present[slot] = present ? 1 : 0;
       if (s < A) {
         AgentView& ag = s_ag[s];
@@ -1228,11 +1263,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     for (int a = 0; a < A; ++a) {
       const AgentView ag = s_ag[a];
       const bool have = lane < V && d.cfg.num_lasers > 0;
-      obs_compact(OL, lane, a, have && S.present[lane], S.x[lane], S.y[lane], S.ux[lane], S.uy[lane], S.hl[lane], S.hw[lane],
-                  S.spd[lane], ag.x, ag.y, d.cfg.lidar_dist);
+      obs_compact<OBJ>(OL, lane, a, have && S.present[lane], OBJ ? (have && s_kind[lane] == PGD_OBJ_VEHICLE) : true, S.x[lane], S.y[lane],
+                  S.ux[lane], S.uy[lane], S.hl[lane], S.hw[lane], S.spd[lane], ag.x, ag.y, d.cfg.lidar_dist);
       __syncthreads();
       PHASE_MARK(21);  // obs: compaction
-      observe_agent(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + ((size_t)blockIdx.x * A + a) * d.D, lane,
+      observe_agent<OBJ>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + ((size_t)blockIdx.x * A + a) * d.D, lane,
                     WAVE);
       __syncthreads();
     }
@@ -1320,7 +1355,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
   const int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
   const pgd_spawn* spb = d.spawns + (size_t)scen * d.sstride;
   if (tid < WAVE) {  // wave 0: broad phase r = lidar distance (lidar.py:109-124), compacted into LDS
-    bool present = false;
+    bool present = false, is_vehicle = true;
     float x = 0, y = 0, ux = 1, uy = 0, hl = 0, hw = 0, spd = 0;
     if (tid < V && d.cfg.num_lasers > 0) {
       int st = recs[tid].i[SI_STATUS];
@@ -1342,17 +1377,18 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
       x = recs[tid].f[SF_X]; y = recs[tid].f[SF_Y];
       sincosf(recs[tid].f[SF_THETA], &uy, &ux);
       const pgd_spawn& so = spb[recs[tid].i[SI_SPAWN]];
-      hl = 0.5f * so.length; hw = 0.5f * so.width;
+      hl = 0.5f * so.length; hw = so.kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * so.width;
+      is_vehicle = so.kind == PGD_OBJ_VEHICLE;
       spd = still ? 0.0f : speed_kmh(recs[tid].f[SF_SPEED]);
     }
-    obs_compact(L, tid, a, present, x, y, ux, uy, hl, hw, spd, ag.x, ag.y, d.cfg.lidar_dist);
+    obs_compact<true>(L, tid, a, present, is_vehicle, x, y, ux, uy, hl, hw, spd, ag.x, ag.y, d.cfg.lidar_dist);
   }
   __syncthreads();
   MapView mv = map_view_of(d, d.scen_map + scen);
   const pgd_spawn& msp = spb[mine.i[SI_SPAWN]];
   const RouteCtx ctx = route_ctx(mv, msp, mine.i[SI_CK0], mine.i[SI_CK1]);
   ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
-  observe_agent(d, mv, msp, ag, L, row, tid, BLOCK);
+  observe_agent<true>(d, mv, msp, ag, L, row, tid, BLOCK);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1378,6 +1414,7 @@ struct pgd_engine {
   std::vector<hipEvent_t>* prof_ev;  // 3 events per recorded step
   int prof_cap, prof_n, prof_stride, prof_tick;
   bool prof_grouped;
+  bool has_objects;  // some spawn record is a traffic object (pgd_upload_scenarios): selects the OBJ kernels
   bool step_timing;  // record ev0 / ev1 around every step (pgd_last_step_ms)
   bool no_fuse;      // PGD_NO_FUSE was set when the engine was created (debug: always run the stand-alone k_observe)
   bool prof_fused;
@@ -1531,6 +1568,9 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   if ((rc = upload(&h->scen, scen, n_scen, h->stream))) return rc;
   if ((rc = upload(&h->spawns, spawns, (size_t)n_scen * h->d.sstride, h->stream))) return rc;
   h->d.scen = h->scen; h->d.spawns = h->spawns; h->d.n_scen = n_scen;
+  h->has_objects = false;
+  for (size_t k = 0; k < (size_t)n_scen * h->d.sstride; ++k)
+    if (spawns[k].lane >= 0 && spawns[k].kind != PGD_OBJ_VEHICLE) { h->has_objects = true; break; }
   if (!h->h_scen) h->h_scen = new std::vector<pgd_scenario>();
   h->h_scen->assign(scen, scen + n_scen);
   if ((rc = build_scen_map(h))) return rc;
@@ -1589,9 +1629,10 @@ int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward
   if (prof || timing || g_open) HIPCHK(hipEventRecord((prof || g_open) ? pe[0] : h->ev0, h->stream));
   int blocks = (h->d.N + h->d.epw - 1) / h->d.epw;
   if (marl && h->d.epw != 1) return PGD_ERR_STATE;  // the multi-agent tail needs the env in one wave (V >= 33 or SUB split)
-  void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*) = k_step<false, false>;
-  if (marl) kern = k_step<true, true>;
-  else if (h->d.epw == 1) kern = k_step<true, false>;
+  void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*) = k_step<false, false, false>;
+  if (marl) kern = k_step<true, true, false>;  // (no traffic objects on the multi-agent maps)
+  else if (h->d.epw == 1) kern = h->has_objects ? k_step<true, false, true> : k_step<true, false, false>;
+  else if (h->has_objects) kern = k_step<false, false, true>;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), (size_t)h->d.lds_bytes, h->stream, h->d, d_actions, d_reward, d_done,
                      d_flags, fuse ? d_obs : (float*)nullptr);
   HIPCHK(hipGetLastError());

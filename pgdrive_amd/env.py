@@ -62,13 +62,8 @@ class PGDriveEnv:
         self.episode_reward += r
         fl = int(flags[0].item()) & 0xFFFFFFFF
         f, i, _ = self.vec.engine.get_state()
-        info = {k: bool(v) for k, v in self.vec.info_from_flags(np.array([fl])).items()}
         info = {k: bool(np.asarray(v).reshape(-1)[0]) for k, v in self.vec.info_from_flags(np.array([fl])).items()}
-        cost = 0.0  # cost_function (pgdrive_env.py:197-207)
-        if info["out_of_road"]:
-            cost = 1.0
-        elif info["crash_vehicle"]:
-            cost = 1.0
+        cost = float(self.vec.cost_from_flags(np.array([fl]))[0])  # cost_function (pgdrive_env.py:197-207)
         info.update(
             cost=cost, velocity=float(f[_abi.SF["SPEED"], 0, 0] * 3.6), steering=float(f[_abi.SF["STEER"], 0, 0]),
             acceleration=float(f[_abi.SF["THROTTLE"], 0, 0]), step_reward=r, episode_reward=self.episode_reward,
@@ -81,6 +76,37 @@ class PGDriveEnv:
 
     def close(self):
         self.vec.close()
+
+
+class SafePGDriveEnv(PGDriveEnv):
+    """pgdrive/envs/safe_pgdrive_env.py:7-60: accident scenes (traffic cones, broken-down vehicles with warning tripods,
+    barriers; manager/object_manager.py) on the Straight / Curve / ramp blocks, crashes are costs instead of
+    terminations, `info["total_cost"]` accumulates over the episode."""
+    DEFAULTS = dict(environment_num=100, accident_prob=0.8, traffic_density=0.05, safe_rl_env=True, crash_vehicle_cost=1.0,
+                    crash_object_cost=1.0, out_of_road_cost=1.0, use_lateral=False)
+
+    def __init__(self, config=None):
+        cfg = dict(self.DEFAULTS)
+        user = dict(config or {})
+        cost_to_reward = user.pop("cost_to_reward", False)
+        cfg.update(user)
+        if cost_to_reward:  # _post_process_config (safe_pgdrive_env.py:41-47)
+            from .vec_env import DEFAULT_CONFIG
+            for pen, cost in (("crash_vehicle_penalty", "crash_vehicle_cost"), ("crash_object_penalty", "crash_object_cost"),
+                              ("out_of_road_penalty", "out_of_road_cost")):
+                cfg[pen] = cfg.get(pen, DEFAULT_CONFIG[pen]) + cfg[cost]
+        super().__init__(cfg)
+        self.episode_cost = 0.0
+
+    def reset(self, *args, **kwargs):
+        self.episode_cost = 0.0
+        return super().reset(*args, **kwargs)
+
+    def step(self, action):
+        o, r, d, info = super().step(action)
+        self.episode_cost += info["cost"]
+        info["total_cost"] = self.episode_cost
+        return o, r, d, info
 
 
 def make(env_id, **kw):

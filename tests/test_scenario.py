@@ -122,3 +122,36 @@ def test_respawn_mode_and_auto_termination_scenarios(descs):
     import pytest
     with pytest.raises(ValueError):
         scenario.build_scenario(d, 0, d["seed"], 1, 16, 0.1, traffic_mode="nope")
+
+
+def test_object_proposals_match_reference_manager():
+    """TrafficObjectManager.reset (object_manager.py:40-124) run on the reference's block objects with a recording
+    spawn_object (oracle/gen_golden.py:gen_objects): same scenes, lanes, longitudes, laterals, world positions; the
+    traffic manager that follows skips the accident lanes and has its type stream advanced by the broken-down vehicles."""
+    from pgdrive_amd import mapgen
+    with open(os.path.join(GOLD, "objects_v0.json")) as f:
+        cases = json.load(f)["cases"]
+    cls_name = dict(cone="TrafficCone", warning="TrafficWarning", barrier="TrafficBarrier")
+    n_obj = n_veh = 0
+    for c in cases:
+        d = mapgen.generate_map(c["seed"], **c["kw"])
+        objs, acc, n_draws = scenario.propose_objects(d, c["seed"], c["prob"])
+        assert acc == c["accident_lanes"]
+        assert len(objs) == len(c["objects"])
+        res = scenario.propose_traffic(d, c["seed"], 0.2, skip_lanes=set(acc), type_draws=n_draws)
+        groups, pre_types = res if n_draws else (res, [])
+        for o, r in zip(objs, c["objects"]):
+            assert o["lane"] == r[1] and abs(o["long"] - r[2]) < 1e-9 and abs(o["lat"] - r[3]) < 1e-9
+            if o["cls"] == "vehicle":
+                assert r[0] == "vehicle" and pre_types[o["type_draw"]] == r[4]
+                n_veh += 1
+            else:
+                assert cls_name[o["cls"]] == r[0]
+                L = d["lanes"][o["lane"]]
+                x, y = mapdata.lane_position(L, o["long"], o["lat"])
+                assert abs(x - r[4]) < 1e-9 and abs(y - r[5]) < 1e-9
+                assert abs(mapdata.lane_heading_at(L, o["long"]) - r[6]) < 1e-12
+            n_obj += 1
+        mine = [[[v["lane"], v["long"], v["vtype"], v["policy_seed"]] for v in g["vehicles"]] for g in groups]
+        assert mine == c["traffic_0_2"]
+    assert n_obj > 250 and n_veh >= 3
