@@ -187,6 +187,10 @@ typedef struct pgd_config {
 #define PGD_MA_CRASH_DONE     2  /* crash_done       (multi_agent_pgdrive.py:21) */
 #define PGD_MA_OUT_ROAD_DONE  4  /* out_of_road_done (multi_agent_pgdrive.py:22) */
 #define PGD_MA_ALLOW_RESPAWN  8  /* allow_respawn    (multi_agent_pgdrive.py:26) */
+#define PGD_MA_PLAIN_REWARD  16  /* MultiAgentBottleneckEnv.reward_function (marl_bottleneck.py:91-128): no -1 factor on a
+                                    negative road when the vehicle is off its reference lanes */
+#define PGD_MA_YELLOW_OK     32  /* cross_yellow_line_done = False (marl_bottleneck.py:130-136): a yellow line is not
+                                    out-of-road */
 
 typedef struct pgd_engine* pgd_handle;
 

@@ -61,6 +61,18 @@ def main_marl():
     print("wrote", out, os.path.getsize(out))
 
 
+def main_marl_bottleneck():
+    """MABottleneckMap (envs/marl_envs/marl_bottleneck.py:28-67) -> tests/golden/ma_bottleneck_v0.json.gz (+ boxes)"""
+    root = os.path.dirname(HERE)
+    m = ref_export.generate_ma_bottleneck()
+    np.savez_compressed(os.path.join(root, "tests", "golden", "boxes_ma_bottleneck.npz"), boxes=m["boxes"])
+    out = os.path.join(root, "tests", "golden", "ma_bottleneck_v0.json.gz")
+    with gzip.GzipFile(out, "wb", mtime=0) as f:
+        f.write(json.dumps(dict(version=0, source="decisionforce/pgdrive v0.1.4 MABottleneckMap (4 lanes, neck 1 lane x 20 m)",
+                                maps=[strip(m)]), separators=(",", ":")).encode())
+    print("wrote", out, os.path.getsize(out))
+
+
 def main_mapgen_goldens():
     """Extra goldens for pgdrive_amd/mapgen.py beyond the 100-seed bank: other block counts, lane counts / widths and
     explicit block sequences through every block type -> tests/golden/mapgen_v0.json.gz"""
@@ -81,7 +93,9 @@ def main_mapgen_goldens():
 
 
 if __name__ == "__main__":
-    if "--marl" in sys.argv:
+    if "--bottleneck" in sys.argv:
+        main_marl_bottleneck()
+    elif "--marl" in sys.argv:
         main_marl()
     elif "--mapgen" in sys.argv:
         main_mapgen_goldens()

@@ -89,6 +89,20 @@ def generate_ma_roundabout(lane_num=2, lane_width=3.5, exit_length=60):
     return generate(0, lane_num, lane_width, exit_length, prebuilt=(net, _Blocks([first, rb])))
 
 
+def generate_ma_bottleneck(lane_width=3.5, exit_length=60, bottle_lane_num=4, neck_lane_num=1, neck_length=20):
+    """MABottleneckMap._generate (envs/marl_envs/marl_bottleneck.py:28-67)."""
+    from pgdrive.component.blocks.bottleneck import Merge, Split
+    from pgdrive.component.blocks.first_block import FirstPGBlock
+    net = RoadNetwork()
+    pw = refstub.FakePhysicsWorld()
+    first = FirstPGBlock(net, lane_width, bottle_lane_num, None, pw, length=exit_length)
+    merge = Merge(1, first.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    assert merge.construct_from_config(dict(lane_num=bottle_lane_num - neck_lane_num, length=neck_length), None, pw)
+    split = Split(2, merge.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    assert split.construct_from_config({"length": exit_length, "lane_num": bottle_lane_num - neck_lane_num}, None, pw)
+    return generate(0, bottle_lane_num, lane_width, exit_length, prebuilt=(net, _Blocks([first, merge, split])))
+
+
 def generate_ma_intersection(lane_num=2, lane_width=3.5, exit_length=60):
     """MAIntersectionMap._generate (envs/marl_envs/marl_intersection.py:29-54): first block + one intersection with
     u-turns, exit parts as long as the entrance road."""

@@ -25,7 +25,7 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
                 out_of_road_done=True, allow_respawn=True, delay_done=25, agent_limit=0, respawn_places=0,
                 respawn_dests=0, side_lasers=0, side_dist=50.0, lane_line_lasers=0, lane_line_dist=20.0,
                 discrete_action=False, discrete_steering_dim=5, discrete_throttle_dim=5, increment_steering=False,
-                safe_rl_env=False):
+                safe_rl_env=False, plain_reward=False, cross_yellow_line_done=True):
     """Defaults mirror PGDriveEnv_DEFAULT_CONFIG / BASE_DEFAULT_CONFIG (pgdrive_env.py:22-109, base_env.py:19-90)."""
     c = PgdConfig()
     c.num_envs, c.num_agents, c.num_traffic = num_envs, num_agents, num_traffic
@@ -43,7 +43,8 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
     c.safe_rl_env = int(bool(safe_rl_env))
     if multi_agent:
         c.marl_flags = MA_ENABLED | (MA_CRASH_DONE if crash_done else 0) | (MA_OUT_ROAD_DONE if out_of_road_done else 0) | \
-            (MA_ALLOW_RESPAWN if allow_respawn else 0)
+            (MA_ALLOW_RESPAWN if allow_respawn else 0) | (MA_PLAIN_REWARD if plain_reward else 0) | \
+            (0 if cross_yellow_line_done else MA_YELLOW_OK)
         c.delay_done, c.agent_limit = int(delay_done), int(agent_limit or num_agents)
         c.respawn_places, c.respawn_dests = int(respawn_places), int(respawn_dests)
     return c
@@ -61,7 +62,7 @@ SI = dict(STATUS=0, LANE=1, CK0=2, CK1=3, RLANE=4, TIMER=5, VFLAGS=6, SPAWN=7)
 EI = dict(SCEN=0, NEXT_GROUP=1, EP_STEPS=2, EPISODES=3, STEPS_TOTAL=4, NEXT_AGENT=5)
 NF, NI, NEI = 24, 8, 8
 ST_EMPTY, ST_PENDING, ST_ACTIVE, ST_REMOVED, ST_DYING = 0, 1, 2, 3, 4
-MA_ENABLED, MA_CRASH_DONE, MA_OUT_ROAD_DONE, MA_ALLOW_RESPAWN = 1, 2, 4, 8
+MA_ENABLED, MA_CRASH_DONE, MA_OUT_ROAD_DONE, MA_ALLOW_RESPAWN, MA_PLAIN_REWARD, MA_YELLOW_OK = 1, 2, 4, 8, 16, 32
 
 F_ARRIVE, F_OUT_OF_ROAD, F_CRASH_VEHICLE, F_CRASH_OBJECT, F_CRASH_BUILDING, F_MAX_STEP = 1, 2, 4, 8, 16, 32
 F_ON_YELLOW, F_ON_WHITE, F_ON_BROKEN, F_CRASH_SIDEWALK, F_OFF_LANE, F_OUT_OF_ROUTE = 256, 512, 1024, 2048, 4096, 8192

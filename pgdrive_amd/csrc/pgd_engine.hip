@@ -633,7 +633,7 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
   const pgd_lane& VL = mv.lanes[r.lane];
   bool in_ref = VL.road == ctx.road_cur;
   const pgd_lane& cl = in_ref ? VL : mv.lanes[ctx.cur_first];
-  float positive = in_ref ? 1.0f : (mv.roads[VL.road].negative ? -1.0f : 1.0f);
+  float positive = (in_ref || (g.marl_flags & PGD_MA_PLAIN_REWARD)) ? 1.0f : (mv.roads[VL.road].negative ? -1.0f : 1.0f);
   float l0, t0, l1, t1;
   lane_local(cl, r.lastx, r.lasty, l0, t0);
   lane_local(cl, r.x, r.y, l1, t1);
@@ -647,7 +647,10 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
   float lon, lat;
   lane_local(fl, r.x, r.y, lon, lat);
   bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - ctx.cur_n) * w);
-  bool oor = (vf & (PGD_F_ON_YELLOW | PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK)) != 0;
+  const unsigned oor_bits = (g.marl_flags & PGD_MA_YELLOW_OK)
+                                ? (PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK)
+                                : (PGD_F_ON_YELLOW | PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK);
+  bool oor = (vf & oor_bits) != 0;
   if (g.out_of_route_done) oor = oor || (vf & PGD_F_OUT_OF_ROUTE);
   bool crash = (vf & PGD_F_CRASH_VEHICLE) != 0, crash_obj = (vf & PGD_F_CRASH_OBJECT) != 0;
   if (arrive) out |= PGD_F_ARRIVE;

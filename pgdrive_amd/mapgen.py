@@ -289,6 +289,20 @@ def create_bend_straight(prev, following_len, radius, angle, clockwise=True, wid
     return bend, straight
 
 
+def create_wave_lanes(pre_lane, lateral_dist, wave_length, last_straight_length, lane_width, toward_left=True):
+    """create_wave_lanes (create_block_utils.py:308-329): two opposite arcs that shift a lane sideways by `lateral_dist`
+    over `wave_length`, followed by a straight lane."""
+    angle = np.pi - 2 * np.arctan(wave_length / (2 * lateral_dist))
+    radius = wave_length / (2 * math.sin(angle))
+    c1, pre = create_bend_straight(pre_lane, 10, radius, angle, False if toward_left else True, lane_width, [NONE, NONE])
+    s, e = pre.position(-10, 0), pre.position(pre.length - 10, 0)
+    pre.start, pre.end = np.array(s, dtype=np.float64), np.array(e, dtype=np.float64)  # reset_start_end
+    pre.update_properties()
+    c2, straight = create_bend_straight(pre, last_straight_length, radius, angle, True if toward_left else False,
+                                        lane_width, [NONE, NONE])
+    return c1, c2, straight
+
+
 def extend_straight(lane, extend_length, line_types):
     new = copy.deepcopy(lane)
     new.start = lane.end
@@ -381,6 +395,8 @@ SPACES = {
     "r": {"length": ("box", 20, 40)},
     "R": {"length": ("box", 20, 40)},
     "I": {},
+    "y": {"length": ("box", 20, 50), "lane_num": ("disc", 1, 2), "bottle_len": ("const", 20)},  # BOTTLENECK_PARAMETER
+    "Y": {"length": ("box", 20, 50), "lane_num": ("disc", 1, 2), "bottle_len": ("const", 20)},
 }
 
 
@@ -884,6 +900,81 @@ class Roundabout(Block):
 
 
 # BLOCK_TYPE_DISTRIBUTION_V2 in dict order (blocks_prob_dist.py:31-49); zero-probability types keep their slot
+class Merge(Block):
+    """bottleneck.py:21-161: the outer `lane_num` lanes of each direction bend into the remaining straight ones."""
+    ID = "y"
+
+    def build(self):
+        p = self.config
+        L, changed = p["bottle_len"], p["lane_num"]
+        start = self.pre_socket.pos[1]
+        straight_n = max(1, int(self.pos_lane_num - changed))
+        none3 = dict(center_line_type=NONE, inner_type=NONE)
+        ref = extend_straight(self.pos_lanes[straight_n - 1], L, [NONE, NONE])
+        sroad = (start, self.node(0, 0))
+        ok = self.rf(ref, straight_n, sroad, center_line_type=CONTINUOUS, side_type=NONE, inner_type=NONE)
+        ok = self.ar(sroad, inner_type=NONE, side_type=NONE, center_line_type=CONTINUOUS) and ok
+        ref = extend_straight(ref, p["length"], [NONE, NONE])
+        sock = (self.node(0, 0), self.node(0, 1))
+        ok = self.rf(ref, straight_n, sock, center_line_type=CONTINUOUS, side_type=SIDE, inner_type=BROKEN) and ok
+        ok = self.ar(sock, inner_type=BROKEN, side_type=SIDE, center_line_type=CONTINUOUS) and ok
+        self.add_socket(Socket(sock, neg(sock)))
+        for index, lane in enumerate(self.pos_lanes[straight_n:], 1):
+            lat = index * self.lane_width / 2
+            inner = self.node(1, index)
+            side_t = SIDE if index == self.pos_lane_num - straight_n else NONE
+            c1, c2, _ = create_wave_lanes(lane, lat, L, 5, self.lane_width)
+            r1, r2 = (start, inner), (inner, self.node(0, 0))
+            ok = self.rf(c1, 1, r1, side_type=side_t, **none3) and ok
+            ok = self.rf(c2, 1, r2, side_type=side_t, **none3) and ok
+            lane2 = self.net.lanes(neg(sock))[-1]
+            c2b, c1b, _ = create_wave_lanes(lane2, lat, L, 5, self.lane_width, False)
+            ok = self.rf(c2b, 1, neg(r2), side_type=side_t, **none3) and ok
+            ok = self.rf(c1b, 1, neg(r1), side_type=side_t, **none3) and ok
+        return ok
+
+
+class Split(Block):
+    """bottleneck.py:164-311: `lane_num` extra lanes fan out on each side after the neck."""
+    ID = "Y"
+
+    def build(self):
+        p = self.config
+        L, circ_n = p["bottle_len"], p["lane_num"]
+        start = self.pre_socket.pos[1]
+        straight_n = self.pos_lane_num
+        total = straight_n + circ_n
+        none3 = dict(center_line_type=NONE, inner_type=NONE)
+        ref = extend_straight(self.pos_lanes[straight_n - 1], L, [NONE, NONE])
+        sroad = (start, self.node(0, 0))
+        ok = self.rf(ref, straight_n, sroad, center_line_type=CONTINUOUS, side_type=NONE, inner_type=NONE)
+        ok = self.ar(sroad, inner_type=NONE, side_type=NONE, center_line_type=CONTINUOUS) and ok
+        lane = self.pos_lanes[-1]
+        sock_ref = None
+        for index in range(1, circ_n + 1):
+            lat = index * self.lane_width / 2
+            inner = self.node(1, index)
+            side_t = SIDE if index == circ_n else NONE
+            c1, c2, straight = create_wave_lanes(lane, lat, L, p["length"], self.lane_width, False)
+            if index == circ_n:
+                sock_ref = straight
+            ok = self.rf(c1, 1, (start, inner), side_type=side_t, **none3) and ok
+            ok = self.rf(c2, 1, (inner, self.node(0, 0)), side_type=side_t, **none3) and ok
+        sock = (self.node(0, 0), self.node(0, 1))
+        ok = self.rf(sock_ref, total, sock, center_line_type=CONTINUOUS, side_type=SIDE, inner_type=BROKEN) and ok
+        ok = self.ar(sock, inner_type=BROKEN, side_type=SIDE, center_line_type=CONTINUOUS) and ok
+        self.add_socket(Socket(sock, neg(sock)))
+        lanes = self.net.lanes(neg(sock))
+        for index, lane in enumerate(lanes[self.pos_lane_num:], 1):
+            lat = index * self.lane_width / 2
+            inner = self.node(1, index)
+            side_t = SIDE if index == circ_n else NONE
+            c1, c2, _ = create_wave_lanes(lane, lat, L, 5, self.lane_width)
+            ok = self.rf(c1, 1, neg((inner, self.node(0, 0))), side_type=side_t, **none3) and ok
+            ok = self.rf(c2, 1, neg((start, inner)), side_type=side_t, **none3) and ok
+        return ok
+
+
 BLOCK_TYPES = [Curve, Straight, InRamp, OutRamp, Intersection, TIntersection, Roundabout, None, None, None, None, None, None]
 BLOCK_PROBS = [0.3, 0.1, 0.1, 0.1, 0.15, 0.15, 0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
 BY_ID = {c.ID: c for c in BLOCK_TYPES if c is not None}
@@ -993,6 +1084,18 @@ class FullIntersection(Intersection):
     """InterSection proper (intersection.py:15-238): the lane-count change of the crossing road is sampled, not forced to 0."""
     def build(self):
         return self.build_x()
+
+
+def generate_ma_bottleneck(lane_width=3.5, exit_length=60, bottle_lane_num=4, neck_lane_num=1, neck_length=20):
+    """MABottleneckMap._generate (envs/marl_envs/marl_bottleneck.py:28-67): 4-lane first block, Merge down to the neck,
+    Split back to 4 lanes."""
+    gnet = Net()
+    first = FirstBlock(gnet, lane_width, bottle_lane_num, exit_length)
+    merge = Merge(1, first.get_socket(0), gnet, 1)
+    assert merge.construct(extra_config=dict(lane_num=bottle_lane_num - neck_lane_num, length=neck_length))
+    split = Split(2, merge.get_socket(0), gnet, 1)
+    assert split.construct(extra_config=dict(length=exit_length, lane_num=bottle_lane_num - neck_lane_num))
+    return to_description(0, gnet, [first, merge, split], bottle_lane_num, lane_width, exit_length)
 
 
 def generate_ma_intersection(lane_num=2, lane_width=3.5, exit_length=60):

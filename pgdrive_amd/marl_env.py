@@ -28,7 +28,9 @@ MA_DEFAULT_CONFIG = dict(
     delay_done=25,
     allow_respawn=True,
     horizon=1000,
-    vehicle_config=dict(lidar=dict(num_lasers=72, distance=40, num_others=0)),
+    vehicle_config=dict(lidar=dict(num_lasers=72, distance=40, num_others=0),
+                        side_detector=dict(num_lasers=0, distance=50), lane_line_detector=dict(num_lasers=0, distance=20)),
+    cross_yellow_line_done=True,  # only read by the bottleneck env (marl_bottleneck.py:130-136)
     success_reward=10.0,
     out_of_road_penalty=10,
     crash_vehicle_penalty=10,
@@ -48,6 +50,7 @@ MA_DEFAULT_CONFIG = dict(
 class MultiAgentRoundaboutVecEnv:
     MAP_KIND = "roundabout"
     DEFAULTS = MA_DEFAULT_CONFIG
+    PLAIN_REWARD = False
 
     @staticmethod
     def _generate_map(mc):
@@ -57,6 +60,7 @@ class MultiAgentRoundaboutVecEnv:
     def __init__(self, config=None):
         self.config = c = merge_config(self.DEFAULTS, config)
         lid = c["vehicle_config"]["lidar"]
+        sd, ld = c["vehicle_config"]["side_detector"], c["vehicle_config"]["lane_line_detector"]
         if lid["num_others"] != 0:
             raise NotImplementedError("LidarStateObservationMARound with num_others > 0 is not built (reference default 0)")
         self.desc = self._generate_map(c["map_config"])
@@ -74,7 +78,10 @@ class MultiAgentRoundaboutVecEnv:
             driving_reward=c["driving_reward"], speed_reward=c["speed_reward"], use_lateral=c["use_lateral"],
             multi_agent=True, crash_done=c["crash_done"], out_of_road_done=c["out_of_road_done"],
             allow_respawn=c["allow_respawn"], delay_done=c["delay_done"], agent_limit=c["num_agents"],
-            respawn_places=self.scen_bank.P, respawn_dests=self.scen_bank.Dn
+            respawn_places=self.scen_bank.P, respawn_dests=self.scen_bank.Dn,
+            side_lasers=sd["num_lasers"] if sd["distance"] > 0 else 0, side_dist=sd["distance"],
+            lane_line_lasers=ld["num_lasers"] if ld["distance"] > 0 else 0, lane_line_dist=ld["distance"],
+            plain_reward=self.PLAIN_REWARD, cross_yellow_line_done=c["cross_yellow_line_done"]
         )
         from .engine import Engine
         self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])
@@ -111,6 +118,26 @@ class MultiAgentIntersectionVecEnv(MultiAgentRoundaboutVecEnv):
     def _generate_map(mc):
         from . import mapgen
         return mapgen.generate_ma_intersection(mc["lane_num"], mc["lane_width"], mc["exit_length"])
+
+
+class MultiAgentBottleneckVecEnv(MultiAgentRoundaboutVecEnv):
+    """MultiAgentBottleneckEnv (marl_bottleneck.py:11-137) batched: 4-lane road merging into a 1-lane neck and splitting
+    again, 20 agents, side (4 x 50 m) and lane-line (4 x 20 m) detector fans in the observation, its own reward / out-of-road
+    variants, destinations from Navigation's default rule."""
+    MAP_KIND = "bottleneck"
+    PLAIN_REWARD = True
+    DEFAULTS = dict(
+        MA_DEFAULT_CONFIG, num_agents=20,
+        map_config=dict(exit_length=60, lane_width=3.5, bottle_lane_num=4, neck_lane_num=1, neck_length=20),
+        vehicle_config=dict(lidar=dict(num_lasers=72, distance=40, num_others=0), side_detector=dict(num_lasers=4, distance=50),
+                            lane_line_detector=dict(num_lasers=4, distance=20)),
+    )
+
+    @staticmethod
+    def _generate_map(mc):
+        from . import mapgen
+        return mapgen.generate_ma_bottleneck(mc["lane_width"], mc["exit_length"], mc["bottle_lane_num"], mc["neck_lane_num"],
+                                             mc["neck_length"])
 
 
 class MultiAgentRoundaboutEnv:
@@ -187,3 +214,8 @@ class MultiAgentRoundaboutEnv:
 class MultiAgentIntersectionEnv(MultiAgentRoundaboutEnv):
     """Dict protocol on the intersection map (marl_intersection.py:65-109)."""
     VEC = MultiAgentIntersectionVecEnv
+
+
+class MultiAgentBottleneckEnv(MultiAgentRoundaboutEnv):
+    """Dict protocol on the bottleneck map (marl_bottleneck.py:70-137)."""
+    VEC = MultiAgentBottleneckVecEnv

@@ -462,7 +462,17 @@ def intersection_spawn_roads(desc):
     return roads
 
 
-MARL_SPAWN_ROADS = {"roundabout": roundabout_spawn_roads, "intersection": intersection_spawn_roads}
+def bottleneck_spawn_roads(desc):
+    """MABottleneckConfig.spawn_roads (marl_bottleneck.py:12): '>>'->'>>>' and the far end of the Split block, negated."""
+    n = desc["nodes"]
+    return [(n.index(">>"), n.index(">>>")), neg_road(desc, n.index("2Y0_0_"), n.index("2Y0_1_"))]
+
+
+MARL_SPAWN_ROADS = {"roundabout": roundabout_spawn_roads, "intersection": intersection_spawn_roads,
+                    "bottleneck": bottleneck_spawn_roads}
+# destination rule: the roundabout / intersection spawn managers draw a negated spawn road; the bottleneck env keeps the
+# default SpawnManager.update_destination_for (spawn_manager.py:221-225), i.e. Navigation.update's own choice
+MARL_AUTO_DEST = {"bottleneck"}
 
 
 def spawn_slots(desc, spawn_roads):
@@ -495,7 +505,13 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
     slots, safe = spawn_slots(desc, spawn_roads)
     if num_agents > len(slots):
         raise ValueError("Too many agents! We only accept %d agents" % len(slots))
-    dests = [neg_road(desc, *r)[1] for r in spawn_roads]  # end node of the negated spawn road
+    auto = kind in MARL_AUTO_DEST
+
+    def auto_dest(c):  # Navigation.update (navigation.py:99-121): last block's socket, first block's on a negative road
+        road = desc["roads"][desc["lanes"][c["lane"]]["road"]]
+        return choose_destination(desc, 0, road["frm"], negative=road["negative"])
+
+    dests = [None] if auto else [neg_road(desc, *r)[1] for r in spawn_roads]  # end node of the negated spawn road
     P, Dn = len(safe), len(dests)
     recs = np.zeros(A + P * Dn, dtype=SPAWN_DT)
     recs["lane"] = -1
@@ -508,13 +524,13 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
         lat = c["lat"] + rng.uniform(-la / 2, la / 2)
         params = sample_vehicle_params(vehicle_model, int(rng.randint(0, MAX_RAND_INT)))
         _fill_vehicle(recs[a], desc, c["lane"], lon, lat, params)
-        _fill_route(recs[a], desc, c["lane"], dests[int(rng.randint(0, Dn))])
+        _fill_route(recs[a], desc, c["lane"], auto_dest(c) if auto else dests[int(rng.randint(0, Dn))])
     for p, c in enumerate(safe):
         for dn, dest in enumerate(dests):
             r = recs[A + p * Dn + dn]
             params = sample_vehicle_params(vehicle_model, int(rng.randint(0, MAX_RAND_INT)))
             _fill_vehicle(r, desc, c["lane"], c["long"], c["lat"], params)
-            _fill_route(r, desc, c["lane"], dest)
+            _fill_route(r, desc, c["lane"], auto_dest(c) if auto else dest)
     scen = np.zeros((), dtype=SCEN_DT)
     scen["map"] = map_index
     scen["trigger_road"][:] = -1

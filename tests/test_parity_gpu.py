@@ -302,7 +302,7 @@ def test_empty_and_edge_slots(descs):
 
 
 @pytest.mark.parametrize("num_agents,capacity", [(8, 8), (12, 16), (40, 40)])
-def test_marl_roundabout_parity(num_agents, capacity, kind="roundabout"):
+def test_marl_roundabout_parity(num_agents, capacity, kind="roundabout", **cfg_kw):
     """BASELINE config 5: multi-agent roundabout (envs/marl_envs/marl_inout_roundabout.py) — per-agent done, delay-done
     queue, respawn into free 8 m x 3 m places, __all__, agent ids; teacher-forced against the oracle."""
     import torch
@@ -310,7 +310,7 @@ def test_marl_roundabout_parity(num_agents, capacity, kind="roundabout"):
     from pgdrive_amd.engine import Engine
     d, mb, sb = util.make_marl_banks(num_agents=num_agents, capacity=capacity, kind=kind)
     n_envs = 32
-    cfg = util.marl_config(n_envs, sb, horizon=120)  # short horizon so that the episode end / reset path is exercised
+    cfg = util.marl_config(n_envs, sb, horizon=120, **cfg_kw)  # short horizon so that the episode end / reset path is exercised
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
     ids = np.arange(n_envs) % 8
@@ -343,3 +343,10 @@ def test_marl_roundabout_parity(num_agents, capacity, kind="roundabout"):
 def test_marl_intersection_parity():
     """MultiAgentIntersectionEnv (envs/marl_envs/marl_intersection.py): 4-way intersection with u-turns, 30 agents."""
     test_marl_roundabout_parity(30, 30, kind="intersection")
+
+
+def test_marl_bottleneck_parity():
+    """MultiAgentBottleneckEnv (envs/marl_envs/marl_bottleneck.py): Merge / Split blocks, side + lane-line detector fans in
+    the multi-agent observation, plain reward, Navigation's own destinations."""
+    test_marl_roundabout_parity(20, 20, kind="bottleneck", side_lasers=4, side_dist=50.0, lane_line_lasers=4,
+                                lane_line_dist=20.0, plain_reward=True)

@@ -26,7 +26,8 @@ def round_state_f32(f):
 
 def make_marl_banks(num_agents=8, n_variants=8, seed=1, capacity=None, kind="roundabout"):
     from pgdrive_amd import mapgen
-    d = mapgen.generate_ma_roundabout() if kind == "roundabout" else mapgen.generate_ma_intersection()
+    d = dict(roundabout=mapgen.generate_ma_roundabout, intersection=mapgen.generate_ma_intersection,
+             bottleneck=mapgen.generate_ma_bottleneck)[kind]()
     mb = mapdata.MapBank([d])
     sb = scenario.MarlScenarioBank(d, num_agents=num_agents, capacity=capacity, n_variants=n_variants, seed=seed, kind=kind)
     return d, mb, sb
