@@ -106,6 +106,11 @@ def main():
     ap.add_argument("--lasers", type=int, default=240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="replicas only: skip the per-step RCCL gather")
+    ap.add_argument("--actions", default="uniform", choices=["uniform", "straight"],
+                    help="uniform(-1,1) (the metric's stream) or drive straight [0,1] with small steering noise (SURVEY 8d)")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
+                    help="c3: single-agent PGDrive-v0 (the metric); c5: multi-agent roundabout, --agents agents per env")
+    ap.add_argument("--agents", type=int, default=8)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     args = ap.parse_args()
 
@@ -125,19 +130,40 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    descs = bank.get_descriptions(range(1000, 1100))  # generated on the host by our own BIG (pgdrive_amd/mapgen.py)
-    mb = mapdata.MapBank(descs)
-    sb = scenario.ScenarioBank(descs, [d["seed"] for d in descs], num_agents=1, num_traffic=args.traffic)
-    N, A = args.envs, 1
-    cfg = _abi.make_config(N, num_agents=A, num_traffic=args.traffic, num_lasers=args.lasers, auto_reset=1,
-                           seed=1234 + rank)
+    N = args.envs
+    if args.workload == "c5":  # BASELINE config 5: multi-agent roundabout (reported next to the metric, never as the metric)
+        from pgdrive_amd import mapgen
+        A = args.agents
+        args.traffic, args.lasers = 0, 72
+        descs = [mapgen.generate_ma_roundabout()]
+        mb = mapdata.MapBank(descs)
+        sb = scenario.MarlScenarioBank(descs[0], num_agents=A, n_variants=16, seed=rank)
+        cfg = _abi.make_config(N, num_agents=A, num_traffic=0, num_lasers=72, num_others=0, lidar_dist=40.0, multi_agent=True,
+                               horizon=1000, agent_limit=A, respawn_places=sb.P, respawn_dests=sb.Dn,
+                               out_of_road_penalty=10.0, crash_vehicle_penalty=10.0, crash_object_penalty=10.0,
+                               delay_done=25, auto_reset=1, resample_scenario=1, seed=1234 + rank)
+        n_scen = len(sb.scenarios)
+    else:
+        A = 1
+        descs = bank.get_descriptions(range(1000, 1100))  # generated on the host by our own BIG (pgdrive_amd/mapgen.py)
+        mb = mapdata.MapBank(descs)
+        sb = scenario.ScenarioBank(descs, [d["seed"] for d in descs], num_agents=1, num_traffic=args.traffic)
+        cfg = _abi.make_config(N, num_agents=A, num_traffic=args.traffic, num_lasers=args.lasers, auto_reset=1,
+                               seed=1234 + rank)
+        n_scen = len(descs)
     eng = Engine(cfg, mb, sb, device=local_rank)
     D = eng.D
-    eng.reset((np.arange(N) + rank * N) % len(descs))
+    eng.reset((np.arange(N) + rank * N) % n_scen)
 
     rng = np.random.default_rng(rank)  # rank 0 == default_rng(0)
     CYC = 64
-    actions = torch.from_numpy(rng.uniform(-1, 1, size=(CYC, N, A, 2)).astype(np.float32)).to(dev)
+    if args.actions == "uniform":
+        acts = rng.uniform(-1, 1, size=(CYC, N, A, 2)).astype(np.float32)
+    else:  # "drive straight" (profile_pgdrive.py:16): full throttle, a little steering noise so that episodes differ
+        acts = np.zeros((CYC, N, A, 2), dtype=np.float32)
+        acts[..., 0] = rng.normal(0, 0.05, size=(CYC, N, A))
+        acts[..., 1] = 1.0
+    actions = torch.from_numpy(acts).to(dev)
 
     gather = world > 1 and not args.no_gather
     if gather:
@@ -214,8 +240,12 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "C3: %d envs/GPU x (1 ego + %d IDM traffic slots) x %d lidar beams, PGDrive-v0 maps "
-                            "seeds 1000-1099, uniform(-1,1) actions, auto-reset" % (N, args.traffic, args.lasers),
+                "workload": ("C3: %d envs/GPU x (1 ego + %d IDM traffic slots) x %d lidar beams, PGDrive-v0 maps "
+                             "seeds 1000-1099, %s actions, auto-reset" % (
+                                 N, args.traffic, args.lasers, "uniform(-1,1)" if args.actions == "uniform" else "drive-straight"))
+                if args.workload == "c3" else
+                ("C5: %d envs/GPU x %d agents, multi-agent roundabout, 72 beams x 40 m, %s actions, respawn, auto-reset; "
+                 "agent-steps/s = value x %d" % (N, A, args.actions, A)),
                 "envs_per_gpu": N, "global_envs": N * world, "obs_dim": D,
                 "parallelism": "env-sharded dp%d%s" % (world, " + 1 RCCL all_gather(obs,reward,done)/step, double-buffered" if gather else ""),
             },
@@ -227,7 +257,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(descs, args)
+            out["cpu_baseline"] = cpu_baseline(descs, args) if args.workload == "c3" else None
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -1583,7 +1583,7 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
 
 static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags) {
   int blocks = h->d.N * h->d.A;
-  if (h->d.cfg.num_lasers > 64)
+  if (h->d.cfg.num_lasers > 128)  // up to 128 beams one wave does it in two rounds: 4x fewer waves than 256-thread blocks
     hipLaunchKernelGGL(k_observe<256>, dim3(blocks), dim3(256), 0, h->stream, h->d, d_obs, d_flags);
   else hipLaunchKernelGGL(k_observe<64>, dim3(blocks), dim3(64), 0, h->stream, h->d, d_obs, d_flags);
   HIPCHK(hipGetLastError());
