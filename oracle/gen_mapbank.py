@@ -73,6 +73,26 @@ def main_marl_bottleneck():
     print("wrote", out, os.path.getsize(out))
 
 
+def main_mapjson():
+    """BaseMap.save_map (component/map/base_map.py:103-118) of BIG-generated maps -> tests/golden/mapjson_v0.json: the
+    reference's own block_sequence JSON (block parameters, id, pre_block_socket_index) per seed."""
+    root = os.path.dirname(HERE)
+    out = {}
+    for seed, kw in [(1000, dict(block_num=3)), (1003, dict(block_num=3)), (1042, dict(block_num=3)), (0, dict(block_num=7)),
+                     (10, dict(block_seq="CrXRTOS")), (11, dict(block_num=4, lane_num=2))]:
+        m = ref_export.generate(seed, **kw)
+        seq = []
+        for b in m["big"].blocks:  # == BaseMap.save_map
+            cfg = b.get_config().get_serializable_dict()
+            cfg["id"] = b.ID
+            cfg["pre_block_socket_index"] = b.pre_block_socket_index
+            seq.append(cfg)
+        out[str(seed)] = dict(kw=kw, block_sequence=seq)
+    with open(os.path.join(root, "tests", "golden", "mapjson_v0.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote mapjson goldens", {k: [b["id"] for b in v["block_sequence"]] for k, v in out.items()})
+
+
 def main_mapgen_goldens():
     """Extra goldens for pgdrive_amd/mapgen.py beyond the 100-seed bank: other block counts, lane counts / widths and
     explicit block sequences through every block type -> tests/golden/mapgen_v0.json.gz"""
@@ -93,7 +113,9 @@ def main_mapgen_goldens():
 
 
 if __name__ == "__main__":
-    if "--bottleneck" in sys.argv:
+    if "--mapjson" in sys.argv:
+        main_mapjson()
+    elif "--bottleneck" in sys.argv:
         main_marl_bottleneck()
     elif "--marl" in sys.argv:
         main_marl()

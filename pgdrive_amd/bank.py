@@ -10,8 +10,17 @@ MA_ROUNDABOUT_BANK = os.path.join(_ASSETS, "ma_roundabout_v0.json.gz")  # MARoun
 
 
 def load_descriptions(path=DEFAULT_BANK):
-    with gzip.open(path, "rb") as f:
-        data = json.loads(f.read().decode())
+    """Reads either our flattened description bank (.json.gz, key "maps") or a map file in the REFERENCE's format
+    (PGDriveEnv.dump_all_maps: {"map_config", "map_data": {seed: {"block_sequence": [...]}}}, plain or gzipped JSON); the
+    latter is rebuilt block by block from the saved parameters (pgdrive_amd/mapgen.py:generate_from_block_sequence)."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    if raw[:2] == b"\x1f\x8b":
+        raw = gzip.decompress(raw)
+    data = json.loads(raw.decode())
+    if "map_data" in data:
+        from . import mapgen
+        return mapgen.load_all_maps(data)
     return data["maps"]
 
 

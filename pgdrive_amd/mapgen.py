@@ -1027,6 +1027,57 @@ def generate_blocks(seed, lane_num=3, lane_width=3.5, exit_length=50, block_num=
     return gnet, blocks
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# map files: the reference's own JSON (BaseMap.save_map / read_map, component/map/base_map.py:103-130;
+# PGMap._config_generate, pg_map.py:51-80; PGDriveEnv.dump_all_maps / load_all_maps, envs/pgdrive_env.py:260-330)
+# ----------------------------------------------------------------------------------------------------------------------
+def save_map(blocks):
+    """BaseMap.save_map: {"block_sequence": [block parameters + "id" + "pre_block_socket_index"]}."""
+    seq = []
+    for b in blocks:
+        cfg = dict(b.config)
+        cfg["id"] = b.ID
+        cfg["pre_block_socket_index"] = b.pre_socket_index
+        seq.append(cfg)
+    return {"block_sequence": seq}
+
+
+def generate_from_block_sequence(block_sequence, seed=0, lane_num=3, lane_width=3.5, exit_length=50):
+    """PGMap._config_generate: rebuild a map from its saved block sequence (every block takes its parameters from the
+    file, crossing checks are skipped like ignore_intersection_checking=True)."""
+    by_id = dict(BY_ID)
+    by_id.update({"y": Merge, "Y": Split})
+    gnet = Net()
+    blocks = [FirstBlock(gnet, lane_width, lane_num, exit_length)]
+    for k, b in enumerate(block_sequence[1:], 1):
+        cfg = {key: (v if not isinstance(v, list) else np.array(v)) for key, v in b.items() if key not in ("id", "pre_block_socket_index")}
+        blk = by_id[b["id"]](k, blocks[-1].get_socket(b["pre_block_socket_index"]), gnet, seed, skip_check=True)
+        blk.construct(extra_config=cfg)
+        blocks.append(blk)
+    return to_description(seed, gnet, blocks, lane_num, lane_width, exit_length)
+
+
+def dump_all_maps(start_seed, environment_num, lane_num=3, lane_width=3.5, exit_length=50, block_num=3, block_seq=None):
+    """PGDriveEnv.dump_all_maps: {"map_config": {...}, "map_data": {seed: save_map()}} (JSON-serialisable)."""
+    data = {}
+    for seed in range(start_seed, start_seed + environment_num):
+        _, blocks = generate_blocks(seed, lane_num, lane_width, exit_length, block_num, block_seq)
+        data[seed] = save_map(blocks)
+    mc = dict(lane_num=lane_num, lane_width=lane_width, exit_length=exit_length,
+              type="block_num" if block_seq is None else "block_sequence", config=block_num if block_seq is None else block_seq)
+    return dict(map_config=mc, map_data=data)
+
+
+def load_all_maps(data):
+    """PGDriveEnv.load_all_maps: descriptions for every seed of a dump (ours or the reference's own file)."""
+    mc = data["map_config"]
+    out = []
+    for seed, m in sorted(data["map_data"].items(), key=lambda kv: int(kv[0])):
+        out.append(generate_from_block_sequence(m["block_sequence"], int(seed), mc.get("lane_num", 3), mc.get("lane_width", 3.5),
+                                                mc.get("exit_length", 50)))
+    return out
+
+
 def to_description(seed, gnet, blocks, lane_num, lane_width, exit_length):
     """Flatten to the description format of the map bank (same keys as the bank exported from the reference)."""
     nodes = []
