@@ -143,6 +143,7 @@ DEV unsigned group_or(unsigned v, const Grp& g) {
 // Device-side cell index (built by pgd_upload_maps): inside a cell the lane-surface boxes come first (original relative
 // order), the line / sidewalk boxes follow.  cstart[c] = first item | (number of lane boxes << 24); the cell ends where the
 // next one starts.  Localisation scans only the lane part, the contact / ray tests only the rest.
+DEV float ray_grid(const MapView& mv, float px, float py, float dx, float dy, unsigned kinds);
 DEV int cell_first(int c) { return c & 0xffffff; }
 DEV int cell_mid(int c) { return (c & 0xffffff) + (int)((unsigned)c >> 24); }
 
@@ -270,6 +271,7 @@ DEV unsigned state_check(const MapView& mv, const Grp& g, const Obb& car) {
 // navigation.py:155-183): looked up once per step after the checkpoint update, then reused by the side distances, the
 // reward and the observation instead of re-walking spawn record -> road table each time.
 struct RouteCtx {
+  int blk;         // Road.block_ID char of the current road
   int road_cur;    // road id of checkpoints[ck0] -> checkpoints[ck0 + 1]
   int cur_first;   // its first lane (current_ref_lanes[0]) ...
   int cur_n;       // ... and lane count
@@ -279,7 +281,7 @@ DEV RouteCtx route_ctx(const MapView& mv, const pgd_spawn& sp, int ck0, int ck1)
   const int rc = sp.ckpt_road[ck0], rn = sp.ckpt_road[ck1];
   const pgd_road& CR = mv.roads[rc];
   const pgd_road& NR = mv.roads[rn];
-  return RouteCtx{rc, CR.first_lane, CR.n_lanes, NR.first_lane};
+  return RouteCtx{CR.block_id, rc, CR.first_lane, CR.n_lanes, NR.first_lane};
 }
 
 // BaseVehicle.after_step (base_vehicle.py:255-290).  `with_state_check` = false lets the caller run the line / sidewalk
@@ -293,10 +295,19 @@ DEV void after_step_vehicle(const MapView& mv, const Grp& g, const pgd_spawn& sp
     fl &= ~(PGD_F_ON_WHITE | PGD_F_ON_YELLOW | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OUT_OF_ROUTE);
     if (with_state_check) fl |= state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sp.length, 0.5f * sp.width});
     float lon, lat;
-    lane_local(mv.lanes[ctx.cur_first], r.x, r.y, lon, lat);
+    const pgd_lane& L0 = mv.lanes[ctx.cur_first];
+    lane_local(L0, r.x, r.y, lon, lat);
     float w = mv.m->lane_width;
     r.dl = lat + w * 0.5f;
-    r.dr = w * ctx.cur_n - r.dl;
+    float range = w * ctx.cur_n;
+    if (ctx.blk == 'y' || ctx.blk == 'Y') {
+      // Navigation.get_current_lateral_range on Merge / Split blocks (navigation.py:306-320,346-362): a 50 m ray from the
+      // left edge of the leftmost reference lane across the road against the continuous lane lines
+      float sx, sy;
+      lane_position(L0, lon, -0.5f * L0.width, sx, sy);
+      range = 50.0f * ray_grid(mv, sx, sy, -L0.by * 50.0f, L0.bx * 50.0f, (1u << PGD_BOX_WHITE) | (1u << PGD_BOX_YELLOW));
+    }
+    r.dr = range - r.dl;
     if (r.dr < 0.0f || r.dl < 0.0f) fl |= PGD_F_OUT_OF_ROUTE;
     r.vflags = (int)fl;
     float dist = norm2(r.lastx - r.x, r.lasty - r.y) / 1000.0f;
@@ -919,7 +930,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
 
   PHASE_INIT();
   Veh r;
-  RouteCtx ctx{0, 0, 1, 0};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
+  RouteCtx ctx{0, 0, 0, 1, 0};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
   MapView mv;
   const pgd_spawn* sp = nullptr;
   const pgd_scenario* sc = nullptr;

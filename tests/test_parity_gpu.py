@@ -345,8 +345,10 @@ def test_marl_intersection_parity():
     test_marl_roundabout_parity(30, 30, kind="intersection")
 
 
-def test_marl_bottleneck_parity():
+@pytest.mark.parametrize("detectors", [True, False])
+def test_marl_bottleneck_parity(detectors):
     """MultiAgentBottleneckEnv (envs/marl_envs/marl_bottleneck.py): Merge / Split blocks, side + lane-line detector fans in
-    the multi-agent observation, plain reward, Navigation's own destinations."""
-    test_marl_roundabout_parity(20, 20, kind="bottleneck", side_lasers=4, side_dist=50.0, lane_line_lasers=4,
-                                lane_line_dist=20.0, plain_reward=True)
+    the multi-agent observation, plain reward, Navigation's own destinations.  Without the side detector obs[0:2] are the
+    lateral distances, whose right part is ray-measured on Merge / Split blocks (navigation.py:306-320,346-362)."""
+    kw = dict(side_lasers=4, side_dist=50.0, lane_line_lasers=4, lane_line_dist=20.0) if detectors else {}
+    test_marl_roundabout_parity(20, 20, kind="bottleneck", plain_reward=True, **kw)
