@@ -16,7 +16,9 @@ enum {
   SF_ACT0S, SF_ACT0T,         /* last_current_action[0] (older)         base_vehicle.py:171,248 */
   SF_ACT1S, SF_ACT1T,         /* last_current_action[1] (newer) */
   SF_PID_HP, SF_PID_HI,       /* IDM heading PID p_error, i_error       PID_controller.py:1-17 */
-  SF_PID_LP, SF_PID_LI,       /* IDM lateral PID */
+  SF_PID_LP, SF_PID_LI,       /* IDM lateral PID.  Controlled agents have no PID; under PGD_MA_TOLLGATE the four fields hold
+                                 TollGateObservation.in_toll_time and StayTimeManager's entry step, exit step (-1 = none) and
+                                 last block id char (-1 = not seen yet)  marl_tollgate.py:36-60,76-96 */
   SF_TARGET_SPEED,            /* IDMPolicy.target_speed [km/h]          idm_policy.py:182 */
   SF_ENERGY,                  /* energy_consumption                     base_vehicle.py:278-290 */
   SF_DIST_LEFT, SF_DIST_RIGHT,/* dist_to_left_side / right_side         base_vehicle.py:380-388 */

@@ -134,6 +134,8 @@ typedef struct pgd_spawn {  /* 64 B + route */
 #define PGD_OBJ_VEHICLE  0  /* chassis box length x width */
 #define PGD_OBJ_CYLINDER 1  /* TrafficCone / TrafficWarning: circle of radius length / 2 (traffic_object.py:40,60) */
 #define PGD_OBJ_BOX      2  /* TrafficBarrier: box length x width at `heading` (traffic_object.py:80-96) */
+#define PGD_OBJ_BUILDING 3  /* TollGateBuilding: invisible wall length x width (tollgate_building.py, scene_utils.py:260-295);
+                               a contact is crash_building (collision_callback.py:33-35), every step */
 #define PGD_GROUP_NEVER (-2)
 
 typedef struct pgd_scenario {
@@ -181,6 +183,9 @@ typedef struct pgd_config {
   int32_t increment_steering; /* 1: steering += a0 * 0.05, clipped (base_vehicle.py:351-358) */
   int32_t safe_rl_env;      /* 1: SafePGDriveEnv.done_function (safe_pgdrive_env.py:49-56): a step with crash_vehicle, else
                                crash_object, is never terminal */
+  /* MultiAgentTollgateEnv (envs/marl_envs/marl_tollgate.py), read when PGD_MA_TOLLGATE is set */
+  float overspeed_penalty;  /* 0.5: reward = -penalty * speed / max_speed while too fast inside the toll block */
+  int32_t min_pass_steps;   /* 30: an agent that crossed the toll block in fewer steps is terminated (out_of_road) */
 } pgd_config;
 
 #define PGD_MA_ENABLED        1  /* MultiAgentPGDrive semantics: per-agent done, delay-done queue, respawn, __all__ */
@@ -189,13 +194,16 @@ typedef struct pgd_config {
 #define PGD_MA_ALLOW_RESPAWN  8  /* allow_respawn    (multi_agent_pgdrive.py:26) */
 #define PGD_MA_PLAIN_REWARD  16  /* MultiAgentBottleneckEnv.reward_function (marl_bottleneck.py:91-128): no -1 factor on a
                                     negative road when the vehicle is off its reference lanes */
+#define PGD_MA_TOLLGATE      64  /* MultiAgentTollgateEnv: toll reward / out-of-road / stay-time rules, observation without the
+                                    navigation block plus 2 toll floats (marl_tollgate.py:63-105,195-270) */
 #define PGD_MA_YELLOW_OK     32  /* cross_yellow_line_done = False (marl_bottleneck.py:130-136): a yellow line is not
                                     out-of-road */
 
 typedef struct pgd_engine* pgd_handle;
 
 /* Size of one observation row D = (side_lasers or 2) + 6 + lane_line_lasers + 10 + 4*num_others + num_lasers
- * (obs/state_obs.py:17-23,108-114,124-130); 274 at the defaults. */
+ * (obs/state_obs.py:17-23,108-114,124-130); 274 at the defaults.  With PGD_MA_TOLLGATE the 10 navigation floats are
+ * absent and 2 toll floats follow the lidar (marl_tollgate.py:63-105). */
 int pgd_obs_dim(const pgd_config* cfg);
 
 /* Replaces PGDriveEnv.__init__ / lazy_init (envs/base_env.py:100-178): allocates device state for N x V slots. */

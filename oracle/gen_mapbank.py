@@ -93,6 +93,20 @@ def main_mapjson():
     print("wrote mapjson goldens", {k: [b["id"] for b in v["block_sequence"]] for k, v in out.items()})
 
 
+def main_marl_tollgate():
+    """MATollGateMap (envs/marl_envs/marl_tollgate.py:108-160) -> tests/golden/ma_tollgate_v0.json.gz (+ boxes, booths)"""
+    root = os.path.dirname(HERE)
+    m = ref_export.generate_ma_tollgate()
+    np.savez_compressed(os.path.join(root, "tests", "golden", "boxes_ma_tollgate.npz"), boxes=m["boxes"])
+    d = strip(m)
+    d["booths"] = m["booths"]
+    out = os.path.join(root, "tests", "golden", "ma_tollgate_v0.json.gz")
+    with gzip.GzipFile(out, "wb", mtime=0) as f:
+        f.write(json.dumps(dict(version=0, source="decisionforce/pgdrive v0.1.4 MATollGateMap (3 -> 8 -> 3 lanes)", maps=[d]),
+                           separators=(",", ":")).encode())
+    print("wrote", out, os.path.getsize(out), "booths", len(m["booths"]))
+
+
 def main_mapgen_goldens():
     """Extra goldens for pgdrive_amd/mapgen.py beyond the 100-seed bank: other block counts, lane counts / widths and
     explicit block sequences through every block type -> tests/golden/mapgen_v0.json.gz"""
@@ -113,7 +127,9 @@ def main_mapgen_goldens():
 
 
 if __name__ == "__main__":
-    if "--mapjson" in sys.argv:
+    if "--tollgate" in sys.argv:
+        main_marl_tollgate()
+    elif "--mapjson" in sys.argv:
         main_mapjson()
     elif "--bottleneck" in sys.argv:
         main_marl_bottleneck()

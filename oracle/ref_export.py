@@ -6,6 +6,7 @@ lanes (geometry, line types/colours, road, index), roads in `RoadNetwork.graph` 
 (`pgdrive/component/blocks/base_block.py:142-464`), recorded through the stubs in `refstub.py`.
 """
 import math
+import types
 
 import numpy as np
 
@@ -87,6 +88,43 @@ def generate_ma_roundabout(lane_num=2, lane_width=3.5, exit_length=60):
     ok = rb.construct_block(None, pw, extra_config={"exit_radius": 10, "inner_radius": 30, "angle": 70})
     assert ok
     return generate(0, lane_num, lane_width, exit_length, prebuilt=(net, _Blocks([first, rb])))
+
+
+def generate_ma_tollgate(lane_num=3, lane_width=3.5, exit_length=70, toll_lane_num=8, toll_length=10, bottle_length=35):
+    """MATollGateMap._generate (envs/marl_envs/marl_tollgate.py:108-160); the toll booths spawned through get_engine() are
+    recorded (lane, position, heading)."""
+    from pgdrive.component.blocks import tollgate as tg
+    from pgdrive.component.blocks.bottleneck import Merge, Split
+    from pgdrive.component.blocks.first_block import FirstPGBlock
+    net = RoadNetwork()
+    pw = refstub.FakePhysicsWorld()
+    booths = []
+
+    def spawn_object(cls, lane=None, position=None, heading=None):
+        booths.append(dict(lane=lane, x=float(position[0]), y=float(position[1]), heading=float(heading),
+                           length=float(cls.BUILDING_LENGTH), width=float(lane.width)))
+        return types.SimpleNamespace(body=None)
+    old = tg.get_engine
+    tg.get_engine = lambda: types.SimpleNamespace(spawn_object=spawn_object)
+    try:
+        first = FirstPGBlock(net, lane_width, lane_num, None, pw, length=exit_length)
+        split = Split(1, first.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+        assert split.construct_block(None, pw, {"length": 2, "lane_num": toll_lane_num - lane_num, "bottle_len": bottle_length})
+        toll = tg.TollGate(2, split.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+        assert toll.construct_block(None, pw, {"length": toll_length})
+        merge = Merge(3, toll.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+        assert merge.construct_from_config(dict(lane_num=toll_lane_num - lane_num, length=exit_length, bottle_len=bottle_length),
+                                           None, pw)
+    finally:
+        tg.get_engine = old
+    m = generate(0, lane_num, lane_width, exit_length, prebuilt=(net, _Blocks([first, split, toll, merge])))
+    lanes = []
+    for _f, td in net.graph.items():
+        for _t, ls in td.items():
+            lanes += ls
+    m["booths"] = [dict(lane=[k for k, l in enumerate(lanes) if l is b["lane"]][0], x=b["x"], y=b["y"], heading=b["heading"],
+                        length=b["length"], width=b["width"]) for b in booths]
+    return m
 
 
 def generate_ma_bottleneck(lane_width=3.5, exit_length=60, bottle_lane_num=4, neck_lane_num=1, neck_length=20):

@@ -14,7 +14,7 @@ class PgdConfig(C.Structure):
         ("respawn_dests", C.c_int32), ("side_lasers", C.c_int32), ("side_dist", C.c_float),
         ("lane_line_lasers", C.c_int32), ("lane_line_dist", C.c_float), ("discrete_action", C.c_int32),
         ("discrete_steering_dim", C.c_int32), ("discrete_throttle_dim", C.c_int32), ("increment_steering", C.c_int32),
-        ("safe_rl_env", C.c_int32),
+        ("safe_rl_env", C.c_int32), ("overspeed_penalty", C.c_float), ("min_pass_steps", C.c_int32),
     ]
 
 
@@ -25,7 +25,8 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
                 out_of_road_done=True, allow_respawn=True, delay_done=25, agent_limit=0, respawn_places=0,
                 respawn_dests=0, side_lasers=0, side_dist=50.0, lane_line_lasers=0, lane_line_dist=20.0,
                 discrete_action=False, discrete_steering_dim=5, discrete_throttle_dim=5, increment_steering=False,
-                safe_rl_env=False, plain_reward=False, cross_yellow_line_done=True):
+                safe_rl_env=False, plain_reward=False, cross_yellow_line_done=True, tollgate=False, overspeed_penalty=0.5,
+                min_pass_steps=30):
     """Defaults mirror PGDriveEnv_DEFAULT_CONFIG / BASE_DEFAULT_CONFIG (pgdrive_env.py:22-109, base_env.py:19-90)."""
     c = PgdConfig()
     c.num_envs, c.num_agents, c.num_traffic = num_envs, num_agents, num_traffic
@@ -44,14 +45,17 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
     if multi_agent:
         c.marl_flags = MA_ENABLED | (MA_CRASH_DONE if crash_done else 0) | (MA_OUT_ROAD_DONE if out_of_road_done else 0) | \
             (MA_ALLOW_RESPAWN if allow_respawn else 0) | (MA_PLAIN_REWARD if plain_reward else 0) | \
-            (0 if cross_yellow_line_done else MA_YELLOW_OK)
+            (0 if cross_yellow_line_done else MA_YELLOW_OK) | (MA_TOLLGATE if tollgate else 0)
+        c.overspeed_penalty, c.min_pass_steps = float(overspeed_penalty), int(min_pass_steps)
         c.delay_done, c.agent_limit = int(delay_done), int(agent_limit or num_agents)
         c.respawn_places, c.respawn_dests = int(respawn_places), int(respawn_dests)
     return c
 
 
 def obs_dim(cfg):
-    return (cfg.side_lasers or 2) + 6 + cfg.lane_line_lasers + 10 + 4 * cfg.num_others + cfg.num_lasers
+    toll = bool(cfg.marl_flags & MA_TOLLGATE)
+    return (cfg.side_lasers or 2) + 6 + cfg.lane_line_lasers + (0 if toll else 10) + 4 * cfg.num_others + cfg.num_lasers + \
+        (2 if toll else 0)
 
 
 # state layout (include/pgd_state_layout.h)
@@ -62,7 +66,7 @@ SI = dict(STATUS=0, LANE=1, CK0=2, CK1=3, RLANE=4, TIMER=5, VFLAGS=6, SPAWN=7)
 EI = dict(SCEN=0, NEXT_GROUP=1, EP_STEPS=2, EPISODES=3, STEPS_TOTAL=4, NEXT_AGENT=5)
 NF, NI, NEI = 24, 8, 8
 ST_EMPTY, ST_PENDING, ST_ACTIVE, ST_REMOVED, ST_DYING = 0, 1, 2, 3, 4
-MA_ENABLED, MA_CRASH_DONE, MA_OUT_ROAD_DONE, MA_ALLOW_RESPAWN, MA_PLAIN_REWARD, MA_YELLOW_OK = 1, 2, 4, 8, 16, 32
+MA_ENABLED, MA_CRASH_DONE, MA_OUT_ROAD_DONE, MA_ALLOW_RESPAWN, MA_PLAIN_REWARD, MA_YELLOW_OK, MA_TOLLGATE = 1, 2, 4, 8, 16, 32, 64
 
 F_ARRIVE, F_OUT_OF_ROAD, F_CRASH_VEHICLE, F_CRASH_OBJECT, F_CRASH_BUILDING, F_MAX_STEP = 1, 2, 4, 8, 16, 32
 F_ON_YELLOW, F_ON_WHITE, F_ON_BROKEN, F_CRASH_SIDEWALK, F_OFF_LANE, F_OUT_OF_ROUTE = 256, 512, 1024, 2048, 4096, 8192

@@ -620,6 +620,9 @@ DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r) {
 
 DEV void reset_vehicle(const pgd_spawn& p, Veh& r, int spawn_index, bool is_agent) {  // base_vehicle.py:292-339
   memset(&r, 0, sizeof(Veh));
+  // agents have no PID state: under PGD_MA_TOLLGATE the fields carry in_toll_time = 0 and entry / exit / last block = none
+  // (marl_tollgate.py:36-60,76-96); harmless otherwise
+  if (is_agent) { r.phi = -1.0f; r.plp = -1.0f; r.pli = -1.0f; }
   r.spawn = spawn_index;
   r.rlane = is_agent ? 0 : -1;  // agents: episode length; traffic: IDMPolicy.routing_target_lane = None
   r.hx = 1.0f;
@@ -651,16 +654,23 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
   float w = mv.m->lane_width;
   float lateral_factor = g.use_lateral ? clipf(1.0f - 2.0f * fabsf(t1) / w, 0.0f, 1.0f) : 1.0f;
   float reward = g.driving_reward * (l1 - l0) * lateral_factor * positive;
+  if (g.marl_flags & PGD_MA_TOLLGATE) {  // MultiAgentTollgateEnv.reward_function (marl_tollgate.py:195-232)
+    if (ctx.blk == '$') {
+      // BaseVehicle.overspeed (base_vehicle.py:759-761): lane.speed_limit (3 on toll lanes, 1000 elsewhere) < speed [km/h]
+      const bool lane_toll = mv.roads[VL.road].block_id == '$';
+      if (lane_toll && 3.0f < speed_kmh(r.v)) reward = -g.overspeed_penalty * speed_kmh(r.v) / sp.max_speed;
+    } else reward += g.speed_reward * (speed_kmh(r.v) / sp.max_speed);
+  } else
   reward += g.speed_reward * (speed_kmh(r.v) / sp.max_speed) * positive;
   unsigned out = vf & (PGD_F_ON_YELLOW | PGD_F_ON_WHITE | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OFF_LANE |
-                       PGD_F_OUT_OF_ROUTE | PGD_F_CRASH_VEHICLE | PGD_F_CRASH_OBJECT);
+                       PGD_F_OUT_OF_ROUTE | PGD_F_CRASH_VEHICLE | PGD_F_CRASH_OBJECT | PGD_F_CRASH_BUILDING);
   const pgd_lane& fl = mv.lanes[sp.dest_lane];
   float lon, lat;
   lane_local(fl, r.x, r.y, lon, lat);
   bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - ctx.cur_n) * w);
-  const unsigned oor_bits = (g.marl_flags & PGD_MA_YELLOW_OK)
-                                ? (PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK)
-                                : (PGD_F_ON_YELLOW | PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK);
+  unsigned oor_bits = (g.marl_flags & PGD_MA_TOLLGATE) ? PGD_F_CRASH_SIDEWALK  // marl_tollgate.py:234-240
+                                                        : (PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK);
+  if (!(g.marl_flags & PGD_MA_YELLOW_OK)) oor_bits |= PGD_F_ON_YELLOW;
   bool oor = (vf & oor_bits) != 0;
   if (g.out_of_route_done) oor = oor || (vf & PGD_F_OUT_OF_ROUTE);
   bool crash = (vf & PGD_F_CRASH_VEHICLE) != 0, crash_obj = (vf & PGD_F_CRASH_OBJECT) != 0;
@@ -671,7 +681,7 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
   else if (crash) reward = -g.crash_vehicle_penalty;
   else if (crash_obj) reward = -g.crash_object_penalty;
   flags_out = out;
-  done_out = arrive || oor || crash || crash_obj;
+  done_out = arrive || oor || crash || crash_obj || (vf & PGD_F_CRASH_BUILDING) != 0;  // pgdrive_env.py:162-194
   // SafePGDriveEnv.done_function (safe_pgdrive_env.py:49-56): a step with crash_vehicle, else crash_object, is not terminal
   if (g.safe_rl_env && (crash || crash_obj)) done_out = false;
   return reward;
@@ -753,6 +763,8 @@ struct ObsLds {  // bodies inside the lidar broad phase of the observing agent, 
 struct AgentView {  // what the observation needs from the observing vehicle
   float x, y, th, hx, hy, dl, dr, v, steer, a0s, a0t, lhx, lhy;
   int cur_first, cur_n, next_first;  // RouteCtx of the vehicle
+  int blk;                           // block id char of its current road
+  float toll_time;                   // TollGateObservation.in_toll_time (PGD_MA_TOLLGATE)
 };
 
 // one wave compacts the candidates: lane `o` brings vehicle o of the env (present = in the physics world)
@@ -780,7 +792,14 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   // StateObservation.vehicle_state (state_obs.py:58-106) + navi info (navigation.py:185-197): one lane per float.
   // Row layout: [side fan k | 2 lateral distances][6 ego floats][lane-line fan m][10 navi][4*NO neighbours][NL beams]
   const int KS = d.cfg.side_lasers, KM = d.cfg.lane_line_lasers;
-  const int o_ego = KS > 0 ? KS : 2, o_navi = o_ego + 6 + KM, o_oth = o_navi + 10;
+  const bool toll = (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;  // no navigation block, 2 toll floats after the lidar
+  const int o_ego = KS > 0 ? KS : 2, o_navi = o_ego + 6 + KM, o_oth = o_navi + (toll ? 0 : 10);
+  if (toll && tid == 0) {  // TollGateObservation.observe (marl_tollgate.py:84-96)
+    const bool in_toll = ag.blk == '$';
+    float* t2 = row + o_oth + 4 * d.cfg.num_others + NL;
+    t2[0] = in_toll ? 1.0f : 0.0f;
+    t2[1] = (in_toll && ag.toll_time > (float)d.cfg.min_pass_steps) ? 1.0f : 0.0f;
+  }
   if (tid < 18) {
     // every lane fetches the one lane record its float needs BEFORE the branch ladder, so the reads overlap instead of
     // queueing behind each other branch by branch: heading_diff -> last lane of the current road; navi -> first lanes
@@ -808,7 +827,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
       float out[5];
       navi_info_for(ml, mv.m->lane_width, ag.cur_n, px, py, hx, hy, out);
       v = comp == 0 ? out[0] : comp == 1 ? out[1] : comp == 2 ? out[2] : comp == 3 ? out[3] : out[4];
-      col = o_navi + (tid - 8);
+      col = toll ? -1 : o_navi + (tid - 8);
     }
     if (col >= 0) row[col] = v;
   }
@@ -1055,7 +1074,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     }
     PHASE_MARK(2);  // policy (IDM)
     // (3) BaseVehicle.before_step (base_vehicle.py:238-253)
-    r.vflags &= ~(PGD_F_CRASH_VEHICLE | PGD_F_CRASH_OBJECT);
+    r.vflags &= ~(PGD_F_CRASH_VEHICLE | PGD_F_CRASH_OBJECT | PGD_F_CRASH_BUILDING);
     r.lastx = r.x; r.lasty = r.y;
     r.lasthx = r.hx; r.lasthy = r.hy;
     r.a0s = r.a1s; r.a0t = r.a1t;
@@ -1089,15 +1108,16 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       for (int a = 0; a < A; ++a)
         if (a != s && S.present[base + a] && shape_overlap<true>(snap_obb(S, base + a), me)) {
           touched = true;
-          if (leader && live) atomicOr(&s_hit[base + a], kind == PGD_OBJ_VEHICLE ? 1 : 2);
+          if (leader && live) atomicOr(&s_hit[base + a], kind == PGD_OBJ_VEHICLE ? 1 : (kind == PGD_OBJ_BUILDING ? 4 : 2));
         }
-      if (touched && kind != PGD_OBJ_VEHICLE) r.vflags |= (int)PGD_F_OBJECT_HIT;  // every sub-lane keeps its copy in step
+      if (touched && kind != PGD_OBJ_VEHICLE && kind != PGD_OBJ_BUILDING) r.vflags |= (int)PGD_F_OBJECT_HIT;  // all sub-lanes
     }
   }
   __syncthreads();
   if (acting && s < A) {
     if (s_hit[slot] & 1) r.vflags |= PGD_F_CRASH_VEHICLE;
     if (OBJ && (s_hit[slot] & 2)) r.vflags |= PGD_F_CRASH_OBJECT;
+    if (OBJ && (s_hit[slot] & 4)) r.vflags |= PGD_F_CRASH_BUILDING;
   }
   PHASE_MARK(4);  // crash
   // (6) after_step; traffic off the lanes is removed (traffic_manager.py:91-109)
@@ -1135,11 +1155,17 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (marl && one_env) {
     // ---- multi-agent tail: multi_agent_pgdrive.py:109-213, agent_manager.py:134-175, spawn_manager.py:160-215 ----
     const pgd_config& gcf = d.cfg;
+    const bool toll = (gcf.marl_flags & PGD_MA_TOLLGATE) != 0;
     if (valid && s < A && was_active) {
+      if (toll && ctx.blk == '$') r.php += 1.0f;  // TollGateObservation.observe counts its calls inside the toll block
       my_rew = reward_done(d, mv, *sp, r, ctx, my_fl, my_dn);
       const bool arrive = my_fl & PGD_F_ARRIVE, oor = my_fl & PGD_F_OUT_OF_ROAD, crash = my_fl & PGD_F_CRASH_VEHICLE;
       if (crash && !(gcf.marl_flags & PGD_MA_CRASH_DONE) && !(arrive || oor)) my_dn = false;
       if (oor && !(gcf.marl_flags & PGD_MA_OUT_ROAD_DONE) && !arrive) my_dn = false;
+      if (toll && r.phi >= 0.0f && r.plp >= 0.0f && r.plp - r.phi < (float)gcf.min_pass_steps) {  // marl_tollgate.py:262-268
+        my_dn = true;
+        my_fl |= PGD_F_OUT_OF_ROAD;
+      }
       r.rlane += 1;  // episode_length
       if (gcf.horizon > 0 && r.rlane >= gcf.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
       r.eprew += my_rew;
@@ -1193,6 +1219,15 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         }
         next_agent += 1;
         __syncthreads();
+      }
+    }
+    // StayTimeManager.record(active_agents, episode_steps) after the step (marl_tollgate.py:36-60,276-279)
+    if (toll && valid && s < A && r.status == ST_ACTIVE) {
+      const float cur = (float)ctx.blk, last = r.pli;
+      r.pli = cur;
+      if (last >= 0.0f && last != cur) {
+        if (ctx.blk == '$') r.phi = (float)ep_steps;
+        else if ((ctx.blk == 'y' || ctx.blk == 'Y') && last == (float)'$') r.plp = (float)ep_steps;
       }
     }
     // d["__all__"] (multi_agent_pgdrive.py:142-148)
@@ -1267,6 +1302,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         ag.x = r.x; ag.y = r.y; ag.th = r.th; ag.hx = r.hx; ag.hy = r.hy; ag.dl = r.dl; ag.dr = r.dr; ag.v = r.v;
         ag.steer = r.steer; ag.a0s = r.a0s; ag.a0t = r.a0t; ag.lhx = r.lasthx; ag.lhy = r.lasthy;
         ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
+        ag.blk = ctx.blk; ag.toll_time = r.php;
       }
     }
     __syncthreads();
@@ -1402,6 +1438,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
   const pgd_spawn& msp = spb[mine.i[SI_SPAWN]];
   const RouteCtx ctx = route_ctx(mv, msp, mine.i[SI_CK0], mine.i[SI_CK1]);
   ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
+  ag.blk = ctx.blk; ag.toll_time = mine.f[SF_PID_HP];
   observe_agent<true>(d, mv, msp, ag, L, row, tid, BLOCK);
 }
 
@@ -1462,7 +1499,9 @@ extern "C" {
 const char* pgd_version(void) { return "pgdrive_hip 0.1 (gfx950)"; }
 
 int pgd_obs_dim(const pgd_config* c) {
-  return (c->side_lasers > 0 ? c->side_lasers : 2) + 6 + c->lane_line_lasers + PGD_NAVI_DIM + 4 * c->num_others + c->num_lasers;
+  const int toll = (c->marl_flags & PGD_MA_TOLLGATE) != 0;
+  return (c->side_lasers > 0 ? c->side_lasers : 2) + 6 + c->lane_line_lasers + (toll ? 0 : PGD_NAVI_DIM) + 4 * c->num_others +
+         c->num_lasers + (toll ? 2 : 0);
 }
 
 int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* out) {
@@ -1478,7 +1517,8 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->d.D = pgd_obs_dim(cfg);
   h->d.NV = h->d.N * V;
   const bool marl = (cfg->marl_flags & PGD_MA_ENABLED) != 0;
-  if (marl && (cfg->respawn_places < 0 || cfg->respawn_dests < 0 || cfg->num_traffic != 0)) return PGD_ERR_ARG;
+  // multi-agent engines have no IDM traffic; num_traffic slots may hold static bodies (toll booths, group PGD_GROUP_NEVER)
+  if (marl && (cfg->respawn_places < 0 || cfg->respawn_dests < 0)) return PGD_ERR_ARG;
   h->d.sstride = V + (marl ? cfg->respawn_places * cfg->respawn_dests : 0);
   h->d.sub = WAVE / V < 16 ? WAVE / V : 16;  // sub-lanes per vehicle
   h->d.epw = WAVE / (V * h->d.sub);          // whole environments per wave
@@ -1644,7 +1684,7 @@ int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward
   int blocks = (h->d.N + h->d.epw - 1) / h->d.epw;
   if (marl && h->d.epw != 1) return PGD_ERR_STATE;  // the multi-agent tail needs the env in one wave (V >= 33 or SUB split)
   void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*) = k_step<false, false, false>;
-  if (marl) kern = k_step<true, true, false>;  // (no traffic objects on the multi-agent maps)
+  if (marl) kern = h->has_objects ? k_step<true, true, true> : k_step<true, true, false>;  // objects = toll booths
   else if (h->d.epw == 1) kern = h->has_objects ? k_step<true, false, true> : k_step<true, false, false>;
   else if (h->has_objects) kern = k_step<false, false, true>;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), (size_t)h->d.lds_bytes, h->stream, h->d, d_actions, d_reward, d_done,

@@ -397,6 +397,7 @@ SPACES = {
     "I": {},
     "y": {"length": ("box", 20, 50), "lane_num": ("disc", 1, 2), "bottle_len": ("const", 20)},  # BOTTLENECK_PARAMETER
     "Y": {"length": ("box", 20, 50), "lane_num": ("disc", 1, 2), "bottle_len": ("const", 20)},
+    "$": {"length": ("box", 20, 50), "lane_num": ("disc", 1, 2), "bottle_len": ("const", 20)},  # TollGate reuses it
 }
 
 
@@ -975,6 +976,32 @@ class Split(Block):
         return ok
 
 
+class TollGate(Block):
+    """tollgate.py:16-81: a straight piece whose lanes are separated by continuous lines, limited to 3 (sic: compared with
+    km/h, base_vehicle.py:760-761), with a booth (invisible wall, 10 m x lane width) in the middle of every odd lane."""
+    ID = "$"
+    SPEED_LIMIT = 3
+    BUILDING_LENGTH = 10  # TollGateBuilding.BUILDING_LENGTH (tollgate_building.py:8)
+
+    def build(self):
+        self.set_part(0)
+        new_lane = extend_straight(self.pos_basic, self.config["length"], [CONTINUOUS, SIDE])
+        sock = (self.pre_socket.pos[1], self.add_node())
+        kw = dict(center_color=YELLOW, center_line_type=CONTINUOUS, inner_type=CONTINUOUS, side_type=SIDE)
+        ok = self.rf(new_lane, self.pos_lane_num, sock, **kw)
+        ok = self.ar(sock, **kw) and ok
+        self.add_socket(Socket(sock, neg(sock)))
+        self.buildings = []
+        for road in (sock, neg(sock)):
+            for idx, lane in enumerate(self.net.lanes(road)):
+                lane.speed_limit = self.SPEED_LIMIT
+                if idx % 2 == 1:
+                    p = lane.position(lane.length / 2, 0)
+                    self.buildings.append(dict(lane=lane, x=float(p[0]), y=float(p[1]), heading=float(lane.heading_at(0)),
+                                               length=float(self.BUILDING_LENGTH), width=float(lane.width)))
+        return ok
+
+
 BLOCK_TYPES = [Curve, Straight, InRamp, OutRamp, Intersection, TIntersection, Roundabout, None, None, None, None, None, None]
 BLOCK_PROBS = [0.3, 0.1, 0.1, 0.1, 0.15, 0.15, 0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
 BY_ID = {c.ID: c for c in BLOCK_TYPES if c is not None}
@@ -1046,7 +1073,7 @@ def generate_from_block_sequence(block_sequence, seed=0, lane_num=3, lane_width=
     """PGMap._config_generate: rebuild a map from its saved block sequence (every block takes its parameters from the
     file, crossing checks are skipped like ignore_intersection_checking=True)."""
     by_id = dict(BY_ID)
-    by_id.update({"y": Merge, "Y": Split})
+    by_id.update({"y": Merge, "Y": Split, "$": TollGate})
     gnet = Net()
     blocks = [FirstBlock(gnet, lane_width, lane_num, exit_length)]
     for k, b in enumerate(block_sequence[1:], 1):
@@ -1117,7 +1144,11 @@ def to_description(seed, gnet, blocks, lane_num, lane_width, exit_length):
         spawn = [[lane_id[id(l)] for l in ls] for ls in b.intermediate_spawn_lanes()]
         broads = [[rl[(nid(a), nid(t))], [lane_id[id(l)] for l in ls]] for a, td in b.net.graph.items() for t, ls in td.items()]
         trig = b.pre_socket.pos if b.index != 0 else None
-        out_blocks.append(dict(id=b.ID, sockets=sockets, spawn_lanes=spawn,
+        extra = {}
+        if getattr(b, "buildings", None):
+            extra["buildings"] = [dict(lane=lane_id[id(x["lane"])], x=x["x"], y=x["y"], heading=x["heading"], length=x["length"],
+                                       width=x["width"]) for x in b.buildings]
+        out_blocks.append(dict(id=b.ID, sockets=sockets, spawn_lanes=spawn, **extra,
                                respawn_roads=[[nid(r[0]), nid(r[1])] for r in b.respawn_roads], roads=broads,
                                trigger_road=[nid(trig[0]), nid(trig[1])] if trig else None,
                                config=dict(b.config) if b.index != 0 else {}, pre_socket=b.pre_socket_index))
@@ -1135,6 +1166,20 @@ class FullIntersection(Intersection):
     """InterSection proper (intersection.py:15-238): the lane-count change of the crossing road is sampled, not forced to 0."""
     def build(self):
         return self.build_x()
+
+
+def generate_ma_tollgate(lane_num=3, lane_width=3.5, exit_length=70, toll_lane_num=8, toll_length=10, bottle_length=35):
+    """MATollGateMap._generate (envs/marl_envs/marl_tollgate.py:108-160): 3-lane first block, Split out to 8 lanes, the toll
+    plaza, Merge back to 3 lanes."""
+    gnet = Net()
+    first = FirstBlock(gnet, lane_width, lane_num, exit_length)
+    split = Split(1, first.get_socket(0), gnet, 1)
+    assert split.construct(extra_config=dict(length=2, lane_num=toll_lane_num - lane_num, bottle_len=bottle_length))
+    toll = TollGate(2, split.get_socket(0), gnet, 1)
+    assert toll.construct(extra_config=dict(length=toll_length))
+    merge = Merge(3, toll.get_socket(0), gnet, 1)
+    assert merge.construct(extra_config=dict(lane_num=toll_lane_num - lane_num, length=exit_length, bottle_len=bottle_length))
+    return to_description(0, gnet, [first, split, toll, merge], lane_num, lane_width, exit_length)
 
 
 def generate_ma_bottleneck(lane_width=3.5, exit_length=60, bottle_lane_num=4, neck_lane_num=1, neck_length=20):

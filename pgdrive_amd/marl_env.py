@@ -51,6 +51,7 @@ class MultiAgentRoundaboutVecEnv:
     MAP_KIND = "roundabout"
     DEFAULTS = MA_DEFAULT_CONFIG
     PLAIN_REWARD = False
+    TOLLGATE = False
 
     @staticmethod
     def _generate_map(mc):
@@ -70,7 +71,7 @@ class MultiAgentRoundaboutVecEnv:
                                                    n_variants=c["spawn_variants"], seed=c["seed"], kind=self.MAP_KIND)
         self.num_envs, self.A = int(c["num_envs"]), cap
         self.cfg = _abi.make_config(
-            self.num_envs, num_agents=cap, num_traffic=0, num_lasers=lid["num_lasers"], num_others=0,
+            self.num_envs, num_agents=cap, num_traffic=self.scen_bank.B, num_lasers=lid["num_lasers"], num_others=0,
             lidar_dist=lid["distance"], dt=c["physics_world_step_size"], decision_repeat=c["decision_repeat"],
             auto_reset=c["auto_reset"], resample_scenario=1, horizon=c["horizon"] or 0, seed=c["seed"],
             success_reward=c["success_reward"], out_of_road_penalty=c["out_of_road_penalty"],
@@ -81,7 +82,8 @@ class MultiAgentRoundaboutVecEnv:
             respawn_places=self.scen_bank.P, respawn_dests=self.scen_bank.Dn,
             side_lasers=sd["num_lasers"] if sd["distance"] > 0 else 0, side_dist=sd["distance"],
             lane_line_lasers=ld["num_lasers"] if ld["distance"] > 0 else 0, lane_line_dist=ld["distance"],
-            plain_reward=self.PLAIN_REWARD, cross_yellow_line_done=c["cross_yellow_line_done"]
+            plain_reward=self.PLAIN_REWARD, cross_yellow_line_done=c["cross_yellow_line_done"], tollgate=self.TOLLGATE,
+            overspeed_penalty=c.get("overspeed_penalty", 0.5), min_pass_steps=c["vehicle_config"].get("min_pass_steps", 30)
         )
         from .engine import Engine
         self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])
@@ -138,6 +140,29 @@ class MultiAgentBottleneckVecEnv(MultiAgentRoundaboutVecEnv):
         from . import mapgen
         return mapgen.generate_ma_bottleneck(mc["lane_width"], mc["exit_length"], mc["bottle_lane_num"], mc["neck_lane_num"],
                                              mc["neck_length"])
+
+
+class MultiAgentTollgateVecEnv(MultiAgentRoundaboutVecEnv):
+    """MultiAgentTollgateEnv (marl_tollgate.py:14-279) batched: a 3-lane road fanning out to an 8-lane toll plaza (booths on
+    every odd lane: crash_building) and back, 40 agents.  Observation = vehicle state with 72 side + 4 lane-line beams, no
+    navigation block, 72 lidar beams x 20 m and [inside the plaza, stayed longer than min_pass_steps]; inside the plaza
+    driving faster than the lane limit costs `overspeed_penalty`, and an agent that crossed it in fewer than
+    `min_pass_steps` steps is terminated."""
+    MAP_KIND = "tollgate"
+    PLAIN_REWARD = True
+    TOLLGATE = True
+    DEFAULTS = dict(
+        MA_DEFAULT_CONFIG, num_agents=40, speed_reward=0.0, overspeed_penalty=0.5,
+        map_config=dict(exit_length=70, lane_width=3.5, lane_num=3, toll_lane_num=8, toll_length=10),
+        vehicle_config=dict(lidar=dict(num_lasers=72, distance=20, num_others=0), side_detector=dict(num_lasers=72, distance=20),
+                            lane_line_detector=dict(num_lasers=4, distance=20), min_pass_steps=30),
+    )
+
+    @staticmethod
+    def _generate_map(mc):
+        from . import mapgen
+        return mapgen.generate_ma_tollgate(mc["lane_num"], mc["lane_width"], mc["exit_length"], mc["toll_lane_num"],
+                                           mc["toll_length"])
 
 
 class MultiAgentRoundaboutEnv:
@@ -219,3 +244,8 @@ class MultiAgentIntersectionEnv(MultiAgentRoundaboutEnv):
 class MultiAgentBottleneckEnv(MultiAgentRoundaboutEnv):
     """Dict protocol on the bottleneck map (marl_bottleneck.py:70-137)."""
     VEC = MultiAgentBottleneckVecEnv
+
+
+class MultiAgentTollgateEnv(MultiAgentRoundaboutEnv):
+    """Dict protocol on the toll plaza map (marl_tollgate.py:163-279)."""
+    VEC = MultiAgentTollgateVecEnv

@@ -468,11 +468,18 @@ def bottleneck_spawn_roads(desc):
     return [(n.index(">>"), n.index(">>>")), neg_road(desc, n.index("2Y0_0_"), n.index("2Y0_1_"))]
 
 
+def tollgate_spawn_roads(desc):
+    """MATollConfig.spawn_roads (marl_tollgate.py:15): '>>'->'>>>' and the far end of the closing Merge block, negated."""
+    n = desc["nodes"]
+    return [(n.index(">>"), n.index(">>>")), neg_road(desc, n.index("3y0_0_"), n.index("3y0_1_"))]
+
+
 MARL_SPAWN_ROADS = {"roundabout": roundabout_spawn_roads, "intersection": intersection_spawn_roads,
-                    "bottleneck": bottleneck_spawn_roads}
+                    "bottleneck": bottleneck_spawn_roads, "tollgate": tollgate_spawn_roads}
 # destination rule: the roundabout / intersection spawn managers draw a negated spawn road; the bottleneck env keeps the
 # default SpawnManager.update_destination_for (spawn_manager.py:221-225), i.e. Navigation.update's own choice
-MARL_AUTO_DEST = {"bottleneck"}
+MARL_AUTO_DEST = {"bottleneck", "tollgate"}
+OBJ_BUILDING = 3  # PGD_OBJ_BUILDING
 
 
 def spawn_slots(desc, spawn_roads):
@@ -494,6 +501,11 @@ def spawn_slots(desc, spawn_roads):
     return slots, safe
 
 
+def map_buildings(desc):
+    """Static buildings of the map (TollGate booths): dict(lane, x, y, heading, length, width) in block order."""
+    return [b for blk in desc["blocks"] for b in blk.get("buildings", [])]
+
+
 def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle_model="default", kind="roundabout"):
     """SpawnManager.reset (spawn_manager.py:68-101): `num_agents` of the spawn slots without replacement, jittered inside
     the slot, each with a random destination (RoundaboutSpawnManager.update_destination_for,
@@ -513,9 +525,27 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
 
     dests = [None] if auto else [neg_road(desc, *r)[1] for r in spawn_roads]  # end node of the negated spawn road
     P, Dn = len(safe), len(dests)
-    recs = np.zeros(A + P * Dn, dtype=SPAWN_DT)
+    buildings = map_buildings(desc)
+    B = len(buildings)  # static bodies take the slots [A, A + B); the respawn table follows them
+    recs = np.zeros(A + B + P * Dn, dtype=SPAWN_DT)
     recs["lane"] = -1
     recs["group"] = -1
+    for k, b in enumerate(buildings):
+        r = recs[A + k]
+        lane = desc["lanes"][b["lane"]]
+        road = desc["roads"][lane["road"]]
+        r["x"], r["y"], r["lane"], r["kind"], r["group"] = b["x"], b["y"], b["lane"], OBJ_BUILDING, GROUP_NEVER
+        # TollGateBuilding hands panda a heading in radians where degrees are expected (tollgate_building.py:18): the wall
+        # ends up rotated by heading * pi / 180 -- reproduced
+        r["heading"] = b["heading"] * math.pi / 180.0
+        r["length"], r["width"] = b["length"], b["width"]
+        r["wheelbase"], r["mass"], r["max_speed"], r["max_steer"], r["friction"] = 1.0, 1.0, 80.0, 0.1, 0.9
+        r["n_ckpt"] = 2
+        r["ckpt"][:] = -1
+        r["ckpt_road"][:] = -1
+        r["ckpt"][:2] = [road["frm"], road["to"]]
+        r["ckpt_road"][0] = lane["road"]
+        r["dest_lane"] = road["first_lane"] + road["n_lanes"] - 1
     pick = rng.choice(len(slots), num_agents, replace=False)
     lo, la = RESPAWN_REGION_LONGITUDE - MAX_VEHICLE_LENGTH, RESPAWN_REGION_LATERAL - MAX_VEHICLE_WIDTH
     for a, idx in enumerate(pick):
@@ -527,14 +557,14 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
         _fill_route(recs[a], desc, c["lane"], auto_dest(c) if auto else dests[int(rng.randint(0, Dn))])
     for p, c in enumerate(safe):
         for dn, dest in enumerate(dests):
-            r = recs[A + p * Dn + dn]
+            r = recs[A + B + p * Dn + dn]
             params = sample_vehicle_params(vehicle_model, int(rng.randint(0, MAX_RAND_INT)))
             _fill_vehicle(r, desc, c["lane"], c["long"], c["lat"], params)
             _fill_route(r, desc, c["lane"], auto_dest(c) if auto else dest)
     scen = np.zeros((), dtype=SCEN_DT)
     scen["map"] = map_index
     scen["trigger_road"][:] = -1
-    return scen, recs, P, Dn
+    return scen, recs, P, Dn, B
 
 
 class MarlScenarioBank:
@@ -543,13 +573,13 @@ class MarlScenarioBank:
         rng = np.random.RandomState(seed)
         scens, recs = [], []
         for _ in range(n_variants):
-            sc, rc, self.P, self.Dn = build_marl_scenario(desc, 0, rng, num_agents, capacity, kind=kind)
+            sc, rc, self.P, self.Dn, self.B = build_marl_scenario(desc, 0, rng, num_agents, capacity, kind=kind)
             scens.append(sc)
             recs.append(rc)
         self.scenarios = np.array(scens, dtype=SCEN_DT)
         self.spawns = np.concatenate(recs)
         self.A = capacity or num_agents
-        self.V = self.A
+        self.V = self.A + self.B  # agents + static bodies (toll booths)
         self.num_agents = num_agents
-        self.stride = self.A + self.P * self.Dn
+        self.stride = self.V + self.P * self.Dn
         self.info = []

@@ -352,3 +352,99 @@ def test_marl_bottleneck_parity(detectors):
     lateral distances, whose right part is ray-measured on Merge / Split blocks (navigation.py:306-320,346-362)."""
     kw = dict(side_lasers=4, side_dist=50.0, lane_line_lasers=4, lane_line_dist=20.0) if detectors else {}
     test_marl_roundabout_parity(20, 20, kind="bottleneck", plain_reward=True, **kw)
+
+
+TOLL = dict(tollgate=True, plain_reward=True, side_lasers=72, side_dist=20.0, lane_line_lasers=4, lane_line_dist=20.0,
+            num_lasers=72, lidar_dist=20.0, speed_reward=0.0, overspeed_penalty=0.5, min_pass_steps=30)
+
+
+def test_marl_tollgate_parity():
+    """MultiAgentTollgateEnv (envs/marl_envs/marl_tollgate.py): Split -> TollGate -> Merge map with 8 booths (crash_building),
+    observation without navigation block + 2 toll floats, overspeed reward, sidewalk-only out-of-road, stay-time rule.
+    Half of the agents are teleported to the mouth of the toll plaza, some too fast to pass legally."""
+    import torch
+    from oracle import orc
+    from pgdrive_amd import mapdata
+    from pgdrive_amd.engine import Engine
+    d, mb, sb = util.make_marl_banks(num_agents=40, n_variants=4, kind="tollgate")
+    assert sb.B == 8 and sb.V == 48
+    n_envs = 16
+    cfg = util.marl_config(n_envs, sb, horizon=400, **TOLL)
+    eng, ora = Engine(cfg, mb, sb), orc.Oracle(cfg, mb, sb)
+    assert eng.D == 156
+    ids = np.arange(n_envs) % 4
+    o0 = ora.reset(ids)
+    g0 = eng.reset(ids).cpu().numpy()
+    assert (np.abs(g0 - o0) > OBS_TOL).sum() <= 4
+    f, i, ei = ora.get_state()
+    SF, SI = _abi.SF, _abi.SI
+    rng = np.random.default_rng(3)
+    nodes = d["nodes"]
+    moved = 0
+    for e in range(n_envs):
+        sp = sb.spawns[ids[e] * sb.stride:(ids[e] + 1) * sb.stride]
+        for a in range(0, 40, 2):
+            route = [int(r) for r in sp[a]["ckpt_road"][:sp[a]["n_ckpt"] - 1]]
+            toll = [k for k, rid in enumerate(route) if d["roads"][rid]["block_id"] == "$"]
+            if not toll:
+                continue
+            k = toll[0] - 1  # the road that leads into the plaza
+            road = d["roads"][route[k]]
+            lane_id = road["first_lane"] + 2 * int(rng.integers(0, road["n_lanes"] // 2 + road["n_lanes"] % 2))  # a booth-free lane
+            lane = d["lanes"][lane_id]
+            lon = max(lane["length"] - rng.uniform(0.5, 6.0), 0.2)
+            x, y = mapdata.lane_position(lane, lon, 0.0)
+            th = mapdata.lane_heading_at(lane, lon)
+            f[SF["X"], e, a], f[SF["Y"], e, a], f[SF["THETA"], e, a] = x, y, th
+            f[SF["LASTX"], e, a], f[SF["LASTY"], e, a] = x, y
+            f[SF["LASTHX"], e, a], f[SF["LASTHY"], e, a] = np.cos(th), np.sin(th)
+            f[SF["SPEED"], e, a] = rng.choice([0.6, 6.0])  # crawl through, or rush (exit after < 30 steps)
+            i[SI["LANE"], e, a], i[SI["CK0"], e, a], i[SI["CK1"], e, a] = lane_id, k, k + 1
+            moved += 1
+    assert moved > 100
+    f32 = util.round_state_f32(f)
+    ora.set_state(f32, i, ei)
+    eng.set_state(f32, i, ei)
+    stats = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
+    seen = dict(toll_obs=0, long_stay=0, building=0, fast_exit=0, entries=0, exits=0, int_mismatch=0)
+    for t in range(160):
+        act = np.zeros((n_envs, 40, 2), dtype=np.float32)
+        act[..., 0] = np.clip(rng.normal(0, 0.03, size=(n_envs, 40)), -1, 1)
+        act[..., 1] = np.where(np.arange(40) % 4 == 0, 0.02, 0.4)[None, :]
+        o_obs, o_rew, o_done, o_flags = ora.step(act)
+        g_obs, g_rew, g_done, g_flags = eng.step(torch.from_numpy(act).to(eng.device))
+        eng.sync()
+        g_obs = g_obs.cpu().numpy().astype(np.float64)
+        gfl = g_flags.cpu().numpy().astype(np.uint32)
+        same = (gfl == o_flags) & (g_done.cpu().numpy() == o_done)
+        stats["steps"] += same.size
+        stats["flag_mismatch"] += int((~same).sum())
+        dd = np.abs(g_obs - o_obs)[same]
+        fan = np.zeros(156, dtype=bool)
+        fan[:72] = fan[78:82] = fan[82:154] = True
+        stats["obs"] = max(stats["obs"], float(dd[:, ~fan].max()))
+        stats["grazing"] = stats.get("grazing", 0) + int((dd[:, fan] > OBS_TOL).sum())
+        stats["beams"] = stats.get("beams", 0) + dd[:, fan].size
+        stats["rew"] = max(stats["rew"], float(np.abs(g_rew.cpu().numpy() - o_rew)[same].max()))
+        rep = (o_flags & _abi.F_REPORT) != 0
+        seen["toll_obs"] += int((o_obs[..., -2][rep] > 0).sum())
+        seen["long_stay"] += int((o_obs[..., -1][rep] > 0).sum())
+        seen["building"] += int(((o_flags & _abi.F_CRASH_BUILDING) != 0).sum())
+        f, i, ei = ora.get_state()
+        gf, gi, gei = eng.get_state()
+        seen["int_mismatch"] += int((gi != i).any(axis=0).sum()) + int((gei != ei).any(axis=0).sum())
+        for fld in ("PID_HP", "PID_HI", "PID_LP", "PID_LI"):  # toll bookkeeping (integer-valued floats) must be exact
+            assert (gf[SF[fld]][:, :40] == f[SF[fld]][:, :40].astype(np.float32)).all(), fld
+        seen["entries"] = max(seen["entries"], int((f[SF["PID_HI"]][:, :40] >= 0).sum()))
+        seen["exits"] = max(seen["exits"], int((f[SF["PID_LP"]][:, :40] >= 0).sum()))
+        fast = (f[SF["PID_HI"]][:, :40] >= 0) & (f[SF["PID_LP"]][:, :40] >= 0) & \
+               (f[SF["PID_LP"]][:, :40] - f[SF["PID_HI"]][:, :40] < 30)
+        seen["fast_exit"] = max(seen["fast_exit"], int(fast.sum()))
+        f32 = util.round_state_f32(f)
+        ora.set_state(f32, i, ei)
+        eng.set_state(f32, i, ei)
+    print("tollgate parity:", stats, seen)
+    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] <= 2 and seen["int_mismatch"] <= 2
+    assert stats["grazing"] <= 1e-4 * stats["beams"] + 5
+    assert seen["toll_obs"] > 500 and seen["long_stay"] > 50 and seen["entries"] > 20 and seen["exits"] > 10 and seen["building"] > 10
+    assert seen["fast_exit"] >= 5

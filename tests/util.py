@@ -27,7 +27,7 @@ def round_state_f32(f):
 def make_marl_banks(num_agents=8, n_variants=8, seed=1, capacity=None, kind="roundabout"):
     from pgdrive_amd import mapgen
     d = dict(roundabout=mapgen.generate_ma_roundabout, intersection=mapgen.generate_ma_intersection,
-             bottleneck=mapgen.generate_ma_bottleneck)[kind]()
+             bottleneck=mapgen.generate_ma_bottleneck, tollgate=mapgen.generate_ma_tollgate)[kind]()
     mb = mapdata.MapBank([d])
     sb = scenario.MarlScenarioBank(d, num_agents=num_agents, capacity=capacity, n_variants=n_variants, seed=seed, kind=kind)
     return d, mb, sb
@@ -35,7 +35,7 @@ def make_marl_banks(num_agents=8, n_variants=8, seed=1, capacity=None, kind="rou
 
 def marl_config(n_envs, sb, **kw):
     """MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG (multi_agent_pgdrive.py:12-55): 72 beams / 40 m / 0 others, penalties 10."""
-    args = dict(num_agents=sb.A, num_traffic=0, num_lasers=72, num_others=0, lidar_dist=40.0, multi_agent=True, horizon=1000,
+    args = dict(num_agents=sb.A, num_traffic=sb.B, num_lasers=72, num_others=0, lidar_dist=40.0, multi_agent=True, horizon=1000,
                 agent_limit=sb.num_agents, respawn_places=sb.P, respawn_dests=sb.Dn, out_of_road_penalty=10.0,
                 crash_vehicle_penalty=10.0, crash_object_penalty=10.0, delay_done=25, auto_reset=1)
     args.update(kw)
