@@ -93,6 +93,19 @@ def main_mapjson():
     print("wrote mapjson goldens", {k: [b["id"] for b in v["block_sequence"]] for k, v in out.items()})
 
 
+def main_marl_parking_lot():
+    """MAParkingLotMap (envs/marl_envs/marl_parking_lot.py:92-130) -> tests/golden/ma_parking_lot_v0.json.gz (+ boxes)"""
+    root = os.path.dirname(HERE)
+    m = ref_export.generate_ma_parking_lot()
+    np.savez_compressed(os.path.join(root, "tests", "golden", "boxes_ma_parking_lot.npz"), boxes=m["boxes"])
+    d = strip(m)
+    out = os.path.join(root, "tests", "golden", "ma_parking_lot_v0.json.gz")
+    with gzip.GzipFile(out, "wb", mtime=0) as f:
+        f.write(json.dumps(dict(version=0, source="decisionforce/pgdrive v0.1.4 MAParkingLotMap (8 spaces)", maps=[d]),
+                           separators=(",", ":")).encode())
+    print("wrote", out, os.path.getsize(out), "spaces", len(m["parking_space"]))
+
+
 def main_marl_tollgate():
     """MATollGateMap (envs/marl_envs/marl_tollgate.py:108-160) -> tests/golden/ma_tollgate_v0.json.gz (+ boxes, booths)"""
     root = os.path.dirname(HERE)
@@ -127,7 +140,9 @@ def main_mapgen_goldens():
 
 
 if __name__ == "__main__":
-    if "--tollgate" in sys.argv:
+    if "--parking" in sys.argv:
+        main_marl_parking_lot()
+    elif "--tollgate" in sys.argv:
         main_marl_tollgate()
     elif "--mapjson" in sys.argv:
         main_mapjson()

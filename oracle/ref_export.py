@@ -90,6 +90,29 @@ def generate_ma_roundabout(lane_num=2, lane_width=3.5, exit_length=60):
     return generate(0, lane_num, lane_width, exit_length, prebuilt=(net, _Blocks([first, rb])))
 
 
+def generate_ma_parking_lot(lane_width=3.5, exit_length=20, parking_space_num=8):
+    """MAParkingLotMap._generate (envs/marl_envs/marl_parking_lot.py:92-130)."""
+    from pgdrive.component.blocks.first_block import FirstPGBlock
+    from pgdrive.component.blocks.parking_lot import ParkingLot
+    from pgdrive.component.blocks.t_intersection import TInterSection
+    net = RoadNetwork()
+    pw = refstub.FakePhysicsWorld()
+    first = FirstPGBlock(net, lane_width, 1, None, pw, length=exit_length)
+    lot = ParkingLot(1, first.get_socket(0), net, 1, ignore_intersection_checking=False)
+    assert lot.construct_block(None, pw, {"one_side_vehicle_number": int(parking_space_num / 2)})
+    old = TInterSection.EXIT_PART_LENGTH
+    TInterSection.EXIT_PART_LENGTH = 10
+    try:
+        t = TInterSection(2, lot.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+        assert t.construct_block(None, pw, extra_config={"t_type": 1, "change_lane_num": 0})
+    finally:
+        TInterSection.EXIT_PART_LENGTH = old
+    m = generate(0, 1, lane_width, exit_length, prebuilt=(net, _Blocks([first, lot, t])))
+    m["parking_space"] = [[r.start_node, r.end_node] for r in lot.dest_roads]
+    m["parking_spawn"] = [[r.start_node, r.end_node] for r in lot.spawn_roads]
+    return m
+
+
 def generate_ma_tollgate(lane_num=3, lane_width=3.5, exit_length=70, toll_lane_num=8, toll_length=10, bottle_length=35):
     """MATollGateMap._generate (envs/marl_envs/marl_tollgate.py:108-160); the toll booths spawned through get_engine() are
     recorded (lane, position, heading)."""

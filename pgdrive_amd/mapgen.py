@@ -382,6 +382,27 @@ def create_adverse_road(positive_road, net_get, net_check, ignore=(None, None), 
     return ok
 
 
+def create_two_way_road(road_to_change, net_get, net_check, new_road_name=None, center_line_type=CONTINUOUS, side_type=SIDE,
+                        inner_type=BROKEN, skip=False):
+    """CreateTwoWayRoad (create_block_utils.py:233-295): the same strip of asphalt in the opposite direction under a new
+    road name, so that it can be driven both ways (parking spaces)."""
+    adverse = (road_to_change[1], road_to_change[0]) if new_road_name is None else new_road_name
+    lanes = net_get.lanes(road_to_change)
+    ref = lanes[-1]
+    num = len(lanes)
+    w = ref.width
+    if ref.kind == 0:
+        sym = SLane(ref.position(lanes[-1].length, -(num - 1) * w), ref.position(0, -(num - 1) * w), w, lanes[-1].line_types,
+                    ref.forbidden, ref.speed_limit, ref.priority)
+    else:
+        cw = not (ref.direction == 1)
+        radius = ref.radius + (num - 1) * w if not cw else ref.radius - (num - 1) * w
+        sym = CLane(ref.center, radius, ref.end_phase, ref.start_phase, cw, w, ref.line_types, ref.forbidden,
+                    ref.speed_limit, ref.priority)
+    return create_road_from(sym, num, adverse, net_get, net_check, side_type=side_type, inner_type=inner_type,
+                            center_line_type=center_line_type, skip=skip)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # parameter spaces (utils/space.py:258-306): name -> ("box", min, max) | ("disc", min, max) | ("const", v)
 # ----------------------------------------------------------------------------------------------------------------------
@@ -398,6 +419,7 @@ SPACES = {
     "y": {"length": ("box", 20, 50), "lane_num": ("disc", 1, 2), "bottle_len": ("const", 20)},  # BOTTLENECK_PARAMETER
     "Y": {"length": ("box", 20, 50), "lane_num": ("disc", 1, 2), "bottle_len": ("const", 20)},
     "$": {"length": ("box", 20, 50), "lane_num": ("disc", 1, 2), "bottle_len": ("const", 20)},  # TollGate reuses it
+    "P": {"one_side_vehicle_number": ("disc", 2, 10), "radius": ("const", 4), "length": ("const", 8)},  # PARKING_LOT_PARAMETER
 }
 
 
@@ -1002,6 +1024,106 @@ class TollGate(Block):
         return ok
 
 
+class ParkingLot(Block):
+    """parking_lot.py:13-329: a one-lane two-way road with `one_side_vehicle_number` perpendicular parking spaces on each
+    side; every space has an entry arc from either direction of the main road and exit arcs back to both directions, the
+    space itself is a two-way road (in: nodes 1->2, out: nodes 5->6)."""
+    ID = "P"
+    ANGLE = np.deg2rad(90)
+    SOCKET_LENGTH = 4
+
+    def build(self):
+        self.spawn_roads, self.dest_roads = [], []
+        p = self.config
+        assert self.pos_lane_num == 1, "Lane number of previous block must be 1 in each direction"
+        self.space_length = p["length"]
+        self.space_width = self.lane_width
+        n = int(p["one_side_vehicle_number"])
+        radius = p["radius"]
+        main_len = 2 * radius + (n - 1) * self.space_width
+        main_lane = extend_straight(self.pos_lanes[0], main_len, [BROKEN, NONE])
+        road = (self.pre_socket.pos[1], self.node(0, 0))
+        kw = dict(center_line_type=BROKEN, inner_type=BROKEN, side_type=NONE, center_color=GREY)
+        ok = self.rf(main_lane, self.pos_lane_num, road, **kw)
+        ok = self.ar(road, **kw) and ok
+        out_lane = extend_straight(main_lane, self.SOCKET_LENGTH, [BROKEN, NONE])
+        out_road = (self.node(0, 0), self.node(0, 1))
+        kw2 = dict(center_line_type=BROKEN, inner_type=BROKEN, side_type=SIDE)
+        ok = self.rf(out_lane, self.pos_lane_num, out_road, **kw2) and ok
+        ok = self.ar(out_road, **kw2) and ok
+        sock = Socket(out_road, neg(out_road))
+        self.add_socket(sock)
+        rev = lambda s: Socket(s.neg, s.pos)
+        for i in range(n):
+            ok = self._space(rev(sock), rev(self.pre_socket), i + 1, radius, i * self.space_width,
+                             (n - i - 1) * self.space_width) and ok
+        for i in range(n, 2 * n):
+            j = i - n
+            ok = self._space(self.pre_socket, sock, i + 1, radius, j * self.space_width, (n - j - 1) * self.space_width) and ok
+        return ok
+
+    def _is_pre(self, s):
+        a, b = self.pre_socket.pos, self.pre_socket.neg
+        return (s.pos == a and s.neg == b) or (s.pos == b and s.neg == a)
+
+    def _space(self, in_s, out_s, part, radius, dist_in, dist_out):
+        ok = True
+        none = dict(center_line_type=NONE, inner_type=NONE, side_type=NONE)
+        net = self.gnet if self._is_pre(in_s) else self.net
+        in_lane = net.lanes(in_s.pos)[0]
+        start = in_s.pos[1]
+        if dist_in > 1e-3:
+            in_lane = extend_straight(in_lane, dist_in, [NONE, NONE])
+            self.rf(in_lane, self.pos_lane_num, (in_s.pos[1], self.node(part, 0)), **none)
+            start = self.node(part, 0)
+        bend, straight = create_bend_straight(in_lane, self.space_length, radius, self.ANGLE, True, self.space_width)
+        side_in = SIDE if dist_in < 1e-3 else NONE
+        bend_ok = self.rf(bend, self.pos_lane_num, (start, self.node(part, 1)), center_line_type=NONE, inner_type=NONE,
+                          side_type=side_in)
+        if dist_in < 1e-3:
+            ok = ok and bend_ok
+        space_road = (self.node(part, 1), self.node(part, 2))
+        self.dest_roads.append(space_road)
+        ok = ok and self.rf(straight, self.pos_lane_num, space_road, center_line_type=CONTINUOUS, inner_type=NONE,
+                            side_type=side_in, center_color=GREY)
+        # the second way in, from the other direction of the main road
+        nroad = out_s.neg
+        net = self.gnet if self._is_pre(out_s) else self.net
+        nlane = net.lanes(nroad)[0]
+        start = nroad[1]
+        if dist_out > 1e-3:
+            nlane = extend_straight(nlane, dist_out, [NONE, NONE])
+            self.rf(nlane, self.pos_lane_num, (nroad[1], self.node(part, 3)), **none)
+            start = self.node(part, 3)
+        bend, straight = create_bend_straight(nlane, self.lane_width, radius, self.ANGLE, False, self.space_width)
+        self.rf(bend, self.pos_lane_num, (start, self.node(part, 4)), **none)
+        self.rf(straight, self.pos_lane_num, (self.node(part, 4), self.node(part, 1)), **none)
+        # the space driven outwards is the two-way twin (5 -> 6) of (1 -> 2)
+        park_road = (self.node(part, 5), self.node(part, 6))
+        self.spawn_roads.append(park_road)
+        side_out = SIDE if dist_out < 1e-3 else NONE
+        create_two_way_road(space_road, self.net, self.gnet, park_road, center_line_type=NONE, inner_type=NONE,
+                            side_type=side_out, skip=self.skip)
+        park_lane = self.net.lanes(park_road)[0]
+        bend, straight = create_bend_straight(park_lane, 0.1 if dist_out < 1e-3 else dist_out, radius, self.ANGLE, True,
+                                              park_lane.width)
+        out_bend = (self.node(part, 6), self.node(part, 7) if dist_out > 1e-3 else out_s.pos[0])
+        bend_ok = self.rf(bend, self.pos_lane_num, out_bend, center_line_type=NONE, inner_type=NONE, side_type=side_out)
+        if dist_out < 1e-3:
+            ok = ok and bend_ok
+        if dist_out > 1e-3:
+            ok = ok and self.rf(straight, self.pos_lane_num, (self.node(part, 7), out_s.pos[0]), **none)
+        ext = extend_straight(park_lane, self.lane_width, [NONE, NONE])
+        self.rf(ext, self.pos_lane_num, (self.node(part, 6), self.node(part, 8)), **none)
+        bend, straight = create_bend_straight(ext, 0.1 if dist_in < 1e-3 else dist_in, radius, self.ANGLE, False,
+                                              park_lane.width)
+        out_bend = (self.node(part, 8), self.node(part, 9) if dist_in > 1e-3 else in_s.neg[0])
+        self.rf(bend, self.pos_lane_num, out_bend, **none)
+        if dist_in > 1e-3:
+            self.rf(straight, self.pos_lane_num, (self.node(part, 9), in_s.neg[0]), **none)
+        return ok
+
+
 BLOCK_TYPES = [Curve, Straight, InRamp, OutRamp, Intersection, TIntersection, Roundabout, None, None, None, None, None, None]
 BLOCK_PROBS = [0.3, 0.1, 0.1, 0.1, 0.15, 0.15, 0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
 BY_ID = {c.ID: c for c in BLOCK_TYPES if c is not None}
@@ -1073,7 +1195,7 @@ def generate_from_block_sequence(block_sequence, seed=0, lane_num=3, lane_width=
     """PGMap._config_generate: rebuild a map from its saved block sequence (every block takes its parameters from the
     file, crossing checks are skipped like ignore_intersection_checking=True)."""
     by_id = dict(BY_ID)
-    by_id.update({"y": Merge, "Y": Split, "$": TollGate})
+    by_id.update({"y": Merge, "Y": Split, "$": TollGate, "P": ParkingLot})
     gnet = Net()
     blocks = [FirstBlock(gnet, lane_width, lane_num, exit_length)]
     for k, b in enumerate(block_sequence[1:], 1):
@@ -1166,6 +1288,19 @@ class FullIntersection(Intersection):
     """InterSection proper (intersection.py:15-238): the lane-count change of the crossing road is sampled, not forced to 0."""
     def build(self):
         return self.build_x()
+
+
+def generate_ma_parking_lot(lane_width=3.5, exit_length=20, parking_space_num=8):
+    """MAParkingLotMap._generate (envs/marl_envs/marl_parking_lot.py:92-130): one-lane first block, ParkingLot with
+    parking_space_num / 2 spaces per side, T-intersection (t_type 1, exits 10 m)."""
+    gnet = Net()
+    first = FirstBlock(gnet, lane_width, 1, exit_length)
+    lot = ParkingLot(1, first.get_socket(0), gnet, 1)
+    assert lot.construct(extra_config={"one_side_vehicle_number": int(parking_space_num / 2)})
+    t = TIntersection(2, lot.get_socket(0), gnet, 1)
+    t.EXIT_PART_LENGTH = 10
+    assert t.construct(extra_config={"t_type": 1, "change_lane_num": 0})
+    return to_description(0, gnet, [first, lot, t], 1, lane_width, exit_length)
 
 
 def generate_ma_tollgate(lane_num=3, lane_width=3.5, exit_length=70, toll_lane_num=8, toll_length=10, bottle_length=35):
