@@ -18,7 +18,8 @@ enum {
   SF_PID_HP, SF_PID_HI,       /* IDM heading PID p_error, i_error       PID_controller.py:1-17 */
   SF_PID_LP, SF_PID_LI,       /* IDM lateral PID.  Controlled agents have no PID; under PGD_MA_TOLLGATE the four fields hold
                                  TollGateObservation.in_toll_time and StayTimeManager's entry step, exit step (-1 = none) and
-                                 last block id char (-1 = not seen yet)  marl_tollgate.py:36-60,76-96 */
+                                 last block id char (-1 = not seen yet)  marl_tollgate.py:36-60,76-96; under PGD_MA_PARKING
+                                 SF_PID_HP is 1 + the agent's destination parking space (v_dest_pair), 0 = none */
   SF_TARGET_SPEED,            /* IDMPolicy.target_speed [km/h]          idm_policy.py:182 */
   SF_ENERGY,                  /* energy_consumption                     base_vehicle.py:278-290 */
   SF_DIST_LEFT, SF_DIST_RIGHT,/* dist_to_left_side / right_side         base_vehicle.py:380-388 */
@@ -43,7 +44,8 @@ enum {
   EI_EPISODES,                /* auto-reset count (RNG counter) */
   EI_STEPS_TOTAL,             /* steps since pgd_reset (RNG counter) */
   EI_NEXT_AGENT,              /* next "agent{k}" id (AgentManager.next_agent_count) */
-  EI_SPARE1, EI_SPARE2,
+  EI_AUX,                     /* PGD_MA_PARKING: ParkingLotSpawnManager.parking_space_available as a bit mask */
+  EI_SPARE2,
   PGD_NEI
 };
 enum { ST_EMPTY = 0, ST_PENDING = 1, ST_ACTIVE = 2, ST_REMOVED = 3, ST_DYING = 4 /* finished agent, static, counting down */ };

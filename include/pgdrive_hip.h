@@ -123,7 +123,8 @@ typedef struct pgd_spawn {  /* 64 B + route */
   int16_t timer0;           /* IDMPolicy.overtake_timer initial value (idm_policy.py:185) */
   int16_t dest_lane;        /* Navigation.final_lane (navigation.py:138-140) */
   int16_t kind;             /* PGD_OBJ_*: what occupies the slot */
-  int16_t pad[2];
+  int16_t aux;              /* PGD_MA_PARKING: 1 + index of the parking space this vehicle drives to (0 = none) */
+  int16_t pad;
   int16_t ckpt[PGD_MAX_CKPT];       /* route as node ids (Navigation.checkpoints) */
   int16_t ckpt_road[PGD_MAX_CKPT];  /* road id of (ckpt[k], ckpt[k+1]); -1 past the end */
 } pgd_spawn;
@@ -143,7 +144,7 @@ typedef struct pgd_scenario {
   int32_t n_groups;         /* number of traffic trigger groups */
   int16_t trigger_road[16]; /* BlockVehicles.trigger_road per group, in activation order (traffic_manager.py:283-288) */
   int32_t max_steps;        /* auto_termination: 250 * map.num_blocks (base_env.py:318); 0 = off */
-  int32_t pad;
+  int32_t aux;              /* PGD_MA_PARKING: bit k = parking space k is nobody's destination at reset */
 } pgd_scenario;
 
 typedef struct pgd_config {
@@ -186,6 +187,9 @@ typedef struct pgd_config {
   /* MultiAgentTollgateEnv (envs/marl_envs/marl_tollgate.py), read when PGD_MA_TOLLGATE is set */
   float overspeed_penalty;  /* 0.5: reward = -penalty * speed / max_speed while too fast inside the toll block */
   int32_t min_pass_steps;   /* 30: an agent that crossed the toll block in fewer steps is terminated (out_of_road) */
+  int32_t enable_reverse;   /* vehicle_config.enable_reverse (base_vehicle.py:366-376) for the controlled agents: negative
+                               throttle drives backwards instead of braking (parking-lot env) */
+  int32_t pad;
 } pgd_config;
 
 #define PGD_MA_ENABLED        1  /* MultiAgentPGDrive semantics: per-agent done, delay-done queue, respawn, __all__ */
@@ -196,6 +200,10 @@ typedef struct pgd_config {
                                     negative road when the vehicle is off its reference lanes */
 #define PGD_MA_TOLLGATE      64  /* MultiAgentTollgateEnv: toll reward / out-of-road / stay-time rules, observation without the
                                     navigation block plus 2 toll floats (marl_tollgate.py:63-105,195-270) */
+#define PGD_MA_PARKING      128  /* MultiAgentParkingLotEnv (marl_parking_lot.py:39-90,160-222): destinations of agents entering
+                                    from a road are parking spaces handed out from a per-env pool (released when the agent
+                                    is done); a road place is respawned into only while a space is free; out-of-road =
+                                    yellow line / off lane / sidewalk (white lines may be crossed) */
 #define PGD_MA_YELLOW_OK     32  /* cross_yellow_line_done = False (marl_bottleneck.py:130-136): a yellow line is not
                                     out-of-road */
 

@@ -15,6 +15,7 @@ class PgdConfig(C.Structure):
         ("lane_line_lasers", C.c_int32), ("lane_line_dist", C.c_float), ("discrete_action", C.c_int32),
         ("discrete_steering_dim", C.c_int32), ("discrete_throttle_dim", C.c_int32), ("increment_steering", C.c_int32),
         ("safe_rl_env", C.c_int32), ("overspeed_penalty", C.c_float), ("min_pass_steps", C.c_int32),
+        ("enable_reverse", C.c_int32), ("pad", C.c_int32),
     ]
 
 
@@ -26,7 +27,7 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
                 respawn_dests=0, side_lasers=0, side_dist=50.0, lane_line_lasers=0, lane_line_dist=20.0,
                 discrete_action=False, discrete_steering_dim=5, discrete_throttle_dim=5, increment_steering=False,
                 safe_rl_env=False, plain_reward=False, cross_yellow_line_done=True, tollgate=False, overspeed_penalty=0.5,
-                min_pass_steps=30):
+                min_pass_steps=30, enable_reverse=False, parking=False):
     """Defaults mirror PGDriveEnv_DEFAULT_CONFIG / BASE_DEFAULT_CONFIG (pgdrive_env.py:22-109, base_env.py:19-90)."""
     c = PgdConfig()
     c.num_envs, c.num_agents, c.num_traffic = num_envs, num_agents, num_traffic
@@ -42,10 +43,12 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
     c.discrete_action, c.increment_steering = int(bool(discrete_action)), int(bool(increment_steering))
     c.discrete_steering_dim, c.discrete_throttle_dim = int(discrete_steering_dim), int(discrete_throttle_dim)
     c.safe_rl_env = int(bool(safe_rl_env))
+    c.enable_reverse = int(bool(enable_reverse))
     if multi_agent:
         c.marl_flags = MA_ENABLED | (MA_CRASH_DONE if crash_done else 0) | (MA_OUT_ROAD_DONE if out_of_road_done else 0) | \
             (MA_ALLOW_RESPAWN if allow_respawn else 0) | (MA_PLAIN_REWARD if plain_reward else 0) | \
-            (0 if cross_yellow_line_done else MA_YELLOW_OK) | (MA_TOLLGATE if tollgate else 0)
+            (0 if cross_yellow_line_done else MA_YELLOW_OK) | (MA_TOLLGATE if tollgate else 0) | \
+            (MA_PARKING if parking else 0)
         c.overspeed_penalty, c.min_pass_steps = float(overspeed_penalty), int(min_pass_steps)
         c.delay_done, c.agent_limit = int(delay_done), int(agent_limit or num_agents)
         c.respawn_places, c.respawn_dests = int(respawn_places), int(respawn_dests)
@@ -63,10 +66,11 @@ SF = dict(X=0, Y=1, THETA=2, SPEED=3, STEER=4, THROTTLE=5, LASTX=6, LASTY=7, LAS
           ACT1S=12, ACT1T=13, PID_HP=14, PID_HI=15, PID_LP=16, PID_LI=17, TARGET_SPEED=18, ENERGY=19, DIST_LEFT=20,
           DIST_RIGHT=21, EP_REWARD=22, AGENT_ID=23)
 SI = dict(STATUS=0, LANE=1, CK0=2, CK1=3, RLANE=4, TIMER=5, VFLAGS=6, SPAWN=7)
-EI = dict(SCEN=0, NEXT_GROUP=1, EP_STEPS=2, EPISODES=3, STEPS_TOTAL=4, NEXT_AGENT=5)
+EI = dict(SCEN=0, NEXT_GROUP=1, EP_STEPS=2, EPISODES=3, STEPS_TOTAL=4, NEXT_AGENT=5, AUX=6)
 NF, NI, NEI = 24, 8, 8
 ST_EMPTY, ST_PENDING, ST_ACTIVE, ST_REMOVED, ST_DYING = 0, 1, 2, 3, 4
 MA_ENABLED, MA_CRASH_DONE, MA_OUT_ROAD_DONE, MA_ALLOW_RESPAWN, MA_PLAIN_REWARD, MA_YELLOW_OK, MA_TOLLGATE = 1, 2, 4, 8, 16, 32, 64
+MA_PARKING = 128
 
 F_ARRIVE, F_OUT_OF_ROAD, F_CRASH_VEHICLE, F_CRASH_OBJECT, F_CRASH_BUILDING, F_MAX_STEP = 1, 2, 4, 8, 16, 32
 F_ON_YELLOW, F_ON_WHITE, F_ON_BROKEN, F_CRASH_SIDEWALK, F_OFF_LANE, F_OUT_OF_ROUTE = 256, 512, 1024, 2048, 4096, 8192

@@ -97,7 +97,9 @@ DEV void store_veh(const PgdDev& d, int e, int s, const Veh& r) {
   for (int k = 0; k < 8; ++k) dst[k] = src[k];
 }
 
-DEV float speed_kmh(float v) { return clipf(v * 3.6f, 0.0f, 100000.0f); }  // base_vehicle.py:394-401
+// base_vehicle.py:394-401; the magnitude: a reversing vehicle has a negative speed field, and BaseVehicle.velocity is this
+// magnitude times the FORWARD vector even then (base_vehicle.py:419-425)
+DEV float speed_kmh(float v) { return clipf(fabsf(v) * 3.6f, 0.0f, 100000.0f); }
 
 // env snapshot in LDS (one entry per lane of the wave)
 struct Snap {
@@ -578,12 +580,14 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
 
 // kinematic bicycle (component/highway_vehicle/kinematics.py:134-156) driven by the reference's action -> force mapping
 // (base_vehicle.py:343-376); see DESIGN.md §3 for the substitution of Bullet's raycast vehicle.
-DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r) {
+DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse) {
   float dt = d.cfg.dt;
-  float force = 0.0f, brake;
+  float force = 0.0f, brake = 0.0f;
   if (r.thr >= 0.0f) {
     brake = 2.0f;
-    force = (r.v * 3.6f > p.max_speed) ? 0.0f : p.max_engine_force * r.thr;
+    force = (fabsf(r.v) * 3.6f > p.max_speed) ? 0.0f : p.max_engine_force * r.thr;
+  } else if (reverse) {  // enable_reverse: engine force backwards, no brake (base_vehicle.py:370-373)
+    force = p.max_engine_force * r.thr;
   } else {
     brake = fabsf(r.thr) * p.max_brake_force;
   }
@@ -608,8 +612,8 @@ DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r) {
     sd = sd * cs + cd * sn;
     cd = ncd;
     if (force != 0.0f) r.v += dv_engine;
-    else r.v = fmaxf(0.0f, r.v - dv_brake);
-    r.v = fmaxf(r.v, 0.0f);
+    else r.v = r.v >= 0.0f ? fmaxf(0.0f, r.v - dv_brake) : fminf(0.0f, r.v + dv_brake);
+    if (!reverse) r.v = fmaxf(r.v, 0.0f);
   }
   // heading unit vector = motion direction rotated back by beta, renormalised
   float hx = cd * cb + sd * sb, hy = sd * cb - cd * sb;
@@ -622,7 +626,7 @@ DEV void reset_vehicle(const pgd_spawn& p, Veh& r, int spawn_index, bool is_agen
   memset(&r, 0, sizeof(Veh));
   // agents have no PID state: under PGD_MA_TOLLGATE the fields carry in_toll_time = 0 and entry / exit / last block = none
   // (marl_tollgate.py:36-60,76-96); harmless otherwise
-  if (is_agent) { r.phi = -1.0f; r.plp = -1.0f; r.pli = -1.0f; }
+  if (is_agent) { r.php = (float)p.aux; r.phi = -1.0f; r.plp = -1.0f; r.pli = -1.0f; }  // php: parking destination / toll time
   r.spawn = spawn_index;
   r.rlane = is_agent ? 0 : -1;  // agents: episode length; traffic: IDMPolicy.routing_target_lane = None
   r.hx = 1.0f;
@@ -669,6 +673,7 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
   lane_local(fl, r.x, r.y, lon, lat);
   bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - ctx.cur_n) * w);
   unsigned oor_bits = (g.marl_flags & PGD_MA_TOLLGATE) ? PGD_F_CRASH_SIDEWALK  // marl_tollgate.py:234-240
+                      : (g.marl_flags & PGD_MA_PARKING) ? (PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK)  // marl_parking_lot.py:213-217
                                                         : (PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK);
   if (!(g.marl_flags & PGD_MA_YELLOW_OK)) oor_bits |= PGD_F_ON_YELLOW;
   bool oor = (vf & oor_bits) != 0;
@@ -938,6 +943,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   __shared__ int s_flag[WAVE];
   __shared__ int s_hit[WAVE];  // per snapshot slot: an agent's chassis overlaps another vehicle
   __shared__ int s_pf[WAVE];   // landing zone of the warm-up loads
+  __shared__ int s_aux;        // multi-agent parking lot: pool of free parking spaces (bit mask)
   __shared__ int s_kind[WAVE]; // PGD_OBJ_* of every slot (fused observation: objects are lidar targets, not neighbours)
   const int V = d.V, A = d.A, N = d.N;
   const int lane = threadIdx.x;
@@ -1083,7 +1089,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     r.steer = (s < A && d.cfg.increment_steering) ? clipf(r.steer + st * 0.05f, -1.0f, 1.0f) : st;
     r.thr = tb;
     // (4) physics
-    dynamics(d, *sp, r);
+    dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0);
     PHASE_MARK(3);  // dynamics
   }
   __syncthreads();
@@ -1156,6 +1162,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // ---- multi-agent tail: multi_agent_pgdrive.py:109-213, agent_manager.py:134-175, spawn_manager.py:160-215 ----
     const pgd_config& gcf = d.cfg;
     const bool toll = (gcf.marl_flags & PGD_MA_TOLLGATE) != 0;
+    const bool parking = (gcf.marl_flags & PGD_MA_PARKING) != 0;
+    if (parking && lane == 0) s_aux = d.ei[(size_t)blockIdx.x * PGD_NEI + EI_AUX];  // parking_space_available
+    if (parking) __syncthreads();
     if (valid && s < A && was_active) {
       if (toll && ctx.blk == '$') r.php += 1.0f;  // TollGateObservation.observe counts its calls inside the toll block
       my_rew = reward_done(d, mv, *sp, r, ctx, my_fl, my_dn);
@@ -1170,6 +1179,10 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       if (gcf.horizon > 0 && r.rlane >= gcf.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
       r.eprew += my_rew;
       my_fl |= PGD_F_REPORT;
+      if (my_dn && parking && r.php > 0.0f) {  // ParkingLotSpawnManager.after_vehicle_done: its space is free again
+        if (leader) atomicOr(&s_aux, 1 << ((int)r.php - 1));
+        r.php = 0.0f;
+      }
       if (my_dn) {  // AgentManager.finish
         if (arrive || gcf.delay_done <= 0) r.status = ST_EMPTY;
         else { r.status = ST_DYING; r.timer = gcf.delay_done; }
@@ -1202,8 +1215,19 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         if (em == 0ull) break;
         const int src = __builtin_ffsll((long long)em) - 1;
         const int tslot = (src / d.sub) % V;
-        const int dest = (int)(pgd_rng(gcf.seed, (uint32_t)blockIdx.x, 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
-                               (uint32_t)gcf.respawn_dests);
+        int dest = (int)(pgd_rng(gcf.seed, (uint32_t)blockIdx.x, 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
+                         (uint32_t)gcf.respawn_dests);
+        if (parking) {  // get_parking_space: a random one of the free spaces; none -> nobody enters from a road
+          const unsigned mask = (unsigned)s_aux & ((1u << gcf.respawn_dests) - 1u);
+          if (__ballot(mask != 0u) == 0ull) break;
+          int pick = (int)(pgd_rng(gcf.seed, (uint32_t)blockIdx.x, 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
+                           (uint32_t)__popc(mask));
+          dest = 0;
+          for (int b = 0; b < 32; ++b)
+            if (mask & (1u << b)) { if (pick-- == 0) { dest = b; break; } }
+          __syncthreads();  // everybody has read the pool before lane 0 takes the space out
+          if (lane == 0) s_aux &= ~(1 << dest);
+        }
         if (valid && s == tslot) {
           const int sidx = V + p * gcf.respawn_dests + dest;
           sp = d.spawns + (size_t)scen * d.sstride + sidx;
@@ -1238,6 +1262,10 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       if (gcf.auto_reset) { my_fl |= PGD_F_RESET; s_flag[el] = 1; }
     }
     if (lane == 0) d.ei[(size_t)blockIdx.x * PGD_NEI + EI_NEXT_AGENT] = next_agent;
+    if (parking) {
+      __syncthreads();
+      if (lane == 0) d.ei[(size_t)blockIdx.x * PGD_NEI + EI_AUX] = s_aux;
+    }
   }
   __syncthreads();
   PHASE_MARK(6);  // reward/done
@@ -1268,6 +1296,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
       d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] = episodes;
       d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_AGENT] = A == 1 ? 1 : __popcll(am);
+      d.ei[(size_t)(e) * PGD_NEI + EI_AUX] = sc->aux;  // parking: the pool of the new episode
     }
   }
   if (valid && leader && s < A) {
@@ -1349,6 +1378,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restr
   store_veh(d, e, s, r);
   if (s == 0) {
     d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_AGENT] = A == 1 ? 1 : __popcll(am);
+    d.ei[(size_t)(e) * PGD_NEI + EI_AUX] = d.scen[scen].aux;  // parking: free spaces of the new episode
     d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
     d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP] = 0;
     d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS] = 0;

@@ -326,7 +326,7 @@ def build_grid(boxes, cell=8.0, margin=0.05):
 # ----------------------------------------------------------------------------------------------------------------------
 # packing
 # ----------------------------------------------------------------------------------------------------------------------
-def pack_lanes(desc, succ):
+def pack_lanes(desc, succ, truncate_succ=False):
     n = len(desc["lanes"])
     out = np.zeros(n, dtype=LANE_DT)
     for i, l in enumerate(desc["lanes"]):
@@ -346,7 +346,11 @@ def pack_lanes(desc, succ):
         r["road"], r["index"] = l["road"], l["index"]
         s = succ[i]
         if len(s) > MAX_SUCC:
-            raise ValueError("lane %d has %d successors > PGD_MAX_SUCC" % (i, len(s)))
+            # the successor list only feeds the IDM traffic (neighbour search, routing): maps without IDM traffic (the
+            # multi-agent parking lot: 9 ways out of one lane) may drop the surplus
+            if not truncate_succ:
+                raise ValueError("lane %d has %d successors > PGD_MAX_SUCC" % (i, len(s)))
+            s = s[:MAX_SUCC]
         r["n_succ"] = len(s)
         r["succ"][:] = -1
         r["succ"][:len(s)] = s
@@ -376,7 +380,7 @@ def pack_boxes(boxes):
 
 class MapBank:
     """Concatenated device tables for a list of map descriptions."""
-    def __init__(self, descs, cell=8.0):
+    def __init__(self, descs, cell=8.0, truncate_succ=False):
         self.descs = list(descs)
         maps = np.zeros(len(self.descs), dtype=MAP_DT)
         lanes, roads, boxes, cstart, citems = [], [], [], [], []
@@ -385,7 +389,7 @@ class MapBank:
         for m, d in enumerate(self.descs):
             succ = build_successors(d)
             self.succ.append(succ)
-            L = pack_lanes(d, succ)
+            L = pack_lanes(d, succ, truncate_succ)
             R = pack_roads(d)
             bx = build_boxes(d)
             B = pack_boxes(bx)

@@ -52,6 +52,7 @@ class MultiAgentRoundaboutVecEnv:
     DEFAULTS = MA_DEFAULT_CONFIG
     PLAIN_REWARD = False
     TOLLGATE = False
+    PARKING = False
 
     @staticmethod
     def _generate_map(mc):
@@ -65,7 +66,7 @@ class MultiAgentRoundaboutVecEnv:
         if lid["num_others"] != 0:
             raise NotImplementedError("LidarStateObservationMARound with num_others > 0 is not built (reference default 0)")
         self.desc = self._generate_map(c["map_config"])
-        self.map_bank = mapdata.MapBank([self.desc])
+        self.map_bank = mapdata.MapBank([self.desc], truncate_succ=True)  # no IDM traffic on the multi-agent maps
         cap = c["max_agents"] or c["num_agents"]
         self.scen_bank = scenario.MarlScenarioBank(self.desc, c["num_agents"], capacity=cap,
                                                    n_variants=c["spawn_variants"], seed=c["seed"], kind=self.MAP_KIND)
@@ -83,7 +84,8 @@ class MultiAgentRoundaboutVecEnv:
             side_lasers=sd["num_lasers"] if sd["distance"] > 0 else 0, side_dist=sd["distance"],
             lane_line_lasers=ld["num_lasers"] if ld["distance"] > 0 else 0, lane_line_dist=ld["distance"],
             plain_reward=self.PLAIN_REWARD, cross_yellow_line_done=c["cross_yellow_line_done"], tollgate=self.TOLLGATE,
-            overspeed_penalty=c.get("overspeed_penalty", 0.5), min_pass_steps=c["vehicle_config"].get("min_pass_steps", 30)
+            overspeed_penalty=c.get("overspeed_penalty", 0.5), min_pass_steps=c["vehicle_config"].get("min_pass_steps", 30),
+            parking=self.PARKING, enable_reverse=c["vehicle_config"].get("enable_reverse", False)
         )
         from .engine import Engine
         self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])
@@ -163,6 +165,35 @@ class MultiAgentTollgateVecEnv(MultiAgentRoundaboutVecEnv):
         from . import mapgen
         return mapgen.generate_ma_tollgate(mc["lane_num"], mc["lane_width"], mc["exit_length"], mc["toll_lane_num"],
                                            mc["toll_length"])
+
+
+class MultiAgentParkingLotVecEnv(MultiAgentRoundaboutVecEnv):
+    """MultiAgentParkingLotEnv (marl_parking_lot.py:15-222) batched: a one-lane road through a lot with 8 perpendicular
+    parking spaces and a T-intersection behind it, 10 agents that can reverse; agents entering from a road drive to a free
+    parking space, agents starting in a space leave through a random access road."""
+    MAP_KIND = "parking"
+    PARKING = True
+    DEFAULTS = dict(
+        MA_DEFAULT_CONFIG, num_agents=10, parking_space_num=8, map_config=dict(exit_length=20, lane_width=3.5, lane_num=1),
+        vehicle_config=dict(lidar=dict(num_lasers=72, distance=40, num_others=0), side_detector=dict(num_lasers=0, distance=50),
+                            lane_line_detector=dict(num_lasers=0, distance=20), enable_reverse=True),
+    )
+
+    @staticmethod
+    def _generate_map(mc):
+        from . import mapgen
+        assert mc["lane_num"] == 1, "the parking lot needs a one-lane road (parking_lot.py:29)"
+        return mapgen.generate_ma_parking_lot(mc["lane_width"], mc["exit_length"], mc.get("parking_space_num", 8))
+
+    def __init__(self, config=None):
+        cfg = dict(config or {})
+        n = cfg.get("parking_space_num", 8)
+        assert n % 2 == 0 and n >= 4, "number of parking spaces must be a multiple of 2, at least 4"  # marl_parking_lot.py:146-147
+        mc = dict(cfg.get("map_config", {}))
+        mc["parking_space_num"] = n
+        cfg["map_config"] = mc
+        self.DEFAULTS = dict(self.DEFAULTS, map_config=dict(self.DEFAULTS["map_config"], parking_space_num=8))
+        super().__init__(cfg)
 
 
 class MultiAgentRoundaboutEnv:
@@ -249,3 +280,8 @@ class MultiAgentBottleneckEnv(MultiAgentRoundaboutEnv):
 class MultiAgentTollgateEnv(MultiAgentRoundaboutEnv):
     """Dict protocol on the toll plaza map (marl_tollgate.py:163-279)."""
     VEC = MultiAgentTollgateVecEnv
+
+
+class MultiAgentParkingLotEnv(MultiAgentRoundaboutEnv):
+    """Dict protocol on the parking-lot map (marl_parking_lot.py:133-222)."""
+    VEC = MultiAgentParkingLotVecEnv

@@ -27,12 +27,12 @@ SPAWN_DT = np.dtype(
         ("x", "<f4"), ("y", "<f4"), ("heading", "<f4"), ("length", "<f4"), ("width", "<f4"), ("wheelbase", "<f4"),
         ("mass", "<f4"), ("max_engine_force", "<f4"), ("max_brake_force", "<f4"), ("friction", "<f4"),
         ("max_steer", "<f4"), ("max_speed", "<f4"), ("lane", "<i2"), ("group", "<i2"), ("n_ckpt", "<i2"),
-        ("timer0", "<i2"), ("dest_lane", "<i2"), ("kind", "<i2"), ("pad", "<i2", (2, )), ("ckpt", "<i2", (MAX_CKPT, )),
+        ("timer0", "<i2"), ("dest_lane", "<i2"), ("kind", "<i2"), ("aux", "<i2"), ("pad", "<i2"), ("ckpt", "<i2", (MAX_CKPT, )),
         ("ckpt_road", "<i2", (MAX_CKPT, ))
     ]
 )
 SCEN_DT = np.dtype([("map", "<i4"), ("n_groups", "<i4"), ("trigger_road", "<i2", (MAX_GROUPS, )), ("max_steps", "<i4"),
-                    ("pad", "<i4")])
+                    ("aux", "<i4")])
 assert SPAWN_DT.itemsize == 64 + 4 * MAX_CKPT and SCEN_DT.itemsize == 16 + 2 * MAX_GROUPS
 
 # vehicle_type.py:7-74 (L, W, front+rear wheelbase, mass) and utils/space.py:219-255
@@ -567,13 +567,80 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
     return scen, recs, P, Dn, B
 
 
+def parking_lot_roads(desc):
+    """MAParkingLotConfig (marl_parking_lot.py:15-24,139-152): the three roads leading into the lot, the parking spaces
+    driven outwards (spawn roads 1P{i}_5_ -> 1P{i}_6_) and inwards (destinations 1P{i}_1_ -> 1P{i}_2_)."""
+    n = desc["nodes"]
+    in_roads = [(n.index(">>"), n.index(">>>")), neg_road(desc, n.index("2T0_0_"), n.index("2T0_1_")),
+                neg_road(desc, n.index("2T2_0_"), n.index("2T2_1_"))]
+    k = 1
+    out_roads, spaces = [], []
+    while "1P%d_5_" % k in n:
+        out_roads.append((n.index("1P%d_5_" % k), n.index("1P%d_6_" % k)))
+        spaces.append((n.index("1P%d_1_" % k), n.index("1P%d_2_" % k)))
+        k += 1
+    return in_roads, out_roads, spaces
+
+
+def build_parking_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle_model="default"):
+    """ParkingLotSpawnManager (marl_parking_lot.py:39-90) on top of SpawnManager.reset (spawn_manager.py:72-101): agents
+    start on the three access roads or inside parking spaces; one that starts on a road is handed a free parking space as
+    destination (distinct spaces), one that starts in a space drives out through a random access road.  The respawn table
+    holds [access-road place][parking space]: upstream never re-fills the spaces themselves (its availability test
+    compares the out-direction spawn road with the in-direction destination roads and so never succeeds)."""
+    A = capacity or num_agents
+    in_roads, out_roads, spaces = parking_lot_roads(desc)
+    slots, safe = spawn_slots(desc, in_roads + out_roads)
+    if num_agents > len(slots):
+        raise ValueError("Too many agents! We only accept %d agents" % len(slots))
+    S = len(spaces)
+    places = [c for c in safe if c["road"] in in_roads]
+    P, Dn = len(places), S
+    recs = np.zeros(A + P * Dn, dtype=SPAWN_DT)
+    recs["lane"] = -1
+    recs["group"] = -1
+    avail = list(range(S))
+    pick = rng.choice(len(slots), num_agents, replace=False)
+    lo, la = RESPAWN_REGION_LONGITUDE - MAX_VEHICLE_LENGTH, RESPAWN_REGION_LATERAL - MAX_VEHICLE_WIDTH
+    for a, idx in enumerate(pick):
+        c = slots[int(idx)]
+        lon = c["long"] + rng.uniform(-lo / 2, lo / 2)
+        lat = c["lat"] + rng.uniform(-la / 2, la / 2)
+        params = sample_vehicle_params(vehicle_model, int(rng.randint(0, MAX_RAND_INT)))
+        _fill_vehicle(recs[a], desc, c["lane"], lon, lat, params)
+        if c["road"] in in_roads:  # update_destination_for -> get_parking_space
+            if not avail:
+                raise ValueError("more agents on the access roads than parking spaces")
+            k = avail.pop(int(rng.randint(0, len(avail))))
+            _fill_route(recs[a], desc, c["lane"], spaces[k][1])
+            recs[a]["aux"] = k + 1
+        else:
+            road = in_roads[int(rng.randint(0, len(in_roads)))]
+            _fill_route(recs[a], desc, c["lane"], neg_road(desc, *road)[1])
+    for p, c in enumerate(places):
+        for k in range(S):
+            r = recs[A + p * Dn + k]
+            params = sample_vehicle_params(vehicle_model, int(rng.randint(0, MAX_RAND_INT)))
+            _fill_vehicle(r, desc, c["lane"], c["long"], c["lat"], params)
+            _fill_route(r, desc, c["lane"], spaces[k][1])
+            r["aux"] = k + 1
+    scen = np.zeros((), dtype=SCEN_DT)
+    scen["map"] = map_index
+    scen["trigger_road"][:] = -1
+    scen["aux"] = sum(1 << k for k in avail)
+    return scen, recs, P, Dn, 0
+
+
 class MarlScenarioBank:
     """`n_variants` random initial placements over one multi-agent map (scenarios differ only in spawn choice)."""
     def __init__(self, desc, num_agents, capacity=None, n_variants=16, seed=0, kind="roundabout"):
         rng = np.random.RandomState(seed)
         scens, recs = [], []
         for _ in range(n_variants):
-            sc, rc, self.P, self.Dn, self.B = build_marl_scenario(desc, 0, rng, num_agents, capacity, kind=kind)
+            if kind == "parking":
+                sc, rc, self.P, self.Dn, self.B = build_parking_scenario(desc, 0, rng, num_agents, capacity)
+            else:
+                sc, rc, self.P, self.Dn, self.B = build_marl_scenario(desc, 0, rng, num_agents, capacity, kind=kind)
             scens.append(sc)
             recs.append(rc)
         self.scenarios = np.array(scens, dtype=SCEN_DT)

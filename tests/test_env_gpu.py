@@ -109,14 +109,15 @@ def test_checkpoint_resume_roundtrip():
         env.close()
 
 
-@pytest.mark.parametrize("kind", ["roundabout", "intersection", "bottleneck", "tollgate"])
+@pytest.mark.parametrize("kind", ["roundabout", "intersection", "bottleneck", "tollgate", "parking"])
 def test_marl_dict_protocol(kind):
     """Key-set invariants of the reference's MARL tests (tests/test_env/test_ma_roundabout_env.py:73-200,
     test_marl_reborn.py:6-60): obs/reward/done/info share keys, finished agents disappear, newcomers get fresh
     increasing ids, -penalty => done, __all__ ends the episode."""
     from pgdrive_amd import marl_env
     cls = dict(roundabout=marl_env.MultiAgentRoundaboutEnv, intersection=marl_env.MultiAgentIntersectionEnv,
-               bottleneck=marl_env.MultiAgentBottleneckEnv, tollgate=marl_env.MultiAgentTollgateEnv)[kind]
+               bottleneck=marl_env.MultiAgentBottleneckEnv, tollgate=marl_env.MultiAgentTollgateEnv,
+               parking=marl_env.MultiAgentParkingLotEnv)[kind]
     env = cls(dict(num_agents=8, horizon=150, seed=2))
     D = dict(bottleneck=96, tollgate=156).get(kind, 90)  # bottleneck: 4 side + 6 + 4 lane-line + 10 navi + 72 beams
     try:

@@ -493,3 +493,10 @@ def test_marl_tollgate_parity():
     assert stats["grazing"] <= 1e-4 * stats["beams"] + 5
     assert seen["toll_obs"] > 500 and seen["long_stay"] > 50 and seen["entries"] > 20 and seen["exits"] > 10 and seen["building"] > 10
     assert seen["fast_exit"] >= 5
+
+
+def test_marl_parking_lot_parity():
+    """MultiAgentParkingLotEnv (envs/marl_envs/marl_parking_lot.py): ParkingLot block, reverse driving (enable_reverse),
+    destinations handed out from the pool of free parking spaces (released when an agent is done, respawn from the access
+    roads only while a space is free), white lines may be crossed."""
+    test_marl_roundabout_parity(10, 10, kind="parking", parking=True, enable_reverse=True)

@@ -27,8 +27,9 @@ def round_state_f32(f):
 def make_marl_banks(num_agents=8, n_variants=8, seed=1, capacity=None, kind="roundabout"):
     from pgdrive_amd import mapgen
     d = dict(roundabout=mapgen.generate_ma_roundabout, intersection=mapgen.generate_ma_intersection,
-             bottleneck=mapgen.generate_ma_bottleneck, tollgate=mapgen.generate_ma_tollgate)[kind]()
-    mb = mapdata.MapBank([d])
+             bottleneck=mapgen.generate_ma_bottleneck, tollgate=mapgen.generate_ma_tollgate,
+             parking=mapgen.generate_ma_parking_lot)[kind]()
+    mb = mapdata.MapBank([d], truncate_succ=True)  # no IDM traffic on the multi-agent maps
     sb = scenario.MarlScenarioBank(d, num_agents=num_agents, capacity=capacity, n_variants=n_variants, seed=seed, kind=kind)
     return d, mb, sb
 
