@@ -189,7 +189,8 @@ typedef struct pgd_config {
   int32_t min_pass_steps;   /* 30: an agent that crossed the toll block in fewer steps is terminated (out_of_road) */
   int32_t enable_reverse;   /* vehicle_config.enable_reverse (base_vehicle.py:366-376) for the controlled agents: negative
                                throttle drives backwards instead of braking (parking-lot env) */
-  int32_t pad;
+  int32_t random_agent_model; /* 1: two more state floats, LENGTH / 10 and WIDTH / 2.5, after the lane-line fan
+                               (state_obs.py:21-22,102-105); the vehicle type itself comes with the spawn record */
 } pgd_config;
 
 #define PGD_MA_ENABLED        1  /* MultiAgentPGDrive semantics: per-agent done, delay-done queue, respawn, __all__ */
@@ -209,7 +210,7 @@ typedef struct pgd_config {
 
 typedef struct pgd_engine* pgd_handle;
 
-/* Size of one observation row D = (side_lasers or 2) + 6 + lane_line_lasers + 10 + 4*num_others + num_lasers
+/* Size of one observation row D = (side_lasers or 2) + 6 + lane_line_lasers [+ 2 if random_agent_model] + 10 + 4*num_others + num_lasers
  * (obs/state_obs.py:17-23,108-114,124-130); 274 at the defaults.  With PGD_MA_TOLLGATE the 10 navigation floats are
  * absent and 2 toll floats follow the lidar (marl_tollgate.py:63-105). */
 int pgd_obs_dim(const pgd_config* cfg);

@@ -522,12 +522,14 @@ def gen_detectors(maps):
                 det.perceive = (lambda det_: lambda v, world, detector_mask=None: types.SimpleNamespace(
                     cloud_points=exact_fan(det_, v.position[0], v.position[1], v.heading_theta, m["boxes"])))(det)
                 setattr(ego, attr, det)
+            ram = rep % 3 == 0  # random_agent_model: LENGTH / MAX_LENGTH and WIDTH / MAX_WIDTH follow the lane-line fan
+            ego.MAX_LENGTH, ego.MAX_WIDTH = BaseVehicle.MAX_LENGTH, BaseVehicle.MAX_WIDTH
             sobs = StateObservation.__new__(StateObservation)
-            sobs.config = {"random_agent_model": False}
+            sobs.config = {"random_agent_model": ram}
             state = [float(x) for x in StateObservation.vehicle_state(sobs, ego)]
-            assert len(state) == (ks or 2) + 6 + km
+            assert len(state) == (ks or 2) + 6 + km + (2 if ram else 0)
             cases.append(dict(
-                seed=m["seed"], side=[ks, ds], lane_line=[km, dm], state=state, left=left, right=right,
+                seed=m["seed"], side=[ks, ds], lane_line=[km, dm], state=state, left=left, right=right, random_agent_model=ram,
                 vehicles=[dict(x=p[0], y=p[1], theta=ego.heading_theta, speed_kmh=ego.speed, length=4.51, width=1.852,
                                lane=lane_ids[id(el)], ckpt=[nodes.index(n) for n in ckpt], idx=idx)],
                 ego=dict(steering=ego.steering, act0=list(ego.last_current_action[0]),
@@ -578,8 +580,11 @@ def gen_traffic(maps):
             out.append(row)
     finally:
         idm_mod.IDMPolicy = real_idm
+    # AgentManager._get_vehicles with random_agent_model (agent_manager.py:63-73): random_vehicle_type on the manager's
+    # stream, seeded with the episode seed
+    agent_types = {str(s): names[vt_mod.random_vehicle_type(get_np_random(s))] for s in range(1000, 1030)}
     with open(os.path.join(ROOT, "tests", "golden", "traffic_v0.json"), "w") as f:
-        json.dump(dict(maps=out), f)
+        json.dump(dict(maps=out, random_agent_types=agent_types), f)
     print("wrote traffic goldens:", [(r["seed"], len(r["respawn_0.1"]), sum(len(g["vehicles"]) for g in r["trigger_0.1"]))
                                      for r in out])
 

@@ -798,7 +798,12 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   // Row layout: [side fan k | 2 lateral distances][6 ego floats][lane-line fan m][10 navi][4*NO neighbours][NL beams]
   const int KS = d.cfg.side_lasers, KM = d.cfg.lane_line_lasers;
   const bool toll = (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;  // no navigation block, 2 toll floats after the lidar
-  const int o_ego = KS > 0 ? KS : 2, o_navi = o_ego + 6 + KM, o_oth = o_navi + (toll ? 0 : 10);
+  const int RAM = d.cfg.random_agent_model ? 2 : 0;  // LENGTH / 10, WIDTH / 2.5 after the lane-line fan (state_obs.py:102-105)
+  const int o_ego = KS > 0 ? KS : 2, o_navi = o_ego + 6 + KM + RAM, o_oth = o_navi + (toll ? 0 : 10);
+  if (RAM && tid == nt - 1) {
+    row[o_ego + 6 + KM] = clipf(sp.length / 10.0f, 0.0f, 1.0f);
+    row[o_ego + 6 + KM + 1] = clipf(sp.width / 2.5f, 0.0f, 1.0f);
+  }
   if (toll && tid == 0) {  // TollGateObservation.observe (marl_tollgate.py:84-96)
     const bool in_toll = ag.blk == '$';
     float* t2 = row + o_oth + 4 * d.cfg.num_others + NL;
@@ -1530,8 +1535,8 @@ const char* pgd_version(void) { return "pgdrive_hip 0.1 (gfx950)"; }
 
 int pgd_obs_dim(const pgd_config* c) {
   const int toll = (c->marl_flags & PGD_MA_TOLLGATE) != 0;
-  return (c->side_lasers > 0 ? c->side_lasers : 2) + 6 + c->lane_line_lasers + (toll ? 0 : PGD_NAVI_DIM) + 4 * c->num_others +
-         c->num_lasers + (toll ? 2 : 0);
+  return (c->side_lasers > 0 ? c->side_lasers : 2) + 6 + c->lane_line_lasers + (c->random_agent_model ? 2 : 0) +
+         (toll ? 0 : PGD_NAVI_DIM) + 4 * c->num_others + c->num_lasers + (toll ? 2 : 0);
 }
 
 int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* out) {

@@ -288,7 +288,8 @@ def propose_traffic(desc, seed, density, skip_lanes=(), type_draws=0):
 
 def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=0.1, spawn_lane=None,
                    spawn_longitude=5.0, spawn_lateral=0.0, vehicle_model="default", agent_spawns=None,
-                   traffic_mode="trigger", traffic_seed=None, auto_termination=False, accident_prob=0.0):
+                   traffic_mode="trigger", traffic_seed=None, auto_termination=False, accident_prob=0.0,
+                   random_agent_model=False):
     """One scenario = V = num_agents + num_traffic spawn slots for map `desc` under global seed `seed`."""
     V = num_agents + num_traffic
     scen = np.zeros((), dtype=SCEN_DT)
@@ -313,6 +314,9 @@ def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=
             r = desc["roads"][rl[(desc["nodes"].index(">"), desc["nodes"].index(">>"))]]
             spawn_lane = r["first_lane"] + 0
         agent_spawns = [dict(lane=spawn_lane, long=spawn_longitude, lat=spawn_lateral, dest=None)] * num_agents
+    if random_agent_model:  # AgentManager._get_vehicles (agent_manager.py:63-73): ONE type draw per episode from the
+        # agent manager's own stream (seeded with the episode seed), uniform over s / m / l / xl / default
+        vehicle_model = TYPE_KEYS[int(get_np_random(seed).choice(len(TYPE_KEYS), p=[1 / len(TYPE_KEYS)] * len(TYPE_KEYS)))]
     for a in range(num_agents):
         sp = agent_spawns[a]
         obj_seed = int(engine_rng.randint(0, MAX_RAND_INT))

@@ -27,6 +27,7 @@ DEFAULT_CONFIG = dict(
     discrete_steering_dim=5,
     discrete_throttle_dim=5,
     max_traffic_vehicles=16,  # slot cap per env (the reference has no cap)
+    random_agent_model=False,  # a random vehicle type per episode + its LENGTH / WIDTH in the observation (base_env.py:29)
     accident_prob=0.0,  # TrafficObjectManager (object_manager.py:40-124) when the env registers it (SafePGDriveEnv)
     max_traffic_objects=40,  # extra slots for cones / tripods / barriers / broken-down vehicles when accident_prob > 0
     safe_rl_env=False,  # SafePGDriveEnv.done_function: crashes are not terminal (safe_pgdrive_env.py:49-56)
@@ -107,6 +108,7 @@ class PGDriveVecEnv:
             sel, seeds, num_agents=1, num_traffic=T, density=c["traffic_density"],
             spawn_longitude=vc["spawn_longitude"], spawn_lateral=vc["spawn_lateral"], vehicle_model=vc["vehicle_model"],
             traffic_mode=c["traffic_mode"], auto_termination=c["auto_termination"], accident_prob=c["accident_prob"],
+            random_agent_model=c["random_agent_model"],
             traffic_seeds=np.random.RandomState(c["seed"]).randint(0, scenario.MAX_RAND_INT, len(seeds))
             if c["random_traffic"] else None
         )
@@ -124,7 +126,7 @@ class PGDriveVecEnv:
             lane_line_lasers=ld["num_lasers"] if ld["distance"] > 0 else 0, lane_line_dist=ld["distance"],
             discrete_action=c["discrete_action"], discrete_steering_dim=c["discrete_steering_dim"],
             discrete_throttle_dim=c["discrete_throttle_dim"], increment_steering=vc["increment_steering"],
-            safe_rl_env=c["safe_rl_env"]
+            safe_rl_env=c["safe_rl_env"], random_agent_model=c["random_agent_model"]
         )
         from .engine import Engine
         self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])

@@ -188,11 +188,13 @@ def test_side_and_lane_line_detectors(L, descs):
     worst, flips, total = 0.0, 0, 0
     for sc in cases:
         (ks, ds), (km, dm) = sc["side"], sc["lane_line"]
-        o, f, i, ei, d = _scene_engine(descs, sc, side_lasers=ks, side_dist=ds, lane_line_lasers=km, lane_line_dist=dm)
+        ram = sc.get("random_agent_model", False)
+        o, f, i, ei, d = _scene_engine(descs, sc, side_lasers=ks, side_dist=ds, lane_line_lasers=km, lane_line_dist=dm,
+                                       random_agent_model=ram)
         f[SF["DIST_LEFT"], 0, 0], f[SF["DIST_RIGHT"], 0, 0] = sc["left"], sc["right"]
         o.set_state(f, i, ei)
         obs = o.observe()[0, 0]
-        n = (ks or 2) + 6 + km
+        n = (ks or 2) + 6 + km + (2 if ram else 0)
         assert obs.shape[0] == n + 10 + 16 + 240 and len(sc["state"]) == n
         dl = np.abs(obs[:n] - np.array(sc["state"]))
         bad = dl > 2e-6

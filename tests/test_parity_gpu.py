@@ -21,14 +21,15 @@ def _engines(descs, n_envs, n_maps=8, **kw):
     from oracle import orc
     from pgdrive_amd.engine import Engine
     mb, sb = util.make_banks(descs, n_maps=n_maps, **{k: v for k, v in kw.items() if k in (
-        "num_agents", "num_traffic", "density", "traffic_mode", "auto_termination", "accident_prob")})
+        "num_agents", "num_traffic", "density", "traffic_mode", "auto_termination", "accident_prob", "random_agent_model")})
     cfg = _abi.make_config(n_envs, num_agents=kw.get("num_agents", 1), num_traffic=kw.get("num_traffic", 16),
                            num_lasers=kw.get("num_lasers", 240), auto_reset=kw.get("auto_reset", 1),
                            side_lasers=kw.get("side_lasers", 0), side_dist=kw.get("side_dist", 50.0),
                            lane_line_lasers=kw.get("lane_line_lasers", 0), lane_line_dist=kw.get("lane_line_dist", 20.0),
                            discrete_action=kw.get("discrete_action", False),
                            increment_steering=kw.get("increment_steering", False), horizon=kw.get("horizon", 0),
-                           safe_rl_env=kw.get("safe_rl_env", False), num_others=kw.get("num_others", 4))
+                           safe_rl_env=kw.get("safe_rl_env", False), num_others=kw.get("num_others", 4),
+                           random_agent_model=kw.get("random_agent_model", False))
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
     ora.map_bank, ora.scen_bank = mb, sb
@@ -115,9 +116,10 @@ def test_side_and_lane_line_detector_parity(descs, side, lane_line, num_lasers):
     """SideDetector / LaneLineDetector fans (distance_detector.py:137-152) spliced into the state block
     (state_obs.py:64-71,96-105): device grid walk vs the oracle's brute force over every line box."""
     n_envs = 64
+    ram = num_lasers == 16  # one of the configurations also runs with random_agent_model (vehicle type + 2 state floats)
     torch, eng, ora, cfg = _engines(descs, n_envs, num_lasers=num_lasers, side_lasers=side[0], side_dist=side[1],
-                                    lane_line_lasers=lane_line[0], lane_line_dist=lane_line[1])
-    assert eng.D == (side[0] or 2) + 6 + lane_line[0] + 10 + 4 * cfg.num_others + num_lasers
+                                    lane_line_lasers=lane_line[0], lane_line_dist=lane_line[1], random_agent_model=ram)
+    assert eng.D == (side[0] or 2) + 6 + lane_line[0] + (2 if ram else 0) + 10 + 4 * cfg.num_others + num_lasers
     scen_ids = np.arange(n_envs) % 8
     o0 = ora.reset(scen_ids)
     g0 = eng.reset(scen_ids).cpu().numpy()

@@ -155,3 +155,19 @@ def test_object_proposals_match_reference_manager():
         mine = [[[v["lane"], v["long"], v["vtype"], v["policy_seed"]] for v in g["vehicles"]] for g in groups]
         assert mine == c["traffic_0_2"]
     assert n_obj > 250 and n_veh >= 3
+
+
+def test_random_agent_model_type_draw(descs):
+    """AgentManager._get_vehicles (agent_manager.py:63-73): one uniform vehicle-type draw per episode from the manager's
+    stream; the ego's record then carries that type's dimensions."""
+    with open(os.path.join(GOLD, "traffic_v0.json")) as f:
+        types = json.load(f)["random_agent_types"]
+    from pgdrive_amd import bank
+    seen = set()
+    for seed, vt in types.items():
+        d = bank.get_descriptions([int(seed)])[0]
+        sc, sp, info = scenario.build_scenario(d, 0, int(seed), 1, 4, 0.1, random_agent_model=True)
+        assert abs(float(sp[0]["length"]) - scenario.VEHICLE_TYPES[vt]["length"]) < 1e-6, (seed, vt)
+        assert abs(float(sp[0]["width"]) - scenario.VEHICLE_TYPES[vt]["width"]) < 1e-6
+        seen.add(vt)
+    assert len(seen) >= 4
