@@ -189,6 +189,10 @@ typedef struct pgd_config {
   int32_t min_pass_steps;   /* 30: an agent that crossed the toll block in fewer steps is terminated (out_of_road) */
   int32_t enable_reverse;   /* vehicle_config.enable_reverse (base_vehicle.py:366-376) for the controlled agents: negative
                                throttle drives backwards instead of braking (parking-lot env) */
+  /* LidarStateObservation._add_noise_to_cloud_points (state_obs.py:172-182): beams <- clip(beam + N(0, sigma), 0, 1), then
+   * 0 with probability dropout.  The reference draws from the global numpy RNG; here a counter-based stream of
+   * (seed, env, agent, beam, step) -- same distribution, reproducible */
+  float lidar_gaussian_noise, lidar_dropout_prob;
   int32_t random_agent_model; /* 1: two more state floats, LENGTH / 10 and WIDTH / 2.5, after the lane-line fan
                                (state_obs.py:21-22,102-105); the vehicle type itself comes with the spawn record */
 } pgd_config;

@@ -770,6 +770,8 @@ struct AgentView {  // what the observation needs from the observing vehicle
   int cur_first, cur_n, next_first;  // RouteCtx of the vehicle
   int blk;                           // block id char of its current road
   float toll_time;                   // TollGateObservation.in_toll_time (PGD_MA_TOLLGATE)
+  int env, slot;                     // for the lidar noise stream
+  uint32_t tick;                     // steps since pgd_reset
 };
 
 // one wave compacts the candidates: lane `o` brings vehicle o of the env (present = in the physics world)
@@ -893,6 +895,18 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
     float best = 1.0f;
     for (int k = 0; k < n; ++k)
       best = fminf(best, shape_ray<OBJ>(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
+    if (d.cfg.lidar_gaussian_noise > 0.0f || d.cfg.lidar_dropout_prob > 0.0f) {  // state_obs.py:172-182
+      const uint32_t key = 0x51d0a000u + (uint32_t)ag.slot * 1024u + (uint32_t)i;
+      if (d.cfg.lidar_gaussian_noise > 0.0f) {
+        const float u1 = ((float)(pgd_rng(d.cfg.seed, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(pgd_rng(d.cfg.seed ^ 0x9e3779b9u, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        best = clipf(best + d.cfg.lidar_gaussian_noise * sqrtf(-2.0f * logf(u1)) * cosf(2.0f * PGD_PI * u2), 0.0f, 1.0f);
+      }
+      if (d.cfg.lidar_dropout_prob > 0.0f) {
+        const float u3 = ((float)(pgd_rng(d.cfg.seed ^ 0x7f4a7c15u, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        if (u3 < d.cfg.lidar_dropout_prob) best = 0.0f;
+      }
+    }
     row[o_oth + 4 * NO + i] = best;
   }
   PHASE_MARK(24);  // obs: lidar
@@ -1337,6 +1351,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         ag.steer = r.steer; ag.a0s = r.a0s; ag.a0t = r.a0t; ag.lhx = r.lasthx; ag.lhy = r.lasthy;
         ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
         ag.blk = ctx.blk; ag.toll_time = r.php;
+        ag.env = e; ag.slot = s; ag.tick = steps_total;
       }
     }
     __syncthreads();
@@ -1474,6 +1489,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
   const RouteCtx ctx = route_ctx(mv, msp, mine.i[SI_CK0], mine.i[SI_CK1]);
   ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
   ag.blk = ctx.blk; ag.toll_time = mine.f[SF_PID_HP];
+  ag.env = e; ag.slot = a; ag.tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
   observe_agent<true>(d, mv, msp, ag, L, row, tid, BLOCK);
 }
 

@@ -80,9 +80,8 @@ class PGDriveVecEnv:
         self.config = merge_config(DEFAULT_CONFIG, config)
         c = self.config
         vc = c["vehicle_config"]
-        for det in ("lidar", "side_detector", "lane_line_detector"):
-            if vc[det]["gaussian_noise"] or vc[det]["dropout_prob"]:
-                raise NotImplementedError(det + " noise / dropout (0 in the reference defaults) is not built")
+        # (the noise keys of the side / lane-line detectors exist upstream but are never read: only the lidar cloud is
+        # perturbed, state_obs.py:155-170)
         mc = c["map_config"]
         seeds = list(range(c["start_seed"], c["start_seed"] + c["environment_num"]))
         if c["map_bank"] is not None:  # pre-generated descriptions (load_map_from_json, pgdrive_env.py:38-39)
@@ -126,7 +125,8 @@ class PGDriveVecEnv:
             lane_line_lasers=ld["num_lasers"] if ld["distance"] > 0 else 0, lane_line_dist=ld["distance"],
             discrete_action=c["discrete_action"], discrete_steering_dim=c["discrete_steering_dim"],
             discrete_throttle_dim=c["discrete_throttle_dim"], increment_steering=vc["increment_steering"],
-            safe_rl_env=c["safe_rl_env"], random_agent_model=c["random_agent_model"]
+            safe_rl_env=c["safe_rl_env"], random_agent_model=c["random_agent_model"],
+            lidar_gaussian_noise=lid["gaussian_noise"], lidar_dropout_prob=lid["dropout_prob"]
         )
         from .engine import Engine
         self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])

@@ -72,3 +72,32 @@ def test_oracle_multithreaded_step_is_identical(descs):
             assert np.array_equal(x, y)
     a.close()
     b.close()
+
+
+def test_lidar_noise_and_dropout_statistics(descs):
+    """LidarStateObservation._add_noise_to_cloud_points (state_obs.py:172-182): clip(beam + N(0, sigma), 0, 1), then zero with
+    probability dropout -- checked on the oracle as a distribution (the reference draws from the global numpy RNG)."""
+    from oracle import orc
+    from tests import util
+    mb, sb = util.make_banks(descs, n_maps=4, num_traffic=0)
+    clean = orc.Oracle(_abi.make_config(64, num_agents=1, num_traffic=0, num_lasers=240), mb, sb)
+    noisy = orc.Oracle(_abi.make_config(64, num_agents=1, num_traffic=0, num_lasers=240, lidar_gaussian_noise=0.05,
+                                        lidar_dropout_prob=0.1, seed=5), mb, sb)
+    ids = np.arange(64) % 4
+    a = clean.reset(ids)[:, 0, -240:]
+    b = noisy.reset(ids)[:, 0, -240:]
+    assert (a == 1.0).all()  # no traffic: every beam misses
+    dropped = b == 0.0
+    assert abs(dropped.mean() - 0.1) < 0.01
+    kept = b[~dropped]
+    # clip(1 + N(0, 0.05), 0, 1): half of the mass sits at 1, the rest is the lower half-normal
+    assert abs((kept == 1.0).mean() - 0.5) < 0.02
+    low = 1.0 - kept[kept < 1.0]
+    assert abs(low.mean() - 0.05 * np.sqrt(2 / np.pi)) < 0.002 and abs(np.sqrt((low ** 2).mean()) - 0.05) < 0.002
+    again = noisy.reset(ids)[:, 0, -240:]
+    assert np.array_equal(again, b)  # same (seed, env, agent, beam, step) -> same draw
+    act = np.zeros((64, 1, 2), dtype=np.float32)
+    c = noisy.step(act)[0][:, 0, -240:]
+    assert not np.array_equal(c, b)  # a new step draws afresh
+    clean.close()
+    noisy.close()

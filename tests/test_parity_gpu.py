@@ -29,7 +29,9 @@ def _engines(descs, n_envs, n_maps=8, **kw):
                            discrete_action=kw.get("discrete_action", False),
                            increment_steering=kw.get("increment_steering", False), horizon=kw.get("horizon", 0),
                            safe_rl_env=kw.get("safe_rl_env", False), num_others=kw.get("num_others", 4),
-                           random_agent_model=kw.get("random_agent_model", False))
+                           random_agent_model=kw.get("random_agent_model", False),
+                           lidar_gaussian_noise=kw.get("lidar_gaussian_noise", 0.0),
+                           lidar_dropout_prob=kw.get("lidar_dropout_prob", 0.0), seed=kw.get("seed", 0))
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
     ora.map_bank, ora.scen_bank = mb, sb
@@ -256,6 +258,27 @@ def test_traffic_objects_parity(descs, safe):
     assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] <= 2
     assert n_hit_state >= 8 and stats["n_crash_object"] >= 8
     assert stats.get("grazing", 0) <= 1e-5 * stats.get("beams", 1) + 3
+
+
+def test_lidar_noise_parity(descs):
+    """Lidar noise / dropout (state_obs.py:172-182) from the counter-based stream: device and oracle draw the same numbers."""
+    n_envs = 32
+    torch, eng, ora, cfg = _engines(descs, n_envs, lidar_gaussian_noise=0.05, lidar_dropout_prob=0.1, seed=77)
+    scen_ids = np.arange(n_envs) % 8
+    o0 = ora.reset(scen_ids)
+    g0 = eng.reset(scen_ids).cpu().numpy()
+    assert (np.abs(g0 - o0) > OBS_TOL).sum() <= 2 and (o0[:, 0, -240:] == 0.0).mean() > 0.05
+    rng = np.random.default_rng(8)
+    stats = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
+    for t in range(60):
+        act = util.driving_actions(rng, n_envs)
+        _compare_step(torch, eng, ora, act, stats)
+        f, i, ei = ora.get_state()
+        f32 = util.round_state_f32(f)
+        ora.set_state(f32, i, ei)
+        eng.set_state(f32, i, ei)
+    print("noise parity:", stats)
+    assert stats["obs"] < OBS_TOL and stats["flag_mismatch"] == 0 and stats["grazing"] <= 1e-4 * stats["beams"] + 3
 
 
 def test_maximum_sizes(descs):
