@@ -525,3 +525,13 @@ def test_marl_parking_lot_parity():
     destinations handed out from the pool of free parking spaces (released when an agent is done, respawn from the access
     roads only while a space is free), white lines may be crossed."""
     test_marl_roundabout_parity(10, 10, kind="parking", parking=True, enable_reverse=True)
+
+
+@pytest.mark.parametrize("kind,kw", [("intersection", {}), ("bottleneck", dict(plain_reward=True, side_lasers=4, side_dist=50.0,
+                                                                               lane_line_lasers=4, lane_line_dist=20.0)),
+                                     ("parking", dict(parking=True, enable_reverse=True)), ("tollgate", dict(TOLL))])
+def test_marl_eight_agents_parity(kind, kw):
+    """Every multi-agent map once more with 8 agents (few slots, quick respawn turnover).  (Fusing the multi-agent
+    observation into k_step for <= 8 slots was built and measured: 93.9 us fused vs 41 + 57 us separate at 4096 envs x 8
+    agents -- no gain, the 8 rows are serial in one wave -- so the stand-alone k_observe stays.)"""
+    test_marl_roundabout_parity(8, 8, kind=kind, **kw)
