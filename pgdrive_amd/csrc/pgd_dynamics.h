@@ -1,0 +1,120 @@
+// pgd_dynamics.h -- bicycle dynamics, vehicle reset, reward / done.
+// Part of the single translation unit pgd_engine.hip (included there, in this order, after pgd_device.h).
+#ifndef PGD_DYNAMICS_H
+#define PGD_DYNAMICS_H
+
+// kinematic bicycle (component/highway_vehicle/kinematics.py:134-156) driven by the reference's action -> force mapping
+// (base_vehicle.py:343-376); see DESIGN.md §3 for the substitution of Bullet's raycast vehicle.
+DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse) {
+  float dt = d.cfg.dt;
+  float force = 0.0f, brake = 0.0f;
+  if (r.thr >= 0.0f) {
+    brake = 2.0f;
+    force = (fabsf(r.v) * 3.6f > p.max_speed) ? 0.0f : p.max_engine_force * r.thr;
+  } else if (reverse) {  // enable_reverse: engine force backwards, no brake (base_vehicle.py:370-373)
+    force = p.max_engine_force * r.thr;
+  } else {
+    brake = fabsf(r.thr) * p.max_brake_force;
+  }
+  float delta = -clipf(r.steer, -1.0f, 1.0f) * p.max_steer;
+  // beta = atan(t), t = tan(delta)/2  ->  cos(beta) = 1/sqrt(1+t^2), sin(beta) = t/sqrt(1+t^2)
+  float t = 0.5f * tanf(delta);
+  float cb = 1.0f / sqrtf(1.0f + t * t), sb = t * cb;
+  // unit vector of the motion direction th + beta, advanced by exact small-angle rotations instead of sincos per sub-step
+  float cd = r.hx * cb - r.hy * sb, sd = r.hy * cb + r.hx * sb;
+  float inv_half_base = 2.0f / p.wheelbase;
+  float dv_brake = fminf(4.0f * brake / p.mass, p.friction * 9.81f * dt);
+  float dv_engine = 4.0f * force / p.mass * dt;
+  for (int k = 0; k < d.cfg.decision_repeat; ++k) {
+    r.x += r.v * cd * dt;
+    r.y += r.v * sd * dt;
+    float dth = r.v * sb * inv_half_base * dt;  // |dth| < 0.25 rad at 80 km/h and full lock
+    r.th += dth;
+    float q = dth * dth;
+    float sn = dth * (1.0f + q * (-1.0f / 6.0f + q * (1.0f / 120.0f + q * (-1.0f / 5040.0f))));
+    float cs = 1.0f + q * (-0.5f + q * (1.0f / 24.0f + q * (-1.0f / 720.0f + q * (1.0f / 40320.0f))));
+    float ncd = cd * cs - sd * sn;
+    sd = sd * cs + cd * sn;
+    cd = ncd;
+    if (force != 0.0f) r.v += dv_engine;
+    else r.v = r.v >= 0.0f ? fmaxf(0.0f, r.v - dv_brake) : fminf(0.0f, r.v + dv_brake);
+    if (!reverse) r.v = fmaxf(r.v, 0.0f);
+  }
+  // heading unit vector = motion direction rotated back by beta, renormalised
+  float hx = cd * cb + sd * sb, hy = sd * cb - cd * sb;
+  float inv = 1.0f / sqrtf(hx * hx + hy * hy);
+  r.hx = hx * inv;
+  r.hy = hy * inv;
+}
+
+DEV void reset_vehicle(const pgd_spawn& p, Veh& r, int spawn_index, bool is_agent) {  // base_vehicle.py:292-339
+  memset(&r, 0, sizeof(Veh));
+  // agents have no PID state: under PGD_MA_TOLLGATE the fields carry in_toll_time = 0 and entry / exit / last block = none
+  // (marl_tollgate.py:36-60,76-96); harmless otherwise
+  if (is_agent) { r.php = (float)p.aux; r.phi = -1.0f; r.plp = -1.0f; r.pli = -1.0f; }  // php: parking destination / toll time
+  r.spawn = spawn_index;
+  r.rlane = is_agent ? 0 : -1;  // agents: episode length; traffic: IDMPolicy.routing_target_lane = None
+  r.hx = 1.0f;
+  if (p.lane < 0) { r.status = ST_EMPTY; return; }
+  r.status = p.group == -1 ? ST_ACTIVE : ST_PENDING;  // PGD_GROUP_NEVER (-2): in the world, never driven
+  r.x = p.x; r.y = p.y; r.th = p.heading;
+  r.lastx = p.x; r.lasty = p.y;
+  sincosf(p.heading, &r.lasthy, &r.lasthx);
+  r.hx = r.lasthx; r.hy = r.lasthy;
+  r.target = 30.0f;
+  r.lane = p.lane;
+  r.ck0 = 0;
+  r.ck1 = p.n_ckpt > 2 ? 1 : 0;
+  r.timer = p.timer0;
+}
+
+// reward / done: envs/pgdrive_env.py:162-258, base_vehicle.py:738-745
+DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const Veh& r, const RouteCtx& ctx,
+                      unsigned& flags_out, bool& done_out) {
+  const pgd_config& g = d.cfg;
+  unsigned vf = (unsigned)r.vflags;
+  const pgd_lane& VL = mv.lanes[r.lane];
+  bool in_ref = VL.road == ctx.road_cur;
+  const pgd_lane& cl = in_ref ? VL : mv.lanes[ctx.cur_first];
+  float positive = (in_ref || (g.marl_flags & PGD_MA_PLAIN_REWARD)) ? 1.0f : (mv.roads[VL.road].negative ? -1.0f : 1.0f);
+  float l0, t0, l1, t1;
+  lane_local(cl, r.lastx, r.lasty, l0, t0);
+  lane_local(cl, r.x, r.y, l1, t1);
+  float w = mv.m->lane_width;
+  float lateral_factor = g.use_lateral ? clipf(1.0f - 2.0f * fabsf(t1) / w, 0.0f, 1.0f) : 1.0f;
+  float reward = g.driving_reward * (l1 - l0) * lateral_factor * positive;
+  if (g.marl_flags & PGD_MA_TOLLGATE) {  // MultiAgentTollgateEnv.reward_function (marl_tollgate.py:195-232)
+    if (ctx.blk == '$') {
+      // BaseVehicle.overspeed (base_vehicle.py:759-761): lane.speed_limit (3 on toll lanes, 1000 elsewhere) < speed [km/h]
+      const bool lane_toll = mv.roads[VL.road].block_id == '$';
+      if (lane_toll && 3.0f < speed_kmh(r.v)) reward = -g.overspeed_penalty * speed_kmh(r.v) / sp.max_speed;
+    } else reward += g.speed_reward * (speed_kmh(r.v) / sp.max_speed);
+  } else
+  reward += g.speed_reward * (speed_kmh(r.v) / sp.max_speed) * positive;
+  unsigned out = vf & (PGD_F_ON_YELLOW | PGD_F_ON_WHITE | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OFF_LANE |
+                       PGD_F_OUT_OF_ROUTE | PGD_F_CRASH_VEHICLE | PGD_F_CRASH_OBJECT | PGD_F_CRASH_BUILDING);
+  const pgd_lane& fl = mv.lanes[sp.dest_lane];
+  float lon, lat;
+  lane_local(fl, r.x, r.y, lon, lat);
+  bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - ctx.cur_n) * w);
+  unsigned oor_bits = (g.marl_flags & PGD_MA_TOLLGATE) ? PGD_F_CRASH_SIDEWALK  // marl_tollgate.py:234-240
+                      : (g.marl_flags & PGD_MA_PARKING) ? (PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK)  // marl_parking_lot.py:213-217
+                                                        : (PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK);
+  if (!(g.marl_flags & PGD_MA_YELLOW_OK)) oor_bits |= PGD_F_ON_YELLOW;
+  bool oor = (vf & oor_bits) != 0;
+  if (g.out_of_route_done) oor = oor || (vf & PGD_F_OUT_OF_ROUTE);
+  bool crash = (vf & PGD_F_CRASH_VEHICLE) != 0, crash_obj = (vf & PGD_F_CRASH_OBJECT) != 0;
+  if (arrive) out |= PGD_F_ARRIVE;
+  if (oor) out |= PGD_F_OUT_OF_ROAD;
+  if (arrive) reward = g.success_reward;
+  else if (oor) reward = -g.out_of_road_penalty;
+  else if (crash) reward = -g.crash_vehicle_penalty;
+  else if (crash_obj) reward = -g.crash_object_penalty;
+  flags_out = out;
+  done_out = arrive || oor || crash || crash_obj || (vf & PGD_F_CRASH_BUILDING) != 0;  // pgdrive_env.py:162-194
+  // SafePGDriveEnv.done_function (safe_pgdrive_env.py:49-56): a step with crash_vehicle, else crash_object, is not terminal
+  if (g.safe_rl_env && (crash || crash_obj)) done_out = false;
+  return reward;
+}
+
+#endif

@@ -51,866 +51,11 @@ __shared__ long long s_prof_t0, s_prof_w0;
 #define PHASE_END()
 #endif
 
-// ---------------------------------------------------------------------------------------------------------------------
-// per-lane vehicle registers
-// ---------------------------------------------------------------------------------------------------------------------
-struct Veh {
-  float x, y, th, v, steer, thr, lastx, lasty, lasthx, lasthy, a0s, a0t, a1s, a1t, php, phi, plp, pli, target, energy,
-      dl, dr, eprew;
-  int status, lane, ck0, ck1, rlane, timer, vflags, spawn;
-  float agent_id;
-  float hx, hy;  // unit heading (cos, sin of th): derived, kept in registers, never stored
-};
-
-DEV void load_veh(const PgdDev& d, int e, int s, Veh& r) {
-  VehRec t;
-  const uint4* src = reinterpret_cast<const uint4*>(d.rec + (size_t)e * d.V + s);
-  uint4* dst = reinterpret_cast<uint4*>(&t);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) dst[k] = src[k];
-  r.x = t.f[SF_X]; r.y = t.f[SF_Y]; r.th = t.f[SF_THETA]; r.v = t.f[SF_SPEED];
-  r.steer = t.f[SF_STEER]; r.thr = t.f[SF_THROTTLE];
-  r.lastx = t.f[SF_LASTX]; r.lasty = t.f[SF_LASTY]; r.lasthx = t.f[SF_LASTHX]; r.lasthy = t.f[SF_LASTHY];
-  r.a0s = t.f[SF_ACT0S]; r.a0t = t.f[SF_ACT0T]; r.a1s = t.f[SF_ACT1S]; r.a1t = t.f[SF_ACT1T];
-  r.php = t.f[SF_PID_HP]; r.phi = t.f[SF_PID_HI]; r.plp = t.f[SF_PID_LP]; r.pli = t.f[SF_PID_LI];
-  r.target = t.f[SF_TARGET_SPEED]; r.energy = t.f[SF_ENERGY];
-  r.dl = t.f[SF_DIST_LEFT]; r.dr = t.f[SF_DIST_RIGHT]; r.eprew = t.f[SF_EP_REWARD];
-  r.status = t.i[SI_STATUS]; r.lane = t.i[SI_LANE]; r.ck0 = t.i[SI_CK0]; r.ck1 = t.i[SI_CK1];
-  r.rlane = t.i[SI_RLANE]; r.timer = t.i[SI_TIMER]; r.vflags = t.i[SI_VFLAGS]; r.spawn = t.i[SI_SPAWN];
-  r.agent_id = t.f[SF_AGENT_ID];
-  sincosf(r.th, &r.hy, &r.hx);
-}
-DEV void store_veh(const PgdDev& d, int e, int s, const Veh& r) {
-  VehRec t;
-  t.f[SF_X] = r.x; t.f[SF_Y] = r.y; t.f[SF_THETA] = r.th; t.f[SF_SPEED] = r.v;
-  t.f[SF_STEER] = r.steer; t.f[SF_THROTTLE] = r.thr;
-  t.f[SF_LASTX] = r.lastx; t.f[SF_LASTY] = r.lasty; t.f[SF_LASTHX] = r.lasthx; t.f[SF_LASTHY] = r.lasthy;
-  t.f[SF_ACT0S] = r.a0s; t.f[SF_ACT0T] = r.a0t; t.f[SF_ACT1S] = r.a1s; t.f[SF_ACT1T] = r.a1t;
-  t.f[SF_PID_HP] = r.php; t.f[SF_PID_HI] = r.phi; t.f[SF_PID_LP] = r.plp; t.f[SF_PID_LI] = r.pli;
-  t.f[SF_TARGET_SPEED] = r.target; t.f[SF_ENERGY] = r.energy;
-  t.f[SF_DIST_LEFT] = r.dl; t.f[SF_DIST_RIGHT] = r.dr; t.f[SF_EP_REWARD] = r.eprew; t.f[SF_AGENT_ID] = r.agent_id;
-  t.i[SI_STATUS] = r.status; t.i[SI_LANE] = r.lane; t.i[SI_CK0] = r.ck0; t.i[SI_CK1] = r.ck1;
-  t.i[SI_RLANE] = r.rlane; t.i[SI_TIMER] = r.timer; t.i[SI_VFLAGS] = r.vflags; t.i[SI_SPAWN] = r.spawn;
-  uint4* dst = reinterpret_cast<uint4*>(d.rec + (size_t)e * d.V + s);
-  const uint4* src = reinterpret_cast<const uint4*>(&t);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) dst[k] = src[k];
-}
-
-// base_vehicle.py:394-401; the magnitude: a reversing vehicle has a negative speed field, and BaseVehicle.velocity is this
-// magnitude times the FORWARD vector even then (base_vehicle.py:419-425)
-DEV float speed_kmh(float v) { return clipf(fabsf(v) * 3.6f, 0.0f, 100000.0f); }
-
-// env snapshot in LDS (one entry per lane of the wave)
-struct Snap {
-  float x[WAVE], y[WAVE], ux[WAVE], uy[WAVE], spd[WAVE], hl[WAVE], hw[WAVE];
-  int lane[WAVE], present[WAVE];
-  // for the IDM neighbour search: each vehicle's longitudinal coordinate on its own lane, that lane's length and
-  // successor list (8 x int16), so the O(V^2) search never touches the lane table
-  float lon[WAVE], llen[WAVE];
-  int4 succ[WAVE];
-};
-DEV bool succ_has(const int4& p, int id) {  // 8 packed int16 ids, unused entries are -1
-  unsigned u = (unsigned)id & 0xffffu;
-  unsigned a = (unsigned)p.x, b = (unsigned)p.y, c = (unsigned)p.z, d = (unsigned)p.w;
-  return (a & 0xffffu) == u || (a >> 16) == u || (b & 0xffffu) == u || (b >> 16) == u || (c & 0xffffu) == u ||
-         (c >> 16) == u || (d & 0xffffu) == u || (d >> 16) == u;
-}
-DEV Obb snap_obb(const Snap& S, int k) { return Obb{S.x[k], S.y[k], S.ux[k], S.uy[k], S.hl[k], S.hw[k]}; }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// sub-lane cooperation: a vehicle is carried by SUB consecutive lanes that hold identical copies of its registers; the
-// heavy box / neighbour loops are split across them and recombined with wave shuffles (all lanes of a group are always
-// convergent because they execute on identical data).
-// ---------------------------------------------------------------------------------------------------------------------
-struct Grp {
-  int sub, SUB, lead;
-};
-DEV unsigned group_min(unsigned v, const Grp& g) {
-  unsigned r = v;
-  for (int j = 0; j < g.SUB; ++j) r = min(r, (unsigned)__shfl((int)v, g.lead + j));
-  return r;
-}
-DEV unsigned group_or(unsigned v, const Grp& g) {
-  unsigned r = v;
-  for (int j = 0; j < g.SUB; ++j) r |= (unsigned)__shfl((int)v, g.lead + j);
-  return r;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// localisation: utils/scene_utils.py:138-185 + navigation.py:328-344.  "First hit" = smallest box id (Bullet insertion
-// order); the cell-major box copies keep that order, so the smallest list position per class is the answer.
-// key = (position in cell << 16) | lane id
-// ---------------------------------------------------------------------------------------------------------------------
-// Device-side cell index (built by pgd_upload_maps): inside a cell the lane-surface boxes come first (original relative
-// order), the line / sidewalk boxes follow.  cstart[c] = first item | (number of lane boxes << 24); the cell ends where the
-// next one starts.  Localisation scans only the lane part, the contact / ray tests only the rest.
-DEV float ray_grid(const MapView& mv, float px, float py, float dx, float dy, unsigned kinds);
-DEV int cell_first(int c) { return c & 0xffffff; }
-DEV int cell_mid(int c) { return (c & 0xffffff) + (int)((unsigned)c >> 24); }
-
-DEV int get_current_lane(const MapView& mv, const Grp& g, float px, float py, float hx, float hy, int road_cur,
-                         int road_next) {
-  const pgd_map& m = *mv.m;
-  int cx = (int)floorf((px - m.ox) / m.cell), cy = (int)floorf((py - m.oy) / m.cell);
-  int k0 = 0, k1 = 0;
-  if (cx >= 0 && cy >= 0 && cx < m.gx && cy < m.gy) {
-    const int c = mv.cstart[cy * m.gx + cx];
-    k0 = cell_first(c);
-    k1 = cell_mid(c);
-  }
-  unsigned best_cur = 0xffffffffu, best_next = 0xffffffffu, best_any = 0xffffffffu;
-  const int stride = g.SUB;
-  constexpr int NB = 3;  // boxes per sub-lane and round: a cell holds 3-9 lane boxes, so one round is the rule
-  for (int k = k0 + g.sub; k < k1; k += NB * stride) {
-    pgd_box b[NB];
-    LaneExt x[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      int kk = k + j * stride;
-      kk = kk < k1 ? kk : k;
-      b[j] = mv.cbox[kk];  // batch the independent loads
-      x[j] = mv.cext[kk];
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      int kk = k + j * stride;
-      if (kk >= k1) continue;
-      if (!point_in_obb(obb_of(b[j]), px, py)) continue;
-      unsigned key = ((unsigned)(kk - k0) << 16) | (unsigned)b[j].lane;
-      bool is_cur = x[j].road == road_cur, is_next = x[j].road == road_next;
-      if (!(key < best_any || (is_cur && key < best_cur) || (is_next && key < best_next))) continue;
-      // cos(angle between lane heading at the point and vehicle heading) > 0 (scene_utils.py:158-172); only the sign is
-      // used, so the lane direction is taken in closed form: straight = unit dir; arc = dir * (-dy, dx) around the centre
-      float dirx, diry;
-      if (x[j].dir == 0.0f) { dirx = x[j].ax; diry = x[j].ay; }
-      else { dirx = -x[j].dir * (py - x[j].ay); diry = x[j].dir * (px - x[j].ax); }
-      if (!(dirx * hx + diry * hy > 0.0f)) continue;
-      best_any = min(best_any, key);
-      if (is_cur) best_cur = min(best_cur, key);
-      if (is_next) best_next = min(best_next, key);
-    }
-  }
-  best_cur = group_min(best_cur, g);
-  best_next = group_min(best_next, g);
-  best_any = group_min(best_any, g);
-  unsigned pick = best_cur != 0xffffffffu ? best_cur : (road_next < 0 ? best_any : (best_next != 0xffffffffu ? best_next : best_any));
-  return pick == 0xffffffffu ? -1 : (int)(pick & 0xffffu);
-}
-
-// Navigation._update_target_checkpoints (navigation.py:262-282)
-DEV void update_checkpoints(const MapView& mv, const pgd_spawn& sp, Veh& r, float lon) {
-  if (r.ck0 == r.ck1) return;
-  if (!(lon < 5.0f)) return;
-  int n = sp.n_ckpt;
-  int start_node = mv.roads[mv.lanes[r.lane].road].from;
-  bool in_tail = false;
-  int idx = -1;
-  for (int k = r.ck1; k < n; ++k) {
-    if (sp.ckpt[k] == start_node) {
-      in_tail = true;
-      if (idx < 0 && k < n - 1) idx = k;
-    }
-  }
-  if (!in_tail || idx < 0) return;
-  r.ck0 = idx;
-  r.ck1 = (idx + 1 == n - 1) ? idx : idx + 1;
-}
-
-// Navigation.update_localization (navigation.py:155-183)
-DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r) {
-  const float s = r.hy, c = r.hx;
-  int road_cur = sp.ckpt_road[r.ck0];
-  int road_next = (r.ck0 == r.ck1) ? -1 : sp.ckpt_road[r.ck1];
-  PHASE_MARK(16);  // after_step: route roads
-  int lane = get_current_lane(mv, g, r.x, r.y, c, s, road_cur, road_next);
-  PHASE_MARK(17);  // after_step: get_current_lane
-  bool on_lane = lane >= 0;
-  if (!on_lane) lane = r.lane;
-  r.lane = lane;
-  float lon, lat;
-  lane_local(mv.lanes[lane], r.x, r.y, lon, lat);
-  update_checkpoints(mv, sp, r, lon);
-  r.vflags = on_lane ? (r.vflags & ~PGD_F_OFF_LANE) : (r.vflags | PGD_F_OFF_LANE);
-  PHASE_MARK(18);  // after_step: lane_local + checkpoints
-}
-
-// BaseVehicle._state_check (base_vehicle.py:615-644)
-DEV unsigned state_check(const MapView& mv, const Grp& g, const Obb& car) {
-  const pgd_map& m = *mv.m;
-  float ex = fabsf(car.ux) * car.hl + fabsf(car.uy) * car.hw, ey = fabsf(car.uy) * car.hl + fabsf(car.ux) * car.hw;
-  int cx0 = max((int)floorf((car.cx - ex - m.ox) / m.cell), 0), cx1 = min((int)floorf((car.cx + ex - m.ox) / m.cell), m.gx - 1);
-  int cy0 = max((int)floorf((car.cy - ey - m.oy) / m.cell), 0), cy1 = min((int)floorf((car.cy + ey - m.oy) / m.cell), m.gy - 1);
-  unsigned fl = 0;
-  const int stride = g.SUB;
-  for (int cy = cy0; cy <= cy1; ++cy)
-    for (int cx = cx0; cx <= cx1; ++cx) {
-      int cell = cy * m.gx + cx;
-      int k0 = cell_mid(mv.cstart[cell]), k1 = cell_first(mv.cstart[cell + 1]);
-      for (int k = k0 + g.sub; k < k1; k += 4 * stride) {
-        pgd_box b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int kk = k + j * stride;
-          b[j] = mv.cbox[kk < k1 ? kk : k];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int kk = k + j * stride;
-          if (kk >= k1) continue;
-          unsigned bit = b[j].kind == PGD_BOX_WHITE ? PGD_F_ON_WHITE
-                         : b[j].kind == PGD_BOX_YELLOW ? PGD_F_ON_YELLOW
-                         : b[j].kind == PGD_BOX_BROKEN ? PGD_F_ON_BROKEN : PGD_F_CRASH_SIDEWALK;
-          if (fl & bit) continue;
-          if (obb_overlap(car, obb_of(b[j]))) fl |= bit;
-        }
-      }
-    }
-  return group_or(fl, g);
-}
-
-// What the later phases need from the agent's route position (Navigation.current_ref_lanes / next_ref_lanes,
-// navigation.py:155-183): looked up once per step after the checkpoint update, then reused by the side distances, the
-// reward and the observation instead of re-walking spawn record -> road table each time.
-struct RouteCtx {
-  int blk;         // Road.block_ID char of the current road
-  int road_cur;    // road id of checkpoints[ck0] -> checkpoints[ck0 + 1]
-  int cur_first;   // its first lane (current_ref_lanes[0]) ...
-  int cur_n;       // ... and lane count
-  int next_first;  // first lane of the next checkpoint road (== cur_first on the last road)
-};
-DEV RouteCtx route_ctx(const MapView& mv, const pgd_spawn& sp, int ck0, int ck1) {
-  const int rc = sp.ckpt_road[ck0], rn = sp.ckpt_road[ck1];
-  const pgd_road& CR = mv.roads[rc];
-  const pgd_road& NR = mv.roads[rn];
-  return RouteCtx{CR.block_id, rc, CR.first_lane, CR.n_lanes, NR.first_lane};
-}
-
-// BaseVehicle.after_step (base_vehicle.py:255-290).  `with_state_check` = false lets the caller run the line / sidewalk
-// test wave-cooperatively afterwards (k_step with one env per wave) and OR the result into vflags.
-DEV void after_step_vehicle(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, bool is_agent,
-                            bool with_state_check, RouteCtx& ctx) {
-  update_localization(mv, g, sp, r);
-  if (is_agent) {
-    ctx = route_ctx(mv, sp, r.ck0, r.ck1);
-    unsigned fl = (unsigned)r.vflags;
-    fl &= ~(PGD_F_ON_WHITE | PGD_F_ON_YELLOW | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OUT_OF_ROUTE);
-    if (with_state_check) fl |= state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sp.length, 0.5f * sp.width});
-    float lon, lat;
-    const pgd_lane& L0 = mv.lanes[ctx.cur_first];
-    lane_local(L0, r.x, r.y, lon, lat);
-    float w = mv.m->lane_width;
-    r.dl = lat + w * 0.5f;
-    float range = w * ctx.cur_n;
-    if (ctx.blk == 'y' || ctx.blk == 'Y') {
-      // Navigation.get_current_lateral_range on Merge / Split blocks (navigation.py:306-320,346-362): a 50 m ray from the
-      // left edge of the leftmost reference lane across the road against the continuous lane lines
-      float sx, sy;
-      lane_position(L0, lon, -0.5f * L0.width, sx, sy);
-      range = 50.0f * ray_grid(mv, sx, sy, -L0.by * 50.0f, L0.bx * 50.0f, (1u << PGD_BOX_WHITE) | (1u << PGD_BOX_YELLOW));
-    }
-    r.dr = range - r.dl;
-    if (r.dr < 0.0f || r.dl < 0.0f) fl |= PGD_F_OUT_OF_ROUTE;
-    r.vflags = (int)fl;
-    float dist = norm2(r.lastx - r.x, r.lasty - r.y) / 1000.0f;
-    r.energy += 3.25f * expf(0.01f * speed_kmh(r.v)) * dist / 100.0f * 1000.0f;
-    PHASE_MARK(19);  // after_step: side distances
-  }
-}
-
-// the same test with the whole wave on one car: the (<= 2x2) grid cells under the car are flattened into one index range
-DEV unsigned state_check_wave(const MapView& mv, const Obb& car) {
-  const pgd_map& m = *mv.m;
-  const int lane = threadIdx.x;
-  float ex = fabsf(car.ux) * car.hl + fabsf(car.uy) * car.hw, ey = fabsf(car.uy) * car.hl + fabsf(car.ux) * car.hw;
-  int cx0 = max((int)floorf((car.cx - ex - m.ox) / m.cell), 0), cx1 = min((int)floorf((car.cx + ex - m.ox) / m.cell), m.gx - 1);
-  int cy0 = max((int)floorf((car.cy - ey - m.oy) / m.cell), 0), cy1 = min((int)floorf((car.cy + ey - m.oy) / m.cell), m.gy - 1);
-  unsigned fl = 0;
-  for (int cyb = cy0; cyb <= cy1; cyb += 2)
-    for (int cxb = cx0; cxb <= cx1; cxb += 2) {  // blocks of up to 2x2 cells (a car spans at most 2 cells per axis)
-      int k0[4], pre[5];
-      pre[0] = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int cx = cxb + (q & 1), cy = cyb + (q >> 1);
-        bool in = cx <= cx1 && cy <= cy1;
-        int cell = in ? cy * m.gx + cx : 0;
-        int a = cell_mid(mv.cstart[cell]), b = cell_first(mv.cstart[cell + 1]);
-        k0[q] = a;
-        pre[q + 1] = pre[q] + (in ? b - a : 0);
-      }
-      for (int f = lane; f < pre[4]; f += WAVE) {
-        int q = (f >= pre[1]) + (f >= pre[2]) + (f >= pre[3]);
-        int kk = (q == 0 ? k0[0] : q == 1 ? k0[1] : q == 2 ? k0[2] : k0[3]) + f - (q == 0 ? pre[0] : q == 1 ? pre[1] : q == 2 ? pre[2] : pre[3]);
-        pgd_box b = mv.cbox[kk];
-        unsigned bit = b.kind == PGD_BOX_WHITE ? PGD_F_ON_WHITE
-                       : b.kind == PGD_BOX_YELLOW ? PGD_F_ON_YELLOW
-                       : b.kind == PGD_BOX_BROKEN ? PGD_F_ON_BROKEN : PGD_F_CRASH_SIDEWALK;
-        if (obb_overlap(car, obb_of(b))) fl |= bit;
-      }
-    }
-  unsigned out = 0;
-  if (__ballot((fl & PGD_F_ON_WHITE) != 0)) out |= PGD_F_ON_WHITE;
-  if (__ballot((fl & PGD_F_ON_YELLOW) != 0)) out |= PGD_F_ON_YELLOW;
-  if (__ballot((fl & PGD_F_ON_BROKEN) != 0)) out |= PGD_F_ON_BROKEN;
-  if (__ballot((fl & PGD_F_CRASH_SIDEWALK) != 0)) out |= PGD_F_CRASH_SIDEWALK;
-  return out;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// IDM: policy/idm_policy.py:82-133 (FrontBackObjects), :190-353 (act, lane change), :244-271 (PID + IDM law)
-// ---------------------------------------------------------------------------------------------------------------------
-struct Fbo {
-  int front[3], back[3];
-  float fd[3], bd[3];
-  bool exist[3];
-};
-
-DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int base, int V, int self, unsigned long long objs,
-                         int lane, float max_dist, bool with_ref, Fbo& r) {
-  const pgd_lane& L = mv.lanes[lane];
-  const int idx = L.index;  // the lanes of a road are consecutive; the device copy of the lane carries its road's lane count
-  const int l0 = (with_ref && idx > 0) ? lane - 1 : -1;
-  const int l2 = (with_ref && idx + 1 < L.pad) ? lane + 1 : -1;
-  const float px = S.x[base + self], py = S.y[base + self];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    r.front[i] = r.back[i] = -1;
-    r.fd[i] = r.bd[i] = max_dist;
-  }
-  r.exist[0] = l0 >= 0; r.exist[1] = true; r.exist[2] = l2 >= 0;
-  // target lane t (0 left, 1 own, 2 right) is searched by sub-lane t mod SUB; t is a per-lane runtime value so the
-  // sub-lanes run the same instructions on different target lanes (no serialisation across targets)
-  for (int t = g.sub; t < 3; t += g.SUB) {
-    const int tl = t == 0 ? l0 : (t == 1 ? lane : l2);
-    if (tl < 0) continue;
-    const pgd_lane& li = mv.lanes[tl];
-    float cur, lat;
-    lane_local(li, px, py, cur, lat);
-    const float left_long = li.length - cur;
-    const int4 lsucc = *reinterpret_cast<const int4*>(li.succ);
-    // one pass, five running minima (FrontBackObjects.get_find_front_back_objs, idm_policy.py:107-131):
-    //   same lane front/back; successor-lane front; predecessor-lane back (all / excluding successor-lane objects)
-    float same_f = max_dist, same_b = max_dist, succ_f = max_dist, pred_b = max_dist, pred_bx = max_dist;
-    int o_same_f = -1, o_same_b = -1, o_succ_f = -1, o_pred_b = -1, o_pred_bx = -1;
-    bool found_f = false, found_b = false;
-    // only the vehicles inside the broad phase, in slot order (ties keep the first one like the reference's loop)
-    for (unsigned long long m = objs; m != 0ull; m &= m - 1ull) {
-      const int o = __builtin_ctzll(m);
-      const int ol = S.lane[base + o];
-      const float olon = S.lon[base + o], ollen = S.llen[base + o];
-      const int4 osucc = S.succ[base + o];
-      if (ol == tl) {
-        float lg = olon - cur;
-        if (same_f > lg && lg > 0.0f) { same_f = lg; o_same_f = o; found_f = true; }
-        if (lg < 0.0f && fabsf(lg) < same_b) { same_b = fabsf(lg); o_same_b = o; found_b = true; }
-      } else {
-        const bool is_succ = succ_has(lsucc, ol);
-        if (is_succ) {
-          float lg = olon + left_long;
-          if (succ_f > lg && lg > 0.0f) { succ_f = lg; o_succ_f = o; }
-        }
-        if (succ_has(osucc, tl)) {
-          float lg = ollen - olon + cur;
-          if (pred_b > lg) { pred_b = lg; o_pred_b = o; }
-          if (!is_succ && pred_bx > lg) { pred_bx = lg; o_pred_bx = o; }
-        }
-      }
-    }
-    // objects on the lane itself take precedence; an object on a successor lane is only a "front" candidate while no
-    // same-lane front object exists, and only then is it barred from being a "back" candidate (the reference's elif)
-    const float fd = found_f ? same_f : succ_f;
-    const int fo = found_f ? o_same_f : o_succ_f;
-    const float bd = found_b ? same_b : (found_f ? pred_b : pred_bx);
-    const int bo = found_b ? o_same_b : (found_f ? o_pred_b : o_pred_bx);
-    if (t == 0) { r.fd[0] = fd; r.front[0] = fo; r.bd[0] = bd; r.back[0] = bo; }
-    else if (t == 1) { r.fd[1] = fd; r.front[1] = fo; r.bd[1] = bd; r.back[1] = bo; }
-    else { r.fd[2] = fd; r.front[2] = fo; r.bd[2] = bd; r.back[2] = bo; }
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {  // every sub-lane gets every target lane's result
-    int src = g.lead + (i % g.SUB);
-    r.front[i] = __shfl(r.front[i], src);
-    r.back[i] = __shfl(r.back[i], src);
-    r.fd[i] = __shfl(r.fd[i], src);
-    r.bd[i] = __shfl(r.bd[i], src);
-  }
-}
-
-template <bool OBJ>
-DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spawn& sp, const Snap& S, int base, int V,
-                 int s, int e, uint32_t step_count, unsigned long long pmask, Veh& r, float& out_steer, float& out_acc) {
-  const float NORMAL = 30.0f, CREEP = 5.0f, SAFE = 15.0f, MAXD = 30.0f;
-  const int vlane = r.lane;
-  int rt = r.rlane;
-  // the three reads the routing decision needs are independent of each other: issue them together
-  const int cur_road = sp.ckpt_road[r.ck0];
-  const int vl_road = mv.lanes[vlane].road;
-  const int rt_road = rt < 0 ? vl_road : (int)mv.lanes[rt].road;
-  const pgd_road& CR = mv.roads[cur_road];
-  bool success;
-  // move_to_next_road (idm_policy.py:222-242)
-  if (rt < 0) {
-    rt = vlane;
-    success = vl_road == cur_road;
-  } else if (rt_road != cur_road) {
-    success = false;
-    const pgd_lane& RT = mv.lanes[rt];
-    for (int k = 0; k < CR.n_lanes; ++k)
-      if (lane_is_prev_of(RT, CR.first_lane + k)) { rt = CR.first_lane + k; success = true; break; }
-  } else if (vl_road == cur_road && rt != vlane) {
-    rt = vlane;
-    r.timer = (int)(pgd_rng(d.cfg.seed, (uint32_t)e, (uint32_t)s, step_count) % 25u);
-    success = true;
-  } else success = true;
-  // is the (new) routing lane on the current road?  first case: the vehicle lane's road; second: only a found lane of
-  // CR; third and fourth: established by the branch conditions
-  const bool in_cur = r.rlane < 0 ? (vl_road == cur_road) : (rt_road != cur_road ? success : true);
-  r.rlane = rt;
-
-  // Lidar.get_surrounding_objects (lidar.py:109-124)
-  float px = S.x[base + s], py = S.y[base + s];
-  unsigned long long objs = 0ull;
-  // pmask = slots whose vehicle is in the physics world (wave-uniform with one env per wave: a scalar loop)
-  for (unsigned long long m = pmask & ~(1ull << s); m != 0ull; m &= m - 1ull) {
-    const int o = __builtin_ctzll(m);
-    const Obb ob = snap_obb(S, base + o);
-    const bool in = S.present[base + o] && shape_point_dist<OBJ>(ob, px, py) <= 50.0f;
-    objs |= in ? (1ull << o) : 0ull;
-  }
-
-  PHASE_MARK(9);  // idm: routing + broad phase
-  int front_obj = -1;
-  float front_dist = 5.0f;
-  int steer_lane = rt;
-  float speed = S.spd[base + s];
-  // one neighbour search for both branches of IDMPolicy.act (idm_policy.py:195-208): with the reference lanes when the
-  // routing lane is on the current road, on the routing lane alone otherwise; the reference's failed assert (routing lane
-  // not in ref lanes although move_to_next_road succeeded) falls back to "no front object, distance 5"
-  const bool search = !success || in_cur;
-  Fbo fb;
-  if (search) find_front_back(mv, g, S, base, V, s, objs, rt, MAXD, success, fb);
-  PHASE_MARK(10);  // idm: front/back search
-  if (success && in_cur) {
-    int idx = mv.lanes[rt].index;
-    int n_cur = CR.n_lanes;
-    int avail_lo = 0, avail_hi = n_cur - 1;
-    bool decided = false;
-    if (r.ck0 != r.ck1) {
-      const pgd_road& NR = mv.roads[sp.ckpt_road[r.ck1]];
-      int diff = n_cur - NR.n_lanes;
-      if (diff > 0) {
-        if (lane_is_prev_of(mv.lanes[CR.first_lane], NR.first_lane)) { avail_lo = 0; avail_hi = NR.n_lanes - 1; }
-        else { avail_lo = diff; avail_hi = n_cur - 1; }
-        if (idx < avail_lo || idx > avail_hi) {
-          int side = idx > avail_hi ? 0 : 2;  // 0: change to left, 2: change to right
-          // static indices only: a runtime index would push the whole Fbo into scratch memory
-          const float side_bd = side == 0 ? fb.bd[0] : fb.bd[2], side_fd = side == 0 ? fb.fd[0] : fb.fd[2];
-          const int side_front = side == 0 ? fb.front[0] : fb.front[2];
-          if (side_bd < SAFE || side_fd < 5.0f) {
-            r.target = CREEP;
-            front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
-          } else {
-            r.target = NORMAL;
-            front_obj = side_front; front_dist = side_fd;
-            steer_lane = CR.first_lane + idx + (side == 0 ? -1 : 1);
-          }
-          decided = true;
-        }
-      }
-    }
-    if (!decided) {
-      if (fabsf(speed - NORMAL) > 3.0f && fb.front[1] >= 0 && fabsf(S.spd[base + fb.front[1]] - NORMAL) > 3.0f &&
-          r.timer > 50) {
-        float fs = S.spd[base + fb.front[1]];
-        bool has_r = false, has_l = false;
-        float rs = 0.0f, ls = 0.0f;
-        if (fb.front[2] >= 0) { has_r = true; rs = S.spd[base + fb.front[2]]; }
-        else if (fb.exist[2] && fb.fd[2] > SAFE && fb.bd[2] > SAFE) { has_r = true; rs = 100.0f; }
-        if (fb.front[0] >= 0) { has_l = true; ls = S.spd[base + fb.front[0]]; }
-        else if (fb.exist[0] && fb.fd[0] > SAFE && fb.bd[0] > SAFE) { has_l = true; ls = 100.0f; }
-        if (has_l && ls - fs > 10.0f) {
-          int ex = idx - 1;
-          if (ex >= avail_lo && ex <= avail_hi) {
-            front_obj = fb.front[0]; front_dist = fb.fd[0]; steer_lane = CR.first_lane + ex; decided = true;
-          }
-        }
-        if (!decided && has_r && rs - fs > 10.0f) {
-          int ex = idx + 1;
-          if (ex >= avail_lo && ex <= avail_hi) {
-            front_obj = fb.front[2]; front_dist = fb.fd[2]; steer_lane = CR.first_lane + ex; decided = true;
-          }
-        }
-      }
-      if (!decided) {
-        r.target = NORMAL;
-        r.timer += 1;
-        front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
-      }
-    }
-  } else if (!success) {
-    front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
-  }
-  PHASE_MARK(11);  // idm: lane-change logic
-
-  // steering_control (idm_policy.py:244-252)
-  const pgd_lane& SL = mv.lanes[steer_lane];
-  float lon, lat;
-  lane_local(SL, px, py, lon, lat);
-  float lane_heading = lane_heading_at(SL, lon + 1.0f);
-  float steering = pid_update(r.php, r.phi, 1.7f, 0.01f, 3.5f, wrap_to_pi(lane_heading - r.th));
-  steering += pid_update(r.plp, r.pli, 0.3f, 0.002f, 0.05f, -lat);
-  // acceleration / desired_gap (idm_policy.py:254-271)
-  float ratio = fmaxf(speed, 0.0f) / not_zero(r.target, 0.0f);
-  float r2 = ratio * ratio, r4 = r2 * r2, r8 = r4 * r4;
-  float acc = 1.0f - r8 * r2;
-  if (front_obj >= 0) {
-    float hx = S.ux[base + s], hy = S.uy[base + s];
-    float fsp = S.spd[base + front_obj];
-    float dvx = speed * hx - fsp * S.ux[base + front_obj], dvy = speed * hy - fsp * S.uy[base + front_obj];
-    float dv = dvx * hx + dvy * hy;
-    float d_star = 10.0f + speed * 1.5f + speed * dv / (2.0f * 2.2360679774997896f);
-    float sd = d_star / not_zero(front_dist, 1e-2f);
-    acc -= sd * sd;
-  }
-  out_steer = steering;
-  out_acc = acc;
-  PHASE_MARK(12);  // idm: PID + IDM law
-}
-
-// kinematic bicycle (component/highway_vehicle/kinematics.py:134-156) driven by the reference's action -> force mapping
-// (base_vehicle.py:343-376); see DESIGN.md §3 for the substitution of Bullet's raycast vehicle.
-DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse) {
-  float dt = d.cfg.dt;
-  float force = 0.0f, brake = 0.0f;
-  if (r.thr >= 0.0f) {
-    brake = 2.0f;
-    force = (fabsf(r.v) * 3.6f > p.max_speed) ? 0.0f : p.max_engine_force * r.thr;
-  } else if (reverse) {  // enable_reverse: engine force backwards, no brake (base_vehicle.py:370-373)
-    force = p.max_engine_force * r.thr;
-  } else {
-    brake = fabsf(r.thr) * p.max_brake_force;
-  }
-  float delta = -clipf(r.steer, -1.0f, 1.0f) * p.max_steer;
-  // beta = atan(t), t = tan(delta)/2  ->  cos(beta) = 1/sqrt(1+t^2), sin(beta) = t/sqrt(1+t^2)
-  float t = 0.5f * tanf(delta);
-  float cb = 1.0f / sqrtf(1.0f + t * t), sb = t * cb;
-  // unit vector of the motion direction th + beta, advanced by exact small-angle rotations instead of sincos per sub-step
-  float cd = r.hx * cb - r.hy * sb, sd = r.hy * cb + r.hx * sb;
-  float inv_half_base = 2.0f / p.wheelbase;
-  float dv_brake = fminf(4.0f * brake / p.mass, p.friction * 9.81f * dt);
-  float dv_engine = 4.0f * force / p.mass * dt;
-  for (int k = 0; k < d.cfg.decision_repeat; ++k) {
-    r.x += r.v * cd * dt;
-    r.y += r.v * sd * dt;
-    float dth = r.v * sb * inv_half_base * dt;  // |dth| < 0.25 rad at 80 km/h and full lock
-    r.th += dth;
-    float q = dth * dth;
-    float sn = dth * (1.0f + q * (-1.0f / 6.0f + q * (1.0f / 120.0f + q * (-1.0f / 5040.0f))));
-    float cs = 1.0f + q * (-0.5f + q * (1.0f / 24.0f + q * (-1.0f / 720.0f + q * (1.0f / 40320.0f))));
-    float ncd = cd * cs - sd * sn;
-    sd = sd * cs + cd * sn;
-    cd = ncd;
-    if (force != 0.0f) r.v += dv_engine;
-    else r.v = r.v >= 0.0f ? fmaxf(0.0f, r.v - dv_brake) : fminf(0.0f, r.v + dv_brake);
-    if (!reverse) r.v = fmaxf(r.v, 0.0f);
-  }
-  // heading unit vector = motion direction rotated back by beta, renormalised
-  float hx = cd * cb + sd * sb, hy = sd * cb - cd * sb;
-  float inv = 1.0f / sqrtf(hx * hx + hy * hy);
-  r.hx = hx * inv;
-  r.hy = hy * inv;
-}
-
-DEV void reset_vehicle(const pgd_spawn& p, Veh& r, int spawn_index, bool is_agent) {  // base_vehicle.py:292-339
-  memset(&r, 0, sizeof(Veh));
-  // agents have no PID state: under PGD_MA_TOLLGATE the fields carry in_toll_time = 0 and entry / exit / last block = none
-  // (marl_tollgate.py:36-60,76-96); harmless otherwise
-  if (is_agent) { r.php = (float)p.aux; r.phi = -1.0f; r.plp = -1.0f; r.pli = -1.0f; }  // php: parking destination / toll time
-  r.spawn = spawn_index;
-  r.rlane = is_agent ? 0 : -1;  // agents: episode length; traffic: IDMPolicy.routing_target_lane = None
-  r.hx = 1.0f;
-  if (p.lane < 0) { r.status = ST_EMPTY; return; }
-  r.status = p.group == -1 ? ST_ACTIVE : ST_PENDING;  // PGD_GROUP_NEVER (-2): in the world, never driven
-  r.x = p.x; r.y = p.y; r.th = p.heading;
-  r.lastx = p.x; r.lasty = p.y;
-  sincosf(p.heading, &r.lasthy, &r.lasthx);
-  r.hx = r.lasthx; r.hy = r.lasthy;
-  r.target = 30.0f;
-  r.lane = p.lane;
-  r.ck0 = 0;
-  r.ck1 = p.n_ckpt > 2 ? 1 : 0;
-  r.timer = p.timer0;
-}
-
-// reward / done: envs/pgdrive_env.py:162-258, base_vehicle.py:738-745
-DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const Veh& r, const RouteCtx& ctx,
-                      unsigned& flags_out, bool& done_out) {
-  const pgd_config& g = d.cfg;
-  unsigned vf = (unsigned)r.vflags;
-  const pgd_lane& VL = mv.lanes[r.lane];
-  bool in_ref = VL.road == ctx.road_cur;
-  const pgd_lane& cl = in_ref ? VL : mv.lanes[ctx.cur_first];
-  float positive = (in_ref || (g.marl_flags & PGD_MA_PLAIN_REWARD)) ? 1.0f : (mv.roads[VL.road].negative ? -1.0f : 1.0f);
-  float l0, t0, l1, t1;
-  lane_local(cl, r.lastx, r.lasty, l0, t0);
-  lane_local(cl, r.x, r.y, l1, t1);
-  float w = mv.m->lane_width;
-  float lateral_factor = g.use_lateral ? clipf(1.0f - 2.0f * fabsf(t1) / w, 0.0f, 1.0f) : 1.0f;
-  float reward = g.driving_reward * (l1 - l0) * lateral_factor * positive;
-  if (g.marl_flags & PGD_MA_TOLLGATE) {  // MultiAgentTollgateEnv.reward_function (marl_tollgate.py:195-232)
-    if (ctx.blk == '$') {
-      // BaseVehicle.overspeed (base_vehicle.py:759-761): lane.speed_limit (3 on toll lanes, 1000 elsewhere) < speed [km/h]
-      const bool lane_toll = mv.roads[VL.road].block_id == '$';
-      if (lane_toll && 3.0f < speed_kmh(r.v)) reward = -g.overspeed_penalty * speed_kmh(r.v) / sp.max_speed;
-    } else reward += g.speed_reward * (speed_kmh(r.v) / sp.max_speed);
-  } else
-  reward += g.speed_reward * (speed_kmh(r.v) / sp.max_speed) * positive;
-  unsigned out = vf & (PGD_F_ON_YELLOW | PGD_F_ON_WHITE | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OFF_LANE |
-                       PGD_F_OUT_OF_ROUTE | PGD_F_CRASH_VEHICLE | PGD_F_CRASH_OBJECT | PGD_F_CRASH_BUILDING);
-  const pgd_lane& fl = mv.lanes[sp.dest_lane];
-  float lon, lat;
-  lane_local(fl, r.x, r.y, lon, lat);
-  bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - ctx.cur_n) * w);
-  unsigned oor_bits = (g.marl_flags & PGD_MA_TOLLGATE) ? PGD_F_CRASH_SIDEWALK  // marl_tollgate.py:234-240
-                      : (g.marl_flags & PGD_MA_PARKING) ? (PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK)  // marl_parking_lot.py:213-217
-                                                        : (PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK);
-  if (!(g.marl_flags & PGD_MA_YELLOW_OK)) oor_bits |= PGD_F_ON_YELLOW;
-  bool oor = (vf & oor_bits) != 0;
-  if (g.out_of_route_done) oor = oor || (vf & PGD_F_OUT_OF_ROUTE);
-  bool crash = (vf & PGD_F_CRASH_VEHICLE) != 0, crash_obj = (vf & PGD_F_CRASH_OBJECT) != 0;
-  if (arrive) out |= PGD_F_ARRIVE;
-  if (oor) out |= PGD_F_OUT_OF_ROAD;
-  if (arrive) reward = g.success_reward;
-  else if (oor) reward = -g.out_of_road_penalty;
-  else if (crash) reward = -g.crash_vehicle_penalty;
-  else if (crash_obj) reward = -g.crash_object_penalty;
-  flags_out = out;
-  done_out = arrive || oor || crash || crash_obj || (vf & PGD_F_CRASH_BUILDING) != 0;  // pgdrive_env.py:162-194
-  // SafePGDriveEnv.done_function (safe_pgdrive_env.py:49-56): a step with crash_vehicle, else crash_object, is not terminal
-  if (g.safe_rl_env && (crash || crash_obj)) done_out = false;
-  return reward;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// observation: LidarStateObservation.observe (obs/state_obs.py:132-170) for one (env, agent)
-// ---------------------------------------------------------------------------------------------------------------------
-DEV void navi_info_for(const pgd_lane& ref, float w, int n_cur, float px, float py, float hx, float hy, float* out) {
-  // Navigation._get_info_for_checkpoint (navigation.py:213-260); ref = ref_lanes[0] of the checkpoint's road
-  float later_middle = ((float)n_cur * 0.5f - 0.5f) * w;
-  float cx, cy;
-  lane_position(ref, ref.length, later_middle, cx, cy);
-  float dx = cx - px, dy = cy - py;
-  float dn = norm2(dx, dy);
-  if (dn > 50.0f) { dx = dx / dn * 50.0f; dy = dy / dn * 50.0f; }
-  float ph, ps;
-  projection(hx, hy, dx, dy, ph, ps);
-  float bend = 0.0f, dir = 0.0f, angle = 0.0f;
-  if (ref.dir != 0.0f) {
-    bend = ref.bx / (60.0f + n_cur * w);
-    dir = ref.dir;
-    angle = dir == 1.0f ? ref.c - ref.by : ref.by - ref.c;
-  }
-  out[0] = clipf((ph / 50.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
-  out[1] = clipf((ps / 50.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
-  out[2] = clipf(bend, 0.0f, 1.0f);
-  out[3] = clipf((dir + 1.0f) * 0.5f, 0.0f, 1.0f);
-  out[4] = clipf((angle * (180.0f / PGD_PI) / 135.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
-}
-
-DEV float heading_diff(const pgd_lane& l, float px, float py, float fx, float fy) {  // base_vehicle.py:433-458
-  float lx, ly;
-  if (l.dir == 0.0f) { lx = -l.by; ly = l.bx; }
-  else if (l.dir < 0.0f) { lx = px - l.ax; ly = py - l.ay; }
-  else { lx = l.ax - px; ly = l.ay - py; }
-  float ln = norm2(lx, ly), fn = norm2(fx, fy);
-  if (ln * fn == 0.0f) return 0.0f;
-  return clipf((fx * lx + fy * ly) / (ln * fn), -1.0f, 1.0f) * 0.5f + 0.5f;
-}
-
-// nearest hit fraction of the segment p + t d (t in [0,1]) against the map's boxes whose kind is in `kinds`: Amanatides-Woo
-// walk over the uniform grid; a cell is skipped once its entry parameter is beyond the best hit so far
-DEV float ray_grid(const MapView& mv, float px, float py, float dx, float dy, unsigned kinds) {
-  const pgd_map& m = *mv.m;
-  const float inv = 1.0f / m.cell;
-  int ix = (int)floorf((px - m.ox) * inv), iy = (int)floorf((py - m.oy) * inv);
-  const int sx = dx > 0.0f ? 1 : -1, sy = dy > 0.0f ? 1 : -1;
-  const float big = 3.0e38f;
-  const float tdx = dx != 0.0f ? fabsf(m.cell / dx) : big, tdy = dy != 0.0f ? fabsf(m.cell / dy) : big;
-  float tmx = dx != 0.0f ? ((m.ox + (ix + (dx > 0.0f ? 1 : 0)) * m.cell) - px) / dx : big;
-  float tmy = dy != 0.0f ? ((m.oy + (iy + (dy > 0.0f ? 1 : 0)) * m.cell) - py) / dy : big;
-  float best = 1.0f, t_enter = 0.0f;
-  for (int it = 0; it < 64; ++it) {
-    if (t_enter > best + 0.02f) break;  // boxes are registered with a 5 cm margin: keep a little slack
-    if (ix >= 0 && iy >= 0 && ix < m.gx && iy < m.gy) {
-      const int cell = iy * m.gx + ix;
-      const int k1 = cell_first(mv.cstart[cell + 1]);
-      for (int k = cell_mid(mv.cstart[cell]); k < k1; ++k) {
-        const pgd_box b = mv.cbox[k];
-        if (!((1u << b.kind) & kinds)) continue;
-        best = fminf(best, ray_obb(obb_of(b), px, py, dx, dy));
-      }
-    } else if ((sx > 0 ? ix >= m.gx : ix < 0) || (sy > 0 ? iy >= m.gy : iy < 0)) {
-      break;  // left the grid for good
-    }
-    if (tmx < tmy) { t_enter = tmx; tmx += tdx; ix += sx; }
-    else { t_enter = tmy; tmy += tdy; iy += sy; }
-    if (t_enter > 1.0f) break;
-  }
-  return best;
-}
-
-struct ObsLds {  // bodies inside the lidar broad phase of the observing agent, compacted
-  float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV];
-  float bdist[MAXV];  // centre distance; +inf for traffic objects, which are never ranked as neighbour vehicles
-  int n, nveh;
-};
-struct AgentView {  // what the observation needs from the observing vehicle
-  float x, y, th, hx, hy, dl, dr, v, steer, a0s, a0t, lhx, lhy;
-  int cur_first, cur_n, next_first;  // RouteCtx of the vehicle
-  int blk;                           // block id char of its current road
-  float toll_time;                   // TollGateObservation.in_toll_time (PGD_MA_TOLLGATE)
-  int env, slot;                     // for the lidar noise stream
-  uint32_t tick;                     // steps since pgd_reset
-};
-
-// one wave compacts the candidates: lane `o` brings vehicle o of the env (present = in the physics world)
-template <bool OBJ>
-DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, float x, float y, float ux, float uy, float hl,
-                     float hw, float spd, float px, float py, float R) {
-  if (!OBJ) is_vehicle = true;
-  bool in = present && o != a && shape_point_dist<OBJ>(Obb{x, y, ux, uy, hl, hw}, px, py) <= R;
-  unsigned long long m = __ballot(in), mv_ = OBJ ? __ballot(in && is_vehicle) : m;
-  if (in) {
-    int k = __popcll(m & ((1ull << o) - 1ull));
-    L.bx[k] = x; L.by[k] = y; L.bux[k] = ux; L.buy[k] = uy; L.bhl[k] = hl; L.bhw[k] = hw; L.bspd[k] = spd;
-    L.bdist[k] = is_vehicle ? norm2(px - x, py - y) : __builtin_inff();
-  }
-  if (o == 0) { L.n = __popcll(m); L.nveh = __popcll(mv_); }
-}
-
-// writes the D floats of one agent's row with `nt` cooperating threads (tid in [0, nt))
-template <bool OBJ>
-DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const AgentView& ag, const ObsLds& L,
-                       float* __restrict__ row, int tid, int nt) {
-  const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
-  const float R = d.cfg.lidar_dist;
-  const int NL = d.cfg.num_lasers;
-  // StateObservation.vehicle_state (state_obs.py:58-106) + navi info (navigation.py:185-197): one lane per float.
-  // Row layout: [side fan k | 2 lateral distances][6 ego floats][lane-line fan m][10 navi][4*NO neighbours][NL beams]
-  const int KS = d.cfg.side_lasers, KM = d.cfg.lane_line_lasers;
-  const bool toll = (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;  // no navigation block, 2 toll floats after the lidar
-  const int RAM = d.cfg.random_agent_model ? 2 : 0;  // LENGTH / 10, WIDTH / 2.5 after the lane-line fan (state_obs.py:102-105)
-  const int o_ego = KS > 0 ? KS : 2, o_navi = o_ego + 6 + KM + RAM, o_oth = o_navi + (toll ? 0 : 10);
-  if (RAM && tid == nt - 1) {
-    row[o_ego + 6 + KM] = clipf(sp.length / 10.0f, 0.0f, 1.0f);
-    row[o_ego + 6 + KM + 1] = clipf(sp.width / 2.5f, 0.0f, 1.0f);
-  }
-  if (toll && tid == 0) {  // TollGateObservation.observe (marl_tollgate.py:84-96)
-    const bool in_toll = ag.blk == '$';
-    float* t2 = row + o_oth + 4 * d.cfg.num_others + NL;
-    t2[0] = in_toll ? 1.0f : 0.0f;
-    t2[1] = (in_toll && ag.toll_time > (float)d.cfg.min_pass_steps) ? 1.0f : 0.0f;
-  }
-  if (tid < 18) {
-    // every lane fetches the one lane record its float needs BEFORE the branch ladder, so the reads overlap instead of
-    // queueing behind each other branch by branch: heading_diff -> last lane of the current road; navi -> first lanes
-    const int lid = tid < 8 ? ag.cur_first + ag.cur_n - 1 : (tid < 13 ? ag.cur_first : ag.next_first);
-    const pgd_lane ml = mv.lanes[lid];
-    const float max_speed = sp.max_speed;
-    float v = 0.0f;
-    int col = -1;
-    if (tid == 0) { v = clipf(ag.dl / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 0; }  // (MAX_LANE_NUM+1)*MAX_LANE_WIDTH
-    else if (tid == 1) { v = clipf(ag.dr / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 1; }
-    else if (tid == 2) { v = heading_diff(ml, px, py, hx, hy); col = o_ego; }
-    else if (tid == 3) { v = clipf((speed_kmh(ag.v) + 1.0f) / (max_speed + 1.0f), 0.0f, 1.0f); col = o_ego + 1; }
-    else if (tid == 4) { v = clipf((ag.steer / 60.0f + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 2; }
-    else if (tid == 5) { v = clipf((ag.a0s + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 3; }
-    else if (tid == 6) { v = clipf((ag.a0t + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 4; }
-    else if (tid == 7) {
-      // acos(clip(cos_beta, 0, 1)) (state_obs.py:87-92) evaluated as atan2(|cross|, dot): identical for unit vectors,
-      // but well-conditioned in fp32 near beta = 0 where 1 - cos(beta) underflows the mantissa
-      float dot = hx * ag.lhx + hy * ag.lhy, cross = hx * ag.lhy - hy * ag.lhx;
-      float beta = dot <= 0.0f ? 0.5f * PGD_PI : atan2f(fabsf(cross), dot);
-      v = clipf(beta / 0.1f, 0.0f, 1.0f);
-      col = o_ego + 5;
-    } else {  // lanes 8..12 -> checkpoint 1, 13..17 -> checkpoint 2
-      int which = (tid - 8) / 5, comp = (tid - 8) - which * 5;
-      float out[5];
-      navi_info_for(ml, mv.m->lane_width, ag.cur_n, px, py, hx, hy, out);
-      v = comp == 0 ? out[0] : comp == 1 ? out[1] : comp == 2 ? out[2] : comp == 3 ? out[3] : out[4];
-      col = toll ? -1 : o_navi + (tid - 8);
-    }
-    if (col >= 0) row[col] = v;
-  }
-  // SideDetector / LaneLineDetector fans (distance_detector.py:137-152): beam i at theta + i*2pi/n + 90 deg, cast through
-  // the map grid against the line boxes of the wanted kinds
-  for (int q = tid; q < KS + KM; q += nt) {
-    const bool side = q < KS;
-    const int i = side ? q : q - KS, n = side ? KS : KM;
-    const float dist = side ? d.cfg.side_dist : d.cfg.lane_line_dist;
-    const unsigned kinds = side ? ((1u << PGD_BOX_WHITE) | (1u << PGD_BOX_YELLOW))
-                                : ((1u << PGD_BOX_WHITE) | (1u << PGD_BOX_YELLOW) | (1u << PGD_BOX_BROKEN));
-    float sn, cs;
-    sincosf((float)i * (2.0f * PGD_PI / (float)n) + 0.5f * PGD_PI + ag.th, &sn, &cs);
-    row[side ? i : o_ego + 6 + i] = ray_grid(mv, px, py, dist * cs, dist * sn, kinds);
-  }
-  PHASE_MARK(22);  // obs: state + navi block
-  if (NL <= 0) return;
-  // get_surrounding_vehicles_info (lidar.py:55-77): rank by centre distance (stable), 4 floats per neighbour; the last
-  // threads take this part so that it overlaps the state block of the first ones
-  const int NO = d.cfg.num_others;
-  const int n = L.n, nveh = OBJ ? L.nveh : n;
-  // with objects: indices [0, n) are the compacted bodies, [n, n + NO) the rank rows to zero-fill; without: [0, max(n, NO))
-  for (int k = nt - 1 - tid; k < (OBJ ? n + NO : (n > NO ? n : NO)); k += nt) {
-    if (k < n) {
-      int rank = 0;
-      float dk = L.bdist[k];
-      for (int j = 0; j < n; ++j) rank += (L.bdist[j] < dk || (L.bdist[j] == dk && j < k)) ? 1 : 0;
-      if (rank < NO && dk < __builtin_inff()) {
-        float ph, ps;
-        float ms = sp.max_speed;
-        float sp_me = speed_kmh(ag.v);
-        projection(hx, hy, L.bx[k] - px, L.by[k] - py, ph, ps);
-        float* o = row + o_oth + rank * 4;
-        o[0] = clipf((ph / R + 1.0f) * 0.5f, 0.0f, 1.0f);
-        o[1] = clipf((ps / R + 1.0f) * 0.5f, 0.0f, 1.0f);
-        projection(hx, hy, L.bspd[k] * L.bux[k] - sp_me * hx, L.bspd[k] * L.buy[k] - sp_me * hy, ph, ps);
-        o[2] = clipf((ph / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
-        o[3] = clipf((ps / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
-      }
-    } else if (!OBJ || k - n >= nveh) {  // ranks [nveh, NO): absent neighbour -> zeros
-      float* o = row + o_oth + (OBJ ? k - n : k) * 4;
-      o[0] = o[1] = o[2] = o[3] = 0.0f;
-    }
-  }
-  PHASE_MARK(23);  // obs: neighbours
-  // lidar (distance_detector.py:65-94, cutils.pyx:60-142): beam i at theta + i*2pi/N, nearest hit fraction
-  const float unit = 2.0f * PGD_PI / (float)NL;
-  for (int i = tid; i < NL; i += nt) {
-    float ang = (float)i * unit + ag.th;
-    float sn, cs;
-    sincosf(ang, &sn, &cs);
-    float dx = R * cs, dy = R * sn;
-    float best = 1.0f;
-    for (int k = 0; k < n; ++k)
-      best = fminf(best, shape_ray<OBJ>(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
-    if (d.cfg.lidar_gaussian_noise > 0.0f || d.cfg.lidar_dropout_prob > 0.0f) {  // state_obs.py:172-182
-      const uint32_t key = 0x51d0a000u + (uint32_t)ag.slot * 1024u + (uint32_t)i;
-      if (d.cfg.lidar_gaussian_noise > 0.0f) {
-        const float u1 = ((float)(pgd_rng(d.cfg.seed, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        const float u2 = ((float)(pgd_rng(d.cfg.seed ^ 0x9e3779b9u, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        best = clipf(best + d.cfg.lidar_gaussian_noise * sqrtf(-2.0f * logf(u1)) * cosf(2.0f * PGD_PI * u2), 0.0f, 1.0f);
-      }
-      if (d.cfg.lidar_dropout_prob > 0.0f) {
-        const float u3 = ((float)(pgd_rng(d.cfg.seed ^ 0x7f4a7c15u, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        if (u3 < d.cfg.lidar_dropout_prob) best = 0.0f;
-      }
-    }
-    row[o_oth + 4 * NO + i] = best;
-  }
-  PHASE_MARK(24);  // obs: lidar
-}
+#include "pgd_vehicle.h"
+#include "pgd_localize.h"
+#include "pgd_idm.h"
+#include "pgd_dynamics.h"
+#include "pgd_observe.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_step: one env.step() for every environment (base_env.py:184-224)

@@ -1,0 +1,227 @@
+// pgd_idm.h -- IDM traffic policy: routing, neighbour search, lane change, PID steering, IDM law.
+// Part of the single translation unit pgd_engine.hip (included there, in this order, after pgd_device.h).
+#ifndef PGD_IDM_H
+#define PGD_IDM_H
+
+// ---------------------------------------------------------------------------------------------------------------------
+// IDM: policy/idm_policy.py:82-133 (FrontBackObjects), :190-353 (act, lane change), :244-271 (PID + IDM law)
+// ---------------------------------------------------------------------------------------------------------------------
+struct Fbo {
+  int front[3], back[3];
+  float fd[3], bd[3];
+  bool exist[3];
+};
+
+DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int base, int V, int self, unsigned long long objs,
+                         int lane, float max_dist, bool with_ref, Fbo& r) {
+  const pgd_lane& L = mv.lanes[lane];
+  const int idx = L.index;  // the lanes of a road are consecutive; the device copy of the lane carries its road's lane count
+  const int l0 = (with_ref && idx > 0) ? lane - 1 : -1;
+  const int l2 = (with_ref && idx + 1 < L.pad) ? lane + 1 : -1;
+  const float px = S.x[base + self], py = S.y[base + self];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    r.front[i] = r.back[i] = -1;
+    r.fd[i] = r.bd[i] = max_dist;
+  }
+  r.exist[0] = l0 >= 0; r.exist[1] = true; r.exist[2] = l2 >= 0;
+  // target lane t (0 left, 1 own, 2 right) is searched by sub-lane t mod SUB; t is a per-lane runtime value so the
+  // sub-lanes run the same instructions on different target lanes (no serialisation across targets)
+  for (int t = g.sub; t < 3; t += g.SUB) {
+    const int tl = t == 0 ? l0 : (t == 1 ? lane : l2);
+    if (tl < 0) continue;
+    const pgd_lane& li = mv.lanes[tl];
+    float cur, lat;
+    lane_local(li, px, py, cur, lat);
+    const float left_long = li.length - cur;
+    const int4 lsucc = *reinterpret_cast<const int4*>(li.succ);
+    // one pass, five running minima (FrontBackObjects.get_find_front_back_objs, idm_policy.py:107-131):
+    //   same lane front/back; successor-lane front; predecessor-lane back (all / excluding successor-lane objects)
+    float same_f = max_dist, same_b = max_dist, succ_f = max_dist, pred_b = max_dist, pred_bx = max_dist;
+    int o_same_f = -1, o_same_b = -1, o_succ_f = -1, o_pred_b = -1, o_pred_bx = -1;
+    bool found_f = false, found_b = false;
+    // only the vehicles inside the broad phase, in slot order (ties keep the first one like the reference's loop)
+    for (unsigned long long m = objs; m != 0ull; m &= m - 1ull) {
+      const int o = __builtin_ctzll(m);
+      const int ol = S.lane[base + o];
+      const float olon = S.lon[base + o], ollen = S.llen[base + o];
+      const int4 osucc = S.succ[base + o];
+      if (ol == tl) {
+        float lg = olon - cur;
+        if (same_f > lg && lg > 0.0f) { same_f = lg; o_same_f = o; found_f = true; }
+        if (lg < 0.0f && fabsf(lg) < same_b) { same_b = fabsf(lg); o_same_b = o; found_b = true; }
+      } else {
+        const bool is_succ = succ_has(lsucc, ol);
+        if (is_succ) {
+          float lg = olon + left_long;
+          if (succ_f > lg && lg > 0.0f) { succ_f = lg; o_succ_f = o; }
+        }
+        if (succ_has(osucc, tl)) {
+          float lg = ollen - olon + cur;
+          if (pred_b > lg) { pred_b = lg; o_pred_b = o; }
+          if (!is_succ && pred_bx > lg) { pred_bx = lg; o_pred_bx = o; }
+        }
+      }
+    }
+    // objects on the lane itself take precedence; an object on a successor lane is only a "front" candidate while no
+    // same-lane front object exists, and only then is it barred from being a "back" candidate (the reference's elif)
+    const float fd = found_f ? same_f : succ_f;
+    const int fo = found_f ? o_same_f : o_succ_f;
+    const float bd = found_b ? same_b : (found_f ? pred_b : pred_bx);
+    const int bo = found_b ? o_same_b : (found_f ? o_pred_b : o_pred_bx);
+    if (t == 0) { r.fd[0] = fd; r.front[0] = fo; r.bd[0] = bd; r.back[0] = bo; }
+    else if (t == 1) { r.fd[1] = fd; r.front[1] = fo; r.bd[1] = bd; r.back[1] = bo; }
+    else { r.fd[2] = fd; r.front[2] = fo; r.bd[2] = bd; r.back[2] = bo; }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {  // every sub-lane gets every target lane's result
+    int src = g.lead + (i % g.SUB);
+    r.front[i] = __shfl(r.front[i], src);
+    r.back[i] = __shfl(r.back[i], src);
+    r.fd[i] = __shfl(r.fd[i], src);
+    r.bd[i] = __shfl(r.bd[i], src);
+  }
+}
+
+template <bool OBJ>
+DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spawn& sp, const Snap& S, int base, int V,
+                 int s, int e, uint32_t step_count, unsigned long long pmask, Veh& r, float& out_steer, float& out_acc) {
+  const float NORMAL = 30.0f, CREEP = 5.0f, SAFE = 15.0f, MAXD = 30.0f;
+  const int vlane = r.lane;
+  int rt = r.rlane;
+  // the three reads the routing decision needs are independent of each other: issue them together
+  const int cur_road = sp.ckpt_road[r.ck0];
+  const int vl_road = mv.lanes[vlane].road;
+  const int rt_road = rt < 0 ? vl_road : (int)mv.lanes[rt].road;
+  const pgd_road& CR = mv.roads[cur_road];
+  bool success;
+  // move_to_next_road (idm_policy.py:222-242)
+  if (rt < 0) {
+    rt = vlane;
+    success = vl_road == cur_road;
+  } else if (rt_road != cur_road) {
+    success = false;
+    const pgd_lane& RT = mv.lanes[rt];
+    for (int k = 0; k < CR.n_lanes; ++k)
+      if (lane_is_prev_of(RT, CR.first_lane + k)) { rt = CR.first_lane + k; success = true; break; }
+  } else if (vl_road == cur_road && rt != vlane) {
+    rt = vlane;
+    r.timer = (int)(pgd_rng(d.cfg.seed, (uint32_t)e, (uint32_t)s, step_count) % 25u);
+    success = true;
+  } else success = true;
+  // is the (new) routing lane on the current road?  first case: the vehicle lane's road; second: only a found lane of
+  // CR; third and fourth: established by the branch conditions
+  const bool in_cur = r.rlane < 0 ? (vl_road == cur_road) : (rt_road != cur_road ? success : true);
+  r.rlane = rt;
+
+  // Lidar.get_surrounding_objects (lidar.py:109-124)
+  float px = S.x[base + s], py = S.y[base + s];
+  unsigned long long objs = 0ull;
+  // pmask = slots whose vehicle is in the physics world (wave-uniform with one env per wave: a scalar loop)
+  for (unsigned long long m = pmask & ~(1ull << s); m != 0ull; m &= m - 1ull) {
+    const int o = __builtin_ctzll(m);
+    const Obb ob = snap_obb(S, base + o);
+    const bool in = S.present[base + o] && shape_point_dist<OBJ>(ob, px, py) <= 50.0f;
+    objs |= in ? (1ull << o) : 0ull;
+  }
+
+  PHASE_MARK(9);  // idm: routing + broad phase
+  int front_obj = -1;
+  float front_dist = 5.0f;
+  int steer_lane = rt;
+  float speed = S.spd[base + s];
+  // one neighbour search for both branches of IDMPolicy.act (idm_policy.py:195-208): with the reference lanes when the
+  // routing lane is on the current road, on the routing lane alone otherwise; the reference's failed assert (routing lane
+  // not in ref lanes although move_to_next_road succeeded) falls back to "no front object, distance 5"
+  const bool search = !success || in_cur;
+  Fbo fb;
+  if (search) find_front_back(mv, g, S, base, V, s, objs, rt, MAXD, success, fb);
+  PHASE_MARK(10);  // idm: front/back search
+  if (success && in_cur) {
+    int idx = mv.lanes[rt].index;
+    int n_cur = CR.n_lanes;
+    int avail_lo = 0, avail_hi = n_cur - 1;
+    bool decided = false;
+    if (r.ck0 != r.ck1) {
+      const pgd_road& NR = mv.roads[sp.ckpt_road[r.ck1]];
+      int diff = n_cur - NR.n_lanes;
+      if (diff > 0) {
+        if (lane_is_prev_of(mv.lanes[CR.first_lane], NR.first_lane)) { avail_lo = 0; avail_hi = NR.n_lanes - 1; }
+        else { avail_lo = diff; avail_hi = n_cur - 1; }
+        if (idx < avail_lo || idx > avail_hi) {
+          int side = idx > avail_hi ? 0 : 2;  // 0: change to left, 2: change to right
+          // static indices only: a runtime index would push the whole Fbo into scratch memory
+          const float side_bd = side == 0 ? fb.bd[0] : fb.bd[2], side_fd = side == 0 ? fb.fd[0] : fb.fd[2];
+          const int side_front = side == 0 ? fb.front[0] : fb.front[2];
+          if (side_bd < SAFE || side_fd < 5.0f) {
+            r.target = CREEP;
+            front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
+          } else {
+            r.target = NORMAL;
+            front_obj = side_front; front_dist = side_fd;
+            steer_lane = CR.first_lane + idx + (side == 0 ? -1 : 1);
+          }
+          decided = true;
+        }
+      }
+    }
+    if (!decided) {
+      if (fabsf(speed - NORMAL) > 3.0f && fb.front[1] >= 0 && fabsf(S.spd[base + fb.front[1]] - NORMAL) > 3.0f &&
+          r.timer > 50) {
+        float fs = S.spd[base + fb.front[1]];
+        bool has_r = false, has_l = false;
+        float rs = 0.0f, ls = 0.0f;
+        if (fb.front[2] >= 0) { has_r = true; rs = S.spd[base + fb.front[2]]; }
+        else if (fb.exist[2] && fb.fd[2] > SAFE && fb.bd[2] > SAFE) { has_r = true; rs = 100.0f; }
+        if (fb.front[0] >= 0) { has_l = true; ls = S.spd[base + fb.front[0]]; }
+        else if (fb.exist[0] && fb.fd[0] > SAFE && fb.bd[0] > SAFE) { has_l = true; ls = 100.0f; }
+        if (has_l && ls - fs > 10.0f) {
+          int ex = idx - 1;
+          if (ex >= avail_lo && ex <= avail_hi) {
+            front_obj = fb.front[0]; front_dist = fb.fd[0]; steer_lane = CR.first_lane + ex; decided = true;
+          }
+        }
+        if (!decided && has_r && rs - fs > 10.0f) {
+          int ex = idx + 1;
+          if (ex >= avail_lo && ex <= avail_hi) {
+            front_obj = fb.front[2]; front_dist = fb.fd[2]; steer_lane = CR.first_lane + ex; decided = true;
+          }
+        }
+      }
+      if (!decided) {
+        r.target = NORMAL;
+        r.timer += 1;
+        front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
+      }
+    }
+  } else if (!success) {
+    front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
+  }
+  PHASE_MARK(11);  // idm: lane-change logic
+
+  // steering_control (idm_policy.py:244-252)
+  const pgd_lane& SL = mv.lanes[steer_lane];
+  float lon, lat;
+  lane_local(SL, px, py, lon, lat);
+  float lane_heading = lane_heading_at(SL, lon + 1.0f);
+  float steering = pid_update(r.php, r.phi, 1.7f, 0.01f, 3.5f, wrap_to_pi(lane_heading - r.th));
+  steering += pid_update(r.plp, r.pli, 0.3f, 0.002f, 0.05f, -lat);
+  // acceleration / desired_gap (idm_policy.py:254-271)
+  float ratio = fmaxf(speed, 0.0f) / not_zero(r.target, 0.0f);
+  float r2 = ratio * ratio, r4 = r2 * r2, r8 = r4 * r4;
+  float acc = 1.0f - r8 * r2;
+  if (front_obj >= 0) {
+    float hx = S.ux[base + s], hy = S.uy[base + s];
+    float fsp = S.spd[base + front_obj];
+    float dvx = speed * hx - fsp * S.ux[base + front_obj], dvy = speed * hy - fsp * S.uy[base + front_obj];
+    float dv = dvx * hx + dvy * hy;
+    float d_star = 10.0f + speed * 1.5f + speed * dv / (2.0f * 2.2360679774997896f);
+    float sd = d_star / not_zero(front_dist, 1e-2f);
+    acc -= sd * sd;
+  }
+  out_steer = steering;
+  out_acc = acc;
+  PHASE_MARK(12);  // idm: PID + IDM law
+}
+
+#endif

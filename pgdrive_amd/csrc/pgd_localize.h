@@ -1,0 +1,258 @@
+// pgd_localize.h -- lane localisation, checkpoints, line / sidewalk contacts, route context, after_step.
+// Part of the single translation unit pgd_engine.hip (included there, in this order, after pgd_device.h).
+#ifndef PGD_LOCALIZE_H
+#define PGD_LOCALIZE_H
+
+// ---------------------------------------------------------------------------------------------------------------------
+// localisation: utils/scene_utils.py:138-185 + navigation.py:328-344.  "First hit" = smallest box id (Bullet insertion
+// order); the cell-major box copies keep that order, so the smallest list position per class is the answer.
+// key = (position in cell << 16) | lane id
+// ---------------------------------------------------------------------------------------------------------------------
+// Device-side cell index (built by pgd_upload_maps): inside a cell the lane-surface boxes come first (original relative
+// order), the line / sidewalk boxes follow.  cstart[c] = first item | (number of lane boxes << 24); the cell ends where the
+// next one starts.  Localisation scans only the lane part, the contact / ray tests only the rest.
+DEV int cell_first(int c) { return c & 0xffffff; }
+DEV int cell_mid(int c) { return (c & 0xffffff) + (int)((unsigned)c >> 24); }
+
+// nearest hit fraction of the segment p + t d (t in [0,1]) against the map's boxes whose kind is in `kinds`: Amanatides-Woo
+// walk over the uniform grid; a cell is skipped once its entry parameter is beyond the best hit so far
+DEV float ray_grid(const MapView& mv, float px, float py, float dx, float dy, unsigned kinds) {
+  const pgd_map& m = *mv.m;
+  const float inv = 1.0f / m.cell;
+  int ix = (int)floorf((px - m.ox) * inv), iy = (int)floorf((py - m.oy) * inv);
+  const int sx = dx > 0.0f ? 1 : -1, sy = dy > 0.0f ? 1 : -1;
+  const float big = 3.0e38f;
+  const float tdx = dx != 0.0f ? fabsf(m.cell / dx) : big, tdy = dy != 0.0f ? fabsf(m.cell / dy) : big;
+  float tmx = dx != 0.0f ? ((m.ox + (ix + (dx > 0.0f ? 1 : 0)) * m.cell) - px) / dx : big;
+  float tmy = dy != 0.0f ? ((m.oy + (iy + (dy > 0.0f ? 1 : 0)) * m.cell) - py) / dy : big;
+  float best = 1.0f, t_enter = 0.0f;
+  for (int it = 0; it < 64; ++it) {
+    if (t_enter > best + 0.02f) break;  // boxes are registered with a 5 cm margin: keep a little slack
+    if (ix >= 0 && iy >= 0 && ix < m.gx && iy < m.gy) {
+      const int cell = iy * m.gx + ix;
+      const int k1 = cell_first(mv.cstart[cell + 1]);
+      for (int k = cell_mid(mv.cstart[cell]); k < k1; ++k) {
+        const pgd_box b = mv.cbox[k];
+        if (!((1u << b.kind) & kinds)) continue;
+        best = fminf(best, ray_obb(obb_of(b), px, py, dx, dy));
+      }
+    } else if ((sx > 0 ? ix >= m.gx : ix < 0) || (sy > 0 ? iy >= m.gy : iy < 0)) {
+      break;  // left the grid for good
+    }
+    if (tmx < tmy) { t_enter = tmx; tmx += tdx; ix += sx; }
+    else { t_enter = tmy; tmy += tdy; iy += sy; }
+    if (t_enter > 1.0f) break;
+  }
+  return best;
+}
+
+
+DEV int get_current_lane(const MapView& mv, const Grp& g, float px, float py, float hx, float hy, int road_cur,
+                         int road_next) {
+  const pgd_map& m = *mv.m;
+  int cx = (int)floorf((px - m.ox) / m.cell), cy = (int)floorf((py - m.oy) / m.cell);
+  int k0 = 0, k1 = 0;
+  if (cx >= 0 && cy >= 0 && cx < m.gx && cy < m.gy) {
+    const int c = mv.cstart[cy * m.gx + cx];
+    k0 = cell_first(c);
+    k1 = cell_mid(c);
+  }
+  unsigned best_cur = 0xffffffffu, best_next = 0xffffffffu, best_any = 0xffffffffu;
+  const int stride = g.SUB;
+  constexpr int NB = 3;  // boxes per sub-lane and round: a cell holds 3-9 lane boxes, so one round is the rule
+  for (int k = k0 + g.sub; k < k1; k += NB * stride) {
+    pgd_box b[NB];
+    LaneExt x[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      int kk = k + j * stride;
+      kk = kk < k1 ? kk : k;
+      b[j] = mv.cbox[kk];  // batch the independent loads
+      x[j] = mv.cext[kk];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      int kk = k + j * stride;
+      if (kk >= k1) continue;
+      if (!point_in_obb(obb_of(b[j]), px, py)) continue;
+      unsigned key = ((unsigned)(kk - k0) << 16) | (unsigned)b[j].lane;
+      bool is_cur = x[j].road == road_cur, is_next = x[j].road == road_next;
+      if (!(key < best_any || (is_cur && key < best_cur) || (is_next && key < best_next))) continue;
+      // cos(angle between lane heading at the point and vehicle heading) > 0 (scene_utils.py:158-172); only the sign is
+      // used, so the lane direction is taken in closed form: straight = unit dir; arc = dir * (-dy, dx) around the centre
+      float dirx, diry;
+      if (x[j].dir == 0.0f) { dirx = x[j].ax; diry = x[j].ay; }
+      else { dirx = -x[j].dir * (py - x[j].ay); diry = x[j].dir * (px - x[j].ax); }
+      if (!(dirx * hx + diry * hy > 0.0f)) continue;
+      best_any = min(best_any, key);
+      if (is_cur) best_cur = min(best_cur, key);
+      if (is_next) best_next = min(best_next, key);
+    }
+  }
+  best_cur = group_min(best_cur, g);
+  best_next = group_min(best_next, g);
+  best_any = group_min(best_any, g);
+  unsigned pick = best_cur != 0xffffffffu ? best_cur : (road_next < 0 ? best_any : (best_next != 0xffffffffu ? best_next : best_any));
+  return pick == 0xffffffffu ? -1 : (int)(pick & 0xffffu);
+}
+
+// Navigation._update_target_checkpoints (navigation.py:262-282)
+DEV void update_checkpoints(const MapView& mv, const pgd_spawn& sp, Veh& r, float lon) {
+  if (r.ck0 == r.ck1) return;
+  if (!(lon < 5.0f)) return;
+  int n = sp.n_ckpt;
+  int start_node = mv.roads[mv.lanes[r.lane].road].from;
+  bool in_tail = false;
+  int idx = -1;
+  for (int k = r.ck1; k < n; ++k) {
+    if (sp.ckpt[k] == start_node) {
+      in_tail = true;
+      if (idx < 0 && k < n - 1) idx = k;
+    }
+  }
+  if (!in_tail || idx < 0) return;
+  r.ck0 = idx;
+  r.ck1 = (idx + 1 == n - 1) ? idx : idx + 1;
+}
+
+// Navigation.update_localization (navigation.py:155-183)
+DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r) {
+  const float s = r.hy, c = r.hx;
+  int road_cur = sp.ckpt_road[r.ck0];
+  int road_next = (r.ck0 == r.ck1) ? -1 : sp.ckpt_road[r.ck1];
+  PHASE_MARK(16);  // after_step: route roads
+  int lane = get_current_lane(mv, g, r.x, r.y, c, s, road_cur, road_next);
+  PHASE_MARK(17);  // after_step: get_current_lane
+  bool on_lane = lane >= 0;
+  if (!on_lane) lane = r.lane;
+  r.lane = lane;
+  float lon, lat;
+  lane_local(mv.lanes[lane], r.x, r.y, lon, lat);
+  update_checkpoints(mv, sp, r, lon);
+  r.vflags = on_lane ? (r.vflags & ~PGD_F_OFF_LANE) : (r.vflags | PGD_F_OFF_LANE);
+  PHASE_MARK(18);  // after_step: lane_local + checkpoints
+}
+
+// BaseVehicle._state_check (base_vehicle.py:615-644)
+DEV unsigned state_check(const MapView& mv, const Grp& g, const Obb& car) {
+  const pgd_map& m = *mv.m;
+  float ex = fabsf(car.ux) * car.hl + fabsf(car.uy) * car.hw, ey = fabsf(car.uy) * car.hl + fabsf(car.ux) * car.hw;
+  int cx0 = max((int)floorf((car.cx - ex - m.ox) / m.cell), 0), cx1 = min((int)floorf((car.cx + ex - m.ox) / m.cell), m.gx - 1);
+  int cy0 = max((int)floorf((car.cy - ey - m.oy) / m.cell), 0), cy1 = min((int)floorf((car.cy + ey - m.oy) / m.cell), m.gy - 1);
+  unsigned fl = 0;
+  const int stride = g.SUB;
+  for (int cy = cy0; cy <= cy1; ++cy)
+    for (int cx = cx0; cx <= cx1; ++cx) {
+      int cell = cy * m.gx + cx;
+      int k0 = cell_mid(mv.cstart[cell]), k1 = cell_first(mv.cstart[cell + 1]);
+      for (int k = k0 + g.sub; k < k1; k += 4 * stride) {
+        pgd_box b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int kk = k + j * stride;
+          b[j] = mv.cbox[kk < k1 ? kk : k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int kk = k + j * stride;
+          if (kk >= k1) continue;
+          unsigned bit = b[j].kind == PGD_BOX_WHITE ? PGD_F_ON_WHITE
+                         : b[j].kind == PGD_BOX_YELLOW ? PGD_F_ON_YELLOW
+                         : b[j].kind == PGD_BOX_BROKEN ? PGD_F_ON_BROKEN : PGD_F_CRASH_SIDEWALK;
+          if (fl & bit) continue;
+          if (obb_overlap(car, obb_of(b[j]))) fl |= bit;
+        }
+      }
+    }
+  return group_or(fl, g);
+}
+
+// What the later phases need from the agent's route position (Navigation.current_ref_lanes / next_ref_lanes,
+// navigation.py:155-183): looked up once per step after the checkpoint update, then reused by the side distances, the
+// reward and the observation instead of re-walking spawn record -> road table each time.
+struct RouteCtx {
+  int blk;         // Road.block_ID char of the current road
+  int road_cur;    // road id of checkpoints[ck0] -> checkpoints[ck0 + 1]
+  int cur_first;   // its first lane (current_ref_lanes[0]) ...
+  int cur_n;       // ... and lane count
+  int next_first;  // first lane of the next checkpoint road (== cur_first on the last road)
+};
+DEV RouteCtx route_ctx(const MapView& mv, const pgd_spawn& sp, int ck0, int ck1) {
+  const int rc = sp.ckpt_road[ck0], rn = sp.ckpt_road[ck1];
+  const pgd_road& CR = mv.roads[rc];
+  const pgd_road& NR = mv.roads[rn];
+  return RouteCtx{CR.block_id, rc, CR.first_lane, CR.n_lanes, NR.first_lane};
+}
+
+// BaseVehicle.after_step (base_vehicle.py:255-290).  `with_state_check` = false lets the caller run the line / sidewalk
+// test wave-cooperatively afterwards (k_step with one env per wave) and OR the result into vflags.
+DEV void after_step_vehicle(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, bool is_agent,
+                            bool with_state_check, RouteCtx& ctx) {
+  update_localization(mv, g, sp, r);
+  if (is_agent) {
+    ctx = route_ctx(mv, sp, r.ck0, r.ck1);
+    unsigned fl = (unsigned)r.vflags;
+    fl &= ~(PGD_F_ON_WHITE | PGD_F_ON_YELLOW | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OUT_OF_ROUTE);
+    if (with_state_check) fl |= state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sp.length, 0.5f * sp.width});
+    float lon, lat;
+    const pgd_lane& L0 = mv.lanes[ctx.cur_first];
+    lane_local(L0, r.x, r.y, lon, lat);
+    float w = mv.m->lane_width;
+    r.dl = lat + w * 0.5f;
+    float range = w * ctx.cur_n;
+    if (ctx.blk == 'y' || ctx.blk == 'Y') {
+      // Navigation.get_current_lateral_range on Merge / Split blocks (navigation.py:306-320,346-362): a 50 m ray from the
+      // left edge of the leftmost reference lane across the road against the continuous lane lines
+      float sx, sy;
+      lane_position(L0, lon, -0.5f * L0.width, sx, sy);
+      range = 50.0f * ray_grid(mv, sx, sy, -L0.by * 50.0f, L0.bx * 50.0f, (1u << PGD_BOX_WHITE) | (1u << PGD_BOX_YELLOW));
+    }
+    r.dr = range - r.dl;
+    if (r.dr < 0.0f || r.dl < 0.0f) fl |= PGD_F_OUT_OF_ROUTE;
+    r.vflags = (int)fl;
+    float dist = norm2(r.lastx - r.x, r.lasty - r.y) / 1000.0f;
+    r.energy += 3.25f * expf(0.01f * speed_kmh(r.v)) * dist / 100.0f * 1000.0f;
+    PHASE_MARK(19);  // after_step: side distances
+  }
+}
+
+// the same test with the whole wave on one car: the (<= 2x2) grid cells under the car are flattened into one index range
+DEV unsigned state_check_wave(const MapView& mv, const Obb& car) {
+  const pgd_map& m = *mv.m;
+  const int lane = threadIdx.x;
+  float ex = fabsf(car.ux) * car.hl + fabsf(car.uy) * car.hw, ey = fabsf(car.uy) * car.hl + fabsf(car.ux) * car.hw;
+  int cx0 = max((int)floorf((car.cx - ex - m.ox) / m.cell), 0), cx1 = min((int)floorf((car.cx + ex - m.ox) / m.cell), m.gx - 1);
+  int cy0 = max((int)floorf((car.cy - ey - m.oy) / m.cell), 0), cy1 = min((int)floorf((car.cy + ey - m.oy) / m.cell), m.gy - 1);
+  unsigned fl = 0;
+  for (int cyb = cy0; cyb <= cy1; cyb += 2)
+    for (int cxb = cx0; cxb <= cx1; cxb += 2) {  // blocks of up to 2x2 cells (a car spans at most 2 cells per axis)
+      int k0[4], pre[5];
+      pre[0] = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int cx = cxb + (q & 1), cy = cyb + (q >> 1);
+        bool in = cx <= cx1 && cy <= cy1;
+        int cell = in ? cy * m.gx + cx : 0;
+        int a = cell_mid(mv.cstart[cell]), b = cell_first(mv.cstart[cell + 1]);
+        k0[q] = a;
+        pre[q + 1] = pre[q] + (in ? b - a : 0);
+      }
+      for (int f = lane; f < pre[4]; f += WAVE) {
+        int q = (f >= pre[1]) + (f >= pre[2]) + (f >= pre[3]);
+        int kk = (q == 0 ? k0[0] : q == 1 ? k0[1] : q == 2 ? k0[2] : k0[3]) + f - (q == 0 ? pre[0] : q == 1 ? pre[1] : q == 2 ? pre[2] : pre[3]);
+        pgd_box b = mv.cbox[kk];
+        unsigned bit = b.kind == PGD_BOX_WHITE ? PGD_F_ON_WHITE
+                       : b.kind == PGD_BOX_YELLOW ? PGD_F_ON_YELLOW
+                       : b.kind == PGD_BOX_BROKEN ? PGD_F_ON_BROKEN : PGD_F_CRASH_SIDEWALK;
+        if (obb_overlap(car, obb_of(b))) fl |= bit;
+      }
+    }
+  unsigned out = 0;
+  if (__ballot((fl & PGD_F_ON_WHITE) != 0)) out |= PGD_F_ON_WHITE;
+  if (__ballot((fl & PGD_F_ON_YELLOW) != 0)) out |= PGD_F_ON_YELLOW;
+  if (__ballot((fl & PGD_F_ON_BROKEN) != 0)) out |= PGD_F_ON_BROKEN;
+  if (__ballot((fl & PGD_F_CRASH_SIDEWALK) != 0)) out |= PGD_F_CRASH_SIDEWALK;
+  return out;
+}
+
+#endif

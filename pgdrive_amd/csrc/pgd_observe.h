@@ -1,0 +1,194 @@
+// pgd_observe.h -- observation: state + navigation block, detector fans, neighbour rows, lidar.
+// Part of the single translation unit pgd_engine.hip (included there, in this order, after pgd_device.h).
+#ifndef PGD_OBSERVE_H
+#define PGD_OBSERVE_H
+
+// ---------------------------------------------------------------------------------------------------------------------
+// observation: LidarStateObservation.observe (obs/state_obs.py:132-170) for one (env, agent)
+// ---------------------------------------------------------------------------------------------------------------------
+DEV void navi_info_for(const pgd_lane& ref, float w, int n_cur, float px, float py, float hx, float hy, float* out) {
+  // Navigation._get_info_for_checkpoint (navigation.py:213-260); ref = ref_lanes[0] of the checkpoint's road
+  float later_middle = ((float)n_cur * 0.5f - 0.5f) * w;
+  float cx, cy;
+  lane_position(ref, ref.length, later_middle, cx, cy);
+  float dx = cx - px, dy = cy - py;
+  float dn = norm2(dx, dy);
+  if (dn > 50.0f) { dx = dx / dn * 50.0f; dy = dy / dn * 50.0f; }
+  float ph, ps;
+  projection(hx, hy, dx, dy, ph, ps);
+  float bend = 0.0f, dir = 0.0f, angle = 0.0f;
+  if (ref.dir != 0.0f) {
+    bend = ref.bx / (60.0f + n_cur * w);
+    dir = ref.dir;
+    angle = dir == 1.0f ? ref.c - ref.by : ref.by - ref.c;
+  }
+  out[0] = clipf((ph / 50.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
+  out[1] = clipf((ps / 50.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
+  out[2] = clipf(bend, 0.0f, 1.0f);
+  out[3] = clipf((dir + 1.0f) * 0.5f, 0.0f, 1.0f);
+  out[4] = clipf((angle * (180.0f / PGD_PI) / 135.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
+}
+
+DEV float heading_diff(const pgd_lane& l, float px, float py, float fx, float fy) {  // base_vehicle.py:433-458
+  float lx, ly;
+  if (l.dir == 0.0f) { lx = -l.by; ly = l.bx; }
+  else if (l.dir < 0.0f) { lx = px - l.ax; ly = py - l.ay; }
+  else { lx = l.ax - px; ly = l.ay - py; }
+  float ln = norm2(lx, ly), fn = norm2(fx, fy);
+  if (ln * fn == 0.0f) return 0.0f;
+  return clipf((fx * lx + fy * ly) / (ln * fn), -1.0f, 1.0f) * 0.5f + 0.5f;
+}
+
+struct ObsLds {  // bodies inside the lidar broad phase of the observing agent, compacted
+  float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV];
+  float bdist[MAXV];  // centre distance; +inf for traffic objects, which are never ranked as neighbour vehicles
+  int n, nveh;
+};
+struct AgentView {  // what the observation needs from the observing vehicle
+  float x, y, th, hx, hy, dl, dr, v, steer, a0s, a0t, lhx, lhy;
+  int cur_first, cur_n, next_first;  // RouteCtx of the vehicle
+  int blk;                           // block id char of its current road
+  float toll_time;                   // TollGateObservation.in_toll_time (PGD_MA_TOLLGATE)
+  int env, slot;                     // for the lidar noise stream
+  uint32_t tick;                     // steps since pgd_reset
+};
+
+// one wave compacts the candidates: lane `o` brings vehicle o of the env (present = in the physics world)
+template <bool OBJ>
+DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, float x, float y, float ux, float uy, float hl,
+                     float hw, float spd, float px, float py, float R) {
+  if (!OBJ) is_vehicle = true;
+  bool in = present && o != a && shape_point_dist<OBJ>(Obb{x, y, ux, uy, hl, hw}, px, py) <= R;
+  unsigned long long m = __ballot(in), mv_ = OBJ ? __ballot(in && is_vehicle) : m;
+  if (in) {
+    int k = __popcll(m & ((1ull << o) - 1ull));
+    L.bx[k] = x; L.by[k] = y; L.bux[k] = ux; L.buy[k] = uy; L.bhl[k] = hl; L.bhw[k] = hw; L.bspd[k] = spd;
+    L.bdist[k] = is_vehicle ? norm2(px - x, py - y) : __builtin_inff();
+  }
+  if (o == 0) { L.n = __popcll(m); L.nveh = __popcll(mv_); }
+}
+
+// writes the D floats of one agent's row with `nt` cooperating threads (tid in [0, nt))
+template <bool OBJ>
+DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const AgentView& ag, const ObsLds& L,
+                       float* __restrict__ row, int tid, int nt) {
+  const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
+  const float R = d.cfg.lidar_dist;
+  const int NL = d.cfg.num_lasers;
+  // StateObservation.vehicle_state (state_obs.py:58-106) + navi info (navigation.py:185-197): one lane per float.
+  // Row layout: [side fan k | 2 lateral distances][6 ego floats][lane-line fan m][10 navi][4*NO neighbours][NL beams]
+  const int KS = d.cfg.side_lasers, KM = d.cfg.lane_line_lasers;
+  const bool toll = (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;  // no navigation block, 2 toll floats after the lidar
+  const int RAM = d.cfg.random_agent_model ? 2 : 0;  // LENGTH / 10, WIDTH / 2.5 after the lane-line fan (state_obs.py:102-105)
+  const int o_ego = KS > 0 ? KS : 2, o_navi = o_ego + 6 + KM + RAM, o_oth = o_navi + (toll ? 0 : 10);
+  if (RAM && tid == nt - 1) {
+    row[o_ego + 6 + KM] = clipf(sp.length / 10.0f, 0.0f, 1.0f);
+    row[o_ego + 6 + KM + 1] = clipf(sp.width / 2.5f, 0.0f, 1.0f);
+  }
+  if (toll && tid == 0) {  // TollGateObservation.observe (marl_tollgate.py:84-96)
+    const bool in_toll = ag.blk == '$';
+    float* t2 = row + o_oth + 4 * d.cfg.num_others + NL;
+    t2[0] = in_toll ? 1.0f : 0.0f;
+    t2[1] = (in_toll && ag.toll_time > (float)d.cfg.min_pass_steps) ? 1.0f : 0.0f;
+  }
+  if (tid < 18) {
+    // every lane fetches the one lane record its float needs BEFORE the branch ladder, so the reads overlap instead of
+    // queueing behind each other branch by branch: heading_diff -> last lane of the current road; navi -> first lanes
+    const int lid = tid < 8 ? ag.cur_first + ag.cur_n - 1 : (tid < 13 ? ag.cur_first : ag.next_first);
+    const pgd_lane ml = mv.lanes[lid];
+    const float max_speed = sp.max_speed;
+    float v = 0.0f;
+    int col = -1;
+    if (tid == 0) { v = clipf(ag.dl / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 0; }  // (MAX_LANE_NUM+1)*MAX_LANE_WIDTH
+    else if (tid == 1) { v = clipf(ag.dr / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 1; }
+    else if (tid == 2) { v = heading_diff(ml, px, py, hx, hy); col = o_ego; }
+    else if (tid == 3) { v = clipf((speed_kmh(ag.v) + 1.0f) / (max_speed + 1.0f), 0.0f, 1.0f); col = o_ego + 1; }
+    else if (tid == 4) { v = clipf((ag.steer / 60.0f + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 2; }
+    else if (tid == 5) { v = clipf((ag.a0s + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 3; }
+    else if (tid == 6) { v = clipf((ag.a0t + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 4; }
+    else if (tid == 7) {
+      // acos(clip(cos_beta, 0, 1)) (state_obs.py:87-92) evaluated as atan2(|cross|, dot): identical for unit vectors,
+      // but well-conditioned in fp32 near beta = 0 where 1 - cos(beta) underflows the mantissa
+      float dot = hx * ag.lhx + hy * ag.lhy, cross = hx * ag.lhy - hy * ag.lhx;
+      float beta = dot <= 0.0f ? 0.5f * PGD_PI : atan2f(fabsf(cross), dot);
+      v = clipf(beta / 0.1f, 0.0f, 1.0f);
+      col = o_ego + 5;
+    } else {  // lanes 8..12 -> checkpoint 1, 13..17 -> checkpoint 2
+      int which = (tid - 8) / 5, comp = (tid - 8) - which * 5;
+      float out[5];
+      navi_info_for(ml, mv.m->lane_width, ag.cur_n, px, py, hx, hy, out);
+      v = comp == 0 ? out[0] : comp == 1 ? out[1] : comp == 2 ? out[2] : comp == 3 ? out[3] : out[4];
+      col = toll ? -1 : o_navi + (tid - 8);
+    }
+    if (col >= 0) row[col] = v;
+  }
+  // SideDetector / LaneLineDetector fans (distance_detector.py:137-152): beam i at theta + i*2pi/n + 90 deg, cast through
+  // the map grid against the line boxes of the wanted kinds
+  for (int q = tid; q < KS + KM; q += nt) {
+    const bool side = q < KS;
+    const int i = side ? q : q - KS, n = side ? KS : KM;
+    const float dist = side ? d.cfg.side_dist : d.cfg.lane_line_dist;
+    const unsigned kinds = side ? ((1u << PGD_BOX_WHITE) | (1u << PGD_BOX_YELLOW))
+                                : ((1u << PGD_BOX_WHITE) | (1u << PGD_BOX_YELLOW) | (1u << PGD_BOX_BROKEN));
+    float sn, cs;
+    sincosf((float)i * (2.0f * PGD_PI / (float)n) + 0.5f * PGD_PI + ag.th, &sn, &cs);
+    row[side ? i : o_ego + 6 + i] = ray_grid(mv, px, py, dist * cs, dist * sn, kinds);
+  }
+  PHASE_MARK(22);  // obs: state + navi block
+  if (NL <= 0) return;
+  // get_surrounding_vehicles_info (lidar.py:55-77): rank by centre distance (stable), 4 floats per neighbour; the last
+  // threads take this part so that it overlaps the state block of the first ones
+  const int NO = d.cfg.num_others;
+  const int n = L.n, nveh = OBJ ? L.nveh : n;
+  // with objects: indices [0, n) are the compacted bodies, [n, n + NO) the rank rows to zero-fill; without: [0, max(n, NO))
+  for (int k = nt - 1 - tid; k < (OBJ ? n + NO : (n > NO ? n : NO)); k += nt) {
+    if (k < n) {
+      int rank = 0;
+      float dk = L.bdist[k];
+      for (int j = 0; j < n; ++j) rank += (L.bdist[j] < dk || (L.bdist[j] == dk && j < k)) ? 1 : 0;
+      if (rank < NO && dk < __builtin_inff()) {
+        float ph, ps;
+        float ms = sp.max_speed;
+        float sp_me = speed_kmh(ag.v);
+        projection(hx, hy, L.bx[k] - px, L.by[k] - py, ph, ps);
+        float* o = row + o_oth + rank * 4;
+        o[0] = clipf((ph / R + 1.0f) * 0.5f, 0.0f, 1.0f);
+        o[1] = clipf((ps / R + 1.0f) * 0.5f, 0.0f, 1.0f);
+        projection(hx, hy, L.bspd[k] * L.bux[k] - sp_me * hx, L.bspd[k] * L.buy[k] - sp_me * hy, ph, ps);
+        o[2] = clipf((ph / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
+        o[3] = clipf((ps / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
+      }
+    } else if (!OBJ || k - n >= nveh) {  // ranks [nveh, NO): absent neighbour -> zeros
+      float* o = row + o_oth + (OBJ ? k - n : k) * 4;
+      o[0] = o[1] = o[2] = o[3] = 0.0f;
+    }
+  }
+  PHASE_MARK(23);  // obs: neighbours
+  // lidar (distance_detector.py:65-94, cutils.pyx:60-142): beam i at theta + i*2pi/N, nearest hit fraction
+  const float unit = 2.0f * PGD_PI / (float)NL;
+  for (int i = tid; i < NL; i += nt) {
+    float ang = (float)i * unit + ag.th;
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    float dx = R * cs, dy = R * sn;
+    float best = 1.0f;
+    for (int k = 0; k < n; ++k)
+      best = fminf(best, shape_ray<OBJ>(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
+    if (d.cfg.lidar_gaussian_noise > 0.0f || d.cfg.lidar_dropout_prob > 0.0f) {  // state_obs.py:172-182
+      const uint32_t key = 0x51d0a000u + (uint32_t)ag.slot * 1024u + (uint32_t)i;
+      if (d.cfg.lidar_gaussian_noise > 0.0f) {
+        const float u1 = ((float)(pgd_rng(d.cfg.seed, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(pgd_rng(d.cfg.seed ^ 0x9e3779b9u, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        best = clipf(best + d.cfg.lidar_gaussian_noise * sqrtf(-2.0f * logf(u1)) * cosf(2.0f * PGD_PI * u2), 0.0f, 1.0f);
+      }
+      if (d.cfg.lidar_dropout_prob > 0.0f) {
+        const float u3 = ((float)(pgd_rng(d.cfg.seed ^ 0x7f4a7c15u, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        if (u3 < d.cfg.lidar_dropout_prob) best = 0.0f;
+      }
+    }
+    row[o_oth + 4 * NO + i] = best;
+  }
+  PHASE_MARK(24);  // obs: lidar
+}
+
+#endif
