@@ -69,21 +69,24 @@ DEV void reset_vehicle(const pgd_spawn& p, Veh& r, int spawn_index, bool is_agen
 }
 
 // reward / done: envs/pgdrive_env.py:162-258, base_vehicle.py:738-745
+// MARL = false: the single-agent env; none of the multi-agent reward / out-of-road variants (marl_flags == 0) is compiled in.
+template <bool MARL>
 DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const Veh& r, const RouteCtx& ctx,
                       unsigned& flags_out, bool& done_out) {
   const pgd_config& g = d.cfg;
+  const int mflags = MARL ? g.marl_flags : 0;
   unsigned vf = (unsigned)r.vflags;
   const pgd_lane& VL = mv.lanes[r.lane];
   bool in_ref = VL.road == ctx.road_cur;
   const pgd_lane& cl = in_ref ? VL : mv.lanes[ctx.cur_first];
-  float positive = (in_ref || (g.marl_flags & PGD_MA_PLAIN_REWARD)) ? 1.0f : (mv.roads[VL.road].negative ? -1.0f : 1.0f);
+  float positive = (in_ref || (mflags & PGD_MA_PLAIN_REWARD)) ? 1.0f : (mv.roads[VL.road].negative ? -1.0f : 1.0f);
   float l0, t0, l1, t1;
   lane_local(cl, r.lastx, r.lasty, l0, t0);
   lane_local(cl, r.x, r.y, l1, t1);
   float w = mv.m->lane_width;
   float lateral_factor = g.use_lateral ? clipf(1.0f - 2.0f * fabsf(t1) / w, 0.0f, 1.0f) : 1.0f;
   float reward = g.driving_reward * (l1 - l0) * lateral_factor * positive;
-  if (g.marl_flags & PGD_MA_TOLLGATE) {  // MultiAgentTollgateEnv.reward_function (marl_tollgate.py:195-232)
+  if (mflags & PGD_MA_TOLLGATE) {  // MultiAgentTollgateEnv.reward_function (marl_tollgate.py:195-232)
     if (ctx.blk == '$') {
       // BaseVehicle.overspeed (base_vehicle.py:759-761): lane.speed_limit (3 on toll lanes, 1000 elsewhere) < speed [km/h]
       const bool lane_toll = mv.roads[VL.road].block_id == '$';
@@ -97,10 +100,10 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
   float lon, lat;
   lane_local(fl, r.x, r.y, lon, lat);
   bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - ctx.cur_n) * w);
-  unsigned oor_bits = (g.marl_flags & PGD_MA_TOLLGATE) ? PGD_F_CRASH_SIDEWALK  // marl_tollgate.py:234-240
-                      : (g.marl_flags & PGD_MA_PARKING) ? (PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK)  // marl_parking_lot.py:213-217
+  unsigned oor_bits = (mflags & PGD_MA_TOLLGATE) ? PGD_F_CRASH_SIDEWALK  // marl_tollgate.py:234-240
+                      : (mflags & PGD_MA_PARKING) ? (PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK)  // marl_parking_lot.py:213-217
                                                         : (PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK);
-  if (!(g.marl_flags & PGD_MA_YELLOW_OK)) oor_bits |= PGD_F_ON_YELLOW;
+  if (!(mflags & PGD_MA_YELLOW_OK)) oor_bits |= PGD_F_ON_YELLOW;
   bool oor = (vf & oor_bits) != 0;
   if (g.out_of_route_done) oor = oor || (vf & PGD_F_OUT_OF_ROUTE);
   bool crash = (vf & PGD_F_CRASH_VEHICLE) != 0, crash_obj = (vf & PGD_F_CRASH_OBJECT) != 0;

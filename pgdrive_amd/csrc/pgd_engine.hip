@@ -97,7 +97,8 @@ extern __shared__ __align__(16) unsigned char s_dyn[];  // [lanes | roads] of th
 // occupying ~20 VGPRs per lane for the whole kernel.
 // MARL (multi-agent tail: delay-done, respawn, __all__) is compiled in only for the multi-agent engine.
 // OBJ: traffic objects present in some scenario (circle shapes, crash_object bookkeeping).
-template <bool ONE_ENV, bool MARL, bool OBJ>
+// STD: the fused observation has the default row layout (see observe_agent).
+template <bool ONE_ENV, bool MARL, bool OBJ, bool STD = false>
 __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
                                                 float* __restrict__ obs) {
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   float my_rew = 0.0f;
   const bool was_active = acting;  // status at the start of the step (after the delay-done countdown)
   if (valid && s < A && !marl) {
-    if (r.status == ST_ACTIVE) my_rew = reward_done(d, mv, *sp, r, ctx, my_fl, my_dn);
+    if (r.status == ST_ACTIVE) my_rew = reward_done<false>(d, mv, *sp, r, ctx, my_fl, my_dn);
     if (d.cfg.horizon > 0 && ep_steps >= d.cfg.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
     if (sc->max_steps > 0 && ep_steps >= sc->max_steps) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }  // auto_termination
     r.eprew += my_rew;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (parking) __syncthreads();
     if (valid && s < A && was_active) {
       if (toll && ctx.blk == '$') r.php += 1.0f;  // TollGateObservation.observe counts its calls inside the toll block
-      my_rew = reward_done(d, mv, *sp, r, ctx, my_fl, my_dn);
+      my_rew = reward_done<true>(d, mv, *sp, r, ctx, my_fl, my_dn);
       const bool arrive = my_fl & PGD_F_ARRIVE, oor = my_fl & PGD_F_OUT_OF_ROAD, crash = my_fl & PGD_F_CRASH_VEHICLE;
       if (crash && !(gcf.marl_flags & PGD_MA_CRASH_DONE) && !(arrive || oor)) my_dn = false;
       if (oor && !(gcf.marl_flags & PGD_MA_OUT_ROAD_DONE) && !arrive) my_dn = false;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
                   S.ux[lane], S.uy[lane], S.hl[lane], S.hw[lane], S.spd[lane], ag.x, ag.y, d.cfg.lidar_dist);
       __syncthreads();
       PHASE_MARK(21);  // obs: compaction
-      observe_agent<OBJ>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + ((size_t)blockIdx.x * A + a) * d.D, lane,
+      observe_agent<OBJ, STD>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + ((size_t)blockIdx.x * A + a) * d.D, lane,
                     WAVE);
       __syncthreads();
     }
@@ -881,7 +882,12 @@ int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward
   if (marl && h->d.epw != 1) return PGD_ERR_STATE;  // the multi-agent tail needs the env in one wave (V >= 33 or SUB split)
   void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*) = k_step<false, false, false>;
   if (marl) kern = h->has_objects ? k_step<true, true, true> : k_step<true, true, false>;  // objects = toll booths
-  else if (h->d.epw == 1) kern = h->has_objects ? k_step<true, false, true> : k_step<true, false, false>;
+  else if (h->d.epw == 1) {
+    const pgd_config& c = h->d.cfg;
+    const bool std_obs = c.side_lasers == 0 && c.lane_line_lasers == 0 && !c.random_agent_model &&
+                         c.lidar_gaussian_noise <= 0.0f && c.lidar_dropout_prob <= 0.0f;
+    kern = h->has_objects ? k_step<true, false, true> : (std_obs ? k_step<true, false, false, true> : k_step<true, false, false>);
+  }
   else if (h->has_objects) kern = k_step<false, false, true>;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), (size_t)h->d.lds_bytes, h->stream, h->d, d_actions, d_reward, d_done,
                      d_flags, fuse ? d_obs : (float*)nullptr);

@@ -69,7 +69,9 @@ DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, flo
 }
 
 // writes the D floats of one agent's row with `nt` cooperating threads (tid in [0, nt))
-template <bool OBJ>
+// STD: the reference's default row layout (no detector fans, no random_agent_model, no toll floats, no lidar noise) as a
+// compile-time fact: every column offset is a constant and the optional blocks vanish from the benchmark kernel.
+template <bool OBJ, bool STD = false>
 DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const AgentView& ag, const ObsLds& L,
                        float* __restrict__ row, int tid, int nt) {
   const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
@@ -77,9 +79,9 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   const int NL = d.cfg.num_lasers;
   // StateObservation.vehicle_state (state_obs.py:58-106) + navi info (navigation.py:185-197): one lane per float.
   // Row layout: [side fan k | 2 lateral distances][6 ego floats][lane-line fan m][10 navi][4*NO neighbours][NL beams]
-  const int KS = d.cfg.side_lasers, KM = d.cfg.lane_line_lasers;
-  const bool toll = (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;  // no navigation block, 2 toll floats after the lidar
-  const int RAM = d.cfg.random_agent_model ? 2 : 0;  // LENGTH / 10, WIDTH / 2.5 after the lane-line fan (state_obs.py:102-105)
+  const int KS = STD ? 0 : d.cfg.side_lasers, KM = STD ? 0 : d.cfg.lane_line_lasers;
+  const bool toll = !STD && (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;  // no navigation block, 2 toll floats after the lidar
+  const int RAM = (!STD && d.cfg.random_agent_model) ? 2 : 0;  // LENGTH / 10, WIDTH / 2.5 after the lane-line fan (state_obs.py:102-105)
   const int o_ego = KS > 0 ? KS : 2, o_navi = o_ego + 6 + KM + RAM, o_oth = o_navi + (toll ? 0 : 10);
   if (RAM && tid == nt - 1) {
     row[o_ego + 6 + KM] = clipf(sp.length / 10.0f, 0.0f, 1.0f);
@@ -174,7 +176,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
     float best = 1.0f;
     for (int k = 0; k < n; ++k)
       best = fminf(best, shape_ray<OBJ>(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
-    if (d.cfg.lidar_gaussian_noise > 0.0f || d.cfg.lidar_dropout_prob > 0.0f) {  // state_obs.py:172-182
+    if (!STD && (d.cfg.lidar_gaussian_noise > 0.0f || d.cfg.lidar_dropout_prob > 0.0f)) {  // state_obs.py:172-182
       const uint32_t key = 0x51d0a000u + (uint32_t)ag.slot * 1024u + (uint32_t)i;
       if (d.cfg.lidar_gaussian_noise > 0.0f) {
         const float u1 = ((float)(pgd_rng(d.cfg.seed, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
