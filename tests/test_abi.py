@@ -93,3 +93,35 @@ def test_engine_fails_loudly_without_gpu_or_library(monkeypatch):
     monkeypatch.setattr(engine, "_LIBH", None)
     with pytest.raises(RuntimeError, match="missing"):
         engine.load_library(path="/nonexistent/libpgdrive_hip.so")
+
+
+def test_field_offsets_match_c():
+    """offsetof() of every field of pgd_config / pgd_spawn / pgd_scenario / pgd_lane / pgd_road / pgd_box / pgd_map in the
+    header == the Python mirrors (a size check alone would not notice two swapped fields)."""
+    mirrors = {
+        "pgd_config": [(n, getattr(_abi.PgdConfig, n).offset) for n, _ in _abi.PgdConfig._fields_],
+        "pgd_spawn": [(n, scenario.SPAWN_DT.fields[n][1]) for n in scenario.SPAWN_DT.names],
+        "pgd_scenario": [(n, scenario.SCEN_DT.fields[n][1]) for n in scenario.SCEN_DT.names],
+        "pgd_lane": [(n, mapdata.LANE_DT.fields[n][1]) for n in mapdata.LANE_DT.names],
+        "pgd_road": [(n, mapdata.ROAD_DT.fields[n][1]) for n in mapdata.ROAD_DT.names],
+        "pgd_box": [(n, mapdata.BOX_DT.fields[n][1]) for n in mapdata.BOX_DT.names],
+        "pgd_map": [(n, mapdata.MAP_DT.fields[n][1]) for n in mapdata.MAP_DT.names],
+    }
+    alias = {("pgd_road", "frm"): "from"}  # python keyword
+    lines = []
+    for st, fields in mirrors.items():
+        for n, _ in fields:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (st, n, st, alias.get((st, n), n)))
+    prog = "#include <stdio.h>\n#include <stddef.h>\n#include \"pgdrive_hip.h\"\nint main(void) {\n" + "\n".join(lines) + "\n  return 0;\n}\n"
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "o.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(td, "o")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = dict(line.split() for line in subprocess.check_output([exe]).decode().strip().splitlines())
+    n = 0
+    for st, fields in mirrors.items():
+        for name, off in fields:
+            assert int(out["%s.%s" % (st, name)]) == off, (st, name, out["%s.%s" % (st, name)], off)
+            n += 1
+    assert n > 100
