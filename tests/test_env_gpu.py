@@ -257,3 +257,25 @@ def test_reference_expert_policy_reward_band(traffic_density):
             assert all(success)
     finally:
         env.close()
+
+
+def test_detectors_see_the_yellow_line_at_spawn():
+    """tests/test_functionality/test_distance_detector.py:9-50: at the spawn pose (lane 0, lateral 0) one beam of the
+    2-laser side detector and one of the 2-laser lane-line detector end on the yellow centre line ("yellow == 2"): the hit
+    is half a lane minus half a line width away; the opposite beams end on the broken line (lane-line detector) and on the
+    far side line (side detector)."""
+    from pgdrive_amd.env import PGDriveEnv
+    env = PGDriveEnv(dict(environment_num=1, start_seed=0, map="XXX", traffic_density=0.0,
+                          vehicle_config=dict(side_detector=dict(num_lasers=2, distance=50),
+                                              lane_line_detector=dict(num_lasers=2, distance=50))))
+    try:
+        o = env.reset()
+        assert o.shape == (2 + 6 + 2 + 10 + 16 + 240, )
+        w = 3.5
+        yellow = (w / 2 - 0.075) / 50
+        # PGDrive's frame is left-handed (y points down): heading + 90 deg is the driver's RIGHT, heading + 270 deg the LEFT
+        assert abs(o[1] - yellow) < 1e-4 and abs(o[9] - yellow) < 1e-4  # beam 1 of both fans ends on the yellow centre line
+        assert abs(o[8] - yellow) < 1e-4  # lane-line beam 0: the broken line between lanes 0 and 1, equally far to the right
+        assert abs(o[0] - (2.5 * w - 0.075) / 50) < 1e-4  # side beam 0 skips broken lines: the side line of the 3-lane road
+    finally:
+        env.close()
