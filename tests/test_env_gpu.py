@@ -279,3 +279,42 @@ def test_detectors_see_the_yellow_line_at_spawn():
         assert abs(o[0] - (2.5 * w - 0.075) / 50) < 1e-4  # side beam 0 skips broken lines: the side line of the 3-lane road
     finally:
         env.close()
+
+
+def test_vehicle_lane_is_among_the_closest_lanes():
+    """tests/test_functionality/test_get_closest_lane.py:4-28: on map "rRCXSOTCR" with respawn-mode traffic (density 0.3)
+    the lane a vehicle is localised on (ray localisation) must be one of the three closest lanes by L1 distance
+    (AbstractLane.distance, abs_lane.py:106-112) or closer than 4 m -- checked for every driving traffic vehicle."""
+    import torch
+    from pgdrive_amd import _abi, mapdata
+    from pgdrive_amd.vec_env import PGDriveVecEnv
+    env = PGDriveVecEnv(dict(num_envs=1, environment_num=1, start_seed=0, map="rRCXSOTCR", traffic_density=0.3,
+                             traffic_mode="respawn", max_traffic_vehicles=48, auto_reset=False))
+    try:
+        env.reset()
+        d = env.map_bank.descs[0]
+        lanes = [l for l in d["lanes"] if d["roads"][l["road"]]["valid"]]
+        act = torch.zeros((1, 2), device=env.engine.device)
+        checked = 0
+        for t in range(400):
+            env.step(act)
+            if t % 8:
+                continue
+            env.engine.sync()
+            f, i, _ = env.engine.get_state()
+            for s in range(1, env.engine.V):
+                if i[_abi.SI["STATUS"], 0, s] != _abi.ST_ACTIVE:
+                    continue
+                p = (float(f[_abi.SF["X"], 0, s]), float(f[_abi.SF["Y"], 0, s]))
+                mine = d["lanes"][int(i[_abi.SI["LANE"], 0, s])]
+
+                def l1(l):
+                    lon, lat = mapdata.lane_local_coordinates(l, p)
+                    return abs(lat) + max(lon - l["length"], 0.0) + max(-lon, 0.0)
+                dist = l1(mine)
+                rank = sum(1 for l in lanes if l1(l) < dist)
+                assert not (dist > 4.0 and rank > 2), (t, s, dist, rank)
+                checked += 1
+        assert checked > 300
+    finally:
+        env.close()
