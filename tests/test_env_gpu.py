@@ -318,3 +318,28 @@ def test_vehicle_lane_is_among_the_closest_lanes():
         assert checked > 300
     finally:
         env.close()
+
+
+def test_obs_noise_config():
+    """tests/test_functionality/test_obs_noise.py:23-58: dropout 1.0 wipes the whole lidar cloud, the observation stays
+    inside its space for every corner action; 0 / 0 leaves the cloud untouched."""
+    from pgdrive_amd.env import PGDriveEnv
+    env = PGDriveEnv({"environment_num": 2, "vehicle_config": {"lidar": {"gaussian_noise": 1.0, "dropout_prob": 1.0}}})
+    try:
+        o = env.reset()
+        assert env.observation_space.contains(o) and (o[-240:] == 0.0).all()
+        for x in (-1, 0, 1):
+            env.reset()
+            for y in (-1, 0, 1):
+                o, r, d, info = env.step([x, y])
+                assert env.observation_space.contains(o) and (o[-240:] == 0.0).all() and np.isscalar(r)
+                for k in ("cost", "velocity", "steering", "acceleration", "step_reward", "crash_vehicle", "out_of_road",
+                          "arrive_dest"):
+                    assert k in info
+    finally:
+        env.close()
+    env = PGDriveEnv({"environment_num": 2, "traffic_density": 0.0})
+    try:
+        assert (env.reset()[-240:] == 1.0).all()
+    finally:
+        env.close()
