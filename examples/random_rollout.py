@@ -1,0 +1,34 @@
+"""Minimal use of the batched env: N PGDrive-v0 environments stepped with random actions on one MI355X.
+
+    python examples/random_rollout.py --envs 4096 --steps 1000
+"""
+import argparse
+import time
+
+import torch
+
+from pgdrive_amd import PGDriveVecEnv
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=1000)
+    args = ap.parse_args()
+    env = PGDriveVecEnv(dict(num_envs=args.envs))  # PGDrive-v0: seeds 1000..1099, 1 ego + IDM traffic, 240 lidar beams
+    obs = env.reset()  # cuda float32 [N, 274]
+    episodes = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        actions = torch.rand((args.envs, 2), device=obs.device) * 2 - 1  # any policy producing [N, 2] in [-1, 1]
+        obs, reward, done, flags = env.step(actions)  # finished envs restart by themselves (PGD_F_RESET is set for them)
+        episodes += int(done.sum())
+    env.engine.sync()
+    dt = time.perf_counter() - t0
+    print("%d env-steps in %.3f s = %.1f M env-steps/s, %d episodes finished" % (
+        args.envs * args.steps, dt, args.envs * args.steps / dt / 1e6, episodes))
+    env.close()
+
+
+if __name__ == "__main__":
+    main()
