@@ -3,11 +3,14 @@
     python examples/random_rollout.py --envs 4096 --steps 1000
 """
 import argparse
+import os
+import sys
 import time
 
 import torch
 
-from pgdrive_amd import PGDriveVecEnv
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout without installing
+from pgdrive_amd import PGDriveVecEnv  # noqa: E402
 
 
 def main():
