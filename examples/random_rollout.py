@@ -20,16 +20,17 @@ def main():
     args = ap.parse_args()
     env = PGDriveVecEnv(dict(num_envs=args.envs))  # PGDrive-v0: seeds 1000..1099, 1 ego + IDM traffic, 240 lidar beams
     obs = env.reset()  # cuda float32 [N, 274]
-    episodes = 0
+    episodes = torch.zeros((), dtype=torch.int64, device=obs.device)  # counted on the device: no host sync inside the loop
+    env.engine.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         actions = torch.rand((args.envs, 2), device=obs.device) * 2 - 1  # any policy producing [N, 2] in [-1, 1]
         obs, reward, done, flags = env.step(actions)  # finished envs restart by themselves (PGD_F_RESET is set for them)
-        episodes += int(done.sum())
-    env.engine.sync()
+        episodes += done.sum()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("%d env-steps in %.3f s = %.1f M env-steps/s, %d episodes finished" % (
-        args.envs * args.steps, dt, args.envs * args.steps / dt / 1e6, episodes))
+        args.envs * args.steps, dt, args.envs * args.steps / dt / 1e6, int(episodes)))
     env.close()
 
 
