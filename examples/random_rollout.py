@@ -24,13 +24,13 @@ def main():
     args = ap.parse_args()
     env = PGDriveVecEnv(dict(num_envs=args.envs))  # PGDrive-v0: seeds 1000..1099, 1 ego + IDM traffic, 240 lidar beams
     obs = env.reset()  # cuda float32 [N, 274]
-    episodes = torch.zeros((), dtype=torch.int64, device=obs.device)  # counted on the device: no host sync inside the loop
+    episodes = torch.zeros(1, dtype=torch.int64, device=obs.device)  # counted on the device: no host sync inside the loop
     env.engine.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         actions = torch.rand((args.envs, 2), device=obs.device) * 2 - 1  # any policy producing [N, 2] in [-1, 1]
         obs, reward, done, flags = env.step(actions)  # finished envs restart by themselves (PGD_F_RESET is set for them)
-        episodes += done.sum()
+        episodes += done.sum(0, keepdim=True)  # (a 0-dim operand would be read back to the host as a scalar)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("%d env-steps in %.3f s = %.1f M env-steps/s, %d episodes finished" % (

@@ -109,6 +109,7 @@ class Engine:
         self.reward = torch.zeros((self.N, self.A), dtype=torch.float32, device=dev)
         self.done = torch.zeros((self.N, self.A), dtype=torch.uint8, device=dev)
         self.flags = torch.zeros((self.N, self.A), dtype=torch.int32, device=dev)
+        self._ev_in, self._ev_out = torch.cuda.Event(), torch.cuda.Event()
         torch.cuda.synchronize(dev)
 
     # -- reference surface ------------------------------------------------------------------------------------------
@@ -137,8 +138,9 @@ class Engine:
         obs, reward, done, flags = out if out is not None else (self.obs, self.reward, self.done, self.flags)
         cur = self.torch.cuda.current_stream(self.device)
         foreign = cur != self.stream
-        if foreign:
-            self.stream.wait_stream(cur)
+        if foreign:  # order the engine stream after the caller's stream (persistent events: no allocation per step)
+            self._ev_in.record(cur)
+            self.stream.wait_event(self._ev_in)
         _chk(
             self.L.pgd_step(
                 self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()) if want_obs else None,
@@ -146,7 +148,8 @@ class Engine:
             ), "pgd_step"
         )
         if foreign:
-            cur.wait_stream(self.stream)
+            self._ev_out.record(self.stream)
+            cur.wait_event(self._ev_out)
         return obs, reward, done, flags
 
     def observe(self):
