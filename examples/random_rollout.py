@@ -25,7 +25,10 @@ def main():
     env = PGDriveVecEnv(dict(num_envs=args.envs))  # PGDrive-v0: seeds 1000..1099, 1 ego + IDM traffic, 240 lidar beams
     obs = env.reset()  # cuda float32 [N, 274]
     episodes = torch.zeros(1, dtype=torch.int64, device=obs.device)  # counted on the device: no host sync inside the loop
-    env.engine.sync()
+    for _ in range(20):  # warm-up: the first calls of every torch op load their kernels
+        env.step(torch.rand((args.envs, 2), device=obs.device) * 2 - 1)
+        episodes += env.engine.done.view(-1).sum(0, keepdim=True) * 0
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         actions = torch.rand((args.envs, 2), device=obs.device) * 2 - 1  # any policy producing [N, 2] in [-1, 1]
