@@ -37,6 +37,8 @@ struct PgdDev {
   int n_scen;
   struct VehRec* rec;  // [N*V] one 128-byte record per vehicle slot (device layout; the ABI blobs are field-major)
   int32_t* ei;         // [N][PGD_NEI]
+  const struct VehRec* reset_img;  // [n_scen][V] every slot right after a reset of its scenario (k_reset_image)
+  const float2* beam;  // [num_lasers] (cos, sin) of the beam angle i * 2 pi / num_lasers in the vehicle frame
 };
 
 // Device-side vehicle record: the PGD_NF float fields followed by the PGD_NI int fields of include/pgd_state_layout.h.

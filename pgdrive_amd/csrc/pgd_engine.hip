@@ -224,9 +224,15 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   __syncthreads();
   PHASE_MARK(1);  // trigger + snapshot
-  // slots present in the world: one ballot when the wave carries one env (lane o reads slot o), else "all, test later"
-  const unsigned long long pmask = ONE_ENV ? __ballot(lane < V && S.present[lane] != 0) : ((V >= 64 ? 0ull : (1ull << V)) - 1ull);
   const bool acting = valid && r.status == ST_ACTIVE;
+  if (ONE_ENV) {
+    // every wave of a 4096-env launch is resident at once and the kernel ends with its slowest wave: the envs with the
+    // most driving IDM vehicles get the issue priority, the light ones fill the gaps
+    const int nact = __popcll(__ballot(acting && leader && s >= A));
+    if (nact >= 4) __builtin_amdgcn_s_setprio(3);
+    else if (nact >= 2) __builtin_amdgcn_s_setprio(2);
+    else if (nact > 0) __builtin_amdgcn_s_setprio(1);
+  }
   // (2) policies
   if (acting) {
     float st, tb;
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         tb = tb * (2.0f / (float)(d.cfg.discrete_throttle_dim - 1)) - 1.0f;
       }
     } else {
-      idm_act<OBJ>(d, mv, g, *sp, S, base, V, s, e, steps_total, pmask, r, st, tb);
+      idm_act<OBJ>(d, mv, g, *sp, S, base, V, s, e, steps_total, r, st, tb);
     }
     PHASE_MARK(2);  // policy (IDM)
     // (3) BaseVehicle.before_step (base_vehicle.py:238-253)
@@ -437,7 +443,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // (8) auto reset (base_env.py:269-301): the whole env restarts from its (possibly re-drawn) scenario
   int episodes = 0;
   // ONE_ENV: s_flag[0] is the env's reset flag, the same for every lane: a scalar branch keeps scen / mv in SGPRs
+#ifdef PGD_HACK_NORESET
+  const bool resetting = false;
+#else
   const bool resetting = ONE_ENV ? (__ballot(s_flag[0] != 0) != 0ull) : (valid && s_flag[el]);
+#endif
   if (resetting) {
     episodes = d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] + 1;
     if (d.cfg.resample_scenario)
@@ -449,14 +459,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   if (valid && resetting) {
     sp = d.spawns + (size_t)scen * d.sstride + s;
-    reset_vehicle(*sp, r, s, s < A);
-    if (r.status != ST_EMPTY) after_step_vehicle(mv, g, *sp, r, s < A, true, ctx);
-    // agent ids restart at 0: id = number of spawned agent slots below this one (agent_manager.py:91-132)
+    // the slot right after a reset is a function of the scenario alone (spawn pose, first localisation, side distances,
+    // agent id): read from the image k_reset_image built at upload instead of localising every vehicle again
+    load_rec(d.reset_img + (size_t)scen * V + s, r);
+    if (s < A && r.status != ST_EMPTY) ctx = route_ctx(mv, *sp, r.ck0, r.ck1);
     const unsigned long long am = __ballot(leader && s < A && r.status == ST_ACTIVE);
-    if (s < A && r.status == ST_ACTIVE) {
-      r.agent_id = A == 1 ? 0.0f : (float)__popcll(am & ((1ull << lm.lead) - 1ull));  // A > 1 implies one env per wave
-      if (marl) my_fl |= PGD_F_NEW;
-    }
+    if (marl && s < A && r.status == ST_ACTIVE) my_fl |= PGD_F_NEW;
     if (s == 0 && leader) {
       d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
       d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] = episodes;
@@ -521,25 +529,41 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_END();
 }
 
-// reset of selected envs (base_env.py:269-301); same lane mapping as k_step, unit = position in the id list
-__global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restrict__ env_ids,
-                                                 const int32_t* __restrict__ scen_ids, int n) {
-  const int V = d.V, A = d.A, N = d.N;
-  const LaneMap lm = lane_map(d, blockIdx.x, n);
-  if (!lm.valid) return;
+// slot `s` of scenario `scen` right after a reset (base_env.py:269-301): spawn state + first localisation; agent ids restart
+// at 0: id = number of spawned agent slots below this one (agent_manager.py:91-132).  Returns the ballot of spawned agents.
+DEV unsigned long long reset_slot(const PgdDev& d, const LaneMap& lm, int scen, Veh& r) {
+  const int A = d.A, s = lm.s;
   const Grp g{lm.sub, d.sub, lm.lead};
-  const int k = lm.e, s = lm.s;
-  const int e = env_ids ? env_ids[k] : k;
-  const int scen = scen_ids[k];
-  const pgd_scenario* sc = d.scen + scen;
   const pgd_spawn* sp = d.spawns + (size_t)scen * d.sstride + s;
-  MapView mv = map_view(d, sc->map);
-  Veh r;
+  MapView mv = map_view(d, d.scen[scen].map);
   reset_vehicle(*sp, r, s, s < A);
   RouteCtx ctx;
   if (r.status != ST_EMPTY) after_step_vehicle(mv, g, *sp, r, s < A, true, ctx);
   const unsigned long long am = __ballot(lm.sub == 0 && s < A && r.status == ST_ACTIVE);  // epw == 1 whenever A > 1
   if (s < A && r.status == ST_ACTIVE) r.agent_id = A == 1 ? 0.0f : (float)__popcll(am & ((1ull << lm.lead) - 1ull));
+  return am;
+}
+
+// the reset image: one record per (scenario, slot), read by the auto-reset of k_step; same lane mapping, unit = scenario
+__global__ __launch_bounds__(WAVE) void k_reset_image(PgdDev d, VehRec* __restrict__ img) {
+  const LaneMap lm = lane_map(d, blockIdx.x, d.n_scen);
+  if (!lm.valid) return;
+  Veh r;
+  reset_slot(d, lm, lm.e, r);
+  if (lm.sub == 0) store_rec(img + (size_t)lm.e * d.V + lm.s, r);
+}
+
+// reset of selected envs; same lane mapping as k_step, unit = position in the id list
+__global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restrict__ env_ids,
+                                                 const int32_t* __restrict__ scen_ids, int n) {
+  const int A = d.A;
+  const LaneMap lm = lane_map(d, blockIdx.x, n);
+  if (!lm.valid) return;
+  const int k = lm.e, s = lm.s;
+  const int e = env_ids ? env_ids[k] : k;
+  const int scen = scen_ids[k];
+  Veh r;
+  const unsigned long long am = reset_slot(d, lm, scen, r);
   if (lm.sub != 0) return;
   store_veh(d, e, s, r);
   if (s == 0) {
@@ -653,6 +677,9 @@ struct pgd_engine {
   pgd_box* cell_boxes;
   LaneExt* cell_ext;
   pgd_map* scen_map;  // per scenario: copy of its map header (saves one dependent load per block)
+  float2* beam;       // lidar beam directions in the vehicle frame
+  VehRec* reset_img;  // [n_scen][V], rebuilt after every map / scenario upload
+  bool img_dirty;
   std::vector<pgd_map>* h_maps;
   std::vector<pgd_scenario>* h_scen;
   pgd_scenario* scen; pgd_spawn* spawns;
@@ -688,6 +715,19 @@ static int build_scen_map(pgd_engine* h) {
   int rc = upload(&h->scen_map, sm.data(), sm.size(), h->stream);
   if (rc) return rc;
   h->d.scen_map = h->scen_map;
+  return PGD_OK;
+}
+
+// (re)build the reset image once both the maps and the scenarios are on the device
+static int build_reset_image(pgd_engine* h) {
+  if (!h->img_dirty || !h->have_maps || !h->have_scen) return PGD_OK;
+  if (h->reset_img) { HIPCHK(hipFree(h->reset_img)); h->reset_img = nullptr; }
+  HIPCHK(hipMalloc(&h->reset_img, sizeof(VehRec) * (size_t)h->d.n_scen * h->d.V));
+  h->d.reset_img = h->reset_img;
+  const int blocks = (h->d.n_scen + h->d.epw - 1) / h->d.epw;
+  hipLaunchKernelGGL(k_reset_image, dim3(blocks), dim3(WAVE), 0, h->stream, h->d, h->reset_img);
+  HIPCHK(hipGetLastError());
+  h->img_dirty = false;
   return PGD_OK;
 }
 
@@ -729,6 +769,18 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   HIPCHK(hipMalloc(&h->d_ids, sizeof(int32_t) * (size_t)h->d.N * 2));
   HIPCHK(hipMemsetAsync(h->d.rec, 0, sizeof(VehRec) * nv, h->stream));
   HIPCHK(hipMemsetAsync(h->d.ei, 0, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI, h->stream));
+  {
+    // beam i points at theta + i * 2 pi / n (distance_detector.py:65-94): its direction is the heading rotated by a
+    // constant angle, tabulated once in double precision instead of one sincosf per beam and step
+    std::vector<float2> bt((size_t)(cfg->num_lasers > 0 ? cfg->num_lasers : 1));
+    for (int i = 0; i < cfg->num_lasers; ++i) {
+      const double a = (double)i * (2.0 * 3.14159265358979323846 / (double)cfg->num_lasers);
+      bt[(size_t)i] = make_float2((float)cos(a), (float)sin(a));
+    }
+    int rc = upload(&h->beam, bt.data(), bt.size(), h->stream);
+    if (rc) return rc;
+    h->d.beam = h->beam;
+  }
   *out = h;
   return PGD_OK;
 }
@@ -809,6 +861,7 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
   h->h_maps->assign(maps, maps + n_maps);
   if ((rc = build_scen_map(h))) return rc;
   h->have_maps = true;
+  h->img_dirty = true;
   return PGD_OK;
 }
 
@@ -826,6 +879,7 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   h->h_scen->assign(scen, scen + n_scen);
   if ((rc = build_scen_map(h))) return rc;
   h->have_scen = true;
+  h->img_dirty = true;
   return PGD_OK;
 }
 
@@ -863,6 +917,7 @@ int pgd_reset(pgd_handle h, const int32_t* env_ids, const int32_t* scen_ids, int
 int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done, uint32_t* d_flags) {
   if (!h || !d_actions || !d_reward || !d_done || !d_flags) return PGD_ERR_ARG;
   if (!h->have_maps || !h->have_scen) return PGD_ERR_STATE;
+  if (h->img_dirty) { int rc = build_reset_image(h); if (rc) return rc; }
   const bool marl = (h->d.cfg.marl_flags & PGD_MA_ENABLED) != 0;
   const bool fuse = d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse;
   bool prof = h->prof_ev && h->prof_n < h->prof_cap;
@@ -1014,6 +1069,13 @@ int pgd_profile_end(pgd_handle h, float* k_step_ms, float* k_observe_ms, int* co
 }
 
 #ifdef PGD_PROF
+int pgd_debug_phase_raw(pgd_handle h, unsigned long long* out, int n_blocks) {  // [n_blocks][32], then cleared
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 32 * (size_t)n_blocks));
+  std::vector<unsigned long long> z((size_t)PROF_BLOCKS * 32, 0ull);
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z.data(), sizeof(unsigned long long) * z.size()));
+  return PGD_OK;
+}
 int pgd_debug_phase_cycles(pgd_handle h, unsigned long long* out64, int reset) {
   HIPCHK(hipStreamSynchronize(h->stream));
   std::vector<unsigned long long> all((size_t)PROF_BLOCKS * 32);
@@ -1042,7 +1104,7 @@ int pgd_destroy(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->d.rec, h->d.ei, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
-                  h->cell_items, h->cell_boxes, h->cell_ext, h->scen_map, h->scen, h->spawns};
+                  h->cell_items, h->cell_boxes, h->cell_ext, h->scen_map, h->scen, h->spawns, h->beam, h->reset_img};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   (void)hipEventDestroy(h->ev0);

@@ -85,7 +85,7 @@ DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int bas
 
 template <bool OBJ>
 DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spawn& sp, const Snap& S, int base, int V,
-                 int s, int e, uint32_t step_count, unsigned long long pmask, Veh& r, float& out_steer, float& out_acc) {
+                 int s, int e, uint32_t step_count, Veh& r, float& out_steer, float& out_acc) {
   const float NORMAL = 30.0f, CREEP = 5.0f, SAFE = 15.0f, MAXD = 30.0f;
   const int vlane = r.lane;
   int rt = r.rlane;
@@ -100,10 +100,19 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
     rt = vlane;
     success = vl_road == cur_road;
   } else if (rt_road != cur_road) {
-    success = false;
-    const pgd_lane& RT = mv.lanes[rt];
-    for (int k = 0; k < CR.n_lanes; ++k)
-      if (lane_is_prev_of(RT, CR.first_lane + k)) { rt = CR.first_lane + k; success = true; break; }
+    // the lowest lane of the current road that follows the routing lane (8 packed successor ids, unused = -1)
+    const int4 rs = *reinterpret_cast<const int4*>(mv.lanes[rt].succ);
+    const int first = CR.first_lane, nl = CR.n_lanes;
+    int best = 0x7fff;
+    const int w4[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int lo = (int)(short)(w4[q] & 0xffff) - first, hi = (w4[q] >> 16) - first;
+      if (lo >= 0 && lo < nl) best = min(best, lo);
+      if (hi >= 0 && hi < nl) best = min(best, hi);
+    }
+    success = best != 0x7fff;
+    if (success) rt = first + best;
   } else if (vl_road == cur_road && rt != vlane) {
     rt = vlane;
     r.timer = (int)(pgd_rng(d.cfg.seed, (uint32_t)e, (uint32_t)s, step_count) % 25u);
@@ -117,12 +126,18 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
   // Lidar.get_surrounding_objects (lidar.py:109-124)
   float px = S.x[base + s], py = S.y[base + s];
   unsigned long long objs = 0ull;
-  // pmask = slots whose vehicle is in the physics world (wave-uniform with one env per wave: a scalar loop)
-  for (unsigned long long m = pmask & ~(1ull << s); m != 0ull; m &= m - 1ull) {
-    const int o = __builtin_ctzll(m);
+  // the sub-lanes of the vehicle split the slots (o = sub, sub + SUB, ...) and merge their bit sets: ceil(V / SUB) distance
+  // tests per lane whatever the number of bodies in the world
+  for (int o = g.sub; o < V; o += g.SUB) {
     const Obb ob = snap_obb(S, base + o);
-    const bool in = S.present[base + o] && shape_point_dist<OBJ>(ob, px, py) <= 50.0f;
+    const bool in = o != s && S.present[base + o] && shape_point_dist<OBJ>(ob, px, py) <= 50.0f;
     objs |= in ? (1ull << o) : 0ull;
+  }
+  {
+    unsigned lo = (unsigned)objs, hi = (unsigned)(objs >> 32);
+    lo = group_or(lo, g);
+    hi = V > 32 ? group_or(hi, g) : 0u;
+    objs = ((unsigned long long)hi << 32) | lo;
   }
 
   PHASE_MARK(9);  // idm: routing + broad phase

@@ -97,20 +97,27 @@ DEV int get_current_lane(const MapView& mv, const Grp& g, float px, float py, fl
 }
 
 // Navigation._update_target_checkpoints (navigation.py:262-282)
-DEV void update_checkpoints(const MapView& mv, const pgd_spawn& sp, Veh& r, float lon) {
+DEV void update_checkpoints(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, float lon) {
   if (r.ck0 == r.ck1) return;
   if (!(lon < 5.0f)) return;
   int n = sp.n_ckpt;
   int start_node = mv.roads[mv.lanes[r.lane].road].from;
-  bool in_tail = false;
-  int idx = -1;
-  for (int k = r.ck1; k < n; ++k) {
-    if (sp.ckpt[k] == start_node) {
-      in_tail = true;
-      if (idx < 0 && k < n - 1) idx = k;
-    }
+  // checkpoints[ck1:].index(start_node) with index < len - 1 (navigation.py:270-277): the first match decides, and a match
+  // on the last node alone changes nothing.  The sub-lanes of the vehicle split the tail, four independent reads each per
+  // round (a whole route in one round trip), and take the lowest hit.
+  unsigned hit = 0xffffffffu;
+  const int step = g.SUB;
+  for (int k = r.ck1 + g.sub; k < n - 1; k += 4 * step) {
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = sp.ckpt[min(k + j * step, n - 2)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k + j * step < n - 1 && v[j] == start_node) hit = min(hit, (unsigned)(k + j * step));
   }
-  if (!in_tail || idx < 0) return;
+  hit = group_min(hit, g);
+  if (hit == 0xffffffffu) return;
+  const int idx = (int)hit;
   r.ck0 = idx;
   r.ck1 = (idx + 1 == n - 1) ? idx : idx + 1;
 }
@@ -128,7 +135,7 @@ DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& s
   r.lane = lane;
   float lon, lat;
   lane_local(mv.lanes[lane], r.x, r.y, lon, lat);
-  update_checkpoints(mv, sp, r, lon);
+  update_checkpoints(mv, g, sp, r, lon);
   r.vflags = on_lane ? (r.vflags & ~PGD_F_OFF_LANE) : (r.vflags | PGD_F_OFF_LANE);
   PHASE_MARK(18);  // after_step: lane_local + checkpoints
 }

@@ -167,12 +167,9 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   }
   PHASE_MARK(23);  // obs: neighbours
   // lidar (distance_detector.py:65-94, cutils.pyx:60-142): beam i at theta + i*2pi/N, nearest hit fraction
-  const float unit = 2.0f * PGD_PI / (float)NL;
   for (int i = tid; i < NL; i += nt) {
-    float ang = (float)i * unit + ag.th;
-    float sn, cs;
-    sincosf(ang, &sn, &cs);
-    float dx = R * cs, dy = R * sn;
+    const float2 bd = d.beam[i];  // (cos, sin)(i * 2 pi / NL); rotated by the heading
+    const float dx = R * (bd.x * hx - bd.y * hy), dy = R * (bd.y * hx + bd.x * hy);
     float best = 1.0f;
     for (int k = 0; k < n; ++k)
       best = fminf(best, shape_ray<OBJ>(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));

@@ -14,9 +14,9 @@ struct Veh {
   float hx, hy;  // unit heading (cos, sin of th): derived, kept in registers, never stored
 };
 
-DEV void load_veh(const PgdDev& d, int e, int s, Veh& r) {
+DEV void load_rec(const VehRec* rec, Veh& r) {
   VehRec t;
-  const uint4* src = reinterpret_cast<const uint4*>(d.rec + (size_t)e * d.V + s);
+  const uint4* src = reinterpret_cast<const uint4*>(rec);
   uint4* dst = reinterpret_cast<uint4*>(&t);
 #pragma unroll
   for (int k = 0; k < 8; ++k) dst[k] = src[k];
@@ -32,7 +32,8 @@ DEV void load_veh(const PgdDev& d, int e, int s, Veh& r) {
   r.agent_id = t.f[SF_AGENT_ID];
   sincosf(r.th, &r.hy, &r.hx);
 }
-DEV void store_veh(const PgdDev& d, int e, int s, const Veh& r) {
+DEV void load_veh(const PgdDev& d, int e, int s, Veh& r) { load_rec(d.rec + (size_t)e * d.V + s, r); }
+DEV void store_rec(VehRec* rec, const Veh& r) {
   VehRec t;
   t.f[SF_X] = r.x; t.f[SF_Y] = r.y; t.f[SF_THETA] = r.th; t.f[SF_SPEED] = r.v;
   t.f[SF_STEER] = r.steer; t.f[SF_THROTTLE] = r.thr;
@@ -43,11 +44,12 @@ DEV void store_veh(const PgdDev& d, int e, int s, const Veh& r) {
   t.f[SF_DIST_LEFT] = r.dl; t.f[SF_DIST_RIGHT] = r.dr; t.f[SF_EP_REWARD] = r.eprew; t.f[SF_AGENT_ID] = r.agent_id;
   t.i[SI_STATUS] = r.status; t.i[SI_LANE] = r.lane; t.i[SI_CK0] = r.ck0; t.i[SI_CK1] = r.ck1;
   t.i[SI_RLANE] = r.rlane; t.i[SI_TIMER] = r.timer; t.i[SI_VFLAGS] = r.vflags; t.i[SI_SPAWN] = r.spawn;
-  uint4* dst = reinterpret_cast<uint4*>(d.rec + (size_t)e * d.V + s);
+  uint4* dst = reinterpret_cast<uint4*>(rec);
   const uint4* src = reinterpret_cast<const uint4*>(&t);
 #pragma unroll
   for (int k = 0; k < 8; ++k) dst[k] = src[k];
 }
+DEV void store_veh(const PgdDev& d, int e, int s, const Veh& r) { store_rec(d.rec + (size_t)e * d.V + s, r); }
 
 // base_vehicle.py:394-401; the magnitude: a reversing vehicle has a negative speed field, and BaseVehicle.velocity is this
 // magnitude times the FORWARD vector even then (base_vehicle.py:419-425)
