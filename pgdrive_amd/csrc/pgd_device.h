@@ -37,6 +37,7 @@ struct PgdDev {
   int n_scen;
   struct VehRec* rec;  // [N*V] one 128-byte record per vehicle slot (device layout; the ABI blobs are field-major)
   int32_t* ei;         // [N][PGD_NEI]
+  unsigned long long* imask;  // [N] bit s: slot s of the env still equals its scenario's reset image (never stored since)
   const struct VehRec* reset_img;  // [n_scen][V] every slot right after a reset of its scenario (k_reset_image)
   const float2* beam;  // [num_lasers] (cos, sin) of the beam angle i * 2 pi / num_lasers in the vehicle frame
 };

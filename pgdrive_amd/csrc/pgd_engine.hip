@@ -134,9 +134,15 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   int scen = 0;
   // the vehicle record does not depend on the scenario: its 8 x 16 B reads go out first and overlap the scalar chain
   // env counters -> scenario -> map header -> table pointers below
-  if (valid) load_veh(d, e, s, r);
+  // a slot that was never written since the last reset (waiting trigger traffic: most slots of most envs) still equals the
+  // scenario's reset image: its lane reads the image -- shared by every env of the scenario, cache resident -- instead of the
+  // env's own record in HBM.  One env per wave only; the records in memory stay complete either way.
+  unsigned long long im = 0ull;
+  if (ONE_ENV) im = d.imask[e];
+  if (one_env || valid) scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
+  if (valid) load_rec((ONE_ENV && ((im >> s) & 1ull)) ? d.reset_img + (size_t)scen * V + s : d.rec + (size_t)e * V + s, r);
+  const int key0 = valid ? (r.status ^ (r.vflags << 3)) : 0;  // what a vehicle that does not drive can change: status, flags
   if (one_env || valid) {
-    scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
     sc = d.scen + scen;
     mv = map_view_of(d, d.scen_map + scen);
     ng = d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP];
@@ -443,11 +449,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // (8) auto reset (base_env.py:269-301): the whole env restarts from its (possibly re-drawn) scenario
   int episodes = 0;
   // ONE_ENV: s_flag[0] is the env's reset flag, the same for every lane: a scalar branch keeps scen / mv in SGPRs
-#ifdef PGD_HACK_NORESET
-  const bool resetting = false;
-#else
   const bool resetting = ONE_ENV ? (__ballot(s_flag[0] != 0) != 0ull) : (valid && s_flag[el]);
-#endif
   if (resetting) {
     episodes = d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] + 1;
     if (d.cfg.resample_scenario)
@@ -479,13 +481,24 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     flags[k] = my_fl;
   }
   PHASE_MARK(7);  // reset
+  bool stored = false;
   if (valid && leader) {
-    store_veh(d, e, s, r);
+    // a slot that neither drove, restarted, counted down (delay-done) nor changed status / flags still holds its record:
+    // the waiting traffic of the trigger mode (most slots of most envs) costs no write
+    stored = acting || resetting || (r.status ^ (r.vflags << 3)) != key0 || (key0 & 7) == ST_DYING;
+    if (stored) store_veh(d, e, s, r);
     if (s == 0) {
       d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP] = ng;
       d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS] = ep_steps;
       d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL] = (int)steps_total;
     }
+  }
+  if (ONE_ENV) {  // written slots leave the image; a restart puts every slot back on it
+    const unsigned long long sb = __ballot(stored);
+    const unsigned long long cleared = __ballot(lane < V && ((sb >> (lane * d.sub)) & 1ull) != 0ull);
+    const unsigned long long full = V >= 64 ? ~0ull : ((1ull << V) - 1ull);
+    const unsigned long long nm = resetting ? full : (im & ~cleared);
+    if (lane == 0 && nm != im) d.imask[e] = nm;
   }
   PHASE_MARK(8);  // store
   // (9) observation of the new state, fused: the wave already holds every vehicle of the env (obs/state_obs.py:132-170)
@@ -567,6 +580,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restr
   if (lm.sub != 0) return;
   store_veh(d, e, s, r);
   if (s == 0) {
+    d.imask[e] = d.epw == 1 ? (d.V >= 64 ? ~0ull : ((1ull << d.V) - 1ull)) : 0ull;  // every record equals the image now
     d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_AGENT] = A == 1 ? 1 : __popcll(am);
     d.ei[(size_t)(e) * PGD_NEI + EI_AUX] = d.scen[scen].aux;  // parking: free spaces of the new episode
     d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
@@ -769,6 +783,8 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   HIPCHK(hipMalloc(&h->d_ids, sizeof(int32_t) * (size_t)h->d.N * 2));
   HIPCHK(hipMemsetAsync(h->d.rec, 0, sizeof(VehRec) * nv, h->stream));
   HIPCHK(hipMemsetAsync(h->d.ei, 0, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI, h->stream));
+  HIPCHK(hipMalloc(&h->d.imask, sizeof(unsigned long long) * (size_t)h->d.N));
+  HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
   {
     // beam i points at theta + i * 2 pi / n (distance_detector.py:65-94): its direction is the heading rotated by a
     // constant angle, tabulated once in double precision instead of one sincosf per beam and step
@@ -861,7 +877,8 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
   h->h_maps->assign(maps, maps + n_maps);
   if ((rc = build_scen_map(h))) return rc;
   h->have_maps = true;
-  h->img_dirty = true;
+  h->img_dirty = true;  // running envs fall back to their own records until their next reset
+  HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
   return PGD_OK;
 }
 
@@ -880,6 +897,7 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   if ((rc = build_scen_map(h))) return rc;
   h->have_scen = true;
   h->img_dirty = true;
+  HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
   return PGD_OK;
 }
 
@@ -1012,6 +1030,7 @@ extern "C" int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, con
     for (int q = 0; q < PGD_NEI; ++q) te[(size_t)e * PGD_NEI + q] = ei[(size_t)q * N + e];
   HIPCHK(hipMemcpyAsync(h->d.rec, tr.data(), sizeof(VehRec) * nv, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d.ei, te.data(), sizeof(int32_t) * te.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)N, h->stream));  // arbitrary records: none is the image
   HIPCHK(hipStreamSynchronize(h->stream));
   return PGD_OK;
 }
@@ -1103,7 +1122,7 @@ int pgd_sync(pgd_handle h) {
 int pgd_destroy(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   (void)hipStreamSynchronize(h->stream);
-  void* bufs[] = {h->d.rec, h->d.ei, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
+  void* bufs[] = {h->d.rec, h->d.ei, h->d.imask, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
                   h->cell_items, h->cell_boxes, h->cell_ext, h->scen_map, h->scen, h->spawns, h->beam, h->reset_img};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
