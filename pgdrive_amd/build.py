@@ -28,7 +28,10 @@ def needs_build():
 def build(force=False, verbose=False, extra=()):
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC] + list(extra)
+    # fp32 `/` and sqrtf compile to the 2.5-ulp rcp / rsq sequences instead of the correctly rounded IEEE expansions (about
+    # ten VALU instructions each): the kernel is issue-bound and the parity tolerances are 1e-5 and looser
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+           "-shared", "-fPIC", "-o", LIB, SRC] + list(extra)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -28,6 +28,9 @@
   } while (0)
 
 #define WAVE 64
+#ifndef PGD_HACK_SKIP
+#define PGD_HACK_SKIP 0
+#endif
 #define MAXV 64
 
 // Optional per-phase cycle counters of k_step (build with -DPGD_PROF; never enabled in the shipped library)
@@ -107,7 +110,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   __shared__ AgentView s_ag[FUSE_MAX_AGENTS];
   __shared__ int s_flag[WAVE];
   __shared__ int s_hit[WAVE];  // per snapshot slot: an agent's chassis overlaps another vehicle
+#ifdef PGD_WARM
   __shared__ int s_pf[WAVE];   // landing zone of the warm-up loads
+#endif
   __shared__ int s_aux;        // multi-agent parking lot: pool of free parking spaces (bit mask)
   __shared__ int s_kind[WAVE]; // PGD_OBJ_* of every slot (fused observation: objects are lidar targets, not neighbours)
   const int V = d.V, A = d.A, N = d.N;
@@ -502,6 +507,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   PHASE_MARK(8);  // store
   // (9) observation of the new state, fused: the wave already holds every vehicle of the env (obs/state_obs.py:132-170)
+#if PGD_HACK_SKIP == 4
+  if (false)
+#endif
   if (ONE_ENV && obs != nullptr) {  // host passes obs only when one_env && A <= FUSE_MAX_AGENTS
     __syncthreads();
     if (valid && leader) {
@@ -530,7 +538,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       const AgentView ag = s_ag[a];
       const bool have = lane < V && d.cfg.num_lasers > 0;
       obs_compact<OBJ>(OL, lane, a, have && S.present[lane], OBJ ? (have && s_kind[lane] == PGD_OBJ_VEHICLE) : true, S.x[lane], S.y[lane],
-                  S.ux[lane], S.uy[lane], S.hl[lane], S.hw[lane], S.spd[lane], ag.x, ag.y, d.cfg.lidar_dist);
+                  S.ux[lane], S.uy[lane], S.hl[lane], S.hw[lane], S.spd[lane], ag.x, ag.y, d.cfg.lidar_dist, ag.hx, ag.hy,
+                  d.cfg.num_lasers);
       __syncthreads();
       PHASE_MARK(21);  // obs: compaction
       observe_agent<OBJ, STD>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + ((size_t)blockIdx.x * A + a) * d.D, lane,
@@ -665,7 +674,8 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
       is_vehicle = so.kind == PGD_OBJ_VEHICLE;
       spd = still ? 0.0f : speed_kmh(recs[tid].f[SF_SPEED]);
     }
-    obs_compact<true>(L, tid, a, present, is_vehicle, x, y, ux, uy, hl, hw, spd, ag.x, ag.y, d.cfg.lidar_dist);
+    obs_compact<true>(L, tid, a, present, is_vehicle, x, y, ux, uy, hl, hw, spd, ag.x, ag.y, d.cfg.lidar_dist, ag.hx, ag.hy,
+                      d.cfg.num_lasers);
   }
   __syncthreads();
   MapView mv = map_view_of(d, d.scen_map + scen);

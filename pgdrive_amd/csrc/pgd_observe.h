@@ -42,6 +42,7 @@ DEV float heading_diff(const pgd_lane& l, float px, float py, float fx, float fy
 struct ObsLds {  // bodies inside the lidar broad phase of the observing agent, compacted
   float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV];
   float bdist[MAXV];  // centre distance; +inf for traffic objects, which are never ranked as neighbour vehicles
+  int bi0[MAXV], bcnt[MAXV];  // lidar beams [bi0, bi0 + bcnt) mod num_lasers that can reach the body (conservative)
   int n, nveh;
 };
 struct AgentView {  // what the observation needs from the observing vehicle
@@ -56,14 +57,33 @@ struct AgentView {  // what the observation needs from the observing vehicle
 // one wave compacts the candidates: lane `o` brings vehicle o of the env (present = in the physics world)
 template <bool OBJ>
 DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, float x, float y, float ux, float uy, float hl,
-                     float hw, float spd, float px, float py, float R) {
+                     float hw, float spd, float px, float py, float R, float hx, float hy, int NL) {
   if (!OBJ) is_vehicle = true;
   bool in = present && o != a && shape_point_dist<OBJ>(Obb{x, y, ux, uy, hl, hw}, px, py) <= R;
   unsigned long long m = __ballot(in), mv_ = OBJ ? __ballot(in && is_vehicle) : m;
   if (in) {
     int k = __popcll(m & ((1ull << o) - 1ull));
     L.bx[k] = x; L.by[k] = y; L.bux[k] = ux; L.buy[k] = uy; L.bhl[k] = hl; L.bhw[k] = hw; L.bspd[k] = spd;
-    L.bdist[k] = is_vehicle ? norm2(px - x, py - y) : __builtin_inff();
+    const float dist = norm2(px - x, py - y);
+    L.bdist[k] = is_vehicle ? dist : __builtin_inff();
+    // the body lies inside the circle of radius rad around its centre: only beams within asin(rad / dist) of the centre
+    // direction can reach it.  asin(q) <= q + (pi/2 - 1) q^3 on [0, 1]; 1.5 beams of slack cover the fp32 rounding of the
+    // angle, so the culling never removes a hit and the cloud stays bit-identical to the all-pairs test.
+    const float rad = (hw < 0.0f ? hl : norm2(hl, hw)) * 1.02f + 0.01f;
+    int i0 = 0, cnt = NL;
+    if (dist > rad && NL > 0) {
+      const float rx = (x - px) * hx + (y - py) * hy, ry = (y - py) * hx - (x - px) * hy;  // centre in the vehicle frame
+      const float inv_unit = (float)NL * (0.5f / PGD_PI);
+      const float q = rad / dist;
+      const float ic = atan2f(ry, rx) * inv_unit, hb = (q + 0.5708f * q * q * q) * inv_unit + 1.5f;
+      const int lo = (int)floorf(ic - hb), hi = (int)ceilf(ic + hb);
+      if (hi - lo + 1 < NL) {
+        cnt = hi - lo + 1;
+        i0 = lo % NL;
+        if (i0 < 0) i0 += NL;
+      }
+    }
+    L.bi0[k] = i0; L.bcnt[k] = cnt;
   }
   if (o == 0) { L.n = __popcll(m); L.nveh = __popcll(mv_); }
 }
@@ -93,6 +113,9 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
     t2[0] = in_toll ? 1.0f : 0.0f;
     t2[1] = (in_toll && ag.toll_time > (float)d.cfg.min_pass_steps) ? 1.0f : 0.0f;
   }
+#if PGD_HACK_SKIP == 2
+  if (false)
+#endif
   if (tid < 18) {
     // every lane fetches the one lane record its float needs BEFORE the branch ladder, so the reads overlap instead of
     // queueing behind each other branch by branch: heading_diff -> last lane of the current road; navi -> first lanes
@@ -143,6 +166,9 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   const int NO = d.cfg.num_others;
   const int n = L.n, nveh = OBJ ? L.nveh : n;
   // with objects: indices [0, n) are the compacted bodies, [n, n + NO) the rank rows to zero-fill; without: [0, max(n, NO))
+#if PGD_HACK_SKIP == 3
+  if (false)
+#endif
   for (int k = nt - 1 - tid; k < (OBJ ? n + NO : (n > NO ? n : NO)); k += nt) {
     if (k < n) {
       int rank = 0;
@@ -167,12 +193,19 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   }
   PHASE_MARK(23);  // obs: neighbours
   // lidar (distance_detector.py:65-94, cutils.pyx:60-142): beam i at theta + i*2pi/N, nearest hit fraction
+#if PGD_HACK_SKIP == 1
+  if (false)
+#endif
   for (int i = tid; i < NL; i += nt) {
     const float2 bd = d.beam[i];  // (cos, sin)(i * 2 pi / NL); rotated by the heading
     const float dx = R * (bd.x * hx - bd.y * hy), dy = R * (bd.y * hx + bd.x * hy);
     float best = 1.0f;
-    for (int k = 0; k < n; ++k)
-      best = fminf(best, shape_ray<OBJ>(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
+    for (int k = 0; k < n; ++k) {
+      int off = i - L.bi0[k];
+      off += off < 0 ? NL : 0;
+      if (off < L.bcnt[k])
+        best = fminf(best, shape_ray<OBJ>(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
+    }
     if (!STD && (d.cfg.lidar_gaussian_noise > 0.0f || d.cfg.lidar_dropout_prob > 0.0f)) {  // state_obs.py:172-182
       const uint32_t key = 0x51d0a000u + (uint32_t)ag.slot * 1024u + (uint32_t)i;
       if (d.cfg.lidar_gaussian_noise > 0.0f) {
