@@ -18,6 +18,9 @@ def hipcc():
     raise RuntimeError("hipcc not found: the HIP engine cannot be built")
 
 
+FAST_FP = ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero", "-freciprocal-math"]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -28,10 +31,10 @@ def needs_build():
 def build(force=False, verbose=False, extra=()):
     if not force and not needs_build():
         return LIB
-    # fp32 `/` and sqrtf compile to the 2.5-ulp rcp / rsq sequences instead of the correctly rounded IEEE expansions (about
-    # ten VALU instructions each): the kernel is issue-bound and the parity tolerances are 1e-5 and looser
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-           "-shared", "-fPIC", "-o", LIB, SRC] + list(extra)
+    # the kernel is issue-bound and the parity tolerances are 1e-5 and looser: fp32 `/` compiles to rcp * x and sqrtf to
+    # the rsq sequence (2.5 ulp) instead of the correctly rounded, denormal-safe expansions (about ten VALU instructions
+    # each); sin / cos / atan2 / exp keep their full-precision library versions
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", *FAST_FP, "-shared", "-fPIC", "-o", LIB, SRC] + list(extra)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -21,7 +21,6 @@ struct PgdDev {
   int N, A, T, V, D, NV;
   int epw;        // whole environments per wave in k_step
   int sub;        // sub-lanes cooperating on one vehicle
-  int lds_bytes;  // dynamic LDS of k_step for the staged lane/road tables (0 = tables read from global memory)
   int sstride;    // pgd_spawn records per scenario: V slots + respawn_places * respawn_dests (multi-agent)
   const pgd_map* maps;
   const pgd_lane* lanes;
@@ -31,6 +30,7 @@ struct PgdDev {
   const int32_t* cell_items;
   const pgd_box* cell_boxes;  // cell-major copies of the boxes, lane boxes first inside each cell (pgd_upload_maps)
   const struct LaneExt* cell_ext;  // same indexing: what localisation needs from the lane of a lane box
+  const struct LaneNav* lane_nav;  // per lane: what the navigation block of the observation needs
   const pgd_scenario* scen;
   const pgd_map* scen_map;    // [n_scen] copy of each scenario's map header
   const pgd_spawn* spawns;
@@ -58,6 +58,18 @@ struct __attribute__((aligned(16))) LaneExt {
   int32_t road;  // map-local road id of the lane
 };
 
+// Per lane, device-private, built on upload: what the navigation block of the observation needs from a reference lane
+// (Navigation._get_info_for_checkpoint, navigation.py:213-260).  The check point lane.position(length, lateral) is
+// end + lateral * normal for both lane types, so the kernel evaluates no sincos and reads 32 instead of 64 bytes.
+struct __attribute__((aligned(16))) LaneNav {
+  float ex, ey;   // lane.position(length, 0)
+  float nx, ny;   // d position / d lateral at the lane end
+  float radius;   // CircularLane.radius (0 on straight lanes)
+  float dir;      // 0 = straight, +-1 = CircularLane.direction
+  float angle;    // end_phase - start_phase (dir = 1) or start_phase - end_phase (dir = -1), radians
+  float pad;
+};
+
 struct MapView {
   const pgd_map* m;
   const pgd_lane* lanes;
@@ -66,6 +78,7 @@ struct MapView {
   const int32_t* cstart;
   const LaneExt* cext;
   const pgd_box* cbox;
+  const LaneNav* lnav;
 };
 
 DEV MapView map_view_of(const PgdDev& d, const pgd_map* m) {
@@ -77,19 +90,10 @@ DEV MapView map_view_of(const PgdDev& d, const pgd_map* m) {
   v.cstart = d.cell_start + m->cell_off;
   v.cext = d.cell_ext + m->item_off;
   v.cbox = d.cell_boxes + m->item_off;
+  v.lnav = d.lane_nav + m->lane_off;
   return v;
 }
-DEV MapView map_view(const PgdDev& d, int map) {
-  MapView v;
-  v.m = d.maps + map;
-  v.lanes = d.lanes + v.m->lane_off;
-  v.roads = d.roads + v.m->road_off;
-  v.boxes = d.boxes + v.m->box_off;
-  v.cstart = d.cell_start + v.m->cell_off;
-  v.cext = d.cell_ext + v.m->item_off;
-  v.cbox = d.cell_boxes + v.m->item_off;
-  return v;
-}
+DEV MapView map_view(const PgdDev& d, int map) { return map_view_of(d, d.maps + map); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // scalar helpers: utils/math_utils.py:32-94, cutils.pyx:147-154

@@ -28,9 +28,6 @@
   } while (0)
 
 #define WAVE 64
-#ifndef PGD_HACK_SKIP
-#define PGD_HACK_SKIP 0
-#endif
 #define MAXV 64
 
 // Optional per-phase cycle counters of k_step (build with -DPGD_PROF; never enabled in the shipped library)
@@ -64,12 +61,6 @@ __shared__ long long s_prof_t0, s_prof_w0;
 // k_step: one env.step() for every environment (base_env.py:184-224)
 // lane -> (group g = lane / SUB, sub-lane); group g -> (env-local el = g / V, slot s = g % V)
 // ---------------------------------------------------------------------------------------------------------------------
-// cache warm-up load: one dword of the line at `p` goes straight to LDS (no VGPR destination, nothing waits for it)
-DEV void touch_line(const void* p, int* lds) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                   (__attribute__((address_space(3))) void*)lds, 4, 0, 0);
-}
-
 struct LaneMap {
   int sub, lead, el, s, e, idx, base;
   bool valid;
@@ -89,7 +80,6 @@ DEV LaneMap lane_map(const PgdDev& d, int unit, int n_units) {
   return m;
 }
 
-extern __shared__ __align__(16) unsigned char s_dyn[];  // [lanes | roads] of the block's map when epw == 1
 
 #define FUSE_MAX_AGENTS 8
 #ifndef PGD_WAVES_PER_SIMD
@@ -110,9 +100,6 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   __shared__ AgentView s_ag[FUSE_MAX_AGENTS];
   __shared__ int s_flag[WAVE];
   __shared__ int s_hit[WAVE];  // per snapshot slot: an agent's chassis overlaps another vehicle
-#ifdef PGD_WARM
-  __shared__ int s_pf[WAVE];   // landing zone of the warm-up loads
-#endif
   __shared__ int s_aux;        // multi-agent parking lot: pool of free parking spaces (bit mask)
   __shared__ int s_kind[WAVE]; // PGD_OBJ_* of every slot (fused observation: objects are lidar targets, not neighbours)
   const int V = d.V, A = d.A, N = d.N;
@@ -154,48 +141,6 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     ep_steps = d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS];
     steps_total = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
   }
-  if (one_env && d.lds_bytes > 0) {
-    // stage the env's lane + road tables in LDS (coalesced 16 B loads by all 64 lanes)
-    const pgd_map* bm = mv.m;
-    const int nl16 = bm->n_lanes * 4, nr16 = bm->n_roads;  // 16-byte units
-    if ((nl16 + nr16) * 16 <= d.lds_bytes) {
-      const uint4* gl = reinterpret_cast<const uint4*>(mv.lanes);
-      const uint4* gr = reinterpret_cast<const uint4*>(mv.roads);
-      uint4* sl = reinterpret_cast<uint4*>(s_dyn);
-      const int n16 = nl16 + nr16;  // roads follow the lanes in LDS; both source ranges are 16 B aligned
-      for (int k = lane; k < n16; k += 4 * WAVE) {
-        uint4 v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int kk = k + j * WAVE;
-          if (kk < n16) v[j] = kk < nl16 ? gl[kk] : gr[kk - nl16];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int kk = k + j * WAVE;
-          if (kk < n16) sl[kk] = v[j];
-        }
-      }
-      mv.lanes = reinterpret_cast<const pgd_lane*>(s_dyn);
-      mv.roads = reinterpret_cast<const pgd_road*>(s_dyn + (size_t)bm->n_lanes * sizeof(pgd_lane));
-    }
-  }
-#ifdef PGD_WARM
-  if (ONE_ENV) {
-    // L2 warm-up: the L2 starts cold at every launch; touch the env's tables now (global -> LDS loads without a VGPR
-    // destination) so that the dependent lookups of the later phases hit in L2
-    const pgd_map* bm = mv.m;
-    const char* lp = reinterpret_cast<const char*>(mv.lanes);
-    const int nl = (bm->n_lanes * 64 + 127) / 128;
-    for (int k = lane; k < nl; k += WAVE) touch_line(lp + (size_t)k * 128, s_pf);
-    const char* rp = reinterpret_cast<const char*>(mv.roads);
-    const int nr = (bm->n_roads * 16 + 127) / 128;
-    if (lane < nr) touch_line(rp + (size_t)lane * 128, s_pf);
-    const char* spp = reinterpret_cast<const char*>(d.spawns + (size_t)scen * d.sstride);
-    const int ns = (V * (int)sizeof(pgd_spawn) + 127) / 128;
-    if (lane < ns) touch_line(spp + (size_t)lane * 128, s_pf);
-  }
-#endif
   PHASE_MARK(13);  // load: scenario + table staging
   if (valid) {
     sp = d.spawns + (size_t)scen * d.sstride + r.spawn;
@@ -507,9 +452,6 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   PHASE_MARK(8);  // store
   // (9) observation of the new state, fused: the wave already holds every vehicle of the env (obs/state_obs.py:132-170)
-#if PGD_HACK_SKIP == 4
-  if (false)
-#endif
   if (ONE_ENV && obs != nullptr) {  // host passes obs only when one_env && A <= FUSE_MAX_AGENTS
     __syncthreads();
     if (valid && leader) {
@@ -700,6 +642,7 @@ struct pgd_engine {
   pgd_map* maps; pgd_lane* lanes; pgd_road* roads; pgd_box* boxes; int32_t* cell_start; int32_t* cell_items;
   pgd_box* cell_boxes;
   LaneExt* cell_ext;
+  LaneNav* lane_nav;
   pgd_map* scen_map;  // per scenario: copy of its map header (saves one dependent load per block)
   float2* beam;       // lidar beam directions in the vehicle frame
   VehRec* reset_img;  // [n_scen][V], rebuilt after every map / scenario upload
@@ -831,6 +774,21 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
         L.pad = R.n_lanes;
       }
     if ((rc = upload(&h->lanes, dl.data(), n_lanes, h->stream))) return rc;
+    std::vector<LaneNav> nav((size_t)(n_lanes > 0 ? n_lanes : 1));
+    for (int k = 0; k < n_lanes; ++k) {
+      const pgd_lane& L = lanes[k];
+      LaneNav& v = nav[(size_t)k];
+      if (L.dir == 0.0f) {  // straight_lane.py:53-67: start + lon * direction + lat * direction_lateral
+        v = LaneNav{(float)((double)L.ax + (double)L.length * L.bx), (float)((double)L.ay + (double)L.length * L.by),
+                    -L.by, L.bx, 0.0f, 0.0f, 0.0f, 0.0f};
+      } else {  // circular_lane.py:41-49: centre + (radius - lat * direction) * (cos phi, sin phi)
+        const double phi = (double)L.dir * L.length / L.bx + L.by, c = cos(phi), s = sin(phi);
+        v = LaneNav{(float)(L.ax + (double)L.bx * c), (float)(L.ay + (double)L.bx * s), (float)(-L.dir * c), (float)(-L.dir * s),
+                    L.bx, L.dir, L.dir == 1.0f ? L.c - L.by : L.by - L.c, 0.0f};
+      }
+    }
+    if ((rc = upload(&h->lane_nav, nav.data(), (size_t)n_lanes, h->stream))) return rc;
+    h->d.lane_nav = h->lane_nav;
   }
   if ((rc = upload(&h->roads, roads, n_roads, h->stream))) return rc;
   if ((rc = upload(&h->boxes, boxes, n_boxes, h->stream))) return rc;
@@ -843,7 +801,6 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
     std::vector<pgd_box> cb((size_t)(n_ci > 0 ? n_ci : 1));
     std::vector<LaneExt> cx((size_t)(n_ci > 0 ? n_ci : 1), LaneExt{0.f, 0.f, 0.f, -1});
     std::vector<int32_t> cs2(cs, cs + n_cs);
-    int max_lanes = 0, max_roads = 0;
     for (int m = 0; m < n_maps; ++m) {
       const pgd_map& M = maps[m];
       const int n_cells = M.gx * M.gy;
@@ -869,17 +826,10 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
             }
           }
       }
-      if (M.n_lanes > max_lanes) max_lanes = M.n_lanes;
-      if (M.n_roads > max_roads) max_roads = M.n_roads;
     }
     if ((rc = upload(&h->cell_boxes, cb.data(), (size_t)n_ci, h->stream))) return rc;
     if ((rc = upload(&h->cell_ext, cx.data(), (size_t)n_ci, h->stream))) return rc;
     if ((rc = upload(&h->cell_start, cs2.data(), n_cs, h->stream))) return rc;
-    size_t need = (size_t)max_lanes * sizeof(pgd_lane) + (size_t)max_roads * sizeof(pgd_road);
-    h->d.lds_bytes = (h->d.epw == 1 && need <= 40 * 1024) ? (int)need : 0;  // else: tables stay in global memory
-    // Measured (profiles/r01_notes.md): staging costs a 36 MB L2 burst per step and loses to plain global reads once the
-    // IDM search stopped touching the lane table (58 vs 49 M env-steps/s); kept as an opt-in for larger-V experiments.
-    if (!getenv("PGD_LDS_TABLES")) h->d.lds_bytes = 0;
   }
   h->d.maps = h->maps; h->d.lanes = h->lanes; h->d.roads = h->roads; h->d.boxes = h->boxes;
   h->d.cell_start = h->cell_start; h->d.cell_items = h->cell_items; h->d.cell_boxes = h->cell_boxes; h->d.cell_ext = h->cell_ext;
@@ -972,7 +922,7 @@ int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward
     kern = h->has_objects ? k_step<true, false, true> : (std_obs ? k_step<true, false, false, true> : k_step<true, false, false>);
   }
   else if (h->has_objects) kern = k_step<false, false, true>;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), (size_t)h->d.lds_bytes, h->stream, h->d, d_actions, d_reward, d_done,
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), 0, h->stream, h->d, d_actions, d_reward, d_done,
                      d_flags, fuse ? d_obs : (float*)nullptr);
   HIPCHK(hipGetLastError());
   if (prof || g_close) HIPCHK(hipEventRecord(pe[1], h->stream));
@@ -1133,7 +1083,7 @@ int pgd_destroy(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->d.rec, h->d.ei, h->d.imask, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
-                  h->cell_items, h->cell_boxes, h->cell_ext, h->scen_map, h->scen, h->spawns, h->beam, h->reset_img};
+                  h->cell_items, h->cell_boxes, h->cell_ext, h->lane_nav, h->scen_map, h->scen, h->spawns, h->beam, h->reset_img};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   (void)hipEventDestroy(h->ev0);

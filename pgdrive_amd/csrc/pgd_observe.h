@@ -6,21 +6,19 @@
 // ---------------------------------------------------------------------------------------------------------------------
 // observation: LidarStateObservation.observe (obs/state_obs.py:132-170) for one (env, agent)
 // ---------------------------------------------------------------------------------------------------------------------
-DEV void navi_info_for(const pgd_lane& ref, float w, int n_cur, float px, float py, float hx, float hy, float* out) {
+DEV void navi_info_for(const LaneNav& ref, float w, int n_cur, float px, float py, float hx, float hy, float* out) {
   // Navigation._get_info_for_checkpoint (navigation.py:213-260); ref = ref_lanes[0] of the checkpoint's road
   float later_middle = ((float)n_cur * 0.5f - 0.5f) * w;
-  float cx, cy;
-  lane_position(ref, ref.length, later_middle, cx, cy);
-  float dx = cx - px, dy = cy - py;
+  float dx = ref.ex + later_middle * ref.nx - px, dy = ref.ey + later_middle * ref.ny - py;
   float dn = norm2(dx, dy);
   if (dn > 50.0f) { dx = dx / dn * 50.0f; dy = dy / dn * 50.0f; }
   float ph, ps;
   projection(hx, hy, dx, dy, ph, ps);
   float bend = 0.0f, dir = 0.0f, angle = 0.0f;
   if (ref.dir != 0.0f) {
-    bend = ref.bx / (60.0f + n_cur * w);
+    bend = ref.radius / (60.0f + n_cur * w);
     dir = ref.dir;
-    angle = dir == 1.0f ? ref.c - ref.by : ref.by - ref.c;
+    angle = ref.angle;
   }
   out[0] = clipf((ph / 50.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
   out[1] = clipf((ps / 50.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
@@ -113,14 +111,14 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
     t2[0] = in_toll ? 1.0f : 0.0f;
     t2[1] = (in_toll && ag.toll_time > (float)d.cfg.min_pass_steps) ? 1.0f : 0.0f;
   }
-#if PGD_HACK_SKIP == 2
-  if (false)
-#endif
   if (tid < 18) {
     // every lane fetches the one lane record its float needs BEFORE the branch ladder, so the reads overlap instead of
     // queueing behind each other branch by branch: heading_diff -> last lane of the current road; navi -> first lanes
     const int lid = tid < 8 ? ag.cur_first + ag.cur_n - 1 : (tid < 13 ? ag.cur_first : ag.next_first);
-    const pgd_lane ml = mv.lanes[lid];
+    pgd_lane ml;  // only the heading_diff lane needs the 64-byte lane record
+    LaneNav nv;
+    if (tid == 2) ml = mv.lanes[lid];
+    if (tid >= 8) nv = mv.lnav[lid];
     const float max_speed = sp.max_speed;
     float v = 0.0f;
     int col = -1;
@@ -141,7 +139,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
     } else {  // lanes 8..12 -> checkpoint 1, 13..17 -> checkpoint 2
       int which = (tid - 8) / 5, comp = (tid - 8) - which * 5;
       float out[5];
-      navi_info_for(ml, mv.m->lane_width, ag.cur_n, px, py, hx, hy, out);
+      navi_info_for(nv, mv.m->lane_width, ag.cur_n, px, py, hx, hy, out);
       v = comp == 0 ? out[0] : comp == 1 ? out[1] : comp == 2 ? out[2] : comp == 3 ? out[3] : out[4];
       col = toll ? -1 : o_navi + (tid - 8);
     }
@@ -166,9 +164,6 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   const int NO = d.cfg.num_others;
   const int n = L.n, nveh = OBJ ? L.nveh : n;
   // with objects: indices [0, n) are the compacted bodies, [n, n + NO) the rank rows to zero-fill; without: [0, max(n, NO))
-#if PGD_HACK_SKIP == 3
-  if (false)
-#endif
   for (int k = nt - 1 - tid; k < (OBJ ? n + NO : (n > NO ? n : NO)); k += nt) {
     if (k < n) {
       int rank = 0;
@@ -193,9 +188,6 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   }
   PHASE_MARK(23);  // obs: neighbours
   // lidar (distance_detector.py:65-94, cutils.pyx:60-142): beam i at theta + i*2pi/N, nearest hit fraction
-#if PGD_HACK_SKIP == 1
-  if (false)
-#endif
   for (int i = tid; i < NL; i += nt) {
     const float2 bd = d.beam[i];  // (cos, sin)(i * 2 pi / NL); rotated by the heading
     const float dx = R * (bd.x * hx - bd.y * hy), dy = R * (bd.y * hx + bd.x * hy);
