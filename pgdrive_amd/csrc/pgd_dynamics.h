@@ -76,20 +76,13 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
   const pgd_config& g = d.cfg;
   const int mflags = MARL ? g.marl_flags : 0;
   unsigned vf = (unsigned)r.vflags;
-  const pgd_lane& VL = mv.lanes[r.lane];
-  bool in_ref = VL.road == ctx.road_cur;
-  const pgd_lane& cl = in_ref ? VL : mv.lanes[ctx.cur_first];
-  float positive = (in_ref || (mflags & PGD_MA_PLAIN_REWARD)) ? 1.0f : (mv.roads[VL.road].negative ? -1.0f : 1.0f);
-  float l0, t0, l1, t1;
-  lane_local(cl, r.lastx, r.lasty, l0, t0);
-  lane_local(cl, r.x, r.y, l1, t1);
+  const float positive = ctx.positive;
   float w = mv.m->lane_width;
-  float lateral_factor = g.use_lateral ? clipf(1.0f - 2.0f * fabsf(t1) / w, 0.0f, 1.0f) : 1.0f;
-  float reward = g.driving_reward * (l1 - l0) * lateral_factor * positive;
+  float reward = ctx.drive;  // formed by after_step_vehicle from the coordinates it had just evaluated
   if (mflags & PGD_MA_TOLLGATE) {  // MultiAgentTollgateEnv.reward_function (marl_tollgate.py:195-232)
     if (ctx.blk == '$') {
       // BaseVehicle.overspeed (base_vehicle.py:759-761): lane.speed_limit (3 on toll lanes, 1000 elsewhere) < speed [km/h]
-      const bool lane_toll = mv.roads[VL.road].block_id == '$';
+      const bool lane_toll = mv.roads[mv.lanes[r.lane].road].block_id == '$';
       if (lane_toll && 3.0f < speed_kmh(r.v)) reward = -g.overspeed_penalty * speed_kmh(r.v) / sp.max_speed;
     } else reward += g.speed_reward * (speed_kmh(r.v) / sp.max_speed);
   } else

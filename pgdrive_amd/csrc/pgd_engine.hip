@@ -112,7 +112,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
 
   PHASE_INIT();
   Veh r;
-  RouteCtx ctx{0, 0, 0, 1, 0};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
+  RouteCtx ctx{0, 0, 0, 1, 0, 0.0f, 1.0f};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
   MapView mv;
   const pgd_spawn* sp = nullptr;
   const pgd_scenario* sc = nullptr;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_MARK(4);  // crash
   // (6) after_step; traffic off the lanes is removed (traffic_manager.py:91-109)
   if (acting) {
-    after_step_vehicle(mv, g, *sp, r, s < A, !one_env, ctx);
+    after_step_vehicle(d.cfg, mv, g, *sp, r, s < A, !one_env, ctx);
     if (s >= A && (r.vflags & PGD_F_OFF_LANE)) r.status = ST_REMOVED;
   }
   if (one_env) {  // line / sidewalk test of each agent by the whole wave (base_vehicle.py:615-644)
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
           sp = d.spawns + (size_t)scen * d.sstride + sidx;
           reset_vehicle(*sp, r, sidx, true);
           r.agent_id = (float)next_agent;
-          after_step_vehicle(mv, g, *sp, r, true, true, ctx);
+          after_step_vehicle(d.cfg, mv, g, *sp, r, true, true, ctx);
           my_fl |= PGD_F_NEW;
           if (leader) {
             S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
@@ -502,7 +502,7 @@ DEV unsigned long long reset_slot(const PgdDev& d, const LaneMap& lm, int scen, 
   MapView mv = map_view(d, d.scen[scen].map);
   reset_vehicle(*sp, r, s, s < A);
   RouteCtx ctx;
-  if (r.status != ST_EMPTY) after_step_vehicle(mv, g, *sp, r, s < A, true, ctx);
+  if (r.status != ST_EMPTY) after_step_vehicle(d.cfg, mv, g, *sp, r, s < A, true, ctx);
   const unsigned long long am = __ballot(lm.sub == 0 && s < A && r.status == ST_ACTIVE);  // epw == 1 whenever A > 1
   if (s < A && r.status == ST_ACTIVE) r.agent_id = A == 1 ? 0.0f : (float)__popcll(am & ((1ull << lm.lead) - 1ull));
   return am;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(WAVE) void k_refresh(PgdDev d) {
   int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
   MapView mv = map_view(d, d.scen[scen].map);
   RouteCtx ctx;
-  after_step_vehicle(mv, g, d.spawns[(size_t)scen * d.sstride + r.spawn], r, s < A, true, ctx);
+  after_step_vehicle(d.cfg, mv, g, d.spawns[(size_t)scen * d.sstride + r.spawn], r, s < A, true, ctx);
   if (lm.sub == 0) store_veh(d, e, s, r);
 }
 

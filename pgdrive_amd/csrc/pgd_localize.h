@@ -123,7 +123,7 @@ DEV void update_checkpoints(const MapView& mv, const Grp& g, const pgd_spawn& sp
 }
 
 // Navigation.update_localization (navigation.py:155-183)
-DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r) {
+DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, float& lon_out, float& lat_out) {
   const float s = r.hy, c = r.hx;
   int road_cur = sp.ckpt_road[r.ck0];
   int road_next = (r.ck0 == r.ck1) ? -1 : sp.ckpt_road[r.ck1];
@@ -135,6 +135,7 @@ DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& s
   r.lane = lane;
   float lon, lat;
   lane_local(mv.lanes[lane], r.x, r.y, lon, lat);
+  lon_out = lon; lat_out = lat;
   update_checkpoints(mv, g, sp, r, lon);
   r.vflags = on_lane ? (r.vflags & ~PGD_F_OFF_LANE) : (r.vflags | PGD_F_OFF_LANE);
   PHASE_MARK(18);  // after_step: lane_local + checkpoints
@@ -183,19 +184,22 @@ struct RouteCtx {
   int cur_first;   // its first lane (current_ref_lanes[0]) ...
   int cur_n;       // ... and lane count
   int next_first;  // first lane of the next checkpoint road (== cur_first on the last road)
+  float drive;     // driving_reward * (long_now - long_last) * lateral_factor * positive_road of the step (pgdrive_env.py:209-258)
+  float positive;  // +1 / -1: the sign the reference gives the speed reward on a negative road
 };
 DEV RouteCtx route_ctx(const MapView& mv, const pgd_spawn& sp, int ck0, int ck1) {
   const int rc = sp.ckpt_road[ck0], rn = sp.ckpt_road[ck1];
   const pgd_road& CR = mv.roads[rc];
   const pgd_road& NR = mv.roads[rn];
-  return RouteCtx{CR.block_id, rc, CR.first_lane, CR.n_lanes, NR.first_lane};
+  return RouteCtx{CR.block_id, rc, CR.first_lane, CR.n_lanes, NR.first_lane, 0.0f, 1.0f};
 }
 
 // BaseVehicle.after_step (base_vehicle.py:255-290).  `with_state_check` = false lets the caller run the line / sidewalk
 // test wave-cooperatively afterwards (k_step with one env per wave) and OR the result into vflags.
-DEV void after_step_vehicle(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, bool is_agent,
+DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, bool is_agent,
                             bool with_state_check, RouteCtx& ctx) {
-  update_localization(mv, g, sp, r);
+  float lon_v, lat_v;
+  update_localization(mv, g, sp, r, lon_v, lat_v);
   if (is_agent) {
     ctx = route_ctx(mv, sp, r.ck0, r.ck1);
     unsigned fl = (unsigned)r.vflags;
@@ -215,6 +219,19 @@ DEV void after_step_vehicle(const MapView& mv, const Grp& g, const pgd_spawn& sp
       range = 50.0f * ray_grid(mv, sx, sy, -L0.by * 50.0f, L0.bx * 50.0f, (1u << PGD_BOX_WHITE) | (1u << PGD_BOX_YELLOW));
     }
     r.dr = range - r.dl;
+    {
+      // the driving term of the reward (pgdrive_env.py:209-232): longitudinal progress on the vehicle's own lane when that
+      // lane belongs to the current reference road, else on the first reference lane.  Both coordinate pairs of the new
+      // position were just evaluated, so the term is formed here; reward_done adds the speed term and the terminal cases.
+      const pgd_lane& VL = mv.lanes[r.lane];
+      const bool in_ref = VL.road == ctx.road_cur;
+      float l0, t0;
+      lane_local(in_ref ? VL : L0, r.lastx, r.lasty, l0, t0);
+      const float l1 = in_ref ? lon_v : lon, t1 = in_ref ? lat_v : lat;
+      ctx.positive = (in_ref || (cfg.marl_flags & PGD_MA_PLAIN_REWARD)) ? 1.0f : (mv.roads[VL.road].negative ? -1.0f : 1.0f);
+      const float lateral_factor = cfg.use_lateral ? clipf(1.0f - 2.0f * fabsf(t1) / w, 0.0f, 1.0f) : 1.0f;
+      ctx.drive = cfg.driving_reward * (l1 - l0) * lateral_factor * ctx.positive;
+    }
     if (r.dr < 0.0f || r.dl < 0.0f) fl |= PGD_F_OUT_OF_ROUTE;
     r.vflags = (int)fl;
     float dist = norm2(r.lastx - r.x, r.lasty - r.y) / 1000.0f;
