@@ -597,3 +597,45 @@ def test_full_size_properties():
         assert torch.equal(o4, o_ref)
     for e in (big, small, twin, resumed):
         e.close()
+
+
+def test_record_cache_matches_plain_records(descs):
+    """The step kernel skips the write of a record that did not change and reads never-written slots from the scenario's
+    reset image.  Engine A runs freely with both short cuts; engine B gets A's complete state through get_state /
+    set_state before every step (set_state drops the image marks, so B reads its own records).  Same kernel, same inputs:
+    every output must be bit-identical, through terminations, auto-resets with re-drawn scenarios, a partial pgd_reset
+    and a scenario re-upload in the middle of the run."""
+    n_envs = 96
+    torch, eng_a, ora, cfg = _engines(descs, n_envs, seed=5)
+    _, eng_b, _, _ = _engines(descs, n_envs, seed=5)
+    scen_ids = np.arange(n_envs) % 8
+    eng_a.reset(scen_ids)
+    eng_b.reset(scen_ids)
+    rng = np.random.default_rng(3)
+    n_done = n_pending_rows = 0
+    for t in range(260):
+        act = util.driving_actions(rng, n_envs)
+        if t % 3 == 0:  # a third of the steps: hard steering at full throttle, episodes end quickly
+            act[::2, 0, 0] = 1.0
+            act[::2, 0, 1] = 1.0
+        if t == 90:  # a partial reset of A (then mirrored into B through the state)
+            ids = np.arange(0, n_envs, 5)
+            eng_a.reset((ids + 3) % 8, env_ids=ids)
+        if t == 170:  # the same scenarios uploaded again: A falls back to its own records until the next reset
+            sb = eng_a.scen
+            from pgdrive_amd.engine import _chk, _np_p
+            _chk(eng_a.L.pgd_upload_scenarios(eng_a.h, _np_p(sb.scenarios), len(sb.scenarios), _np_p(sb.spawns)), "upload")
+        f, i, ei = eng_a.get_state()
+        eng_b.set_state(f, i, ei)
+        n_pending_rows += int((i[_abi.SI["STATUS"], :, 1:] == 1).sum())
+        ga = [x.clone() for x in eng_a.step(torch.from_numpy(act).to(eng_a.device))]
+        gb = [x.clone() for x in eng_b.step(torch.from_numpy(act).to(eng_b.device))]
+        eng_a.sync(); eng_b.sync()
+        for xa, xb, name in zip(ga, gb, ("obs", "reward", "done", "flags")):
+            assert torch.equal(xa.cpu(), xb.cpu()), "%s differs at step %d" % (name, t)
+        fa, ia, eia = eng_a.get_state()
+        fb, ib, eib = eng_b.get_state()
+        assert (ia == ib).all() and (eia == eib).all() and (fa.view(np.int32) == fb.view(np.int32)).all(), "state differs at step %d" % t
+        n_done += int(ga[2].sum().item())
+    print("record cache: episodes ended", n_done, "waiting-traffic rows seen", n_pending_rows)
+    assert n_done > 50 and n_pending_rows > 10000
