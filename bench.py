@@ -8,8 +8,10 @@
 One "step" = pgd_step over all local environments: every agent and traffic vehicle advanced 0.1 s + (obs, reward, done)
 written.  Workload = BASELINE config C3: 4096 envs/GPU x (1 ego + 16 IDM traffic slots) x 240 lidar beams, PGDrive-v0
 maps (seeds 1000..1099, env e -> scenario e mod 100), actions uniform(-1,1) from numpy default_rng(0), pre-generated
-on the device, auto-reset on done.  Weak scaling: each rank owns 4096 envs; with N>1 ranks one RCCL all_gather of
-(obs, reward, done) per step over xGMI is inside the timed region.
+on the device, auto-reset on done.  Weak scaling: each rank owns 4096 envs.  Environments are independent, so env.step()
+has no exchange step: ranks share nothing in the timed region (a data-parallel learner consumes its own shard).  `--gather`
+adds the optional learner-side exchange -- one RCCL all_gather of (obs, reward, done) per step over xGMI, double-buffered
+-- inside the timed region.
 """
 import argparse
 import json
@@ -105,7 +107,9 @@ def main():
     ap.add_argument("--traffic", type=int, default=16)
     ap.add_argument("--lasers", type=int, default=240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="replicas only: skip the per-step RCCL gather")
+    ap.add_argument("--gather", action="store_true",
+                    help="N>1: add the learner-side exchange, one RCCL all_gather of (obs, reward, done) per step")
+    ap.add_argument("--no-gather", action="store_true", help="(default behaviour; kept for old command lines)")
     ap.add_argument("--actions", default="uniform", choices=["uniform", "straight"],
                     help="uniform(-1,1) (the metric's stream) or drive straight [0,1] with small steering noise (SURVEY 8d)")
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
@@ -125,10 +129,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
-    local_rank = local_rank % torch.cuda.device_count()  # plumbing tests may oversubscribe one GPU
+    local_rank = local_rank % torch.cuda.device_count()  # plumbing tests (gloo) may oversubscribe one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        kw = dict(device_id=dev) if args.backend == "nccl" else {}  # binds the RCCL communicator to this rank's GPU
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
 
     N = args.envs
     if args.workload == "c5":  # BASELINE config 5: multi-agent roundabout (reported next to the metric, never as the metric)
@@ -165,7 +171,7 @@ def main():
         acts[..., 1] = 1.0
     actions = torch.from_numpy(acts).to(dev)
 
-    gather = world > 1 and not args.no_gather
+    gather = world > 1 and args.gather and not args.no_gather
     if gather:
         # one exchange per step: obs | reward | done packed into a single fp32 row per env, double-buffered:
         # the all_gather of step t (RCCL's own stream) overlaps the kernels of step t+1; buffer b is re-used at step t+2
@@ -247,7 +253,7 @@ def main():
                 ("C5: %d envs/GPU x %d agents, multi-agent roundabout, 72 beams x 40 m, %s actions, respawn, auto-reset; "
                  "agent-steps/s = value x %d" % (N, A, args.actions, A)),
                 "envs_per_gpu": N, "global_envs": N * world, "obs_dim": D,
-                "parallelism": "env-sharded dp%d%s" % (world, " + 1 RCCL all_gather(obs,reward,done)/step, double-buffered" if gather else ""),
+                "parallelism": "env-sharded dp%d%s" % (world, " + 1 RCCL all_gather(obs,reward,done)/step, double-buffered" if gather else ", no data-path collective"),
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom + (" (observation fused)" if fused else ""), "achieved": achieved,
