@@ -211,6 +211,9 @@ typedef struct pgd_config {
                                     yellow line / off lane / sidewalk (white lines may be crossed) */
 #define PGD_MA_YELLOW_OK     32  /* cross_yellow_line_done = False (marl_bottleneck.py:130-136): a yellow line is not
                                     out-of-road */
+#define PGD_MA_OTHERS_STATE 256  /* LidarStateObservationMARound.observe (marl_inout_roundabout.py:82-105): each of the
+                                    num_others neighbour rows is the neighbour's own StateObservation vector (as long as
+                                    the observing agent's state block, zeros when absent) instead of 4 relative floats */
 
 typedef struct pgd_engine* pgd_handle;
 

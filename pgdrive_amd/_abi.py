@@ -28,7 +28,7 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
                 respawn_dests=0, side_lasers=0, side_dist=50.0, lane_line_lasers=0, lane_line_dist=20.0,
                 discrete_action=False, discrete_steering_dim=5, discrete_throttle_dim=5, increment_steering=False,
                 safe_rl_env=False, plain_reward=False, cross_yellow_line_done=True, tollgate=False, overspeed_penalty=0.5,
-                min_pass_steps=30, enable_reverse=False, parking=False, random_agent_model=False,
+                min_pass_steps=30, enable_reverse=False, parking=False, others_state=False, random_agent_model=False,
                 lidar_gaussian_noise=0.0, lidar_dropout_prob=0.0):
     """Defaults mirror PGDriveEnv_DEFAULT_CONFIG / BASE_DEFAULT_CONFIG (pgdrive_env.py:22-109, base_env.py:19-90)."""
     c = PgdConfig()
@@ -52,7 +52,7 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
         c.marl_flags = MA_ENABLED | (MA_CRASH_DONE if crash_done else 0) | (MA_OUT_ROAD_DONE if out_of_road_done else 0) | \
             (MA_ALLOW_RESPAWN if allow_respawn else 0) | (MA_PLAIN_REWARD if plain_reward else 0) | \
             (0 if cross_yellow_line_done else MA_YELLOW_OK) | (MA_TOLLGATE if tollgate else 0) | \
-            (MA_PARKING if parking else 0)
+            (MA_PARKING if parking else 0) | (MA_OTHERS_STATE if others_state else 0)
         c.overspeed_penalty, c.min_pass_steps = float(overspeed_penalty), int(min_pass_steps)
         c.delay_done, c.agent_limit = int(delay_done), int(agent_limit or num_agents)
         c.respawn_places, c.respawn_dests = int(respawn_places), int(respawn_dests)
@@ -61,8 +61,9 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
 
 def obs_dim(cfg):
     toll = bool(cfg.marl_flags & MA_TOLLGATE)
-    return (cfg.side_lasers or 2) + 6 + cfg.lane_line_lasers + (2 if cfg.random_agent_model else 0) + (0 if toll else 10) + \
-        4 * cfg.num_others + cfg.num_lasers + (2 if toll else 0)
+    state = (cfg.side_lasers or 2) + 6 + cfg.lane_line_lasers + (2 if cfg.random_agent_model else 0) + (0 if toll else 10)
+    per_other = state if cfg.marl_flags & MA_OTHERS_STATE else 4
+    return state + per_other * cfg.num_others + cfg.num_lasers + (2 if toll else 0)
 
 
 # state layout (include/pgd_state_layout.h)
@@ -75,6 +76,7 @@ NF, NI, NEI = 24, 8, 8
 ST_EMPTY, ST_PENDING, ST_ACTIVE, ST_REMOVED, ST_DYING = 0, 1, 2, 3, 4
 MA_ENABLED, MA_CRASH_DONE, MA_OUT_ROAD_DONE, MA_ALLOW_RESPAWN, MA_PLAIN_REWARD, MA_YELLOW_OK, MA_TOLLGATE = 1, 2, 4, 8, 16, 32, 64
 MA_PARKING = 128
+MA_OTHERS_STATE = 256
 
 F_ARRIVE, F_OUT_OF_ROAD, F_CRASH_VEHICLE, F_CRASH_OBJECT, F_CRASH_BUILDING, F_MAX_STEP = 1, 2, 4, 8, 16, 32
 F_ON_YELLOW, F_ON_WHITE, F_ON_BROKEN, F_CRASH_SIDEWALK, F_OFF_LANE, F_OUT_OF_ROUTE = 256, 512, 1024, 2048, 4096, 8192

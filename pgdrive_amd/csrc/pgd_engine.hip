@@ -626,7 +626,8 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
   ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
   ag.blk = ctx.blk; ag.toll_time = mine.f[SF_PID_HP];
   ag.env = e; ag.slot = a; ag.tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
-  observe_agent<true>(d, mv, msp, ag, L, row, tid, BLOCK);
+  if (d.cfg.marl_flags & PGD_MA_OTHERS_STATE) observe_agent<true, false, true>(d, mv, msp, ag, L, row, tid, BLOCK, recs, spb);
+  else observe_agent<true>(d, mv, msp, ag, L, row, tid, BLOCK);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -704,8 +705,10 @@ const char* pgd_version(void) { return "pgdrive_hip 0.1 (gfx950)"; }
 
 int pgd_obs_dim(const pgd_config* c) {
   const int toll = (c->marl_flags & PGD_MA_TOLLGATE) != 0;
-  return (c->side_lasers > 0 ? c->side_lasers : 2) + 6 + c->lane_line_lasers + (c->random_agent_model ? 2 : 0) +
-         (toll ? 0 : PGD_NAVI_DIM) + 4 * c->num_others + c->num_lasers + (toll ? 2 : 0);
+  const int state = (c->side_lasers > 0 ? c->side_lasers : 2) + 6 + c->lane_line_lasers + (c->random_agent_model ? 2 : 0) +
+                    (toll ? 0 : PGD_NAVI_DIM);
+  const int per_other = (c->marl_flags & PGD_MA_OTHERS_STATE) ? state : 4;
+  return state + per_other * c->num_others + c->num_lasers + (toll ? 2 : 0);
 }
 
 int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* out) {

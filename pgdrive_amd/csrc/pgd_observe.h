@@ -41,6 +41,9 @@ struct ObsLds {  // bodies inside the lidar broad phase of the observing agent, 
   float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV];
   float bdist[MAXV];  // centre distance; +inf for traffic objects, which are never ranked as neighbour vehicles
   int bi0[MAXV], bcnt[MAXV];  // lidar beams [bi0, bi0 + bcnt) mod num_lasers that can reach the body (conservative)
+  int bslot[MAXV];            // slot of the body in its env
+  int rank_slot[16];          // PGD_MA_OTHERS_STATE: slot of the neighbour of rank r (-1 = none) ...
+  float rank_spd[16];         // ... and its speed [km/h] as the observer sees it (0 for a static finished agent)
   int n, nveh;
 };
 struct AgentView {  // what the observation needs from the observing vehicle
@@ -82,34 +85,26 @@ DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, flo
       }
     }
     L.bi0[k] = i0; L.bcnt[k] = cnt;
+    L.bslot[k] = o;
   }
   if (o == 0) { L.n = __popcll(m); L.nveh = __popcll(mv_); }
 }
 
-// writes the D floats of one agent's row with `nt` cooperating threads (tid in [0, nt))
-// STD: the reference's default row layout (no detector fans, no random_agent_model, no toll floats, no lidar noise) as a
-// compile-time fact: every column offset is a constant and the optional blocks vanish from the benchmark kernel.
-template <bool OBJ, bool STD = false>
-DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const AgentView& ag, const ObsLds& L,
-                       float* __restrict__ row, int tid, int nt) {
+// StateObservation.observe of one vehicle (state_obs.py:42-106): ego state + detector fans + navigation info, written to
+// row[0 .. state length) by threads tid in [0, nt)
+template <bool STD>
+DEV void state_block(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const AgentView& ag, float* __restrict__ row,
+                     int tid, int nt) {
   const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
-  const float R = d.cfg.lidar_dist;
-  const int NL = d.cfg.num_lasers;
   // StateObservation.vehicle_state (state_obs.py:58-106) + navi info (navigation.py:185-197): one lane per float.
   // Row layout: [side fan k | 2 lateral distances][6 ego floats][lane-line fan m][10 navi][4*NO neighbours][NL beams]
   const int KS = STD ? 0 : d.cfg.side_lasers, KM = STD ? 0 : d.cfg.lane_line_lasers;
   const bool toll = !STD && (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;  // no navigation block, 2 toll floats after the lidar
   const int RAM = (!STD && d.cfg.random_agent_model) ? 2 : 0;  // LENGTH / 10, WIDTH / 2.5 after the lane-line fan (state_obs.py:102-105)
-  const int o_ego = KS > 0 ? KS : 2, o_navi = o_ego + 6 + KM + RAM, o_oth = o_navi + (toll ? 0 : 10);
+  const int o_ego = KS > 0 ? KS : 2, o_navi = o_ego + 6 + KM + RAM;
   if (RAM && tid == nt - 1) {
     row[o_ego + 6 + KM] = clipf(sp.length / 10.0f, 0.0f, 1.0f);
     row[o_ego + 6 + KM + 1] = clipf(sp.width / 2.5f, 0.0f, 1.0f);
-  }
-  if (toll && tid == 0) {  // TollGateObservation.observe (marl_tollgate.py:84-96)
-    const bool in_toll = ag.blk == '$';
-    float* t2 = row + o_oth + 4 * d.cfg.num_others + NL;
-    t2[0] = in_toll ? 1.0f : 0.0f;
-    t2[1] = (in_toll && ag.toll_time > (float)d.cfg.min_pass_steps) ? 1.0f : 0.0f;
   }
   if (tid < 18) {
     // every lane fetches the one lane record its float needs BEFORE the branch ladder, so the reads overlap instead of
@@ -157,12 +152,78 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
     sincosf((float)i * (2.0f * PGD_PI / (float)n) + 0.5f * PGD_PI + ag.th, &sn, &cs);
     row[side ? i : o_ego + 6 + i] = ray_grid(mv, px, py, dist * cs, dist * sn, kinds);
   }
+}
+
+// the view of slot `o` of the env as an observed vehicle (the state vector a neighbour contributes to
+// LidarStateObservationMARound); its speed comes from the observer's snapshot
+DEV AgentView view_of_slot(const PgdDev& d, const MapView& mv, const VehRec* recs, const pgd_spawn* spb, int o, float spd_kmh,
+                           int env, uint32_t tick) {
+  const VehRec& rc = recs[o];
+  AgentView ag;
+  ag.x = rc.f[SF_X]; ag.y = rc.f[SF_Y]; ag.th = rc.f[SF_THETA];
+  sincosf(ag.th, &ag.hy, &ag.hx);
+  ag.dl = rc.f[SF_DIST_LEFT]; ag.dr = rc.f[SF_DIST_RIGHT];
+  ag.v = spd_kmh == 0.0f ? 0.0f : rc.f[SF_SPEED];  // the snapshot says 0: an agent that finished in an EARLIER step (static body)
+  ag.steer = rc.f[SF_STEER]; ag.a0s = rc.f[SF_ACT0S]; ag.a0t = rc.f[SF_ACT0T]; ag.lhx = rc.f[SF_LASTHX]; ag.lhy = rc.f[SF_LASTHY];
+  const RouteCtx ctx = route_ctx(mv, spb[rc.i[SI_SPAWN]], rc.i[SI_CK0], rc.i[SI_CK1]);
+  ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
+  ag.blk = ctx.blk; ag.toll_time = rc.f[SF_PID_HP];
+  ag.env = env; ag.slot = o; ag.tick = tick;
+  return ag;
+}
+
+// writes the D floats of one agent's row with `nt` cooperating threads (tid in [0, nt))
+// STD: the reference's default row layout (no detector fans, no random_agent_model, no toll floats, no lidar noise) as a
+// compile-time fact: every column offset is a constant and the optional blocks vanish from the benchmark kernel.
+// OTH: PGD_MA_OTHERS_STATE (stand-alone k_observe only: `recs` / `spb` = the env's records and spawn table)
+template <bool OBJ, bool STD = false, bool OTH = false>
+DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const AgentView& ag, ObsLds& L,
+                       float* __restrict__ row, int tid, int nt, const VehRec* recs = nullptr, const pgd_spawn* spb = nullptr) {
+  const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
+  const float R = d.cfg.lidar_dist;
+  const int NL = d.cfg.num_lasers;
+  const int KS = STD ? 0 : d.cfg.side_lasers, KM = STD ? 0 : d.cfg.lane_line_lasers;
+  const bool toll = !STD && (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;
+  const int RAM = (!STD && d.cfg.random_agent_model) ? 2 : 0;
+  const int o_oth = (KS > 0 ? KS : 2) + 6 + KM + RAM + (toll ? 0 : 10);  // = length of the state block
+  const int NO = d.cfg.num_others;
+  const int per_other = OTH ? o_oth : 4;
+  state_block<STD>(d, mv, sp, ag, row, tid, nt);
+  if (toll && tid == 0) {  // TollGateObservation.observe (marl_tollgate.py:84-96)
+    const bool in_toll = ag.blk == '$';
+    float* t2 = row + o_oth + per_other * NO + NL;
+    t2[0] = in_toll ? 1.0f : 0.0f;
+    t2[1] = (in_toll && ag.toll_time > (float)d.cfg.min_pass_steps) ? 1.0f : 0.0f;
+  }
   PHASE_MARK(22);  // obs: state + navi block
   if (NL <= 0) return;
   // get_surrounding_vehicles_info (lidar.py:55-77): rank by centre distance (stable), 4 floats per neighbour; the last
   // threads take this part so that it overlaps the state block of the first ones
-  const int NO = d.cfg.num_others;
   const int n = L.n, nveh = OBJ ? L.nveh : n;
+  if (OTH) {
+    // LidarStateObservationMARound.observe (marl_inout_roundabout.py:82-105): the num_others nearest vehicles (stable rank
+    // by centre distance) contribute their own state vectors; absent ranks are zeros.  Ranks -> slots through LDS, then
+    // the block evaluates one neighbour after the other with the same state_block code.
+    if (tid < 16) L.rank_slot[tid] = -1;
+    __syncthreads();
+    for (int k = tid; k < n; k += nt) {
+      int rank = 0;
+      const float dk = L.bdist[k];
+      for (int j = 0; j < n; ++j) rank += (L.bdist[j] < dk || (L.bdist[j] == dk && j < k)) ? 1 : 0;
+      if (rank < NO && dk < __builtin_inff()) { L.rank_slot[rank] = L.bslot[k]; L.rank_spd[rank] = L.bspd[k]; }
+    }
+    __syncthreads();
+    for (int r = 0; r < NO; ++r) {
+      const int o = L.rank_slot[r];
+      float* dst = row + o_oth + r * o_oth;
+      if (o < 0) {
+        for (int q = tid; q < o_oth; q += nt) dst[q] = 0.0f;
+      } else {
+        const AgentView oa = view_of_slot(d, mv, recs, spb, o, L.rank_spd[r], ag.env, ag.tick);
+        state_block<STD>(d, mv, spb[recs[o].i[SI_SPAWN]], oa, dst, tid, nt);
+      }
+    }
+  } else
   // with objects: indices [0, n) are the compacted bodies, [n, n + NO) the rank rows to zero-fill; without: [0, max(n, NO))
   for (int k = nt - 1 - tid; k < (OBJ ? n + NO : (n > NO ? n : NO)); k += nt) {
     if (k < n) {
@@ -210,7 +271,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
         if (u3 < d.cfg.lidar_dropout_prob) best = 0.0f;
       }
     }
-    row[o_oth + 4 * NO + i] = best;
+    row[o_oth + per_other * NO + i] = best;
   }
   PHASE_MARK(24);  // obs: lidar
 }

@@ -63,8 +63,8 @@ class MultiAgentRoundaboutVecEnv:
         self.config = c = merge_config(self.DEFAULTS, config)
         lid = c["vehicle_config"]["lidar"]
         sd, ld = c["vehicle_config"]["side_detector"], c["vehicle_config"]["lane_line_detector"]
-        if lid["num_others"] != 0:
-            raise NotImplementedError("LidarStateObservationMARound with num_others > 0 is not built (reference default 0)")
+        if not 0 <= lid["num_others"] <= 16:
+            raise ValueError("lidar.num_others must be in [0, 16]")
         self.desc = self._generate_map(c["map_config"])
         self.map_bank = mapdata.MapBank([self.desc], truncate_succ=True)  # no IDM traffic on the multi-agent maps
         cap = c["max_agents"] or c["num_agents"]
@@ -72,7 +72,10 @@ class MultiAgentRoundaboutVecEnv:
                                                    n_variants=c["spawn_variants"], seed=c["seed"], kind=self.MAP_KIND)
         self.num_envs, self.A = int(c["num_envs"]), cap
         self.cfg = _abi.make_config(
-            self.num_envs, num_agents=cap, num_traffic=self.scen_bank.B, num_lasers=lid["num_lasers"], num_others=0,
+            self.num_envs, num_agents=cap, num_traffic=self.scen_bank.B, num_lasers=lid["num_lasers"],
+            # neighbour rows: the neighbour's own state vector (LidarStateObservationMARound, marl_inout_roundabout.py:82-105);
+            # the tollgate env observes through TollGateObservation, a LidarStateObservation: 4 relative floats per neighbour
+            num_others=lid["num_others"], others_state=lid["num_others"] > 0 and not self.TOLLGATE,
             lidar_dist=lid["distance"], dt=c["physics_world_step_size"], decision_repeat=c["decision_repeat"],
             auto_reset=c["auto_reset"], resample_scenario=1, horizon=c["horizon"] or 0, seed=c["seed"],
             success_reward=c["success_reward"], out_of_road_penalty=c["out_of_road_penalty"],

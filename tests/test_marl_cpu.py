@@ -143,3 +143,36 @@ def test_oracle_intersection_episode_runs():
         assert np.isfinite(obs).all() and obs.min() >= 0.0 and obs.max() <= 1.0
     assert n_new > 10 and n_all >= 2
     o.close()
+
+
+def test_neighbour_state_rows_layout():
+    """PGD_MA_OTHERS_STATE (LidarStateObservationMARound, marl_inout_roundabout.py:72-105): row = state | num_others x state |
+    lidar; a neighbour's row equals the state block of that neighbour's own observation; absent ranks are zero."""
+    from oracle import orc
+    d, mb, sb = util.make_marl_banks(num_agents=8, capacity=8, kind="roundabout")
+    n_envs, NO = 4, 3
+    cfg = util.marl_config(n_envs, sb, num_others=NO, others_state=True)
+    SL = 2 + 6 + 10
+    assert _abi.obs_dim(cfg) == SL + NO * SL + 72
+    ora = orc.Oracle(cfg, mb, sb)
+    ora.reset(np.arange(n_envs) % 4)
+    rng = np.random.default_rng(0)
+    for t in range(30):
+        obs = ora.step(util.marl_actions(rng, n_envs, sb.A))[0]
+    f, i, ei = ora.get_state()
+    checked = zeros = 0
+    for e in range(n_envs):
+        act = np.nonzero(i[_abi.SI["STATUS"], e, :sb.A] == _abi.ST_ACTIVE)[0]
+        for a in act:
+            row = obs[e, a]
+            for r in range(NO):
+                blk = row[SL + r * SL:SL + (r + 1) * SL]
+                if not blk.any():
+                    zeros += 1
+                    continue
+                # it must be the state block of exactly one other active agent's own row
+                hits = [b for b in act if b != a and np.allclose(obs[e, b, :SL], blk, atol=1e-12)]
+                others_dying = (i[_abi.SI["STATUS"], e, :sb.A] == _abi.ST_DYING).any()
+                assert hits or others_dying, (e, a, r)
+                checked += bool(hits)
+    assert checked > 10

@@ -410,6 +410,13 @@ def test_marl_roundabout_parity(num_agents, capacity, kind="roundabout", **cfg_k
     assert seen["dying"] > 0 and stats["n_new"] > 0 and stats["n_all_done"] > 0 and stats["n_report"] > 1000
 
 
+@pytest.mark.parametrize("kind,num_others", [("roundabout", 4), ("intersection", 8)])
+def test_marl_neighbour_state_rows_parity(kind, num_others):
+    """LidarStateObservationMARound with lidar.num_others > 0 (marl_inout_roundabout.py:82-105): every neighbour row is the
+    neighbour's own state vector (19 floats here), finished static neighbours included, zeros when absent."""
+    test_marl_roundabout_parity(12, 16, kind=kind, num_others=num_others, others_state=True)
+
+
 def test_marl_intersection_parity():
     """MultiAgentIntersectionEnv (envs/marl_envs/marl_intersection.py): 4-way intersection with u-turns, 30 agents."""
     test_marl_roundabout_parity(30, 30, kind="intersection")
