@@ -157,6 +157,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   const bool trig = ONE_ENV ? (__ballot(s_flag[0] != 0) != 0ull) : (valid && s_flag[el] != 0);
   if (valid && trig && r.status == ST_PENDING && sp->group == ng) r.status = ST_ACTIVE;
   if (trig) ng += 1;  // every lane of the env keeps the same copy
+  // the own-lane coordinate / lane length / successor list of a vehicle are read by the IDM neighbour search alone: an
+  // env without a driving IDM vehicle in this step (most envs, most steps) skips them
+  const bool idm_runs = ONE_ENV ? (__ballot(valid && s >= A && r.status == ST_ACTIVE) != 0ull) : true;
   // snapshot of the world before physics
   if (valid) {
     if (leader) {
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       S.lane[slot] = r.lane;
       const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
       S.present[slot] = present ? 1 : 0;
-      if (present && V > A) {
+      if (present && V > A && idm_runs) {
         const pgd_lane& ml = mv.lanes[r.lane];
         float lo, la;
         lane_local(ml, r.x, r.y, lo, la);
