@@ -566,7 +566,8 @@ __global__ __launch_bounds__(WAVE) void k_refresh(PgdDev d) {
 // k_observe: stand-alone observation kernel, one block per (env, agent).  pgd_step fuses the observation into k_step when
 // a wave carries exactly one env; this kernel serves pgd_reset / pgd_observe and the configurations that do not fuse.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int BLOCK>
+// OTH: PGD_MA_OTHERS_STATE rows (a kernel of its own: the neighbour-state path would cost the plain one registers)
+template <int BLOCK, bool OTH>
 __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags) {
   __shared__ ObsLds L;
   const int V = d.V, A = d.A, D = d.D;
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
   ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
   ag.blk = ctx.blk; ag.toll_time = mine.f[SF_PID_HP];
   ag.env = e; ag.slot = a; ag.tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
-  if (d.cfg.marl_flags & PGD_MA_OTHERS_STATE) observe_agent<true, false, true>(d, mv, msp, ag, L, row, tid, BLOCK, recs, spb);
+  if (OTH) observe_agent<true, false, true>(d, mv, msp, ag, L, row, tid, BLOCK, recs, spb);
   else observe_agent<true>(d, mv, msp, ag, L, row, tid, BLOCK);
 }
 
@@ -869,9 +870,11 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
 
 static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags) {
   int blocks = h->d.N * h->d.A;
-  if (h->d.cfg.num_lasers > 128)  // up to 128 beams one wave does it in two rounds: 4x fewer waves than 256-thread blocks
-    hipLaunchKernelGGL(k_observe<256>, dim3(blocks), dim3(256), 0, h->stream, h->d, d_obs, d_flags);
-  else hipLaunchKernelGGL(k_observe<64>, dim3(blocks), dim3(64), 0, h->stream, h->d, d_obs, d_flags);
+  const bool oth = (h->d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && h->d.cfg.num_others > 0;
+  const bool wide = h->d.cfg.num_lasers > 128;  // up to 128 beams one wave does it in two rounds: 4x fewer waves than 256-thread blocks
+  void (*kern)(PgdDev, float*, const uint32_t*) =
+      wide ? (oth ? k_observe<256, true> : k_observe<256, false>) : (oth ? k_observe<64, true> : k_observe<64, false>);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(wide ? 256 : 64), 0, h->stream, h->d, d_obs, d_flags);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }
