@@ -754,7 +754,30 @@ def gen_marl_intersection():
     print("wrote intersection slot goldens:", len(rows))
 
 
+def gen_random_lane():
+    """MapManager.add_random_to_map (manager/map_manager.py:157-169) run as-is on a manager re-seeded with the map seed
+    (engine.seed -> every manager, base_engine.py:300-304): the per-seed lane width / lane count of random_lane_width /
+    random_lane_num."""
+    from types import SimpleNamespace
+    from pgdrive.manager.map_manager import MapManager
+    from pgdrive.component.map.pg_map import PGMap
+    cases = []
+    for seed in list(range(0, 6)) + list(range(1000, 1006)) + [123456]:
+        for rw, rn in ((True, False), (False, True), (True, True)):
+            me = SimpleNamespace(np_random=get_np_random(seed), engine=SimpleNamespace(
+                global_config=dict(random_lane_width=rw, random_lane_num=rn, load_map_from_json=False)))
+            cfg = MapManager.add_random_to_map(me, {PGMap.LANE_WIDTH: 3.5, PGMap.LANE_NUM: 3})
+            cases.append(dict(seed=seed, random_lane_width=rw, random_lane_num=rn, lane_width=float(cfg[PGMap.LANE_WIDTH]),
+                              lane_num=int(cfg[PGMap.LANE_NUM])))
+    with open(os.path.join(ROOT, "tests", "golden", "random_lane_v0.json"), "w") as f:
+        json.dump(dict(cases=cases), f)
+    print("random lane cases:", len(cases), cases[:3])
+
+
 def main():
+    if "--random-lane-only" in sys.argv:
+        gen_random_lane()
+        return
     rng = np.random.default_rng(20240927)
     out = {}
     out_json = {}
@@ -763,6 +786,7 @@ def main():
     gen_traffic(maps + [ref_export.generate(s, block_num=3) for s in (1042, 1077)])
     gen_marl_intersection()
     gen_objects()
+    gen_random_lane()
     if "--detectors-only" in sys.argv or "--side-files-only" in sys.argv:
         return
     gen_scalar(rng, out)

@@ -32,14 +32,32 @@ def save_descriptions(descs, path, source="pgdrive_amd"):
 _CACHE = {}
 
 
-def get_descriptions(seeds, lane_num=3, lane_width=3.5, exit_length=50, block_num=3, block_seq=None):
+def randomized_lane_config(seed, lane_num, lane_width, random_lane_width=False, random_lane_num=False):
+    """MapManager.add_random_to_map (manager/map_manager.py:157-169): the manager's RandomState is re-seeded with the map
+    seed at every reset (base_engine.py:300-304), so the draws are a function of the seed: width uniform in
+    [MIN_LANE_WIDTH, MAX_LANE_WIDTH) = [3.0, 4.5), then lane count randint(MIN_LANE_NUM, MAX_LANE_NUM) = randint(2, 3) -- the
+    upper bound is exclusive, i.e. always 2 (pg_map.py:13-16), reproduced as is."""
+    from .scenario import get_np_random
+    rs = get_np_random(seed)
+    if random_lane_width:
+        lane_width = rs.rand() * (4.5 - 3.0) + 3.0
+    if random_lane_num:
+        lane_num = int(rs.randint(2, 3))
+    return lane_num, lane_width
+
+
+def get_descriptions(seeds, lane_num=3, lane_width=3.5, exit_length=50, block_num=3, block_seq=None,
+                     random_lane_width=False, random_lane_num=False):
     """Map descriptions for `seeds`, generated on the host by our own BIG (pgdrive_amd/mapgen.py) and cached per process
     (MapManager's per-seed PGMap cache, manager/map_manager.py:98-155)."""
     from . import mapgen
     out = []
     for s in seeds:
-        key = (int(s), lane_num, lane_width, exit_length, block_num, block_seq)
+        ln, lw = lane_num, lane_width
+        if random_lane_width or random_lane_num:
+            ln, lw = randomized_lane_config(int(s), lane_num, lane_width, random_lane_width, random_lane_num)
+        key = (int(s), ln, lw, exit_length, block_num, block_seq)
         if key not in _CACHE:
-            _CACHE[key] = mapgen.generate_map(int(s), lane_num, lane_width, exit_length, block_num, block_seq)
+            _CACHE[key] = mapgen.generate_map(int(s), ln, lw, exit_length, block_num, block_seq)
         out.append(_CACHE[key])
     return out

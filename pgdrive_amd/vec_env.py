@@ -19,6 +19,8 @@ DEFAULT_CONFIG = dict(
     environment_num=100,
     map=3,
     map_config=dict(lane_width=3.5, lane_num=3, exit_length=50),
+    random_lane_width=False,  # a lane width per map seed, uniform in [3.0, 4.5) (map_manager.py:157-163)
+    random_lane_num=False,  # a lane count per map seed, randint(2, 3) as upstream (map_manager.py:164-167)
     traffic_density=0.1,
     traffic_mode="trigger",  # "trigger" | "hybrid" (same as trigger upstream) | "respawn" (traffic_manager.py:19-27)
     random_traffic=False,  # True: traffic layout drawn from the env seed instead of the map seed (traffic_manager.py:348-350)
@@ -84,6 +86,9 @@ class PGDriveVecEnv:
         # perturbed, state_obs.py:155-170)
         mc = c["map_config"]
         seeds = list(range(c["start_seed"], c["start_seed"] + c["environment_num"]))
+        if (c["random_lane_width"] or c["random_lane_num"]) and c["map_bank"] is not None:
+            raise ValueError("random_lane_width / random_lane_num need generated maps: set map_bank=None "
+                             "(upstream: 'You are supposed to turn off the load_map_from_json', map_manager.py:159-166)")
         if c["map_bank"] is not None:  # pre-generated descriptions (load_map_from_json, pgdrive_env.py:38-39)
             by_seed = {d["seed"]: d for d in bank.load_descriptions(c["map_bank"])}
             missing = [s for s in seeds if s not in by_seed]
@@ -93,7 +98,8 @@ class PGDriveVecEnv:
             m = c["map"]
             kw = dict(block_num=m) if isinstance(m, int) else dict(block_seq=m, block_num=None)
             by_seed = {d["seed"]: d for d in bank.get_descriptions(seeds, mc["lane_num"], mc["lane_width"],
-                                                                   mc["exit_length"], **kw)}
+                                                                   mc["exit_length"], random_lane_width=c["random_lane_width"],
+                                                                   random_lane_num=c["random_lane_num"], **kw)}
         self.seeds = seeds
         sel = [by_seed[s] for s in seeds]
         self.num_envs = int(c["num_envs"])

@@ -112,6 +112,15 @@ def test_teacher_forced_parity(descs, num_traffic, num_lasers):
     assert stats.get("grazing", 0) <= 1e-5 * stats.get("beams", 1) + 2
 
 
+def test_random_lane_width_and_num_maps_parity():
+    """random_lane_width / random_lane_num (map_manager.py:157-169): 2-lane maps with a lane width per seed in [3.0, 4.5)
+    through the same teacher-forced comparison."""
+    from pgdrive_amd import bank
+    maps = bank.get_descriptions(range(1000, 1008), random_lane_width=True, random_lane_num=True)
+    assert all(m["lane_num"] == 2 for m in maps) and len({round(m["lane_width"], 6) for m in maps}) == 8
+    test_teacher_forced_parity(maps, 16, 240)
+
+
 @pytest.mark.parametrize("side,lane_line,num_lasers", [((12, 50.0), (6, 20.0), 240), ((2, 50.0), (2, 50.0), 0),
                                                        ((0, 50.0), (33, 20.0), 16), ((70, 30.0), (0, 20.0), 0)])
 def test_side_and_lane_line_detector_parity(descs, side, lane_line, num_lasers):
