@@ -414,11 +414,37 @@ def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=
     return scen, spawns, dict(dropped=dropped, n_traffic=slot - num_agents, n_objects=n_obj, objects_dropped=obj_dropped)
 
 
+def resolve_lane_index(desc, lane_index):
+    """(from node name, to node name, lane) as in vehicle_config.spawn_lane_index (pgdrive_env.py:77) -> map-local lane id."""
+    frm, to, idx = lane_index
+    nodes = desc["nodes"]
+    if frm not in nodes or to not in nodes:
+        raise KeyError("spawn_lane_index %r: no such node in map seed %s" % (lane_index, desc.get("seed")))
+    rl = mapdata.road_lookup(desc)
+    key = (nodes.index(frm), nodes.index(to))
+    if key not in rl:
+        raise KeyError("spawn_lane_index %r: no such road in map seed %s" % (lane_index, desc.get("seed")))
+    road = desc["roads"][rl[key]]
+    if not 0 <= idx < road["n_lanes"]:
+        raise KeyError("spawn_lane_index %r: the road has %d lanes" % (lane_index, road["n_lanes"]))
+    return road["first_lane"] + int(idx)
+
+
 class ScenarioBank:
-    def __init__(self, descs, seeds, num_agents=1, num_traffic=16, density=0.1, traffic_seeds=None, **kw):
+    def __init__(self, descs, seeds, num_agents=1, num_traffic=16, density=0.1, traffic_seeds=None, spawn_lane_index=None,
+                 destination_node=None, **kw):
+        """`spawn_lane_index` / `destination_node`: vehicle_config overrides of the spawn lane (default ('>', '>>', 0)) and of
+        the destination (default: a seeded random socket of the last block), pgdrive_env.py:76-80, navigation.py:99-121."""
         scens, spawns, self.info = [], [], []
         for m, (d, s) in enumerate(zip(descs, seeds)):
             ts = None if traffic_seeds is None else int(traffic_seeds[m])
+            if spawn_lane_index is not None or destination_node is not None:
+                lane = resolve_lane_index(d, spawn_lane_index if spawn_lane_index is not None else (">", ">>", 0))
+                if destination_node is not None and destination_node not in d["nodes"]:
+                    raise KeyError("destination_node %r: no such node in map seed %s" % (destination_node, d.get("seed")))
+                dest = None if destination_node is None else d["nodes"].index(destination_node)
+                kw = dict(kw, agent_spawns=[dict(lane=lane, long=kw.get("spawn_longitude", 5.0),
+                                                 lat=kw.get("spawn_lateral", 0.0), dest=dest)] * num_agents)
             sc, sp, info = build_scenario(d, m, s, num_agents, num_traffic, density, traffic_seed=ts, **kw)
             scens.append(sc)
             spawns.append(sp)

@@ -41,8 +41,10 @@ DEFAULT_CONFIG = dict(
         lidar=dict(num_lasers=240, distance=50, num_others=4, gaussian_noise=0.0, dropout_prob=0.0),
         side_detector=dict(num_lasers=0, distance=50, gaussian_noise=0.0, dropout_prob=0.0),
         lane_line_detector=dict(num_lasers=0, distance=20, gaussian_noise=0.0, dropout_prob=0.0),
+        spawn_lane_index=None,  # (from node, to node, lane) by node names; None = ('>', '>>', 0) (pgdrive_env.py:77)
         spawn_longitude=5.0,
         spawn_lateral=0.0,
+        destination_node=None,  # node name; None = a seeded random socket of the last block (navigation.py:99-121)
         vehicle_model="default",
         increment_steering=False,
     ),
@@ -112,6 +114,7 @@ class PGDriveVecEnv:
         self.scen_bank = scenario.ScenarioBank(
             sel, seeds, num_agents=1, num_traffic=T, density=c["traffic_density"],
             spawn_longitude=vc["spawn_longitude"], spawn_lateral=vc["spawn_lateral"], vehicle_model=vc["vehicle_model"],
+            spawn_lane_index=vc["spawn_lane_index"], destination_node=vc["destination_node"],
             traffic_mode=c["traffic_mode"], auto_termination=c["auto_termination"], accident_prob=c["accident_prob"],
             random_agent_model=c["random_agent_model"],
             traffic_seeds=np.random.RandomState(c["seed"]).randint(0, scenario.MAX_RAND_INT, len(seeds))

@@ -171,3 +171,31 @@ def test_random_agent_model_type_draw(descs):
         assert abs(float(sp[0]["width"]) - scenario.VEHICLE_TYPES[vt]["width"]) < 1e-6
         seen.add(vt)
     assert len(seen) >= 4
+
+
+def test_spawn_lane_index_and_destination_node_overrides():
+    """vehicle_config.spawn_lane_index / destination_node (pgdrive_env.py:76-80): the ego starts on the named lane and its
+    route ends at the named node (Navigation.set_route, navigation.py:123-148)."""
+    from pgdrive_amd import bank, scenario
+    descs = bank.get_descriptions([1000, 1003])
+    base = scenario.ScenarioBank(descs, [1000, 1003], num_agents=1, num_traffic=4)
+    for m, d in enumerate(descs):
+        # default spawn = lane 0 of '>' -> '>>'
+        lane0 = scenario.resolve_lane_index(d, (">", ">>", 0))
+        assert base.spawns[m * base.V]["lane"] == lane0
+    # spawn on lane 2 of the first road, destination = end of the first block's straight
+    dest = descs[0]["nodes"][4]  # '>>>'
+    sb = scenario.ScenarioBank(descs[:1], [1000], num_agents=1, num_traffic=4, spawn_lane_index=(">", ">>", 2),
+                               destination_node=dest)
+    ego = sb.spawns[0]
+    assert ego["lane"] == scenario.resolve_lane_index(descs[0], (">", ">>", 2))
+    n = int(ego["n_ckpt"])
+    assert descs[0]["nodes"][int(ego["ckpt"][n - 1])] == dest
+    # lateral position: lane 2 is two lane widths to the right of lane 0
+    e0 = base.spawns[0]
+    assert abs(np.hypot(ego["x"] - e0["x"], ego["y"] - e0["y"]) - 2 * descs[0]["lane_width"]) < 1e-4
+    import pytest
+    with pytest.raises(KeyError):
+        scenario.ScenarioBank(descs[:1], [1000], num_agents=1, num_traffic=4, spawn_lane_index=(">", ">>", 7))
+    with pytest.raises(KeyError):
+        scenario.ScenarioBank(descs[:1], [1000], num_agents=1, num_traffic=4, destination_node="nowhere")
