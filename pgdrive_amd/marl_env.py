@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _abi, bank, mapdata, scenario
 from .spaces import Box, Dict
-from .vec_env import merge_config
+from .vec_env import merge_config, strip_reference_only_keys
 
 # MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG + MARoundaboutConfig (multi_agent_pgdrive.py:12-55, marl_inout_roundabout.py:15-28)
 MA_DEFAULT_CONFIG = dict(
@@ -60,7 +60,9 @@ class MultiAgentRoundaboutVecEnv:
         return mapgen.generate_ma_roundabout(mc["lane_num"], mc["lane_width"], mc["exit_length"])
 
     def __init__(self, config=None):
-        self.config = c = merge_config(self.DEFAULTS, config)
+        config = {k: v for k, v in (config or {}).items() if k != "is_multi_agent"}  # always True here (multi_agent_pgdrive.py:14)
+        self.config = c = merge_config(self.DEFAULTS, strip_reference_only_keys(
+            config, keep=("num_agents", "allow_respawn", "delay_done")))
         lid = c["vehicle_config"]["lidar"]
         sd, ld = c["vehicle_config"]["side_detector"], c["vehicle_config"]["lane_line_detector"]
         if not 0 <= lid["num_others"] <= 16:

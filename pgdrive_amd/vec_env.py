@@ -41,6 +41,8 @@ DEFAULT_CONFIG = dict(
         lidar=dict(num_lasers=240, distance=50, num_others=4, gaussian_noise=0.0, dropout_prob=0.0),
         side_detector=dict(num_lasers=0, distance=50, gaussian_noise=0.0, dropout_prob=0.0),
         lane_line_detector=dict(num_lasers=0, distance=20, gaussian_noise=0.0, dropout_prob=0.0),
+        action_check=False,  # step() asserts that the actions lie in the action space (base_vehicle.py:231-236)
+        enable_reverse=False,  # negative throttle drives backwards instead of braking (base_vehicle.py:370-373)
         spawn_lane_index=None,  # (from node, to node, lane) by node names; None = ('>', '>>', 0) (pgdrive_env.py:77)
         spawn_longitude=5.0,
         spawn_lateral=0.0,
@@ -64,6 +66,65 @@ DEFAULT_CONFIG = dict(
 )
 
 
+# Reference config keys this engine does not act on (BASE_DEFAULT_CONFIG base_env.py:19-90, PGDriveEnv_DEFAULT_CONFIG
+# pgdrive_env.py:22-109), so that a config written for the reference can be passed unchanged.
+# VISUAL: rendering / window / camera / debugging switches without any effect on what step() returns: dropped.
+VISUAL_KEYS = {
+    "debug", "fast", "cull_scene", "controller", "use_chase_camera_follow_lane", "camera_height", "camera_dist",
+    "prefer_track_agent", "draw_map_resolution", "top_down_camera_initial_x", "top_down_camera_initial_y",
+    "top_down_camera_initial_z", "window_size", "show_fps", "global_light", "onscreen_message", "debug_physics_world",
+    "debug_static_world", "headless_machine_render", "pstats", "max_distance", "rgb_clip", "_disable_detector_mask",
+    "load_map_from_json", "_load_map_from_json", "save_level",
+    # unused upstream (no reader in the reference's reward function)
+    "acceleration_penalty", "low_speed_penalty", "general_penalty",
+}
+VISUAL_VEHICLE_KEYS = {
+    "show_navi_mark", "random_navi_mark_color", "show_dest_mark", "show_line_to_dest", "am_i_the_special_one", "show_lidar",
+    "show_side_detector", "show_lane_line_detector", "mini_map", "rgb_camera", "depth_camera", "image_source", "random_color",
+}
+# NEUTRAL: features outside the step path (rendering, image observations, manual / scripted ego control, recording); the
+# neutral value is accepted, anything else is refused by name instead of being silently ignored.
+NEUTRAL_KEYS = {
+    "use_render": False, "manual_control": False, "offscreen_render": False, "use_topdown": False, "use_saver": False,
+    "record_episode": False, "_debug_crash_object": False, "IDM_agent": False, "is_multi_agent": False, "num_agents": 1,
+    "allow_respawn": False, "delay_done": 0, "gaussian_noise": 0.0, "dropout_prob": 0.0,
+}
+# overtake_stat: BaseVehicle._update_overtake_stat calls Lidar.get_surrounding_vehicles() without its argument in this
+# version of the reference (base_vehicle.py:700-703, lidar.py:45-53): the switch cannot be turned on upstream either
+NEUTRAL_VEHICLE_KEYS = {"extra_action_dim": 0, "overtake_stat": False}
+
+
+def strip_reference_only_keys(user, keep=()):
+    """Drops the VISUAL keys and the NEUTRAL keys at their neutral value; raises NotImplementedError for a NEUTRAL key
+    that asks for a feature this engine does not have."""
+    if not user:
+        return user
+    out = {}
+    for k, v in user.items():
+        if k in VISUAL_KEYS:
+            continue
+        if k in NEUTRAL_KEYS and k not in keep:
+            if v != NEUTRAL_KEYS[k] and not (v is None and NEUTRAL_KEYS[k] is False):
+                raise NotImplementedError("config['%s'] = %r: outside the step path this engine implements (only %r is "
+                                          "accepted); see DESIGN.md section 8" % (k, v, NEUTRAL_KEYS[k]))
+            continue
+        if k == "vehicle_config" and isinstance(v, dict):
+            vc = {}
+            for kk, vv in v.items():
+                if kk in VISUAL_VEHICLE_KEYS:
+                    continue
+                if kk in NEUTRAL_VEHICLE_KEYS:
+                    if vv != NEUTRAL_VEHICLE_KEYS[kk]:
+                        raise NotImplementedError("config['vehicle_config']['%s'] = %r is not supported (only %r)" % (
+                            kk, vv, NEUTRAL_VEHICLE_KEYS[kk]))
+                    continue
+                vc[kk] = vv
+            out[k] = vc
+            continue
+        out[k] = v
+    return out
+
+
 def merge_config(default, user, path=""):
     """Nested update that rejects unknown keys (utils/config.py:115-125)."""
     out = copy.deepcopy(default)
@@ -81,7 +142,7 @@ def merge_config(default, user, path=""):
 class PGDriveVecEnv:
     """N independent PGDrive environments stepped by one HIP launch pair per step."""
     def __init__(self, config=None):
-        self.config = merge_config(DEFAULT_CONFIG, config)
+        self.config = merge_config(DEFAULT_CONFIG, strip_reference_only_keys(config))
         c = self.config
         vc = c["vehicle_config"]
         # (the noise keys of the side / lane-line detectors exist upstream but are never read: only the lidar cloud is
@@ -134,7 +195,7 @@ class PGDriveVecEnv:
             lane_line_lasers=ld["num_lasers"] if ld["distance"] > 0 else 0, lane_line_dist=ld["distance"],
             discrete_action=c["discrete_action"], discrete_steering_dim=c["discrete_steering_dim"],
             discrete_throttle_dim=c["discrete_throttle_dim"], increment_steering=vc["increment_steering"],
-            safe_rl_env=c["safe_rl_env"], random_agent_model=c["random_agent_model"],
+            safe_rl_env=c["safe_rl_env"], random_agent_model=c["random_agent_model"], enable_reverse=vc["enable_reverse"],
             lidar_gaussian_noise=lid["gaussian_noise"], lidar_dropout_prob=lid["dropout_prob"]
         )
         from .engine import Engine
@@ -161,6 +222,14 @@ class PGDriveVecEnv:
 
     def step(self, actions):
         """actions: cuda float32 tensor [N, 2] -> (obs [N,D], reward [N], done [N] uint8, flags [N] int32) on the GPU."""
+        if self.config["vehicle_config"]["action_check"]:  # opt-in: costs a device round trip
+            a = actions.reshape(self.num_envs, 2)
+            if self.config["discrete_action"]:
+                hi = a.new_tensor([self.config["discrete_steering_dim"] - 1, self.config["discrete_throttle_dim"] - 1])
+                ok = bool(((a >= 0) & (a <= hi) & (a == a.round())).all())
+            else:
+                ok = bool(((a >= -1.0) & (a <= 1.0)).all())
+            assert ok, "Input actions are not compatible with action space {}!".format(self.single_action_space)
         obs, rew, done, flags = self.engine.step(actions.contiguous().view(self.num_envs, 1, 2))
         return obs.view(self.num_envs, self.obs_dim), rew.view(-1), done.view(-1), flags.view(-1)
 

@@ -101,3 +101,24 @@ def test_lidar_noise_and_dropout_statistics(descs):
     assert not np.array_equal(c, b)  # a new step draws afresh
     clean.close()
     noisy.close()
+
+
+def test_reference_config_keys_are_accepted_or_refused_by_name():
+    """A config written for the reference passes: visual / debugging keys are dropped, out-of-scope features are accepted at
+    their neutral value and refused by name otherwise; unknown keys still raise KeyError (utils/config.py:115-125)."""
+    import pytest
+    from pgdrive_amd.vec_env import DEFAULT_CONFIG, merge_config, strip_reference_only_keys
+    ref_style = dict(
+        start_seed=5, environment_num=3, use_render=False, manual_control=False, window_size=(1200, 900), camera_height=1.8,
+        pstats=False, load_map_from_json=True, use_topdown=False, rgb_clip=True, general_penalty=0.0, num_agents=1,
+        vehicle_config=dict(show_navi_mark=True, show_lidar=False, rgb_camera=(84, 84), overtake_stat=False, extra_action_dim=0,
+                            lidar=dict(num_lasers=120)), traffic_density=0.2)
+    c = merge_config(DEFAULT_CONFIG, strip_reference_only_keys(ref_style))
+    assert c["start_seed"] == 5 and c["traffic_density"] == 0.2 and c["vehicle_config"]["lidar"]["num_lasers"] == 120
+    assert c["vehicle_config"]["lidar"]["distance"] == 50 and "use_render" not in c and "show_lidar" not in c["vehicle_config"]
+    for bad in (dict(use_render=True), dict(use_topdown=True), dict(manual_control=True), dict(IDM_agent=True),
+                dict(vehicle_config=dict(overtake_stat=True)), dict(num_agents=4)):
+        with pytest.raises(NotImplementedError):
+            strip_reference_only_keys(bad)
+    with pytest.raises(KeyError):
+        merge_config(DEFAULT_CONFIG, strip_reference_only_keys(dict(not_a_key=1)))
