@@ -40,6 +40,7 @@ class PGDriveEnv:
         self.episode_steps = 0
         self.episode_reward = 0.0
         self._done = False
+        self._last_energy = 0.0
         import torch
         self._torch = torch
 
@@ -49,6 +50,7 @@ class PGDriveEnv:
         self.episode_steps = 0
         self.episode_reward = 0.0
         self._done = False
+        self._last_energy = 0.0
         return obs[0].cpu().numpy()
 
     def step(self, action):
@@ -64,11 +66,17 @@ class PGDriveEnv:
         f, i, _ = self.vec.engine.get_state()
         info = {k: bool(np.asarray(v).reshape(-1)[0]) for k, v in self.vec.info_from_flags(np.array([fl])).items()}
         cost = float(self.vec.cost_from_flags(np.array([fl]))[0])  # cost_function (pgdrive_env.py:197-207)
+        energy = float(f[_abi.SF["ENERGY"], 0, 0])
+        raw = np.asarray(action, dtype=np.float64).reshape(-1)
+        # the keys of BaseVehicle.after_step (base_vehicle.py:255-273), _preprocess_action (:231-236), reward / cost / done
+        # functions (pgdrive_env.py:162-258) and _get_step_return (base_env.py:303-344)
         info.update(
-            cost=cost, velocity=float(f[_abi.SF["SPEED"], 0, 0] * 3.6), steering=float(f[_abi.SF["STEER"], 0, 0]),
+            cost=cost, velocity=abs(float(f[_abi.SF["SPEED"], 0, 0])) * 3.6, steering=float(f[_abi.SF["STEER"], 0, 0]),
             acceleration=float(f[_abi.SF["THROTTLE"], 0, 0]), step_reward=r, episode_reward=self.episode_reward,
-            episode_length=self.episode_steps, episode_energy=float(f[_abi.SF["ENERGY"], 0, 0]),
+            episode_length=self.episode_steps, episode_energy=energy, step_energy=energy - self._last_energy,
+            raw_action=(float(raw[0]), float(raw[1])), overtake_vehicle_num=0,  # overtake_stat cannot be on (vec_env.py)
         )
+        self._last_energy = energy
         return obs[0].cpu().numpy(), r, d, info
 
     def seed(self, seed=None):

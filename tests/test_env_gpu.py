@@ -25,8 +25,10 @@ def test_single_env_protocol():
             if done:
                 break
         for k in ("cost", "velocity", "steering", "acceleration", "step_reward", "crash_vehicle", "out_of_road",
-                  "arrive_dest"):
-            assert k in info
+                  "arrive_dest", "crash_object", "crash_building", "crash", "max_step", "episode_reward", "episode_length",
+                  "step_energy", "episode_energy", "raw_action", "overtake_vehicle_num"):
+            assert k in info  # the reference's step-info keys (base_vehicle.py:255-273, base_env.py:303-344)
+        assert info["raw_action"] == (0.0, 1.0) and info["step_energy"] >= 0.0 and info["episode_length"] == t + 1
         assert done and (info["out_of_road"] or info["crash_vehicle"] or info["arrive_dest"])
         if info["out_of_road"]:
             assert r == -5.0 and info["cost"] == 1.0  # test_reward_cost_done.py:54-74
