@@ -68,7 +68,8 @@ class MultiAgentRoundaboutVecEnv:
         if not 0 <= lid["num_others"] <= 16:
             raise ValueError("lidar.num_others must be in [0, 16]")
         self.desc = self._generate_map(c["map_config"])
-        self.map_bank = mapdata.MapBank([self.desc], truncate_succ=True)  # no IDM traffic on the multi-agent maps
+        descs = self.desc if isinstance(self.desc, (list, tuple)) else [self.desc]
+        self.map_bank = mapdata.MapBank(list(descs), truncate_succ=True)  # no IDM traffic on the multi-agent maps
         cap = c["max_agents"] or c["num_agents"]
         self.scen_bank = scenario.MarlScenarioBank(self.desc, c["num_agents"], capacity=cap,
                                                    n_variants=c["spawn_variants"], seed=c["seed"], kind=self.MAP_KIND)
@@ -290,3 +291,20 @@ class MultiAgentTollgateEnv(MultiAgentRoundaboutEnv):
 class MultiAgentParkingLotEnv(MultiAgentRoundaboutEnv):
     """Dict protocol on the parking-lot map (marl_parking_lot.py:133-222)."""
     VEC = MultiAgentParkingLotVecEnv
+
+
+class MultiAgentPGDriveVecEnv(MultiAgentRoundaboutVecEnv):
+    """MultiAgentPGDrive itself (multi_agent_pgdrive.py:12-213) batched: the generic multi-agent env over generated PG maps
+    (`start_seed` .. `start_seed + environment_num`), 15 agents spawned on the straight of the first block ('>>' -> '>>>':
+    5 slots x 3 lanes), destinations from Navigation's default rule, respawn into the same slots."""
+    MAP_KIND = "pg"
+    DEFAULTS = dict(MA_DEFAULT_CONFIG, num_agents=15, start_seed=0, environment_num=1, map=3,
+                    map_config=dict(exit_length=50, lane_num=3, lane_width=3.5))
+
+    def _generate_map(self, mc):
+        c = self.config
+        m = c["map"]
+        kw = dict(block_num=m) if isinstance(m, int) else dict(block_seq=m, block_num=None)
+        seeds = range(c["start_seed"], c["start_seed"] + c["environment_num"])
+        return bank.get_descriptions(seeds, mc["lane_num"], mc["lane_width"], mc["exit_length"], **kw)
+

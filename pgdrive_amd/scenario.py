@@ -504,11 +504,17 @@ def tollgate_spawn_roads(desc):
     return [(n.index(">>"), n.index(">>>")), neg_road(desc, n.index("3y0_0_"), n.index("3y0_1_"))]
 
 
+def pg_spawn_roads(desc):
+    """MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG.spawn_roads (multi_agent_pgdrive.py:27): the straight of the first block."""
+    n = desc["nodes"]
+    return [(n.index(">>"), n.index(">>>"))]
+
+
 MARL_SPAWN_ROADS = {"roundabout": roundabout_spawn_roads, "intersection": intersection_spawn_roads,
-                    "bottleneck": bottleneck_spawn_roads, "tollgate": tollgate_spawn_roads}
+                    "bottleneck": bottleneck_spawn_roads, "tollgate": tollgate_spawn_roads, "pg": pg_spawn_roads}
 # destination rule: the roundabout / intersection spawn managers draw a negated spawn road; the bottleneck env keeps the
 # default SpawnManager.update_destination_for (spawn_manager.py:221-225), i.e. Navigation.update's own choice
-MARL_AUTO_DEST = {"bottleneck", "tollgate"}
+MARL_AUTO_DEST = {"bottleneck", "tollgate", "pg"}
 OBJ_BUILDING = 3  # PGD_OBJ_BUILDING
 
 
@@ -551,7 +557,7 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
 
     def auto_dest(c):  # Navigation.update (navigation.py:99-121): last block's socket, first block's on a negative road
         road = desc["roads"][desc["lanes"][c["lane"]]["road"]]
-        return choose_destination(desc, 0, road["frm"], negative=road["negative"])
+        return choose_destination(desc, desc.get("seed", 0) if kind == "pg" else 0, road["frm"], negative=road["negative"])
 
     dests = [None] if auto else [neg_road(desc, *r)[1] for r in spawn_roads]  # end node of the negated spawn road
     P, Dn = len(safe), len(dests)
@@ -664,15 +670,25 @@ def build_parking_scenario(desc, map_index, rng, num_agents, capacity=None, vehi
 class MarlScenarioBank:
     """`n_variants` random initial placements over one multi-agent map (scenarios differ only in spawn choice)."""
     def __init__(self, desc, num_agents, capacity=None, n_variants=16, seed=0, kind="roundabout"):
+        """`desc`: one map description, or a list of them (kind "pg": the generic multi-agent env over several generated
+        maps, `n_variants` placements per map; the respawn table has the same shape on every map)."""
         rng = np.random.RandomState(seed)
         scens, recs = [], []
-        for _ in range(n_variants):
-            if kind == "parking":
-                sc, rc, self.P, self.Dn, self.B = build_parking_scenario(desc, 0, rng, num_agents, capacity)
-            else:
-                sc, rc, self.P, self.Dn, self.B = build_marl_scenario(desc, 0, rng, num_agents, capacity, kind=kind)
-            scens.append(sc)
-            recs.append(rc)
+        descs = desc if isinstance(desc, (list, tuple)) else [desc]
+        shape = None
+        for m, dm in enumerate(descs):
+            for _ in range(n_variants):
+                if kind == "parking":
+                    sc, rc, self.P, self.Dn, self.B = build_parking_scenario(dm, m, rng, num_agents, capacity)
+                else:
+                    sc, rc, self.P, self.Dn, self.B = build_marl_scenario(dm, m, rng, num_agents, capacity, kind=kind)
+                if shape is None:
+                    shape = (self.P, self.Dn, self.B)
+                elif shape != (self.P, self.Dn, self.B):
+                    raise ValueError("maps of one multi-agent bank need equal respawn tables: %r vs %r" % (
+                        shape, (self.P, self.Dn, self.B)))
+                scens.append(sc)
+                recs.append(rc)
         self.scenarios = np.array(scens, dtype=SCEN_DT)
         self.spawns = np.concatenate(recs)
         self.A = capacity or num_agents

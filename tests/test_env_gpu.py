@@ -345,3 +345,25 @@ def test_obs_noise_config():
         assert (env.reset()[-240:] == 1.0).all()
     finally:
         env.close()
+
+
+def test_generic_multi_agent_vec_env():
+    """MultiAgentPGDriveVecEnv: three generated maps, 15 agents, respawn; rows of active slots are valid observations."""
+    import torch
+    from pgdrive_amd import _abi
+    from pgdrive_amd.marl_env import MultiAgentPGDriveVecEnv
+    env = MultiAgentPGDriveVecEnv(dict(num_envs=8, start_seed=10, environment_num=3, horizon=150, is_multi_agent=True,
+                                       use_render=False, camera_height=4))
+    obs = env.reset()
+    assert tuple(obs.shape) == (8, 15, 90)
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    new = 0
+    for t in range(200):
+        a = torch.rand((8, 15, 2), device="cuda", generator=g) * 2 - 1
+        a[..., 1] = a[..., 1].abs()
+        obs, rew, done, fl = env.step(a)
+        new += int(((fl & _abi.F_NEW) != 0).sum().item())
+        assert torch.isfinite(obs).all() and float(obs.min()) >= 0.0 and float(obs.max()) <= 1.0
+    assert new > 8 * 15
+    env.close()
+

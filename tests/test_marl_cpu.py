@@ -176,3 +176,28 @@ def test_neighbour_state_rows_layout():
                 assert hits or others_dying, (e, a, r)
                 checked += bool(hits)
     assert checked > 10
+
+
+def test_generic_multi_agent_scenarios_over_generated_maps():
+    """MultiAgentPGDrive itself (multi_agent_pgdrive.py:12-55): spawn road '>>' -> '>>>' of generated maps = 5 slots x 3 lanes,
+    destinations by Navigation's seeded default, the same respawn-table shape on every map; oracle episode runs."""
+    from oracle import orc
+    descs = bank.get_descriptions([3, 4, 5])
+    sb = scenario.MarlScenarioBank(descs, 15, n_variants=2, seed=1, kind="pg")
+    assert sb.P == 3 and sb.Dn == 1 and sb.B == 0 and len(sb.scenarios) == 6  # respawn only into the safe first slot of a lane
+    assert sorted(set(int(m) for m in sb.scenarios["map"])) == [0, 1, 2]
+    with __import__("pytest").raises(ValueError):
+        scenario.MarlScenarioBank(descs[:1], 16, n_variants=1, kind="pg")  # only 15 slots
+    mb = mapdata.MapBank(descs, truncate_succ=True)
+    n_envs = 6
+    cfg = util.marl_config(n_envs, sb, horizon=200)
+    ora = orc.Oracle(cfg, mb, sb)
+    obs = ora.reset(np.arange(n_envs))
+    assert obs.shape == (n_envs, 15, 18 + 72) and np.isfinite(obs).all()
+    rng = np.random.default_rng(0)
+    new = 0
+    for t in range(260):
+        o, r, d, fl = ora.step(util.marl_actions(rng, n_envs, 15))
+        new += int(((fl & _abi.F_NEW) != 0).sum())
+        assert np.isfinite(o).all() and o.min() >= 0.0 and o.max() <= 1.0
+    assert new > 15 * n_envs  # respawns happened after the initial placement

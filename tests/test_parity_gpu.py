@@ -426,6 +426,11 @@ def test_marl_neighbour_state_rows_parity(kind, num_others):
     test_marl_roundabout_parity(12, 16, kind=kind, num_others=num_others, others_state=True)
 
 
+def test_marl_generic_pg_maps_parity():
+    """MultiAgentPGDrive itself (multi_agent_pgdrive.py:12-213): 15 agents on the first straight of four generated maps."""
+    test_marl_roundabout_parity(15, 15, kind="pg")
+
+
 def test_marl_intersection_parity():
     """MultiAgentIntersectionEnv (envs/marl_envs/marl_intersection.py): 4-way intersection with u-turns, 30 agents."""
     test_marl_roundabout_parity(30, 30, kind="intersection")

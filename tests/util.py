@@ -26,6 +26,13 @@ def round_state_f32(f):
 
 def make_marl_banks(num_agents=8, n_variants=8, seed=1, capacity=None, kind="roundabout"):
     from pgdrive_amd import mapgen
+    if kind == "pg":  # the generic MultiAgentPGDrive over generated maps (multi_agent_pgdrive.py:12-55)
+        from pgdrive_amd import bank
+        d = bank.get_descriptions([3, 4, 5, 6])
+        mb = mapdata.MapBank(d, truncate_succ=True)
+        sb = scenario.MarlScenarioBank(d, num_agents=num_agents, capacity=capacity, n_variants=max(1, n_variants // 4), seed=seed,
+                                       kind=kind)
+        return d, mb, sb
     d = dict(roundabout=mapgen.generate_ma_roundabout, intersection=mapgen.generate_ma_intersection,
              bottleneck=mapgen.generate_ma_bottleneck, tollgate=mapgen.generate_ma_tollgate,
              parking=mapgen.generate_ma_parking_lot)[kind]()
