@@ -308,3 +308,7 @@ class MultiAgentPGDriveVecEnv(MultiAgentRoundaboutVecEnv):
         seeds = range(c["start_seed"], c["start_seed"] + c["environment_num"])
         return bank.get_descriptions(seeds, mc["lane_num"], mc["lane_width"], mc["exit_length"], **kw)
 
+
+class MultiAgentPGDrive(MultiAgentRoundaboutEnv):
+    """Dict protocol of the generic multi-agent env (multi_agent_pgdrive.py:58-213)."""
+    VEC = MultiAgentPGDriveVecEnv
