@@ -10,9 +10,12 @@ def __getattr__(name):
     if name == "PGDriveVecEnv":
         from .vec_env import PGDriveVecEnv
         return PGDriveVecEnv
-    if name in ("PGDriveEnv", "make"):
+    if name in ("PGDriveEnv", "SafePGDriveEnv", "make"):
         from . import env
         return getattr(env, name)
+    if name.startswith("MultiAgent"):  # MultiAgent{Roundabout,Intersection,Bottleneck,Tollgate,ParkingLot}[Vec]Env, MultiAgentPGDrive[VecEnv]
+        from . import marl_env
+        return getattr(marl_env, name)
     if name == "Engine":
         from .engine import Engine
         return Engine
