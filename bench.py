@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
                     help="c3: single-agent PGDrive-v0 (the metric); c5: multi-agent roundabout, --agents agents per env")
     ap.add_argument("--agents", type=int, default=8)
+    ap.add_argument("--engines", type=int, default=1,
+                    help="E independent engines of --envs environments each, on their own streams, stepped round-robin "
+                         "(asynchronous vector-env groups): consecutive steps of different engines overlap on the GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     args = ap.parse_args()
 
@@ -160,6 +163,14 @@ def main():
     eng = Engine(cfg, mb, sb, device=local_rank)
     D = eng.D
     eng.reset((np.arange(N) + rank * N) % n_scen)
+    extra = []  # --engines E: E - 1 more engines with their own streams, seeds and scenario offsets
+    for j in range(1, max(1, args.engines)):
+        import copy
+        cfg_j = copy.copy(cfg)
+        cfg_j.seed = cfg.seed + 1000 * j
+        ej = Engine(cfg_j, mb, sb, device=local_rank)
+        ej.reset((np.arange(N) + (rank * args.engines + j) * N) % n_scen)
+        extra.append(ej)
 
     rng = np.random.default_rng(rank)  # rank 0 == default_rng(0)
     CYC = 64
@@ -184,6 +195,9 @@ def main():
     def one_step(k):
         if not gather:
             eng.step(actions[k % CYC])
+            for j, ej in enumerate(extra):  # each engine enqueues on its own stream: no ordering between engines
+                with torch.cuda.stream(ej.stream):
+                    ej.step(actions[(k + 7 * (j + 1)) % CYC])
             return
         b = k % 2
         if pending[b] is not None:
@@ -230,7 +244,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        total_env_steps = float(N) * world * args.steps
+        total_env_steps = float(N) * world * args.steps * max(1, args.engines)
         value = total_env_steps / elapsed
         b_step, b_obs, b_fused = algorithmic_bytes(A, args.traffic, D)
         fused = prof["k_observe_ms"] == 0.0  # pgd_step ran the observation inside k_step (one env per wave)
@@ -252,7 +266,11 @@ def main():
                 if args.workload == "c3" else
                 ("C5: %d envs/GPU x %d agents, multi-agent roundabout, 72 beams x 40 m, %s actions, respawn, auto-reset; "
                  "agent-steps/s = value x %d" % (N, A, args.actions, A)),
-                "envs_per_gpu": N, "global_envs": N * world, "obs_dim": D,
+                **({"note": "%d independent engines x %d envs on their own streams, stepped round-robin: consecutive steps "
+                            "of different engines overlap (asynchronous vector-env groups)" % (args.engines, N)}
+                   if args.engines > 1 else {}),
+                "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
+                "engines_per_gpu": max(1, args.engines),
                 "parallelism": "env-sharded dp%d%s" % (world, " + 1 RCCL all_gather(obs,reward,done)/step, double-buffered" if gather else ", no data-path collective"),
             },
             "roofline": {
