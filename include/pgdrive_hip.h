@@ -267,6 +267,10 @@ int pgd_profile_begin(pgd_handle h, int capacity);
 int pgd_profile_begin_strided(pgd_handle h, int capacity, int stride);
 int pgd_profile_end(pgd_handle h, float* k_step_ms, float* k_observe_ms, int* count);
 
+/* Move the engine to another HIP stream (e.g. the caller's current framework stream, so that a step is ordered like any
+ * other op of that stream and needs no events).  Work already enqueued on the previous stream is ordered before anything
+ * enqueued on the new one.  The engine never owns `hip_stream`; NULL is the device's default stream. */
+int pgd_set_stream(pgd_handle h, void* hip_stream);
 int pgd_sync(pgd_handle h);
 int pgd_destroy(pgd_handle h);
 const char* pgd_version(void);

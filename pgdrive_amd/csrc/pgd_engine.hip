@@ -642,6 +642,7 @@ struct pgd_engine {
   int device;
   hipStream_t stream;
   bool own_stream;
+  hipStream_t retired;  // the engine's own stream after pgd_set_stream moved it away
   hipEvent_t ev0, ev1;
   bool ev_valid;
   pgd_map* maps; pgd_lane* lanes; pgd_road* roads; pgd_box* boxes; int32_t* cell_start; int32_t* cell_items;
@@ -1082,6 +1083,18 @@ int pgd_debug_phase_cycles(pgd_handle h, unsigned long long* out64, int reset) {
 }
 #endif
 
+int pgd_set_stream(pgd_handle h, void* hip_stream) {
+  if (!h) return PGD_ERR_ARG;
+  hipStream_t ns = (hipStream_t)hip_stream;  // null = the device's default stream
+  if (ns == h->stream) return PGD_OK;
+  HIPCHK(hipEventRecord(h->ev0, h->stream));  // everything enqueued so far happens before the first op on the new stream
+  HIPCHK(hipStreamWaitEvent(ns, h->ev0, 0));
+  h->ev_valid = false;
+  if (h->own_stream) { h->retired = h->stream; h->own_stream = false; }  // destroyed with the engine
+  h->stream = ns;
+  return PGD_OK;
+}
+
 int pgd_sync(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1104,6 +1117,7 @@ int pgd_destroy(pgd_handle h) {
   delete h->h_maps;
   delete h->h_scen;
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  if (h->retired) (void)hipStreamDestroy(h->retired);
   free(h);
   return PGD_OK;
 }

@@ -29,6 +29,7 @@ _SIGS = {
     "pgd_profile_begin_strided": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pgd_enable_step_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pgd_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "pgd_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pgd_sync": (C.c_int, [C.c_void_p]),
     "pgd_destroy": (C.c_int, [C.c_void_p]),
     "pgd_version": (C.c_char_p, []),
@@ -109,7 +110,7 @@ class Engine:
         self.reward = torch.zeros((self.N, self.A), dtype=torch.float32, device=dev)
         self.done = torch.zeros((self.N, self.A), dtype=torch.uint8, device=dev)
         self.flags = torch.zeros((self.N, self.A), dtype=torch.int32, device=dev)
-        self._ev_in, self._ev_out = torch.cuda.Event(), torch.cuda.Event()
+        self._bound_stream = self.stream.cuda_stream  # the stream pgd_create was given
         torch.cuda.synchronize(dev)
 
     # -- reference surface ------------------------------------------------------------------------------------------
@@ -136,20 +137,18 @@ class Engine:
         assert actions.is_cuda and actions.dtype == self.torch.float32 and actions.is_contiguous()
         assert actions.numel() == self.N * self.A * 2
         obs, reward, done, flags = out if out is not None else (self.obs, self.reward, self.done, self.flags)
-        cur = self.torch.cuda.current_stream(self.device)
-        foreign = cur != self.stream
-        if foreign:  # order the engine stream after the caller's stream (persistent events: no allocation per step)
-            self._ev_in.record(cur)
-            self.stream.wait_event(self._ev_in)
+        # the engine follows the caller's current stream (like a torch op): no events, no cross-stream waits per step;
+        # pgd_set_stream orders the hand-over when the stream changes
+        cur = self.torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self._bound_stream:
+            _chk(self.L.pgd_set_stream(self.h, C.c_void_p(cur)), "pgd_set_stream")
+            self._bound_stream = cur
         _chk(
             self.L.pgd_step(
                 self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()) if want_obs else None,
                 C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(flags.data_ptr())
             ), "pgd_step"
         )
-        if foreign:
-            self._ev_out.record(self.stream)
-            cur.wait_event(self._ev_out)
         return obs, reward, done, flags
 
     def observe(self):
