@@ -111,6 +111,7 @@ class Engine:
         self.done = torch.zeros((self.N, self.A), dtype=torch.uint8, device=dev)
         self.flags = torch.zeros((self.N, self.A), dtype=torch.int32, device=dev)
         self._bound_stream = self.stream.cuda_stream  # the stream pgd_create was given
+        self._own_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in (self.obs, self.reward, self.done, self.flags))
         torch.cuda.synchronize(dev)
 
     # -- reference surface ------------------------------------------------------------------------------------------
@@ -136,7 +137,13 @@ class Engine:
         `out` = (obs, reward, done, flags) tensors to write instead of the engine's own buffers."""
         assert actions.is_cuda and actions.dtype == self.torch.float32 and actions.is_contiguous()
         assert actions.numel() == self.N * self.A * 2
-        obs, reward, done, flags = out if out is not None else (self.obs, self.reward, self.done, self.flags)
+        if out is None:  # the engine's own output buffers: their addresses never change
+            obs, reward, done, flags = self.obs, self.reward, self.done, self.flags
+            p_obs, p_rew, p_done, p_flags = self._own_ptrs
+        else:
+            obs, reward, done, flags = out
+            p_obs, p_rew, p_done, p_flags = (C.c_void_p(obs.data_ptr()), C.c_void_p(reward.data_ptr()),
+                                             C.c_void_p(done.data_ptr()), C.c_void_p(flags.data_ptr()))
         # the engine follows the caller's current stream (like a torch op): no events, no cross-stream waits per step;
         # pgd_set_stream orders the hand-over when the stream changes
         cur = self.torch.cuda.current_stream(self.device).cuda_stream
@@ -144,10 +151,8 @@ class Engine:
             _chk(self.L.pgd_set_stream(self.h, C.c_void_p(cur)), "pgd_set_stream")
             self._bound_stream = cur
         _chk(
-            self.L.pgd_step(
-                self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()) if want_obs else None,
-                C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(flags.data_ptr())
-            ), "pgd_step"
+            self.L.pgd_step(self.h, C.c_void_p(actions.data_ptr()), p_obs if want_obs else None, p_rew, p_done, p_flags),
+            "pgd_step"
         )
         return obs, reward, done, flags
 
