@@ -660,3 +660,43 @@ def test_record_cache_matches_plain_records(descs):
         n_done += int(ga[2].sum().item())
     print("record cache: episodes ended", n_done, "waiting-traffic rows seen", n_pending_rows)
     assert n_done > 50 and n_pending_rows > 10000
+
+
+def test_config_combinations_fuzz(descs):
+    """Random combinations of every engine switch (action modes, detector fans, noise, objects, traffic modes, horizon,
+    Safe env, random_agent_model ...), 20 short teacher-forced runs against the oracle.  (240 such combinations were run once
+    with tools-style seeds 1-4: clean apart from the IDM 30 m tie of profiles/r01_parity_campaign.md at density 0.3.)"""
+    master = np.random.default_rng(20260928)
+    for trial in range(20):
+        r = master
+        kw = dict(
+            num_traffic=int(r.choice([0, 5, 16])), num_lasers=int(r.choice([0, 30, 72, 240])), num_others=int(r.choice([0, 2, 4])),
+            side_lasers=int(r.choice([0, 0, 2, 7])), side_dist=50.0, lane_line_lasers=int(r.choice([0, 0, 4])),
+            lane_line_dist=20.0, discrete_action=bool(r.integers(2)), increment_steering=bool(r.integers(2)),
+            horizon=int(r.choice([0, 0, 40])), safe_rl_env=bool(r.integers(2)), random_agent_model=bool(r.integers(2)),
+            traffic_mode=str(r.choice(["trigger", "respawn", "hybrid"])), auto_termination=bool(r.integers(2)),
+            accident_prob=float(r.choice([0.0, 0.0, 0.8])), density=float(r.choice([0.05, 0.1])),
+            lidar_gaussian_noise=float(r.choice([0.0, 0.0, 0.02])), lidar_dropout_prob=float(r.choice([0.0, 0.0, 0.05])),
+            seed=int(r.integers(1000)))
+        if kw["num_traffic"] == 0:
+            kw["accident_prob"] = 0.0
+        if kw["num_lasers"] == 0:
+            kw.update(num_others=0, lidar_gaussian_noise=0.0, lidar_dropout_prob=0.0)
+        n_envs = 32
+        torch, eng, ora, cfg = _engines(descs, n_envs, n_maps=8, **kw)
+        ids = np.arange(n_envs) % 8
+        o0 = ora.reset(ids)
+        g0 = eng.reset(ids).cpu().numpy()
+        assert np.abs(g0 - o0).max() < OBS_TOL, kw
+        rng = np.random.default_rng(trial)
+        st = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
+        for t in range(100):
+            act = rng.integers(0, 5, size=(n_envs, 1, 2)).astype(np.float32) if kw["discrete_action"] else \
+                util.driving_actions(rng, n_envs)
+            _compare_step(torch, eng, ora, act, st)
+            f, i, ei = ora.get_state()
+            f32 = util.round_state_f32(f)
+            ora.set_state(f32, i, ei)
+            eng.set_state(f32, i, ei)
+        assert st["obs"] < OBS_TOL and st["rew"] < REW_TOL and st["flag_mismatch"] <= 2, (kw, st)
+        eng.close()
