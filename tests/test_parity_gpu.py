@@ -58,11 +58,19 @@ def _compare_step(torch, eng, ora, act, stats):
         fan = np.zeros(d.shape[1], dtype=bool)  # ray-cast columns: side fan, lane-line fan, lidar
         fan[:ks] = True
         fan[(ks or 2) + 6:(ks or 2) + 6 + km] = True
+        if eng.cfg.marl_flags & _abi.MA_OTHERS_STATE:  # the neighbours' state vectors carry their own detector fans
+            toll = bool(eng.cfg.marl_flags & _abi.MA_TOLLGATE)
+            sl = (ks or 2) + 6 + km + (2 if eng.cfg.random_agent_model else 0) + (0 if toll else 10)
+            for r_ in range(eng.cfg.num_others):
+                off = sl + r_ * sl
+                fan[off:off + ks] = True
+                fan[off + (ks or 2) + 6:off + (ks or 2) + 6 + km] = True
         if nl:
             fan[-nl:] = True
         stats["obs"] = max(stats["obs"], float(d[:, ~fan].max()))
         if ks + km:  # same treatment as the lidar beams below, plus origin-on-a-line-edge flips
-            beams = d[:, fan][:, :ks + km]
+            n_det = int(fan.sum()) - (nl if nl else 0)
+            beams = d[:, fan][:, :n_det]
             graze = beams > OBS_TOL
             stats["det_beams"] = stats.get("det_beams", 0) + beams.size
             stats["det_grazing"] = stats.get("det_grazing", 0) + int(graze.sum())
@@ -699,4 +707,52 @@ def test_config_combinations_fuzz(descs):
             ora.set_state(f32, i, ei)
             eng.set_state(f32, i, ei)
         assert st["obs"] < OBS_TOL and st["rew"] < REW_TOL and st["flag_mismatch"] <= 2, (kw, st)
+        eng.close()
+
+
+def test_marl_config_combinations_fuzz():
+    """Random combinations of the multi-agent switches (map kind, agent count / capacity, crash_done, out_of_road_done,
+    allow_respawn, delay_done, horizon, neighbour-state rows, detector fans), 16 teacher-forced runs against the oracle.
+    (120 such combinations were run once: clean apart from ties of the kind profiles/r01_parity_campaign.md lists -- two
+    neighbours at the same distance ranked by the last bit, the engine-force cut-off exactly at max_speed.)"""
+    import torch
+    from oracle import orc
+    from pgdrive_amd.engine import Engine
+    r = np.random.default_rng(1)
+    for trial in range(16):
+        kind = str(r.choice(["roundabout", "intersection", "bottleneck", "parking", "pg"]))
+        na = int(r.choice([4, 8, 12]))
+        cap = int(r.choice([na, na + 4]))
+        if kind == "pg":
+            cap = min(cap, 15)
+            na = min(na, cap)
+        if kind == "parking":
+            na = min(na, 10)
+        no = int(r.choice([0, 0, 3]))
+        kw = dict(crash_done=bool(r.integers(2)), out_of_road_done=bool(r.integers(2)), allow_respawn=bool(r.integers(4) > 0),
+                  delay_done=int(r.choice([0, 5, 25])), horizon=int(r.choice([60, 150, 1000])), num_others=no,
+                  others_state=no > 0, side_lasers=int(r.choice([0, 0, 4])), side_dist=50.0,
+                  lane_line_lasers=int(r.choice([0, 0, 4])), lane_line_dist=20.0, seed=int(r.integers(1000)))
+        if kind == "bottleneck":
+            kw.update(plain_reward=True, cross_yellow_line_done=bool(r.integers(2)))
+        if kind == "parking":
+            kw.update(parking=True, enable_reverse=True)
+        d, mb, sb = util.make_marl_banks(num_agents=na, capacity=cap, kind=kind)
+        n_envs = 24
+        cfg = util.marl_config(n_envs, sb, **kw)
+        eng, ora = Engine(cfg, mb, sb), orc.Oracle(cfg, mb, sb)
+        ids = np.arange(n_envs) % len(sb.scenarios)
+        assert np.abs(eng.reset(ids).cpu().numpy() - ora.reset(ids)).max() < OBS_TOL
+        rng = np.random.default_rng(trial)
+        st = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
+        im = 0
+        for t in range(200):
+            _compare_step(torch, eng, ora, util.marl_actions(rng, n_envs, sb.A), st)
+            f, i, ei = ora.get_state()
+            gf, gi, gei = eng.get_state()
+            im += int((gi != i).any(axis=0).sum()) + int((gei != ei).any(axis=0).sum())
+            f32 = util.round_state_f32(f)
+            ora.set_state(f32, i, ei)
+            eng.set_state(f32, i, ei)
+        assert st["obs"] < OBS_TOL and st["rew"] < REW_TOL and st["flag_mismatch"] <= 2 and im <= 2, (kind, na, cap, kw, st, im)
         eng.close()
