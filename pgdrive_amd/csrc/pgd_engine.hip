@@ -1087,8 +1087,13 @@ int pgd_set_stream(pgd_handle h, void* hip_stream) {
   if (!h) return PGD_ERR_ARG;
   hipStream_t ns = (hipStream_t)hip_stream;  // null = the device's default stream
   if (ns == h->stream) return PGD_OK;
-  HIPCHK(hipEventRecord(h->ev0, h->stream));  // everything enqueued so far happens before the first op on the new stream
-  HIPCHK(hipStreamWaitEvent(ns, h->ev0, 0));
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(ns, &cap);
+  if (cap == hipStreamCaptureStatusNone) {
+    HIPCHK(hipEventRecord(h->ev0, h->stream));  // everything enqueued so far happens before the first op on the new stream
+    HIPCHK(hipStreamWaitEvent(ns, h->ev0, 0));
+  }  // a capturing stream (hipGraph capture of policy + step) must not wait on work outside the capture: the caller has
+     // synchronised before starting the capture, as graph capture requires anyway
   h->ev_valid = false;
   if (h->own_stream) { h->retired = h->stream; h->own_stream = false; }  // destroyed with the engine
   h->stream = ns;
