@@ -47,16 +47,17 @@ DEV float ray_grid(const MapView& mv, float px, float py, float dx, float dy, un
 }
 
 
-DEV int get_current_lane(const MapView& mv, const Grp& g, float px, float py, float hx, float hy, int road_cur,
-                         int road_next) {
+// cell_start entry of the grid cell under (px, py); 0 (an empty range) outside the grid
+DEV int cell_entry(const MapView& mv, float px, float py) {
   const pgd_map& m = *mv.m;
   int cx = (int)floorf((px - m.ox) / m.cell), cy = (int)floorf((py - m.oy) / m.cell);
-  int k0 = 0, k1 = 0;
-  if (cx >= 0 && cy >= 0 && cx < m.gx && cy < m.gy) {
-    const int c = mv.cstart[cy * m.gx + cx];
-    k0 = cell_first(c);
-    k1 = cell_mid(c);
-  }
+  return (cx >= 0 && cy >= 0 && cx < m.gx && cy < m.gy) ? mv.cstart[cy * m.gx + cx] : 0;
+}
+
+// `c` = cell_entry(mv, px, py), read by the caller ahead of time
+DEV int get_current_lane(const MapView& mv, const Grp& g, int c, float px, float py, float hx, float hy, int road_cur,
+                         int road_next) {
+  const int k0 = cell_first(c), k1 = cell_mid(c);
   unsigned best_cur = 0xffffffffu, best_next = 0xffffffffu, best_any = 0xffffffffu;
   const int stride = g.SUB;
   constexpr int NB = 3;  // boxes per sub-lane and round: a cell holds 3-9 lane boxes, so one round is the rule
@@ -128,13 +129,30 @@ DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& s
   int road_cur = sp.ckpt_road[r.ck0];
   int road_next = (r.ck0 == r.ck1) ? -1 : sp.ckpt_road[r.ck1];
   PHASE_MARK(16);  // after_step: route roads
-  int lane = get_current_lane(mv, g, r.x, r.y, c, s, road_cur, road_next);
+  // Staying on a straight lane of the current road needs no grid walk.  The surface box of a lane is (length + 0.1) x
+  // (width + 1.2) (base_block.py:396-456), the boxes of a road's lanes overlap by 1.2 m and the first hit in creation order
+  // -- lane index order inside the road -- wins, boxes of the current road before all others.  So the previous lane is the
+  // answer when the vehicle is inside its box, outside the box of the left neighbour (the only earlier box of the road that
+  // can reach it) and heads along it.  Margins of 5 cm keep the decision away from the fp32 rounding of either form.
+  float lon = 0.0f, lat = 0.0f;
+  bool stay = false;
+  const int cell = cell_entry(mv, r.x, r.y);  // in flight together with the lane record below
+  {
+    const pgd_lane& PL = mv.lanes[r.lane];
+    if (PL.dir == 0.0f && PL.road == road_cur) {
+      lane_local(PL, r.x, r.y, lon, lat);
+      const float hw = 0.5f * PL.width;
+      stay = lon >= 0.0f && lon <= PL.length && lat <= hw + 0.55f && lat >= (PL.index > 0 ? 0.65f - hw : -hw - 0.55f) &&
+             PL.bx * c + PL.by * s > 0.0f;
+    }
+  }
+  int lane = r.lane;
+  if (!stay) lane = get_current_lane(mv, g, cell, r.x, r.y, c, s, road_cur, road_next);
   PHASE_MARK(17);  // after_step: get_current_lane
   bool on_lane = lane >= 0;
   if (!on_lane) lane = r.lane;
   r.lane = lane;
-  float lon, lat;
-  lane_local(mv.lanes[lane], r.x, r.y, lon, lat);
+  if (!stay) lane_local(mv.lanes[lane], r.x, r.y, lon, lat);
   lon_out = lon; lat_out = lat;
   update_checkpoints(mv, g, sp, r, lon);
   r.vflags = on_lane ? (r.vflags & ~PGD_F_OFF_LANE) : (r.vflags | PGD_F_OFF_LANE);
