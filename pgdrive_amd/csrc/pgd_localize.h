@@ -129,7 +129,7 @@ DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& s
   int road_cur = sp.ckpt_road[r.ck0];
   int road_next = (r.ck0 == r.ck1) ? -1 : sp.ckpt_road[r.ck1];
   PHASE_MARK(16);  // after_step: route roads
-  // Staying on a straight lane of the current road needs no grid walk.  The surface box of a lane is (length + 0.1) x
+  // Staying on a lane of the current road needs no grid walk.  The surface box of a lane is (length + 0.1) x
   // (width + 1.2) (base_block.py:396-456), the boxes of a road's lanes overlap by 1.2 m and the first hit in creation order
   // -- lane index order inside the road -- wins, boxes of the current road before all others.  So the previous lane is the
   // answer when the vehicle is inside its box, outside the box of the left neighbour (the only earlier box of the road that
@@ -139,11 +139,36 @@ DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& s
   const int cell = cell_entry(mv, r.x, r.y);  // in flight together with the lane record below
   {
     const pgd_lane& PL = mv.lanes[r.lane];
-    if (PL.dir == 0.0f && PL.road == road_cur) {
+    if (PL.road == road_cur) {
       lane_local(PL, r.x, r.y, lon, lat);
       const float hw = 0.5f * PL.width;
-      stay = lon >= 0.0f && lon <= PL.length && lat <= hw + 0.55f && lat >= (PL.index > 0 ? 0.65f - hw : -hw - 0.55f) &&
-             PL.bx * c + PL.by * s > 0.0f;
+      if (PL.dir == 0.0f) {
+        stay = lon >= 0.0f && lon <= PL.length && lat <= hw + 0.55f && lat >= (PL.index > 0 ? 0.65f - hw : -hw - 0.55f) &&
+               PL.bx * c + PL.by * s > 0.0f;
+      } else {
+        // Arc lanes are covered by n = int(length / 4) boxes of 1.3 x the segment length, each centred ON the arc and
+        // turned along the second half of its segment (base_block.py:413-423): within its segment a box axis leaves the arc
+        // by less than seg^2 / (4 R).  With that bound (taken on the innermost radius in play, 10 % and 5 cm of slack) the
+        // same two statements hold: inside an own box, outside every box of the left neighbour -- whose segments may be
+        // longer.  A lane shorter than one segment has no box at all; tight arcs simply take the grid walk.
+        const int n = (int)(PL.length * 0.25f);
+        const float r_in = PL.bx - PL.width - 1.0f;  // PL.bx: radius
+        if (n >= 1 && r_in > 4.0f) {
+          const float seg = PL.length / (float)n;
+          const float dev = seg * seg / (4.0f * r_in) * 1.1f + 0.05f;
+          float lo = -hw - 0.6f + dev;
+          if (PL.index > 0) {
+            const float nl = mv.lanes[r.lane - 1].length;
+            const int nn = (int)(nl * 0.25f);
+            if (nn >= 1) {
+              const float nseg = nl / (float)nn;
+              lo = fmaxf(lo, 0.6f - hw + nseg * nseg / (4.0f * r_in) * 1.1f + 0.05f);
+            }
+          }
+          const float tx = -PL.dir * (r.y - PL.ay), ty = PL.dir * (r.x - PL.ax);  // lane direction at the point (x |radius|)
+          stay = lon >= 0.0f && lon <= PL.length && lat <= hw + 0.6f - dev && lat >= lo && tx * c + ty * s > 0.0f;
+        }
+      }
     }
   }
   int lane = r.lane;
