@@ -112,7 +112,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
 
   PHASE_INIT();
   Veh r;
-  RouteCtx ctx{0, 0, 0, 1, 0, 0.0f, 1.0f};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
+  RouteCtx ctx{0, 0, 0, 1, 0, 0.0f, 1.0f, 0};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
   MapView mv;
   const pgd_spawn* sp = nullptr;
   const pgd_scenario* sc = nullptr;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (s >= A && (r.vflags & PGD_F_OFF_LANE)) r.status = ST_REMOVED;
   }
   if (one_env) {  // line / sidewalk test of each agent by the whole wave (base_vehicle.py:615-644)
-    if (leader && valid && s < A) s_flag[A + s] = acting ? 1 : 0;
+    if (leader && valid && s < A) s_flag[A + s] = (acting && !ctx.clear) ? 1 : 0;  // clear: provably no contact (after_step)
     __syncthreads();
     for (int a = 0; a < A; ++a) {
       if (!s_flag[A + a]) continue;
@@ -780,6 +780,34 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
         const pgd_road& R = roads[maps[m].road_off + L.road];
         if (R.first_lane + L.index != k) return PGD_ERR_ARG;
         L.pad = R.n_lanes;
+        // device-private use of `ex` (the end point is not read on the device): half-width of the strip around a straight
+        // lane's axis that no line / sidewalk box of the map reaches (between 6 m before and after the lane).  The lateral
+        // coordinate is linear over a box, so its extremes sit at the corners; a box with corners on both sides crosses.
+        // A car whose box stays inside that strip touches nothing: k_step then skips the line / sidewalk test.
+        double clear = 0.0;
+        if (L.dir == 0.0f) {
+          clear = 1e9;
+          const pgd_map& M = maps[m];
+          for (int b = 0; b < M.n_boxes && clear > 0.0; ++b) {
+            const pgd_box& B = boxes[M.box_off + b];
+            if (B.kind == PGD_BOX_LANE) continue;
+            double lo_lon = 1e30, hi_lon = -1e30, lo_lat = 1e30, hi_lat = -1e30;
+            for (int q = 0; q < 4; ++q) {
+              const double sl = (q & 1) ? 1.0 : -1.0, sw = (q & 2) ? 1.0 : -1.0;
+              const double px = B.cx + sl * B.hl * B.ux - sw * B.hw * B.uy, py = B.cy + sl * B.hl * B.uy + sw * B.hw * B.ux;
+              const double dx = px - L.ax, dy = py - L.ay;
+              const double lon = dx * L.bx + dy * L.by, lat = dy * L.bx - dx * L.by;
+              lo_lon = std::min(lo_lon, lon); hi_lon = std::max(hi_lon, lon);
+              lo_lat = std::min(lo_lat, lat); hi_lat = std::max(hi_lat, lat);
+            }
+            if (hi_lon < -6.0 || lo_lon > (double)L.length + 6.0) continue;
+            if (lo_lat <= 0.0 && hi_lat >= 0.0) clear = 0.0;
+            else clear = std::min(clear, std::min(std::fabs(lo_lat), std::fabs(hi_lat)));
+          }
+          clear = clear > 1e8 ? 0.0 : std::max(0.0, clear - 0.03);  // 3 cm of slack for the fp32 forms on the device
+        }
+        L.ex = (float)clear;
+        L.ey = 0.0f;
       }
     if ((rc = upload(&h->lanes, dl.data(), n_lanes, h->stream))) return rc;
     std::vector<LaneNav> nav((size_t)(n_lanes > 0 ? n_lanes : 1));

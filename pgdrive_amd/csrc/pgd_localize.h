@@ -229,12 +229,13 @@ struct RouteCtx {
   int next_first;  // first lane of the next checkpoint road (== cur_first on the last road)
   float drive;     // driving_reward * (long_now - long_last) * lateral_factor * positive_road of the step (pgdrive_env.py:209-258)
   float positive;  // +1 / -1: the sign the reference gives the speed reward on a negative road
+  int clear;       // the car's box lies inside the line-free strip of its (straight) lane: no line / sidewalk contact possible
 };
 DEV RouteCtx route_ctx(const MapView& mv, const pgd_spawn& sp, int ck0, int ck1) {
   const int rc = sp.ckpt_road[ck0], rn = sp.ckpt_road[ck1];
   const pgd_road& CR = mv.roads[rc];
   const pgd_road& NR = mv.roads[rn];
-  return RouteCtx{CR.block_id, rc, CR.first_lane, CR.n_lanes, NR.first_lane, 0.0f, 1.0f};
+  return RouteCtx{CR.block_id, rc, CR.first_lane, CR.n_lanes, NR.first_lane, 0.0f, 1.0f, 0};
 }
 
 // BaseVehicle.after_step (base_vehicle.py:255-290).  `with_state_check` = false lets the caller run the line / sidewalk
@@ -245,6 +246,17 @@ DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp&
   update_localization(mv, g, sp, r, lon_v, lat_v);
   if (is_agent) {
     ctx = route_ctx(mv, sp, r.ck0, r.ck1);
+    {
+      // line / sidewalk contacts (base_vehicle.py:615-644) need no grid walk while the car's box stays inside the strip of
+      // its straight lane that no such box reaches (`ex` of the device lane copy, pgd_upload_maps)
+      const pgd_lane& VL = mv.lanes[r.lane];
+      if (VL.dir == 0.0f && VL.ex > 0.0f) {
+        const float ca = fabsf(r.hx * VL.bx + r.hy * VL.by), sa = fabsf(r.hy * VL.bx - r.hx * VL.by);
+        const float hl = 0.5f * sp.length, hw = 0.5f * sp.width;
+        const float e_lat = hw * ca + hl * sa, e_lon = hl * ca + hw * sa;
+        ctx.clear = (fabsf(lat_v) + e_lat <= VL.ex && lon_v - e_lon >= 0.0f && lon_v + e_lon <= VL.length) ? 1 : 0;
+      }
+    }
     unsigned fl = (unsigned)r.vflags;
     fl &= ~(PGD_F_ON_WHITE | PGD_F_ON_YELLOW | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OUT_OF_ROUTE);
     if (with_state_check) fl |= state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sp.length, 0.5f * sp.width});
