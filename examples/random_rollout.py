@@ -2,9 +2,9 @@
 
     python examples/random_rollout.py --envs 32768 --steps 500
 
-The engine step itself takes ~25 us for 4096 envs (bench.py: 165 M env-steps/s); in a Python loop like this one the
+The engine step itself takes ~25 us for 4096 envs (bench.py: 166 M env-steps/s); in a Python loop like this one the
 host-side launch cost of the surrounding torch ops (random actions, the `done` count) dominates at small N, so use a
-large N per GPU -- the step kernel scales to 296 M env-steps/s at 262144 envs.
+large N per GPU -- the step kernel scales to 318 M env-steps/s at 262144 envs.
 """
 import argparse
 import os
