@@ -2,20 +2,31 @@
 """bench.py — env-steps/sec of the batched PGDrive step engine (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 2000 --warmup 200
+    python bench.py --gpus 8 ...                        (spawns the 8 ranks itself when WORLD_SIZE is not set)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One "step" = pgd_step over all local environments: every agent and traffic vehicle advanced 0.1 s + (obs, reward, done)
 written.  Workload = BASELINE config C3: 4096 envs/GPU x (1 ego + 16 IDM traffic slots) x 240 lidar beams, PGDrive-v0
 maps (seeds 1000..1099, env e -> scenario e mod 100), actions uniform(-1,1) from numpy default_rng(0), pre-generated
-on the device, auto-reset on done.  Weak scaling: each rank owns 4096 envs.  Environments are independent, so env.step()
-has no exchange step: ranks share nothing in the timed region (a data-parallel learner consumes its own shard).  `--gather`
-adds the optional learner-side exchange -- one RCCL all_gather of (obs, reward, done) per step over xGMI, double-buffered
--- inside the timed region.
+on the device, auto-reset on done.  Weak scaling: each rank owns 4096 envs.
+
+Steady state.  The first ~1000 steps after a reset are cheaper than the rest (the trigger traffic is still parked), so a
+short run would report an early-episode number.  The bench therefore ALWAYS pre-rolls at least PREROLL_MIN steps before
+the timed region and times at least TIMED_MIN steps, whatever --warmup / --steps say; the JSON line carries the requested
+counts ("steps", "warmup") and the counts actually run ("steps_timed", "warmup_run"); `ms_per_step` and `value` refer to
+the timed steps.  --exact turns the floors off.
+
+N > 1.  Environments are independent: the step itself has no exchange.  The north star adds ONE gather of
+(obs, reward, done) per step over xGMI; both are measured in the same invocation: `value` is WITH the per-step gather
+(pgd_step_packed writes the packed row straight into the rank's slice of the receive buffer, one in-place RCCL
+all_gather_into_tensor per step, double-buffered), `value_replicas` is without it (a data-parallel learner that consumes
+its own shard).  --transport peer uses direct peer writes instead of the RCCL collective (pgdrive_amd/peer.py).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -24,13 +35,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Algorithmic HBM bytes per env-step for this build's record layout (DESIGN.md §5):
+PROF_STRIDE = 16      # k_step launches per HIP-event group
+PREROLL_MIN = 1500    # steps before the timed region (steady-state traffic)
+TIMED_MIN = 2000      # timed steps (>= 64 event groups of PROF_STRIDE launches)
+
+
+# Algorithmic HBM bytes per env-step for this build's record layout (DESIGN.md §4):
 #   state r/w   2 * V * (23 f32 + 7 i32) * 4 B  + env ints 2*5*4
 #   actions 8*A, spawn params read V*48, obs write 4*A*D, reward/done/flags 9*A,
 #   k_observe re-read of 7 floats/vehicle
-PROF_STRIDE = 16
-
-
 def algorithmic_bytes(A, T, D):
     V = A + T
     k_step = 2 * V * (23 + 7) * 4 + 40 + 8 * A + V * 48 + 9 * A
@@ -41,14 +54,16 @@ def algorithmic_bytes(A, T, D):
 
 def load_traffic(N, args):
     """HBM bytes per k_step launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate
-    runs of this same command, profiles/r01_pmc_traffic.json); null when the workload differs from the profiled one."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(p):
-        return None
-    t = json.load(open(p))
-    if (t.get("envs"), t.get("traffic"), t.get("lasers")) != (N, args.traffic, args.lasers):
-        return None
-    return t.get("bytes_per_launch")
+    runs of this same command, newest profiles/r*_pmc_traffic.json whose workload matches); null when none matches."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(p))
+        except Exception:
+            continue
+        if (t.get("envs"), t.get("traffic"), t.get("lasers")) == (N, args.traffic, args.lasers):
+            return t.get("bytes_per_launch"), os.path.basename(p)
+    return None, None
 
 
 def cpu_baseline(descs, args, seconds=10.0):
@@ -98,18 +113,25 @@ def cpu_baseline(descs, args, seconds=10.0):
                 all_cores=allc)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--exact", action="store_true",
+                    help="run exactly --warmup / --steps (no steady-state floors): for plumbing tests and quick A/B runs")
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--traffic", type=int, default=16)
-    ap.add_argument("--lasers", type=int, default=240)
+    ap.add_argument("--lasers", type=int, default=None,
+                    help="lidar beams: default 240 for c3; for c5 72 x 40 m (the reference's multi-agent default) unless given "
+                         "(BASELINE.md C5 is --lasers 240)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true",
-                    help="N>1: add the learner-side exchange, one RCCL all_gather of (obs, reward, done) per step")
-    ap.add_argument("--no-gather", action="store_true", help="(default behaviour; kept for old command lines)")
+    ap.add_argument("--mode", default="both", choices=["both", "gather", "replicas"],
+                    help="N>1: time the step with the per-step gather (value), without it (value_replicas), or both")
+    ap.add_argument("--gather", action="store_true", help="(old flag) same as --mode gather")
+    ap.add_argument("--no-gather", action="store_true", help="(old flag) same as --mode replicas")
+    ap.add_argument("--transport", default="collective", choices=["collective", "peer"],
+                    help="the per-step gather: RCCL all_gather_into_tensor (default) or direct peer writes over HIP IPC")
     ap.add_argument("--actions", default="uniform", choices=["uniform", "straight"],
                     help="uniform(-1,1) (the metric's stream) or drive straight [0,1] with small steering noise (SURVEY 8d)")
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
@@ -119,20 +141,34 @@ def main():
                     help="E independent engines of --envs environments each, on their own streams, stepped round-robin "
                          "(asynchronous vector-env groups): consecutive steps of different engines overlap on the GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
-    args = ap.parse_args()
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="plumbing tests: allow more ranks than GPUs (ranks share devices; needs --backend gloo)")
+    args = ap.parse_args(argv)
+    if args.gather:
+        args.mode = "gather"
+    if args.no_gather:
+        args.mode = "replicas"
+    if args.lasers is None:
+        args.lasers = 240 if args.workload == "c3" else 72
+    return args
 
+
+def run_rank(args, rank, world, local_rank):
     import torch
     import torch.distributed as dist
     from pgdrive_amd import _abi, bank, mapdata, scenario
+    from pgdrive_amd import dist as pdist
     from pgdrive_amd.engine import Engine
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    local_rank = local_rank % torch.cuda.device_count()  # plumbing tests (gloo) may oversubscribe one GPU
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise RuntimeError("bench.py needs a GPU: the step engine has no CPU path")
+    if world > n_dev and not args.oversubscribe:
+        raise RuntimeError("%d ranks but only %d GPUs visible (use --oversubscribe --backend gloo for plumbing tests)" % (world, n_dev))
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -143,14 +179,14 @@ def main():
     if args.workload == "c5":  # BASELINE config 5: multi-agent roundabout (reported next to the metric, never as the metric)
         from pgdrive_amd import mapgen
         A = args.agents
-        args.traffic, args.lasers = 0, 72
+        args.traffic = 0
         descs = [mapgen.generate_ma_roundabout()]
         mb = mapdata.MapBank(descs)
         sb = scenario.MarlScenarioBank(descs[0], num_agents=A, n_variants=16, seed=rank)
-        cfg = _abi.make_config(N, num_agents=A, num_traffic=0, num_lasers=72, num_others=0, lidar_dist=40.0, multi_agent=True,
+        cfg = _abi.make_config(N, num_agents=A, num_traffic=0, num_lasers=args.lasers, num_others=0, lidar_dist=40.0, multi_agent=True,
                                horizon=1000, agent_limit=A, respawn_places=sb.P, respawn_dests=sb.Dn,
                                out_of_road_penalty=10.0, crash_vehicle_penalty=10.0, crash_object_penalty=10.0,
-                               delay_done=25, auto_reset=1, resample_scenario=1, seed=1234 + rank)
+                               delay_done=25, auto_reset=1, resample_scenario=1, seed=1234 + rank, env_base=rank * N)
         n_scen = len(sb.scenarios)
     else:
         A = 1
@@ -158,7 +194,7 @@ def main():
         mb = mapdata.MapBank(descs)
         sb = scenario.ScenarioBank(descs, [d["seed"] for d in descs], num_agents=1, num_traffic=args.traffic)
         cfg = _abi.make_config(N, num_agents=A, num_traffic=args.traffic, num_lasers=args.lasers, auto_reset=1,
-                               seed=1234 + rank)
+                               seed=1234 + rank, env_base=rank * N)
         n_scen = len(descs)
     eng = Engine(cfg, mb, sb, device=local_rank)
     D = eng.D
@@ -182,111 +218,177 @@ def main():
         acts[..., 1] = 1.0
     actions = torch.from_numpy(acts).to(dev)
 
-    gather = world > 1 and args.gather and not args.no_gather
-    if gather:
-        # one exchange per step: obs | reward | done packed into a single fp32 row per env, double-buffered:
-        # the all_gather of step t (RCCL's own stream) overlaps the kernels of step t+1; buffer b is re-used at step t+2
-        # only after its gather has completed
-        bufs = [eng.make_outputs() for _ in range(2)]
-        packs = [torch.empty((N, A * (D + 2)), dtype=torch.float32, device=dev) for _ in range(2)]
-        gathered = [torch.empty((world * N, A * (D + 2)), dtype=torch.float32, device=dev) for _ in range(2)]
-        pending = [None, None]
+    warm = args.warmup if args.exact else max(args.warmup, PREROLL_MIN)
+    timed = args.steps if args.exact else max(args.steps, TIMED_MIN)
+    modes = ["replicas"] if world == 1 else (["gather", "replicas"] if args.mode == "both" else [args.mode])
+    gatherer = None
+    if "gather" in modes:
+        gatherer = pdist.StepGather(torch, dist, N, D, A, device=dev, transport=args.transport, engine_lib=eng.L)
 
-    def one_step(k):
-        if not gather:
-            eng.step(actions[k % CYC])
-            for j, ej in enumerate(extra):  # each engine enqueues on its own stream: no ordering between engines
-                with torch.cuda.stream(ej.stream):
-                    ej.step(actions[(k + 7 * (j + 1)) % CYC])
-            return
-        b = k % 2
-        if pending[b] is not None:
-            pending[b].wait()  # stream-level wait: step k may overwrite what the gather of step k-2 was reading
-        obs, rew, done, flags = eng.step(actions[k % CYC], out=bufs[b])
-        pack = packs[b]
-        pack[:, :A * D] = obs.view(N, A * D)
-        pack[:, A * D:A * D + A] = rew
-        pack[:, A * D + A:] = done.to(torch.float32)
-        pending[b] = dist.all_gather_into_tensor(gathered[b], pack, async_op=True)
+    def step_replica(k):
+        eng.step(actions[k % CYC])
+        for j, ej in enumerate(extra):  # each engine enqueues on its own stream: no ordering between engines
+            with torch.cuda.stream(ej.stream):
+                ej.step(actions[(k + 7 * (j + 1)) % CYC])
 
-    def drain():
-        if gather:
-            for w in pending:
-                if w is not None:
-                    w.wait()
+    def step_gather(k):
+        a = actions[k % CYC]
+        gatherer.step(lambda rows: eng.step_packed(a, rows))
 
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    results = {}
+    counter = 0
     with torch.cuda.stream(eng.stream):
-        for k in range(args.warmup):
-            one_step(k)
-        drain()
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        # HIP events bracket groups of PROF_STRIDE consecutive k_step launches over the whole timed region; the average
-        # launch duration is group time / PROF_STRIDE (two event packets around EVERY launch leave the command processor
-        # idle between back-to-back kernels and slow the thing being measured: 102 -> 125 M env-steps/s without them)
-        eng.profile_begin(args.steps // PROF_STRIDE + 1, stride=PROF_STRIDE)
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            one_step(args.warmup + k)
-        drain()
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        prof = eng.profile_end()
-    elapsed = t1 - t0
+        for k in range(warm):  # pre-roll to steady-state traffic, once, shared by both modes
+            step_replica(counter)
+            counter += 1
+        for mode in modes:
+            one_step = step_gather if mode == "gather" else step_replica
+            for k in range(16 if not args.exact else min(16, args.warmup)):  # the mode's own buffers / communicator warm-up
+                one_step(counter)
+                counter += 1
+            if gatherer is not None:
+                gatherer.drain()
+            fence()
+            # HIP events bracket groups of PROF_STRIDE consecutive k_step launches over the whole timed region; the average
+            # launch duration is group time / PROF_STRIDE (two event packets around EVERY launch leave the command processor
+            # idle between back-to-back kernels and slow the thing being measured)
+            profiled = mode == "replicas"
+            if profiled:
+                eng.profile_begin(timed // PROF_STRIDE + 1, stride=PROF_STRIDE)
+            t0 = time.perf_counter()
+            for k in range(timed):
+                one_step(counter)
+                counter += 1
+            if mode == "gather":
+                gatherer.drain()
+            fence()
+            t1 = time.perf_counter()
+            prof = eng.profile_end() if profiled else None
+            elapsed = t1 - t0
+            if world > 1:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            results[mode] = dict(elapsed=elapsed, prof=prof)
+
+    ranks_ran = world
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        ranks_ran = int(round(t.item()))
 
     if rank == 0:
-        total_env_steps = float(N) * world * args.steps * max(1, args.engines)
-        value = total_env_steps / elapsed
-        b_step, b_obs, b_fused = algorithmic_bytes(A, args.traffic, D)
-        fused = prof["k_observe_ms"] == 0.0  # pgd_step ran the observation inside k_step (one env per wave)
-        if fused:
-            b_step, b_obs = b_fused, 0
-        dom = "k_observe" if prof["k_observe_ms"] >= prof["k_step_ms"] else "k_step"
-        dom_ms = max(prof["k_observe_ms"], prof["k_step_ms"])
-        dom_bytes = (b_obs if dom == "k_observe" else b_step) * N
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        per_step_units = float(N) * world * max(1, args.engines)
+        head = "gather" if "gather" in results else "replicas"
+        elapsed = results[head]["elapsed"]
+        value = per_step_units * timed / elapsed
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs x 240 lidar beams",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "env-steps/s", "n_gpus": ranks_ran, "steps": args.steps, "warmup": args.warmup,
+            "steps_timed": timed, "warmup_run": warm,
+            "ms_per_step": elapsed / timed * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": ("C3: %d envs/GPU x (1 ego + %d IDM traffic slots) x %d lidar beams, PGDrive-v0 maps "
-                             "seeds 1000-1099, %s actions, auto-reset" % (
-                                 N, args.traffic, args.lasers, "uniform(-1,1)" if args.actions == "uniform" else "drive-straight"))
-                if args.workload == "c3" else
-                ("C5: %d envs/GPU x %d agents, multi-agent roundabout, 72 beams x 40 m, %s actions, respawn, auto-reset; "
-                 "agent-steps/s = value x %d" % (N, A, args.actions, A)),
-                **({"note": "%d independent engines x %d envs on their own streams, stepped round-robin: consecutive steps "
-                            "of different engines overlap (asynchronous vector-env groups)" % (args.engines, N)}
-                   if args.engines > 1 else {}),
-                "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
-                "engines_per_gpu": max(1, args.engines),
-                "parallelism": "env-sharded dp%d%s" % (world, " + 1 RCCL all_gather(obs,reward,done)/step, double-buffered" if gather else ", no data-path collective"),
-            },
-            "roofline": {
+        }
+        if world > 1:
+            out["value_mode"] = head
+            for m in results:
+                out["value_" + m] = per_step_units * timed / results[m]["elapsed"]
+                out["ms_per_step_" + m] = results[m]["elapsed"] / timed * 1e3
+        if head == "gather":
+            par = "env-sharded dp%d + %s, double-buffered" % (world, gatherer.describe())
+        else:
+            par = "env-sharded dp%d, no data-path collective" % world
+        out["config"] = {
+            "workload": ("C3: %d envs/GPU x (1 ego + %d IDM traffic slots) x %d lidar beams, PGDrive-v0 maps "
+                         "seeds 1000-1099, %s actions, auto-reset" % (
+                             N, args.traffic, args.lasers, "uniform(-1,1)" if args.actions == "uniform" else "drive-straight"))
+            if args.workload == "c3" else
+            ("C5: %d envs/GPU x %d agents, multi-agent roundabout, %d beams x 40 m, %s actions, respawn, auto-reset; "
+             "agent-steps/s = value x %d" % (N, A, args.lasers, args.actions, A)),
+            **({"note": "%d independent engines x %d envs on their own streams, stepped round-robin: consecutive steps "
+                        "of different engines overlap (asynchronous vector-env groups)" % (args.engines, N)}
+               if args.engines > 1 else {}),
+            "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
+            "engines_per_gpu": max(1, args.engines),
+            "parallelism": par, "backend": (args.backend if world > 1 else "none"),
+            "steady_state": "pre-roll %d steps, %d timed steps (floors %d / %d%s)" % (
+                warm, timed, PREROLL_MIN, TIMED_MIN, ", off: --exact" if args.exact else ""),
+        }
+        prof = results.get("replicas", {}).get("prof")
+        if prof is not None:
+            b_step, b_obs, b_fused = algorithmic_bytes(A, args.traffic, D)
+            fused = prof["k_observe_ms"] == 0.0  # pgd_step ran the observation inside k_step (one env per wave)
+            if fused:
+                b_step, b_obs = b_fused, 0
+            dom = "k_observe" if prof["k_observe_ms"] >= prof["k_step_ms"] else "k_step"
+            dom_ms = max(prof["k_observe_ms"], prof["k_step_ms"])
+            dom_bytes = (b_obs if dom == "k_observe" else b_step) * N
+            achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            traffic, traffic_src = load_traffic(N, args)
+            out["roofline"] = {
                 "bound": "hbm", "kernel": dom + (" (observation fused)" if fused else ""), "achieved": achieved,
-                "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": load_traffic(N, args),
+                "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                # the same ratio with the HBM bytes the counters saw instead of the algorithmic bytes
+                "frac_traffic": (traffic / (dom_ms * 1e-3) / 8e12) if (traffic and dom_ms > 0) else None,
+                "traffic_source": traffic_src,
                 "bytes_per_env_step": {"k_step": b_step, "k_observe": b_obs},
                 "k_step_ms": prof["k_step_ms"], "k_observe_ms": prof["k_observe_ms"], "events": prof["count"],
-            },
-        }
+                "launches_per_event_group": PROF_STRIDE if fused else 1,
+            }
+        else:
+            out["roofline"] = None
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(descs, args) if args.workload == "c3" else None
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if gatherer is not None:
+        gatherer.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def _spawned(local_rank, args, world, port):
+    os.environ["RANK"] = str(local_rank)
+    os.environ["LOCAL_RANK"] = str(local_rank)
+    os.environ["WORLD_SIZE"] = str(world)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    run_rank(args, local_rank, world, local_rank)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) >= 1 and "RANK" in os.environ:
+        # launched by torch.distributed.run (or any launcher that sets the rendezvous environment)
+        world = int(os.environ["WORLD_SIZE"])
+        if args.gpus != world and int(os.environ["RANK"]) == 0:
+            print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, world, world),
+                  file=sys.stderr)
+        run_rank(args, int(os.environ["RANK"]), world, int(os.environ.get("LOCAL_RANK", "0")))
+        return
+    if args.gpus <= 1:
+        run_rank(args, 0, 1, 0)
+        return
+    # `python bench.py --gpus N` without a launcher: start the N ranks here, one per GPU
+    import torch
+    import torch.multiprocessing as mp
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not args.oversubscribe:
+        raise SystemExit("bench.py --gpus %d: only %d GPUs visible" % (args.gpus, n_dev))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mp.spawn(_spawned, args=(args, args.gpus, port), nprocs=args.gpus, join=True)
 
 
 if __name__ == "__main__":

@@ -195,6 +195,9 @@ typedef struct pgd_config {
   float lidar_gaussian_noise, lidar_dropout_prob;
   int32_t random_agent_model; /* 1: two more state floats, LENGTH / 10 and WIDTH / 2.5, after the lane-line fan
                                (state_obs.py:21-22,102-105); the vehicle type itself comes with the spawn record */
+  int32_t env_base;         /* global index of this engine's env 0.  The device RNG streams (IDM timers, lidar noise, scenario
+                               re-draws, respawn destinations) are keyed by env_base + e, so envs sharded over several engines
+                               / GPUs reproduce the single-engine run env for env */
 } pgd_config;
 
 #define PGD_MA_ENABLED        1  /* MultiAgentPGDrive semantics: per-agent done, delay-done queue, respawn, __all__ */
@@ -243,6 +246,14 @@ int pgd_reset(pgd_handle h, const int32_t* h_env_ids, const int32_t* h_scen_ids,
 int pgd_step(pgd_handle h, const float* d_actions /*[N,A,2]*/, float* d_obs /*[N,A,D]*/, float* d_reward /*[N,A]*/,
              uint8_t* d_done /*[N,A]*/, uint32_t* d_flags /*[N,A]*/);
 
+/* The same step with the env's results written as ONE packed fp32 row per env, the unit of the per-step gather that
+ * BASELINE.json's north star names (envs shard across GPUs, one gather of (obs, reward, done) per step):
+ *   d_rows[e * row_stride + ...] = [A*D observation floats | A rewards | A done flags as 0.0 / 1.0], row_stride >= A*(D+2).
+ * The kernel writes the row itself -- d_rows is typically this rank's slice of the gather's receive buffer, so no copy
+ * kernel packs anything.  d_reward / d_done / d_flags are written as by pgd_step (rank-local bookkeeping). */
+int pgd_step_packed(pgd_handle h, const float* d_actions, float* d_rows /*[N,row_stride]*/, int row_stride,
+                    float* d_reward /*[N,A]*/, uint8_t* d_done /*[N,A]*/, uint32_t* d_flags /*[N,A]*/);
+
 /* Checkpoint / resume (BaseVehicle.get_state/set_state, base_vehicle.py:683-698): raw SoA state blobs.
  * Layout: nf float fields then ni int fields, each [N*V]; query sizes with pgd_state_dims. HOST buffers. */
 int pgd_state_dims(pgd_handle h, int* n_float_fields, int* n_int_fields, int* n_env_int_fields);
@@ -274,6 +285,29 @@ int pgd_set_stream(pgd_handle h, void* hip_stream);
 int pgd_sync(pgd_handle h);
 int pgd_destroy(pgd_handle h);
 const char* pgd_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Per-step gather by direct peer writes (multi-GPU, one process per GPU).  The reference has no distributed layer (one env
+ * per process, engine_utils.py:8-15); BASELINE.json's north star shards the envs over the GPUs of a node with one gather of
+ * (obs, reward, done) per step.  xGMI is point to point, so instead of a ring every rank writes its packed rows (the rows
+ * pgd_step_packed produces) into the receive buffers of all peers at once.  Each rank owns `nbuf` receive buffers of
+ * [world * n_rows][row_floats] fp32 (rank r's rows at row offset r * n_rows) plus a small flag area, in one device block
+ * that peers map over HIP IPC.  Sequence numbers start at 1 and grow by 1 per push; buffer use is round robin.
+ *   create  -> export (handle blob, exchanged by the host, e.g. torch.distributed.all_gather_object) -> connect per peer
+ *   per step: pgd_step_packed(d_rows = own slice of pgd_gather_buffer(buf)) ; pgd_gather_push(buf, seq)
+ *   consumer: pgd_gather_wait(buf, seq) ... read the buffer ... pgd_gather_release(buf, seq)
+ * All three are asynchronous on the given stream; a peer that never arrives sets the status word instead of hanging. */
+#define PGD_GATHER_HANDLE_BYTES 64
+typedef struct pgd_gather* pgd_gather_handle;
+int pgd_gather_create(int device, int world, int rank, int n_rows, int row_floats, int nbuf, pgd_gather_handle* out);
+int pgd_gather_buffer(pgd_gather_handle g, int buf, float** d_recv /* [world*n_rows, row_floats] */);
+int pgd_gather_export(pgd_gather_handle g, void* h_handle /* PGD_GATHER_HANDLE_BYTES */);
+int pgd_gather_connect(pgd_gather_handle g, int peer, const void* h_handle);
+int pgd_gather_push(pgd_gather_handle g, int buf, int seq, void* hip_stream);
+int pgd_gather_wait(pgd_gather_handle g, int buf, int seq, void* hip_stream);
+int pgd_gather_release(pgd_gather_handle g, int buf, int seq, void* hip_stream);
+int pgd_gather_status(pgd_gather_handle g, int* err /* 0 = ok, 1 = an ack never came, 2 = rows never came */);
+int pgd_gather_destroy(pgd_gather_handle g);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,12 @@ struct PgdDev {
   unsigned long long* imask;  // [N] bit s: slot s of the env still equals its scenario's reset image (never stored since)
   const struct VehRec* reset_img;  // [n_scen][V] every slot right after a reset of its scenario (k_reset_image)
   const float2* beam;  // [num_lasers] (cos, sin) of the beam angle i * 2 pi / num_lasers in the vehicle frame
+  // output addressing of one launch: the observation row of (env e, agent a) starts at obs + e * ostride + a * D.
+  // pgd_step: ostride = A * D (dense [N, A, D]).  pgd_step_packed: ostride = the caller's row stride and `prow` = the same
+  // buffer: reward and done (as 0 / 1 floats) are written behind the A * D observation floats of the env's row, so the row
+  // is the unit of the per-step gather (pgdrive_hip.h) and no copy kernel packs it
+  int ostride;
+  float* prow;
 };
 
 // Device-side vehicle record: the PGD_NF float fields followed by the PGD_NI int fields of include/pgd_state_layout.h.

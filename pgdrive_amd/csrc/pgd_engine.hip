@@ -1,13 +1,17 @@
 // pgd_engine.hip — kernels + C ABI (include/pgdrive_hip.h) of the MI355X-native batched PGDrive step engine.
 //
 // Execution model (gfx950, wave64):
-//   k_step     one 64-lane wave per block; lane = one vehicle slot, a wave carries floor(64/V) whole environments.
-//              IDM neighbour search, crash test and trigger logic read the env's vehicle snapshot from LDS;
-//              localisation / line / sidewalk tests walk the per-map uniform grid (L2-resident, immutable).
-//              Reward, done and auto-reset are fused at the end, so one launch advances every vehicle 0.1 s.
-//   k_observe  one 256-thread block per (env, agent): vehicle boxes of the env are compacted into LDS with a wave
-//              ballot, one lidar beam per thread (min over LDS-broadcast boxes), 274-float row written coalesced.
-// The reference call stack this replaces: envs/base_env.py:184-224,303-344 (see DESIGN.md §2).
+//   k_step     one 64-lane wave per block and, whenever V * SUB <= 64 leaves no room for a second one, ONE environment
+//              per wave: a vehicle slot is carried by SUB = min(16, 64 / V) consecutive lanes that hold identical register
+//              copies of its 128-byte record and split the heavy loops (grid walks, broad phase, neighbour search) between
+//              them.  IDM neighbour search, contacts and trigger logic read the env's vehicle snapshot from LDS; map tables
+//              (immutable, L2 resident) are read through the per-map 8 m grid.  Policy, 5 x 0.02 s physics, contacts,
+//              localisation, line / sidewalk test, reward, done, auto-reset AND the observation row (state + navigation +
+//              neighbours + lidar fan) run in this one launch; the stand-alone k_observe serves pgd_reset / pgd_observe,
+//              engines with several envs per wave and the multi-agent step.
+//   k_observe  one block per (env, agent): wave 0 compacts the bodies inside the lidar broad phase into LDS with a ballot,
+//              then every thread casts beams against the compacted bodies and the row is written coalesced.
+// The reference call stack this replaces: envs/base_env.py:184-224,303-344 (DESIGN.md section 1).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -345,12 +349,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         if (em == 0ull) break;
         const int src = __builtin_ffsll((long long)em) - 1;
         const int tslot = (src / d.sub) % V;
-        int dest = (int)(pgd_rng(gcf.seed, (uint32_t)blockIdx.x, 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
+        int dest = (int)(pgd_rng(gcf.seed, (uint32_t)(gcf.env_base + (int)blockIdx.x), 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
                          (uint32_t)gcf.respawn_dests);
         if (parking) {  // get_parking_space: a random one of the free spaces; none -> nobody enters from a road
           const unsigned mask = (unsigned)s_aux & ((1u << gcf.respawn_dests) - 1u);
           if (__ballot(mask != 0u) == 0ull) break;
-          int pick = (int)(pgd_rng(gcf.seed, (uint32_t)blockIdx.x, 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
+          int pick = (int)(pgd_rng(gcf.seed, (uint32_t)(gcf.env_base + (int)blockIdx.x), 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
                            (uint32_t)__popc(mask));
           dest = 0;
           for (int b = 0; b < 32; ++b)
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (resetting) {
     episodes = d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] + 1;
     if (d.cfg.resample_scenario)
-      scen = (int)(pgd_rng(d.cfg.seed, (uint32_t)e, 0x5ce9a210u, (uint32_t)episodes) % (uint32_t)d.n_scen);
+      scen = (int)(pgd_rng(d.cfg.seed, (uint32_t)(d.cfg.env_base + e), 0x5ce9a210u, (uint32_t)episodes) % (uint32_t)d.n_scen);
     sc = d.scen + scen;
     mv = map_view(d, sc->map);  // global tables: the staged map may not be the new one
     ng = 0;
@@ -432,6 +436,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     reward[k] = my_rew;
     done[k] = my_dn ? 1 : 0;
     flags[k] = my_fl;
+    if (d.prow) {  // pgd_step_packed: [A*D obs | A reward | A done] per env
+      float* tail = d.prow + (size_t)e * d.ostride + (size_t)A * d.D;
+      tail[s] = my_rew;
+      tail[A + s] = my_dn ? 1.0f : 0.0f;
+    }
   }
   PHASE_MARK(7);  // reset
   bool stored = false;
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
                   d.cfg.num_lasers);
       __syncthreads();
       PHASE_MARK(21);  // obs: compaction
-      observe_agent<OBJ, STD>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + ((size_t)blockIdx.x * A + a) * d.D, lane,
+      observe_agent<OBJ, STD>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + (size_t)blockIdx.x * d.ostride + (size_t)a * d.D, lane,
                     WAVE);
       __syncthreads();
     }
@@ -540,8 +549,8 @@ __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restr
     d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
     d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP] = 0;
     d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS] = 0;
-    d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] = 0;
-    d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL] = 0;
+    // EI_EPISODES / EI_STEPS_TOTAL are the counters of the device RNG streams (scenario re-draw on auto-reset, IDM timers,
+    // lidar noise): they run on through pgd_reset, so a repeated env.reset() does not replay the same draws
   }
 }
 
@@ -575,7 +584,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
   const int tid = threadIdx.x;
   const VehRec* recs = d.rec + (size_t)e * V;  // the env's vehicle records
   const VehRec& mine = recs[a];
-  float* row = obs + ((size_t)e * A + a) * D;
+  float* row = obs + (size_t)e * d.ostride + (size_t)a * D;
   // which slots get a row: after a multi-agent step the ones that reported or were (re)spawned, else the active ones
   bool want = mine.i[SI_STATUS] == ST_ACTIVE;
   if (flags) {
@@ -645,6 +654,10 @@ struct pgd_engine {
   hipStream_t retired;  // the engine's own stream after pgd_set_stream moved it away
   hipEvent_t ev0, ev1;
   bool ev_valid;
+  hipEvent_t ev_move;   // pgd_set_stream: orders the old stream before the new one
+  hipEvent_t ev_ids;    // pgd_reset: the pinned id staging buffer has been consumed
+  int32_t* h_ids;       // pinned staging [2N] of pgd_reset's host id lists (no stream synchronisation per reset)
+  bool ids_pending;
   pgd_map* maps; pgd_lane* lanes; pgd_road* roads; pgd_box* boxes; int32_t* cell_start; int32_t* cell_items;
   pgd_box* cell_boxes;
   LaneExt* cell_ext;
@@ -728,6 +741,8 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->d.N = cfg->num_envs; h->d.A = cfg->num_agents; h->d.T = cfg->num_traffic; h->d.V = V;
   h->d.D = pgd_obs_dim(cfg);
   h->d.NV = h->d.N * V;
+  h->d.ostride = h->d.A * h->d.D;
+  h->d.prow = nullptr;
   const bool marl = (cfg->marl_flags & PGD_MA_ENABLED) != 0;
   // multi-agent engines have no IDM traffic; num_traffic slots may hold static bodies (toll booths, group PGD_GROUP_NEVER)
   if (marl && (cfg->respawn_places < 0 || cfg->respawn_dests < 0)) return PGD_ERR_ARG;
@@ -738,6 +753,9 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipEventCreate(&h->ev1));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_move, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_ids, hipEventDisableTiming));
+  HIPCHK(hipHostMalloc((void**)&h->h_ids, sizeof(int32_t) * (size_t)cfg->num_envs * 2, hipHostMallocDefault));
   size_t nv = (size_t)h->d.NV;
   HIPCHK(hipMalloc(&h->d.rec, sizeof(VehRec) * nv));
   HIPCHK(hipMalloc(&h->d.ei, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI));
@@ -875,7 +893,7 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
   h->have_maps = true;
   h->img_dirty = true;  // running envs fall back to their own records until their next reset
   HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
-  return PGD_OK;
+  return build_reset_image(h);  // eagerly (needs maps + scenarios): pgd_step never allocates, so it can be graph-captured
 }
 
 int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, const pgd_spawn* spawns) {
@@ -894,16 +912,17 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   h->have_scen = true;
   h->img_dirty = true;
   HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
-  return PGD_OK;
+  return build_reset_image(h);
 }
 
-static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags) {
+static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, const PgdDev* dv = nullptr) {
+  const PgdDev& D = dv ? *dv : h->d;
   int blocks = h->d.N * h->d.A;
   const bool oth = (h->d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && h->d.cfg.num_others > 0;
   const bool wide = h->d.cfg.num_lasers > 128;  // up to 128 beams one wave does it in two rounds: 4x fewer waves than 256-thread blocks
   void (*kern)(PgdDev, float*, const uint32_t*) =
       wide ? (oth ? k_observe<256, true> : k_observe<256, false>) : (oth ? k_observe<64, true> : k_observe<64, false>);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(wide ? 256 : 64), 0, h->stream, h->d, d_obs, d_flags);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(wide ? 256 : 64), 0, h->stream, D, d_obs, d_flags);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }
@@ -916,24 +935,37 @@ int pgd_reset(pgd_handle h, const int32_t* env_ids, const int32_t* scen_ids, int
     if (scen_ids[k] < 0 || scen_ids[k] >= h->d.n_scen) return PGD_ERR_ARG;
     if (env_ids && (env_ids[k] < 0 || env_ids[k] >= h->d.N)) return PGD_ERR_ARG;
   }
+  // the caller's id lists are copied into pinned staging here, so they may be reused as soon as this call returns and the
+  // stream is not synchronised (a partial reset between two steps does not stall the device); the staging buffer itself
+  // is guarded by an event (a second reset waits until the first one's copies have been consumed)
+  if (h->ids_pending) { HIPCHK(hipEventSynchronize(h->ev_ids)); h->ids_pending = false; }
   int32_t* d_env = nullptr;
   if (env_ids) {
-    HIPCHK(hipMemcpyAsync(h->d_ids, env_ids, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+    memcpy(h->h_ids, env_ids, sizeof(int32_t) * (size_t)n);
+    HIPCHK(hipMemcpyAsync(h->d_ids, h->h_ids, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
     d_env = h->d_ids;
   }
-  HIPCHK(hipMemcpyAsync(h->d_ids + h->d.N, scen_ids, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+  memcpy(h->h_ids + h->d.N, scen_ids, sizeof(int32_t) * (size_t)n);
+  HIPCHK(hipMemcpyAsync(h->d_ids + h->d.N, h->h_ids + h->d.N, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(h->stream, &cap);
+  if (cap == hipStreamCaptureStatusNone) { HIPCHK(hipEventRecord(h->ev_ids, h->stream)); h->ids_pending = true; }
   int blocks = (n + h->d.epw - 1) / h->d.epw;
   hipLaunchKernelGGL(k_reset, dim3(blocks), dim3(WAVE), 0, h->stream, h->d, d_env, h->d_ids + h->d.N, n);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream));  // host id buffers may be reused by the caller
   if (d_obs) return launch_observe(h, d_obs, nullptr);
   return PGD_OK;
 }
 
-int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done, uint32_t* d_flags) {
+static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done, uint32_t* d_flags,
+                     int ostride, bool packed) {
   if (!h || !d_actions || !d_reward || !d_done || !d_flags) return PGD_ERR_ARG;
   if (!h->have_maps || !h->have_scen) return PGD_ERR_STATE;
-  if (h->img_dirty) { int rc = build_reset_image(h); if (rc) return rc; }
+  if (h->img_dirty) return PGD_ERR_STATE;  // the reset image is built by the upload calls
+  HIPCHK(hipSetDevice(h->device));
+  PgdDev dv = h->d;  // this launch's output addressing
+  dv.ostride = ostride;
+  dv.prow = packed ? d_obs : nullptr;
   const bool marl = (h->d.cfg.marl_flags & PGD_MA_ENABLED) != 0;
   const bool fuse = d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse;
   bool prof = h->prof_ev && h->prof_n < h->prof_cap;
@@ -960,13 +992,13 @@ int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward
     kern = h->has_objects ? k_step<true, false, true> : (std_obs ? k_step<true, false, false, true> : k_step<true, false, false>);
   }
   else if (h->has_objects) kern = k_step<false, false, true>;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), 0, h->stream, h->d, d_actions, d_reward, d_done,
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), 0, h->stream, dv, d_actions, d_reward, d_done,
                      d_flags, fuse ? d_obs : (float*)nullptr);
   HIPCHK(hipGetLastError());
   if (prof || g_close) HIPCHK(hipEventRecord(pe[1], h->stream));
   if (g_close) h->prof_n += 1;
   if (d_obs && !fuse) {
-    int rc = launch_observe(h, d_obs, marl ? d_flags : (const uint32_t*)nullptr);
+    int rc = launch_observe(h, d_obs, marl ? d_flags : (const uint32_t*)nullptr, &dv);
     if (rc) return rc;
   }
   h->prof_fused = fuse;
@@ -977,9 +1009,21 @@ int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward
   return PGD_OK;
 }
 
+int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done, uint32_t* d_flags) {
+  if (!h) return PGD_ERR_ARG;
+  return step_impl(h, d_actions, d_obs, d_reward, d_done, d_flags, h->d.A * h->d.D, false);
+}
+
+int pgd_step_packed(pgd_handle h, const float* d_actions, float* d_rows, int row_stride, float* d_reward, uint8_t* d_done,
+                    uint32_t* d_flags) {
+  if (!h || !d_rows || row_stride < h->d.A * (h->d.D + 2)) return PGD_ERR_ARG;
+  return step_impl(h, d_actions, d_rows, d_reward, d_done, d_flags, row_stride, true);
+}
+
 int pgd_observe(pgd_handle h, float* d_obs) {
   if (!h || !d_obs) return PGD_ERR_ARG;
   if (!h->have_maps || !h->have_scen) return PGD_ERR_STATE;
+  HIPCHK(hipSetDevice(h->device));
   int blocks = (h->d.N + h->d.epw - 1) / h->d.epw;
   hipLaunchKernelGGL(k_refresh, dim3(blocks), dim3(WAVE), 0, h->stream, h->d);
   HIPCHK(hipGetLastError());
@@ -1001,6 +1045,7 @@ extern "C" int pgd_get_state(pgd_handle h, float* f, int32_t* i, int32_t* ei) {
   if (!h || !f || !i || !ei) return PGD_ERR_ARG;
   const size_t nv = (size_t)h->d.NV;
   const int N = h->d.N;
+  HIPCHK(hipSetDevice(h->device));
   std::vector<VehRec> tr(nv);
   std::vector<int32_t> te((size_t)N * PGD_NEI);
   HIPCHK(hipMemcpyAsync(tr.data(), h->d.rec, sizeof(VehRec) * nv, hipMemcpyDeviceToHost, h->stream));
@@ -1026,6 +1071,7 @@ extern "C" int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, con
   }
   for (int e = 0; e < N; ++e)
     for (int q = 0; q < PGD_NEI; ++q) te[(size_t)e * PGD_NEI + q] = ei[(size_t)q * N + e];
+  HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(h->d.rec, tr.data(), sizeof(VehRec) * nv, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d.ei, te.data(), sizeof(int32_t) * te.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)N, h->stream));  // arbitrary records: none is the image
@@ -1117,9 +1163,11 @@ int pgd_set_stream(pgd_handle h, void* hip_stream) {
   if (ns == h->stream) return PGD_OK;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(ns, &cap);
-  if (cap == hipStreamCaptureStatusNone) {
-    HIPCHK(hipEventRecord(h->ev0, h->stream));  // everything enqueued so far happens before the first op on the new stream
-    HIPCHK(hipStreamWaitEvent(ns, h->ev0, 0));
+  hipStreamCaptureStatus cap_old = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(h->stream, &cap_old);
+  if (cap == hipStreamCaptureStatusNone && cap_old == hipStreamCaptureStatusNone) {
+    HIPCHK(hipEventRecord(h->ev_move, h->stream));  // everything enqueued so far happens before the first op on the new stream
+    HIPCHK(hipStreamWaitEvent(ns, h->ev_move, 0));
   }  // a capturing stream (hipGraph capture of policy + step) must not wait on work outside the capture: the caller has
      // synchronised before starting the capture, as graph capture requires anyway
   h->ev_valid = false;
@@ -1143,6 +1191,9 @@ int pgd_destroy(pgd_handle h) {
     if (b) (void)hipFree(b);
   (void)hipEventDestroy(h->ev0);
   (void)hipEventDestroy(h->ev1);
+  (void)hipEventDestroy(h->ev_move);
+  (void)hipEventDestroy(h->ev_ids);
+  if (h->h_ids) (void)hipHostFree(h->h_ids);
   if (h->prof_ev) {
     for (hipEvent_t ev : *h->prof_ev) (void)hipEventDestroy(ev);
     delete h->prof_ev;
@@ -1156,3 +1207,5 @@ int pgd_destroy(pgd_handle h) {
 }
 
 }  // extern "C"
+
+#include "pgd_gather.h"

@@ -115,7 +115,7 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
     if (success) rt = first + best;
   } else if (vl_road == cur_road && rt != vlane) {
     rt = vlane;
-    r.timer = (int)(pgd_rng(d.cfg.seed, (uint32_t)e, (uint32_t)s, step_count) % 25u);
+    r.timer = (int)(pgd_rng(d.cfg.seed, (uint32_t)(d.cfg.env_base + e), (uint32_t)s, step_count) % 25u);
     success = true;
   } else success = true;
   // is the (new) routing lane on the current road?  first case: the vehicle lane's road; second: only a found lane of

@@ -262,12 +262,12 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
     if (!STD && (d.cfg.lidar_gaussian_noise > 0.0f || d.cfg.lidar_dropout_prob > 0.0f)) {  // state_obs.py:172-182
       const uint32_t key = 0x51d0a000u + (uint32_t)ag.slot * 1024u + (uint32_t)i;
       if (d.cfg.lidar_gaussian_noise > 0.0f) {
-        const float u1 = ((float)(pgd_rng(d.cfg.seed, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        const float u2 = ((float)(pgd_rng(d.cfg.seed ^ 0x9e3779b9u, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u1 = ((float)(pgd_rng(d.cfg.seed, (uint32_t)(d.cfg.env_base + ag.env), key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(pgd_rng(d.cfg.seed ^ 0x9e3779b9u, (uint32_t)(d.cfg.env_base + ag.env), key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
         best = clipf(best + d.cfg.lidar_gaussian_noise * sqrtf(-2.0f * logf(u1)) * cosf(2.0f * PGD_PI * u2), 0.0f, 1.0f);
       }
       if (d.cfg.lidar_dropout_prob > 0.0f) {
-        const float u3 = ((float)(pgd_rng(d.cfg.seed ^ 0x7f4a7c15u, (uint32_t)ag.env, key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u3 = ((float)(pgd_rng(d.cfg.seed ^ 0x7f4a7c15u, (uint32_t)(d.cfg.env_base + ag.env), key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
         if (u3 < d.cfg.lidar_dropout_prob) best = 0.0f;
       }
     }

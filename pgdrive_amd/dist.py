@@ -1,9 +1,17 @@
 """Env-sharded data parallelism: one process per GPU, contiguous env ranges, ONE gather of (obs, reward, done) per step.
 
 The reference has no distributed layer (one env per process, engine_utils.py:8-15).  Here GPU g of G owns environments
-[g*N/G, (g+1)*N/G); maps are replicated (immutable); the only exchange is the per-step gather, done with a single
-torch.distributed all_gather_into_tensor on a packed fp32 row per env (backend "nccl" = RCCL over xGMI on the GPU box,
-"gloo" in the CPU tests).
+[g*N/G, (g+1)*N/G); maps are replicated (immutable); the only exchange is the per-step gather of one packed fp32 row per
+env, [A*D obs | A reward | A done].  The engine writes that row itself (pgd_step_packed) straight into this rank's slice of
+the receive buffer, so nothing is packed or copied before the exchange.  Two transports:
+
+  "collective"  torch.distributed all_gather_into_tensor, in place (send = own slice of the receive buffer).  Backend "nccl"
+                is RCCL over xGMI on the GPU box; "gloo" serves the CPU / one-GPU plumbing tests (not in place there).
+  "peer"        direct peer writes (pgd_gather_* in include/pgdrive_hip.h): every rank maps the receive buffers of its
+                peers over HIP IPC and one kernel pushes the rank's slice over all xGMI links at once, followed by a
+                sequence flag per sender; the consumer waits on the flags.  No ring: xGMI is point to point.
+
+Receive buffers are double-buffered: the exchange of step t overlaps the kernels of step t+1.
 """
 import numpy as np
 
@@ -25,13 +33,14 @@ def pack_width(obs_dim, num_agents=1):
 
 
 def pack(torch, obs, reward, done, out=None):
-    """[n, A, D] obs + [n, A] reward + [n, A] done -> one fp32 row [n, A*(D+2)] (single collective per step)."""
+    """[n, A, D] obs + [n, A] reward + [n, A] done -> one fp32 row [n, A*(D+2)] (what pgd_step_packed writes on the device;
+    used by hosts that produce the three arrays separately, e.g. the CPU tests)."""
     n, A, D = obs.shape
     if out is None:
         out = torch.empty((n, A * (D + 2)), dtype=torch.float32, device=obs.device)
     out[:, :A * D] = obs.reshape(n, A * D)
     out[:, A * D:A * D + A] = reward
-    out[:, A * D + A:] = done.to(torch.float32)
+    out[:, A * D + A:A * D + 2 * A] = done.to(torch.float32)
     return out
 
 
@@ -40,25 +49,87 @@ def unpack(packed, obs_dim, num_agents=1):
     A, D = num_agents, obs_dim
     obs = packed[:, :A * D].reshape(n, A, D)
     reward = packed[:, A * D:A * D + A]
-    done = packed[:, A * D + A:] > 0.5
+    done = packed[:, A * D + A:A * D + 2 * A] > 0.5
     return obs, reward, done
 
 
 class StepGather:
-    """Owns the send / receive buffers of the per-step collective (equal shard sizes required by all_gather_into_tensor)."""
-    def __init__(self, torch, dist, n_local, obs_dim, num_agents=1, device="cpu"):
-        self.torch, self.dist = torch, dist
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.n_local, self.D, self.A = n_local, obs_dim, num_agents
-        w = pack_width(obs_dim, num_agents)
-        self.send = torch.empty((n_local, w), dtype=torch.float32, device=device)
-        self.recv = torch.empty((self.world * n_local, w), dtype=torch.float32, device=device)
+    """The per-step exchange.  `produce(rows)` must write this rank's packed rows [n_local, W] (asynchronously on the current
+    stream is fine): Engine.step_packed on the GPU, oracle + pack() in the CPU tests.
 
-    def __call__(self, obs, reward, done):
-        pack(self.torch, obs, reward, done, out=self.send)
-        if self.world > 1:
-            self.dist.all_gather_into_tensor(self.recv, self.send)
+        g = StepGather(torch, dist, n_local, D, A, device, transport="collective")
+        b = g.step(lambda rows: eng.step_packed(actions, rows))     # enqueue step + exchange, returns the buffer index
+        obs, reward, done = g.result(b)                              # [world * n_local, ...] once the exchange has landed
+    """
+    def __init__(self, torch, dist, n_local, obs_dim, num_agents=1, device="cpu", transport="collective", nbuf=2,
+                 engine_lib=None):
+        self.torch, self.dist = torch, dist
+        on = dist is not None and dist.is_initialized()
+        self.world = dist.get_world_size() if on else 1
+        self.rank = dist.get_rank() if on else 0
+        self.n_local, self.D, self.A = n_local, obs_dim, num_agents
+        self.W = pack_width(obs_dim, num_agents)
+        self.nbuf = nbuf
+        self.transport = transport if self.world > 1 else "local"
+        self.backend = dist.get_backend() if on else "none"
+        self.k = 0
+        self.pending = [None] * nbuf
+        lo = self.rank * n_local
+        if self.transport == "peer":
+            from . import peer
+            self.peer = peer.PeerGather(torch, dist, engine_lib, n_local, self.W, nbuf, device)
+            self.recv = self.peer.recv
+            self.send = [r[lo:lo + n_local] for r in self.recv]
+            self.inplace = True
         else:
-            self.recv.copy_(self.send)
-        return unpack(self.recv, self.D, self.A)
+            self.peer = None
+            self.recv = [torch.empty((self.world * n_local, self.W), dtype=torch.float32, device=device) for _ in range(nbuf)]
+            # RCCL / NCCL run all_gather in place when the input is the rank's own slice of the output
+            self.inplace = self.world == 1 or self.backend == "nccl"
+            self.send = [r[lo:lo + n_local] if self.inplace else
+                         torch.empty((n_local, self.W), dtype=torch.float32, device=device) for r in self.recv]
+
+    def describe(self):
+        if self.transport == "peer":
+            return "direct peer writes over HIP IPC (1 push kernel + sequence flags per step, all xGMI links at once)"
+        if self.transport == "local":
+            return "single rank: rows written in place, no exchange"
+        return "1 %s all_gather_into_tensor(obs|reward|done) per step%s" % (
+            "RCCL" if self.backend == "nccl" else self.backend, ", in place" if self.inplace else "")
+
+    def step(self, produce):
+        b = self.k % self.nbuf
+        self.wait(b)  # buffer b is about to be overwritten: its previous exchange must have completed
+        if self.transport == "peer" and self.k >= self.nbuf:
+            self.peer.release(b, self.k + 1 - self.nbuf)  # the readers of the previous generation were enqueued before this
+        produce(self.send[b])
+        if self.transport == "collective":
+            self.pending[b] = self.dist.all_gather_into_tensor(self.recv[b], self.send[b], async_op=True)
+        elif self.transport == "peer":
+            self.peer.push(b, self.k + 1)
+            self.pending[b] = self.k + 1
+        self.k += 1
+        return b
+
+    def wait(self, b):
+        p = self.pending[b]
+        if p is None:
+            return
+        if self.transport == "peer":
+            self.peer.wait(b, p)
+        else:
+            p.wait()  # stream-level wait on CUDA tensors, blocking on CPU tensors
+        self.pending[b] = None
+
+    def drain(self):
+        for b in range(self.nbuf):
+            self.wait(b)
+
+    def result(self, b):
+        self.wait(b)
+        return unpack(self.recv[b], self.D, self.A)
+
+    def close(self):
+        if self.peer is not None:
+            self.peer.close()
+            self.peer = None

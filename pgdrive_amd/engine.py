@@ -20,6 +20,7 @@ _SIGS = {
     "pgd_upload_scenarios": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pgd_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pgd_step": (C.c_int, [C.c_void_p] * 6),
+    "pgd_step_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgd_state_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pgd_get_state": (C.c_int, [C.c_void_p] * 4),
     "pgd_set_state": (C.c_int, [C.c_void_p] * 4),
@@ -33,6 +34,15 @@ _SIGS = {
     "pgd_sync": (C.c_int, [C.c_void_p]),
     "pgd_destroy": (C.c_int, [C.c_void_p]),
     "pgd_version": (C.c_char_p, []),
+    "pgd_gather_create": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_void_p)]),
+    "pgd_gather_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "pgd_gather_export": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pgd_gather_connect": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "pgd_gather_push": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pgd_gather_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pgd_gather_release": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pgd_gather_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "pgd_gather_destroy": (C.c_int, [C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS.keys())
 
@@ -155,6 +165,21 @@ class Engine:
             "pgd_step"
         )
         return obs, reward, done, flags
+
+    def step_packed(self, actions, rows):
+        """Like step(), but the env's results go into `rows` [N, >= A*(D+2)] fp32 as [A*D obs | A reward | A done]: the
+        row a per-step gather sends (pgdrive_amd/dist.py); `rows` may be a slice of the gather's receive buffer."""
+        assert actions.is_cuda and actions.dtype == self.torch.float32 and actions.is_contiguous()
+        assert rows.is_cuda and rows.dtype == self.torch.float32 and rows.dim() == 2 and rows.shape[0] == self.N
+        assert rows.stride(1) == 1 and rows.stride(0) >= self.A * (self.D + 2)
+        cur = self.torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self._bound_stream:
+            _chk(self.L.pgd_set_stream(self.h, C.c_void_p(cur)), "pgd_set_stream")
+            self._bound_stream = cur
+        p_obs, p_rew, p_done, p_flags = self._own_ptrs
+        _chk(self.L.pgd_step_packed(self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(rows.data_ptr()),
+                                    int(rows.stride(0)), p_rew, p_done, p_flags), "pgd_step_packed")
+        return rows, self.reward, self.done, self.flags
 
     def observe(self):
         _chk(self.L.pgd_observe(self.h, C.c_void_p(self.obs.data_ptr())), "pgd_observe")

@@ -1,0 +1,84 @@
+"""Direct-peer-write transport of the per-step gather (pgd_gather_* in include/pgdrive_hip.h): ctypes binding + the IPC
+handle exchange over torch.distributed.  See pgdrive_amd/csrc/pgd_gather.h for the protocol."""
+import ctypes as C
+
+HANDLE_BYTES = 64
+
+
+class PeerGather:
+    def __init__(self, torch, dist, lib, n_local, row_floats, nbuf, device):
+        if lib is None:
+            from .engine import load_library
+            lib = load_library()
+        self.torch, self.dist, self.L = torch, dist, lib
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.n_local, self.W, self.nbuf = n_local, row_floats, nbuf
+        dev = torch.device(device)
+        self.device = dev
+        h = C.c_void_p()
+        rc = lib.pgd_gather_create(dev.index or 0, self.world, self.rank, n_local, row_floats, nbuf, C.byref(h))
+        if rc:
+            raise RuntimeError("pgd_gather_create failed with status %d" % rc)
+        self.h = h
+        blob = C.create_string_buffer(HANDLE_BYTES)
+        self._chk(lib.pgd_gather_export(h, blob), "pgd_gather_export")
+        blobs = [None] * self.world
+        dist.all_gather_object(blobs, bytes(blob.raw))
+        for p, b in enumerate(blobs):
+            if p != self.rank:
+                self._chk(lib.pgd_gather_connect(h, p, C.create_string_buffer(b, HANDLE_BYTES)), "pgd_gather_connect")
+        dist.barrier()  # every rank has mapped every block before the first push
+        # torch views of the receive buffers (the memory belongs to the gather handle)
+        self.recv = []
+        for b in range(nbuf):
+            ptr = C.c_void_p()
+            self._chk(lib.pgd_gather_buffer(h, b, C.byref(ptr)), "pgd_gather_buffer")
+            self.recv.append(_as_tensor(torch, ptr.value, (self.world * n_local, row_floats), dev))
+        self.released = [0] * nbuf
+
+    def _chk(self, rc, what):
+        if rc:
+            raise RuntimeError("%s failed with status %d" % (what, rc))
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def push(self, buf, seq):
+        self._chk(self.L.pgd_gather_push(self.h, buf, seq, self._stream()), "pgd_gather_push")
+
+    def wait(self, buf, seq):
+        """Stream-level wait until every peer's rows of sequence `seq` have landed in buffer `buf`."""
+        self._chk(self.L.pgd_gather_wait(self.h, buf, seq, self._stream()), "pgd_gather_wait")
+
+    def release(self, buf, seq):
+        """Tell the senders that this rank has finished with generation `seq` of buffer `buf`.  Called on the consumer's stream
+        after its reads have been enqueued (StepGather does it when the buffer is about to be reused): stream order makes the
+        ack follow the reads."""
+        if seq > self.released[buf]:
+            self._chk(self.L.pgd_gather_release(self.h, buf, seq, self._stream()), "pgd_gather_release")
+            self.released[buf] = seq
+
+    def status(self):
+        e = C.c_int()
+        self._chk(self.L.pgd_gather_status(self.h, C.byref(e)), "pgd_gather_status")
+        return e.value
+
+    def close(self):
+        if self.h:
+            self.torch.cuda.synchronize(self.device)
+            err = self.status()
+            self.dist.barrier()  # nobody unmaps while a peer may still write
+            self.L.pgd_gather_destroy(self.h)
+            self.h = None
+            if err:
+                raise RuntimeError("peer gather: a bounded spin ran out (status %d)" % err)
+
+
+def _as_tensor(torch, ptr, shape, device):
+    """A float32 torch view of device memory owned by the HIP library (no copy, no ownership)."""
+    import numpy as np
+    n = int(np.prod(shape))
+
+    class _Mem:
+        __cuda_array_interface__ = dict(shape=(n,), typestr="<f4", data=(int(ptr), False), version=2)
+    return torch.as_tensor(_Mem(), device=device).view(*shape)

@@ -1,0 +1,157 @@
+"""The N > 1 path with the REAL engine (GPU box has one GPU: the ranks share it; gloo carries the collective):
+pgd_step_packed rows, the per-step gather of pgdrive_amd/dist.py as bench.py drives it, and bench.py's own rank spawning."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pgdrive_amd import _abi
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_packed_rows_equal_the_plain_outputs(descs):
+    """pgd_step_packed writes [A*D obs | A reward | A done] per env, bit-identical to pgd_step's three arrays; a wider
+    row stride leaves the padding untouched.  Single-agent (fused observation) and multi-agent (stand-alone k_observe)."""
+    import torch
+    from pgdrive_amd.engine import Engine
+    for marl in (False, True):
+        if marl:
+            d, mb, sb = util.make_marl_banks(num_agents=4, n_variants=4, seed=3)
+            cfg = util.marl_config(32, sb)
+            n_scen = len(sb.scenarios)
+        else:
+            mb, sb = util.make_banks(descs, n_maps=4)
+            cfg = _abi.make_config(32, num_lasers=240)
+            n_scen = 4
+        a, b = Engine(cfg, mb, sb), Engine(cfg, mb, sb)
+        ids = np.arange(32) % n_scen
+        a.reset(ids)
+        b.reset(ids)
+        A, D = a.A, a.D
+        W = A * (D + 2) + 5
+        rows = torch.full((32, W), -7.0, dtype=torch.float32, device=a.device)
+        rng = np.random.default_rng(3)
+        n_done = 0
+        for t in range(150):
+            act = torch.from_numpy(util.driving_actions(rng, 32, A)).to(a.device)
+            o, r, dn, fl = a.step(act)
+            _, r2, dn2, fl2 = b.step_packed(act, rows)
+            a.sync()
+            b.sync()
+            assert torch.equal(rows[:, :A * D].reshape(32, A, D), o)
+            assert torch.equal(rows[:, A * D:A * D + A], r) and torch.equal(r2, r)
+            assert torch.equal(rows[:, A * D + A:A * D + 2 * A] > 0.5, dn > 0) and torch.equal(dn2, dn) and torch.equal(fl2, fl)
+            assert (rows[:, A * (D + 2):] == -7.0).all()
+            n_done += int(dn.sum())
+        assert n_done > 0
+        a.close()
+        b.close()
+
+
+def _worker(rank, world, port, n_total, steps, transport, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from pgdrive_amd import bank, mapdata, scenario
+    from pgdrive_amd import dist as pdist
+    from pgdrive_amd.engine import Engine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    descs = bank.get_descriptions(range(1000, 1004))
+    mb = mapdata.MapBank(descs)
+    sb = scenario.ScenarioBank(descs, [d["seed"] for d in descs], num_traffic=16)
+    lo, hi = pdist.shard_range(n_total, rank, world)
+    n = hi - lo
+    cfg = _abi.make_config(n, num_traffic=16, num_lasers=240, seed=5, env_base=lo)  # RNG streams keyed by the GLOBAL env index
+    eng = Engine(cfg, mb, sb, device=0)
+    eng.reset(pdist.scenario_ids_for(lo, hi, 4))
+    g = pdist.StepGather(torch, dist if world > 1 else None, n, eng.D, eng.A, device=eng.device, transport=transport,
+                         engine_lib=eng.L)
+    rng = np.random.default_rng(0)
+    outs = []
+    with torch.cuda.stream(eng.stream):
+        for t in range(steps):
+            act = torch.from_numpy(rng.uniform(-1, 1, size=(n_total, 1, 2)).astype(np.float32)[lo:hi].copy()).to(eng.device)
+            b = g.step(lambda rows: eng.step_packed(act, rows))
+            obs, rew, done = g.result(b)
+            torch.cuda.synchronize()
+            outs.append((obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), done.cpu().numpy().copy()))
+    if rank == 0:
+        q.put(outs)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    g.close()
+    eng.close()
+
+
+def _run_world(world, n_total, steps, transport, port):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, steps, transport, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=500)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("transport", ["collective", "peer"])
+def test_two_rank_engine_gather_matches_single_process(transport):
+    """Two processes, each with its own engine over half of the envs (sharing the box's one GPU), exchange packed rows every
+    step through StepGather -- the code path of `bench.py --gpus 2` -- and rank 0 sees exactly the rows one process
+    computes for all envs.  Envs are independent and the device RNG streams are keyed by the global env index
+    (pgd_config.env_base), so the comparison is bit-exact."""
+    n_total, steps = 64, 120
+    one = _run_world(1, n_total, steps, "collective", 29711)
+    two = _run_world(2, n_total, steps, transport, 29713 if transport == "collective" else 29715)
+    n_done = 0
+    for (o1, r1, d1), (o2, r2, d2) in zip(one, two):
+        assert o1.shape == o2.shape == (n_total, 1, 274)
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
+        n_done += int(d1.sum())
+    assert n_done > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself, reports n_gpus = 2 and both modes."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--backend", "gloo",
+                          "--exact", "--steps", "24", "--warmup", "8", "--envs", "256", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 24 and d["steps_timed"] == 24
+    assert d["value_mode"] == "gather" and d["value"] == d["value_gather"] and d["value_replicas"] > 0
+    assert d["config"]["global_envs"] == 512 and "all_gather" in d["config"]["parallelism"]
+    assert d["roofline"]["k_step_ms"] > 0  # measured in the replicas pass
+
+
+def test_bench_default_run_is_steady_state_and_reproducible_from_events():
+    """--steps 20 (what the driver passes) still pre-rolls and times the floors; the roofline time comes from >= 64 event groups."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["steps_timed"] >= 2000 and d["warmup_run"] >= 1500
+    assert d["n_gpus"] == 1 and d["roofline"]["events"] >= 64
+    # launch-to-launch time (wall / steps) and the event time of the kernel agree: same workload phase
+    assert abs(d["ms_per_step"] - d["roofline"]["k_step_ms"]) < 0.15 * d["ms_per_step"]

@@ -28,14 +28,18 @@ def _worker(rank, world, port, n_total, q):
     o = orc.Oracle(cfg, mb, sb)  # the oracle stands in for the engine: this test is about sharding + the collective
     o.reset(pdist.scenario_ids_for(lo, hi, 4))
     D = _abi.obs_dim(cfg)
-    g = pdist.StepGather(torch, dist, n, D)
+    g = pdist.StepGather(torch, dist, n, D)  # the class bench.py and the GPU world-size-2 test drive with the real engine
     rng = np.random.default_rng(0)
     outs = []
     for t in range(5):
         act = rng.uniform(-1, 1, size=(n_total, 1, 2)).astype(np.float32)[lo:hi]
-        obs, rew, done, flags = o.step(act)
-        go, gr, gd = g(torch.from_numpy(obs.astype(np.float32)), torch.from_numpy(rew.astype(np.float32)),
-                       torch.from_numpy(done))
+
+        def produce(rows):  # what pgd_step_packed does on the device
+            obs, rew, done, flags = o.step(act)
+            pdist.pack(torch, torch.from_numpy(obs.astype(np.float32)), torch.from_numpy(rew.astype(np.float32)),
+                       torch.from_numpy(done), out=rows)
+        b = g.step(produce)
+        go, gr, gd = g.result(b)
         outs.append((go.numpy().copy(), gr.numpy().copy(), gd.numpy().copy()))
     if rank == 0:
         q.put(outs)
