@@ -81,17 +81,19 @@ def _worker(rank, world, port, n_total, steps, transport, q):
     outs = []
     with torch.cuda.stream(eng.stream):
         for t in range(steps):
-            act = torch.from_numpy(rng.uniform(-1, 1, size=(n_total, 1, 2)).astype(np.float32)[lo:hi].copy()).to(eng.device)
+            a = rng.normal(0.0, 0.3, size=(n_total, 1, 2)).astype(np.float32)  # full throttle, noisy steering: episodes end soon
+            a[..., 1] = 1.0
+            act = torch.from_numpy(a[lo:hi].copy()).to(eng.device)
             b = g.step(lambda rows: eng.step_packed(act, rows))
             obs, rew, done = g.result(b)
             torch.cuda.synchronize()
             outs.append((obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), done.cpu().numpy().copy()))
     if rank == 0:
         q.put(outs)
+    g.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    g.close()
     eng.close()
 
 
@@ -116,7 +118,7 @@ def test_two_rank_engine_gather_matches_single_process(transport):
     step through StepGather -- the code path of `bench.py --gpus 2` -- and rank 0 sees exactly the rows one process
     computes for all envs.  Envs are independent and the device RNG streams are keyed by the global env index
     (pgd_config.env_base), so the comparison is bit-exact."""
-    n_total, steps = 64, 120
+    n_total, steps = 64, 200
     one = _run_world(1, n_total, steps, "collective", 29711)
     two = _run_world(2, n_total, steps, transport, 29713 if transport == "collective" else 29715)
     n_done = 0
