@@ -25,6 +25,11 @@ enum {
   SF_DIST_LEFT, SF_DIST_RIGHT,/* dist_to_left_side / right_side         base_vehicle.py:380-388 */
   SF_EP_REWARD,               /* episode_rewards                        base_env.py:335-339 */
   SF_AGENT_ID,                /* multi-agent: k of "agent{k}" (integer-valued)  agent_manager.py:154-175 */
+  SF_HX, SF_HY,               /* unit heading vector (cos, sin of SF_THETA) as the engine carries it from step to step (the
+                                 physics advances it by rotations instead of calling sincos per step).  Part of the checkpoint
+                                 so that get_state -> set_state resumes bit-exactly; pgd_set_state keeps it only while it agrees
+                                 with SF_THETA to 1e-4 (an edited THETA, or a state built by hand, gets cos / sin of THETA).  SF_THROTTLE is returned equal to SF_ACT1T: the last
+                                 applied throttle IS the newer entry of the action deque (base_vehicle.py:343-349) */
   PGD_NF
 };
 enum {

@@ -35,10 +35,10 @@ struct PgdDev {
   const pgd_map* scen_map;    // [n_scen] copy of each scenario's map header
   const pgd_spawn* spawns;
   int n_scen;
-  struct VehRec* rec;  // [N*V] one 128-byte record per vehicle slot (device layout; the ABI blobs are field-major)
+  struct Veh* rec;  // [N*V] one 128-byte record per vehicle slot (device layout; the ABI blobs are field-major)
   int32_t* ei;         // [N][PGD_NEI]
   unsigned long long* imask;  // [N] bit s: slot s of the env still equals its scenario's reset image (never stored since)
-  const struct VehRec* reset_img;  // [n_scen][V] every slot right after a reset of its scenario (k_reset_image)
+  const struct Veh* reset_img;  // [n_scen][V] every slot right after a reset of its scenario (k_reset_image)
   const float2* beam;  // [num_lasers] (cos, sin) of the beam angle i * 2 pi / num_lasers in the vehicle frame
   // output addressing of one launch: the observation row of (env e, agent a) starts at obs + e * ostride + a * D.
   // pgd_step: ostride = A * D (dense [N, A, D]).  pgd_step_packed: ostride = the caller's row stride and `prow` = the same
@@ -48,13 +48,36 @@ struct PgdDev {
   float* prow;
 };
 
-// Device-side vehicle record: the PGD_NF float fields followed by the PGD_NI int fields of include/pgd_state_layout.h.
-// 128 B = one cache line per vehicle: a lane loads / stores its vehicle with 8 dwordx4 transactions, full-line writes.
-struct __attribute__((aligned(16))) VehRec {
-  float f[PGD_NF];
-  int32_t i[PGD_NI];
+// Device-side vehicle record = the per-lane register image of a vehicle (device-private; pgd_get_state / pgd_set_state
+// convert to the ABI's field-major blobs).  128 B = one cache line: a lane loads / stores its vehicle with 8 dwordx4
+// transactions, full-line writes, and no field shuffling -- the struct in registers IS the record.
+// Besides the ABI fields of include/pgd_state_layout.h (SF_THROTTLE is not stored: the last applied throttle always equals
+// the newer entry of the action deque, SF_ACT1T; base_vehicle.py:343-349 sets both from the same action) the line carries
+// state DERIVED from them, kept from step to step instead of being recomputed through dependent table reads every step:
+//   hx, hy     unit heading vector (cos, sin of th) -- no sincosf per vehicle and step
+//   lon        longitudinal coordinate of the vehicle on its own lane (what the IDM neighbour search reads)
+//   road_cur.. route context (Navigation.current_ref_lanes / next_ref_lanes, navigation.py:155-183): road ids, first lanes
+//              and lane counts of the current and the next checkpoint pair, block id of the current road; changes only
+//              when a checkpoint is passed (route_refresh)
+// The int fields are bit-fields: 15 ints live in 6 registers and the compiler extracts them with v_bfe where they are used.
+struct __attribute__((aligned(16))) Veh {
+  float x, y, th, v;                  // position, heading_theta [rad], speed [m/s]
+  float hx, hy, lon, steer;
+  uint32_t lane : 16, spawn : 16;
+  int32_t rlane : 16;                 // traffic: routing target lane (-1 = None); agents: episode length
+  uint32_t timer : 16;                // saturating
+  uint32_t vflags : 16, status : 4, ck0 : 6, ck1 : 6;
+  uint32_t road_cur : 12, road_next : 12, blk : 8;  // road ids (0xfff = none), Road.block_ID char
+  uint32_t cur_first : 16, next_first : 16;
+  uint32_t cur_n : 8, next_n : 8, spare : 16;
+  float target, agent_id;
+  float php, phi, plp, pli;           // IDM PIDs; agents: toll / parking bookkeeping (pgd_state_layout.h)
+  float lastx, lasty, lasthx, lasthy;
+  float a0s, a0t, a1s, a1t;
+  float energy, dl, dr, eprew;
 };
-static_assert(sizeof(VehRec) == 128, "vehicle record must be exactly one 128-byte line");
+typedef Veh VehRec;
+static_assert(sizeof(Veh) == 128, "vehicle record must be exactly one 128-byte line");
 
 // Per lane-box extract of its lane (device-private, built on upload): the heading test and the road preference of
 // ray_localization (scene_utils.py:158-172, navigation.py:328-344) then need no dependent read of the 64-byte lane record.
@@ -107,11 +130,14 @@ DEV MapView map_view(const PgdDev& d, int map) { return map_view_of(d, d.maps + 
 DEV float clipf(float a, float lo, float hi) { return fminf(fmaxf(a, lo), hi); }
 DEV float norm2(float x, float y) { return sqrtf(x * x + y * y); }
 DEV float wrap_to_pi(float x) {  // ((x + pi) % (2 pi)) - pi with Python's sign-of-divisor modulo: result in [-pi, pi)
+#pragma clang fp contract(off)
   float y = x + PGD_PI;
   float r = y - 2.0f * PGD_PI * floorf(y * (0.5f / PGD_PI));
   r = r < 0.0f ? r + 2.0f * PGD_PI : (r >= 2.0f * PGD_PI ? r - 2.0f * PGD_PI : r);
   return r - PGD_PI;
 }
+// BaseVehicle.heading_theta (base_vehicle.py:411-416): (-getH() - 90) deg with getH in (-180, 180]: [-3 pi / 2, pi / 2)
+DEV float heading_wrap(float th) { return wrap_to_pi(th + 0.5f * PGD_PI) - 0.5f * PGD_PI; }
 DEV float not_zero(float x, float eps) { return fabsf(x) > eps ? x : (x > 0.0f ? eps : -eps); }
 
 // counter RNG (IDM timer reseed idm_policy.py:239, scenario resampling base_env.py:451-458)
@@ -128,6 +154,9 @@ DEV uint32_t pgd_rng(uint32_t seed, uint32_t a, uint32_t b, uint32_t c) {
 // lanes: component/lane/straight_lane.py:53-67, circular_lane.py:41-67
 // ---------------------------------------------------------------------------------------------------------------------
 DEV void lane_local(const pgd_lane& l, float px, float py, float& lon, float& lat) {
+  // no fp contraction inside: the own-lane coordinate is carried in the vehicle record AND re-derived by k_derive after
+  // pgd_set_state; both must give the same bits, whatever the compiler fuses around the inlined copy
+#pragma clang fp contract(off)
   float dx = px - l.ax, dy = py - l.ay;
   if (l.dir == 0.0f) {
     lon = dx * l.bx + dy * l.by;
@@ -136,7 +165,7 @@ DEV void lane_local(const pgd_lane& l, float px, float py, float& lon, float& la
     float R = l.bx, p0 = l.by;
     float phi = p0 + wrap_to_pi(atan2f(dy, dx) - p0);
     lon = l.dir * (phi - p0) * R;
-    lat = l.dir * (R - norm2(dx, dy));
+    lat = l.dir * (R - sqrtf(dx * dx + dy * dy));
   }
 }
 DEV void lane_position(const pgd_lane& l, float lon, float lat, float& x, float& y) {

@@ -3,22 +3,31 @@
 #ifndef PGD_DYNAMICS_H
 #define PGD_DYNAMICS_H
 
+// tan on |x| <= 1 rad (steering locks are 35-50 deg; pgd_upload_scenarios rejects max_steer > 1) as sin / cos from their
+// Taylor polynomials (truncation < 2e-10): the error is the fp32 rounding of the quotient, at a sixth of tanf's instructions
+DEV float tan_small(float x) {
+  const float q = x * x;
+  const float sn = x * (1.0f + q * (-1.0f / 6.0f + q * (1.0f / 120.0f + q * (-1.0f / 5040.0f + q * (1.0f / 362880.0f + q * (-1.0f / 39916800.0f))))));
+  const float cs = 1.0f + q * (-0.5f + q * (1.0f / 24.0f + q * (-1.0f / 720.0f + q * (1.0f / 40320.0f + q * (-1.0f / 3628800.0f + q * (1.0f / 479001600.0f))))));
+  return sn / cs;
+}
+
 // kinematic bicycle (component/highway_vehicle/kinematics.py:134-156) driven by the reference's action -> force mapping
 // (base_vehicle.py:343-376); see DESIGN.md §3 for the substitution of Bullet's raycast vehicle.
-DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse) {
+DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse, const float thr) {
   float dt = d.cfg.dt;
   float force = 0.0f, brake = 0.0f;
-  if (r.thr >= 0.0f) {
+  if (thr >= 0.0f) {
     brake = 2.0f;
-    force = (fabsf(r.v) * 3.6f > p.max_speed) ? 0.0f : p.max_engine_force * r.thr;
+    force = (fabsf(r.v) * 3.6f > p.max_speed) ? 0.0f : p.max_engine_force * thr;
   } else if (reverse) {  // enable_reverse: engine force backwards, no brake (base_vehicle.py:370-373)
-    force = p.max_engine_force * r.thr;
+    force = p.max_engine_force * thr;
   } else {
-    brake = fabsf(r.thr) * p.max_brake_force;
+    brake = fabsf(thr) * p.max_brake_force;
   }
   float delta = -clipf(r.steer, -1.0f, 1.0f) * p.max_steer;
   // beta = atan(t), t = tan(delta)/2  ->  cos(beta) = 1/sqrt(1+t^2), sin(beta) = t/sqrt(1+t^2)
-  float t = 0.5f * tanf(delta);
+  float t = 0.5f * tan_small(delta);
   float cb = 1.0f / sqrtf(1.0f + t * t), sb = t * cb;
   // unit vector of the motion direction th + beta, advanced by exact small-angle rotations instead of sincos per sub-step
   float cd = r.hx * cb - r.hy * sb, sd = r.hy * cb + r.hx * sb;
@@ -45,6 +54,9 @@ DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse) {
   float inv = 1.0f / sqrtf(hx * hx + hy * hy);
   r.hx = hx * inv;
   r.hy = hy * inv;
+  // heading_theta as the reference reports it; keeps the fp32 angle exact to an ulp of pi however often the car has turned
+  // (the carried heading vector above is what the geometry uses)
+  r.th = heading_wrap(r.th);
 }
 
 DEV void reset_vehicle(const pgd_spawn& p, Veh& r, int spawn_index, bool is_agent) {  // base_vehicle.py:292-339
@@ -57,7 +69,7 @@ DEV void reset_vehicle(const pgd_spawn& p, Veh& r, int spawn_index, bool is_agen
   r.hx = 1.0f;
   if (p.lane < 0) { r.status = ST_EMPTY; return; }
   r.status = p.group == -1 ? ST_ACTIVE : ST_PENDING;  // PGD_GROUP_NEVER (-2): in the world, never driven
-  r.x = p.x; r.y = p.y; r.th = p.heading;
+  r.x = p.x; r.y = p.y; r.th = heading_wrap(p.heading);
   r.lastx = p.x; r.lasty = p.y;
   sincosf(p.heading, &r.lasthy, &r.lasthx);
   r.hx = r.lasthx; r.hy = r.lasthy;

@@ -177,9 +177,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       S.present[slot] = present ? 1 : 0;
       if (present && V > A && idm_runs) {
         const pgd_lane& ml = mv.lanes[r.lane];
-        float lo, la;
-        lane_local(ml, r.x, r.y, lo, la);
-        S.lon[slot] = lo;
+        S.lon[slot] = r.lon;  // carried in the record since the vehicle's last localisation
         S.llen[slot] = ml.length;
         S.succ[slot] = *reinterpret_cast<const int4*>(ml.succ);
       }
@@ -221,9 +219,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     r.a1s = st; r.a1t = tb;
     // _set_action / _set_incremental_action (base_vehicle.py:343-358)
     r.steer = (s < A && d.cfg.increment_steering) ? clipf(r.steer + st * 0.05f, -1.0f, 1.0f) : st;
-    r.thr = tb;
     // (4) physics
-    dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0);
+    dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0, tb);
     PHASE_MARK(3);  // dynamics
   }
   __syncthreads();
@@ -366,6 +363,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
           const int sidx = V + p * gcf.respawn_dests + dest;
           sp = d.spawns + (size_t)scen * d.sstride + sidx;
           reset_vehicle(*sp, r, sidx, true);
+          route_refresh(mv, *sp, r);
           r.agent_id = (float)next_agent;
           after_step_vehicle(d.cfg, mv, g, *sp, r, true, true, ctx);
           my_fl |= PGD_F_NEW;
@@ -421,7 +419,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // the slot right after a reset is a function of the scenario alone (spawn pose, first localisation, side distances,
     // agent id): read from the image k_reset_image built at upload instead of localising every vehicle again
     load_rec(d.reset_img + (size_t)scen * V + s, r);
-    if (s < A && r.status != ST_EMPTY) ctx = route_ctx(mv, *sp, r.ck0, r.ck1);
+    if (s < A && r.status != ST_EMPTY) ctx = route_ctx_of(r);
     const unsigned long long am = __ballot(leader && s < A && r.status == ST_ACTIVE);
     if (marl && s < A && r.status == ST_ACTIVE) my_fl |= PGD_F_NEW;
     if (s == 0 && leader) {
@@ -514,7 +512,10 @@ DEV unsigned long long reset_slot(const PgdDev& d, const LaneMap& lm, int scen, 
   MapView mv = map_view(d, d.scen[scen].map);
   reset_vehicle(*sp, r, s, s < A);
   RouteCtx ctx;
-  if (r.status != ST_EMPTY) after_step_vehicle(d.cfg, mv, g, *sp, r, s < A, true, ctx);
+  if (r.status != ST_EMPTY) {
+    route_refresh(mv, *sp, r);
+    after_step_vehicle(d.cfg, mv, g, *sp, r, s < A, true, ctx);
+  }
   const unsigned long long am = __ballot(lm.sub == 0 && s < A && r.status == ST_ACTIVE);  // epw == 1 whenever A > 1
   if (s < A && r.status == ST_ACTIVE) r.agent_id = A == 1 ? 0.0f : (float)__popcll(am & ((1ull << lm.lead) - 1ull));
   return am;
@@ -554,6 +555,30 @@ __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restr
   }
 }
 
+// Rebuilds the derived part of every record (heading vector, own-lane coordinate, route context) from its ABI fields and
+// the current tables: after pgd_set_state and after a map / scenario upload while envs are running.
+__global__ __launch_bounds__(256) void k_derive(PgdDev d) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d.NV) return;
+  Veh r;
+  load_rec(d.rec + k, r);
+  if (r.hx == 0.0f && r.hy == 0.0f) sincosf(r.th, &r.hy, &r.hx);  // a checkpoint carries the heading vector (SF_HX / SF_HY)
+  r.lon = 0.0f;
+  r.road_cur = 0; r.road_next = 0; r.blk = 0; r.cur_first = 0; r.next_first = 0; r.cur_n = 0; r.next_n = 0;
+  const int e = k / d.V;
+  const int scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
+  if (r.status != ST_EMPTY && scen >= 0 && scen < d.n_scen && (int)r.spawn < d.sstride) {
+    const MapView mv = map_view(d, d.scen[scen].map);
+    const pgd_spawn& sp = d.spawns[(size_t)scen * d.sstride + r.spawn];
+    if ((int)r.lane < mv.m->n_lanes) {
+      float lat;
+      lane_local(mv.lanes[r.lane], r.x, r.y, r.lon, lat);
+    }
+    if (r.ck0 < PGD_MAX_CKPT && r.ck1 < PGD_MAX_CKPT) route_refresh(mv, sp, r);
+  }
+  store_rec(d.rec + k, r);
+}
+
 // engine.after_step on the current state (used after pgd_set_state)
 __global__ __launch_bounds__(WAVE) void k_refresh(PgdDev d) {
   const int V = d.V, A = d.A, N = d.N;
@@ -586,7 +611,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
   const VehRec& mine = recs[a];
   float* row = obs + (size_t)e * d.ostride + (size_t)a * D;
   // which slots get a row: after a multi-agent step the ones that reported or were (re)spawned, else the active ones
-  bool want = mine.i[SI_STATUS] == ST_ACTIVE;
+  bool want = mine.status == ST_ACTIVE;
   if (flags) {
     const uint32_t fa = flags[(size_t)e * A + a];
     want = (fa & PGD_F_RESET) ? want : (fa & (PGD_F_REPORT | PGD_F_NEW)) != 0;  // after a reset only the new episode counts
@@ -596,17 +621,17 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
     return;
   }
   AgentView ag;
-  ag.x = mine.f[SF_X]; ag.y = mine.f[SF_Y]; ag.th = mine.f[SF_THETA];
-  sincosf(ag.th, &ag.hy, &ag.hx);
-  ag.dl = mine.f[SF_DIST_LEFT]; ag.dr = mine.f[SF_DIST_RIGHT]; ag.v = mine.f[SF_SPEED]; ag.steer = mine.f[SF_STEER];
-  ag.a0s = mine.f[SF_ACT0S]; ag.a0t = mine.f[SF_ACT0T]; ag.lhx = mine.f[SF_LASTHX]; ag.lhy = mine.f[SF_LASTHY];
+  ag.x = mine.x; ag.y = mine.y; ag.th = mine.th;
+  ag.hx = mine.hx; ag.hy = mine.hy;
+  ag.dl = mine.dl; ag.dr = mine.dr; ag.v = mine.v; ag.steer = mine.steer;
+  ag.a0s = mine.a0s; ag.a0t = mine.a0t; ag.lhx = mine.lasthx; ag.lhy = mine.lasthy;
   const int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
   const pgd_spawn* spb = d.spawns + (size_t)scen * d.sstride;
   if (tid < WAVE) {  // wave 0: broad phase r = lidar distance (lidar.py:109-124), compacted into LDS
     bool present = false, is_vehicle = true;
     float x = 0, y = 0, ux = 1, uy = 0, hl = 0, hw = 0, spd = 0;
     if (tid < V && d.cfg.num_lasers > 0) {
-      int st = recs[tid].i[SI_STATUS];
+      int st = recs[tid].status;
       present = st == ST_PENDING || st == ST_ACTIVE || st == ST_DYING;
       bool still = st == ST_DYING;  // a finished agent is a static body (zero velocity)
       if (flags && tid < A) {
@@ -616,28 +641,28 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
         const uint32_t fa = flags[(size_t)e * A + a], fo = flags[(size_t)e * A + tid];
         if (fa & PGD_F_RESET) {
         } else if (fa & PGD_F_NEW) {
-          present = present && (!(fo & PGD_F_NEW) || recs[tid].f[SF_AGENT_ID] < mine.f[SF_AGENT_ID]);
+          present = present && (!(fo & PGD_F_NEW) || recs[tid].agent_id < mine.agent_id);
         } else {
           present = (fo & PGD_F_REPORT) || (present && !(fo & PGD_F_NEW));
           still = still && !(fo & PGD_F_REPORT);
         }
       }
-      x = recs[tid].f[SF_X]; y = recs[tid].f[SF_Y];
-      sincosf(recs[tid].f[SF_THETA], &uy, &ux);
-      const pgd_spawn& so = spb[recs[tid].i[SI_SPAWN]];
+      x = recs[tid].x; y = recs[tid].y;
+      ux = recs[tid].hx; uy = recs[tid].hy;
+      const pgd_spawn& so = spb[recs[tid].spawn];
       hl = 0.5f * so.length; hw = so.kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * so.width;
       is_vehicle = so.kind == PGD_OBJ_VEHICLE;
-      spd = still ? 0.0f : speed_kmh(recs[tid].f[SF_SPEED]);
+      spd = still ? 0.0f : speed_kmh(recs[tid].v);
     }
     obs_compact<true>(L, tid, a, present, is_vehicle, x, y, ux, uy, hl, hw, spd, ag.x, ag.y, d.cfg.lidar_dist, ag.hx, ag.hy,
                       d.cfg.num_lasers);
   }
   __syncthreads();
   MapView mv = map_view_of(d, d.scen_map + scen);
-  const pgd_spawn& msp = spb[mine.i[SI_SPAWN]];
-  const RouteCtx ctx = route_ctx(mv, msp, mine.i[SI_CK0], mine.i[SI_CK1]);
+  const pgd_spawn& msp = spb[mine.spawn];
+  const RouteCtx ctx = route_ctx_of(mine);
   ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
-  ag.blk = ctx.blk; ag.toll_time = mine.f[SF_PID_HP];
+  ag.blk = ctx.blk; ag.toll_time = mine.php;
   ag.env = e; ag.slot = a; ag.tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
   if (OTH) observe_agent<true, false, true>(d, mv, msp, ag, L, row, tid, BLOCK, recs, spb);
   else observe_agent<true>(d, mv, msp, ag, L, row, tid, BLOCK);
@@ -675,6 +700,7 @@ struct pgd_engine {
   std::vector<hipEvent_t>* prof_ev;  // 3 events per recorded step
   int prof_cap, prof_n, prof_stride, prof_tick;
   bool prof_grouped;
+  bool derive_pending;  // records were written through the ABI or the tables changed: k_derive has to run
   bool has_objects;  // some spawn record is a traffic object (pgd_upload_scenarios): selects the OBJ kernels
   bool step_timing;  // record ev0 / ev1 around every step (pgd_last_step_ms)
   bool no_fuse;      // PGD_NO_FUSE was set when the engine was created (debug: always run the stand-alone k_observe)
@@ -704,9 +730,22 @@ static int build_scen_map(pgd_engine* h) {
   return PGD_OK;
 }
 
+// rebuild the derived part of the records (needs maps + scenarios; deferred until both are there)
+static int derive_records(pgd_engine* h) {
+  if (!h->derive_pending || !h->have_maps || !h->have_scen) return PGD_OK;
+  hipLaunchKernelGGL(k_derive, dim3((h->d.NV + 255) / 256), dim3(256), 0, h->stream, h->d);
+  HIPCHK(hipGetLastError());
+  h->derive_pending = false;
+  return PGD_OK;
+}
+
 // (re)build the reset image once both the maps and the scenarios are on the device
 static int build_reset_image(pgd_engine* h) {
-  if (!h->img_dirty || !h->have_maps || !h->have_scen) return PGD_OK;
+  if (!h->have_maps || !h->have_scen) return PGD_OK;
+  // the route context cached in the records of running envs refers to the tables: rebuild it after every upload
+  h->derive_pending = true;
+  { int rc = derive_records(h); if (rc) return rc; }
+  if (!h->img_dirty) return PGD_OK;
   if (h->reset_img) { HIPCHK(hipFree(h->reset_img)); h->reset_img = nullptr; }
   HIPCHK(hipMalloc(&h->reset_img, sizeof(VehRec) * (size_t)h->d.n_scen * h->d.V));
   h->d.reset_img = h->reset_img;
@@ -784,6 +823,8 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
                     const pgd_road* roads, int n_roads, const pgd_box* boxes, int n_boxes, const int32_t* cs, int n_cs,
                     const int32_t* ci, int n_ci) {
   if (!h || !maps || n_maps <= 0) return PGD_ERR_ARG;
+  for (int m = 0; m < n_maps; ++m)  // packed ids of the device record: 12-bit road ids, 16-bit lane ids
+    if (maps[m].n_roads > 4095 || maps[m].n_lanes > 65535) return PGD_ERR_ARG;
   HIPCHK(hipSetDevice(h->device));
   int rc;
   if ((rc = upload(&h->maps, maps, n_maps, h->stream))) return rc;
@@ -903,6 +944,8 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   if ((rc = upload(&h->scen, scen, n_scen, h->stream))) return rc;
   if ((rc = upload(&h->spawns, spawns, (size_t)n_scen * h->d.sstride, h->stream))) return rc;
   h->d.scen = h->scen; h->d.spawns = h->spawns; h->d.n_scen = n_scen;
+  for (size_t k = 0; k < (size_t)n_scen * h->d.sstride; ++k)
+    if (spawns[k].lane >= 0 && (!(spawns[k].max_steer <= 1.0f) || spawns[k].n_ckpt > PGD_MAX_CKPT)) return PGD_ERR_ARG;  // tan_small
   h->has_objects = false;
   for (size_t k = 0; k < (size_t)n_scen * h->d.sstride; ++k)
     if (spawns[k].lane >= 0 && spawns[k].kind != PGD_OBJ_VEHICLE) { h->has_objects = true; break; }
@@ -1051,9 +1094,14 @@ extern "C" int pgd_get_state(pgd_handle h, float* f, int32_t* i, int32_t* ei) {
   HIPCHK(hipMemcpyAsync(tr.data(), h->d.rec, sizeof(VehRec) * nv, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(te.data(), h->d.ei, sizeof(int32_t) * te.size(), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  for (size_t k = 0; k < nv; ++k) {
-    for (int q = 0; q < PGD_NF; ++q) f[(size_t)q * nv + k] = tr[k].f[q];
-    for (int q = 0; q < PGD_NI; ++q) i[(size_t)q * nv + k] = tr[k].i[q];
+  for (size_t k = 0; k < nv; ++k) {  // device record -> ABI fields (struct Veh in pgd_device.h)
+    const VehRec& t = tr[k];
+    const float fv[PGD_NF] = {t.x, t.y, t.th, t.v, t.steer, t.a1t /* SF_THROTTLE */, t.lastx, t.lasty, t.lasthx, t.lasthy, t.a0s, t.a0t,
+                              t.a1s, t.a1t, t.php, t.phi, t.plp, t.pli, t.target, t.energy, t.dl, t.dr, t.eprew, t.agent_id, t.hx, t.hy};
+    const int32_t iv[PGD_NI] = {(int32_t)t.status, (int32_t)t.lane, (int32_t)t.ck0, (int32_t)t.ck1, (int32_t)t.rlane, (int32_t)t.timer,
+                                (int32_t)t.vflags, (int32_t)t.spawn};
+    for (int q = 0; q < PGD_NF; ++q) f[(size_t)q * nv + k] = fv[q];
+    for (int q = 0; q < PGD_NI; ++q) i[(size_t)q * nv + k] = iv[q];
   }
   for (int e = 0; e < N; ++e)
     for (int q = 0; q < PGD_NEI; ++q) ei[(size_t)q * N + e] = te[(size_t)e * PGD_NEI + q];
@@ -1065,9 +1113,30 @@ extern "C" int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, con
   const int N = h->d.N;
   std::vector<VehRec> tr(nv);
   std::vector<int32_t> te((size_t)N * PGD_NEI);
-  for (size_t k = 0; k < nv; ++k) {
-    for (int q = 0; q < PGD_NF; ++q) tr[k].f[q] = f[(size_t)q * nv + k];
-    for (int q = 0; q < PGD_NI; ++q) tr[k].i[q] = i[(size_t)q * nv + k];
+  for (size_t k = 0; k < nv; ++k) {  // ABI fields -> device record; the derived part is rebuilt on the device (k_derive)
+    VehRec& t = tr[k];
+    memset(&t, 0, sizeof(t));
+    auto F = [&](int q) { return f[(size_t)q * nv + k]; };
+    auto I = [&](int q) { return i[(size_t)q * nv + k]; };
+    t.x = F(SF_X); t.y = F(SF_Y); t.th = F(SF_THETA); t.v = F(SF_SPEED); t.steer = F(SF_STEER);
+    t.lastx = F(SF_LASTX); t.lasty = F(SF_LASTY); t.lasthx = F(SF_LASTHX); t.lasthy = F(SF_LASTHY);
+    t.a0s = F(SF_ACT0S); t.a0t = F(SF_ACT0T); t.a1s = F(SF_ACT1S); t.a1t = F(SF_ACT1T);
+    t.php = F(SF_PID_HP); t.phi = F(SF_PID_HI); t.plp = F(SF_PID_LP); t.pli = F(SF_PID_LI);
+    t.target = F(SF_TARGET_SPEED); t.energy = F(SF_ENERGY); t.dl = F(SF_DIST_LEFT); t.dr = F(SF_DIST_RIGHT);
+    t.eprew = F(SF_EP_REWARD); t.agent_id = F(SF_AGENT_ID);
+    {  // the carried heading vector is taken from the checkpoint only while it agrees with THETA (a caller that edits THETA,
+       // or builds a state by hand, gets cos / sin of it)
+      const double c = cos((double)t.th), sn = sin((double)t.th);
+      t.hx = F(SF_HX); t.hy = F(SF_HY);
+      if (!(fabs((double)t.hx - c) <= 1e-4 && fabs((double)t.hy - sn) <= 1e-4)) { t.hx = (float)c; t.hy = (float)sn; }
+    }
+    const int32_t lane = I(SI_LANE), spawn = I(SI_SPAWN), rlane = I(SI_RLANE), timer = I(SI_TIMER), vflags = I(SI_VFLAGS),
+                  status = I(SI_STATUS), ck0 = I(SI_CK0), ck1 = I(SI_CK1);
+    if (lane < 0 || lane > 0xffff || spawn < 0 || spawn > 0xffff || rlane < -1 || rlane > 0x7fff || timer < 0 || status < 0 ||
+        status > 15 || ck0 < 0 || ck0 >= PGD_MAX_CKPT || ck1 < 0 || ck1 >= PGD_MAX_CKPT || (vflags & ~0xffff))
+      return PGD_ERR_ARG;
+    t.lane = (uint32_t)lane; t.spawn = (uint32_t)spawn; t.rlane = rlane; t.timer = (uint32_t)std::min(timer, 0xffff);
+    t.vflags = (uint32_t)vflags; t.status = (uint32_t)status; t.ck0 = (uint32_t)ck0; t.ck1 = (uint32_t)ck1;
   }
   for (int e = 0; e < N; ++e)
     for (int q = 0; q < PGD_NEI; ++q) te[(size_t)e * PGD_NEI + q] = ei[(size_t)q * N + e];
@@ -1075,6 +1144,8 @@ extern "C" int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, con
   HIPCHK(hipMemcpyAsync(h->d.rec, tr.data(), sizeof(VehRec) * nv, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d.ei, te.data(), sizeof(int32_t) * te.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)N, h->stream));  // arbitrary records: none is the image
+  h->derive_pending = true;
+  { int rc = derive_records(h); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(h->stream));
   return PGD_OK;
 }

@@ -89,11 +89,11 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
   const float NORMAL = 30.0f, CREEP = 5.0f, SAFE = 15.0f, MAXD = 30.0f;
   const int vlane = r.lane;
   int rt = r.rlane;
-  // the three reads the routing decision needs are independent of each other: issue them together
-  const int cur_road = sp.ckpt_road[r.ck0];
+  // the current road and its lanes come from the record's route context; the two lane reads are independent
+  const int cur_road = r.road_cur;
   const int vl_road = mv.lanes[vlane].road;
   const int rt_road = rt < 0 ? vl_road : (int)mv.lanes[rt].road;
-  const pgd_road& CR = mv.roads[cur_road];
+  struct { int first_lane, n_lanes; } const CR{r.cur_first, r.cur_n};
   bool success;
   // move_to_next_road (idm_policy.py:222-242)
   if (rt < 0) {
@@ -115,7 +115,7 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
     if (success) rt = first + best;
   } else if (vl_road == cur_road && rt != vlane) {
     rt = vlane;
-    r.timer = (int)(pgd_rng(d.cfg.seed, (uint32_t)(d.cfg.env_base + e), (uint32_t)s, step_count) % 25u);
+    r.timer = (pgd_rng(d.cfg.seed, (uint32_t)(d.cfg.env_base + e), (uint32_t)s, step_count) % 25u);
     success = true;
   } else success = true;
   // is the (new) routing lane on the current road?  first case: the vehicle lane's road; second: only a found lane of
@@ -158,7 +158,7 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
     int avail_lo = 0, avail_hi = n_cur - 1;
     bool decided = false;
     if (r.ck0 != r.ck1) {
-      const pgd_road& NR = mv.roads[sp.ckpt_road[r.ck1]];
+      struct { int first_lane, n_lanes; } const NR{r.next_first, r.next_n};
       int diff = n_cur - NR.n_lanes;
       if (diff > 0) {
         if (lane_is_prev_of(mv.lanes[CR.first_lane], NR.first_lane)) { avail_lo = 0; avail_hi = NR.n_lanes - 1; }
@@ -205,7 +205,7 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
       }
       if (!decided) {
         r.target = NORMAL;
-        r.timer += 1;
+        r.timer = min((int)r.timer + 1, 0xffff);
         front_obj = fb.front[1]; front_dist = fb.fd[1]; steer_lane = rt;
       }
     }

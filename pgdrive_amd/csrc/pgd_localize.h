@@ -97,6 +97,24 @@ DEV int get_current_lane(const MapView& mv, const Grp& g, int c, float px, float
   return pick == 0xffffffffu ? -1 : (int)(pick & 0xffffu);
 }
 
+// Route context of the vehicle (Navigation.current_ref_lanes / next_ref_lanes, navigation.py:155-183): roads of the current
+// and the next checkpoint pair, their first lanes and lane counts, block id of the current road.  Kept in the vehicle record
+// and rebuilt only here -- when a checkpoint is passed, at (re)spawn and by k_derive -- so that localisation, the IDM routing,
+// side distances, reward and observation read it from registers instead of walking spawn record -> road table every step.
+DEV void route_refresh(const MapView& mv, const pgd_spawn& sp, Veh& r) {
+  const int rc = sp.ckpt_road[r.ck0], rn = sp.ckpt_road[r.ck1];
+  r.road_cur = (uint32_t)rc; r.road_next = (uint32_t)rn;  // -1 (no road) becomes 0xfff, which no map uses (<= 4095 roads)
+  r.blk = 0; r.cur_first = 0; r.cur_n = 0; r.next_first = 0; r.next_n = 0;
+  if (rc >= 0) {
+    const pgd_road& CR = mv.roads[rc];
+    r.blk = CR.block_id; r.cur_first = CR.first_lane; r.cur_n = CR.n_lanes;
+  }
+  if (rn >= 0) {
+    const pgd_road& NR = mv.roads[rn];
+    r.next_first = NR.first_lane; r.next_n = NR.n_lanes;
+  }
+}
+
 // Navigation._update_target_checkpoints (navigation.py:262-282)
 DEV void update_checkpoints(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, float lon) {
   if (r.ck0 == r.ck1) return;
@@ -121,13 +139,14 @@ DEV void update_checkpoints(const MapView& mv, const Grp& g, const pgd_spawn& sp
   const int idx = (int)hit;
   r.ck0 = idx;
   r.ck1 = (idx + 1 == n - 1) ? idx : idx + 1;
+  route_refresh(mv, sp, r);
 }
 
 // Navigation.update_localization (navigation.py:155-183)
 DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, float& lon_out, float& lat_out) {
   const float s = r.hy, c = r.hx;
-  int road_cur = sp.ckpt_road[r.ck0];
-  int road_next = (r.ck0 == r.ck1) ? -1 : sp.ckpt_road[r.ck1];
+  const int road_cur = (int)r.road_cur;  // the record's route context: no spawn-record read
+  const int road_next = (r.ck0 == r.ck1) ? -1 : (int)r.road_next;
   PHASE_MARK(16);  // after_step: route roads
   // Staying on a lane of the current road needs no grid walk.  The surface box of a lane is (length + 0.1) x
   // (width + 1.2) (base_block.py:396-456), the boxes of a road's lanes overlap by 1.2 m and the first hit in creation order
@@ -179,6 +198,7 @@ DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& s
   r.lane = lane;
   if (!stay) lane_local(mv.lanes[lane], r.x, r.y, lon, lat);
   lon_out = lon; lat_out = lat;
+  r.lon = lon;
   update_checkpoints(mv, g, sp, r, lon);
   r.vflags = on_lane ? (r.vflags & ~PGD_F_OFF_LANE) : (r.vflags | PGD_F_OFF_LANE);
   PHASE_MARK(18);  // after_step: lane_local + checkpoints
@@ -231,11 +251,8 @@ struct RouteCtx {
   float positive;  // +1 / -1: the sign the reference gives the speed reward on a negative road
   int clear;       // the car's box lies inside the line-free strip of its (straight) lane: no line / sidewalk contact possible
 };
-DEV RouteCtx route_ctx(const MapView& mv, const pgd_spawn& sp, int ck0, int ck1) {
-  const int rc = sp.ckpt_road[ck0], rn = sp.ckpt_road[ck1];
-  const pgd_road& CR = mv.roads[rc];
-  const pgd_road& NR = mv.roads[rn];
-  return RouteCtx{CR.block_id, rc, CR.first_lane, CR.n_lanes, NR.first_lane, 0.0f, 1.0f, 0};
+DEV RouteCtx route_ctx_of(const Veh& r) {  // from the route context carried in the vehicle record (route_refresh)
+  return RouteCtx{(int)r.blk, (int)r.road_cur, (int)r.cur_first, (int)r.cur_n, (int)r.next_first, 0.0f, 1.0f, 0};
 }
 
 // BaseVehicle.after_step (base_vehicle.py:255-290).  `with_state_check` = false lets the caller run the line / sidewalk
@@ -245,7 +262,7 @@ DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp&
   float lon_v, lat_v;
   update_localization(mv, g, sp, r, lon_v, lat_v);
   if (is_agent) {
-    ctx = route_ctx(mv, sp, r.ck0, r.ck1);
+    ctx = route_ctx_of(r);
     {
       // line / sidewalk contacts (base_vehicle.py:615-644) need no grid walk while the car's box stays inside the strip of
       // its straight lane that no such box reaches (`ex` of the device lane copy, pgd_upload_maps)

@@ -160,14 +160,14 @@ DEV AgentView view_of_slot(const PgdDev& d, const MapView& mv, const VehRec* rec
                            int env, uint32_t tick) {
   const VehRec& rc = recs[o];
   AgentView ag;
-  ag.x = rc.f[SF_X]; ag.y = rc.f[SF_Y]; ag.th = rc.f[SF_THETA];
-  sincosf(ag.th, &ag.hy, &ag.hx);
-  ag.dl = rc.f[SF_DIST_LEFT]; ag.dr = rc.f[SF_DIST_RIGHT];
-  ag.v = spd_kmh == 0.0f ? 0.0f : rc.f[SF_SPEED];  // the snapshot says 0: an agent that finished in an EARLIER step (static body)
-  ag.steer = rc.f[SF_STEER]; ag.a0s = rc.f[SF_ACT0S]; ag.a0t = rc.f[SF_ACT0T]; ag.lhx = rc.f[SF_LASTHX]; ag.lhy = rc.f[SF_LASTHY];
-  const RouteCtx ctx = route_ctx(mv, spb[rc.i[SI_SPAWN]], rc.i[SI_CK0], rc.i[SI_CK1]);
+  ag.x = rc.x; ag.y = rc.y; ag.th = rc.th;
+  ag.hx = rc.hx; ag.hy = rc.hy;
+  ag.dl = rc.dl; ag.dr = rc.dr;
+  ag.v = spd_kmh == 0.0f ? 0.0f : rc.v;  // the snapshot says 0: an agent that finished in an EARLIER step (static body)
+  ag.steer = rc.steer; ag.a0s = rc.a0s; ag.a0t = rc.a0t; ag.lhx = rc.lasthx; ag.lhy = rc.lasthy;
+  const RouteCtx ctx = route_ctx_of(rc);
   ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
-  ag.blk = ctx.blk; ag.toll_time = rc.f[SF_PID_HP];
+  ag.blk = ctx.blk; ag.toll_time = rc.php;
   ag.env = env; ag.slot = o; ag.tick = tick;
   return ag;
 }
@@ -220,7 +220,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
         for (int q = tid; q < o_oth; q += nt) dst[q] = 0.0f;
       } else {
         const AgentView oa = view_of_slot(d, mv, recs, spb, o, L.rank_spd[r], ag.env, ag.tick);
-        state_block<STD>(d, mv, spb[recs[o].i[SI_SPAWN]], oa, dst, tid, nt);
+        state_block<STD>(d, mv, spb[recs[o].spawn], oa, dst, tid, nt);
       }
     }
   } else

@@ -50,6 +50,7 @@ for mode, steps in (("driving", 1500), ("uniform", 600), ("straight", 900)):
         st["idm_30m_ties"]=st.get("idm_30m_ties",0)+int((tie&agree).sum())
         for fld in ("X","Y","THETA","SPEED"):
             dd=np.abs(gf[_abi.SF[fld]].astype(np.float64)-f[_abi.SF[fld]])[agree&~tie]
+            if fld=="THETA": dd=np.minimum(dd,np.abs(dd-2*np.pi))
             st["pose"]=max(st["pose"],float(dd.max()))
         f32=util.round_state_f32(f); ora.set_state(f32,i,ei); eng.set_state(f32,i,ei)
     st["mode"]=mode; st["seconds"]=round(time.time()-t0,1)

@@ -110,6 +110,8 @@ def test_teacher_forced_parity(descs, num_traffic, num_lasers):
         if agree.any():
             for fld in ("X", "Y", "THETA", "SPEED"):
                 dlt = np.abs(gf[_abi.SF[fld]].astype(np.float64) - f[_abi.SF[fld]])[agree]
+                if fld == "THETA":  # heading_theta lives in [-3 pi / 2, pi / 2): a value on the seam may wrap on one side only
+                    dlt = np.minimum(dlt, np.abs(dlt - 2 * np.pi))
                 pose = max(pose, float(dlt.max()))
         f32 = util.round_state_f32(f)
         ora.set_state(f32, i, ei)

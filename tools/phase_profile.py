@@ -4,7 +4,7 @@ import torch
 from pgdrive_amd import _abi, bank, mapdata, scenario, build
 # build a profiling variant next to the shipped lib
 lib = os.path.join("gpurun_out", "libpgd_prof.so")
-subprocess.check_call([build.hipcc(), '--offload-arch=gfx950','-O3','-std=c++17','-fno-hip-fp32-correctly-rounded-divide-sqrt','-shared','-fPIC','-DPGD_PROF','-o',lib, build.SRC] + os.environ.get('PGD_EXTRA','').split())
+subprocess.check_call([build.hipcc(), '--offload-arch=gfx950','-O3','-std=c++17',*build.FAST_FP,'-shared','-fPIC','-DPGD_PROF','-o',lib, build.SRC] + os.environ.get('PGD_EXTRA','').split())
 from pgdrive_amd import engine
 engine._LIBH = None
 L = engine.load_library(path=lib); engine._LIBH = L
@@ -24,7 +24,7 @@ else:
 names=['load','trig+snap','policy','dynamics','crash','after_step','reward','reset','store','i_route','i_search','i_lc','i_pid','ld_stage','obs','WALL','as_route','as_getlane','as_local','as_side','o_pub','o_compact','o_state','o_neigh','o_lidar']
 out=(C.c_ulonglong*64)()
 with torch.cuda.stream(eng.stream):
-    for k in range(200): eng.step(acts[k%64])
+    for k in range(1500): eng.step(acts[k%64])
     L.pgd_debug_phase_cycles(eng.h, out, 1)
     for rep in range(3):
         for k in range(300): eng.step(acts[k%64])

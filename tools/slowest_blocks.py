@@ -3,7 +3,7 @@ sys.path.insert(0,'.')
 import torch
 from pgdrive_amd import _abi, bank, mapdata, scenario, build
 lib = os.path.join("gpurun_out", "libpgd_prof.so")
-subprocess.check_call([build.hipcc(), '--offload-arch=gfx950','-O3','-std=c++17','-fno-hip-fp32-correctly-rounded-divide-sqrt','-shared','-fPIC','-DPGD_PROF','-o',lib, build.SRC])
+subprocess.check_call([build.hipcc(), '--offload-arch=gfx950','-O3','-std=c++17',*build.FAST_FP,'-shared','-fPIC','-DPGD_PROF','-o',lib, build.SRC])
 from pgdrive_amd import engine
 L = engine.load_library(path=lib); engine._LIBH = L
 descs = bank.load_descriptions()
@@ -18,7 +18,7 @@ names=['load','trig+snap','policy','dynamics','crash','after_step','reward','res
 raw=(C.c_ulonglong*(N*32))()
 L.pgd_debug_phase_raw.argtypes=[C.c_void_p, C.c_void_p, C.c_int]
 with torch.cuda.stream(eng.stream):
-    for k in range(300): eng.step(acts[k%64])
+    for k in range(1500): eng.step(acts[k%64])
     L.pgd_debug_phase_raw(eng.h, raw, N)
     for k in range(6):
         f,i,ei=eng.get_state()
