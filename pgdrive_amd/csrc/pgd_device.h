@@ -37,6 +37,9 @@ struct PgdDev {
   int n_scen;
   struct Veh* rec;  // [N*V] one 128-byte record per vehicle slot (device layout; the ABI blobs are field-major)
   int32_t* ei;         // [N][PGD_NEI]
+  pgd_map* env_map;    // [N] copy of the map header of the env's running scenario (rewritten on reset): the map view of a
+                       // step needs no env -> scenario -> header chain
+  int use_imask;       // 0: every slot is read from the env's own record (small N: one dependent load level less)
   unsigned long long* imask;  // [N] bit s: slot s of the env still equals its scenario's reset image (never stored since)
   const struct Veh* reset_img;  // [n_scen][V] every slot right after a reset of its scenario (k_reset_image)
   const float2* beam;  // [num_lasers] (cos, sin) of the beam angle i * 2 pi / num_lasers in the vehicle frame
@@ -46,6 +49,7 @@ struct PgdDev {
   // is the unit of the per-step gather (pgdrive_hip.h) and no copy kernel packs it
   int ostride;
   float* prow;
+  int dbg_exit;  // exit-profile builds only (PGD_EXITAT)
 };
 
 // Device-side vehicle record = the per-lane register image of a vehicle (device-private; pgd_get_state / pgd_set_state

@@ -49,10 +49,20 @@ __shared__ long long s_prof_t0, s_prof_w0;
   } while (0)
 #define PHASE_INIT() do { if (threadIdx.x == 0) { s_prof_t0 = clock64(); s_prof_w0 = wall_clock64(); } } while (0)
 #define PHASE_END() do { if (threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS) g_phase_cycles[blockIdx.x * 32 + 15] += (unsigned long long)(wall_clock64() - s_prof_w0); } while (0)
+#elif defined(PGD_EXITAT)
+// "exit profile" build (tools/exit_profile.py; never shipped): every wave leaves the kernel at top-level mark d.dbg_exit
+// without storing anything, so the launch time up to each point of the step is measured on an unchanging state
+#define PHASE_MARK(k)
+#define PHASE_INIT()
+#define PHASE_END()
+#define XMARK(k) do { if (d.dbg_exit == (k)) return; } while (0)
 #else
 #define PHASE_MARK(k)
 #define PHASE_INIT()
 #define PHASE_END()
+#endif
+#ifndef XMARK
+#define XMARK(k)
 #endif
 
 #include "pgd_vehicle.h"
@@ -115,6 +125,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   const int slot = base + s;  // my entry of the LDS snapshot
 
   PHASE_INIT();
+  XMARK(99);
   Veh r;
   RouteCtx ctx{0, 0, 0, 1, 0, 0.0f, 1.0f, 0};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
   MapView mv;
@@ -134,18 +145,22 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // scenario's reset image: its lane reads the image -- shared by every env of the scenario, cache resident -- instead of the
   // env's own record in HBM.  One env per wave only; the records in memory stay complete either way.
   unsigned long long im = 0ull;
-  if (ONE_ENV) im = d.imask[e];
+  if (ONE_ENV && d.use_imask) im = d.imask[e];
+  // the agent's action does not depend on anything: its (HBM) read goes out with the first loads
+  float act0 = 0.0f, act1 = 0.0f;
+  if (valid && s < A) { act0 = act[((size_t)e * A + s) * 2 + 0]; act1 = act[((size_t)e * A + s) * 2 + 1]; }
   if (one_env || valid) scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
   if (valid) load_rec((ONE_ENV && ((im >> s) & 1ull)) ? d.reset_img + (size_t)scen * V + s : d.rec + (size_t)e * V + s, r);
   const int key0 = valid ? (r.status ^ (r.vflags << 3)) : 0;  // what a vehicle that does not drive can change: status, flags
   if (one_env || valid) {
     sc = d.scen + scen;
-    mv = map_view_of(d, d.scen_map + scen);
+    mv = map_view_of(d, d.env_map + e);  // per-env header copy: address known at kernel start
     ng = d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP];
     ep_steps = d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS];
     steps_total = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
   }
   PHASE_MARK(13);  // load: scenario + table staging
+  XMARK(13);
   if (valid) {
     sp = d.spawns + (size_t)scen * d.sstride + r.spawn;
     // (0) AgentManager.before_step (agent_manager.py:191-199): finished agents count down, then leave the world
@@ -158,6 +173,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   __syncthreads();
   PHASE_MARK(0);  // load
+  XMARK(0);
   const bool trig = ONE_ENV ? (__ballot(s_flag[0] != 0) != 0ull) : (valid && s_flag[el] != 0);
   if (valid && trig && r.status == ST_PENDING && sp->group == ng) r.status = ST_ACTIVE;
   if (trig) ng += 1;  // every lane of the env keeps the same copy
@@ -185,6 +201,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   __syncthreads();
   PHASE_MARK(1);  // trigger + snapshot
+  XMARK(1);
   const bool acting = valid && r.status == ST_ACTIVE;
   if (ONE_ENV) {
     // every wave of a 4096-env launch is resident at once and the kernel ends with its slowest wave: the envs with the
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (acting) {
     float st, tb;
     if (s < A) {  // EnvInputPolicy.act (env_input_policy.py:17-26); NaN made harmless (test_ego_vehicle.py:78-84)
-      float a0 = act[((size_t)e * A + s) * 2 + 0], a1 = act[((size_t)e * A + s) * 2 + 1];
+      float a0 = act0, a1 = act1;
       if (a0 != a0) a0 = 0.0f;
       if (a1 != a1) a1 = 0.0f;
       st = clipf(a0, -1.0f, 1.0f);
@@ -257,6 +274,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (OBJ && (s_hit[slot] & 4)) r.vflags |= PGD_F_CRASH_BUILDING;
   }
   PHASE_MARK(4);  // crash
+  XMARK(4);
   // (6) after_step; traffic off the lanes is removed (traffic_manager.py:91-109)
   if (acting) {
     after_step_vehicle(d.cfg, mv, g, *sp, r, s < A, !one_env, ctx);
@@ -272,6 +290,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     }
   }
   PHASE_MARK(5);  // after_step
+  XMARK(5);
   ep_steps += 1;
   steps_total += 1;
   // (7) reward / done (base_env.py:303-344)
@@ -401,6 +420,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   __syncthreads();
   PHASE_MARK(6);  // reward/done
+  XMARK(6);
   // (8) auto reset (base_env.py:269-301): the whole env restarts from its (possibly re-drawn) scenario
   int episodes = 0;
   // ONE_ENV: s_flag[0] is the env's reset flag, the same for every lane: a scalar branch keeps scen / mv in SGPRs
@@ -410,7 +430,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (d.cfg.resample_scenario)
       scen = (int)(pgd_rng(d.cfg.seed, (uint32_t)(d.cfg.env_base + e), 0x5ce9a210u, (uint32_t)episodes) % (uint32_t)d.n_scen);
     sc = d.scen + scen;
-    mv = map_view(d, sc->map);  // global tables: the staged map may not be the new one
+    mv = map_view_of(d, d.scen_map + scen);  // the header of the new episode's map (the per-env copy is rewritten below)
     ng = 0;
     ep_steps = 0;
   }
@@ -422,6 +442,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (s < A && r.status != ST_EMPTY) ctx = route_ctx_of(r);
     const unsigned long long am = __ballot(leader && s < A && r.status == ST_ACTIVE);
     if (marl && s < A && r.status == ST_ACTIVE) my_fl |= PGD_F_NEW;
+    if (s == 0 && g.sub < (int)(sizeof(pgd_map) / 16) && d.cfg.resample_scenario)  // the env's header copy follows the scenario
+      reinterpret_cast<uint4*>(d.env_map + e)[g.sub] = reinterpret_cast<const uint4*>(d.scen_map + scen)[g.sub];
     if (s == 0 && leader) {
       d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
       d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] = episodes;
@@ -441,6 +463,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     }
   }
   PHASE_MARK(7);  // reset
+  XMARK(7);
   bool stored = false;
   if (valid && leader) {
     // a slot that neither drove, restarted, counted down (delay-done) nor changed status / flags still holds its record:
@@ -458,9 +481,10 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     const unsigned long long cleared = __ballot(lane < V && ((sb >> (lane * d.sub)) & 1ull) != 0ull);
     const unsigned long long full = V >= 64 ? ~0ull : ((1ull << V) - 1ull);
     const unsigned long long nm = resetting ? full : (im & ~cleared);
-    if (lane == 0 && nm != im) d.imask[e] = nm;
+    if (lane == 0 && nm != im && d.use_imask) d.imask[e] = nm;
   }
   PHASE_MARK(8);  // store
+  XMARK(8);
   // (9) observation of the new state, fused: the wave already holds every vehicle of the env (obs/state_obs.py:132-170)
   if (ONE_ENV && obs != nullptr) {  // host passes obs only when one_env && A <= FUSE_MAX_AGENTS
     __syncthreads();
@@ -486,6 +510,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     const int scen_now = scen;
     const MapView& mvo = mv;
     PHASE_MARK(20);  // obs: publish
+  XMARK(20);
     for (int a = 0; a < A; ++a) {
       const AgentView ag = s_ag[a];
       const bool have = lane < V && d.cfg.num_lasers > 0;
@@ -500,6 +525,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     }
   }
   PHASE_MARK(14);  // fused observation
+  XMARK(14);
   PHASE_END();
 }
 
@@ -544,7 +570,8 @@ __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restr
   if (lm.sub != 0) return;
   store_veh(d, e, s, r);
   if (s == 0) {
-    d.imask[e] = d.epw == 1 ? (d.V >= 64 ? ~0ull : ((1ull << d.V) - 1ull)) : 0ull;  // every record equals the image now
+    d.env_map[e] = d.scen_map[scen];
+    d.imask[e] = (d.epw == 1 && d.use_imask) ? (d.V >= 64 ? ~0ull : ((1ull << d.V) - 1ull)) : 0ull;  // every record equals the image now
     d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_AGENT] = A == 1 ? 1 : __popcll(am);
     d.ei[(size_t)(e) * PGD_NEI + EI_AUX] = d.scen[scen].aux;  // parking: free spaces of the new episode
     d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
@@ -567,6 +594,7 @@ __global__ __launch_bounds__(256) void k_derive(PgdDev d) {
   r.road_cur = 0; r.road_next = 0; r.blk = 0; r.cur_first = 0; r.next_first = 0; r.cur_n = 0; r.next_n = 0;
   const int e = k / d.V;
   const int scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
+  if (k == e * d.V && scen >= 0 && scen < d.n_scen) d.env_map[e] = d.scen_map[scen];  // the env's copy of its map header
   if (r.status != ST_EMPTY && scen >= 0 && scen < d.n_scen && (int)r.spawn < d.sstride) {
     const MapView mv = map_view(d, d.scen[scen].map);
     const pgd_spawn& sp = d.spawns[(size_t)scen * d.sstride + r.spawn];
@@ -782,6 +810,7 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->d.NV = h->d.N * V;
   h->d.ostride = h->d.A * h->d.D;
   h->d.prow = nullptr;
+  h->d.dbg_exit = -1;
   const bool marl = (cfg->marl_flags & PGD_MA_ENABLED) != 0;
   // multi-agent engines have no IDM traffic; num_traffic slots may hold static bodies (toll booths, group PGD_GROUP_NEVER)
   if (marl && (cfg->respawn_places < 0 || cfg->respawn_dests < 0)) return PGD_ERR_ARG;
@@ -801,6 +830,11 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   HIPCHK(hipMalloc(&h->d_ids, sizeof(int32_t) * (size_t)h->d.N * 2));
   HIPCHK(hipMemsetAsync(h->d.rec, 0, sizeof(VehRec) * nv, h->stream));
   HIPCHK(hipMemsetAsync(h->d.ei, 0, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI, h->stream));
+  HIPCHK(hipMalloc(&h->d.env_map, sizeof(pgd_map) * (size_t)h->d.N));
+  HIPCHK(hipMemsetAsync(h->d.env_map, 0, sizeof(pgd_map) * (size_t)h->d.N, h->stream));
+  // reading never-written slots from the scenario's reset image saves HBM traffic at large N (+13 % at 262144 envs) but puts
+  // a dependent load (mask -> record address) at the head of every wave: off below 16384 envs, where the step is latency bound
+  h->d.use_imask = (cfg->num_envs >= 16384 || getenv("PGD_FORCE_IMASK")) && !getenv("PGD_NO_IMASK");
   HIPCHK(hipMalloc(&h->d.imask, sizeof(unsigned long long) * (size_t)h->d.N));
   HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
   {
@@ -1228,6 +1262,10 @@ int pgd_debug_phase_cycles(pgd_handle h, unsigned long long* out64, int reset) {
 }
 #endif
 
+#ifdef PGD_EXITAT
+int pgd_debug_exit_at(pgd_handle h, int k) { h->d.dbg_exit = k; return PGD_OK; }
+#endif
+
 int pgd_set_stream(pgd_handle h, void* hip_stream) {
   if (!h) return PGD_ERR_ARG;
   hipStream_t ns = (hipStream_t)hip_stream;  // null = the device's default stream
@@ -1256,7 +1294,7 @@ int pgd_sync(pgd_handle h) {
 int pgd_destroy(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   (void)hipStreamSynchronize(h->stream);
-  void* bufs[] = {h->d.rec, h->d.ei, h->d.imask, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
+  void* bufs[] = {h->d.rec, h->d.ei, h->d.imask, h->d.env_map, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
                   h->cell_items, h->cell_boxes, h->cell_ext, h->lane_nav, h->scen_map, h->scen, h->spawns, h->beam, h->reset_img};
   for (void* b : bufs)
     if (b) (void)hipFree(b);

@@ -55,7 +55,7 @@ def load_library(path=None):
     # torch bundles its own HIP runtime: import it first so this library binds to the same libamdhip64 (two runtimes
     # in one process do not see each other's devices / streams)
     import torch  # noqa: F401
-    p = path or LIB
+    p = path or os.environ.get("PGD_LIB") or LIB  # PGD_LIB: A/B runs of experimental builds (tools/ab.sh)
     if not os.path.exists(p):
         raise RuntimeError(
             "pgdrive_amd: %s is missing — build it with `python -m pgdrive_amd.build` (hipcc, gfx950). "

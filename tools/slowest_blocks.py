@@ -8,7 +8,7 @@ from pgdrive_amd import engine
 L = engine.load_library(path=lib); engine._LIBH = L
 descs = bank.load_descriptions()
 mb = mapdata.MapBank(descs); sb = scenario.ScenarioBank(descs,[d['seed'] for d in descs])
-N=4096
+N=int(sys.argv[1]) if len(sys.argv)>1 else 4096
 cfg=_abi.make_config(N)
 eng = engine.Engine(cfg, mb, sb)
 eng.reset(np.arange(N)%100)
