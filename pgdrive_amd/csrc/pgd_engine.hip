@@ -225,7 +225,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         tb = tb * (2.0f / (float)(d.cfg.discrete_throttle_dim - 1)) - 1.0f;
       }
     } else {
+#ifdef PGD_NO_IDM
+      st = 0.0f; tb = 0.0f;
+#else
       idm_act<OBJ>(d, mv, g, *sp, S, base, V, s, e, steps_total, r, st, tb);
+#endif
     }
     PHASE_MARK(2);  // policy (IDM)
     // (3) BaseVehicle.before_step (base_vehicle.py:238-253)
@@ -1264,6 +1268,11 @@ int pgd_debug_phase_cycles(pgd_handle h, unsigned long long* out64, int reset) {
 
 #ifdef PGD_EXITAT
 int pgd_debug_exit_at(pgd_handle h, int k) { h->d.dbg_exit = k; return PGD_OK; }
+// n back-to-back steps launched from C (the Python call costs ~7 us per step: longer than the early exit points)
+int pgd_debug_step_many(pgd_handle h, const float* a, float* o, float* r, uint8_t* dn, uint32_t* f, int n) {
+  for (int k = 0; k < n; ++k) { int rc = pgd_step(h, a, o, r, dn, f); if (rc) return rc; }
+  return PGD_OK;
+}
 #endif
 
 int pgd_set_stream(pgd_handle h, void* hip_stream) {

@@ -50,12 +50,25 @@ DEV Obb snap_obb(const Snap& S, int k) { return Obb{S.x[k], S.y[k], S.ux[k], S.u
 struct Grp {
   int sub, SUB, lead;
 };
+// up to 4 sub-lanes (V >= 16): four INDEPENDENT shuffles (clamped index) that pipeline, instead of a dependent loop
 DEV unsigned group_min(unsigned v, const Grp& g) {
+  if (g.SUB <= 4) {
+    const int m = g.SUB - 1;
+    const unsigned a = (unsigned)__shfl((int)v, g.lead), b = (unsigned)__shfl((int)v, g.lead + min(1, m)),
+                   c = (unsigned)__shfl((int)v, g.lead + min(2, m)), e = (unsigned)__shfl((int)v, g.lead + m);
+    return min(min(a, b), min(c, e));
+  }
   unsigned r = v;
   for (int j = 0; j < g.SUB; ++j) r = min(r, (unsigned)__shfl((int)v, g.lead + j));
   return r;
 }
 DEV unsigned group_or(unsigned v, const Grp& g) {
+  if (g.SUB <= 4) {
+    const int m = g.SUB - 1;
+    const unsigned a = (unsigned)__shfl((int)v, g.lead), b = (unsigned)__shfl((int)v, g.lead + min(1, m)),
+                   c = (unsigned)__shfl((int)v, g.lead + min(2, m)), e = (unsigned)__shfl((int)v, g.lead + m);
+    return a | b | c | e;
+  }
   unsigned r = v;
   for (int j = 0; j < g.SUB; ++j) r |= (unsigned)__shfl((int)v, g.lead + j);
   return r;

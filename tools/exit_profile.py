@@ -10,6 +10,7 @@ subprocess.check_call([build.hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++1
 from pgdrive_amd import engine
 L = engine.load_library(path=lib); engine._LIBH = L
 L.pgd_debug_exit_at.argtypes = [C.c_void_p, C.c_int]
+L.pgd_debug_step_many.argtypes = [C.c_void_p] * 6 + [C.c_int]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 mode = sys.argv[2] if len(sys.argv) > 2 else 'uniform'
 descs = bank.get_descriptions(range(1000, 1100))
@@ -31,8 +32,9 @@ with torch.cuda.stream(eng.stream):
         L.pgd_debug_exit_at(eng.h, pt)
         for k in range(50): eng.step(acts[0])
         eng.sync()
+        ptrs = [C.c_void_p(t.data_ptr()) for t in (acts[0], eng.obs, eng.reward, eng.done, eng.flags)]
         t0 = time.perf_counter()
-        for k in range(1000): eng.step(acts[0])
+        L.pgd_debug_step_many(eng.h, *ptrs, 1000)
         eng.sync()
         us = (time.perf_counter() - t0) / 1000 * 1e6
         print('exit at %-26s %6.2f us   (+%.2f)' % (names[pt], us, us - prev))
