@@ -86,12 +86,12 @@ def _chk(rc, what):
 
 class Engine:
     """One simulation handle on one GPU: N envs x (A agents + T traffic slots)."""
-    def __init__(self, cfg, bank, scen, device=0, stream=None):
+    def __init__(self, cfg, bank, scen, device=0, stream=None, lib=None):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("pgdrive_amd.Engine needs a GPU (MI355X); no CPU fallback exists")
         self.torch = torch
-        self.L = load_library()
+        self.L = lib if lib is not None else load_library()  # `lib`: another build of the same ABI (tests: IEEE-math A/B)
         self.cfg = cfg
         self.N, self.A, self.T = cfg.num_envs, cfg.num_agents, cfg.num_traffic
         self.V = self.A + self.T

@@ -118,7 +118,7 @@ def test_teacher_forced_parity(descs, num_traffic, num_lasers):
         eng.set_state(f32, i, ei)
     print("teacher-forced parity:", stats, "pose", pose)
     assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and pose < 1e-3
-    assert stats["flag_mismatch"] <= 1e-3 * stats["steps"]
+    assert stats["flag_mismatch"] == 0  # done / flags bit-exact (north star); no tie class occurs on these 8 maps
     assert stats.get("grazing", 0) <= 1e-5 * stats.get("beams", 1) + 2
 
 
@@ -156,7 +156,7 @@ def test_side_and_lane_line_detector_parity(descs, side, lane_line, num_lasers):
         eng.set_state(f32, i, ei)
     print("detector parity:", stats)
     assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL
-    assert stats["flag_mismatch"] <= 1e-3 * stats["steps"]
+    assert stats["flag_mismatch"] == 0
     assert stats["det_grazing"] <= 1e-4 * stats["det_beams"] + 2
     assert stats.get("grazing", 0) <= 1e-5 * stats.get("beams", 1) + 2
 
@@ -205,7 +205,7 @@ def test_action_modes_respawn_traffic_auto_termination(descs, discrete):
         eng.set_state(f32, i, ei)
     print("action modes parity:", stats, "max_step flags", n_max_step)
     assert n_max_step >= n_envs // 4  # the jumped envs hit 250 * num_blocks unless they crashed before
-    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] <= 1e-3 * stats["steps"]
+    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] == 0
 
 
 def _teleport_to_objects(mb, sb, scen_ids, f, i, back=9.0):
@@ -274,7 +274,7 @@ def test_traffic_objects_parity(descs, safe):
         ora.set_state(f32, i, ei)
         eng.set_state(f32, i, ei)
     print("objects parity:", stats, "objects hit", n_hit_state)
-    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] <= 2
+    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] == 0
     assert n_hit_state >= 8 and stats["n_crash_object"] >= 8
     assert stats.get("grazing", 0) <= 1e-5 * stats.get("beams", 1) + 3
 
@@ -341,7 +341,7 @@ def test_maximum_sizes(descs):
         ora.set_state(f32, i, ei)
         eng.set_state(f32, i, ei)
     print("max sizes parity:", stats, "rows with a tie-flipped neighbour velocity", tie_rows, "of", rows)
-    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] <= 2
+    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] == 0
     assert stats["grazing"] <= 1e-4 * stats["beams"] + 3 and tie_rows <= 0.01 * rows
 
 
@@ -425,7 +425,9 @@ def test_marl_roundabout_parity(num_agents, capacity, kind="roundabout", **cfg_k
         eng.set_state(f32, i, ei)
     print("marl parity:", stats, seen)
     assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL
-    assert stats["flag_mismatch"] <= 2 and seen["int_mismatch"] <= 2 and seen["id_mismatch"] == 0
+    # the only tie class seen in the multi-agent runs: a car whose box touches a line box exactly (fp32 vs fp64 SAT), one
+    # agent-step in 153,600 of the 12-of-16 configuration; every other configuration is bit-exact
+    assert stats["flag_mismatch"] <= 1 and seen["int_mismatch"] <= 1 and seen["id_mismatch"] == 0
     assert seen["dying"] > 0 and stats["n_new"] > 0 and stats["n_all_done"] > 0 and stats["n_report"] > 1000
 
 
@@ -545,7 +547,7 @@ def test_marl_tollgate_parity():
         ora.set_state(f32, i, ei)
         eng.set_state(f32, i, ei)
     print("tollgate parity:", stats, seen)
-    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] <= 2 and seen["int_mismatch"] <= 2
+    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] == 0 and seen["int_mismatch"] == 0
     assert stats["grazing"] <= 1e-4 * stats["beams"] + 5
     assert seen["toll_obs"] > 500 and seen["long_stay"] > 50 and seen["entries"] > 20 and seen["exits"] > 10 and seen["building"] > 10
     assert seen["fast_exit"] >= 5
