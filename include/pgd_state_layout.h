@@ -50,7 +50,8 @@ enum {
   EI_STEPS_TOTAL,             /* steps since pgd_reset (RNG counter) */
   EI_NEXT_AGENT,              /* next "agent{k}" id (AgentManager.next_agent_count) */
   EI_AUX,                     /* PGD_MA_PARKING: ParkingLotSpawnManager.parking_space_available as a bit mask */
-  EI_SPARE2,
+  EI_NEAR,                    /* device-private hint (pgd_get_state returns 0, pgd_set_state ignores it): left by the fused
+                                 observation, 0 = no body can reach an agent during the next step (contact tests skipped) */
   PGD_NEI
 };
 enum { ST_EMPTY = 0, ST_PENDING = 1, ST_ACTIVE = 2, ST_REMOVED = 3, ST_DYING = 4 /* finished agent, static, counting down */ };

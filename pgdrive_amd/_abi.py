@@ -72,7 +72,7 @@ SF = dict(X=0, Y=1, THETA=2, SPEED=3, STEER=4, THROTTLE=5, LASTX=6, LASTY=7, LAS
           ACT1S=12, ACT1T=13, PID_HP=14, PID_HI=15, PID_LP=16, PID_LI=17, TARGET_SPEED=18, ENERGY=19, DIST_LEFT=20,
           DIST_RIGHT=21, EP_REWARD=22, AGENT_ID=23, HX=24, HY=25)
 SI = dict(STATUS=0, LANE=1, CK0=2, CK1=3, RLANE=4, TIMER=5, VFLAGS=6, SPAWN=7)
-EI = dict(SCEN=0, NEXT_GROUP=1, EP_STEPS=2, EPISODES=3, STEPS_TOTAL=4, NEXT_AGENT=5, AUX=6)
+EI = dict(SCEN=0, NEXT_GROUP=1, EP_STEPS=2, EPISODES=3, STEPS_TOTAL=4, NEXT_AGENT=5, AUX=6, NEAR=7)
 NF, NI, NEI = 26, 8, 8
 ST_EMPTY, ST_PENDING, ST_ACTIVE, ST_REMOVED, ST_DYING = 0, 1, 2, 3, 4
 MA_ENABLED, MA_CRASH_DONE, MA_OUT_ROAD_DONE, MA_ALLOW_RESPAWN, MA_PLAIN_REWARD, MA_YELLOW_OK, MA_TOLLGATE = 1, 2, 4, 8, 16, 32, 64

@@ -14,7 +14,10 @@ DEV float tan_small(float x) {
 
 // kinematic bicycle (component/highway_vehicle/kinematics.py:134-156) driven by the reference's action -> force mapping
 // (base_vehicle.py:343-376); see DESIGN.md §3 for the substitution of Bullet's raycast vehicle.
-DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse, const float thr) {
+// keep (wave-uniform where one wave carries one env): record the pose after every sub-step and the path length for the
+// contact test of this step.  ONE compiled body for both cases: two instantiations would contract their multiply-adds
+// differently and an env would not step bit-identically with and without the bookkeeping.
+DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse, const float thr, struct SubPose* sub, int slot, const bool keep) {
   float dt = d.cfg.dt;
   float force = 0.0f, brake = 0.0f;
   if (thr >= 0.0f) {
@@ -34,7 +37,10 @@ DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse, con
   float inv_half_base = 2.0f / p.wheelbase;
   float dv_brake = fminf(4.0f * brake / p.mass, p.friction * 9.81f * dt);
   float dv_engine = 4.0f * force / p.mass * dt;
+  float trav = 0.0f;
+  const int n_mid = (keep && d.cfg.decision_repeat <= PGD_MAX_SUB) ? d.cfg.decision_repeat - 1 : 0;  // sub-step poses kept
   for (int k = 0; k < d.cfg.decision_repeat; ++k) {
+    trav += fabsf(r.v) * dt;
     r.x += r.v * cd * dt;
     r.y += r.v * sd * dt;
     float dth = r.v * sb * inv_half_base * dt;  // |dth| < 0.25 rad at 80 km/h and full lock
@@ -48,6 +54,12 @@ DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse, con
     if (force != 0.0f) r.v += dv_engine;
     else r.v = r.v >= 0.0f ? fmaxf(0.0f, r.v - dv_brake) : fminf(0.0f, r.v + dv_brake);
     if (!reverse) r.v = fmaxf(r.v, 0.0f);
+    if (k < n_mid) {  // pose after this sub-step
+      if (sub) sub->p[k][slot] = make_float4(r.x, r.y, cd, sd);
+    }
+  }
+  if (keep) {
+    if (sub) { sub->trav[slot] = trav; sub->beta[slot] = make_float2(cb, sb); }
   }
   // heading unit vector = motion direction rotated back by beta, renormalised
   float hx = cd * cb + sd * sb, hy = sd * cb - cd * sb;
@@ -92,7 +104,7 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
   float w = mv.m->lane_width;
   float reward = ctx.drive;  // formed by after_step_vehicle from the coordinates it had just evaluated
   if (mflags & PGD_MA_TOLLGATE) {  // MultiAgentTollgateEnv.reward_function (marl_tollgate.py:195-232)
-    if (ctx.blk == '$') {
+    if (r.blk == '$') {
       // BaseVehicle.overspeed (base_vehicle.py:759-761): lane.speed_limit (3 on toll lanes, 1000 elsewhere) < speed [km/h]
       const bool lane_toll = mv.roads[mv.lanes[r.lane].road].block_id == '$';
       if (lane_toll && 3.0f < speed_kmh(r.v)) reward = -g.overspeed_penalty * speed_kmh(r.v) / sp.max_speed;
@@ -104,7 +116,7 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
   const pgd_lane& fl = mv.lanes[sp.dest_lane];
   float lon, lat;
   lane_local(fl, r.x, r.y, lon, lat);
-  bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - ctx.cur_n) * w);
+  bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - (float)r.cur_n) * w);
   unsigned oor_bits = (mflags & PGD_MA_TOLLGATE) ? PGD_F_CRASH_SIDEWALK  // marl_tollgate.py:234-240
                       : (mflags & PGD_MA_PARKING) ? (PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK)  // marl_parking_lot.py:213-217
                                                         : (PGD_F_ON_WHITE | PGD_F_OFF_LANE | PGD_F_CRASH_SIDEWALK);

@@ -110,12 +110,14 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
                                                 float* __restrict__ obs) {
   __shared__ Snap S;
-  __shared__ ObsLds OL;
+  __shared__ ObsScratch OU;  // sub-step poses (contact test), then the observation's compaction scratch
+  ObsLds& OL = OU.ol;
+  SubPose& SUBP = OU.sp;
   __shared__ AgentView s_ag[FUSE_MAX_AGENTS];
   __shared__ int s_flag[WAVE];
   __shared__ int s_hit[WAVE];  // per snapshot slot: an agent's chassis overlaps another vehicle
   __shared__ int s_aux;        // multi-agent parking lot: pool of free parking spaces (bit mask)
-  __shared__ int s_kind[WAVE]; // PGD_OBJ_* of every slot (fused observation: objects are lidar targets, not neighbours)
+  __shared__ uint8_t s_kind[WAVE]; // PGD_OBJ_* of every slot (fused observation: objects are lidar targets, not neighbours)
   const int V = d.V, A = d.A, N = d.N;
   const int lane = threadIdx.x;
   const LaneMap lm = lane_map(d, blockIdx.x, N);
@@ -127,15 +129,19 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_INIT();
   XMARK(99);
   Veh r;
-  RouteCtx ctx{0, 0, 0, 1, 0, 0.0f, 1.0f, 0};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
+  RouteCtx ctx{0.0f, 1.0f, 0};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
   MapView mv;
   const pgd_spawn* sp = nullptr;
   const pgd_scenario* sc = nullptr;
   int ng = 0, ep_steps = 0;
   uint32_t steps_total = 0;
+  // EI_NEAR, left by the observation of the previous step: 0 = no body of the env can reach an agent during this step, so no
+  // sub-step pose is kept and no contact test runs; anything else (and every engine without the fused observation) tests
+  bool near_env = true;
   S.present[lane] = 0;
   s_flag[lane] = 0;
   s_hit[lane] = 0;
+  if (lane < PGD_SUBV) SUBP.trav[lane] = 0.0f;
   constexpr bool one_env = ONE_ENV;
   constexpr bool marl = MARL;
   int scen = 0;
@@ -146,9 +152,6 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // env's own record in HBM.  One env per wave only; the records in memory stay complete either way.
   unsigned long long im = 0ull;
   if (ONE_ENV && d.use_imask) im = d.imask[e];
-  // the agent's action does not depend on anything: its (HBM) read goes out with the first loads
-  float act0 = 0.0f, act1 = 0.0f;
-  if (valid && s < A) { act0 = act[((size_t)e * A + s) * 2 + 0]; act1 = act[((size_t)e * A + s) * 2 + 1]; }
   if (one_env || valid) scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
   if (valid) load_rec((ONE_ENV && ((im >> s) & 1ull)) ? d.reset_img + (size_t)scen * V + s : d.rec + (size_t)e * V + s, r);
   const int key0 = valid ? (r.status ^ (r.vflags << 3)) : 0;  // what a vehicle that does not drive can change: status, flags
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     ng = d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP];
     ep_steps = d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS];
     steps_total = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
+    if (ONE_ENV) near_env = d.ei[(size_t)(e) * PGD_NEI + EI_NEAR] != 0;
   }
   PHASE_MARK(13);  // load: scenario + table staging
   XMARK(13);
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (acting) {
     float st, tb;
     if (s < A) {  // EnvInputPolicy.act (env_input_policy.py:17-26); NaN made harmless (test_ego_vehicle.py:78-84)
-      float a0 = act0, a1 = act1;
+      float a0 = act[((size_t)e * A + s) * 2 + 0], a1 = act[((size_t)e * A + s) * 2 + 1];
       if (a0 != a0) a0 = 0.0f;
       if (a1 != a1) a1 = 0.0f;
       st = clipf(a0, -1.0f, 1.0f);
@@ -241,41 +245,60 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // _set_action / _set_incremental_action (base_vehicle.py:343-358)
     r.steer = (s < A && d.cfg.increment_steering) ? clipf(r.steer + st * 0.05f, -1.0f, 1.0f) : st;
     // (4) physics
-    dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0, tb);
+    dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0, tb, leader ? &SUBP : nullptr, slot, near_env);
     PHASE_MARK(3);  // dynamics
   }
   __syncthreads();
   if (acting && leader) { S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy; }
   __syncthreads();
-  // (5) vehicle-vehicle contacts on the post-physics poses (collision_callback.py:7-36): every body in the world tests
-  // itself against each agent of its env, so the A x V pair tests run in parallel lanes
-  if (!OBJ) {
-    if (valid && leader && S.present[slot]) {
-      Obb me = snap_obb(S, slot);
-      for (int a = 0; a < A; ++a)
-        if (a != s && obb_overlap(snap_obb(S, base + a), me)) s_hit[base + a] = 1;
-    }
-  } else {
-    const int my_kind = valid ? s_kind[slot] : PGD_OBJ_VEHICLE;
-    if (valid && S.present[slot] && (leader || my_kind != PGD_OBJ_VEHICLE)) {  // object sub-lanes all keep their copy of the bit
+  // (5) contacts (collision_callback.py:7-36).  The reference's callback runs inside each of the decision_repeat doPhysics
+  // calls (engine_core.py:276-278): two bodies are in contact when they overlap after ANY sub-step, not only at the end of
+  // the 0.1 s step.  Every body in the world tests itself against each agent of its env (A x V pair tests in parallel lanes):
+  // first against the reach of the two paths (centre distance vs circumradii + path lengths: exact, never drops a contact),
+  // then pose by pose.  Bodies that did not drive stand still.  Bullet's collision margin is not modelled (see the oracle).
+  const int n_mid = d.cfg.decision_repeat <= PGD_MAX_SUB ? d.cfg.decision_repeat - 1 : 0;
+  if (near_env) {
+    const int my_kind = (OBJ && valid) ? s_kind[slot] : PGD_OBJ_VEHICLE;
+    if (valid && S.present[slot] && (leader || (OBJ && my_kind != PGD_OBJ_VEHICLE))) {  // object sub-lanes all keep their copy of the bit
       const Obb me = snap_obb(S, slot);
-      const int kind = my_kind;
+      const float my_trav = SUBP.trav[slot];
+      const float my_rad = me.hl + (me.hw < 0.0f ? 0.0f : me.hw);  // >= the circumradius
       // a traffic object reports only its first contact (TrafficObject.crashed / COST_ONCE, collision_callback.py:27-32)
-      const bool live = kind == PGD_OBJ_VEHICLE || !(r.vflags & (int)PGD_F_OBJECT_HIT);
+      const bool live = !OBJ || my_kind == PGD_OBJ_VEHICLE || !(r.vflags & (int)PGD_F_OBJECT_HIT);
       bool touched = false;
-      for (int a = 0; a < A; ++a)
-        if (a != s && S.present[base + a] && shape_overlap<true>(snap_obb(S, base + a), me)) {
-          touched = true;
-          if (leader && live) atomicOr(&s_hit[base + a], kind == PGD_OBJ_VEHICLE ? 1 : (kind == PGD_OBJ_BUILDING ? 4 : 2));
+      for (int a = 0; a < A; ++a) {
+        if (a == s || (OBJ && !S.present[base + a])) continue;
+        const Obb ag = snap_obb(S, base + a);
+        const float ag_trav = SUBP.trav[base + a];
+        const float reach = my_rad + ag.hl + ag.hw + my_trav + ag_trav + 0.01f;
+        const float ddx = ag.cx - me.cx, ddy = ag.cy - me.cy;
+        if (ddx * ddx + ddy * ddy > reach * reach) continue;
+        bool hit = shape_overlap<OBJ>(ag, me);
+        for (int k = 0; k < n_mid && !hit; ++k) {
+          Obb ak = ag, mk = me;
+          if (ag_trav > 0.0f) {  // heading = motion direction rotated back by the slip angle (unit up to rounding)
+            const float4 q = SUBP.p[k][base + a]; const float2 b = SUBP.beta[base + a];
+            ak.cx = q.x; ak.cy = q.y; ak.ux = q.z * b.x + q.w * b.y; ak.uy = q.w * b.x - q.z * b.y;
+          }
+          if (my_trav > 0.0f) {
+            const float4 q = SUBP.p[k][slot]; const float2 b = SUBP.beta[slot];
+            mk.cx = q.x; mk.cy = q.y; mk.ux = q.z * b.x + q.w * b.y; mk.uy = q.w * b.x - q.z * b.y;
+          }
+          hit = shape_overlap<OBJ>(ak, mk);
         }
-      if (touched && kind != PGD_OBJ_VEHICLE && kind != PGD_OBJ_BUILDING) r.vflags |= (int)PGD_F_OBJECT_HIT;  // all sub-lanes
+        if (!hit) continue;
+        touched = true;
+        if (!OBJ) s_hit[base + a] = 1;
+        else if (leader && live) atomicOr(&s_hit[base + a], my_kind == PGD_OBJ_VEHICLE ? 1 : (my_kind == PGD_OBJ_BUILDING ? 4 : 2));
+      }
+      if (OBJ && touched && my_kind != PGD_OBJ_VEHICLE && my_kind != PGD_OBJ_BUILDING) r.vflags |= (int)PGD_F_OBJECT_HIT;  // all sub-lanes
     }
-  }
-  __syncthreads();
-  if (acting && s < A) {
-    if (s_hit[slot] & 1) r.vflags |= PGD_F_CRASH_VEHICLE;
-    if (OBJ && (s_hit[slot] & 2)) r.vflags |= PGD_F_CRASH_OBJECT;
-    if (OBJ && (s_hit[slot] & 4)) r.vflags |= PGD_F_CRASH_BUILDING;
+    __syncthreads();
+    if (acting && s < A) {
+      if (s_hit[slot] & 1) r.vflags |= PGD_F_CRASH_VEHICLE;
+      if (OBJ && (s_hit[slot] & 2)) r.vflags |= PGD_F_CRASH_OBJECT;
+      if (OBJ && (s_hit[slot] & 4)) r.vflags |= PGD_F_CRASH_BUILDING;
+    }
   }
   PHASE_MARK(4);  // crash
   XMARK(4);
@@ -320,7 +343,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (parking && lane == 0) s_aux = d.ei[(size_t)blockIdx.x * PGD_NEI + EI_AUX];  // parking_space_available
     if (parking) __syncthreads();
     if (valid && s < A && was_active) {
-      if (toll && ctx.blk == '$') r.php += 1.0f;  // TollGateObservation.observe counts its calls inside the toll block
+      if (toll && r.blk == '$') r.php += 1.0f;  // TollGateObservation.observe counts its calls inside the toll block
       my_rew = reward_done<true>(d, mv, *sp, r, ctx, my_fl, my_dn);
       const bool arrive = my_fl & PGD_F_ARRIVE, oor = my_fl & PGD_F_OUT_OF_ROAD, crash = my_fl & PGD_F_CRASH_VEHICLE;
       if (crash && !(gcf.marl_flags & PGD_MA_CRASH_DONE) && !(arrive || oor)) my_dn = false;
@@ -402,11 +425,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     }
     // StayTimeManager.record(active_agents, episode_steps) after the step (marl_tollgate.py:36-60,276-279)
     if (toll && valid && s < A && r.status == ST_ACTIVE) {
-      const float cur = (float)ctx.blk, last = r.pli;
+      const float cur = (float)r.blk, last = r.pli;
       r.pli = cur;
       if (last >= 0.0f && last != cur) {
-        if (ctx.blk == '$') r.phi = (float)ep_steps;
-        else if ((ctx.blk == 'y' || ctx.blk == 'Y') && last == (float)'$') r.plp = (float)ep_steps;
+        if (r.blk == '$') r.phi = (float)ep_steps;
+        else if ((r.blk == 'y' || r.blk == 'Y') && last == (float)'$') r.plp = (float)ep_steps;
       }
     }
     // d["__all__"] (multi_agent_pgdrive.py:142-148)
@@ -443,7 +466,6 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // the slot right after a reset is a function of the scenario alone (spawn pose, first localisation, side distances,
     // agent id): read from the image k_reset_image built at upload instead of localising every vehicle again
     load_rec(d.reset_img + (size_t)scen * V + s, r);
-    if (s < A && r.status != ST_EMPTY) ctx = route_ctx_of(r);
     const unsigned long long am = __ballot(leader && s < A && r.status == ST_ACTIVE);
     if (marl && s < A && r.status == ST_ACTIVE) my_fl |= PGD_F_NEW;
     if (s == 0 && g.sub < (int)(sizeof(pgd_map) / 16) && d.cfg.resample_scenario)  // the env's header copy follows the scenario
@@ -490,6 +512,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_MARK(8);  // store
   XMARK(8);
   // (9) observation of the new state, fused: the wave already holds every vehicle of the env (obs/state_obs.py:132-170)
+  bool near_next = true;  // EI_NEAR of the next step: only the fused observation can clear it
   if (ONE_ENV && obs != nullptr) {  // host passes obs only when one_env && A <= FUSE_MAX_AGENTS
     __syncthreads();
     if (valid && leader) {
@@ -504,8 +527,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         AgentView& ag = s_ag[s];
         ag.x = r.x; ag.y = r.y; ag.th = r.th; ag.hx = r.hx; ag.hy = r.hy; ag.dl = r.dl; ag.dr = r.dr; ag.v = r.v;
         ag.steer = r.steer; ag.a0s = r.a0s; ag.a0t = r.a0t; ag.lhx = r.lasthx; ag.lhy = r.lasthy;
-        ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
-        ag.blk = ctx.blk; ag.toll_time = r.php;
+        ag.cur_first = r.cur_first; ag.cur_n = r.cur_n; ag.next_first = r.next_first;
+        ag.blk = r.blk; ag.toll_time = r.php;
         ag.env = e; ag.slot = s; ag.tick = steps_total;
       }
     }
@@ -515,19 +538,25 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     const MapView& mvo = mv;
     PHASE_MARK(20);  // obs: publish
   XMARK(20);
+    bool near_any = false;
     for (int a = 0; a < A; ++a) {
       const AgentView ag = s_ag[a];
       const bool have = lane < V && d.cfg.num_lasers > 0;
+      bool near_a = false;
       obs_compact<OBJ>(OL, lane, a, have && S.present[lane], OBJ ? (have && s_kind[lane] == PGD_OBJ_VEHICLE) : true, S.x[lane], S.y[lane],
                   S.ux[lane], S.uy[lane], S.hl[lane], S.hw[lane], S.spd[lane], ag.x, ag.y, d.cfg.lidar_dist, ag.hx, ag.hy,
-                  d.cfg.num_lasers);
+                  d.cfg.num_lasers, S.hl[a] + S.hw[a] + (fabsf(ag.v) + 1.0f) * 0.105f, &near_a);
+      near_any = near_any || near_a;
       __syncthreads();
       PHASE_MARK(21);  // obs: compaction
       observe_agent<OBJ, STD>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + (size_t)blockIdx.x * d.ostride + (size_t)a * d.D, lane,
                     WAVE);
       __syncthreads();
     }
+    // hint for the next step's contact tests (EI_NEAR); without a lidar the compaction looked at nothing: always test
+    near_next = d.cfg.num_lasers > 0 ? (__ballot(near_any) != 0ull) : true;
   }
+  if (ONE_ENV && lane == 0 && (int)near_next != (int)near_env) d.ei[(size_t)blockIdx.x * PGD_NEI + EI_NEAR] = near_next ? 1 : 0;
   PHASE_MARK(14);  // fused observation
   XMARK(14);
   PHASE_END();
@@ -581,6 +610,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restr
     d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
     d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP] = 0;
     d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS] = 0;
+    d.ei[(size_t)(e) * PGD_NEI + EI_NEAR] = 1;
     // EI_EPISODES / EI_STEPS_TOTAL are the counters of the device RNG streams (scenario re-draw on auto-reset, IDM timers,
     // lidar noise): they run on through pgd_reset, so a repeated env.reset() does not replay the same draws
   }
@@ -692,9 +722,8 @@ __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__
   __syncthreads();
   MapView mv = map_view_of(d, d.scen_map + scen);
   const pgd_spawn& msp = spb[mine.spawn];
-  const RouteCtx ctx = route_ctx_of(mine);
-  ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
-  ag.blk = ctx.blk; ag.toll_time = mine.php;
+  ag.cur_first = mine.cur_first; ag.cur_n = mine.cur_n; ag.next_first = mine.next_first;
+  ag.blk = mine.blk; ag.toll_time = mine.php;
   ag.env = e; ag.slot = a; ag.tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
   if (OTH) observe_agent<true, false, true>(d, mv, msp, ag, L, row, tid, BLOCK, recs, spb);
   else observe_agent<true>(d, mv, msp, ag, L, row, tid, BLOCK);
@@ -1142,7 +1171,7 @@ extern "C" int pgd_get_state(pgd_handle h, float* f, int32_t* i, int32_t* ei) {
     for (int q = 0; q < PGD_NI; ++q) i[(size_t)q * nv + k] = iv[q];
   }
   for (int e = 0; e < N; ++e)
-    for (int q = 0; q < PGD_NEI; ++q) ei[(size_t)q * N + e] = te[(size_t)e * PGD_NEI + q];
+    for (int q = 0; q < PGD_NEI; ++q) ei[(size_t)q * N + e] = q == EI_NEAR ? 0 : te[(size_t)e * PGD_NEI + q];
   return PGD_OK;
 }
 extern "C" int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, const int32_t* ei) {
@@ -1177,7 +1206,7 @@ extern "C" int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, con
     t.vflags = (uint32_t)vflags; t.status = (uint32_t)status; t.ck0 = (uint32_t)ck0; t.ck1 = (uint32_t)ck1;
   }
   for (int e = 0; e < N; ++e)
-    for (int q = 0; q < PGD_NEI; ++q) te[(size_t)e * PGD_NEI + q] = ei[(size_t)q * N + e];
+    for (int q = 0; q < PGD_NEI; ++q) te[(size_t)e * PGD_NEI + q] = q == EI_NEAR ? 1 : ei[(size_t)q * N + e];
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(h->d.rec, tr.data(), sizeof(VehRec) * nv, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d.ei, te.data(), sizeof(int32_t) * te.size(), hipMemcpyHostToDevice, h->stream));

@@ -241,19 +241,12 @@ DEV unsigned state_check(const MapView& mv, const Grp& g, const Obb& car) {
 // What the later phases need from the agent's route position (Navigation.current_ref_lanes / next_ref_lanes,
 // navigation.py:155-183): looked up once per step after the checkpoint update, then reused by the side distances, the
 // reward and the observation instead of re-walking spawn record -> road table each time.
-struct RouteCtx {
-  int blk;         // Road.block_ID char of the current road
-  int road_cur;    // road id of checkpoints[ck0] -> checkpoints[ck0 + 1]
-  int cur_first;   // its first lane (current_ref_lanes[0]) ...
-  int cur_n;       // ... and lane count
-  int next_first;  // first lane of the next checkpoint road (== cur_first on the last road)
+struct RouteCtx {   // per-step by-products of an agent's after_step, consumed by reward_done (the route itself -- current / next
+                    // road, reference lanes, lane counts, block id -- lives in the vehicle record: route_refresh)
   float drive;     // driving_reward * (long_now - long_last) * lateral_factor * positive_road of the step (pgdrive_env.py:209-258)
   float positive;  // +1 / -1: the sign the reference gives the speed reward on a negative road
   int clear;       // the car's box lies inside the line-free strip of its (straight) lane: no line / sidewalk contact possible
 };
-DEV RouteCtx route_ctx_of(const Veh& r) {  // from the route context carried in the vehicle record (route_refresh)
-  return RouteCtx{(int)r.blk, (int)r.road_cur, (int)r.cur_first, (int)r.cur_n, (int)r.next_first, 0.0f, 1.0f, 0};
-}
 
 // BaseVehicle.after_step (base_vehicle.py:255-290).  `with_state_check` = false lets the caller run the line / sidewalk
 // test wave-cooperatively afterwards (k_step with one env per wave) and OR the result into vflags.
@@ -262,7 +255,7 @@ DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp&
   float lon_v, lat_v;
   update_localization(mv, g, sp, r, lon_v, lat_v);
   if (is_agent) {
-    ctx = route_ctx_of(r);
+    ctx = RouteCtx{0.0f, 1.0f, 0};
     {
       // line / sidewalk contacts (base_vehicle.py:615-644) need no grid walk while the car's box stays inside the strip of
       // its straight lane that no such box reaches (`ex` of the device lane copy, pgd_upload_maps)
@@ -278,12 +271,12 @@ DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp&
     fl &= ~(PGD_F_ON_WHITE | PGD_F_ON_YELLOW | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OUT_OF_ROUTE);
     if (with_state_check) fl |= state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sp.length, 0.5f * sp.width});
     float lon, lat;
-    const pgd_lane& L0 = mv.lanes[ctx.cur_first];
+    const pgd_lane& L0 = mv.lanes[r.cur_first];
     lane_local(L0, r.x, r.y, lon, lat);
     float w = mv.m->lane_width;
     r.dl = lat + w * 0.5f;
-    float range = w * ctx.cur_n;
-    if (ctx.blk == 'y' || ctx.blk == 'Y') {
+    float range = w * (float)r.cur_n;
+    if (r.blk == 'y' || r.blk == 'Y') {
       // Navigation.get_current_lateral_range on Merge / Split blocks (navigation.py:306-320,346-362): a 50 m ray from the
       // left edge of the leftmost reference lane across the road against the continuous lane lines
       float sx, sy;
@@ -296,7 +289,7 @@ DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp&
       // lane belongs to the current reference road, else on the first reference lane.  Both coordinate pairs of the new
       // position were just evaluated, so the term is formed here; reward_done adds the speed term and the terminal cases.
       const pgd_lane& VL = mv.lanes[r.lane];
-      const bool in_ref = VL.road == ctx.road_cur;
+      const bool in_ref = VL.road == (int)r.road_cur;
       float l0, t0;
       lane_local(in_ref ? VL : L0, r.lastx, r.lasty, l0, t0);
       const float l1 = in_ref ? lon_v : lon, t1 = in_ref ? lat_v : lat;

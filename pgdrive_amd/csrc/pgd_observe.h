@@ -46,6 +46,10 @@ struct ObsLds {  // bodies inside the lidar broad phase of the observing agent, 
   float rank_spd[16];         // ... and its speed [km/h] as the observer sees it (0 for a static finished agent)
   int n, nveh;
 };
+union ObsScratch {
+  ObsLds ol;
+  SubPose sp;
+};
 struct AgentView {  // what the observation needs from the observing vehicle
   float x, y, th, hx, hy, dl, dr, v, steer, a0s, a0t, lhx, lhy;
   int cur_first, cur_n, next_first;  // RouteCtx of the vehicle
@@ -56,11 +60,20 @@ struct AgentView {  // what the observation needs from the observing vehicle
 };
 
 // one wave compacts the candidates: lane `o` brings vehicle o of the env (present = in the physics world)
+// `near_out` (optional): set when body o can reach the observing agent during the NEXT step -- centre distance within the two
+// sizes (half length + half width bounds the circumradius) plus the longest paths both can drive in 0.1 s (speed + 1 m/s of
+// acceleration, 5 % slack).  k_step skips its contact tests in envs where no body is near any agent.
 template <bool OBJ>
 DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, float x, float y, float ux, float uy, float hl,
-                     float hw, float spd, float px, float py, float R, float hx, float hy, int NL) {
+                     float hw, float spd, float px, float py, float R, float hx, float hy, int NL, float ag_reach = 0.0f,
+                     bool* near_out = nullptr) {
   if (!OBJ) is_vehicle = true;
   bool in = present && o != a && shape_point_dist<OBJ>(Obb{x, y, ux, uy, hl, hw}, px, py) <= R;
+  if (near_out) {
+    const float reach = ag_reach + hl + (hw < 0.0f ? 0.0f : hw) + (spd * (1.0f / 3.6f) + 1.0f) * 0.105f + 0.05f;
+    const float ddx = x - px, ddy = y - py;
+    *near_out = present && o != a && ddx * ddx + ddy * ddy <= reach * reach;
+  }
   unsigned long long m = __ballot(in), mv_ = OBJ ? __ballot(in && is_vehicle) : m;
   if (in) {
     int k = __popcll(m & ((1ull << o) - 1ull));
@@ -165,9 +178,8 @@ DEV AgentView view_of_slot(const PgdDev& d, const MapView& mv, const VehRec* rec
   ag.dl = rc.dl; ag.dr = rc.dr;
   ag.v = spd_kmh == 0.0f ? 0.0f : rc.v;  // the snapshot says 0: an agent that finished in an EARLIER step (static body)
   ag.steer = rc.steer; ag.a0s = rc.a0s; ag.a0t = rc.a0t; ag.lhx = rc.lasthx; ag.lhy = rc.lasthy;
-  const RouteCtx ctx = route_ctx_of(rc);
-  ag.cur_first = ctx.cur_first; ag.cur_n = ctx.cur_n; ag.next_first = ctx.next_first;
-  ag.blk = ctx.blk; ag.toll_time = rc.php;
+  ag.cur_first = rc.cur_first; ag.cur_n = rc.cur_n; ag.next_first = rc.next_first;
+  ag.blk = rc.blk; ag.toll_time = rc.php;
   ag.env = env; ag.slot = o; ag.tick = tick;
   return ag;
 }

@@ -42,6 +42,19 @@ DEV bool succ_has(const int4& p, int id) {  // 8 packed int16 ids, unused entrie
 }
 DEV Obb snap_obb(const Snap& S, int k) { return Obb{S.x[k], S.y[k], S.ux[k], S.uy[k], S.hl[k], S.hw[k]}; }
 
+// Poses of every vehicle after the sub-steps of the physics BEFORE the last one (the last is the snapshot itself): contacts are
+// raised inside each doPhysics call (engine_core.py:276-278, collision_callback.py:7-36).  Lives in the same LDS bytes as
+// ObsLds (union ObsScratch, pgd_observe.h): the contact test is over before the observation scratch is first written.
+#define PGD_MAX_SUB 5
+#ifndef PGD_SUBV
+#define PGD_SUBV MAXV
+#endif
+struct SubPose {
+  float4 p[PGD_MAX_SUB - 1][PGD_SUBV];  // (x, y, unit vector of the MOTION direction) of the slot after sub-step k + 1
+  float2 beta[PGD_SUBV];                // (cos, sin) of the slip angle: heading = motion direction rotated back by it
+  float trav[PGD_SUBV];                 // path length of the slot in this step (0 = did not move: p[] is not written)
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 // sub-lane cooperation: a vehicle is carried by SUB consecutive lanes that hold identical copies of its registers; the
 // heavy box / neighbour loops are split across them and recombined with wave shuffles (all lanes of a group are always

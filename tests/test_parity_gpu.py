@@ -12,7 +12,7 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
-OBS_TOL = 2e-5
+OBS_TOL = 2.5e-5  # ray fractions: SURVEY 8c's 0.5 mm at the shortest fan range in the suite (20 m); state floats stay < 1e-5
 REW_TOL = 2e-4
 
 
@@ -760,3 +760,71 @@ def test_marl_config_combinations_fuzz():
             eng.set_state(f32, i, ei)
         assert st["obs"] < OBS_TOL and st["rew"] < REW_TOL and st["flag_mismatch"] <= 2 and im <= 2, (kind, na, cap, kw, st, im)
         eng.close()
+
+
+def _np_obb_overlap(ax, ay, ath, al, aw, bx, by, bth, bl, bw):
+    """Closed-rectangle SAT on arrays (chassis boxes length x width at heading th)."""
+    dx, dy = bx - ax, by - ay
+    aux, auy, bux, buy = np.cos(ath), np.sin(ath), np.cos(bth), np.sin(bth)
+    ac, as_ = np.abs(aux * bux + auy * buy), np.abs(aux * buy - auy * bux)
+    ahl, ahw, bhl, bhw = al / 2, aw / 2, bl / 2, bw / 2
+    sep = (np.abs(dx * aux + dy * auy) > ahl + bhl * ac + bhw * as_) | (np.abs(dy * aux - dx * auy) > ahw + bhl * as_ + bhw * ac) | \
+          (np.abs(dx * bux + dy * buy) > bhl + ahl * ac + ahw * as_) | (np.abs(dy * bux - dx * buy) > bhw + ahl * as_ + ahw * ac)
+    return ~sep
+
+
+def test_contacts_inside_the_sub_steps(descs):
+    """collision_callback.py:7-36 runs inside each of the 5 doPhysics calls of a step (engine_core.py:276-278): a fast car
+    that clips a corner in the middle of the 0.1 s step and is clear again at its end has crashed.  Egos are teleported next
+    to a waiting traffic vehicle at 10-25 m/s with random headings / steering; GPU and oracle must agree flag for flag, and
+    some of the crash_vehicle flags must belong to pairs whose END-of-step boxes do not overlap."""
+    n_envs = 512
+    torch, eng, ora, cfg = _engines(descs, n_envs, seed=21, auto_reset=0)  # no auto-reset: the state after the crash stays
+    scen_ids = np.arange(n_envs) % 8
+    ora.reset(scen_ids)
+    eng.reset(scen_ids)
+    sb = ora.scen_bank
+    V = sb.V
+    rng = np.random.default_rng(31)
+    SF, SI = _abi.SF, _abi.SI
+    stats = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
+    n_crash = n_mid_only = 0
+    f0, i0, ei0 = ora.get_state()
+    for rnd in range(8):
+        f, i, ei = f0.copy(), i0.copy(), ei0.copy()
+        tgt = np.zeros(n_envs, dtype=int)
+        for e in range(n_envs):
+            cand = np.nonzero(i[SI["STATUS"], e, 1:] == _abi.ST_PENDING)[0] + 1
+            k = int(cand[rng.integers(len(cand))])
+            tgt[e] = k
+            ang, dist = rng.uniform(0, 2 * np.pi), rng.uniform(2.2, 5.2)
+            f[SF["X"], e, 0] = f[SF["X"], e, k] + dist * np.cos(ang)
+            f[SF["Y"], e, 0] = f[SF["Y"], e, k] + dist * np.sin(ang)
+            f[SF["THETA"], e, 0] = rng.uniform(-np.pi, np.pi)
+            f[SF["SPEED"], e, 0] = rng.uniform(10.0, 25.0)
+            f[SF["HX"], e, 0] = f[SF["HY"], e, 0] = 0.0  # edited heading: the engine derives the vector from THETA
+        f32 = util.round_state_f32(f)
+        ora.set_state(f32, i, ei)
+        eng.set_state(f32, i, ei)
+        act = rng.uniform(-1, 1, size=(n_envs, 1, 2)).astype(np.float32)
+        _compare_step(torch, eng, ora, act, stats)
+        gf, gi, gei = eng.get_state()
+        fl = eng.flags.cpu().numpy().astype(np.uint32)[:, 0]
+        crash = (fl & _abi.F_CRASH_VEHICLE) != 0
+        ee = np.arange(n_envs)
+        spw = sb.spawns.reshape(-1, V) if sb.spawns.ndim == 1 else sb.spawns
+        sp_e = spw[scen_ids]
+        # end-of-step boxes of the ego and of EVERY other present body
+        cont = np.ones(n_envs, dtype=bool)
+        end_any = np.zeros(n_envs, dtype=bool)
+        for k in range(1, V):
+            pres = np.isin(gi[SI["STATUS"], :, k], (_abi.ST_PENDING, _abi.ST_ACTIVE))
+            end_any |= pres & _np_obb_overlap(gf[SF["X"], :, 0], gf[SF["Y"], :, 0], gf[SF["THETA"], :, 0], sp_e["length"][:, 0],
+                                              sp_e["width"][:, 0], gf[SF["X"], :, k], gf[SF["Y"], :, k], gf[SF["THETA"], :, k],
+                                              sp_e["length"][:, k], sp_e["width"][:, k])
+        n_crash += int(crash.sum())
+        n_mid_only += int((crash & cont & ~end_any).sum())
+        assert not (end_any & cont & ~crash).any()  # an overlap at the end of the step is a contact, always
+    print("sub-step contacts:", stats, "crash_vehicle", n_crash, "of which clear again at the end of the step", n_mid_only)
+    assert stats["flag_mismatch"] == 0 and stats["obs"] < OBS_TOL
+    assert n_crash > 300 and n_mid_only >= 5
