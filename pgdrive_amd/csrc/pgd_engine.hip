@@ -245,7 +245,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // _set_action / _set_incremental_action (base_vehicle.py:343-358)
     r.steer = (s < A && d.cfg.increment_steering) ? clipf(r.steer + st * 0.05f, -1.0f, 1.0f) : st;
     // (4) physics
-    dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0, tb, leader ? &SUBP : nullptr, slot, near_env);
+    dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0, tb, leader ? &SUBP : nullptr, slot, near_env && V <= PGD_SUBV);
     PHASE_MARK(3);  // dynamics
   }
   __syncthreads();
@@ -256,12 +256,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // the 0.1 s step.  Every body in the world tests itself against each agent of its env (A x V pair tests in parallel lanes):
   // first against the reach of the two paths (centre distance vs circumradii + path lengths: exact, never drops a contact),
   // then pose by pose.  Bodies that did not drive stand still.  Bullet's collision margin is not modelled (see the oracle).
-  const int n_mid = d.cfg.decision_repeat <= PGD_MAX_SUB ? d.cfg.decision_repeat - 1 : 0;
+  const int n_mid = (d.cfg.decision_repeat <= PGD_MAX_SUB && V <= PGD_SUBV) ? d.cfg.decision_repeat - 1 : 0;
   if (near_env) {
     const int my_kind = (OBJ && valid) ? s_kind[slot] : PGD_OBJ_VEHICLE;
     if (valid && S.present[slot] && (leader || (OBJ && my_kind != PGD_OBJ_VEHICLE))) {  // object sub-lanes all keep their copy of the bit
       const Obb me = snap_obb(S, slot);
-      const float my_trav = SUBP.trav[slot];
+      const float my_trav = V <= PGD_SUBV ? SUBP.trav[slot] : 0.0f;
       const float my_rad = me.hl + (me.hw < 0.0f ? 0.0f : me.hw);  // >= the circumradius
       // a traffic object reports only its first contact (TrafficObject.crashed / COST_ONCE, collision_callback.py:27-32)
       const bool live = !OBJ || my_kind == PGD_OBJ_VEHICLE || !(r.vflags & (int)PGD_F_OBJECT_HIT);
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       for (int a = 0; a < A; ++a) {
         if (a == s || (OBJ && !S.present[base + a])) continue;
         const Obb ag = snap_obb(S, base + a);
-        const float ag_trav = SUBP.trav[base + a];
+        const float ag_trav = V <= PGD_SUBV ? SUBP.trav[base + a] : 0.0f;
         const float reach = my_rad + ag.hl + ag.hw + my_trav + ag_trav + 0.01f;
         const float ddx = ag.cx - me.cx, ddy = ag.cy - me.cy;
         if (ddx * ddx + ddy * ddy > reach * reach) continue;

@@ -69,17 +69,15 @@ DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, flo
                      bool* near_out = nullptr) {
   if (!OBJ) is_vehicle = true;
   bool in = present && o != a && shape_point_dist<OBJ>(Obb{x, y, ux, uy, hl, hw}, px, py) <= R;
-  if (near_out) {
-    const float reach = ag_reach + hl + (hw < 0.0f ? 0.0f : hw) + (spd * (1.0f / 3.6f) + 1.0f) * 0.105f + 0.05f;
-    const float ddx = x - px, ddy = y - py;
-    *near_out = present && o != a && ddx * ddx + ddy * ddy <= reach * reach;
-  }
+  if (near_out) *near_out = false;
   unsigned long long m = __ballot(in), mv_ = OBJ ? __ballot(in && is_vehicle) : m;
   if (in) {
     int k = __popcll(m & ((1ull << o) - 1ull));
     L.bx[k] = x; L.by[k] = y; L.bux[k] = ux; L.buy[k] = uy; L.bhl[k] = hl; L.bhw[k] = hw; L.bspd[k] = spd;
     const float dist = norm2(px - x, py - y);
     L.bdist[k] = is_vehicle ? dist : __builtin_inff();
+    // (a body that can reach the agent within a step is inside the lidar broad phase a fortiori: R >= 20 m in every config)
+    if (near_out) *near_out = dist <= ag_reach + hl + (hw < 0.0f ? 0.0f : hw) + (spd * (1.0f / 3.6f) + 1.0f) * 0.105f + 0.05f;
     // the body lies inside the circle of radius rad around its centre: only beams within asin(rad / dist) of the centre
     // direction can reach it.  asin(q) <= q + (pi/2 - 1) q^3 on [0, 1]; 1.5 beams of slack cover the fp32 rounding of the
     // angle, so the culling never removes a hit and the cloud stays bit-identical to the all-pairs test.
