@@ -140,6 +140,9 @@ def parse_args(argv=None):
     ap.add_argument("--engines", type=int, default=1,
                     help="E independent engines of --envs environments each, on their own streams, stepped round-robin "
                          "(asynchronous vector-env groups): consecutive steps of different engines overlap on the GPU")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="split the --envs environments of the engine into G asynchronous env groups (pgd_set_groups / "
+                         "pgd_step_group): one 'step' = every group stepped once, the groups' launches overlap")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="plumbing tests: allow more ranks than GPUs (ranks share devices; needs --backend gloo)")
@@ -225,7 +228,14 @@ def run_rank(args, rank, world, local_rank):
     if "gather" in modes:
         gatherer = pdist.StepGather(torch, dist, N, D, A, device=dev, transport=args.transport, engine_lib=eng.L)
 
+    if args.groups > 1:
+        eng.set_groups(args.groups)
+
     def step_replica(k):
+        if args.groups > 1:
+            for g in range(args.groups):  # each group on its own internal stream: the launches overlap
+                eng.step_group(g, actions[(k + 5 * g) % CYC])
+            return
         eng.step(actions[k % CYC])
         for j, ej in enumerate(extra):  # each engine enqueues on its own stream: no ordering between engines
             with torch.cuda.stream(ej.stream):
@@ -236,6 +246,8 @@ def run_rank(args, rank, world, local_rank):
         gatherer.step(lambda rows: eng.step_packed(a, rows))
 
     def fence():
+        for g in range(args.groups if args.groups > 1 else 0):
+            eng.group_sync(g)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -315,7 +327,7 @@ def run_rank(args, rank, world, local_rank):
                         "of different engines overlap (asynchronous vector-env groups)" % (args.engines, N)}
                if args.engines > 1 else {}),
             "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
-            "engines_per_gpu": max(1, args.engines),
+            "engines_per_gpu": max(1, args.engines), "env_groups": args.groups,
             "parallelism": par, "backend": (args.backend if world > 1 else "none"),
             "steady_state": "pre-roll %d steps, %d timed steps (floors %d / %d%s)" % (
                 warm, timed, PREROLL_MIN, TIMED_MIN, ", off: --exact" if args.exact else ""),

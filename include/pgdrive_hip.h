@@ -254,6 +254,19 @@ int pgd_step(pgd_handle h, const float* d_actions /*[N,A,2]*/, float* d_obs /*[N
 int pgd_step_packed(pgd_handle h, const float* d_actions, float* d_rows /*[N,row_stride]*/, int row_stride,
                     float* d_reward /*[N,A]*/, uint8_t* d_done /*[N,A]*/, uint32_t* d_flags /*[N,A]*/);
 
+/* Asynchronous env groups (double-buffered sampling: the policy of group A runs while group B steps).  The reference runs
+ * one env per process and lets the RL library interleave processes; here one handle is split into n_groups equal, contiguous
+ * groups of envs, each with an internal stream.  pgd_step_group steps ONLY the envs of `group` on that group's stream --
+ * consecutive steps of different groups overlap on the GPU (a launch ends with its slowest wave; another group's step fills
+ * that tail).  All pointers address the FULL [N, ...] arrays; only the group's rows are read / written.  pgd_group_stream
+ * hands out the stream so that the caller can order its own kernels (the policy) with the group's steps; work submitted
+ * through pgd_step / pgd_reset (engine stream) is NOT ordered against the group streams: synchronise when switching. */
+int pgd_set_groups(pgd_handle h, int n_groups);   /* N % n_groups == 0; 1 = back to a single group */
+int pgd_step_group(pgd_handle h, int group, const float* d_actions /*[N,A,2]*/, float* d_obs /*[N,A,D]*/, float* d_reward,
+                   uint8_t* d_done, uint32_t* d_flags);
+int pgd_group_stream(pgd_handle h, int group, void** hip_stream);
+int pgd_group_sync(pgd_handle h, int group);
+
 /* Checkpoint / resume (BaseVehicle.get_state/set_state, base_vehicle.py:683-698): raw SoA state blobs.
  * Layout: nf float fields then ni int fields, each [N*V]; query sizes with pgd_state_dims. HOST buffers. */
 int pgd_state_dims(pgd_handle h, int* n_float_fields, int* n_int_fields, int* n_env_int_fields);

@@ -50,6 +50,7 @@ struct PgdDev {
   int ostride;
   float* prow;
   int dbg_exit;  // exit-profile builds only (PGD_EXITAT)
+  int unit_off;  // first block unit of this launch (pgd_step_group); 0 for a whole-engine step
 };
 
 // Device-side vehicle record = the per-lane register image of a vehicle (device-private; pgd_get_state / pgd_set_state

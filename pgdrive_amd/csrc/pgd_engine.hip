@@ -120,8 +120,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   __shared__ uint8_t s_kind[WAVE]; // PGD_OBJ_* of every slot (fused observation: objects are lidar targets, not neighbours)
   const int V = d.V, A = d.A, N = d.N;
   const int lane = threadIdx.x;
-  const LaneMap lm = lane_map(d, blockIdx.x, N);
-  const int el = ONE_ENV ? 0 : lm.el, s = lm.s, e = ONE_ENV ? (int)blockIdx.x : lm.e, base = ONE_ENV ? 0 : lm.base;
+  const int unit = (int)blockIdx.x + d.unit_off;  // pgd_step_group launches only the blocks of one env group
+  const LaneMap lm = lane_map(d, unit, N);
+  const int el = ONE_ENV ? 0 : lm.el, s = lm.s, e = ONE_ENV ? unit : lm.e, base = ONE_ENV ? 0 : lm.base;
   const bool valid = lm.valid, leader = lm.sub == 0;
   const Grp g{lm.sub, d.sub, lm.lead};
   const int slot = base + s;  // my entry of the LDS snapshot
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     const pgd_config& gcf = d.cfg;
     const bool toll = (gcf.marl_flags & PGD_MA_TOLLGATE) != 0;
     const bool parking = (gcf.marl_flags & PGD_MA_PARKING) != 0;
-    if (parking && lane == 0) s_aux = d.ei[(size_t)blockIdx.x * PGD_NEI + EI_AUX];  // parking_space_available
+    if (parking && lane == 0) s_aux = d.ei[(size_t)e * PGD_NEI + EI_AUX];  // parking_space_available
     if (parking) __syncthreads();
     if (valid && s < A && was_active) {
       if (toll && r.blk == '$') r.php += 1.0f;  // TollGateObservation.observe counts its calls inside the toll block
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     __syncthreads();
     const bool is_lead_agent = valid && leader && s < A;
     int alive = __popcll(__ballot(is_lead_agent && (r.status == ST_ACTIVE || r.status == ST_DYING)));
-    int next_agent = d.ei[(size_t)blockIdx.x * PGD_NEI + EI_NEXT_AGENT];
+    int next_agent = d.ei[(size_t)e * PGD_NEI + EI_NEXT_AGENT];
     const bool allow = (gcf.marl_flags & PGD_MA_ALLOW_RESPAWN) && !(gcf.horizon > 0 && ep_steps >= gcf.horizon) &&
                        alive < gcf.agent_limit;
     if (allow) {
@@ -392,12 +393,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         if (em == 0ull) break;
         const int src = __builtin_ffsll((long long)em) - 1;
         const int tslot = (src / d.sub) % V;
-        int dest = (int)(pgd_rng(gcf.seed, (uint32_t)(gcf.env_base + (int)blockIdx.x), 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
+        int dest = (int)(pgd_rng(gcf.seed, (uint32_t)(gcf.env_base + e), 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
                          (uint32_t)gcf.respawn_dests);
         if (parking) {  // get_parking_space: a random one of the free spaces; none -> nobody enters from a road
           const unsigned mask = (unsigned)s_aux & ((1u << gcf.respawn_dests) - 1u);
           if (__ballot(mask != 0u) == 0ull) break;
-          int pick = (int)(pgd_rng(gcf.seed, (uint32_t)(gcf.env_base + (int)blockIdx.x), 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
+          int pick = (int)(pgd_rng(gcf.seed, (uint32_t)(gcf.env_base + e), 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
                            (uint32_t)__popc(mask));
           dest = 0;
           for (int b = 0; b < 32; ++b)
@@ -439,10 +440,10 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       my_fl |= PGD_F_ALL_DONE;
       if (gcf.auto_reset) { my_fl |= PGD_F_RESET; s_flag[el] = 1; }
     }
-    if (lane == 0) d.ei[(size_t)blockIdx.x * PGD_NEI + EI_NEXT_AGENT] = next_agent;
+    if (lane == 0) d.ei[(size_t)e * PGD_NEI + EI_NEXT_AGENT] = next_agent;
     if (parking) {
       __syncthreads();
-      if (lane == 0) d.ei[(size_t)blockIdx.x * PGD_NEI + EI_AUX] = s_aux;
+      if (lane == 0) d.ei[(size_t)e * PGD_NEI + EI_AUX] = s_aux;
     }
   }
   __syncthreads();
@@ -549,14 +550,14 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       near_any = near_any || near_a;
       __syncthreads();
       PHASE_MARK(21);  // obs: compaction
-      observe_agent<OBJ, STD>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + (size_t)blockIdx.x * d.ostride + (size_t)a * d.D, lane,
+      observe_agent<OBJ, STD>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + (size_t)e * d.ostride + (size_t)a * d.D, lane,
                     WAVE);
       __syncthreads();
     }
     // hint for the next step's contact tests (EI_NEAR); without a lidar the compaction looked at nothing: always test
     near_next = d.cfg.num_lasers > 0 ? (__ballot(near_any) != 0ull) : true;
   }
-  if (ONE_ENV && lane == 0 && (int)near_next != (int)near_env) d.ei[(size_t)blockIdx.x * PGD_NEI + EI_NEAR] = near_next ? 1 : 0;
+  if (ONE_ENV && lane == 0 && (int)near_next != (int)near_env) d.ei[(size_t)e * PGD_NEI + EI_NEAR] = near_next ? 1 : 0;
   PHASE_MARK(14);  // fused observation
   XMARK(14);
   PHASE_END();
@@ -667,7 +668,7 @@ template <int BLOCK, bool OTH>
 __global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags) {
   __shared__ ObsLds L;
   const int V = d.V, A = d.A, D = d.D;
-  const int e = blockIdx.x / A, a = blockIdx.x - e * A;
+  const int e = (int)blockIdx.x / A + d.unit_off * d.epw, a = (int)blockIdx.x % A;
   const int tid = threadIdx.x;
   const VehRec* recs = d.rec + (size_t)e * V;  // the env's vehicle records
   const VehRec& mine = recs[a];
@@ -761,6 +762,8 @@ struct pgd_engine {
   std::vector<hipEvent_t>* prof_ev;  // 3 events per recorded step
   int prof_cap, prof_n, prof_stride, prof_tick;
   bool prof_grouped;
+  int n_groups;          // env groups of pgd_set_groups (1 = none)
+  hipStream_t* gstreams; // [n_groups] internal streams
   bool derive_pending;  // records were written through the ABI or the tables changed: k_derive has to run
   bool has_objects;  // some spawn record is a traffic object (pgd_upload_scenarios): selects the OBJ kernels
   bool step_timing;  // record ev0 / ev1 around every step (pgd_last_step_ms)
@@ -844,6 +847,8 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->d.ostride = h->d.A * h->d.D;
   h->d.prow = nullptr;
   h->d.dbg_exit = -1;
+  h->d.unit_off = 0;
+  h->n_groups = 1;
   const bool marl = (cfg->marl_flags & PGD_MA_ENABLED) != 0;
   // multi-agent engines have no IDM traffic; num_traffic slots may hold static bodies (toll booths, group PGD_GROUP_NEVER)
   if (marl && (cfg->respawn_places < 0 || cfg->respawn_dests < 0)) return PGD_ERR_ARG;
@@ -1025,14 +1030,16 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   return build_reset_image(h);
 }
 
-static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, const PgdDev* dv = nullptr) {
+static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, const PgdDev* dv = nullptr, hipStream_t stream = nullptr,
+                          int n_envs = 0) {
   const PgdDev& D = dv ? *dv : h->d;
-  int blocks = h->d.N * h->d.A;
+  if (!stream) stream = h->stream;
+  int blocks = (n_envs > 0 ? n_envs : h->d.N) * h->d.A;
   const bool oth = (h->d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && h->d.cfg.num_others > 0;
   const bool wide = h->d.cfg.num_lasers > 128;  // up to 128 beams one wave does it in two rounds: 4x fewer waves than 256-thread blocks
   void (*kern)(PgdDev, float*, const uint32_t*) =
       wide ? (oth ? k_observe<256, true> : k_observe<256, false>) : (oth ? k_observe<64, true> : k_observe<64, false>);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(wide ? 256 : 64), 0, h->stream, D, d_obs, d_flags);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(wide ? 256 : 64), 0, stream, D, d_obs, d_flags);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }
@@ -1068,7 +1075,7 @@ int pgd_reset(pgd_handle h, const int32_t* env_ids, const int32_t* scen_ids, int
 }
 
 static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done, uint32_t* d_flags,
-                     int ostride, bool packed) {
+                     int ostride, bool packed, int group = -1) {
   if (!h || !d_actions || !d_reward || !d_done || !d_flags) return PGD_ERR_ARG;
   if (!h->have_maps || !h->have_scen) return PGD_ERR_STATE;
   if (h->img_dirty) return PGD_ERR_STATE;  // the reset image is built by the upload calls
@@ -1076,9 +1083,18 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   PgdDev dv = h->d;  // this launch's output addressing
   dv.ostride = ostride;
   dv.prow = packed ? d_obs : nullptr;
+  // env group: the blocks (and the stream) of envs [group * N / G, (group + 1) * N / G); -1 = all envs on the engine stream
+  hipStream_t stream = h->stream;
+  int n_env_launch = h->d.N;
+  if (group >= 0) {
+    if (group >= h->n_groups || !h->gstreams) return PGD_ERR_ARG;
+    n_env_launch = h->d.N / h->n_groups;
+    dv.unit_off = group * n_env_launch / h->d.epw;
+    stream = h->gstreams[group];
+  }
   const bool marl = (h->d.cfg.marl_flags & PGD_MA_ENABLED) != 0;
   const bool fuse = d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse;
-  bool prof = h->prof_ev && h->prof_n < h->prof_cap;
+  bool prof = h->prof_ev && h->prof_n < h->prof_cap && group < 0;
   // strided profile: with the observation fused (one kernel per step) events [0] / [1] bracket a GROUP of `stride`
   // back-to-back launches and the group time is divided by the stride; otherwise every stride-th step is bracketed
   const bool grouped = prof && h->prof_stride > 1 && fuse;
@@ -1089,9 +1105,9 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
     else prof = ph == 0;
   }
   hipEvent_t* pe = (prof || g_open || g_close) ? &(*h->prof_ev)[(size_t)h->prof_n * 3] : nullptr;
-  const bool timing = h->step_timing && !prof && !grouped;
+  const bool timing = h->step_timing && !prof && !grouped && group < 0;
   if (prof || timing || g_open) HIPCHK(hipEventRecord((prof || g_open) ? pe[0] : h->ev0, h->stream));
-  int blocks = (h->d.N + h->d.epw - 1) / h->d.epw;
+  int blocks = (n_env_launch + h->d.epw - 1) / h->d.epw;
   if (marl && h->d.epw != 1) return PGD_ERR_STATE;  // the multi-agent tail needs the env in one wave (V >= 33 or SUB split)
   void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*) = k_step<false, false, false>;
   if (marl) kern = h->has_objects ? k_step<true, true, true> : k_step<true, true, false>;  // objects = toll booths
@@ -1102,13 +1118,13 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
     kern = h->has_objects ? k_step<true, false, true> : (std_obs ? k_step<true, false, false, true> : k_step<true, false, false>);
   }
   else if (h->has_objects) kern = k_step<false, false, true>;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), 0, h->stream, dv, d_actions, d_reward, d_done,
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), 0, stream, dv, d_actions, d_reward, d_done,
                      d_flags, fuse ? d_obs : (float*)nullptr);
   HIPCHK(hipGetLastError());
   if (prof || g_close) HIPCHK(hipEventRecord(pe[1], h->stream));
   if (g_close) h->prof_n += 1;
   if (d_obs && !fuse) {
-    int rc = launch_observe(h, d_obs, marl ? d_flags : (const uint32_t*)nullptr, &dv);
+    int rc = launch_observe(h, d_obs, marl ? d_flags : (const uint32_t*)nullptr, &dv, stream, n_env_launch);
     if (rc) return rc;
   }
   h->prof_fused = fuse;
@@ -1128,6 +1144,42 @@ int pgd_step_packed(pgd_handle h, const float* d_actions, float* d_rows, int row
                     uint32_t* d_flags) {
   if (!h || !d_rows || row_stride < h->d.A * (h->d.D + 2)) return PGD_ERR_ARG;
   return step_impl(h, d_actions, d_rows, d_reward, d_done, d_flags, row_stride, true);
+}
+
+/* ---- env groups: asynchronous vector-env groups inside one handle ---------------------------------------------------- */
+int pgd_set_groups(pgd_handle h, int n_groups) {
+  if (!h || n_groups < 1 || n_groups > 64) return PGD_ERR_ARG;
+  if (h->d.N % n_groups != 0 || (h->d.N / n_groups) % h->d.epw != 0) return PGD_ERR_ARG;  // equal groups of whole waves
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->gstreams) {
+    for (int g = 0; g < h->n_groups; ++g) { (void)hipStreamSynchronize(h->gstreams[g]); (void)hipStreamDestroy(h->gstreams[g]); }
+    free(h->gstreams);
+    h->gstreams = nullptr;
+  }
+  h->n_groups = n_groups;
+  if (n_groups > 1) {
+    h->gstreams = (hipStream_t*)calloc((size_t)n_groups, sizeof(hipStream_t));
+    for (int g = 0; g < n_groups; ++g) HIPCHK(hipStreamCreateWithFlags(&h->gstreams[g], hipStreamNonBlocking));
+  }
+  return PGD_OK;
+}
+
+int pgd_step_group(pgd_handle h, int group, const float* d_actions, float* d_obs, float* d_reward, uint8_t* d_done, uint32_t* d_flags) {
+  if (!h || group < 0) return PGD_ERR_ARG;
+  return step_impl(h, d_actions, d_obs, d_reward, d_done, d_flags, h->d.A * h->d.D, false, group);
+}
+
+int pgd_group_stream(pgd_handle h, int group, void** hip_stream) {
+  if (!h || !hip_stream || group < 0 || group >= h->n_groups || !h->gstreams) return PGD_ERR_ARG;
+  *hip_stream = (void*)h->gstreams[group];
+  return PGD_OK;
+}
+
+int pgd_group_sync(pgd_handle h, int group) {
+  if (!h || group < 0 || group >= h->n_groups || !h->gstreams) return PGD_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->gstreams[group]));
+  return PGD_OK;
 }
 
 int pgd_observe(pgd_handle h, float* d_obs) {
@@ -1344,6 +1396,10 @@ int pgd_destroy(pgd_handle h) {
   if (h->prof_ev) {
     for (hipEvent_t ev : *h->prof_ev) (void)hipEventDestroy(ev);
     delete h->prof_ev;
+  }
+  if (h->gstreams) {
+    for (int g = 0; g < h->n_groups; ++g) { (void)hipStreamSynchronize(h->gstreams[g]); (void)hipStreamDestroy(h->gstreams[g]); }
+    free(h->gstreams);
   }
   delete h->h_maps;
   delete h->h_scen;

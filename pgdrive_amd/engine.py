@@ -25,6 +25,10 @@ _SIGS = {
     "pgd_get_state": (C.c_int, [C.c_void_p] * 4),
     "pgd_set_state": (C.c_int, [C.c_void_p] * 4),
     "pgd_observe": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pgd_set_groups": (C.c_int, [C.c_void_p, C.c_int]),
+    "pgd_step_group": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5),
+    "pgd_group_stream": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "pgd_group_sync": (C.c_int, [C.c_void_p, C.c_int]),
     "pgd_last_step_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "pgd_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "pgd_profile_begin_strided": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
@@ -180,6 +184,35 @@ class Engine:
         _chk(self.L.pgd_step_packed(self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(rows.data_ptr()),
                                     int(rows.stride(0)), p_rew, p_done, p_flags), "pgd_step_packed")
         return rows, self.reward, self.done, self.flags
+
+    # -- asynchronous env groups ----------------------------------------------------------------------------------------
+    def set_groups(self, n_groups):
+        """Split the envs into `n_groups` equal contiguous groups with their own internal streams (pgd_set_groups)."""
+        self.torch.cuda.synchronize(self.device)
+        _chk(self.L.pgd_set_groups(self.h, int(n_groups)), "pgd_set_groups")
+        self.n_groups = int(n_groups)
+        self.group_streams = []
+        for g in range(self.n_groups if n_groups > 1 else 0):
+            p = C.c_void_p()
+            _chk(self.L.pgd_group_stream(self.h, g, C.byref(p)), "pgd_group_stream")
+            self.group_streams.append(self.torch.cuda.ExternalStream(p.value, device=self.device))
+
+    def group_slice(self, g):
+        n = self.N // self.n_groups
+        return slice(g * n, (g + 1) * n)
+
+    def step_group(self, g, actions):
+        """Step only the envs of group g, asynchronously on the group's stream; `actions` is the full [N, A, 2] tensor.
+        Returns views of the group's rows of the engine's output buffers."""
+        assert actions.is_cuda and actions.dtype == self.torch.float32 and actions.is_contiguous()
+        assert actions.numel() == self.N * self.A * 2
+        p_obs, p_rew, p_done, p_flags = self._own_ptrs
+        _chk(self.L.pgd_step_group(self.h, int(g), C.c_void_p(actions.data_ptr()), p_obs, p_rew, p_done, p_flags), "pgd_step_group")
+        sl = self.group_slice(g)
+        return self.obs[sl], self.reward[sl], self.done[sl], self.flags[sl]
+
+    def group_sync(self, g):
+        _chk(self.L.pgd_group_sync(self.h, int(g)), "pgd_group_sync")
 
     def observe(self):
         _chk(self.L.pgd_observe(self.h, C.c_void_p(self.obs.data_ptr())), "pgd_observe")
