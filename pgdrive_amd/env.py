@@ -67,17 +67,42 @@ class PGDriveEnv:
         info = {k: bool(np.asarray(v).reshape(-1)[0]) for k, v in self.vec.info_from_flags(np.array([fl])).items()}
         cost = float(self.vec.cost_from_flags(np.array([fl]))[0])  # cost_function (pgdrive_env.py:197-207)
         energy = float(f[_abi.SF["ENERGY"], 0, 0])
+        # step_reward is the shaping reward BEFORE the terminal override (pgdrive_env.py:236-246); a terminal step's is
+        # re-derived on the host from the state the engine left (single env: a few lane formulas)
+        shaping = r if not (info["arrive_dest"] or info["out_of_road"] or info["crash_vehicle"] or info["crash_object"]) \
+            else self._shaping_reward(f, i)
         raw = np.asarray(action, dtype=np.float64).reshape(-1)
         # the keys of BaseVehicle.after_step (base_vehicle.py:255-273), _preprocess_action (:231-236), reward / cost / done
         # functions (pgdrive_env.py:162-258) and _get_step_return (base_env.py:303-344)
         info.update(
             cost=cost, velocity=abs(float(f[_abi.SF["SPEED"], 0, 0])) * 3.6, steering=float(f[_abi.SF["STEER"], 0, 0]),
-            acceleration=float(f[_abi.SF["THROTTLE"], 0, 0]), step_reward=r, episode_reward=self.episode_reward,
+            acceleration=float(f[_abi.SF["THROTTLE"], 0, 0]), step_reward=shaping, episode_reward=self.episode_reward,
             episode_length=self.episode_steps, episode_energy=energy, step_energy=energy - self._last_energy,
             raw_action=(float(raw[0]), float(raw[1])), overtake_vehicle_num=0,  # overtake_stat cannot be on (vec_env.py)
         )
         self._last_energy = energy
         return obs[0].cpu().numpy(), r, d, info
+
+    def _shaping_reward(self, f, i):
+        """PGDriveEnv.reward_function up to `step_info["step_reward"] = reward` (pgdrive_env.py:209-236) from the state."""
+        from . import mapdata
+        SF, SI, c = _abi.SF, _abi.SI, self.config
+        scen = int(self.vec.engine.get_state()[2][_abi.EI["SCEN"], 0])
+        sb, mb = self.vec.scen_bank, self.vec.map_bank
+        d = mb.descs[int(sb.scenarios["map"][scen])]
+        sp = sb.spawns[scen * sb.V]
+        lane = d["lanes"][int(i[SI["LANE"], 0, 0])]
+        cur_road = int(sp["ckpt_road"][int(i[SI["CK0"], 0, 0])])
+        road = d["roads"][cur_road]
+        positive = 1.0
+        if lane["road"] != cur_road:  # off the reference lanes: first reference lane, sign of the road the car is on
+            positive = -1.0 if d["roads"][lane["road"]]["negative"] else 1.0
+            lane = d["lanes"][road["first_lane"]]
+        l0, _ = mapdata.lane_local_coordinates(lane, (float(f[SF["LASTX"], 0, 0]), float(f[SF["LASTY"], 0, 0])))
+        l1, t1 = mapdata.lane_local_coordinates(lane, (float(f[SF["X"], 0, 0]), float(f[SF["Y"], 0, 0])))
+        lateral = min(max(1.0 - 2.0 * abs(t1) / d["lane_width"], 0.0), 1.0) if c["use_lateral"] else 1.0
+        speed_kmh = abs(float(f[SF["SPEED"], 0, 0])) * 3.6
+        return c["driving_reward"] * (l1 - l0) * lateral * positive + c["speed_reward"] * (speed_kmh / float(sp["max_speed"])) * positive
 
     def seed(self, seed=None):
         self.vec.seed(seed)

@@ -240,9 +240,11 @@ class MultiAgentRoundaboutEnv:
         for k, s in self._slots.items():  # extra keys are ignored like base_env.py:205-212
             if k in actions:
                 a[0, s] = np.asarray(actions[k], dtype=np.float32)
+        f0, i0, _ = self.vec.engine.get_state()  # episode_reward / episode_length of the agents that are about to act
         obs, rew, done, flags = self.vec.step(self._torch.from_numpy(a).to(self.vec.engine.device))
         self.vec.engine.sync()
         obs, rew, done = obs[0].cpu().numpy(), rew[0].cpu().numpy(), done[0].cpu().numpy()
+        f1, i1, _ = self.vec.engine.get_state()
         fl = flags[0].cpu().numpy().astype(np.uint32)
         self.episode_steps += 1
         o, r, d, info = {}, {}, {}, {}
@@ -252,9 +254,17 @@ class MultiAgentRoundaboutEnv:
             info[k] = dict(
                 arrive_dest=bool(fl[s] & _abi.F_ARRIVE), out_of_road=bool(fl[s] & _abi.F_OUT_OF_ROAD),
                 crash_vehicle=bool(fl[s] & _abi.F_CRASH_VEHICLE), crash=bool(fl[s] & _abi.F_CRASH_VEHICLE),
+                crash_object=bool(fl[s] & _abi.F_CRASH_OBJECT), crash_building=bool(fl[s] & _abi.F_CRASH_BUILDING),
                 max_step=bool(fl[s] & _abi.F_MAX_STEP), step_reward=float(rew[s]),
                 cost=1 if (fl[s] & _abi.F_CRASH_VEHICLE and not fl[s] & _abi.F_OUT_OF_ROAD) else 0,
+                # _get_step_return (base_env.py:335-339) and BaseVehicle.after_step (base_vehicle.py:255-273)
+                episode_reward=float(f0[_abi.SF["EP_REWARD"], 0, s]) + float(rew[s]),
+                episode_length=int(i0[_abi.SI["RLANE"], 0, s]) + 1,
+                raw_action=(float(a[0, s, 0]), float(a[0, s, 1])),
             )
+            if i1[_abi.SI["SPAWN"], 0, s] == i0[_abi.SI["SPAWN"], 0, s] and f1[_abi.SF["AGENT_ID"], 0, s] == f0[_abi.SF["AGENT_ID"], 0, s]:
+                info[k].update(velocity=abs(float(f1[_abi.SF["SPEED"], 0, s])) * 3.6, steering=float(f1[_abi.SF["STEER"], 0, s]),
+                               acceleration=float(f1[_abi.SF["THROTTLE"], 0, s]))  # the slot still holds this agent
         all_done = bool(fl[0] & _abi.F_ALL_DONE)
         self._refresh_slots()
         if not all_done:

@@ -382,8 +382,11 @@ def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=
     n_groups = 0
     dropped = 0
     for g in groups:
-        if n_groups >= MAX_GROUPS:
-            break
+        if n_groups >= MAX_GROUPS:  # more traffic blocks than pgd_scenario.trigger_road holds: counted like slot-cap drops
+            for v in g["vehicles"]:
+                engine_rng.randint(0, MAX_RAND_INT)
+                dropped += 1
+            continue
         if not respawn:
             scen["trigger_road"][n_groups] = g["trigger_road"]
         for v in g["vehicles"]:

@@ -15,8 +15,8 @@ from .spaces import Box, MultiDiscrete
 # Reference defaults this build honours (pgdrive_env.py:22-109, base_env.py:19-90)
 DEFAULT_CONFIG = dict(
     num_envs=1,
-    start_seed=1000,  # PGDrive-v0 (register.py:14-17)
-    environment_num=100,
+    start_seed=0,  # the reference's defaults (base_env.py:20-21, pgdrive_env.py:24-25); gym ids set their own ranges
+    environment_num=1,  # (pgdrive_amd.env.ENV_IDS = register.py:5-38, e.g. PGDrive-v0: start_seed 1000, 100 maps)
     map=3,
     map_config=dict(lane_width=3.5, lane_num=3, exit_length=50),
     random_lane_width=False,  # a lane width per map seed, uniform in [3.0, 4.5) (map_manager.py:157-163)
@@ -181,6 +181,13 @@ class PGDriveVecEnv:
             traffic_seeds=np.random.RandomState(c["seed"]).randint(0, scenario.MAX_RAND_INT, len(seeds))
             if c["random_traffic"] else None
         )
+        # the reference has no cap on traffic vehicles / objects: say so when the slot caps cut a scenario short
+        lost = sum(i["dropped"] for i in self.scen_bank.info), sum(i["objects_dropped"] for i in self.scen_bank.info)
+        if lost[0] or lost[1]:
+            import warnings
+            warnings.warn("pgdrive_amd: %d traffic vehicles and %d traffic objects of the reference's scenarios do not fit the slot "
+                          "caps (max_traffic_vehicles=%d, max_traffic_objects=%d): raise the caps to reproduce the reference's "
+                          "traffic" % (lost[0], lost[1], c["max_traffic_vehicles"], c["max_traffic_objects"]))
         lid, sd, ld = vc["lidar"], vc["side_detector"], vc["lane_line_detector"]
         nl = lid["num_lasers"] if lid["distance"] > 0 else 0
         self.cfg = _abi.make_config(
@@ -211,7 +218,11 @@ class PGDriveVecEnv:
 
     def reset(self, force_seed=None):
         """Reset every env; `force_seed` (int or array) pins the map seed(s), else seeds are drawn uniformly from
-        [start_seed, start_seed + environment_num) (base_env.py:451-458).  Returns a cuda float32 tensor [N, D]."""
+        [start_seed, start_seed + environment_num) (base_env.py:451-458).  Returns a cuda float32 tensor [N, D].
+
+        The tensors returned by reset() / step() are VIEWS of the engine's own output buffers, which the next step
+        overwrites (no per-step allocation): a rollout buffer must copy what it keeps (`.clone()`), or pass its own buffers
+        through `Engine.step(out=...)`."""
         if force_seed is None:
             ids = self._rng.randint(0, len(self.seeds), size=self.num_envs)
         else:
