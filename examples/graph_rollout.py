@@ -27,7 +27,7 @@ def main():
     torch.manual_seed(0)
     policy = torch.nn.Sequential(torch.nn.Linear(274, 256), torch.nn.Tanh(), torch.nn.Linear(256, 256), torch.nn.Tanh(),
                                  torch.nn.Linear(256, 2), torch.nn.Tanh()).cuda()
-    env = PGDriveVecEnv(dict(num_envs=args.envs))
+    env = PGDriveVecEnv(dict(num_envs=args.envs, start_seed=1000, environment_num=100))
     obs = env.reset()  # the engine's own observation buffer: env.step() rewrites it in place
     ret = torch.zeros(1, device=obs.device)
 

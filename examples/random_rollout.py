@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--envs", type=int, default=32768)
     ap.add_argument("--steps", type=int, default=500)
     args = ap.parse_args()
-    env = PGDriveVecEnv(dict(num_envs=args.envs))  # PGDrive-v0: seeds 1000..1099, 1 ego + IDM traffic, 240 lidar beams
+    env = PGDriveVecEnv(dict(num_envs=args.envs, start_seed=1000, environment_num=100))  # PGDrive-v0: seeds 1000..1099, 1 ego + IDM traffic, 240 lidar beams
     obs = env.reset()  # cuda float32 [N, 274]
     episodes = torch.zeros(1, dtype=torch.int64, device=obs.device)  # counted on the device: no host sync inside the loop
     for _ in range(20):  # warm-up: the first calls of every torch op load their kernels

@@ -139,6 +139,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // EI_NEAR, left by the observation of the previous step: 0 = no body of the env can reach an agent during this step, so no
   // sub-step pose is kept and no contact test runs; anything else (and every engine without the fused observation) tests
   bool near_env = true;
+#ifdef PGD_NO_SUBSTEP
+  constexpr bool n_mid_enabled = false;
+#else
+  constexpr bool n_mid_enabled = true;
+#endif
   S.present[lane] = 0;
   s_flag[lane] = 0;
   s_hit[lane] = 0;
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // _set_action / _set_incremental_action (base_vehicle.py:343-358)
     r.steer = (s < A && d.cfg.increment_steering) ? clipf(r.steer + st * 0.05f, -1.0f, 1.0f) : st;
     // (4) physics
-    dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0, tb, leader ? &SUBP : nullptr, slot, near_env && V <= PGD_SUBV);
+    dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0, tb, leader ? &SUBP : nullptr, slot, near_env && V <= PGD_SUBV && n_mid_enabled);
     PHASE_MARK(3);  // dynamics
   }
   __syncthreads();
@@ -257,7 +262,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // the 0.1 s step.  Every body in the world tests itself against each agent of its env (A x V pair tests in parallel lanes):
   // first against the reach of the two paths (centre distance vs circumradii + path lengths: exact, never drops a contact),
   // then pose by pose.  Bodies that did not drive stand still.  Bullet's collision margin is not modelled (see the oracle).
+#ifdef PGD_NO_SUBSTEP
+  const int n_mid = 0;
+#else
   const int n_mid = (d.cfg.decision_repeat <= PGD_MAX_SUB && V <= PGD_SUBV) ? d.cfg.decision_repeat - 1 : 0;
+#endif
   if (near_env) {
     const int my_kind = (OBJ && valid) ? s_kind[slot] : PGD_OBJ_VEHICLE;
     if (valid && S.present[slot] && (leader || (OBJ && my_kind != PGD_OBJ_VEHICLE))) {  // object sub-lanes all keep their copy of the bit

@@ -93,7 +93,7 @@ def test_checkpoint_resume_roundtrip():
     """get_state -> set_state reproduces the same next step bit-for-bit (BaseVehicle.get_state/set_state)."""
     import torch
     from pgdrive_amd.vec_env import PGDriveVecEnv
-    env = PGDriveVecEnv(dict(num_envs=64, seed=1, resample_scenario=False))
+    env = PGDriveVecEnv(dict(num_envs=64, seed=1, resample_scenario=False, start_seed=1000, environment_num=100))
     try:
         env.reset(force_seed=[1000 + (k % 10) for k in range(64)])
         a = torch.zeros((64, 2), device="cuda")
@@ -326,7 +326,7 @@ def test_obs_noise_config():
     """tests/test_functionality/test_obs_noise.py:23-58: dropout 1.0 wipes the whole lidar cloud, the observation stays
     inside its space for every corner action; 0 / 0 leaves the cloud untouched."""
     from pgdrive_amd.env import PGDriveEnv
-    env = PGDriveEnv({"environment_num": 2, "vehicle_config": {"lidar": {"gaussian_noise": 1.0, "dropout_prob": 1.0}}})
+    env = PGDriveEnv({"start_seed": 1000, "environment_num": 2, "vehicle_config": {"lidar": {"gaussian_noise": 1.0, "dropout_prob": 1.0}}})
     try:
         o = env.reset()
         assert env.observation_space.contains(o) and (o[-240:] == 0.0).all()
@@ -340,7 +340,7 @@ def test_obs_noise_config():
                     assert k in info
     finally:
         env.close()
-    env = PGDriveEnv({"environment_num": 2, "traffic_density": 0.0})
+    env = PGDriveEnv({"start_seed": 1000, "environment_num": 2, "traffic_density": 0.0})
     try:
         assert (env.reset()[-240:] == 1.0).all()
     finally:
@@ -375,8 +375,8 @@ def test_step_captured_in_a_hip_graph_matches_eager():
     import torch
     from pgdrive_amd import PGDriveVecEnv
     n = 256
-    eager = PGDriveVecEnv(dict(num_envs=n, seed=3))
-    graphed = PGDriveVecEnv(dict(num_envs=n, seed=3))
+    eager = PGDriveVecEnv(dict(num_envs=n, seed=3, start_seed=1000, environment_num=100))
+    graphed = PGDriveVecEnv(dict(num_envs=n, seed=3, start_seed=1000, environment_num=100))
     eager.reset(force_seed=np.arange(n) % 100 + 1000)
     graphed.reset(force_seed=np.arange(n) % 100 + 1000)
     g = torch.Generator(device="cuda")
