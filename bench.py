@@ -143,6 +143,9 @@ def parse_args(argv=None):
     ap.add_argument("--groups", type=int, default=1,
                     help="split the --envs environments of the engine into G asynchronous env groups (pgd_set_groups / "
                          "pgd_step_group): one 'step' = every group stepped once, the groups' launches overlap")
+    ap.add_argument("--topdown", action="store_true",
+                    help="c3 with the top-down image observation (TopDownPGDriveEnv: 84 x 84 x 5, lidar off): pgd_step + "
+                         "pgd_observe_topdown per step; reported next to the metric, never as the metric")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="plumbing tests: allow more ranks than GPUs (ranks share devices; needs --backend gloo)")
@@ -152,7 +155,7 @@ def parse_args(argv=None):
     if args.no_gather:
         args.mode = "replicas"
     if args.lasers is None:
-        args.lasers = 240 if args.workload == "c3" else 72
+        args.lasers = (0 if args.topdown else 240) if args.workload == "c3" else 72
     return args
 
 
@@ -230,13 +233,17 @@ def run_rank(args, rank, world, local_rank):
 
     if args.groups > 1:
         eng.set_groups(args.groups)
+    if args.topdown:
+        eng.enable_topdown()
 
     def step_replica(k):
         if args.groups > 1:
             for g in range(args.groups):  # each group on its own internal stream: the launches overlap
                 eng.step_group(g, actions[(k + 5 * g) % CYC])
             return
-        eng.step(actions[k % CYC])
+        eng.step(actions[k % CYC], want_obs=not args.topdown)
+        if args.topdown:
+            eng.observe_topdown()
         for j, ej in enumerate(extra):  # each engine enqueues on its own stream: no ordering between engines
             with torch.cuda.stream(ej.stream):
                 ej.step(actions[(k + 7 * (j + 1)) % CYC])
@@ -328,6 +335,8 @@ def run_rank(args, rank, world, local_rank):
                if args.engines > 1 else {}),
             "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
             "engines_per_gpu": max(1, args.engines), "env_groups": args.groups,
+            **({"observation": "top-down image 84 x 84 x 5 float32 (pgd_observe_topdown), %.1f MB written per step" % (
+                N * 84 * 84 * 5 * 4 / 1e6)} if args.topdown else {}),
             "parallelism": par, "backend": (args.backend if world > 1 else "none"),
             "steady_state": "pre-roll %d steps, %d timed steps (floors %d / %d%s)" % (
                 warm, timed, PREROLL_MIN, TIMED_MIN, ", off: --exact" if args.exact else ""),

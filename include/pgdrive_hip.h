@@ -299,6 +299,23 @@ int pgd_sync(pgd_handle h);
 int pgd_destroy(pgd_handle h);
 const char* pgd_version(void);
 
+/* Top-down (bird's-eye) multi-channel observation: TopDownMultiChannel.observe (obs/top_down_obs_multi_channel.py:18-280) of
+ * TopDownPGDriveEnv (envs/top_down_env.py:28-42) as a rasteriser kernel.  Image [N, R, R, 2 + frame_stack] float32 in [0, 1]:
+ * channel 0 road network (lane lines, route lanes), 1 past ego positions, 2.. the other vehicles now and frame_skip, 2 *
+ * frame_skip ... steps ago, the ego at the centre heading up, +-distance metres.  pgd_observe_topdown is called ONCE after
+ * every pgd_step (and after pgd_reset): it appends the present state to the per-env history it draws the older frames from.
+ * Single-agent engines only, like the reference.  Exact definition: pgdrive_amd/csrc/pgd_topdown.h. */
+typedef struct pgd_topdown_config {
+  int32_t resolution;       /* R: 84 (top_down_env.py:19) */
+  float distance;           /* 30 m */
+  int32_t frame_stack;      /* 3 traffic frames */
+  int32_t post_stack;       /* 5 past positions */
+  int32_t frame_skip;       /* 5 steps between stacked entries */
+} pgd_topdown_config;
+int pgd_topdown_channels(const pgd_topdown_config* cfg);
+int pgd_topdown_enable(pgd_handle h, const pgd_topdown_config* cfg);
+int pgd_observe_topdown(pgd_handle h, float* d_img /*[N,R,R,C]*/);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Per-step gather by direct peer writes (multi-GPU, one process per GPU).  The reference has no distributed layer (one env
  * per process, engine_utils.py:8-15); BASELINE.json's north star shards the envs over the GPUs of a node with one gather of

@@ -100,6 +100,19 @@ class Oracle:
         self.L.orc_observe(self.h, _p(obs))
         return obs
 
+    def enable_topdown(self, td_cfg):
+        import ctypes as C
+        self.td_cfg = td_cfg
+        self.L.orc_topdown_enable.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_observe_topdown.argtypes = [C.c_void_p, C.c_void_p]
+        assert self.L.orc_topdown_enable(self.h, C.byref(td_cfg)) == 0
+
+    def observe_topdown(self):
+        R, Cn = self.td_cfg.resolution, 2 + self.td_cfg.frame_stack
+        img = np.zeros((self.N, R, R, Cn), dtype=np.float64)
+        assert self.L.orc_observe_topdown(self.h, _p(img)) == 0
+        return img
+
     def refresh(self):
         self.L.orc_refresh(self.h)
 

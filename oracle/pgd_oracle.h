@@ -32,4 +32,6 @@ int orc_run_mt(orc_handle h, int threads, int steps, const float* actions, int n
 int orc_step_range(orc_handle h, int e0, int e1, const float* actions, double* obs, double* reward, uint8_t* done,
                    uint32_t* flags);
 uint32_t orc_rng(uint32_t seed, uint32_t a, uint32_t b, uint32_t c);
+int orc_topdown_enable(orc_handle h, const pgd_topdown_config* c);
+int orc_observe_topdown(orc_handle h, double* img /*[N,R,R,C]*/);
 #endif

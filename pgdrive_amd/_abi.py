@@ -20,6 +20,16 @@ class PgdConfig(C.Structure):
     ]
 
 
+class TopDownConfig(C.Structure):
+    """pgd_topdown_config; defaults = TopDownPGDriveEnv (envs/top_down_env.py:8-42)."""
+    _fields_ = [("resolution", C.c_int32), ("distance", C.c_float), ("frame_stack", C.c_int32), ("post_stack", C.c_int32),
+                ("frame_skip", C.c_int32)]
+
+
+def make_topdown_config(resolution=84, distance=30.0, frame_stack=3, post_stack=5, frame_skip=5):
+    return TopDownConfig(int(resolution), float(distance), int(frame_stack), int(post_stack), int(frame_skip))
+
+
 def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_others=4, lidar_dist=50.0, dt=0.02,
                 decision_repeat=5, auto_reset=1, resample_scenario=0, horizon=0, seed=0, success_reward=10.0,
                 out_of_road_penalty=5.0, crash_vehicle_penalty=5.0, crash_object_penalty=5.0, driving_reward=1.0,

@@ -51,6 +51,7 @@ struct PgdDev {
   float* prow;
   int dbg_exit;  // exit-profile builds only (PGD_EXITAT)
   int unit_off;  // first block unit of this launch (pgd_step_group); 0 for a whole-engine step
+  uint8_t* bev_fill;  // [N] or null: the env was reset -- the top-down observation refills its history (pgd_topdown.h)
 };
 
 // Device-side vehicle record = the per-lane register image of a vehicle (device-private; pgd_get_state / pgd_set_state

@@ -485,6 +485,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] = episodes;
       d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_AGENT] = A == 1 ? 1 : __popcll(am);
       d.ei[(size_t)(e) * PGD_NEI + EI_AUX] = sc->aux;  // parking: the pool of the new episode
+      if (d.bev_fill) d.bev_fill[e] = 1;
     }
   }
   if (valid && leader && s < A) {
@@ -614,6 +615,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restr
   store_veh(d, e, s, r);
   if (s == 0) {
     d.env_map[e] = d.scen_map[scen];
+    if (d.bev_fill) d.bev_fill[e] = 1;
     d.imask[e] = (d.epw == 1 && d.use_imask) ? (d.V >= 64 ? ~0ull : ((1ull << d.V) - 1ull)) : 0ull;  // every record equals the image now
     d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_AGENT] = A == 1 ? 1 : __popcll(am);
     d.ei[(size_t)(e) * PGD_NEI + EI_AUX] = d.scen[scen].aux;  // parking: free spaces of the new episode
@@ -771,6 +773,7 @@ struct pgd_engine {
   std::vector<hipEvent_t>* prof_ev;  // 3 events per recorded step
   int prof_cap, prof_n, prof_stride, prof_tick;
   bool prof_grouped;
+  struct pgd_topdown_state* topdown;  // top-down observation (pgd_topdown.h), null until pgd_topdown_enable
   int n_groups;          // env groups of pgd_set_groups (1 = none)
   hipStream_t* gstreams; // [n_groups] internal streams
   bool derive_pending;  // records were written through the ABI or the tables changed: k_derive has to run
@@ -779,6 +782,8 @@ struct pgd_engine {
   bool no_fuse;      // PGD_NO_FUSE was set when the engine was created (debug: always run the stand-alone k_observe)
   bool prof_fused;
 };
+
+static void topdown_free(pgd_engine* h);
 
 template <typename T>
 static int upload(T** dst, const T* src, size_t n, hipStream_t st) {
@@ -813,8 +818,10 @@ static int derive_records(pgd_engine* h) {
 }
 
 // (re)build the reset image once both the maps and the scenarios are on the device
+static void topdown_mark_dirty(pgd_engine* h);
 static int build_reset_image(pgd_engine* h) {
   if (!h->have_maps || !h->have_scen) return PGD_OK;
+  topdown_mark_dirty(h);  // the top-down rasters follow the tables
   // the route context cached in the records of running envs refers to the tables: rebuild it after every upload
   h->derive_pending = true;
   { int rc = derive_records(h); if (rc) return rc; }
@@ -1410,6 +1417,7 @@ int pgd_destroy(pgd_handle h) {
     for (int g = 0; g < h->n_groups; ++g) { (void)hipStreamSynchronize(h->gstreams[g]); (void)hipStreamDestroy(h->gstreams[g]); }
     free(h->gstreams);
   }
+  topdown_free(h);
   delete h->h_maps;
   delete h->h_scen;
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -1420,4 +1428,5 @@ int pgd_destroy(pgd_handle h) {
 
 }  // extern "C"
 
+#include "pgd_topdown.h"
 #include "pgd_gather.h"

@@ -1,0 +1,325 @@
+// pgd_topdown.h -- top-down (bird's-eye) multi-channel observation: obs/top_down_obs_multi_channel.py:18-280 as a rasteriser
+// kernel.  Part of the single translation unit pgd_engine.hip (included at its end, before pgd_gather.h).
+//
+// The reference draws the map and the vehicles with pygame on 2000 x 2000 canvases, crops a window around the ego, rotates it
+// so that the ego heads up (ObservationWindow, top_down_obs_impl.py:15-90), converts to grey and stacks channels
+//   [road_network * 2, past_pos, traffic_flow(t), traffic_flow(t - skip), ...]      (top_down_obs_multi_channel.py:203-247)
+// into a [R, R, 2 + frame_stack] image in [0, 1] (TopDownPGDriveEnv: R = 84, distance = 30 m, frame_stack 3, post_stack 5,
+// frame_skip 5; envs/top_down_env.py:8-42).  pygame is not available here (nor on the GPU box), so pixel parity with its
+// polygon / line / rotozoom / smoothscale rasterisation is UNPINNED; this kernel evaluates the same scene analytically, one
+// pixel centre at a time, and the oracle restates exactly this definition in fp64:
+//   window   pixel (row i, col j) <-> ego frame: forward = (R/2 - i - 0.5) / s, right = (j + 0.5 - R/2) / s, s = R / (2 distance)
+//            px per metre (the crop of ObservationWindow: +-distance around the ego, ego heading up, top_down_obs_impl.py:30-82)
+//   ch 0     road_network: like the reference, the map is drawn ONCE -- a raster per scenario at TD_TEXEL = 0.25 m (the
+//            reference's background canvas: 2000 px over the map's extent + 20 m, i.e. 3-4 px / m), every texel classified
+//            analytically at its centre (k_topdown_raster) -- and the window samples its nearest texel:
+//            2 * 35/255 where the texel centre lies within 0.25 m (half of LANE_LINE_WIDTH = 0.5, or half a window pixel if
+//            that is more) of a lane-line box of the map (continuous and broken lines; LANE_LINE_COLOR (35,35,35)); else
+//            2 * 64/255 inside a lane (|lateral| <= width / 2, 0 <= longitudinal <= length) of a road on the ego's route
+//            (draw_navigation with (64,64,64)); else 0.  Deviation: stripes follow the map's physical broken-line boxes, not
+//            the renderer's cosmetic 3 m / 5 m pattern.
+//   ch 1     past_pos: 1 at the pixels of the ego's positions t, t - skip, ... (post_stack entries at most), in the CURRENT ego
+//            frame, with the reference's own scale R / distance (twice the window's: reproduced as is) and its clip
+//   ch 2..   traffic_flow at t, t - skip, ...: grey(100,200,255)/255 = 0.6917 inside the box of every other vehicle (all
+//            BaseVehicles of the engine: waiting and driving traffic, broken-down vehicles; not cones / barriers), each
+//            frame in the ego frame OF ITS OWN TIME; headings within 2 deg of 0 snap to 0 (top_down_obs_multi_channel.py:141-150)
+// State: the engine keeps, per env, the last (post_stack - 1) * skip + 1 ego positions and the last (frame_stack - 1) * skip + 1
+// pose sets (every slot + the ego) and re-rasterises old frames from poses (3 KB per env instead of 78 KB of stored images).
+// After a reset the history is the first frame repeated (the reference fills its deque the same way; its past_pos deque shows
+// the previous episode's points in the first frame after a reset -- not reproduced).
+#ifndef PGD_TOPDOWN_H
+#define PGD_TOPDOWN_H
+
+struct TopDown {
+  int R, C, frame_stack, post_stack, frame_skip, n_pos, n_frames;
+  float distance;
+  float2* pos;    // [N][n_pos]   newest first
+  float4* pose;   // [N][n_frames][V]  (x, y, hx, hy); hx = hy = 0: not drawn; newest first; slot 0 = the ego of that time
+  int* n_hist;    // [N] valid entries of pos
+  // road-network raster, one per scenario (the route is the scenario's): texel = TD_TEXEL m, value 0 / 1 (route lane) / 2 (line)
+  const uint8_t* tex;        // all rasters back to back
+  const long long* tex_off;  // [n_scen] offset of the scenario's raster
+  float line_r;
+};
+#define TD_TEXEL 0.25f
+
+#define TD_LINE 0.27450980392156865f   // 2 * 35 / 255
+#define TD_NAVI 0.50196078431372548f   // 2 * 64 / 255
+#define TD_VEH 0.69164705882352939f    // (0.299 * 100 + 0.587 * 200 + 0.114 * 255) / 255
+
+// road-network class of a world point: 2 = within line_r of a lane-line box, 1 = inside a lane of a road of the route, 0 = neither
+DEV int td_classify(const MapView& mv, const uint32_t* route, float wx, float wy, float line_r) {
+  const pgd_map& m = *mv.m;
+  const int cx = (int)floorf((wx - m.ox) / m.cell), cy = (int)floorf((wy - m.oy) / m.cell);
+  bool line = false, navi = false;
+  // a line box within line_r of the point may be registered in a neighbouring cell only: look at the 3 x 3 block when the
+  // point is closer than line_r to a cell border, else at its own cell
+  const float fx = (wx - m.ox) - (float)cx * m.cell, fy = (wy - m.oy) - (float)cy * m.cell;
+  const int x0 = fx < line_r ? cx - 1 : cx, x1 = fx > m.cell - line_r ? cx + 1 : cx;
+  const int y0 = fy < line_r ? cy - 1 : cy, y1 = fy > m.cell - line_r ? cy + 1 : cy;
+  for (int yy = y0; yy <= y1 && !line; ++yy)
+    for (int xx = x0; xx <= x1 && !line; ++xx) {
+      if (xx < 0 || yy < 0 || xx >= m.gx || yy >= m.gy) continue;
+      const int cell = yy * m.gx + xx;
+      const int k1 = cell_first(mv.cstart[cell + 1]);
+      if (xx == cx && yy == cy && !navi)
+        for (int k = cell_first(mv.cstart[cell]); k < cell_mid(mv.cstart[cell]); ++k) {  // lane boxes: candidates for the exact lane test
+          const pgd_box b = mv.cbox[k];
+          const pgd_lane& L = mv.lanes[b.lane];
+          if (!((route[L.road >> 5] >> (L.road & 31)) & 1u)) continue;
+          float lo, la;
+          lane_local(L, wx, wy, lo, la);
+          if (fabsf(la) <= 0.5f * L.width && lo >= 0.0f && lo <= L.length) { navi = true; break; }
+        }
+      for (int k = cell_mid(mv.cstart[cell]); k < k1; ++k) {
+        const pgd_box b = mv.cbox[k];
+        if (b.kind == PGD_BOX_SIDEWALK) continue;
+        if (point_obb_dist(obb_of(b), wx, wy) <= line_r) { line = true; break; }
+      }
+    }
+  return line ? 2 : (navi ? 1 : 0);
+}
+
+// The road-network raster of one scenario (once per upload: what the reference's 2000 x 2000 background canvas is, here at a fixed
+// TD_TEXEL = 0.25 m): every texel classified analytically at its centre.  k_topdown samples it with the nearest texel.
+__global__ __launch_bounds__(256) void k_topdown_raster(PgdDev d, int scen, float line_r, uint8_t* __restrict__ tex, int W, int H) {
+  __shared__ uint32_t s_route[128];
+  for (int k = threadIdx.x; k < 128; k += 256) s_route[k] = 0u;
+  __syncthreads();
+  const pgd_spawn& sp = d.spawns[(size_t)scen * d.sstride];
+  if ((int)threadIdx.x < sp.n_ckpt - 1) { const int r = sp.ckpt_road[threadIdx.x]; if (r >= 0) atomicOr(&s_route[r >> 5], 1u << (r & 31)); }
+  __syncthreads();
+  const MapView mv = map_view_of(d, d.scen_map + scen);
+  const long long n = (long long)W * H;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
+    const int iy = (int)(p / W), ix = (int)(p - (long long)iy * W);
+    tex[p] = (uint8_t)td_classify(mv, s_route, mv.m->ox + ((float)ix + 0.5f) * TD_TEXEL, mv.m->oy + ((float)iy + 0.5f) * TD_TEXEL, line_r);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_topdown(PgdDev d, TopDown t, uint8_t* __restrict__ fill, float* __restrict__ img) {
+  __shared__ float4 s_pose[16][MAXV];        // pose history after this step's insertion (n_frames <= 16)
+  __shared__ float2 s_pos[64];               // ego position history (n_pos <= 64)
+  __shared__ float s_hl[MAXV], s_hw[MAXV];
+  __shared__ int s_nhist;
+  // per stacked frame: the vehicles that can show up in the window, already in the ego frame of that time
+  __shared__ float4 s_vc[4][MAXV];   // (forward, right) of the box centre, (forward, right) components of its long axis
+  __shared__ float2 s_vh[4][MAXV];   // half extents
+  __shared__ int s_nvis[4];
+  __shared__ float s_out[256 * 8];   // one batch of 256 pixels x C channels, written out linearly (coalesced)
+  const int e = blockIdx.x, tid = threadIdx.x, V = d.V;
+  const VehRec* recs = d.rec + (size_t)e * V;
+  const int scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
+  const pgd_spawn* spb = d.spawns + (size_t)scen * d.sstride;
+  const MapView mv = map_view_of(d, d.scen_map + scen);
+  const bool refill = fill[e] != 0;
+  // ---- history: shift by one and insert the current state (or fill everything with it after a reset) ----
+  float4* hp = t.pose + (size_t)e * t.n_frames * V;
+  float2* pp = t.pos + (size_t)e * t.n_pos;
+  for (int k = tid; k < t.n_frames * V; k += 256) {
+    const int f = k / V, s = k - f * V;
+    float4 q;
+    if (f == 0 || refill) {
+      const VehRec& rc = recs[s];
+      const bool drawn = (rc.status == ST_PENDING || rc.status == ST_ACTIVE || rc.status == ST_DYING) && spb[rc.spawn].kind == PGD_OBJ_VEHICLE;
+      float hx = rc.hx, hy = rc.hy;
+      if (s != 0 && fabsf(rc.th) <= 2.0f * PGD_PI / 180.0f) { hx = 1.0f; hy = 0.0f; }  // the reference snaps small headings of the others
+      q = drawn ? make_float4(rc.x, rc.y, hx, hy) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else q = hp[(size_t)(f - 1) * V + s];
+    s_pose[f][s] = q;
+  }
+  for (int k = tid; k < t.n_pos; k += 256) s_pos[k] = (k == 0 || refill) ? make_float2(recs[0].x, recs[0].y) : pp[k - 1];
+  if (tid < V) { const pgd_spawn& so = spb[recs[tid].spawn]; s_hl[tid] = 0.5f * so.length; s_hw[tid] = 0.5f * so.width; }
+  if (tid == 0) s_nhist = refill ? 1 : min(t.n_hist[e] + 1, t.n_pos);
+  __syncthreads();
+  for (int k = tid; k < t.n_frames * V; k += 256) hp[k] = s_pose[k / V][k % V];
+  for (int k = tid; k < t.n_pos; k += 256) pp[k] = s_pos[k];
+  if (tid == 0) { t.n_hist[e] = s_nhist; fill[e] = 0; }
+  __syncthreads();
+  // ---- per frame: cull the vehicles against the window and move them into that frame's ego coordinates (one wave per frame) ----
+  {
+    const int w = tid >> 6, lane = tid & 63;
+    for (int f = w; f < t.frame_stack && f < 4; f += 4) {
+      const int fi = f * t.frame_skip;
+      const float4 eg = s_pose[fi][0];
+      bool vis = false;
+      float4 vc = make_float4(0.f, 0.f, 1.f, 0.f);
+      if (lane >= 1 && lane < V) {
+        const float4 q = s_pose[fi][lane];
+        if (!(q.z == 0.0f && q.w == 0.0f)) {
+          const float dx = q.x - eg.x, dy = q.y - eg.y;
+          vc = make_float4(dx * eg.z + dy * eg.w, dy * eg.z - dx * eg.w, q.z * eg.z + q.w * eg.w, q.w * eg.z - q.z * eg.w);
+          const float reach = t.distance + s_hl[lane] + s_hw[lane];
+          vis = fabsf(vc.x) <= reach && fabsf(vc.y) <= reach;
+        }
+      }
+      const unsigned long long m = __ballot(vis);
+      if (vis) {
+        const int k = __popcll(m & ((1ull << lane) - 1ull));
+        s_vc[f][k] = vc;
+        s_vh[f][k] = make_float2(s_hl[lane], s_hw[lane]);
+      }
+      if (lane == 0) s_nvis[f] = __popcll(m);
+    }
+  }
+  __syncthreads();
+  // ---- rasterise ----
+  const int R = t.R, C = t.C;
+  const float s_px = (float)R / (2.0f * t.distance), inv_s = 1.0f / s_px;
+  const pgd_map& m = *mv.m;
+  const int tw = (int)((float)m.gx * m.cell / TD_TEXEL), th = (int)((float)m.gy * m.cell / TD_TEXEL);
+  const uint8_t* tex = t.tex + t.tex_off[scen];
+  float* out = img + (size_t)e * R * R * C;
+  for (int p0 = 0; p0 < R * R; p0 += 256) {
+    const int p = p0 + tid;
+    const int i = p / R, j = p - i * R;
+    const float fwd = ((float)R * 0.5f - (float)i - 0.5f) * inv_s, rgt = ((float)j + 0.5f - (float)R * 0.5f) * inv_s;
+    float* px = s_out + tid * C;  // staged: the batch goes out with consecutive lanes on consecutive floats
+    if (p < R * R) {
+    // ch 0: road network around the CURRENT ego pose (right = heading rotated by +90 deg in the engine's x / y frame): the
+    // nearest texel of the scenario's raster
+    {
+      const float4 eg = s_pose[0][0];
+      const float wx = eg.x + fwd * eg.z - rgt * eg.w, wy = eg.y + fwd * eg.w + rgt * eg.z;
+      const int ix = (int)floorf((wx - m.ox) * (1.0f / TD_TEXEL)), iy = (int)floorf((wy - m.oy) * (1.0f / TD_TEXEL));
+      int cls = 0;
+      if (ix >= 0 && iy >= 0 && ix < tw && iy < th) cls = tex[(long long)iy * tw + ix];
+      px[0] = cls == 2 ? TD_LINE : (cls == 1 ? TD_NAVI : 0.0f);
+    }
+    px[1] = 0.0f;
+    // ch 2..: the other vehicles at t, t - skip, ...: point (fwd, rgt) against the culled boxes in that frame's ego coordinates
+    for (int f = 0; f < t.frame_stack; ++f) {
+      float v = 0.0f;
+      if (f < 4) {
+        const int nv = s_nvis[f];
+        for (int k = 0; k < nv; ++k) {
+          const float4 b = s_vc[f][k];
+          const float2 hh = s_vh[f][k];
+          const float dx = fwd - b.x, dy = rgt - b.y;
+          if (fabsf(dx * b.z + dy * b.w) <= hh.x && fabsf(dy * b.z - dx * b.w) <= hh.y) { v = TD_VEH; break; }
+        }
+      }
+      px[2 + f] = v;
+    }
+    }
+    __syncthreads();
+    {
+      const int n_batch = min(256, R * R - p0) * C;
+      float* dst = out + (size_t)p0 * C;
+      for (int k = tid; k < n_batch; k += 256) dst[k] = s_out[k];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  // ch 1: past positions of the ego, newest first, in the current ego frame (top_down_obs_multi_channel.py:152-170)
+  if (tid < t.post_stack) {
+    const int k = tid * t.frame_skip;
+    if (k < s_nhist) {
+      const float4 eg = s_pose[0][0];
+      const bool snap = fabsf(recs[0].th) <= 2.0f * PGD_PI / 180.0f;  // the reference rotates by the snapped ego heading here
+      const float ehx = snap ? 1.0f : eg.z, ehy = snap ? 0.0f : eg.w;
+      const float dx = s_pos[k].x - eg.x, dy = s_pos[k].y - eg.y, sc = (float)R / t.distance;
+      float u = (dy * ehx - dx * ehy) * sc + (float)R * 0.5f, vv = -(dx * ehx + dy * ehy) * sc + (float)R * 0.5f;
+      u = clipf(u, -(float)R, (float)R); vv = clipf(vv, -(float)R, (float)R);
+      const int jj = (int)floorf(u), ii = (int)floorf(vv);
+      if (ii >= 0 && jj >= 0 && ii < R && jj < R) out[((size_t)ii * R + jj) * C + 1] = 1.0f;
+    }
+  }
+}
+
+struct pgd_topdown_state {
+  TopDown t;
+  uint8_t* tex;          // device rasters
+  long long* tex_off;    // device offsets
+  bool tex_dirty;        // maps / scenarios were uploaded since the rasters were built
+};
+
+// (re)build the road-network rasters of every scenario (needs maps + scenarios on the device)
+static int topdown_build_rasters(pgd_engine* h) {
+  pgd_topdown_state* s = h->topdown;
+  if (!s || !h->have_maps || !h->have_scen || !h->h_maps || !h->h_scen) return PGD_OK;
+  const int n_scen = (int)h->h_scen->size();
+  std::vector<long long> off((size_t)n_scen);
+  long long total = 0;
+  for (int k = 0; k < n_scen; ++k) {
+    const pgd_map& M = (*h->h_maps)[(size_t)(*h->h_scen)[(size_t)k].map];
+    off[(size_t)k] = total;
+    total += (long long)((float)M.gx * M.cell / TD_TEXEL) * (long long)((float)M.gy * M.cell / TD_TEXEL);
+  }
+  if (s->tex) { HIPCHK(hipFree(s->tex)); s->tex = nullptr; }
+  if (s->tex_off) { HIPCHK(hipFree(s->tex_off)); s->tex_off = nullptr; }
+  HIPCHK(hipMalloc(&s->tex, (size_t)(total > 0 ? total : 1)));
+  HIPCHK(hipMalloc(&s->tex_off, sizeof(long long) * (size_t)n_scen));
+  HIPCHK(hipMemcpyAsync(s->tex_off, off.data(), sizeof(long long) * (size_t)n_scen, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < n_scen; ++k) {
+    const pgd_map& M = (*h->h_maps)[(size_t)(*h->h_scen)[(size_t)k].map];
+    const int W = (int)((float)M.gx * M.cell / TD_TEXEL), H = (int)((float)M.gy * M.cell / TD_TEXEL);
+    const long long n = (long long)W * H;
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_topdown_raster, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, h->stream, h->d, k, s->t.line_r, s->tex + off[(size_t)k], W, H);
+  }
+  HIPCHK(hipGetLastError());
+  s->t.tex = s->tex;
+  s->t.tex_off = s->tex_off;
+  s->tex_dirty = false;
+  return PGD_OK;
+}
+
+extern "C" {
+
+int pgd_topdown_channels(const pgd_topdown_config* c) { return c ? 2 + c->frame_stack : 0; }
+
+int pgd_topdown_enable(pgd_handle h, const pgd_topdown_config* c) {
+  if (!h || !c || c->resolution < 8 || c->resolution > 512 || !(c->distance > 0.0f) || c->frame_stack < 1 || c->post_stack < 1 ||
+      c->frame_skip < 1)
+    return PGD_ERR_ARG;
+  if (c->frame_stack > 4) return PGD_ERR_ARG;  // one wave of the block per stacked frame; s_out holds 256 pixels x (2 + 4) channels
+  if (h->d.A != 1) return PGD_ERR_ARG;  // "Don't support multi-agent top-down observation yet" (top_down_obs_multi_channel.py:130)
+  const int n_pos = (c->post_stack - 1) * c->frame_skip + 1, n_frames = (c->frame_stack - 1) * c->frame_skip + 1;
+  if (n_pos > 64 || n_frames > 16) return PGD_ERR_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->topdown) h->topdown = (pgd_topdown_state*)calloc(1, sizeof(pgd_topdown_state));
+  pgd_topdown_state* s = h->topdown;
+  if (s->t.pos) { (void)hipFree(s->t.pos); (void)hipFree(s->t.pose); (void)hipFree(s->t.n_hist); }
+  s->t = TopDown{c->resolution, 2 + c->frame_stack, c->frame_stack, c->post_stack, c->frame_skip, n_pos, n_frames, c->distance,
+                 nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f};
+  s->t.line_r = fmaxf(0.25f, 0.5f * (2.0f * c->distance) / (float)c->resolution);
+  s->tex_dirty = true;
+  const size_t N = (size_t)h->d.N;
+  HIPCHK(hipMalloc(&s->t.pos, sizeof(float2) * N * n_pos));
+  HIPCHK(hipMalloc(&s->t.pose, sizeof(float4) * N * n_frames * h->d.V));
+  HIPCHK(hipMalloc(&s->t.n_hist, sizeof(int) * N));
+  HIPCHK(hipMemsetAsync(s->t.n_hist, 0, sizeof(int) * N, h->stream));
+  if (!h->d.bev_fill) {
+    HIPCHK(hipMalloc(&h->d.bev_fill, N));
+  }
+  HIPCHK(hipMemsetAsync(h->d.bev_fill, 1, N, h->stream));  // every env starts with a filled history
+  return PGD_OK;
+}
+
+int pgd_observe_topdown(pgd_handle h, float* d_img) {
+  if (!h || !d_img) return PGD_ERR_ARG;
+  if (!h->topdown || !h->have_maps || !h->have_scen) return PGD_ERR_STATE;
+  HIPCHK(hipSetDevice(h->device));
+  if (h->topdown->tex_dirty) { int rc = topdown_build_rasters(h); if (rc) return rc; }
+  hipLaunchKernelGGL(k_topdown, dim3(h->d.N), dim3(256), 0, h->stream, h->d, h->topdown->t, h->d.bev_fill, d_img);
+  HIPCHK(hipGetLastError());
+  return PGD_OK;
+}
+
+}  // extern "C"
+
+static void topdown_mark_dirty(pgd_engine* h) { if (h->topdown) h->topdown->tex_dirty = true; }
+
+static void topdown_free(pgd_engine* h) {
+  if (!h->topdown) return;
+  if (h->topdown->t.pos) { (void)hipFree(h->topdown->t.pos); (void)hipFree(h->topdown->t.pose); (void)hipFree(h->topdown->t.n_hist); }
+  if (h->topdown->tex) (void)hipFree(h->topdown->tex);
+  if (h->topdown->tex_off) (void)hipFree(h->topdown->tex_off);
+  if (h->d.bev_fill) (void)hipFree(h->d.bev_fill);
+  free(h->topdown);
+  h->topdown = nullptr;
+}
+
+#endif

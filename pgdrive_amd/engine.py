@@ -25,6 +25,9 @@ _SIGS = {
     "pgd_get_state": (C.c_int, [C.c_void_p] * 4),
     "pgd_set_state": (C.c_int, [C.c_void_p] * 4),
     "pgd_observe": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pgd_topdown_channels": (C.c_int, [C.POINTER(_abi.TopDownConfig)]),
+    "pgd_topdown_enable": (C.c_int, [C.c_void_p, C.POINTER(_abi.TopDownConfig)]),
+    "pgd_observe_topdown": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pgd_set_groups": (C.c_int, [C.c_void_p, C.c_int]),
     "pgd_step_group": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5),
     "pgd_group_stream": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
@@ -184,6 +187,24 @@ class Engine:
         _chk(self.L.pgd_step_packed(self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(rows.data_ptr()),
                                     int(rows.stride(0)), p_rew, p_done, p_flags), "pgd_step_packed")
         return rows, self.reward, self.done, self.flags
+
+    # -- top-down observation (obs/top_down_obs_multi_channel.py) -----------------------------------------------------------
+    def enable_topdown(self, td_cfg=None):
+        """Switch on the bird's-eye multi-channel observation; `td_cfg` = _abi.make_topdown_config(...)."""
+        self.td_cfg = td_cfg or _abi.make_topdown_config()
+        _chk(self.L.pgd_topdown_enable(self.h, C.byref(self.td_cfg)), "pgd_topdown_enable")
+        R, Cn = self.td_cfg.resolution, self.L.pgd_topdown_channels(C.byref(self.td_cfg))
+        self.img = self.torch.zeros((self.N, R, R, Cn), dtype=self.torch.float32, device=self.device)
+
+    def observe_topdown(self, out=None):
+        """Image [N, R, R, C] of the present state; call once after every step / reset (it advances the frame history)."""
+        img = self.img if out is None else out
+        cur = self.torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self._bound_stream:
+            _chk(self.L.pgd_set_stream(self.h, C.c_void_p(cur)), "pgd_set_stream")
+            self._bound_stream = cur
+        _chk(self.L.pgd_observe_topdown(self.h, C.c_void_p(img.data_ptr())), "pgd_observe_topdown")
+        return img
 
     # -- asynchronous env groups ----------------------------------------------------------------------------------------
     def set_groups(self, n_groups):

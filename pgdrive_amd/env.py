@@ -142,6 +142,21 @@ class SafePGDriveEnv(PGDriveEnv):
         return o, r, d, info
 
 
+class TopDownPGDriveEnv(PGDriveEnv):
+    """pgdrive/envs/top_down_env.py:28-42: PGDriveEnv with the TopDownMultiChannel observation, [84, 84, 2 + frame_stack]
+    float32 in [0, 1], the lidar switched off."""
+    DEFAULTS = dict(use_topdown=True, frame_skip=5, frame_stack=3, post_stack=5, rgb_clip=True, resolution_size=84, distance=30)
+
+    def __init__(self, config=None):
+        cfg = dict(self.DEFAULTS)
+        user = dict(config or {})
+        vc = dict(user.pop("vehicle_config", {}) or {})
+        vc.setdefault("lidar", dict(num_lasers=0, distance=0))  # "Remove lidar" (top_down_env.py:12)
+        cfg.update(user)
+        cfg["vehicle_config"] = vc
+        super().__init__(cfg)
+
+
 def make(env_id, **kw):
     cfg = dict(ENV_IDS[env_id])
     cfg.update(kw)

@@ -62,6 +62,9 @@ DEFAULT_CONFIG = dict(
     resample_scenario=True,  # a new seed per episode like _reset_global_seed (base_env.py:451-458)
     device=0,
     seed=0,
+    # top-down multi-channel image observation instead of the state + lidar vector (TopDownPGDriveEnv, envs/top_down_env.py:8-42,
+    # obs/top_down_obs_multi_channel.py); pgdrive_amd/csrc/pgd_topdown.h states what exactly is drawn
+    use_topdown=False, frame_stack=3, post_stack=5, frame_skip=5, resolution_size=84, distance=30, rgb_clip=True,
     map_bank=None,  # path of a pre-generated description bank; None -> generate with our BIG (pgdrive_amd/mapgen.py)
 )
 
@@ -73,7 +76,7 @@ VISUAL_KEYS = {
     "debug", "fast", "cull_scene", "controller", "use_chase_camera_follow_lane", "camera_height", "camera_dist",
     "prefer_track_agent", "draw_map_resolution", "top_down_camera_initial_x", "top_down_camera_initial_y",
     "top_down_camera_initial_z", "window_size", "show_fps", "global_light", "onscreen_message", "debug_physics_world",
-    "debug_static_world", "headless_machine_render", "pstats", "max_distance", "rgb_clip", "_disable_detector_mask",
+    "debug_static_world", "headless_machine_render", "pstats", "max_distance", "_disable_detector_mask",
     "load_map_from_json", "_load_map_from_json", "save_level",
     # unused upstream (no reader in the reference's reward function)
     "acceleration_penalty", "low_speed_penalty", "general_penalty",
@@ -85,7 +88,7 @@ VISUAL_VEHICLE_KEYS = {
 # NEUTRAL: features outside the step path (rendering, image observations, manual / scripted ego control, recording); the
 # neutral value is accepted, anything else is refused by name instead of being silently ignored.
 NEUTRAL_KEYS = {
-    "use_render": False, "manual_control": False, "offscreen_render": False, "use_topdown": False, "use_saver": False,
+    "use_render": False, "manual_control": False, "offscreen_render": False, "use_saver": False,
     "record_episode": False, "_debug_crash_object": False, "IDM_agent": False, "is_multi_agent": False, "num_agents": 1,
     "allow_respawn": False, "delay_done": 0, "gaussian_noise": 0.0, "dropout_prob": 0.0,
 }
@@ -208,8 +211,16 @@ class PGDriveVecEnv:
         from .engine import Engine
         self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])
         self.obs_dim = self.engine.D
+        self.topdown = bool(c["use_topdown"])
+        if self.topdown:
+            if not c["rgb_clip"]:
+                raise NotImplementedError("use_topdown with rgb_clip=False (uint8 images) is not built: images are float32 in [0, 1]")
+            self.engine.enable_topdown(_abi.make_topdown_config(c["resolution_size"], c["distance"], c["frame_stack"],
+                                                                c["post_stack"], c["frame_skip"]))
         # spaces (base_vehicle.py:720-727, state_obs.py:124-130)
         self.single_observation_space = Box(-0.0, 1.0, (self.obs_dim, ), np.float32)
+        if self.topdown:
+            self.single_observation_space = Box(-0.0, 1.0, tuple(self.engine.img.shape[1:]), np.float32)
         self.single_action_space = MultiDiscrete([c["discrete_steering_dim"], c["discrete_throttle_dim"]]) \
             if c["discrete_action"] else Box(-1.0, 1.0, (2, ), np.float32)
         self.observation_space = self.single_observation_space
@@ -229,6 +240,8 @@ class PGDriveVecEnv:
             fs = np.broadcast_to(np.asarray(force_seed), (self.num_envs, ))
             ids = np.array([self.seeds.index(int(s)) for s in fs])
         obs = self.engine.reset(ids.astype(np.int32))
+        if self.topdown:
+            return self.engine.observe_topdown()
         return obs.view(self.num_envs, self.obs_dim)
 
     def step(self, actions):
@@ -242,6 +255,8 @@ class PGDriveVecEnv:
                 ok = bool(((a >= -1.0) & (a <= 1.0)).all())
             assert ok, "Input actions are not compatible with action space {}!".format(self.single_action_space)
         obs, rew, done, flags = self.engine.step(actions.contiguous().view(self.num_envs, 1, 2))
+        if self.topdown:
+            return self.engine.observe_topdown(), rew.view(-1), done.view(-1), flags.view(-1)
         return obs.view(self.num_envs, self.obs_dim), rew.view(-1), done.view(-1), flags.view(-1)
 
     def info_from_flags(self, flags):

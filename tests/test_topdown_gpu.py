@@ -1,0 +1,158 @@
+"""Top-down multi-channel observation (obs/top_down_obs_multi_channel.py as a rasteriser kernel, pgdrive_amd/csrc/pgd_topdown.h):
+GPU vs the oracle's brute-force fp64 restatement of the same definition, known answers, frame stacking and reset behaviour.
+(pygame, which the reference rasterises with, exists neither here nor on the GPU box: pixel parity with it is unpinned.)"""
+import numpy as np
+import pytest
+
+from pgdrive_amd import _abi
+from tests import util
+
+pytestmark = pytest.mark.gpu
+TD_LINE, TD_NAVI, TD_VEH = 2 * 35 / 255, 2 * 64 / 255, (0.299 * 100 + 0.587 * 200 + 0.114 * 255) / 255
+
+
+def _setup(descs, n_envs, td=None, **kw):
+    import torch
+    from oracle import orc
+    from pgdrive_amd.engine import Engine
+    mb, sb = util.make_banks(descs, n_maps=8)
+    cfg = _abi.make_config(n_envs, num_agents=1, num_traffic=16, num_lasers=0, auto_reset=kw.get("auto_reset", 1), seed=3)
+    eng, ora = Engine(cfg, mb, sb), orc.Oracle(cfg, mb, sb)
+    td = td or _abi.make_topdown_config()
+    eng.enable_topdown(td)
+    ora.enable_topdown(td)
+    return torch, eng, ora, mb, sb
+
+
+def test_topdown_parity_with_the_oracle(descs):
+    """84 x 84 x 5 images (TopDownPGDriveEnv defaults) of 48 envs over 70 teacher-forced steps incl. auto-resets: every pixel is one
+    of the channel's two or three exact values, so the comparison is exact except where a pixel centre sits on an edge (fp32 vs
+    fp64 inside / outside); such pixels are counted."""
+    n = 32
+    torch, eng, ora, mb, sb = _setup(descs, n)
+    ids = np.arange(n) % 8
+    ora.reset(ids)
+    eng.reset(ids)
+    rng = np.random.default_rng(2)
+    tot = diff = 0
+    seen = dict(line=0, navi=0, veh=0, past=0, old_frames=0, resets=0)
+    # waiting traffic moved into view: a few vehicles around every ego (random offsets / headings), so that the traffic
+    # channels have something to show from the first frame on
+    f, i, ei = ora.get_state()
+    SF, SI = _abi.SF, _abi.SI
+    for k in range(1, 6):
+        th = f[SF["THETA"], :, 0]
+        fw, lt = rng.uniform(6, 26, n), rng.uniform(-9, 9, n)
+        f[SF["X"], :, k] = f[SF["X"], :, 0] + fw * np.cos(th) - lt * np.sin(th)
+        f[SF["Y"], :, k] = f[SF["Y"], :, 0] + fw * np.sin(th) + lt * np.cos(th)
+        f[SF["THETA"], :, k] = th + rng.uniform(-3.0, 3.0, n) * (k % 2)  # every other one keeps the ego's heading (snapped when ~0)
+        f[SF["HX"], :, k] = f[SF["HY"], :, k] = 0.0
+        i[SI["STATUS"], :, k] = _abi.ST_PENDING
+    f32 = util.round_state_f32(f)
+    ora.set_state(f32, i, ei)
+    eng.set_state(f32, i, ei)
+
+    def compare():
+        nonlocal tot, diff
+        g = eng.observe_topdown().cpu().numpy().astype(np.float64)
+        o = ora.observe_topdown()
+        assert g.shape == o.shape == (n, 84, 84, 5)
+        assert set(np.unique(np.round(g[..., 0], 6))) <= {0.0, round(TD_LINE, 6), round(TD_NAVI, 6)}
+        assert set(np.unique(g[..., 1])) <= {0.0, 1.0}
+        assert set(np.unique(np.round(g[..., 2:], 6))) <= {0.0, round(TD_VEH, 6)}
+        d = np.abs(g - o) > 1e-6
+        tot += d.size
+        diff += int(d.sum())
+        seen["line"] += int((o[..., 0] == TD_LINE).sum()); seen["navi"] += int((o[..., 0] == TD_NAVI).sum())
+        seen["veh"] += int((o[..., 2] > 0).sum()); seen["past"] += int(o[..., 1].sum())
+        seen["old_frames"] += int((np.abs(o[..., 2] - o[..., 4]) > 0).any(axis=(1, 2)).sum())
+        return g
+
+    compare()
+    for t in range(56):
+        act = util.driving_actions(rng, n)
+        act[:, 0, 1] = np.abs(act[:, 0, 1]) * 0.7 + 0.3
+        if t % 4 == 0:
+            act[::3, 0, 0] = 1.0
+        o_out = ora.step(act)
+        eng.step(torch.from_numpy(act).to(eng.device))
+        eng.sync()
+        seen["resets"] += int(o_out[2].sum())
+        f, i, ei = ora.get_state()
+        f32 = util.round_state_f32(f)
+        ora.set_state(f32, i, ei)
+        eng.set_state(f32, i, ei)
+        compare()
+    print("top-down parity: pixels", tot, "edge pixels that differ", diff, seen)
+    assert diff <= 2e-5 * tot
+    assert seen["line"] > 100000 and seen["navi"] > 500000 and seen["veh"] > 5000 and seen["past"] > 2000
+    assert seen["old_frames"] > 100 and seen["resets"] > 5
+    eng.close()
+
+
+def test_topdown_known_answers(descs):
+    """Right after a reset: the ego stands on its route (centre pixel = navigation grey, ego not drawn in the traffic channels),
+    the three traffic frames are identical (the history is the first frame repeated), past_pos has exactly the centre pixel;
+    a vehicle teleported 10 m ahead appears as a blob of its box size centred 14 px above the centre; after six steps the
+    newest frame differs from the oldest for a moving ego."""
+    n = 8
+    torch, eng, ora, mb, sb = _setup(descs, n, auto_reset=0)
+    ids = np.arange(n) % 8
+    eng.reset(ids)
+    ora.reset(ids)
+    g = eng.observe_topdown().cpu().numpy()
+    c = 42
+    assert np.allclose(g[:, c, c, 0], TD_NAVI, atol=1e-6) or (np.isin(np.round(g[:, c, c, 0], 5), [round(TD_NAVI, 5), round(TD_LINE, 5)])).all()
+    assert (g[:, c - 1:c + 1, c - 1:c + 1, 2:] == 0).all()
+    assert (g[..., 2] == g[..., 3]).all() and (g[..., 3] == g[..., 4]).all()
+    assert (g[..., 1].sum(axis=(1, 2)) == 1).all() and (g[:, c, c, 1] == 1).all()
+    # a vehicle 10 m straight ahead of the ego
+    f, i, ei = ora.get_state()
+    SF, SI = _abi.SF, _abi.SI
+    k = 1
+    th = f[SF["THETA"], :, 0]
+    f[SF["X"], :, k] = f[SF["X"], :, 0] + 10 * np.cos(th)
+    f[SF["Y"], :, k] = f[SF["Y"], :, 0] + 10 * np.sin(th)
+    f[SF["THETA"], :, k] = th
+    f[SF["HX"], :, k] = f[SF["HY"], :, k] = 0.0
+    i[SI["STATUS"], :, k] = _abi.ST_PENDING
+    eng.set_state(f, i, ei)
+    eng.reset  # (no reset: the history keeps the old frames, the new frame shows the vehicle)
+    g = eng.observe_topdown().cpu().numpy()
+    blob = g[..., 2] > 0
+    rows = np.array([np.nonzero(blob[e].any(axis=1))[0].mean() for e in range(n)])
+    cols = np.array([np.nonzero(blob[e].any(axis=0))[0].mean() for e in range(n)])
+    assert np.abs(rows - (c - 0.5 - 14)).max() < 1.2 and np.abs(cols - (c - 0.5)).max() < 1.2  # 10 m * 1.4 px/m ahead = up
+    sp = sb.spawns[ids * sb.V + k]
+    area = blob.sum(axis=(1, 2))
+    assert np.all(np.abs(area - sp["length"] * sp["width"] * 1.4 * 1.4) < 6)
+    assert (g[..., 3][blob] == 0).all()  # the older frames do not have it
+    # drive: after 6 steps the frame of 5 steps ago is a different picture from the newest one
+    act = np.zeros((n, 1, 2), np.float32)
+    act[..., 1] = 1.0
+    for t in range(12):
+        eng.step(torch.from_numpy(act).to(eng.device))
+        g = eng.observe_topdown().cpu().numpy()
+    assert (g[..., 2] != g[..., 3]).any(axis=(1, 2)).all()
+    assert (g[..., 1].sum(axis=(1, 2)) >= 2).all()  # several past positions marked by now
+    eng.close()
+
+
+def test_topdown_env_class():
+    """TopDownPGDriveEnv mirrors envs/top_down_env.py:28-42: image observation space [84, 84, 5], lidar removed."""
+    from pgdrive_amd.env import TopDownPGDriveEnv
+    env = TopDownPGDriveEnv(dict(start_seed=1000, environment_num=4))
+    try:
+        assert env.observation_space.shape == (84, 84, 5)
+        o = env.reset()
+        assert o.shape == (84, 84, 5) and o.dtype == np.float32 and o.min() >= 0.0 and o.max() <= 1.0
+        tot = 0
+        for t in range(30):
+            o, r, d, info = env.step([0.0, 1.0])
+            assert o.shape == (84, 84, 5) and env.observation_space.contains(o)
+            tot += r
+            if d:
+                o = env.reset()
+        assert tot > 1.0
+    finally:
+        env.close()
