@@ -40,13 +40,13 @@ PREROLL_MIN = 1500    # steps before the timed region (steady-state traffic)
 TIMED_MIN = 2000      # timed steps (>= 64 event groups of PROF_STRIDE launches)
 
 
-# Algorithmic HBM bytes per env-step for this build's record layout (DESIGN.md §4):
-#   state r/w   2 * V * (23 f32 + 7 i32) * 4 B  + env ints 2*5*4
-#   actions 8*A, spawn params read V*48, obs write 4*A*D, reward/done/flags 9*A,
-#   k_observe re-read of 7 floats/vehicle
+# Algorithmic HBM bytes per env-step for this build's record layout (DESIGN.md section 4):
+#   vehicle records  V x 128 B read + V x 128 B written (one cache line per slot: ABI fields + carried derived state)
+#   env row 32 B read + written, per-env map header 64 B read, actions 8*A, spawn parameters V*48 (pose .. max_speed),
+#   reward / done / flags 9*A, observation row 4*A*D written (fused) -- k_observe (stand-alone): V records' 28 B + row + view
 def algorithmic_bytes(A, T, D):
     V = A + T
-    k_step = 2 * V * (23 + 7) * 4 + 40 + 8 * A + V * 48 + 9 * A
+    k_step = 2 * V * 128 + 64 + 64 + 8 * A + V * 48 + 9 * A
     k_obs = V * (5 * 4 + 8) + 4 * A * D + A * 12 * 4
     fused = k_step + 4 * A * D  # observation fused into k_step: no re-read of the vehicle records, obs row written once
     return k_step, k_obs, fused

@@ -1,0 +1,41 @@
+"""Summarise the separate rocprofv3 --pmc passes of tools/profile_pass.sh into the traffic record bench.py reads
+(profiles/rNN_pmc_traffic.json): HBM bytes per k_step launch = FETCH_SIZE * c_f + WRITE_SIZE * c_w, both corrections measured on
+this engine's own access pattern with profiles/r01_calib.hip (the guide's gfx950 rule: FETCH_SIZE reports half of a wide
+coalesced read)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+O = sys.argv[1]
+
+
+def pmc(d, steady_only=False):
+    acc = collections.defaultdict(list)
+    for f in glob.glob("%s/%s/**/*counter_collection.csv" % (O, d), recursive=True):
+        for row in csv.DictReader(open(f)):
+            acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+    return acc
+
+
+fetch, write, cf, cw = pmc("fetch"), pmc("write"), pmc("cal_fetch"), pmc("cal_write")
+kname = [k for k in fetch if "k_step" in k][0]
+steady = lambda v: v[len(v) * 3 // 4:]  # the last quarter of the dispatches: steady-state traffic (after the 1500-step pre-roll)
+fk = sum(steady(fetch[kname])) / len(steady(fetch[kname]))
+wk = sum(steady(write[kname])) / len(steady(write[kname]))
+rec_bytes, row_bytes = 4096 * 17 * 128, 4096 * 274 * 4
+rc_f = sum(cf["rec_copy"]) / len(cf["rec_copy"])
+rc_w = sum(cw["rec_copy"]) / len(cw["rec_copy"])
+rw_w = sum(cw["row_write"]) / len(cw["row_write"])
+c_f, c_w = rec_bytes / (rc_f * 1024.0), rec_bytes / (rc_w * 1024.0)
+out = dict(envs=4096, traffic=16, lasers=240, kernel=kname, FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk,
+           dispatches_averaged=len(steady(fetch[kname])),
+           calibration=dict(rec_copy_bytes=rec_bytes, rec_copy_FETCH_SIZE_KB=rc_f, rec_copy_WRITE_SIZE_KB=rc_w, row_write_bytes=row_bytes,
+                            row_write_WRITE_SIZE_KB=rw_w, fetch_correction=c_f, write_correction_records=c_w,
+                            write_correction_rows=row_bytes / (rw_w * 1024.0)),
+           bytes_per_launch=(fk * c_f + wk * c_w) * 1024.0, bytes_per_env_step=(fk * c_f + wk * c_w) * 1024.0 / 4096,
+           note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --exact --steps 200 --warmup 1500` "
+                "(KB per dispatch, last quarter of the k_step dispatches = steady state). Corrections as MI355X_MICROARCH.md (HBM "
+                "section) prescribes, measured on the engine's own record pattern with profiles/r01_calib.hip.")
+print(json.dumps(out, indent=1))
