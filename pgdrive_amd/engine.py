@@ -70,6 +70,8 @@ def load_library(path=None):
         )
     L = C.CDLL(p)
     for name, (res, args) in _SIGS.items():
+        if path is None and os.environ.get("PGD_LIB") and not hasattr(L, name):
+            continue  # A/B runs of an OLDER build (tools/ab.sh): entry points it does not have yet are simply absent
         fn = getattr(L, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
