@@ -1,16 +1,18 @@
 #!/bin/bash
-# usage: pmc.sh tag "COUNTER1 COUNTER2 ..."
-R=$GRAFT_REPO_ROOT
+# usage: pmc.sh TAG "COUNTER1 COUNTER2 ..." [bench args]  -- one rocprofv3 --pmc pass, averaged per k_step dispatch (steady state)
+R=$GRAFT_REPO_ROOT; TAG=$1; CNT=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
-mkdir -p $R/gpurun_out/pmc_$1
-timeout 300 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$1 -- python $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline > $R/gpurun_out/pmc_$1/log.txt 2>&1 < /dev/null
+mkdir -p $R/gpurun_out/pmc_$TAG
+timeout 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$TAG -- python $R/bench.py --exact --steps 100 --warmup 1500 --no-cpu-baseline "$@" > $R/gpurun_out/pmc_$TAG/log.txt 2>&1 < /dev/null
 python - <<PY
 import csv,glob,collections
-fs=glob.glob("$R/gpurun_out/pmc_$1/**/*counter_collection.csv", recursive=True)
-acc=collections.defaultdict(lambda:[0.0,0])
+fs=glob.glob("$R/gpurun_out/pmc_$TAG/**/*counter_collection.csv", recursive=True)
+acc=collections.defaultdict(list)
 for f in fs:
     for row in csv.DictReader(open(f)):
         if 'k_step' in row['Kernel_Name']:
-            a=acc[row['Counter_Name']]; a[0]+=float(row['Counter_Value']); a[1]+=1
-for k,(v,n) in sorted(acc.items()): print("$1", k, "per launch", round(v/n,1), "launches", n)
+            acc[row['Counter_Name']].append(float(row['Counter_Value']))
+for k,v in sorted(acc.items()):
+    v=v[len(v)//2:]
+    print("$TAG", k, "per launch", round(sum(v)/len(v),1), "launches", len(v))
 PY
