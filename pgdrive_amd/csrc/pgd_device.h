@@ -34,6 +34,7 @@ struct PgdDev {
   const pgd_scenario* scen;
   const pgd_map* scen_map;    // [n_scen] copy of each scenario's map header
   const pgd_spawn* spawns;
+  const float2* spawn_hv;     // [n_scen * sstride] (cos, sin) of each spawn heading (k_spawn_hv at upload)
   int n_scen;
   struct Veh* rec;  // [N*V] one 128-byte record per vehicle slot (device layout; the ABI blobs are field-major)
   int32_t* ei;         // [N][PGD_NEI]

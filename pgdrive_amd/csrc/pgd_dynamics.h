@@ -71,7 +71,7 @@ DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse, con
   r.th = heading_wrap(r.th);
 }
 
-DEV void reset_vehicle(const pgd_spawn& p, Veh& r, int spawn_index, bool is_agent) {  // base_vehicle.py:292-339
+DEV void reset_vehicle(const pgd_spawn& p, const float2 hv, Veh& r, int spawn_index, bool is_agent) {  // base_vehicle.py:292-339
   memset(&r, 0, sizeof(Veh));
   // agents have no PID state: under PGD_MA_TOLLGATE the fields carry in_toll_time = 0 and entry / exit / last block = none
   // (marl_tollgate.py:36-60,76-96); harmless otherwise
@@ -83,7 +83,7 @@ DEV void reset_vehicle(const pgd_spawn& p, Veh& r, int spawn_index, bool is_agen
   r.status = p.group == -1 ? ST_ACTIVE : ST_PENDING;  // PGD_GROUP_NEVER (-2): in the world, never driven
   r.x = p.x; r.y = p.y; r.th = heading_wrap(p.heading);
   r.lastx = p.x; r.lasty = p.y;
-  sincosf(p.heading, &r.lasthy, &r.lasthx);
+  r.lasthx = hv.x; r.lasthy = hv.y;
   r.hx = r.lasthx; r.hy = r.lasthy;
   r.target = 30.0f;
   r.lane = p.lane;

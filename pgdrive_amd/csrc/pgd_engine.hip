@@ -269,14 +269,15 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
 #endif
   if (near_env) {
     const int my_kind = (OBJ && valid) ? s_kind[slot] : PGD_OBJ_VEHICLE;
-    if (valid && S.present[slot] && (leader || (OBJ && my_kind != PGD_OBJ_VEHICLE))) {  // object sub-lanes all keep their copy of the bit
+    if (valid && S.present[slot]) {  // a vehicle's sub-lanes split the agents; object sub-lanes all keep their copy of the bit
       const Obb me = snap_obb(S, slot);
       const float my_trav = V <= PGD_SUBV ? SUBP.trav[slot] : 0.0f;
       const float my_rad = me.hl + (me.hw < 0.0f ? 0.0f : me.hw);  // >= the circumradius
       // a traffic object reports only its first contact (TrafficObject.crashed / COST_ONCE, collision_callback.py:27-32)
       const bool live = !OBJ || my_kind == PGD_OBJ_VEHICLE || !(r.vflags & (int)PGD_F_OBJECT_HIT);
       bool touched = false;
-      for (int a = 0; a < A; ++a) {
+      const bool split = !OBJ || my_kind == PGD_OBJ_VEHICLE;
+      for (int a = split ? g.sub : 0; a < A; a += split ? g.SUB : 1) {
         if (a == s || (OBJ && !S.present[base + a])) continue;
         const Obb ag = snap_obb(S, base + a);
         const float ag_trav = V <= PGD_SUBV ? SUBP.trav[base + a] : 0.0f;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         if (!hit) continue;
         touched = true;
         if (!OBJ) s_hit[base + a] = 1;
-        else if (leader && live) atomicOr(&s_hit[base + a], my_kind == PGD_OBJ_VEHICLE ? 1 : (my_kind == PGD_OBJ_BUILDING ? 4 : 2));
+        else if ((leader || split) && live) atomicOr(&s_hit[base + a], my_kind == PGD_OBJ_VEHICLE ? 1 : (my_kind == PGD_OBJ_BUILDING ? 4 : 2));
       }
       if (OBJ && touched && my_kind != PGD_OBJ_VEHICLE && my_kind != PGD_OBJ_BUILDING) r.vflags |= (int)PGD_F_OBJECT_HIT;  // all sub-lanes
     }
@@ -314,10 +315,13 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   XMARK(4);
   // (6) after_step; traffic off the lanes is removed (traffic_manager.py:91-109)
   if (acting) {
-    after_step_vehicle(d.cfg, mv, g, *sp, r, s < A, !one_env, ctx);
+    // several agents: each tests its own box against the lines with its sub-lanes (all agents at once) instead of the
+    // whole wave working through the agents one after the other
+    after_step_vehicle(d.cfg, mv, g, *sp, r, s < A, !one_env || A > 1, ctx);
     if (s >= A && (r.vflags & PGD_F_OFF_LANE)) r.status = ST_REMOVED;
   }
-  if (one_env) {  // line / sidewalk test of each agent by the whole wave (base_vehicle.py:615-644)
+  PHASE_MARK(25);  // after_step: per-vehicle part
+  if (one_env && A == 1) {  // line / sidewalk test of the agent by the whole wave (base_vehicle.py:615-644)
     if (leader && valid && s < A) s_flag[A + s] = (acting && !ctx.clear) ? 1 : 0;  // clear: provably no contact (after_step)
     __syncthreads();
     for (int a = 0; a < A; ++a) {
@@ -334,6 +338,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   s_flag[lane] = 0;
   __syncthreads();
   unsigned my_fl = 0;
+  bool fresh = false;  // multi-agent: this lane's slot received a new agent in this step
   bool my_dn = false;
   float my_rew = 0.0f;
   const bool was_active = acting;  // status at the start of the step (after the delay-done countdown)
@@ -375,6 +380,17 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         else { r.status = ST_DYING; r.timer = gcf.delay_done; }
       }
     }
+    if (valid && leader && s < A) {  // reward and done are final here: written now, not carried across the respawn code
+      const size_t k = (size_t)e * A + s;
+      reward[k] = my_rew;
+      done[k] = my_dn ? 1 : 0;
+      if (d.prow) {
+        float* tail = d.prow + (size_t)e * d.ostride + (size_t)A * d.D;
+        tail[s] = my_rew;
+        tail[A + s] = my_dn ? 1.0f : 0.0f;
+      }
+    }
+    PHASE_MARK(26);  // marl: reward / done / finish
     // the world after the finishes (leaders publish, everybody reads)
     __syncthreads();
     if (valid && leader) {
@@ -392,8 +408,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       const pgd_spawn* rbase = d.spawns + (size_t)scen * d.sstride + V;
       for (int p = 0; p < gcf.respawn_places; ++p) {
         const pgd_spawn& place = rbase[p * gcf.respawn_dests];
-        float ps, pc;
-        sincosf(place.heading, &ps, &pc);
+        const float2 phv = d.spawn_hv[(size_t)scen * d.sstride + V + p * gcf.respawn_dests];
+        const float pc = phv.x, ps = phv.y;
         const Obb region{place.x, place.y, pc, ps, 4.0f, 1.5f};  // RESPAWN_REGION 8 m x 3 m (spawn_manager.py:27-28)
         const bool blocks = lane < V && S.present[lane] && obb_overlap(region, snap_obb(S, lane));
         if (__ballot(blocks) != 0ull) continue;
@@ -418,10 +434,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         if (valid && s == tslot) {
           const int sidx = V + p * gcf.respawn_dests + dest;
           sp = d.spawns + (size_t)scen * d.sstride + sidx;
-          reset_vehicle(*sp, r, sidx, true);
-          route_refresh(mv, *sp, r);
+          reset_vehicle(*sp, d.spawn_hv[(size_t)scen * d.sstride + sidx], r, sidx, true);
           r.agent_id = (float)next_agent;
-          after_step_vehicle(d.cfg, mv, g, *sp, r, true, true, ctx);
+          fresh = true;
           my_fl |= PGD_F_NEW;
           if (leader) {
             S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
@@ -433,6 +448,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         __syncthreads();
       }
     }
+    if (fresh) route_refresh(mv, *sp, r);  // the toll bookkeeping below reads the new agent's block id
+    PHASE_MARK(27);  // marl: respawn
     // StayTimeManager.record(active_agents, episode_steps) after the step (marl_tollgate.py:36-60,276-279)
     if (toll && valid && s < A && r.status == ST_ACTIVE) {
       const float cur = (float)r.blk, last = r.pli;
@@ -490,17 +507,22 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   if (valid && leader && s < A) {
     size_t k = (size_t)e * A + s;
-    reward[k] = my_rew;
-    done[k] = my_dn ? 1 : 0;
     flags[k] = my_fl;
-    if (d.prow) {  // pgd_step_packed: [A*D obs | A reward | A done] per env
-      float* tail = d.prow + (size_t)e * d.ostride + (size_t)A * d.D;
-      tail[s] = my_rew;
-      tail[A + s] = my_dn ? 1.0f : 0.0f;
+    if (!marl) {
+      reward[k] = my_rew;
+      done[k] = my_dn ? 1 : 0;
+      if (d.prow) {  // pgd_step_packed: [A*D obs | A reward | A done] per env
+        float* tail = d.prow + (size_t)e * d.ostride + (size_t)A * d.D;
+        tail[s] = my_rew;
+        tail[A + s] = my_dn ? 1.0f : 0.0f;
+      }
     }
   }
   PHASE_MARK(7);  // reset
   XMARK(7);
+  // first localisation of the agents that entered in this step: all of them at once, at the point of the kernel where
+  // nothing but the record itself is still needed (the place loop reads spawn poses only; a restart discards the agent)
+  if (marl && fresh && !resetting) after_step_vehicle(d.cfg, mv, g, *sp, r, true, true, ctx);
   bool stored = false;
   if (valid && leader) {
     // a slot that neither drove, restarted, counted down (delay-done) nor changed status / flags still holds its record:
@@ -524,7 +546,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   XMARK(8);
   // (9) observation of the new state, fused: the wave already holds every vehicle of the env (obs/state_obs.py:132-170)
   bool near_next = true;  // EI_NEAR of the next step: only the fused observation can clear it
-  if (ONE_ENV && obs != nullptr) {  // host passes obs only when one_env && A <= FUSE_MAX_AGENTS
+  if (ONE_ENV && !MARL && obs != nullptr) {  // host passes obs only when one_env && !marl && A <= FUSE_MAX_AGENTS
     __syncthreads();
     if (valid && leader) {
       const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
@@ -573,6 +595,15 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_END();
 }
 
+// heading vectors of the spawn poses, once per upload (the restart of a vehicle then evaluates no sincosf)
+__global__ void k_spawn_hv(const pgd_spawn* __restrict__ sp, float2* __restrict__ hv, size_t n) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  float sn, cs;
+  sincosf(sp[k].heading, &sn, &cs);
+  hv[k] = make_float2(cs, sn);
+}
+
 // slot `s` of scenario `scen` right after a reset (base_env.py:269-301): spawn state + first localisation; agent ids restart
 // at 0: id = number of spawned agent slots below this one (agent_manager.py:91-132).  Returns the ballot of spawned agents.
 DEV unsigned long long reset_slot(const PgdDev& d, const LaneMap& lm, int scen, Veh& r) {
@@ -580,7 +611,7 @@ DEV unsigned long long reset_slot(const PgdDev& d, const LaneMap& lm, int scen, 
   const Grp g{lm.sub, d.sub, lm.lead};
   const pgd_spawn* sp = d.spawns + (size_t)scen * d.sstride + s;
   MapView mv = map_view(d, d.scen[scen].map);
-  reset_vehicle(*sp, r, s, s < A);
+  reset_vehicle(*sp, d.spawn_hv[(size_t)scen * d.sstride + s], r, s, s < A);
   RouteCtx ctx;
   if (r.status != ST_EMPTY) {
     route_refresh(mv, *sp, r);
@@ -760,6 +791,7 @@ struct pgd_engine {
   pgd_box* cell_boxes;
   LaneExt* cell_ext;
   LaneNav* lane_nav;
+  float2* spawn_hv;
   pgd_map* scen_map;  // per scenario: copy of its map header (saves one dependent load per block)
   float2* beam;       // lidar beam directions in the vehicle frame
   VehRec* reset_img;  // [n_scen][V], rebuilt after every map / scenario upload
@@ -1033,6 +1065,14 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   if ((rc = upload(&h->scen, scen, n_scen, h->stream))) return rc;
   if ((rc = upload(&h->spawns, spawns, (size_t)n_scen * h->d.sstride, h->stream))) return rc;
   h->d.scen = h->scen; h->d.spawns = h->spawns; h->d.n_scen = n_scen;
+  {
+    const size_t ns = (size_t)n_scen * h->d.sstride;
+    if (h->spawn_hv) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipFree(h->spawn_hv)); h->spawn_hv = nullptr; }
+    HIPCHK(hipMalloc((void**)&h->spawn_hv, sizeof(float2) * ns));
+    hipLaunchKernelGGL(k_spawn_hv, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, h->stream, h->spawns, h->spawn_hv, ns);
+    HIPCHK(hipGetLastError());
+    h->d.spawn_hv = h->spawn_hv;
+  }
   for (size_t k = 0; k < (size_t)n_scen * h->d.sstride; ++k)
     if (spawns[k].lane >= 0 && (!(spawns[k].max_steer <= 1.0f) || spawns[k].n_ckpt > PGD_MAX_CKPT)) return PGD_ERR_ARG;  // tan_small
   h->has_objects = false;
@@ -1402,7 +1442,7 @@ int pgd_destroy(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->d.rec, h->d.ei, h->d.imask, h->d.env_map, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
-                  h->cell_items, h->cell_boxes, h->cell_ext, h->lane_nav, h->scen_map, h->scen, h->spawns, h->beam, h->reset_img};
+                  h->cell_items, h->cell_boxes, h->cell_ext, h->lane_nav, h->scen_map, h->scen, h->spawns, h->spawn_hv, h->beam, h->reset_img};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   (void)hipEventDestroy(h->ev0);

@@ -204,32 +204,47 @@ DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& s
   PHASE_MARK(18);  // after_step: lane_local + checkpoints
 }
 
-// BaseVehicle._state_check (base_vehicle.py:615-644)
+// BaseVehicle._state_check (base_vehicle.py:615-644): the car's box against the line / sidewalk boxes of the grid cells under
+// it.  The (<= 2 x 2) cells are flattened into one index range (their four start offsets are read at once: one dependent
+// level for the whole neighbourhood) that the sub-lanes of the vehicle stride through, two boxes in flight per lane.
 DEV unsigned state_check(const MapView& mv, const Grp& g, const Obb& car) {
   const pgd_map& m = *mv.m;
   float ex = fabsf(car.ux) * car.hl + fabsf(car.uy) * car.hw, ey = fabsf(car.uy) * car.hl + fabsf(car.ux) * car.hw;
   int cx0 = max((int)floorf((car.cx - ex - m.ox) / m.cell), 0), cx1 = min((int)floorf((car.cx + ex - m.ox) / m.cell), m.gx - 1);
   int cy0 = max((int)floorf((car.cy - ey - m.oy) / m.cell), 0), cy1 = min((int)floorf((car.cy + ey - m.oy) / m.cell), m.gy - 1);
   unsigned fl = 0;
-  const int stride = g.SUB;
-  for (int cy = cy0; cy <= cy1; ++cy)
-    for (int cx = cx0; cx <= cx1; ++cx) {
-      int cell = cy * m.gx + cx;
-      int k0 = cell_mid(mv.cstart[cell]), k1 = cell_first(mv.cstart[cell + 1]);
-      for (int k = k0 + g.sub; k < k1; k += 4 * stride) {
-        pgd_box b[4];
+  for (int cyb = cy0; cyb <= cy1; cyb += 2)
+    for (int cxb = cx0; cxb <= cx1; cxb += 2) {  // blocks of up to 2x2 cells (a car spans at most 2 cells per axis)
+      int k0[4], pre[5];
+      pre[0] = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int kk = k + j * stride;
-          b[j] = mv.cbox[kk < k1 ? kk : k];
+      for (int q = 0; q < 4; ++q) {
+        int cx = cxb + (q & 1), cy = cyb + (q >> 1);
+        bool in = cx <= cx1 && cy <= cy1;
+        int cell = in ? cy * m.gx + cx : 0;
+        int a = cell_mid(mv.cstart[cell]), b = cell_first(mv.cstart[cell + 1]);
+        k0[q] = a;
+        pre[q + 1] = pre[q] + (in ? b - a : 0);
+      }
+      const int n = pre[4];
+      for (int f = g.sub; f < n; f += 2 * g.SUB) {
+        pgd_box b[2];
+        bool have[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int fj = f + j * g.SUB;
+          have[j] = fj < n;
+          const int ff = have[j] ? fj : f;
+          const int q = (ff >= pre[1]) + (ff >= pre[2]) + (ff >= pre[3]);
+          const int kk = (q == 0 ? k0[0] : q == 1 ? k0[1] : q == 2 ? k0[2] : k0[3]) + ff - (q == 0 ? pre[0] : q == 1 ? pre[1] : q == 2 ? pre[2] : pre[3]);
+          b[j] = mv.cbox[kk];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int kk = k + j * stride;
-          if (kk >= k1) continue;
-          unsigned bit = b[j].kind == PGD_BOX_WHITE ? PGD_F_ON_WHITE
-                         : b[j].kind == PGD_BOX_YELLOW ? PGD_F_ON_YELLOW
-                         : b[j].kind == PGD_BOX_BROKEN ? PGD_F_ON_BROKEN : PGD_F_CRASH_SIDEWALK;
+        for (int j = 0; j < 2; ++j) {
+          if (!have[j]) continue;
+          const unsigned bit = b[j].kind == PGD_BOX_WHITE ? PGD_F_ON_WHITE
+                               : b[j].kind == PGD_BOX_YELLOW ? PGD_F_ON_YELLOW
+                               : b[j].kind == PGD_BOX_BROKEN ? PGD_F_ON_BROKEN : PGD_F_CRASH_SIDEWALK;
           if (fl & bit) continue;
           if (obb_overlap(car, obb_of(b[j]))) fl |= bit;
         }
@@ -269,7 +284,7 @@ DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp&
     }
     unsigned fl = (unsigned)r.vflags;
     fl &= ~(PGD_F_ON_WHITE | PGD_F_ON_YELLOW | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OUT_OF_ROUTE);
-    if (with_state_check) fl |= state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sp.length, 0.5f * sp.width});
+    if (with_state_check && !ctx.clear) fl |= state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sp.length, 0.5f * sp.width});
     float lon, lat;
     const pgd_lane& L0 = mv.lanes[r.cur_first];
     lane_local(L0, r.x, r.y, lon, lat);
