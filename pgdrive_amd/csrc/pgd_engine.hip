@@ -48,18 +48,21 @@ __shared__ long long s_prof_t0, s_prof_w0;
     }                                                                                                      \
   } while (0)
 #define PHASE_INIT() do { if (threadIdx.x == 0) { s_prof_t0 = clock64(); s_prof_w0 = wall_clock64(); } } while (0)
-#define PHASE_END() do { if (threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS) g_phase_cycles[blockIdx.x * 32 + 15] += (unsigned long long)(wall_clock64() - s_prof_w0); } while (0)
+#define PHASE_END_AT(k) do { if (threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS) g_phase_cycles[blockIdx.x * 32 + (k)] += (unsigned long long)(wall_clock64() - s_prof_w0); } while (0)
+#define PHASE_END() PHASE_END_AT(15)
 #elif defined(PGD_EXITAT)
 // "exit profile" build (tools/exit_profile.py; never shipped): every wave leaves the kernel at top-level mark d.dbg_exit
 // without storing anything, so the launch time up to each point of the step is measured on an unchanging state
 #define PHASE_MARK(k)
 #define PHASE_INIT()
 #define PHASE_END()
+#define PHASE_END_AT(k)
 #define XMARK(k) do { if (d.dbg_exit == (k)) return; } while (0)
 #else
 #define PHASE_MARK(k)
 #define PHASE_INIT()
 #define PHASE_END()
+#define PHASE_END_AT(k)
 #endif
 #ifndef XMARK
 #define XMARK(k)
@@ -495,8 +498,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     load_rec(d.reset_img + (size_t)scen * V + s, r);
     const unsigned long long am = __ballot(leader && s < A && r.status == ST_ACTIVE);
     if (marl && s < A && r.status == ST_ACTIVE) my_fl |= PGD_F_NEW;
-    if (s == 0 && g.sub < (int)(sizeof(pgd_map) / 16) && d.cfg.resample_scenario)  // the env's header copy follows the scenario
-      reinterpret_cast<uint4*>(d.env_map + e)[g.sub] = reinterpret_cast<const uint4*>(d.scen_map + scen)[g.sub];
+    if (s == 0 && d.cfg.resample_scenario)  // the env's header copy follows the scenario (any number of sub-lanes)
+      for (int q = g.sub; q < (int)(sizeof(pgd_map) / 16); q += g.SUB)
+        reinterpret_cast<uint4*>(d.env_map + e)[q] = reinterpret_cast<const uint4*>(d.scen_map + scen)[q];
     if (s == 0 && leader) {
       d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
       d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] = episodes;
@@ -706,70 +710,97 @@ __global__ __launch_bounds__(WAVE) void k_refresh(PgdDev d) {
 // a wave carries exactly one env; this kernel serves pgd_reset / pgd_observe and the configurations that do not fuse.
 // ---------------------------------------------------------------------------------------------------------------------
 // OTH: PGD_MA_OTHERS_STATE rows (a kernel of its own: the neighbour-state path would cost the plain one registers)
+// BLOCK threads produce one row.  BLOCK = 64: the block holds OBS_RPB independent rows, one per wave (a block per 64-lane
+// row made the launch dispatch-bound: 32768 workgroups that each live ~5 us); BLOCK = 256: one row per block.
+#define OBS_RPB 4
 template <int BLOCK, bool OTH>
-__global__ __launch_bounds__(BLOCK) void k_observe(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags) {
-  __shared__ ObsLds L;
+__global__ __launch_bounds__(BLOCK == WAVE ? WAVE * OBS_RPB : BLOCK, 8) void k_observe(PgdDev d, float* __restrict__ obs,
+                                                                                 const uint32_t* __restrict__ flags, int n_rows) {
+  constexpr bool WROW = BLOCK == WAVE;
+  __shared__ ObsLds Ls[WROW ? OBS_RPB : 1];
   const int V = d.V, A = d.A, D = d.D;
-  const int e = (int)blockIdx.x / A + d.unit_off * d.epw, a = (int)blockIdx.x % A;
-  const int tid = threadIdx.x;
+  const int rowi = WROW ? (int)blockIdx.x * OBS_RPB + (int)(threadIdx.x / WAVE) : (int)blockIdx.x;
+  if (rowi >= n_rows) return;
+  ObsLds& L = Ls[WROW ? threadIdx.x / WAVE : 0];
+  const int e = rowi / A + d.unit_off * d.epw, a = rowi % A;
+  const int tid = WROW ? (int)(threadIdx.x % WAVE) : (int)threadIdx.x;
   const VehRec* recs = d.rec + (size_t)e * V;  // the env's vehicle records
-  const VehRec& mine = recs[a];
   float* row = obs + (size_t)e * d.ostride + (size_t)a * D;
+  PHASE_INIT();
+  // A row lives a few microseconds and almost all of that is load latency, so the reads go out in three batches instead of
+  // one dependent chain.  Batch 1: every address that follows from the block index -- the observer's record, the first half
+  // of body `tid`'s record (pose, speed, status, spawn index, agent id), the step flags, the env's scenario and step count.
+  const int ob = tid < V ? tid : 0;
+  Veh me;
+  load_rec(recs + a, me);
+  uint4 bw[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bw[k] = reinterpret_cast<const uint4*>(recs + ob)[k];
+  const uint32_t fa = flags ? flags[(size_t)e * A + a] : 0u, fo = flags ? flags[(size_t)e * A + (tid < A ? tid : 0)] : 0u;
+  const int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
+  const uint32_t tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
+  Veh body;  // only the first 64 bytes are filled
+#pragma unroll
+  for (int k = 0; k < 4; ++k) reinterpret_cast<uint4*>(&body)[k] = bw[k];
   // which slots get a row: after a multi-agent step the ones that reported or were (re)spawned, else the active ones
-  bool want = mine.status == ST_ACTIVE;
-  if (flags) {
-    const uint32_t fa = flags[(size_t)e * A + a];
-    want = (fa & PGD_F_RESET) ? want : (fa & (PGD_F_REPORT | PGD_F_NEW)) != 0;  // after a reset only the new episode counts
-  }
+  bool want = me.status == ST_ACTIVE;
+  if (flags) want = (fa & PGD_F_RESET) ? want : (fa & (PGD_F_REPORT | PGD_F_NEW)) != 0;  // after a reset only the new episode counts
   if (!want) {
     for (int k = tid; k < D; k += BLOCK) row[k] = 0.0f;
     return;
   }
-  AgentView ag;
-  ag.x = mine.x; ag.y = mine.y; ag.th = mine.th;
-  ag.hx = mine.hx; ag.hy = mine.hy;
-  ag.dl = mine.dl; ag.dr = mine.dr; ag.v = mine.v; ag.steer = mine.steer;
-  ag.a0s = mine.a0s; ag.a0t = mine.a0t; ag.lhx = mine.lasthx; ag.lhy = mine.lasthy;
-  const int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
+  // batch 2: what the scenario and the spawn indices lead to -- map header, the observer's and the body's static parameters
   const pgd_spawn* spb = d.spawns + (size_t)scen * d.sstride;
+  const pgd_spawn& msp = spb[me.spawn];
+  const pgd_spawn& so = spb[body.spawn];
+  const float so_len = so.length, so_wid = so.width;
+  const int so_kind = so.kind;
+  MapView mv = map_view_of(d, d.scen_map + scen);
+  AgentView ag;
+  ag.x = me.x; ag.y = me.y; ag.th = me.th;
+  ag.hx = me.hx; ag.hy = me.hy;
+  ag.dl = me.dl; ag.dr = me.dr; ag.v = me.v; ag.steer = me.steer;
+  ag.a0s = me.a0s; ag.a0t = me.a0t; ag.lhx = me.lasthx; ag.lhy = me.lasthy;
+  ag.cur_first = me.cur_first; ag.cur_n = me.cur_n; ag.next_first = me.next_first;
+  ag.blk = me.blk; ag.toll_time = me.php;
+  ag.env = e; ag.slot = a; ag.tick = tick;
+  // batch 3 (lane records of the route) belongs to the state block, which needs nothing from the other bodies: it runs first
+  // and its reads overlap the spawn reads the compaction waits for
+  state_block<false>(d, mv, msp, ag, row, tid, BLOCK);
+  PHASE_MARK(22);  // obs: state + navi block
   if (tid < WAVE) {  // wave 0: broad phase r = lidar distance (lidar.py:109-124), compacted into LDS
     bool present = false, is_vehicle = true;
     float x = 0, y = 0, ux = 1, uy = 0, hl = 0, hw = 0, spd = 0;
     if (tid < V && d.cfg.num_lasers > 0) {
-      int st = recs[tid].status;
+      const int st = body.status;
       present = st == ST_PENDING || st == ST_ACTIVE || st == ST_DYING;
       bool still = st == ST_DYING;  // a finished agent is a static body (zero velocity)
       if (flags && tid < A) {
         // multi-agent step: rows of agents that drove this step show the world before the finishes / respawns
         // (base_env.py:303-344 runs before multi_agent_pgdrive.py:128-141); an agent spawned this step sees the world at
         // its spawn time, i.e. the earlier spawns of the step only
-        const uint32_t fa = flags[(size_t)e * A + a], fo = flags[(size_t)e * A + tid];
         if (fa & PGD_F_RESET) {
         } else if (fa & PGD_F_NEW) {
-          present = present && (!(fo & PGD_F_NEW) || recs[tid].agent_id < mine.agent_id);
+          present = present && (!(fo & PGD_F_NEW) || body.agent_id < me.agent_id);
         } else {
           present = (fo & PGD_F_REPORT) || (present && !(fo & PGD_F_NEW));
           still = still && !(fo & PGD_F_REPORT);
         }
       }
-      x = recs[tid].x; y = recs[tid].y;
-      ux = recs[tid].hx; uy = recs[tid].hy;
-      const pgd_spawn& so = spb[recs[tid].spawn];
-      hl = 0.5f * so.length; hw = so.kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * so.width;
-      is_vehicle = so.kind == PGD_OBJ_VEHICLE;
-      spd = still ? 0.0f : speed_kmh(recs[tid].v);
+      x = body.x; y = body.y;
+      ux = body.hx; uy = body.hy;
+      hl = 0.5f * so_len; hw = so_kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * so_wid;
+      is_vehicle = so_kind == PGD_OBJ_VEHICLE;
+      spd = still ? 0.0f : speed_kmh(body.v);
     }
     obs_compact<true>(L, tid, a, present, is_vehicle, x, y, ux, uy, hl, hw, spd, ag.x, ag.y, d.cfg.lidar_dist, ag.hx, ag.hy,
                       d.cfg.num_lasers);
   }
-  __syncthreads();
-  MapView mv = map_view_of(d, d.scen_map + scen);
-  const pgd_spawn& msp = spb[mine.spawn];
-  ag.cur_first = mine.cur_first; ag.cur_n = mine.cur_n; ag.next_first = mine.next_first;
-  ag.blk = mine.blk; ag.toll_time = mine.php;
-  ag.env = e; ag.slot = a; ag.tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
-  if (OTH) observe_agent<true, false, true>(d, mv, msp, ag, L, row, tid, BLOCK, recs, spb);
-  else observe_agent<true>(d, mv, msp, ag, L, row, tid, BLOCK);
+  row_sync<WROW>();
+  PHASE_MARK(28);  // k_observe: compaction
+  if (OTH) observe_agent<true, false, true, false, WROW>(d, mv, msp, ag, L, row, tid, BLOCK, recs, spb);
+  else observe_agent<true, false, false, false, WROW>(d, mv, msp, ag, L, row, tid, BLOCK);
+  PHASE_END_AT(29);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1091,12 +1122,12 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
                           int n_envs = 0) {
   const PgdDev& D = dv ? *dv : h->d;
   if (!stream) stream = h->stream;
-  int blocks = (n_envs > 0 ? n_envs : h->d.N) * h->d.A;
+  const int rows = (n_envs > 0 ? n_envs : h->d.N) * h->d.A;
   const bool oth = (h->d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && h->d.cfg.num_others > 0;
   const bool wide = h->d.cfg.num_lasers > 128;  // up to 128 beams one wave does it in two rounds: 4x fewer waves than 256-thread blocks
-  void (*kern)(PgdDev, float*, const uint32_t*) =
+  void (*kern)(PgdDev, float*, const uint32_t*, int) =
       wide ? (oth ? k_observe<256, true> : k_observe<256, false>) : (oth ? k_observe<64, true> : k_observe<64, false>);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(wide ? 256 : 64), 0, stream, D, d_obs, d_flags);
+  hipLaunchKernelGGL(kern, dim3(wide ? rows : (rows + OBS_RPB - 1) / OBS_RPB), dim3(wide ? 256 : WAVE * OBS_RPB), 0, stream, D, d_obs, d_flags, rows);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }

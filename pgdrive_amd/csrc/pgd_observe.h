@@ -186,7 +186,19 @@ DEV AgentView view_of_slot(const PgdDev& d, const MapView& mv, const VehRec* rec
 // STD: the reference's default row layout (no detector fans, no random_agent_model, no toll floats, no lidar noise) as a
 // compile-time fact: every column offset is a constant and the optional blocks vanish from the benchmark kernel.
 // OTH: PGD_MA_OTHERS_STATE (stand-alone k_observe only: `recs` / `spb` = the env's records and spawn table)
-template <bool OBJ, bool STD = false, bool OTH = false>
+// the threads that produce one row meet: a block-wide barrier, or -- when the row belongs to ONE wave of a block that holds
+// several rows -- nothing but the ordering of that wave's own LDS traffic (the waves of the block stay independent)
+template <bool WAVE_ROW>
+DEV void row_sync() {
+  if (WAVE_ROW) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } else __syncthreads();
+}
+
+// STATE = false: the caller has written the state block (and the toll floats' inputs are unchanged) already
+// WAVE_ROW: see row_sync
+template <bool OBJ, bool STD = false, bool OTH = false, bool STATE = true, bool WAVE_ROW = false>
 DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const AgentView& ag, ObsLds& L,
                        float* __restrict__ row, int tid, int nt, const VehRec* recs = nullptr, const pgd_spawn* spb = nullptr) {
   const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
@@ -198,7 +210,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   const int o_oth = (KS > 0 ? KS : 2) + 6 + KM + RAM + (toll ? 0 : 10);  // = length of the state block
   const int NO = d.cfg.num_others;
   const int per_other = OTH ? o_oth : 4;
-  state_block<STD>(d, mv, sp, ag, row, tid, nt);
+  if (STATE) state_block<STD>(d, mv, sp, ag, row, tid, nt);
   if (toll && tid == 0) {  // TollGateObservation.observe (marl_tollgate.py:84-96)
     const bool in_toll = ag.blk == '$';
     float* t2 = row + o_oth + per_other * NO + NL;
@@ -215,14 +227,14 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
     // by centre distance) contribute their own state vectors; absent ranks are zeros.  Ranks -> slots through LDS, then
     // the block evaluates one neighbour after the other with the same state_block code.
     if (tid < 16) L.rank_slot[tid] = -1;
-    __syncthreads();
+    row_sync<WAVE_ROW>();
     for (int k = tid; k < n; k += nt) {
       int rank = 0;
       const float dk = L.bdist[k];
       for (int j = 0; j < n; ++j) rank += (L.bdist[j] < dk || (L.bdist[j] == dk && j < k)) ? 1 : 0;
       if (rank < NO && dk < __builtin_inff()) { L.rank_slot[rank] = L.bslot[k]; L.rank_spd[rank] = L.bspd[k]; }
     }
-    __syncthreads();
+    row_sync<WAVE_ROW>();
     for (int r = 0; r < NO; ++r) {
       const int o = L.rank_slot[r];
       float* dst = row + o_oth + r * o_oth;

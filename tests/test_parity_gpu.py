@@ -31,7 +31,8 @@ def _engines(descs, n_envs, n_maps=8, **kw):
                            safe_rl_env=kw.get("safe_rl_env", False), num_others=kw.get("num_others", 4),
                            random_agent_model=kw.get("random_agent_model", False),
                            lidar_gaussian_noise=kw.get("lidar_gaussian_noise", 0.0),
-                           lidar_dropout_prob=kw.get("lidar_dropout_prob", 0.0), seed=kw.get("seed", 0))
+                           lidar_dropout_prob=kw.get("lidar_dropout_prob", 0.0), seed=kw.get("seed", 0),
+                           resample_scenario=kw.get("resample_scenario", 0))
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
     ora.map_bank, ora.scen_bank = mb, sb
@@ -632,15 +633,17 @@ def test_full_size_properties():
         e.close()
 
 
-def test_record_cache_matches_plain_records(descs):
+@pytest.mark.parametrize("num_traffic", [16, 24, 40])  # 3, 2, 1 sub-lanes per vehicle slot
+def test_record_cache_matches_plain_records(descs, num_traffic):
     """The step kernel skips the write of a record that did not change and reads never-written slots from the scenario's
     reset image.  Engine A runs freely with both short cuts; engine B gets A's complete state through get_state /
     set_state before every step (set_state drops the image marks, so B reads its own records).  Same kernel, same inputs:
     every output must be bit-identical, through terminations, auto-resets with re-drawn scenarios, a partial pgd_reset
-    and a scenario re-upload in the middle of the run."""
+    and a scenario re-upload in the middle of the run.  (A free-running env also keeps its own copy of the map header, which
+    set_state rebuilds: with fewer than four sub-lanes per slot the copy used to follow a re-drawn scenario only in part.)"""
     n_envs = 96
-    torch, eng_a, ora, cfg = _engines(descs, n_envs, seed=5)
-    _, eng_b, _, _ = _engines(descs, n_envs, seed=5)
+    torch, eng_a, ora, cfg = _engines(descs, n_envs, seed=5, num_traffic=num_traffic, resample_scenario=1)
+    _, eng_b, _, _ = _engines(descs, n_envs, seed=5, num_traffic=num_traffic, resample_scenario=1)
     scen_ids = np.arange(n_envs) % 8
     eng_a.reset(scen_ids)
     eng_b.reset(scen_ids)

@@ -30,7 +30,8 @@ def _actions(mode, rng, n):
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize("mode,steps", [("driving", 260), ("uniform", 120), ("straight", 200)])
 def test_all_maps_campaign(mode, steps):
-    """Teacher-forced GPU vs oracle on ALL 100 PGDrive-v0 maps (8 envs per map), 17 slots, 240 beams, auto-reset: done / flags
+    """Teacher-forced GPU vs oracle on ALL 100 PGDrive-v0 maps (8 envs per map), 17 slots, 240 beams, auto-reset onto a
+    re-drawn scenario: done / flags
     and the integer state bit-exact; observations, rewards and poses within tolerance.  Discrete fp32-vs-fp64 ties are
     counted by class, as in the one-off campaign of round 1 (profiles/r01_parity_campaign.md, 3.07 M env-steps, 0 flag
     mismatches): grazing lidar beams, a body exactly on the 50 m neighbour radius, an IDM leader exactly MAX_DIST = 30 m
@@ -42,7 +43,7 @@ def test_all_maps_campaign(mode, steps):
     descs = bank.get_descriptions(range(1000, 1100))
     n_envs = 800
     mb, sb = util.make_banks(descs, n_maps=100)
-    cfg = _abi.make_config(n_envs, num_agents=1, num_traffic=16, num_lasers=240, auto_reset=1, seed=11)
+    cfg = _abi.make_config(n_envs, num_agents=1, num_traffic=16, num_lasers=240, auto_reset=1, seed=11, resample_scenario=1)
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
     ids = np.arange(n_envs) % 100
@@ -110,7 +111,7 @@ def test_c2_1024_envs_parity():
     descs = bank.get_descriptions(range(1000, 1100))
     n_envs = 1024
     mb, sb = util.make_banks(descs, n_maps=100, num_traffic=0)
-    cfg = _abi.make_config(n_envs, num_agents=1, num_traffic=0, num_lasers=0, auto_reset=1, seed=3)
+    cfg = _abi.make_config(n_envs, num_agents=1, num_traffic=0, num_lasers=0, auto_reset=1, seed=3, resample_scenario=1)
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
     assert eng.D == 18

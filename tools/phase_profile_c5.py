@@ -23,7 +23,7 @@ eng.reset(np.arange(N) % len(sb.scenarios))
 rng = np.random.default_rng(0)
 acts = torch.from_numpy(rng.uniform(-1, 1, size=(64, N, A, 2)).astype(np.float32)).cuda()
 names = ['load', 'trig+snap', 'policy', 'dynamics', 'crash', 'linetest', 'tail_end', 'reset', 'store', 'i_route', 'i_search', 'i_lc', 'i_pid', 'ld_stage', 'obs',
-         'WALL', 'as_route', 'as_getlane', 'as_local', 'as_side', 'o_pub', 'o_compact', 'o_state', 'o_neigh', 'o_lidar', 'as_rest', 'm_reward', 'm_respawn']
+         'WALL', 'as_route', 'as_getlane', 'as_local', 'as_side', 'o_pub', 'o_compact', 'o_state', 'o_neigh', 'o_lidar', 'as_rest', 'm_reward', 'm_respawn', 'ko_load', 'KO_WALL']
 out = (C.c_ulonglong * 64)()
 with torch.cuda.stream(eng.stream):
     for k in range(1500): eng.step(acts[k % 64])
@@ -33,5 +33,6 @@ with torch.cuda.stream(eng.stream):
         L.pgd_debug_phase_cycles(eng.h, out, 1)
         nb = 300 * min(N, 8192)
         tot = sum(out[:15]) + sum(out[16:28])
+        print('k_observe cycles/block (first 8192 rows):', {n: int(out[i] / (300 * 8192)) for i, n in enumerate(names) if i in (22, 23, 24, 28)}, 'wall us', round(out[29] / (300 * 8192) / 100, 2))
         print('cycles/block:', {n: int(out[i] / nb) for i, n in enumerate(names) if out[i]}, 'total', int(tot / nb), '=> us', round(out[15] / nb / 100, 2))
         print('   MAX over blocks:', {n: int(out[32 + i] / 300) for i, n in enumerate(names) if out[i]})
