@@ -117,25 +117,26 @@ DEV void state_block(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, co
     row[o_ego + 6 + KM] = clipf(sp.length / 10.0f, 0.0f, 1.0f);
     row[o_ego + 6 + KM + 1] = clipf(sp.width / 2.5f, 0.0f, 1.0f);
   }
-  if (tid < 18) {
+  // one lane per float; fewer than 18 cooperating threads (k_observe_env: a few lanes per agent) take several floats each
+  for (int q = tid; q < 18; q += nt) {
     // every lane fetches the one lane record its float needs BEFORE the branch ladder, so the reads overlap instead of
     // queueing behind each other branch by branch: heading_diff -> last lane of the current road; navi -> first lanes
-    const int lid = tid < 8 ? ag.cur_first + ag.cur_n - 1 : (tid < 13 ? ag.cur_first : ag.next_first);
+    const int lid = q < 8 ? ag.cur_first + ag.cur_n - 1 : (q < 13 ? ag.cur_first : ag.next_first);
     pgd_lane ml;  // only the heading_diff lane needs the 64-byte lane record
     LaneNav nv;
-    if (tid == 2) ml = mv.lanes[lid];
-    if (tid >= 8) nv = mv.lnav[lid];
+    if (q == 2) ml = mv.lanes[lid];
+    if (q >= 8) nv = mv.lnav[lid];
     const float max_speed = sp.max_speed;
     float v = 0.0f;
     int col = -1;
-    if (tid == 0) { v = clipf(ag.dl / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 0; }  // (MAX_LANE_NUM+1)*MAX_LANE_WIDTH
-    else if (tid == 1) { v = clipf(ag.dr / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 1; }
-    else if (tid == 2) { v = heading_diff(ml, px, py, hx, hy); col = o_ego; }
-    else if (tid == 3) { v = clipf((speed_kmh(ag.v) + 1.0f) / (max_speed + 1.0f), 0.0f, 1.0f); col = o_ego + 1; }
-    else if (tid == 4) { v = clipf((ag.steer / 60.0f + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 2; }
-    else if (tid == 5) { v = clipf((ag.a0s + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 3; }
-    else if (tid == 6) { v = clipf((ag.a0t + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 4; }
-    else if (tid == 7) {
+    if (q == 0) { v = clipf(ag.dl / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 0; }  // (MAX_LANE_NUM+1)*MAX_LANE_WIDTH
+    else if (q == 1) { v = clipf(ag.dr / 18.0f, 0.0f, 1.0f); col = KS > 0 ? -1 : 1; }
+    else if (q == 2) { v = heading_diff(ml, px, py, hx, hy); col = o_ego; }
+    else if (q == 3) { v = clipf((speed_kmh(ag.v) + 1.0f) / (max_speed + 1.0f), 0.0f, 1.0f); col = o_ego + 1; }
+    else if (q == 4) { v = clipf((ag.steer / 60.0f + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 2; }
+    else if (q == 5) { v = clipf((ag.a0s + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 3; }
+    else if (q == 6) { v = clipf((ag.a0t + 1.0f) * 0.5f, 0.0f, 1.0f); col = o_ego + 4; }
+    else if (q == 7) {
       // acos(clip(cos_beta, 0, 1)) (state_obs.py:87-92) evaluated as atan2(|cross|, dot): identical for unit vectors,
       // but well-conditioned in fp32 near beta = 0 where 1 - cos(beta) underflows the mantissa
       float dot = hx * ag.lhx + hy * ag.lhy, cross = hx * ag.lhy - hy * ag.lhx;
@@ -143,11 +144,11 @@ DEV void state_block(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, co
       v = clipf(beta / 0.1f, 0.0f, 1.0f);
       col = o_ego + 5;
     } else {  // lanes 8..12 -> checkpoint 1, 13..17 -> checkpoint 2
-      int which = (tid - 8) / 5, comp = (tid - 8) - which * 5;
+      int which = (q - 8) / 5, comp = (q - 8) - which * 5;
       float out[5];
       navi_info_for(nv, mv.m->lane_width, ag.cur_n, px, py, hx, hy, out);
       v = comp == 0 ? out[0] : comp == 1 ? out[1] : comp == 2 ? out[2] : comp == 3 ? out[3] : out[4];
-      col = toll ? -1 : o_navi + (tid - 8);
+      col = toll ? -1 : o_navi + (q - 8);
     }
     if (col >= 0) row[col] = v;
   }
@@ -186,6 +187,22 @@ DEV AgentView view_of_slot(const PgdDev& d, const MapView& mv, const VehRec* rec
 // STD: the reference's default row layout (no detector fans, no random_agent_model, no toll floats, no lidar noise) as a
 // compile-time fact: every column offset is a constant and the optional blocks vanish from the benchmark kernel.
 // OTH: PGD_MA_OTHERS_STATE (stand-alone k_observe only: `recs` / `spb` = the env's records and spawn table)
+// gaussian noise / dropout of one lidar value (state_obs.py:172-182), from the counter RNG keyed by (env, agent slot, beam, step)
+DEV float lidar_noise(const PgdDev& d, int env, int slot, uint32_t tick, int i, float best) {
+  if (!(d.cfg.lidar_gaussian_noise > 0.0f || d.cfg.lidar_dropout_prob > 0.0f)) return best;
+  const uint32_t key = 0x51d0a000u + (uint32_t)slot * 1024u + (uint32_t)i;
+  if (d.cfg.lidar_gaussian_noise > 0.0f) {
+    const float u1 = ((float)(pgd_rng(d.cfg.seed, (uint32_t)(d.cfg.env_base + env), key, tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(pgd_rng(d.cfg.seed ^ 0x9e3779b9u, (uint32_t)(d.cfg.env_base + env), key, tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    best = clipf(best + d.cfg.lidar_gaussian_noise * sqrtf(-2.0f * logf(u1)) * cosf(2.0f * PGD_PI * u2), 0.0f, 1.0f);
+  }
+  if (d.cfg.lidar_dropout_prob > 0.0f) {
+    const float u3 = ((float)(pgd_rng(d.cfg.seed ^ 0x7f4a7c15u, (uint32_t)(d.cfg.env_base + env), key, tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    if (u3 < d.cfg.lidar_dropout_prob) best = 0.0f;
+  }
+  return best;
+}
+
 // the threads that produce one row meet: a block-wide barrier, or -- when the row belongs to ONE wave of a block that holds
 // several rows -- nothing but the ordering of that wave's own LDS traffic (the waves of the block stay independent)
 template <bool WAVE_ROW>
@@ -281,18 +298,7 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
       if (off < L.bcnt[k])
         best = fminf(best, shape_ray<OBJ>(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
     }
-    if (!STD && (d.cfg.lidar_gaussian_noise > 0.0f || d.cfg.lidar_dropout_prob > 0.0f)) {  // state_obs.py:172-182
-      const uint32_t key = 0x51d0a000u + (uint32_t)ag.slot * 1024u + (uint32_t)i;
-      if (d.cfg.lidar_gaussian_noise > 0.0f) {
-        const float u1 = ((float)(pgd_rng(d.cfg.seed, (uint32_t)(d.cfg.env_base + ag.env), key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        const float u2 = ((float)(pgd_rng(d.cfg.seed ^ 0x9e3779b9u, (uint32_t)(d.cfg.env_base + ag.env), key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        best = clipf(best + d.cfg.lidar_gaussian_noise * sqrtf(-2.0f * logf(u1)) * cosf(2.0f * PGD_PI * u2), 0.0f, 1.0f);
-      }
-      if (d.cfg.lidar_dropout_prob > 0.0f) {
-        const float u3 = ((float)(pgd_rng(d.cfg.seed ^ 0x7f4a7c15u, (uint32_t)(d.cfg.env_base + ag.env), key, ag.tick) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        if (u3 < d.cfg.lidar_dropout_prob) best = 0.0f;
-      }
-    }
+    if (!STD) best = lidar_noise(d, ag.env, ag.slot, ag.tick, i, best);
     row[o_oth + per_other * NO + i] = best;
   }
   PHASE_MARK(24);  // obs: lidar

@@ -831,3 +831,62 @@ def test_contacts_inside_the_sub_steps(descs):
     print("sub-step contacts:", stats, "crash_vehicle", n_crash, "of which clear again at the end of the step", n_mid_only)
     assert stats["flag_mismatch"] == 0 and stats["obs"] < OBS_TOL
     assert n_crash > 300 and n_mid_only >= 5
+
+
+@pytest.mark.parametrize("kind,num_agents,capacity,kw", [
+    ("roundabout", 8, 8, dict(num_others=4)),
+    ("roundabout", 12, 16, dict(num_others=4, num_lasers=240, lidar_dist=50.0)),
+    ("roundabout", 40, 40, dict(num_others=2, lidar_gaussian_noise=0.05, lidar_dropout_prob=0.1)),
+    ("tollgate", 12, 12, dict(TOLL, num_others=4)),
+    ("bottleneck", 20, 20, dict(plain_reward=True, side_lasers=4, side_dist=50.0, lane_line_lasers=4, lane_line_dist=20.0)),
+])
+def test_env_observation_kernel_equals_row_kernel(kind, num_agents, capacity, kw):
+    """The multi-agent observation comes from k_observe_env (one wave per env: all agents' state blocks at once, lidar
+    as flattened body-beam incidences with an LDS min).  PGD_ROW_OBSERVE keeps the one-block-per-row kernel that the
+    oracle parity tests were first run with: free-running engines, same actions.  Reward, done and flags come from the same
+    k_step and must be bit-identical; the two observation kernels contract their multiply-adds differently, so the rows agree
+    to an fp32 ulp or two (1e-6), up to a beam that grazes a box corner."""
+    import os
+    import torch
+    from pgdrive_amd.engine import Engine
+    d, mb, sb = util.make_marl_banks(num_agents=num_agents, capacity=capacity, kind=kind)
+    n_envs = 48
+    cfg = util.marl_config(n_envs, sb, horizon=150, resample_scenario=1, seed=9, **kw)
+    eng_a = Engine(cfg, mb, sb)
+    os.environ["PGD_ROW_OBSERVE"] = "1"
+    try:
+        eng_b = Engine(cfg, mb, sb)
+    finally:
+        del os.environ["PGD_ROW_OBSERVE"]
+    ids = np.arange(n_envs) % len(sb.scenarios)
+    nl = cfg.num_lasers
+    tail = 2 if kw.get("tollgate") else 0  # the toll floats follow the lidar
+    st = dict(beams=0, grazing=0, worst=0.0)
+
+    def close(xa, xb):
+        dd = np.abs(xa.cpu().numpy().astype(np.float64) - xb.cpu().numpy())
+        D = dd.shape[-1]
+        beams = dd[..., D - tail - nl:D - tail]
+        st["beams"] += beams.size
+        st["grazing"] += int((beams > 1e-6).sum())
+        beams[beams > 1e-6] = 0.0
+        st["worst"] = max(st["worst"], float(dd.max()))
+
+    close(eng_a.reset(ids), eng_b.reset(ids))
+    rng = np.random.default_rng(4)
+    n_rows = n_new = 0
+    for t in range(260):
+        act = torch.from_numpy(util.marl_actions(rng, n_envs, sb.A))
+        ga = [x.clone() for x in eng_a.step(act.to(eng_a.device))]
+        gb = [x.clone() for x in eng_b.step(act.to(eng_b.device))]
+        eng_a.sync(); eng_b.sync()
+        close(ga[0], gb[0])
+        for xa, xb, name in zip(ga[1:], gb[1:], ("reward", "done", "flags")):
+            assert torch.equal(xa.cpu(), xb.cpu()), "%s differs at step %d" % (name, t)
+        fl = ga[3].cpu().numpy()
+        n_rows += int(((fl & _abi.F_REPORT) != 0).sum())
+        n_new += int(((fl & _abi.F_NEW) != 0).sum())
+    print("env vs row observation kernel:", st, "rows", n_rows, "new agents", n_new)
+    assert st["worst"] < 1e-6 and st["grazing"] <= 1e-5 * st["beams"] + 2
+    assert n_rows > 5000 and n_new > 20
+    eng_a.close(); eng_b.close()
