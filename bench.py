@@ -122,6 +122,8 @@ def parse_args(argv=None):
                     help="run exactly --warmup / --steps (no steady-state floors): for plumbing tests and quick A/B runs")
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--traffic", type=int, default=16)
+    ap.add_argument("--maps", type=int, default=100,
+                    help="c3: number of PGDrive-v0 maps (seeds 1000 ...) the envs are spread over; the metric's workload is 100")
     ap.add_argument("--lasers", type=int, default=None,
                     help="lidar beams: default 240 for c3; for c5 72 x 40 m (the reference's multi-agent default) unless given "
                          "(BASELINE.md C5 is --lasers 240)")
@@ -196,7 +198,7 @@ def run_rank(args, rank, world, local_rank):
         n_scen = len(sb.scenarios)
     else:
         A = 1
-        descs = bank.get_descriptions(range(1000, 1100))  # generated on the host by our own BIG (pgdrive_amd/mapgen.py)
+        descs = bank.get_descriptions(range(1000, 1000 + args.maps))  # generated on the host by our own BIG (pgdrive_amd/mapgen.py)
         mb = mapdata.MapBank(descs)
         sb = scenario.ScenarioBank(descs, [d["seed"] for d in descs], num_agents=1, num_traffic=args.traffic)
         cfg = _abi.make_config(N, num_agents=A, num_traffic=args.traffic, num_lasers=args.lasers, auto_reset=1,

@@ -813,31 +813,35 @@ __global__ __launch_bounds__(BLOCK == WAVE ? WAVE * OBS_RPB : BLOCK) void k_obse
 //                  pairs' window sizes and dealt out to the lanes 64 at a time: a body is tested against the few beams that
 //                  can reach it and nothing else; the nearest hit per beam is an unsigned min in LDS (fractions are >= 0).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags) {
-  extern __shared__ unsigned s_minb[];  // [G * NL] nearest hit fraction per (observer of the pass, beam), float bits
+// NW waves per env: the state blocks get NW * WAVE / A lanes per agent and the passes of the pair phase are dealt out to the waves
+// (wave w takes passes w, w + NW, ...; each wave has its own scratch and synchronises with itself only).  NW = 4 when there
+// are at least four passes (A >= 4 * (WAVE / V)), else 1.
+template <int NW>
+__global__ __launch_bounds__(WAVE * NW) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags) {
+  extern __shared__ unsigned s_minb_all[];  // [NW][G * NL] nearest hit fraction per (observer of the pass, beam), float bits
   __shared__ float bX[WAVE], bY[WAVE], bUX[WAVE], bUY[WAVE], bHL[WAVE], bHW[WAVE], bV[WAVE], bAID[WAVE];
   __shared__ int bST[WAVE];       // status | kind << 8
   __shared__ uint32_t bFL[WAVE];  // step flags of agent slot o (0 beyond A or without flags)
   __shared__ float aMS[WAVE];     // observer: max_speed of its vehicle
   __shared__ int aWant[WAVE];
-  __shared__ float pDist[WAVE];
-  __shared__ int pPref[WAVE + 1], pI0[WAVE];
+  __shared__ float pDist_all[NW][WAVE];
+  __shared__ int pPref_all[NW][WAVE + 1], pI0_all[NW][WAVE];
   const int V = d.V, A = d.A, D = d.D, NL = d.cfg.num_lasers, NO = d.cfg.num_others;
   const int e = (int)blockIdx.x + d.unit_off * d.epw;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, wv = tid / WAVE, lane = tid % WAVE;
   const VehRec* recs = d.rec + (size_t)e * V;
   // ---- loads whose addresses follow from the block index: body `lane` (first half of its record), the agent of this lane's
   // state group (whole record), step flags, scenario, step count, the env's map header
-  const int LPA = WAVE / A;  // lanes per agent in the state phase (A <= WAVE)
-  const int sa = lane / LPA, st = lane - sa * LPA;
+  const int LPA = WAVE * NW / A;  // lanes per agent in the state phase (A <= WAVE)
+  const int sa = tid / LPA, st = tid - sa * LPA;
   const bool s_on = sa < A;
   Veh me;
   load_rec(recs + (s_on ? sa : 0), me);
   Veh body;  // only the first 64 bytes are filled
 #pragma unroll
-  for (int k = 0; k < 4; ++k) reinterpret_cast<uint4*>(&body)[k] = reinterpret_cast<const uint4*>(recs + (lane < V ? lane : 0))[k];
+  for (int k = 0; k < 4; ++k) reinterpret_cast<uint4*>(&body)[k] = reinterpret_cast<const uint4*>(recs + (tid < V ? tid : 0))[k];
   const uint32_t f_me = (flags && s_on) ? flags[(size_t)e * A + sa] : 0u;
-  const uint32_t f_body = (flags && lane < A) ? flags[(size_t)e * A + lane] : 0u;
+  const uint32_t f_body = (flags && tid < A) ? flags[(size_t)e * A + tid] : 0u;
   const int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
   const uint32_t tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
   const MapView mv = map_view_of(d, d.env_map + e);
@@ -851,12 +855,12 @@ __global__ __launch_bounds__(WAVE) void k_observe_env(PgdDev d, float* __restric
   if (flags) want = (f_me & PGD_F_RESET) ? want : (f_me & (PGD_F_REPORT | PGD_F_NEW)) != 0;
   want = want && s_on;
   // ---- publish the bodies and the observers
-  if (lane < V) {
-    bX[lane] = body.x; bY[lane] = body.y; bUX[lane] = body.hx; bUY[lane] = body.hy;
-    bHL[lane] = 0.5f * so_len; bHW[lane] = so_kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * so_wid;
-    bV[lane] = body.v; bAID[lane] = body.agent_id;
-    bST[lane] = (int)body.status | (so_kind << 8);
-    bFL[lane] = f_body;
+  if (tid < V) {
+    bX[tid] = body.x; bY[tid] = body.y; bUX[tid] = body.hx; bUY[tid] = body.hy;
+    bHL[tid] = 0.5f * so_len; bHW[tid] = so_kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * so_wid;
+    bV[tid] = body.v; bAID[tid] = body.agent_id;
+    bST[tid] = (int)body.status | (so_kind << 8);
+    bFL[tid] = f_body;
   }
   if (s_on && st == 0) { aMS[sa] = msp.max_speed; aWant[sa] = want ? 1 : 0; }
   // ---- state blocks: every agent at once, LPA lanes each
@@ -889,7 +893,11 @@ __global__ __launch_bounds__(WAVE) void k_observe_env(PgdDev d, float* __restric
   const float R = d.cfg.lidar_dist;
   const int G = WAVE / V;
   const int pa = lane / V, o = lane - pa * V;
-  for (int g0 = 0; g0 < A; g0 += G) {
+  unsigned* s_minb = s_minb_all + (size_t)wv * G * NL;
+  float* pDist = pDist_all[wv];
+  int* pPref = pPref_all[wv];
+  int* pI0 = pI0_all[wv];
+  for (int g0 = wv * G; g0 < A; g0 += G * NW) {
     const int a = g0 + pa;
     const bool pv = pa < G && a < A && aWant[a < A ? a : 0] != 0;
     const int ac = pv ? a : 0;
@@ -949,7 +957,7 @@ __global__ __launch_bounds__(WAVE) void k_observe_env(PgdDev d, float* __restric
     pPref[lane + 1] = inc;
     if (lane == 0) pPref[0] = 0;
     for (int k = lane; k < G * NL; k += WAVE) s_minb[k] = __float_as_uint(1.0f);
-    __syncthreads();
+    row_sync<true>();  // the pass belongs to this wave alone
     const int T = pPref[WAVE];
     if (pv) {
       int rank = 0, nveh = 0;
@@ -990,13 +998,13 @@ __global__ __launch_bounds__(WAVE) void k_observe_env(PgdDev d, float* __restric
       const float f = shape_ray<true>(Obb{bX[qo], bY[qo], bUX[qo], bUY[qo], bHL[qo], bHW[qo]}, ax, ay, dx, dy);
       atomicMin(&s_minb[qa * NL + i], __float_as_uint(f));
     }
-    __syncthreads();
+    row_sync<true>();  // the pass belongs to this wave alone
     for (int k = lane; k < G * NL; k += WAVE) {
       const int qa = k / NL, i = k - qa * NL, ga = g0 + qa;
       if (ga < A && aWant[ga])
         obs[(size_t)e * d.ostride + (size_t)ga * D + o_oth + 4 * NO + i] = lidar_noise(d, e, ga, tick, i, __uint_as_float(s_minb[k]));
     }
-    __syncthreads();
+    row_sync<true>();  // the pass belongs to this wave alone
   }
 }
 
@@ -1325,8 +1333,10 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
   const bool oth = (h->d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && h->d.cfg.num_others > 0;
   const int envs = n_envs > 0 ? n_envs : h->d.N;
   const size_t minb = sizeof(unsigned) * (size_t)(WAVE / h->d.V) * (size_t)(h->d.cfg.num_lasers > 0 ? h->d.cfg.num_lasers : 0);
-  if (h->d.A > 1 && !oth && h->d.epw == 1 && minb <= 32768 && !h->row_observe) {  // all rows of an env by one wave
-    hipLaunchKernelGGL(k_observe_env, dim3(envs), dim3(WAVE), minb, stream, D, d_obs, d_flags);
+  if (h->d.A > 1 && !oth && h->d.epw == 1 && 4 * minb <= 49152 && !h->row_observe) {  // all rows of an env by one block
+    const bool four = h->d.A >= 4 * (WAVE / h->d.V);  // at least four passes of the pair phase
+    if (four) hipLaunchKernelGGL(k_observe_env<4>, dim3(envs), dim3(WAVE * 4), 4 * minb, stream, D, d_obs, d_flags);
+    else hipLaunchKernelGGL(k_observe_env<1>, dim3(envs), dim3(WAVE), minb, stream, D, d_obs, d_flags);
     HIPCHK(hipGetLastError());
     return PGD_OK;
   }
