@@ -774,9 +774,107 @@ def gen_random_lane():
     print("random lane cases:", len(cases), cases[:3])
 
 
+def gen_maround(maps):
+    """LidarStateObservationMARound.observe (marl_inout_roundabout.py:66-122), run as-is: the observer's state vector, then the
+    state vectors of the num_others nearest detected vehicles (the reference's own StateObservation on each of them; zeros
+    when absent), then the cloud.  Every vehicle of a scene is a full agent (steering, last action, last heading, route,
+    lateral distances from BaseVehicle._dist_to_route_left_right); the lidar's perceive() is the exact intersector of
+    the reference's detector test, as in the scene fixtures.  Own rng, own file (tests/golden/maround_v0.json)."""
+    from pgdrive.envs.marl_envs.marl_inout_roundabout import LidarStateObservationMARound
+    rng = np.random.default_rng(77)
+    NO = 4
+    cfg = {"lidar": dict(num_lasers=240, distance=50, num_others=NO, gaussian_noise=0.0, dropout_prob=0.0),
+           "random_agent_model": False, "side_detector": dict(num_lasers=0), "lane_line_detector": dict(num_lasers=0)}
+    cases = []
+    for m in maps:
+        fmap = FakeMap(m)
+        lanes = ref_lanes_in_order(m)
+        lane_ids = {id(l): k for k, l in enumerate(lanes)}
+        nodes = m["nodes"]
+        net = m["net"]
+        dest = my_scenario.choose_destination(m, m["seed"], nodes.index(">"))
+        for rep in range(5):
+            allv = []
+            tries = 0
+            want = int(rng.integers(2, 9))
+            while len(allv) < want and tries < 200:
+                tries += 1
+                tl = lanes[int(rng.integers(0, len(lanes)))]
+                try:
+                    tck_ids, _, _, _ = my_scenario.make_route(m, lane_ids[id(tl)], dest)
+                except Exception:
+                    continue
+                tck = [nodes[i] for i in tck_ids]
+                if len(tck) < 2:
+                    continue
+                tlon = rng.uniform(0.5, max(tl.length - 0.5, 1.0))
+                tp = tl.position(tlon, rng.uniform(-0.8, 0.8))
+                if allv and (math.hypot(tp[0] - allv[0].position[0], tp[1] - allv[0].position[1]) > 70.0):
+                    continue  # keep the scene compact: most vehicles inside each other's 50 m
+                if any(math.hypot(tp[0] - w.position[0], tp[1] - w.position[1]) < 6.5 for w in allv):
+                    continue  # no ray origin inside a box
+                L, W = [(4.25, 1.7), (4.4, 1.85), (4.51, 1.852), (5.8, 2.3)][int(rng.integers(0, 4))]
+                v = FakeVehicle(tp[0], tp[1], tl.heading_at(tlon) + rng.normal(0, 0.1), rng.uniform(0, 80), L, W)
+                v.lane, v.lane_index = tl, tl.index
+                v.steering = rng.uniform(-1, 1)
+                v.last_current_action = [(rng.uniform(-1, 1), rng.uniform(-1, 1)), (0.3, 0.2)]
+                lth = v.heading_theta - rng.normal(0, 0.02)
+                v.last_heading_dir = Vector((math.cos(lth), math.sin(lth)))
+                v.last_position = Vector((tp[0] - 0.8 * math.cos(lth), tp[1] - 0.8 * math.sin(lth)))
+                v.navigation = make_navigation(fmap, tck, [0, 1] if len(tck) > 2 else [0, 0])
+                allv.append(v)
+
+            def _ok(v):
+                return all(abs(_point_box_dist(w.position, v) - 50.0) > 0.6 and abs(_point_box_dist(v.position, w) - 50.0) > 0.6
+                           for w in allv if w is not v)
+            allv = [v for v in allv if _ok(v)]
+            if len(allv) < 2:
+                continue
+            for v in allv:
+                v.lidar.objs = set(allv)
+                v.engine = None
+                v.dist_to_left_side, v.dist_to_right_side = BaseVehicle._dist_to_route_left_right(v)
+                v.navigation._navi_info = ref_navi_info(v.navigation, v)
+            rows = []
+            for a, v in enumerate(allv):
+                boxes = [(o.position[0], o.position[1], o.heading_theta, o.LENGTH / 2, o.WIDTH / 2) for o in allv if o is not v]
+                cloud = exact_lidar(v.position[0], v.position[1], v.heading_theta, boxes)
+                detected = v.lidar.get_surrounding_objects(v)
+                dists = sorted(math.hypot(v.position[0] - o.position[0], v.position[1] - o.position[1]) for o in detected)
+                if any(b - a_ < 1e-3 for a_, b in zip(dists, dists[1:])):
+                    continue  # the reference sorts a list made from a set: equal distances would be order-dependent
+                v.lidar.perceive = (lambda c, dset: (lambda veh: (list(c), dset)))(cloud, detected)
+                ob = LidarStateObservationMARound.__new__(LidarStateObservationMARound)
+                ob.config = cfg
+                ob.state_obs = StateObservation.__new__(StateObservation)
+                ob.state_obs.config = cfg
+                ob.state_length = 18
+                row = np.asarray(ob.observe(v), dtype=np.float64)
+                assert row.shape == (18 + NO * 18 + 240, )
+                rows.append(dict(slot=a, row=row.tolist(), n_detected=len(detected)))
+            cases.append(dict(
+                seed=m["seed"],
+                vehicles=[dict(x=v.position[0], y=v.position[1], theta=v.heading_theta, speed_kmh=v.speed,
+                               length=v.LENGTH, width=v.WIDTH, lane=lane_ids[id(v.lane)],
+                               ckpt=[nodes.index(n) for n in v.navigation.checkpoints],
+                               idx=list(v.navigation._target_checkpoints_index), steering=v.steering,
+                               act0=list(v.last_current_action[0]),
+                               last_heading=[v.last_heading_dir[0], v.last_heading_dir[1]],
+                               last_position=[v.last_position[0], v.last_position[1]],
+                               left=v.dist_to_left_side, right=v.dist_to_right_side) for v in allv],
+                rows=rows))
+    with open(os.path.join(ROOT, "tests", "golden", "maround_v0.json"), "w") as f:
+        json.dump(dict(num_others=NO, cases=cases), f)
+    print("wrote MARound observation goldens:", len(cases), "scenes,", sum(len(c["rows"]) for c in cases), "rows,",
+          sum(1 for c in cases for r in c["rows"] if r["n_detected"] > NO), "with more than num_others neighbours")
+
+
 def main():
     if "--random-lane-only" in sys.argv:
         gen_random_lane()
+        return
+    if "--maround-only" in sys.argv:
+        gen_maround([ref_export.generate(s, block_num=3) for s in (1000, 1003, 1017)])
         return
     rng = np.random.default_rng(20240927)
     out = {}
@@ -787,6 +885,7 @@ def main():
     gen_marl_intersection()
     gen_objects()
     gen_random_lane()
+    gen_maround(maps)
     if "--detectors-only" in sys.argv or "--side-files-only" in sys.argv:
         return
     gen_scalar(rng, out)

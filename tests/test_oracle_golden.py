@@ -180,6 +180,92 @@ def test_scene_observation(L, descs, scenes):
     assert worst["lidar"] < 1e-6 and flips <= 3
 
 
+def agents_scene_banks(descs, sc, **cfg_kw):
+    """Banks + config + state of a scene whose vehicles are ALL agents of one multi-agent env (tests/golden/maround_v0.json);
+    shared with the GPU variant of the test."""
+    d = [m for m in descs if m["seed"] == sc["seed"]][0]
+    mb = mapdata.MapBank([d])
+    V = len(sc["vehicles"])
+    spawns = np.zeros(V, dtype=scenario.SPAWN_DT)
+    rl = mapdata.road_lookup(d)
+    for k, v in enumerate(sc["vehicles"]):
+        r = spawns[k]
+        r["x"], r["y"], r["heading"] = v["x"], v["y"], v["theta"]
+        r["length"], r["width"] = v["length"], v["width"]
+        r["wheelbase"], r["mass"], r["max_engine_force"], r["max_brake_force"] = 2.46894, 1100, 800, 130
+        r["friction"], r["max_steer"], r["max_speed"] = 0.9, np.deg2rad(40), 80
+        r["lane"], r["group"], r["n_ckpt"] = v["lane"], -1, len(v["ckpt"])
+        r["ckpt"][:] = -1
+        r["ckpt_road"][:] = -1
+        r["ckpt"][:len(v["ckpt"])] = v["ckpt"]
+        roads = [rl[(v["ckpt"][j], v["ckpt"][j + 1])] for j in range(len(v["ckpt"]) - 1)]
+        r["ckpt_road"][:len(roads)] = roads
+        fr = d["roads"][roads[-1]]
+        r["dest_lane"] = fr["first_lane"] + fr["n_lanes"] - 1
+    sb = scenario.ScenarioBank.__new__(scenario.ScenarioBank)
+    scen = np.zeros(1, dtype=scenario.SCEN_DT)
+    scen["trigger_road"][:] = -1
+    sb.scenarios, sb.spawns, sb.V, sb.info = scen, spawns, V, []
+    cfg = _abi.make_config(1, num_agents=V, num_traffic=0, multi_agent=True, agent_limit=V, respawn_places=0, respawn_dests=0,
+                           allow_respawn=False, auto_reset=0, **cfg_kw)
+    return mb, sb, cfg
+
+
+def agents_scene_state(sc, f, i):
+    SF, SI = _abi.SF, _abi.SI
+    for k, v in enumerate(sc["vehicles"]):
+        f[SF["X"], 0, k], f[SF["Y"], 0, k], f[SF["THETA"], 0, k] = v["x"], v["y"], v["theta"]
+        f[SF["HX"], 0, k], f[SF["HY"], 0, k] = np.cos(v["theta"]), np.sin(v["theta"])
+        f[SF["SPEED"], 0, k] = v["speed_kmh"] / 3.6
+        i[SI["STATUS"], 0, k] = _abi.ST_ACTIVE
+        i[SI["LANE"], 0, k] = v["lane"]
+        i[SI["CK0"], 0, k], i[SI["CK1"], 0, k] = v["idx"]
+        f[SF["STEER"], 0, k] = v["steering"]
+        f[SF["ACT0S"], 0, k], f[SF["ACT0T"], 0, k] = v["act0"]
+        f[SF["LASTHX"], 0, k], f[SF["LASTHY"], 0, k] = v["last_heading"]
+        f[SF["LASTX"], 0, k], f[SF["LASTY"], 0, k] = v["last_position"]
+        f[SF["DIST_LEFT"], 0, k], f[SF["DIST_RIGHT"], 0, k] = v["left"], v["right"]
+
+
+def compare_maround_rows(sc, obs, worst, beam_tol=1e-6):
+    """rows [state 18 | 4 x neighbour state 18 | 240 beams] of the reference's LidarStateObservationMARound; returns corner beams"""
+    flips = 0
+    for r in sc["rows"]:
+        ref = np.array(r["row"])
+        got = obs[r["slot"]].astype(np.float64)
+        assert got.shape == ref.shape
+        worst["state"] = max(worst["state"], float(np.abs(got[:18] - ref[:18]).max()))
+        worst["others"] = max(worst["others"], float(np.abs(got[18:90] - ref[18:90]).max()))
+        dl = np.abs(got[90:] - ref[90:])
+        flips += int((dl > beam_tol).sum())
+        worst["lidar"] = max(worst["lidar"], float(dl[dl <= beam_tol].max()))
+        worst["rows"] += 1
+        worst["absent"] += int(sum(1 for q in range(4) if not ref[18 + 18 * q:36 + 18 * q].any()))
+    return flips
+
+
+def test_maround_neighbour_state_rows(L, descs):
+    """LidarStateObservationMARound.observe run as-is by oracle/gen_golden.py::gen_maround (marl_inout_roundabout.py:66-122):
+    the num_others nearest detected vehicles contribute their OWN state vectors in distance order, absent ranks are zeros."""
+    from oracle import orc
+    with open(os.path.join(GOLD, "maround_v0.json")) as fh:
+        gold = json.load(fh)
+    worst = dict(state=0.0, others=0.0, lidar=0.0, rows=0, absent=0)
+    flips = 0
+    for sc in gold["cases"]:
+        mb, sb, cfg = agents_scene_banks(descs, sc, num_lasers=240, lidar_dist=50.0, num_others=gold["num_others"], others_state=True)
+        o = orc.Oracle(cfg, mb, sb)
+        o.reset(np.zeros(1, dtype=np.int32))
+        f, i, ei = o.get_state()
+        agents_scene_state(sc, f, i)
+        o.set_state(f, i, ei)
+        flips += compare_maround_rows(sc, o.observe()[0], worst)
+        o.close()
+    print("MARound rows:", worst, "corner beams", flips)
+    assert worst["rows"] >= 50 and worst["absent"] > 20
+    assert worst["state"] < 2e-6 and worst["others"] < 2e-6 and worst["lidar"] < 1e-6 and flips <= 3
+
+
 def test_side_and_lane_line_detectors(L, descs):
     """SideDetector / LaneLineDetector fans spliced into vehicle_state by the reference's own StateObservation
     (state_obs.py:64-71,96-105; distance_detector.py:137-152), cast against the reference-recorded line boxes."""

@@ -890,3 +890,31 @@ def test_env_observation_kernel_equals_row_kernel(kind, num_agents, capacity, kw
     assert st["worst"] < 1e-6 and st["grazing"] <= 1e-5 * st["beams"] + 2
     assert n_rows > 5000 and n_new > 20
     eng_a.close(); eng_b.close()
+
+
+def test_maround_rows_against_the_reference_fixture(descs):
+    """tests/golden/maround_v0.json holds rows of the reference's LidarStateObservationMARound.observe (own state, the state
+    vectors of the four nearest detected vehicles, 240 beams) computed by the reference's Python on scenes where every vehicle
+    is an agent: the engine's PGD_MA_OTHERS_STATE observation (k_observe<.., OTH>) must reproduce them from the same state."""
+    import json
+    import os
+    from pgdrive_amd.engine import Engine
+    from tests.test_oracle_golden import GOLD, agents_scene_banks, agents_scene_state, compare_maround_rows
+    with open(os.path.join(GOLD, "maround_v0.json")) as fh:
+        gold = json.load(fh)
+    worst = dict(state=0.0, others=0.0, lidar=0.0, rows=0, absent=0)
+    flips = 0
+    for sc in gold["cases"]:
+        mb, sb, cfg = agents_scene_banks(descs, sc, num_lasers=240, lidar_dist=50.0, num_others=gold["num_others"], others_state=True)
+        eng = Engine(cfg, mb, sb)
+        eng.reset(np.zeros(1, dtype=np.int32))
+        f, i, ei = eng.get_state()
+        agents_scene_state(sc, f, i)
+        eng.set_state(f, i, ei)
+        obs = eng.observe()
+        eng.sync()
+        # corner beams: the reference helper pads box edges by 1e-5, fp32 adds its own grazing cases (bounded below)
+        flips += compare_maround_rows(sc, obs.cpu().numpy()[0], worst, beam_tol=OBS_TOL)
+        eng.close()
+    print("MARound rows on the GPU:", worst, "corner beams", flips)
+    assert worst["rows"] >= 50 and worst["state"] < OBS_TOL and worst["others"] < OBS_TOL and worst["lidar"] <= OBS_TOL and flips <= 4
