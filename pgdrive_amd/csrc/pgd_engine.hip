@@ -108,12 +108,28 @@ DEV LaneMap lane_map(const PgdDev& d, int unit, int n_units) {
 // MARL (multi-agent tail: delay-done, respawn, __all__) is compiled in only for the multi-agent engine.
 // OBJ: traffic objects present in some scenario (circle shapes, crash_object bookkeeping).
 // STD: the fused observation has the default row layout (see observe_agent).
+// LDS of the step proper; the multi-agent engine's fused observation (observe_env_body at the end of k_step) reuses it
+struct StepLds {
+  Snap S;
+  ObsScratch OU;
+};
+constexpr int STEP_MINB_WORDS = ((int)sizeof(StepLds) - (int)sizeof(ObsEnvLds<1>)) / 4;  // what is left for the per-beam minima
+static_assert(STEP_MINB_WORDS >= 8 * 72, "the fused multi-agent observation of 8 agents x 72 beams must fit the step's LDS");
+union StepUnion {
+  StepLds step;
+  struct {
+    ObsEnvLds<1> m;
+    unsigned minb[STEP_MINB_WORDS];
+  } obs;
+};
+
 template <bool ONE_ENV, bool MARL, bool OBJ, bool STD = false>
 __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
                                                 float* __restrict__ obs) {
-  __shared__ Snap S;
-  __shared__ ObsScratch OU;  // sub-step poses (contact test), then the observation's compaction scratch
+  __shared__ StepUnion U;
+  Snap& S = U.step.S;
+  ObsScratch& OU = U.step.OU;  // sub-step poses (contact test), then the observation's compaction scratch
   ObsLds& OL = OU.ol;
   SubPose& SUBP = OU.sp;
   __shared__ AgentView s_ag[FUSE_MAX_AGENTS];
@@ -594,6 +610,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     near_next = d.cfg.num_lasers > 0 ? (__ballot(near_any) != 0ull) : true;
   }
   if (ONE_ENV && lane == 0 && (int)near_next != (int)near_env) d.ei[(size_t)e * PGD_NEI + EI_NEAR] = near_next ? 1 : 0;
+  // multi-agent engine: the rows of all agents, from the records and flags this wave has just written (the barrier makes
+  // them visible to the whole workgroup); the step's LDS is free by now
+  if (ONE_ENV && MARL && obs != nullptr) {
+    __syncthreads();
+    observe_env_body<1>(d, e, obs, flags, U.obs.m, U.obs.minb);
+  }
   PHASE_MARK(14);  // fused observation
   XMARK(14);
   PHASE_END();
@@ -816,196 +838,12 @@ __global__ __launch_bounds__(BLOCK == WAVE ? WAVE * OBS_RPB : BLOCK) void k_obse
 // NW waves per env: the state blocks get NW * WAVE / A lanes per agent and the passes of the pair phase are dealt out to the waves
 // (wave w takes passes w, w + NW, ...; each wave has its own scratch and synchronises with itself only).  NW = 4 when there
 // are at least four passes (A >= 4 * (WAVE / V)), else 1.
+// NW = 4 when the pair phase has at least four passes (A >= 4 * (WAVE / V)), else 1.
 template <int NW>
 __global__ __launch_bounds__(WAVE * NW) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags) {
-  extern __shared__ unsigned s_minb_all[];  // [NW][G * NL] nearest hit fraction per (observer of the pass, beam), float bits
-  __shared__ float bX[WAVE], bY[WAVE], bUX[WAVE], bUY[WAVE], bHL[WAVE], bHW[WAVE], bV[WAVE], bAID[WAVE];
-  __shared__ int bST[WAVE];       // status | kind << 8
-  __shared__ uint32_t bFL[WAVE];  // step flags of agent slot o (0 beyond A or without flags)
-  __shared__ float aMS[WAVE];     // observer: max_speed of its vehicle
-  __shared__ int aWant[WAVE];
-  __shared__ float pDist_all[NW][WAVE];
-  __shared__ int pPref_all[NW][WAVE + 1], pI0_all[NW][WAVE];
-  const int V = d.V, A = d.A, D = d.D, NL = d.cfg.num_lasers, NO = d.cfg.num_others;
-  const int e = (int)blockIdx.x + d.unit_off * d.epw;
-  const int tid = threadIdx.x, wv = tid / WAVE, lane = tid % WAVE;
-  const VehRec* recs = d.rec + (size_t)e * V;
-  // ---- loads whose addresses follow from the block index: body `lane` (first half of its record), the agent of this lane's
-  // state group (whole record), step flags, scenario, step count, the env's map header
-  const int LPA = WAVE * NW / A;  // lanes per agent in the state phase (A <= WAVE)
-  const int sa = tid / LPA, st = tid - sa * LPA;
-  const bool s_on = sa < A;
-  Veh me;
-  load_rec(recs + (s_on ? sa : 0), me);
-  Veh body;  // only the first 64 bytes are filled
-#pragma unroll
-  for (int k = 0; k < 4; ++k) reinterpret_cast<uint4*>(&body)[k] = reinterpret_cast<const uint4*>(recs + (tid < V ? tid : 0))[k];
-  const uint32_t f_me = (flags && s_on) ? flags[(size_t)e * A + sa] : 0u;
-  const uint32_t f_body = (flags && tid < A) ? flags[(size_t)e * A + tid] : 0u;
-  const int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
-  const uint32_t tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
-  const MapView mv = map_view_of(d, d.env_map + e);
-  const pgd_spawn* spb = d.spawns + (size_t)scen * d.sstride;
-  const pgd_spawn& msp = spb[me.spawn];
-  const pgd_spawn& so = spb[body.spawn];
-  const float so_len = so.length, so_wid = so.width;
-  const int so_kind = so.kind;
-  // which slots get a row: after a multi-agent step the ones that reported or were (re)spawned, else the active ones
-  bool want = me.status == ST_ACTIVE;
-  if (flags) want = (f_me & PGD_F_RESET) ? want : (f_me & (PGD_F_REPORT | PGD_F_NEW)) != 0;
-  want = want && s_on;
-  // ---- publish the bodies and the observers
-  if (tid < V) {
-    bX[tid] = body.x; bY[tid] = body.y; bUX[tid] = body.hx; bUY[tid] = body.hy;
-    bHL[tid] = 0.5f * so_len; bHW[tid] = so_kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * so_wid;
-    bV[tid] = body.v; bAID[tid] = body.agent_id;
-    bST[tid] = (int)body.status | (so_kind << 8);
-    bFL[tid] = f_body;
-  }
-  if (s_on && st == 0) { aMS[sa] = msp.max_speed; aWant[sa] = want ? 1 : 0; }
-  // ---- state blocks: every agent at once, LPA lanes each
-  float* row = obs + (size_t)e * d.ostride + (size_t)(s_on ? sa : 0) * D;
-  if (s_on && !want)
-    for (int k = st; k < D; k += LPA) row[k] = 0.0f;
-  if (want) {
-    AgentView ag;
-    ag.x = me.x; ag.y = me.y; ag.th = me.th;
-    ag.hx = me.hx; ag.hy = me.hy;
-    ag.dl = me.dl; ag.dr = me.dr; ag.v = me.v; ag.steer = me.steer;
-    ag.a0s = me.a0s; ag.a0t = me.a0t; ag.lhx = me.lasthx; ag.lhy = me.lasthy;
-    ag.cur_first = me.cur_first; ag.cur_n = me.cur_n; ag.next_first = me.next_first;
-    ag.blk = me.blk; ag.toll_time = me.php;
-    ag.env = e; ag.slot = sa; ag.tick = tick;
-    state_block<false>(d, mv, msp, ag, row, st, LPA);
-    if ((d.cfg.marl_flags & PGD_MA_TOLLGATE) && st == 0) {  // TollGateObservation.observe (marl_tollgate.py:84-96)
-      const int KS = d.cfg.side_lasers, KM = d.cfg.lane_line_lasers, RAM = d.cfg.random_agent_model ? 2 : 0;
-      const bool in_toll = ag.blk == '$';
-      float* t2 = row + (KS > 0 ? KS : 2) + 6 + KM + RAM + 4 * NO + NL;
-      t2[0] = in_toll ? 1.0f : 0.0f;
-      t2[1] = (in_toll && ag.toll_time > (float)d.cfg.min_pass_steps) ? 1.0f : 0.0f;
-    }
-  }
-  if (NL <= 0) return;
-  __syncthreads();
-  // ---- pairs: G observers per pass, lane = (observer pa of the pass, body o)
-  const bool toll = (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;
-  const int o_oth = (d.cfg.side_lasers > 0 ? d.cfg.side_lasers : 2) + 6 + d.cfg.lane_line_lasers + (d.cfg.random_agent_model ? 2 : 0) + (toll ? 0 : 10);
-  const float R = d.cfg.lidar_dist;
-  const int G = WAVE / V;
-  const int pa = lane / V, o = lane - pa * V;
-  unsigned* s_minb = s_minb_all + (size_t)wv * G * NL;
-  float* pDist = pDist_all[wv];
-  int* pPref = pPref_all[wv];
-  int* pI0 = pI0_all[wv];
-  for (int g0 = wv * G; g0 < A; g0 += G * NW) {
-    const int a = g0 + pa;
-    const bool pv = pa < G && a < A && aWant[a < A ? a : 0] != 0;
-    const int ac = pv ? a : 0;
-    const float px = bX[ac], py = bY[ac], hx = bUX[ac], hy = bUY[ac];
-    bool in = false, is_vehicle = true;
-    float dist = 0.0f, spd = 0.0f;
-    int i0 = 0, cnt = 0;
-    if (pv) {
-      const int stt = bST[o] & 0xff, kind = bST[o] >> 8;
-      bool present = stt == ST_PENDING || stt == ST_ACTIVE || stt == ST_DYING;
-      bool still = stt == ST_DYING;  // a finished agent is a static body (zero velocity)
-      if (flags && o < A) {
-        // multi-agent step: rows of agents that drove this step show the world before the finishes / respawns
-        // (base_env.py:303-344 runs before multi_agent_pgdrive.py:128-141); an agent spawned this step sees the world at
-        // its spawn time, i.e. the earlier spawns of the step only
-        const uint32_t fa = bFL[a], fo = bFL[o];
-        if (fa & PGD_F_RESET) {
-        } else if (fa & PGD_F_NEW) {
-          present = present && (!(fo & PGD_F_NEW) || bAID[o] < bAID[a]);
-        } else {
-          present = (fo & PGD_F_REPORT) || (present && !(fo & PGD_F_NEW));
-          still = still && !(fo & PGD_F_REPORT);
-        }
-      }
-      is_vehicle = kind == PGD_OBJ_VEHICLE;
-      const float x = bX[o], y = bY[o], hl = bHL[o], hw = bHW[o];
-      in = present && o != a && shape_point_dist<true>(Obb{x, y, bUX[o], bUY[o], hl, hw}, px, py) <= R;
-      if (in) {  // the arithmetic of obs_compact
-        spd = still ? 0.0f : speed_kmh(bV[o]);
-        dist = norm2(px - x, py - y);
-        const float rad = (hw < 0.0f ? hl : norm2(hl, hw)) * 1.02f + 0.01f;
-        i0 = 0; cnt = NL;
-        if (dist > rad) {
-          const float rx = (x - px) * hx + (y - py) * hy, ry = (y - py) * hx - (x - px) * hy;
-          const float inv_unit = (float)NL * (0.5f / PGD_PI);
-          const float q = rad / dist;
-          const float ic = atan2f(ry, rx) * inv_unit, hb = (q + 0.5708f * q * q * q) * inv_unit + 1.5f;
-          const int lo = (int)floorf(ic - hb), hi = (int)ceilf(ic + hb);
-          if (hi - lo + 1 < NL) {
-            cnt = hi - lo + 1;
-            i0 = lo % NL;
-            if (i0 < 0) i0 += NL;
-          }
-        }
-      }
-    }
-    // neighbour ranks inside the observer's segment of the wave (lidar.py:55-77: by centre distance, stable in slot order)
-    const float dk = (in && is_vehicle) ? dist : __builtin_inff();
-    pDist[lane] = dk;
-    pI0[lane] = i0;
-    int inc = cnt;  // inclusive prefix sum of the window sizes over the wave
-#pragma unroll
-    for (int sh = 1; sh < WAVE; sh <<= 1) {
-      const int up = __shfl_up(inc, sh);
-      if (lane >= sh) inc += up;
-    }
-    pPref[lane + 1] = inc;
-    if (lane == 0) pPref[0] = 0;
-    for (int k = lane; k < G * NL; k += WAVE) s_minb[k] = __float_as_uint(1.0f);
-    row_sync<true>();  // the pass belongs to this wave alone
-    const int T = pPref[WAVE];
-    if (pv) {
-      int rank = 0, nveh = 0;
-      for (int j = 0; j < V; ++j) {
-        const float dj = pDist[pa * V + j];
-        nveh += dj < __builtin_inff() ? 1 : 0;
-        rank += (dj < dk || (dj == dk && j < o)) ? 1 : 0;
-      }
-      float* nb = obs + (size_t)e * d.ostride + (size_t)a * D + o_oth;
-      if (dk < __builtin_inff() && rank < NO) {
-        const float ms = aMS[a], sp_me = speed_kmh(bV[a]);
-        float ph, ps;
-        projection(hx, hy, bX[o] - px, bY[o] - py, ph, ps);
-        float* w = nb + rank * 4;
-        w[0] = clipf((ph / R + 1.0f) * 0.5f, 0.0f, 1.0f);
-        w[1] = clipf((ps / R + 1.0f) * 0.5f, 0.0f, 1.0f);
-        projection(hx, hy, spd * bUX[o] - sp_me * hx, spd * bUY[o] - sp_me * hy, ph, ps);
-        w[2] = clipf((ph / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
-        w[3] = clipf((ps / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
-      }
-      for (int r = nveh + o; r < NO; r += V) {  // absent neighbours -> zeros
-        float* w = nb + r * 4;
-        w[0] = w[1] = w[2] = w[3] = 0.0f;
-      }
-    }
-    // lidar (distance_detector.py:65-94, cutils.pyx:60-142): incidence t belongs to the pair p with pPref[p] <= t < pPref[p + 1]
-    for (int t = lane; t < T; t += WAVE) {
-      int p = 0;
-#pragma unroll
-      for (int sh = WAVE / 2; sh > 0; sh >>= 1)
-        if (pPref[p + sh] <= t) p += sh;
-      const int qa = p / V, qo = p - qa * V, ga = g0 + qa;
-      int i = pI0[p] + (t - pPref[p]);
-      i -= i >= NL ? NL : 0;
-      const float ax = bX[ga], ay = bY[ga], ahx = bUX[ga], ahy = bUY[ga];
-      const float2 bd = d.beam[i];  // (cos, sin)(i * 2 pi / NL); rotated by the heading
-      const float dx = R * (bd.x * ahx - bd.y * ahy), dy = R * (bd.y * ahx + bd.x * ahy);
-      const float f = shape_ray<true>(Obb{bX[qo], bY[qo], bUX[qo], bUY[qo], bHL[qo], bHW[qo]}, ax, ay, dx, dy);
-      atomicMin(&s_minb[qa * NL + i], __float_as_uint(f));
-    }
-    row_sync<true>();  // the pass belongs to this wave alone
-    for (int k = lane; k < G * NL; k += WAVE) {
-      const int qa = k / NL, i = k - qa * NL, ga = g0 + qa;
-      if (ga < A && aWant[ga])
-        obs[(size_t)e * d.ostride + (size_t)ga * D + o_oth + 4 * NO + i] = lidar_noise(d, e, ga, tick, i, __uint_as_float(s_minb[k]));
-    }
-    row_sync<true>();  // the pass belongs to this wave alone
-  }
+  extern __shared__ unsigned s_minb_dyn[];
+  __shared__ ObsEnvLds<NW> M;
+  observe_env_body<NW>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1397,7 +1235,13 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
     stream = h->gstreams[group];
   }
   const bool marl = (h->d.cfg.marl_flags & PGD_MA_ENABLED) != 0;
-  const bool fuse = d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse;
+  // single-agent engines fuse the row into the wave that stepped the env; multi-agent engines append observe_env_body
+  // (all rows of the env) when its per-beam minima fit the step's LDS -- one launch per step either way
+  const bool oth_rows = (h->d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && h->d.cfg.num_others > 0;
+  const bool fuse_env = d_obs && marl && h->d.epw == 1 && h->d.A > 1 && !oth_rows && !h->no_fuse && !h->row_observe &&
+                        h->d.A < 4 * (WAVE / h->d.V) &&  // else the four-wave k_observe_env is the faster one
+                        (WAVE / h->d.V) * (h->d.cfg.num_lasers > 0 ? h->d.cfg.num_lasers : 0) <= STEP_MINB_WORDS;
+  const bool fuse = (d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse) || fuse_env;
   bool prof = h->prof_ev && h->prof_n < h->prof_cap && group < 0;
   // strided profile: with the observation fused (one kernel per step) events [0] / [1] bracket a GROUP of `stride`
   // back-to-back launches and the group time is divided by the stride; otherwise every stride-th step is bracketed
