@@ -52,6 +52,7 @@ struct PgdDev {
   float* prow;
   int dbg_exit;  // exit-profile builds only (PGD_EXITAT)
   int unit_off;  // first block unit of this launch (pgd_step_group); 0 for a whole-engine step
+  int obs_g;     // multi-agent k_step with the fused observation: observers per pass (what fits the step's LDS)
   uint8_t* bev_fill;  // [N] or null: the env was reset -- the top-down observation refills its history (pgd_topdown.h)
 };
 

@@ -614,7 +614,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // them visible to the whole workgroup); the step's LDS is free by now
   if (ONE_ENV && MARL && obs != nullptr) {
     __syncthreads();
-    observe_env_body<1>(d, e, obs, flags, U.obs.m, U.obs.minb);
+    observe_env_body<1>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
   }
   PHASE_MARK(14);  // fused observation
   XMARK(14);
@@ -843,7 +843,7 @@ template <int NW>
 __global__ __launch_bounds__(WAVE * NW) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags) {
   extern __shared__ unsigned s_minb_dyn[];
   __shared__ ObsEnvLds<NW> M;
-  observe_env_body<NW>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn);
+  observe_env_body<NW>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, WAVE / d.V);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1225,6 +1225,7 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   PgdDev dv = h->d;  // this launch's output addressing
   dv.ostride = ostride;
   dv.prow = packed ? d_obs : nullptr;
+  dv.obs_g = std::min(WAVE / h->d.V, STEP_MINB_WORDS / std::max(h->d.cfg.num_lasers, 1));  // fused multi-agent observation
   // env group: the blocks (and the stream) of envs [group * N / G, (group + 1) * N / G); -1 = all envs on the engine stream
   hipStream_t stream = h->stream;
   int n_env_launch = h->d.N;
@@ -1240,7 +1241,7 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   const bool oth_rows = (h->d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && h->d.cfg.num_others > 0;
   const bool fuse_env = d_obs && marl && h->d.epw == 1 && h->d.A > 1 && !oth_rows && !h->no_fuse && !h->row_observe &&
                         h->d.A < 4 * (WAVE / h->d.V) &&  // else the four-wave k_observe_env is the faster one
-                        (WAVE / h->d.V) * (h->d.cfg.num_lasers > 0 ? h->d.cfg.num_lasers : 0) <= STEP_MINB_WORDS;
+                        h->d.cfg.num_lasers <= STEP_MINB_WORDS;  // at least one observer per pass
   const bool fuse = (d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse) || fuse_env;
   bool prof = h->prof_ev && h->prof_n < h->prof_cap && group < 0;
   // strided profile: with the observation fused (one kernel per step) events [0] / [1] bracket a GROUP of `stride`

@@ -329,10 +329,11 @@ struct ObsEnvLds {
   float pDist[NW][WAVE];
   int pPref[NW][WAVE + 1], pI0[NW][WAVE];
 };
-// `s_minb_all`: [NW][(WAVE / V) * num_lasers] words of LDS: nearest hit fraction per (observer of the pass, beam), float bits
+// `G` observers per pass (at most WAVE / V; fewer when the LDS for the per-beam minima is short);
+// `s_minb_all`: [NW][G * num_lasers] words of LDS: nearest hit fraction per (observer of the pass, beam), float bits
 template <int NW>
 DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const uint32_t* flags, ObsEnvLds<NW>& M,
-                          unsigned* s_minb_all) {
+                          unsigned* s_minb_all, const int G) {
   float (&bX)[WAVE] = M.bX; float (&bY)[WAVE] = M.bY; float (&bUX)[WAVE] = M.bUX; float (&bUY)[WAVE] = M.bUY;
   float (&bHL)[WAVE] = M.bHL; float (&bHW)[WAVE] = M.bHW; float (&bV)[WAVE] = M.bV; float (&bAID)[WAVE] = M.bAID;
   int (&bST)[WAVE] = M.bST; uint32_t (&bFL)[WAVE] = M.bFL; float (&aMS)[WAVE] = M.aMS; int (&aWant)[WAVE] = M.aWant;
@@ -401,7 +402,6 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   const bool toll = (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;
   const int o_oth = (d.cfg.side_lasers > 0 ? d.cfg.side_lasers : 2) + 6 + d.cfg.lane_line_lasers + (d.cfg.random_agent_model ? 2 : 0) + (toll ? 0 : 10);
   const float R = d.cfg.lidar_dist;
-  const int G = WAVE / V;
   const int pa = lane / V, o = lane - pa * V;
   unsigned* s_minb = s_minb_all + (size_t)wv * G * NL;
   float* pDist = pDist_all[wv];
