@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <vector>
+#include <type_traits>
 
 #include "pgd_device.h"
 

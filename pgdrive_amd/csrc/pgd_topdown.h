@@ -29,6 +29,7 @@
 // the previous episode's points in the first frame after a reset -- not reproduced).
 #ifndef PGD_TOPDOWN_H
 #define PGD_TOPDOWN_H
+#define TD_CHUNK 7168  /* pixels per gather / write chunk of k_topdown, a multiple of 256 (84 x 84 = 7056 pixels in one) */
 
 struct TopDown {
   int R, C, frame_stack, post_stack, frame_skip, n_pos, n_frames;
@@ -98,16 +99,21 @@ __global__ __launch_bounds__(256) void k_topdown_raster(PgdDev d, int scen, floa
 }
 
 __global__ __launch_bounds__(256) void k_topdown(PgdDev d, TopDown t, uint8_t* __restrict__ fill, float* __restrict__ img) {
-  __shared__ float4 s_pose[16][MAXV];        // pose history after this step's insertion (n_frames <= 16)
+  // dynamic LDS, sized by the engine's V instead of the 64-slot maximum (more blocks per CU: a block alternates between phases
+  // that wait for reads and a phase that only writes, and the CU overlaps them across blocks):
+  //   pose history after this step's insertion [n_frames][V] | per stacked frame the visible boxes [4][V] (centre, axis) | [4][V] half extents
+  extern __shared__ float4 s_dyn4[];
   __shared__ float2 s_pos[64];               // ego position history (n_pos <= 64)
   __shared__ float s_hl[MAXV], s_hw[MAXV];
   __shared__ int s_nhist;
   // per stacked frame: the vehicles that can show up in the window, already in the ego frame of that time
-  __shared__ float4 s_vc[4][MAXV];   // (forward, right) of the box centre, (forward, right) components of its long axis
-  __shared__ float2 s_vh[4][MAXV];   // half extents
   __shared__ int s_nvis[4];
+  __shared__ uint8_t s_cls[TD_CHUNK];  // texel classes of a chunk of pixels: gathered first, then the chunk is written out
   __shared__ float s_out[256 * 8];   // one batch of 256 pixels x C channels, written out linearly (coalesced)
   const int e = blockIdx.x, tid = threadIdx.x, V = d.V;
+  float4* s_pose = s_dyn4;                                  // [f * V + s]
+  float4* s_vc = s_dyn4 + (size_t)t.n_frames * V;           // [f * V + k]: (forward, right) of the box centre, (forward, right) of its long axis
+  float2* s_vh = reinterpret_cast<float2*>(s_vc + 4 * V);   // [f * V + k]: half extents
   const VehRec* recs = d.rec + (size_t)e * V;
   const int scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
   const pgd_spawn* spb = d.spawns + (size_t)scen * d.sstride;
@@ -126,13 +132,13 @@ __global__ __launch_bounds__(256) void k_topdown(PgdDev d, TopDown t, uint8_t* _
       if (s != 0 && fabsf(rc.th) <= 2.0f * PGD_PI / 180.0f) { hx = 1.0f; hy = 0.0f; }  // the reference snaps small headings of the others
       q = drawn ? make_float4(rc.x, rc.y, hx, hy) : make_float4(0.f, 0.f, 0.f, 0.f);
     } else q = hp[(size_t)(f - 1) * V + s];
-    s_pose[f][s] = q;
+    s_pose[f * V + s] = q;
   }
   for (int k = tid; k < t.n_pos; k += 256) s_pos[k] = (k == 0 || refill) ? make_float2(recs[0].x, recs[0].y) : pp[k - 1];
   if (tid < V) { const pgd_spawn& so = spb[recs[tid].spawn]; s_hl[tid] = 0.5f * so.length; s_hw[tid] = 0.5f * so.width; }
   if (tid == 0) s_nhist = refill ? 1 : min(t.n_hist[e] + 1, t.n_pos);
   __syncthreads();
-  for (int k = tid; k < t.n_frames * V; k += 256) hp[k] = s_pose[k / V][k % V];
+  for (int k = tid; k < t.n_frames * V; k += 256) hp[k] = s_pose[k];
   for (int k = tid; k < t.n_pos; k += 256) pp[k] = s_pos[k];
   if (tid == 0) { t.n_hist[e] = s_nhist; fill[e] = 0; }
   __syncthreads();
@@ -141,11 +147,11 @@ __global__ __launch_bounds__(256) void k_topdown(PgdDev d, TopDown t, uint8_t* _
     const int w = tid >> 6, lane = tid & 63;
     for (int f = w; f < t.frame_stack && f < 4; f += 4) {
       const int fi = f * t.frame_skip;
-      const float4 eg = s_pose[fi][0];
+      const float4 eg = s_pose[fi * V];
       bool vis = false;
       float4 vc = make_float4(0.f, 0.f, 1.f, 0.f);
       if (lane >= 1 && lane < V) {
-        const float4 q = s_pose[fi][lane];
+        const float4 q = s_pose[fi * V + lane];
         if (!(q.z == 0.0f && q.w == 0.0f)) {
           const float dx = q.x - eg.x, dy = q.y - eg.y;
           vc = make_float4(dx * eg.z + dy * eg.w, dy * eg.z - dx * eg.w, q.z * eg.z + q.w * eg.w, q.w * eg.z - q.z * eg.w);
@@ -156,8 +162,8 @@ __global__ __launch_bounds__(256) void k_topdown(PgdDev d, TopDown t, uint8_t* _
       const unsigned long long m = __ballot(vis);
       if (vis) {
         const int k = __popcll(m & ((1ull << lane) - 1ull));
-        s_vc[f][k] = vc;
-        s_vh[f][k] = make_float2(s_hl[lane], s_hw[lane]);
+        s_vc[f * V + k] = vc;
+        s_vh[f * V + k] = make_float2(s_hl[lane], s_hw[lane]);
       }
       if (lane == 0) s_nvis[f] = __popcll(m);
     }
@@ -170,52 +176,99 @@ __global__ __launch_bounds__(256) void k_topdown(PgdDev d, TopDown t, uint8_t* _
   const int tw = (int)((float)m.gx * m.cell / TD_TEXEL), th = (int)((float)m.gy * m.cell / TD_TEXEL);
   const uint8_t* tex = t.tex + t.tex_off[scen];
   float* out = img + (size_t)e * R * R * C;
-  for (int p0 = 0; p0 < R * R; p0 += 256) {
-    const int p = p0 + tid;
-    const int i = p / R, j = p - i * R;
-    const float fwd = ((float)R * 0.5f - (float)i - 0.5f) * inv_s, rgt = ((float)j + 0.5f - (float)R * 0.5f) * inv_s;
-    float* px = s_out + tid * C;  // staged: the batch goes out with consecutive lanes on consecutive floats
-    if (p < R * R) {
-    // ch 0: road network around the CURRENT ego pose (right = heading rotated by +90 deg in the engine's x / y frame): the
-    // nearest texel of the scenario's raster
+  // The image is almost empty outside channel 0: the code below writes the road channel and zeros, then the few pixels the
+  // vehicles cover are set.  Loads and stores share one completion counter on this hardware and complete out of order with
+  // respect to each other, so a wave that waits for a texel also waits for every store it has in flight: the texel classes
+  // of a chunk of pixels are therefore gathered into LDS first (many reads in flight, no store pending), and the store loop
+  // that follows contains no global read at all -- each wave streams its batches of 64 consecutive pixels out of its own
+  // staging area and never waits for memory or for the other three waves.
+  const int wv = tid >> 6, lane = tid & 63, n_pix = R * R;
+  float* so = s_out + wv * 64 * 8;  // the wave's staging area: 64 pixels x C (<= 6) floats, then written out linearly
+  for (int k = lane; k < 64 * 8; k += 64) so[k] = 0.0f;  // channels 1.. stay zero: only ch 0 is rewritten per batch
+  const bool vec_ok = ((n_pix * C) & 3) == 0 && ((64 * C) & 3) == 0;  // every batch is then a whole number of float4
+  const float4 eg0 = s_pose[0];
+  const float m_ox = m.ox, m_oy = m.oy;
+  // texel class under pixel (pi, pj): the road network around the CURRENT ego pose (right = heading rotated by +90 deg in the
+  // engine's x / y frame), nearest texel of the scenario's raster
+  auto texel_addr = [&](int pi, int pj, bool on, bool& in) -> long long {
+    const float fw = ((float)R * 0.5f - (float)pi - 0.5f) * inv_s, rg = ((float)pj + 0.5f - (float)R * 0.5f) * inv_s;
+    const float wx = eg0.x + fw * eg0.z - rg * eg0.w, wy = eg0.y + fw * eg0.w + rg * eg0.z;
+    const int ix = (int)floorf((wx - m_ox) * (1.0f / TD_TEXEL)), iy = (int)floorf((wy - m_oy) * (1.0f / TD_TEXEL));
+    in = on && ix >= 0 && iy >= 0 && ix < tw && iy < th;
+    return in ? (long long)iy * tw + ix : 0ll;
+  };
+  for (int c0 = 0; c0 < n_pix; c0 += TD_CHUNK) {
+    const int c1 = min(c0 + TD_CHUNK, n_pix);
+    // ---- gather: pixel c0 + tid + 256 k; all reads of the chunk (TD_CHUNK / 256 per lane) are in flight at once
     {
-      const float4 eg = s_pose[0][0];
-      const float wx = eg.x + fwd * eg.z - rgt * eg.w, wy = eg.y + fwd * eg.w + rgt * eg.z;
-      const int ix = (int)floorf((wx - m.ox) * (1.0f / TD_TEXEL)), iy = (int)floorf((wy - m.oy) * (1.0f / TD_TEXEL));
-      int cls = 0;
-      if (ix >= 0 && iy >= 0 && ix < tw && iy < th) cls = tex[(long long)iy * tw + ix];
-      px[0] = cls == 2 ? TD_LINE : (cls == 1 ? TD_NAVI : 0.0f);
-    }
-    px[1] = 0.0f;
-    // ch 2..: the other vehicles at t, t - skip, ...: point (fwd, rgt) against the culled boxes in that frame's ego coordinates
-    for (int f = 0; f < t.frame_stack; ++f) {
-      float v = 0.0f;
-      if (f < 4) {
-        const int nv = s_nvis[f];
-        for (int k = 0; k < nv; ++k) {
-          const float4 b = s_vc[f][k];
-          const float2 hh = s_vh[f][k];
-          const float dx = fwd - b.x, dy = rgt - b.y;
-          if (fabsf(dx * b.z + dy * b.w) <= hh.x && fabsf(dy * b.z - dx * b.w) <= hh.y) { v = TD_VEH; break; }
-        }
+      const int pb = c0 + tid;
+      const int q256 = 256 / R, r256 = 256 - q256 * R;  // (row, column) of a pixel advance by 256 pixels without a division
+      int i = pb / R, j = pb - i * R;
+      constexpr int NK = TD_CHUNK / 256;
+      int v[NK];
+      bool in[NK];
+#pragma unroll
+      for (int u = 0; u < NK; ++u) {
+        v[u] = tex[texel_addr(i, j, pb + 256 * u < c1, in[u])];
+        j += r256; i += q256;
+        if (j >= R) { j -= R; i += 1; }
       }
-      px[2 + f] = v;
-    }
+#pragma unroll
+      for (int u = 0; u < NK; ++u)
+        if (pb + 256 * u < c1) s_cls[pb + 256 * u - c0] = (uint8_t)(in[u] ? v[u] : 0);
     }
     __syncthreads();
-    {
-      const int n_batch = min(256, R * R - p0) * C;
-      float* dst = out + (size_t)p0 * C;
-      for (int k = tid; k < n_batch; k += 256) dst[k] = s_out[k];
-    }
+    // ---- stream out: no global read in this loop
+    auto store_loop = [&](auto vec_tag) {
+      constexpr bool VEC = decltype(vec_tag)::value;
+      for (int p0 = c0 + wv * 64; p0 < c1; p0 += 256) {
+        const int n_here = min(64, c1 - p0);
+        const int cls = lane < n_here ? (int)s_cls[p0 - c0 + lane] : 0;
+        so[lane * C] = cls == 2 ? TD_LINE : (cls == 1 ? TD_NAVI : 0.0f);
+        row_sync<true>();  // the wave's own LDS traffic only
+        const int nf = n_here * C;
+        float* dst = out + (size_t)p0 * C;
+        if (VEC) {  // 64 x C floats = at most 128 float4 (C <= 8): two predicated stores, no loop
+          const int n4 = nf >> 2;
+          if (lane < n4) reinterpret_cast<float4*>(dst)[lane] = reinterpret_cast<const float4*>(so)[lane];
+          if (lane + 64 < n4) reinterpret_cast<float4*>(dst)[lane + 64] = reinterpret_cast<const float4*>(so)[lane + 64];
+        } else {
+          for (int k = lane; k < nf; k += 64) dst[k] = so[k];
+        }
+        row_sync<true>();
+      }
+    };
+    if (vec_ok) store_loop(std::true_type{});
+    else store_loop(std::false_type{});
     __syncthreads();
   }
   __syncthreads();
+  // ch 2..: the other vehicles at t, t - skip, ...: the pixels whose centre (fwd, rgt) lies inside a box, in that frame's ego
+  // coordinates.  One wave per (frame, box) pair in turn; its lanes walk the pixel rectangle around the box (circumradius + a
+  // pixel of slack), 8 x 8 at a time, with the exact point-in-box test.
+  for (int q = wv; q < 4 * MAXV; q += 4) {
+    const int f = q / MAXV, k = q - f * MAXV;
+    if (f >= t.frame_stack || k >= s_nvis[f]) continue;
+    const float4 b = s_vc[f * V + k];
+    const float2 hh = s_vh[f * V + k];
+    const float rad = (hh.x + hh.y) * s_px + 1.5f;
+    const float ci = (float)R * 0.5f - 0.5f - b.x * s_px, cj = b.y * s_px + (float)R * 0.5f - 0.5f;
+    const int ia = max((int)floorf(ci - rad), 0), ib = min((int)ceilf(ci + rad), R - 1);
+    const int ja = max((int)floorf(cj - rad), 0), jb = min((int)ceilf(cj + rad), R - 1);
+    for (int ti = ia; ti <= ib; ti += 8)
+      for (int tj = ja; tj <= jb; tj += 8) {
+        const int pi = ti + (lane >> 3), pj = tj + (lane & 7);
+        if (pi > ib || pj > jb) continue;
+        const float fwd = ((float)R * 0.5f - (float)pi - 0.5f) * inv_s, rgt = ((float)pj + 0.5f - (float)R * 0.5f) * inv_s;
+        const float dx = fwd - b.x, dy = rgt - b.y;
+        if (fabsf(dx * b.z + dy * b.w) <= hh.x && fabsf(dy * b.z - dx * b.w) <= hh.y) out[((size_t)pi * R + pj) * C + 2 + f] = TD_VEH;
+      }
+  }
   // ch 1: past positions of the ego, newest first, in the current ego frame (top_down_obs_multi_channel.py:152-170)
   if (tid < t.post_stack) {
     const int k = tid * t.frame_skip;
     if (k < s_nhist) {
-      const float4 eg = s_pose[0][0];
+      const float4 eg = s_pose[0];
       const bool snap = fabsf(recs[0].th) <= 2.0f * PGD_PI / 180.0f;  // the reference rotates by the snapped ego heading here
       const float ehx = snap ? 1.0f : eg.z, ehy = snap ? 0.0f : eg.w;
       const float dx = s_pos[k].x - eg.x, dy = s_pos[k].y - eg.y, sc = (float)R / t.distance;
@@ -303,7 +356,8 @@ int pgd_observe_topdown(pgd_handle h, float* d_img) {
   if (!h->topdown || !h->have_maps || !h->have_scen) return PGD_ERR_STATE;
   HIPCHK(hipSetDevice(h->device));
   if (h->topdown->tex_dirty) { int rc = topdown_build_rasters(h); if (rc) return rc; }
-  hipLaunchKernelGGL(k_topdown, dim3(h->d.N), dim3(256), 0, h->stream, h->d, h->topdown->t, h->d.bev_fill, d_img);
+  const size_t dyn = sizeof(float4) * ((size_t)h->topdown->t.n_frames + 4) * h->d.V + sizeof(float2) * 4 * (size_t)h->d.V;
+  hipLaunchKernelGGL(k_topdown, dim3(h->d.N), dim3(256), dyn, h->stream, h->d, h->topdown->t, h->d.bev_fill, d_img);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }
