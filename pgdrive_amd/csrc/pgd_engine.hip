@@ -617,6 +617,22 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     __syncthreads();
     observe_env_body<1>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
   }
+  // several envs per wave (small V) and an observation without a lidar (BASELINE config 2: dynamics + reward + state vector):
+  // the row is the state block alone, written by the sub-lanes of the agent that has just been stepped
+  if (!ONE_ENV && !MARL && obs != nullptr && valid && s < A) {
+    float* row = obs + (size_t)e * d.ostride + (size_t)s * d.D;
+    if (r.status != ST_ACTIVE) {
+      for (int k = g.sub; k < d.D; k += g.SUB) row[k] = 0.0f;
+    } else {
+      AgentView ag;
+      ag.x = r.x; ag.y = r.y; ag.th = r.th; ag.hx = r.hx; ag.hy = r.hy; ag.dl = r.dl; ag.dr = r.dr; ag.v = r.v;
+      ag.steer = r.steer; ag.a0s = r.a0s; ag.a0t = r.a0t; ag.lhx = r.lasthx; ag.lhy = r.lasthy;
+      ag.cur_first = r.cur_first; ag.cur_n = r.cur_n; ag.next_first = r.next_first;
+      ag.blk = r.blk; ag.toll_time = r.php;
+      ag.env = e; ag.slot = s; ag.tick = steps_total;
+      state_block<false>(d, mv, *sp, ag, row, g.sub, g.SUB);
+    }
+  }
   PHASE_MARK(14);  // fused observation
   XMARK(14);
   PHASE_END();
@@ -1243,7 +1259,8 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   const bool fuse_env = d_obs && marl && h->d.epw == 1 && h->d.A > 1 && !oth_rows && !h->no_fuse && !h->row_observe &&
                         h->d.A < 4 * (WAVE / h->d.V) &&  // else the four-wave k_observe_env is the faster one
                         h->d.cfg.num_lasers <= STEP_MINB_WORDS;  // at least one observer per pass
-  const bool fuse = (d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse) || fuse_env;
+  const bool fuse_state = d_obs && !marl && h->d.epw > 1 && h->d.cfg.num_lasers <= 0 && !h->no_fuse;  // state-only rows, several envs per wave
+  const bool fuse = (d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse) || fuse_env || fuse_state;
   bool prof = h->prof_ev && h->prof_n < h->prof_cap && group < 0;
   // strided profile: with the observation fused (one kernel per step) events [0] / [1] bracket a GROUP of `stride`
   // back-to-back launches and the group time is divided by the stride; otherwise every stride-th step is bracketed
