@@ -29,7 +29,10 @@
 // the previous episode's points in the first frame after a reset -- not reproduced).
 #ifndef PGD_TOPDOWN_H
 #define PGD_TOPDOWN_H
-#define TD_CHUNK 7168  /* pixels per gather / write chunk of k_topdown, a multiple of 256 (84 x 84 = 7056 pixels in one) */
+#define TD_CHUNK 7424  /* pixels per gather / write chunk of k_topdown: whole image rows, a multiple of 8 of them (84 x 84 fits in one) */
+// The rasters are stored in tiles of 8 x 8 texels = one 64-byte line each: the window is rotated against the raster, and a
+// tile of 8 x 8 window pixels (the lanes of a gathering wave) then touches a dozen lines instead of one line per lane
+DEV long long td_tiled(int ix, int iy, int tiles_x) { return ((long long)(iy >> 3) * tiles_x + (ix >> 3)) * 64 + ((iy & 7) << 3) + (ix & 7); }
 
 struct TopDown {
   int R, C, frame_stack, post_stack, frame_skip, n_pos, n_frames;
@@ -91,10 +94,14 @@ __global__ __launch_bounds__(256) void k_topdown_raster(PgdDev d, int scen, floa
   if ((int)threadIdx.x < sp.n_ckpt - 1) { const int r = sp.ckpt_road[threadIdx.x]; if (r >= 0) atomicOr(&s_route[r >> 5], 1u << (r & 31)); }
   __syncthreads();
   const MapView mv = map_view_of(d, d.scen_map + scen);
-  const long long n = (long long)W * H;
+  const int tbw = (W + 7) >> 3, tbh = (H + 7) >> 3;
+  const long long n = (long long)tbw * tbh * 64;  // tiled layout (td_tiled); texels past the edge of the last tiles are 0
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
-    const int iy = (int)(p / W), ix = (int)(p - (long long)iy * W);
-    tex[p] = (uint8_t)td_classify(mv, s_route, mv.m->ox + ((float)ix + 0.5f) * TD_TEXEL, mv.m->oy + ((float)iy + 0.5f) * TD_TEXEL, line_r);
+    const long long tile = p >> 6;
+    const int in_t = (int)(p & 63), by = (int)(tile / tbw), bx = (int)(tile - (long long)by * tbw);
+    const int iy = by * 8 + (in_t >> 3), ix = bx * 8 + (in_t & 7);
+    tex[p] = (ix < W && iy < H) ? (uint8_t)td_classify(mv, s_route, mv.m->ox + ((float)ix + 0.5f) * TD_TEXEL, mv.m->oy + ((float)iy + 0.5f) * TD_TEXEL, line_r)
+                                : (uint8_t)0;
   }
 }
 
@@ -188,6 +195,7 @@ __global__ __launch_bounds__(256) void k_topdown(PgdDev d, TopDown t, uint8_t* _
   const bool vec_ok = ((n_pix * C) & 3) == 0 && ((64 * C) & 3) == 0;  // every batch is then a whole number of float4
   const float4 eg0 = s_pose[0];
   const float m_ox = m.ox, m_oy = m.oy;
+  const int tbw = (tw + 7) >> 3;
   // texel class under pixel (pi, pj): the road network around the CURRENT ego pose (right = heading rotated by +90 deg in the
   // engine's x / y frame), nearest texel of the scenario's raster
   auto texel_addr = [&](int pi, int pj, bool on, bool& in) -> long long {
@@ -195,27 +203,33 @@ __global__ __launch_bounds__(256) void k_topdown(PgdDev d, TopDown t, uint8_t* _
     const float wx = eg0.x + fw * eg0.z - rg * eg0.w, wy = eg0.y + fw * eg0.w + rg * eg0.z;
     const int ix = (int)floorf((wx - m_ox) * (1.0f / TD_TEXEL)), iy = (int)floorf((wy - m_oy) * (1.0f / TD_TEXEL));
     in = on && ix >= 0 && iy >= 0 && ix < tw && iy < th;
-    return in ? (long long)iy * tw + ix : 0ll;
+    return in ? td_tiled(ix, iy, tbw) : 0ll;
   };
-  for (int c0 = 0; c0 < n_pix; c0 += TD_CHUNK) {
-    const int c1 = min(c0 + TD_CHUNK, n_pix);
-    // ---- gather: pixel c0 + tid + 256 k; all reads of the chunk (TD_CHUNK / 256 per lane) are in flight at once
+  const int rows_c = min((TD_CHUNK / R) & ~7, (R + 7) & ~7);  // image rows per chunk
+  for (int row0 = 0; row0 < R; row0 += rows_c) {
+    const int row1 = min(row0 + rows_c, R);
+    const int c0 = row0 * R, c1 = row1 * R;
+    // ---- gather: the waves take the 8 x 8 pixel tiles of the band in turn, lane = pixel of the tile, 4 tiles in flight (80 VGPRs: 6 blocks per CU; 8 in flight cost a block)
     {
-      const int pb = c0 + tid;
-      const int q256 = 256 / R, r256 = 256 - q256 * R;  // (row, column) of a pixel advance by 256 pixels without a division
-      int i = pb / R, j = pb - i * R;
-      constexpr int NK = TD_CHUNK / 256;
-      int v[NK];
-      bool in[NK];
+      const int txn = (R + 7) >> 3, n_tiles = ((row1 - row0 + 7) >> 3) * txn;
+      constexpr int NK = 4;
+      for (int q0 = wv; q0 < n_tiles; q0 += 4 * NK) {
+        int v[NK], pix[NK];
 #pragma unroll
-      for (int u = 0; u < NK; ++u) {
-        v[u] = tex[texel_addr(i, j, pb + 256 * u < c1, in[u])];
-        j += r256; i += q256;
-        if (j >= R) { j -= R; i += 1; }
+        for (int u = 0; u < NK; ++u) {
+          const int q = q0 + 4 * u;
+          const int ty = q / txn, tx = q - ty * txn;
+          const int i = row0 + ty * 8 + (lane >> 3), j = tx * 8 + (lane & 7);
+          const bool on = q < n_tiles && i < row1 && j < R;
+          bool in;
+          v[u] = tex[texel_addr(i, j, on, in)];
+          if (!in) v[u] = 0;
+          pix[u] = on ? i * R + j - c0 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < NK; ++u)
+          if (pix[u] >= 0) s_cls[pix[u]] = (uint8_t)v[u];
       }
-#pragma unroll
-      for (int u = 0; u < NK; ++u)
-        if (pb + 256 * u < c1) s_cls[pb + 256 * u - c0] = (uint8_t)(in[u] ? v[u] : 0);
     }
     __syncthreads();
     // ---- stream out: no global read in this loop
@@ -297,7 +311,8 @@ static int topdown_build_rasters(pgd_engine* h) {
   for (int k = 0; k < n_scen; ++k) {
     const pgd_map& M = (*h->h_maps)[(size_t)(*h->h_scen)[(size_t)k].map];
     off[(size_t)k] = total;
-    total += (long long)((float)M.gx * M.cell / TD_TEXEL) * (long long)((float)M.gy * M.cell / TD_TEXEL);
+    const long long W = (long long)((float)M.gx * M.cell / TD_TEXEL), H = (long long)((float)M.gy * M.cell / TD_TEXEL);
+    total += ((W + 7) / 8) * ((H + 7) / 8) * 64;
   }
   if (s->tex) { HIPCHK(hipFree(s->tex)); s->tex = nullptr; }
   if (s->tex_off) { HIPCHK(hipFree(s->tex_off)); s->tex_off = nullptr; }
@@ -308,7 +323,7 @@ static int topdown_build_rasters(pgd_engine* h) {
   for (int k = 0; k < n_scen; ++k) {
     const pgd_map& M = (*h->h_maps)[(size_t)(*h->h_scen)[(size_t)k].map];
     const int W = (int)((float)M.gx * M.cell / TD_TEXEL), H = (int)((float)M.gy * M.cell / TD_TEXEL);
-    const long long n = (long long)W * H;
+    const long long n = (long long)((W + 7) / 8) * ((H + 7) / 8) * 64;
     const int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
     hipLaunchKernelGGL(k_topdown_raster, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, h->stream, h->d, k, s->t.line_r, s->tex + off[(size_t)k], W, H);
   }
