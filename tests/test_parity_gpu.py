@@ -918,3 +918,56 @@ def test_maround_rows_against_the_reference_fixture(descs):
         eng.close()
     print("MARound rows on the GPU:", worst, "corner beams", flips)
     assert worst["rows"] >= 50 and worst["state"] < OBS_TOL and worst["others"] < OBS_TOL and worst["lidar"] <= OBS_TOL and flips <= 4
+
+
+@pytest.mark.parametrize("case", ["c3", "c2", "c2_fans", "marl8", "marl8_240"])
+def test_fused_observation_equals_stand_alone_kernels(descs, case):
+    """One launch per step: the single-agent row (k_step's own wave), the state-only row of several envs per wave, and the
+    multi-agent rows (observe_env_body appended to k_step) are written by the step kernel.  PGD_NO_FUSE keeps the stand-alone
+    observation kernels after k_step: same engine otherwise, free-running with the same actions -- reward / done / flags
+    bit-identical, rows equal up to the contraction of multiply-adds in the two code instances (1e-6; grazing beams counted)."""
+    import os
+    import torch
+    from pgdrive_amd.engine import Engine
+    n_envs = 64
+    if case.startswith("marl"):
+        d, mb, sb = util.make_marl_banks(num_agents=8, capacity=8, kind="roundabout")
+        kw = dict(num_others=4, num_lasers=240, lidar_dist=50.0) if case == "marl8_240" else dict(num_others=4)
+        cfg = util.marl_config(n_envs, sb, horizon=150, resample_scenario=1, seed=2, **kw)
+        A = sb.A
+    else:
+        nt, nl = (16, 240) if case == "c3" else (0, 0)
+        mb, sb = util.make_banks(descs, n_maps=8, num_traffic=nt)
+        fans = dict(side_lasers=6, side_dist=50.0, lane_line_lasers=4, lane_line_dist=20.0) if case == "c2_fans" else {}
+        cfg = _abi.make_config(n_envs, num_agents=1, num_traffic=nt, num_lasers=nl, auto_reset=1, seed=2, resample_scenario=1, **fans)
+        A = 1
+    eng_a = Engine(cfg, mb, sb)
+    os.environ["PGD_NO_FUSE"] = "1"
+    try:
+        eng_b = Engine(cfg, mb, sb)
+    finally:
+        del os.environ["PGD_NO_FUSE"]
+    ids = np.arange(n_envs) % len(sb.scenarios)
+    eng_a.reset(ids); eng_b.reset(ids)
+    rng = np.random.default_rng(8)
+    nl = cfg.num_lasers
+    worst, grazing, beams, n_done = 0.0, 0, 0, 0
+    for t in range(240):
+        act = util.marl_actions(rng, n_envs, A) if A > 1 else util.driving_actions(rng, n_envs)
+        act = torch.from_numpy(act)
+        ga = [x.clone() for x in eng_a.step(act.to(eng_a.device))]
+        gb = [x.clone() for x in eng_b.step(act.to(eng_b.device))]
+        eng_a.sync(); eng_b.sync()
+        for xa, xb, name in zip(ga[1:], gb[1:], ("reward", "done", "flags")):
+            assert torch.equal(xa.cpu(), xb.cpu()), "%s differs at step %d" % (name, t)
+        dd = np.abs(ga[0].cpu().numpy().astype(np.float64) - gb[0].cpu().numpy())
+        if nl:
+            b = dd[..., -nl:]
+            beams += b.size
+            grazing += int((b > 1e-6).sum())
+            b[b > 1e-6] = 0.0
+        worst = max(worst, float(dd.max()))
+        n_done += int(ga[2].sum().item())
+    print("fused vs stand-alone observation", case, "worst", worst, "grazing", grazing, "of", beams, "episodes", n_done)
+    assert worst < 1e-6 and grazing <= 1e-5 * beams + 2 and n_done > 10
+    eng_a.close(); eng_b.close()
