@@ -469,7 +469,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     for (int k = lane; k < G * NL; k += WAVE) s_minb[k] = __float_as_uint(1.0f);
     row_sync<true>();  // the pass belongs to this wave alone
     const int T = pPref[WAVE];
-    if (pv) {
+    if (pv && NO > 0) {  // (the multi-agent default observes no neighbour rows: nothing to rank)
       int rank = 0, nveh = 0;
       for (int j = 0; j < V; ++j) {
         const float dj = pDist[pa * V + j];
