@@ -145,6 +145,9 @@ def parse_args(argv=None):
     ap.add_argument("--groups", type=int, default=1,
                     help="split the --envs environments of the engine into G asynchronous env groups (pgd_set_groups / "
                          "pgd_step_group): one 'step' = every group stepped once, the groups' launches overlap")
+    ap.add_argument("--step-n", type=int, default=1,
+                    help="open-loop variant: K steps of the action ring per pgd_step_n call (observation only for the last state of "
+                         "each call); reported next to the metric, never as the metric (the metric is the closed loop)")
     ap.add_argument("--topdown", action="store_true",
                     help="c3 with the top-down image observation (TopDownPGDriveEnv: 84 x 84 x 5, lidar off): pgd_step + "
                          "pgd_observe_topdown per step; reported next to the metric, never as the metric")
@@ -243,6 +246,10 @@ def run_rank(args, rank, world, local_rank):
             for g in range(args.groups):  # each group on its own internal stream: the launches overlap
                 eng.step_group(g, actions[(k + 5 * g) % CYC])
             return
+        if args.step_n > 1:  # one call per K steps; the other K - 1 "steps" of the loop are part of that call
+            if k % args.step_n == 0:
+                eng.step_n(actions, k % CYC, args.step_n)
+            return
         eng.step(actions[k % CYC], want_obs=not args.topdown)
         if args.topdown:
             eng.observe_topdown()
@@ -279,7 +286,7 @@ def run_rank(args, rank, world, local_rank):
             # HIP events bracket groups of PROF_STRIDE consecutive k_step launches over the whole timed region; the average
             # launch duration is group time / PROF_STRIDE (two event packets around EVERY launch leave the command processor
             # idle between back-to-back kernels and slow the thing being measured)
-            profiled = mode == "replicas"
+            profiled = mode == "replicas" and args.step_n == 1  # (the open-loop variant mixes launches with and without the observation)
             if profiled:
                 eng.profile_begin(timed // PROF_STRIDE + 1, stride=PROF_STRIDE)
             t0 = time.perf_counter()
@@ -337,6 +344,8 @@ def run_rank(args, rank, world, local_rank):
                if args.engines > 1 else {}),
             "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
             "engines_per_gpu": max(1, args.engines), "env_groups": args.groups,
+            **({"open_loop": "pgd_step_n: %d steps of the action ring per call, one observation per call -- NOT the metric's closed "
+                             "loop" % args.step_n} if args.step_n > 1 else {}),
             **({"observation": "top-down image 84 x 84 x 5 float32 (pgd_observe_topdown), %.1f MB written per step" % (
                 N * 84 * 84 * 5 * 4 / 1e6)} if args.topdown else {}),
             "parallelism": par, "backend": (args.backend if world > 1 else "none"),

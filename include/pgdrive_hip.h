@@ -246,6 +246,16 @@ int pgd_reset(pgd_handle h, const int32_t* h_env_ids, const int32_t* h_scen_ids,
 int pgd_step(pgd_handle h, const float* d_actions /*[N,A,2]*/, float* d_obs /*[N,A,D]*/, float* d_reward /*[N,A]*/,
              uint8_t* d_done /*[N,A]*/, uint32_t* d_flags /*[N,A]*/);
 
+/* K steps of an action ring in one call (open-loop use: action repeat / frame skip, scripted roll-outs, benchmarks): step k
+ * (k = 0 .. n_steps - 1) applies d_action_ring[(first + k) % ring_len] ([ring_len][N,A,2]) exactly as pgd_step would -- auto-reset
+ * included -- and writes its reward / done / flags into slice k of d_reward / d_done / d_flags ([n_steps][N,A]).  The
+ * observation (d_obs, may be NULL) is evaluated ONCE, for the state after the last step: the intermediate steps run without
+ * the observation part of the kernel.  n_steps launches on the stream, no host synchronisation in between; the closed loop
+ * policy -> action -> step needs pgd_step (the reference's env.step has no counterpart of this call; its decision_repeat is
+ * the five physics sub-steps inside every step). */
+int pgd_step_n(pgd_handle h, const float* d_action_ring, int ring_len, int first, int n_steps, float* d_obs /*[N,A,D]*/,
+               float* d_reward /*[n_steps][N,A]*/, uint8_t* d_done /*[n_steps][N,A]*/, uint32_t* d_flags /*[n_steps][N,A]*/);
+
 /* The same step with the env's results written as ONE packed fp32 row per env, the unit of the per-step gather that
  * BASELINE.json's north star names (envs shard across GPUs, one gather of (obs, reward, done) per step):
  *   d_rows[e * row_stride + ...] = [A*D observation floats | A rewards | A done flags as 0.0 / 1.0], row_stride >= A*(D+2).

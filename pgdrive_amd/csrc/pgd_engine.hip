@@ -1307,6 +1307,19 @@ int pgd_step(pgd_handle h, const float* d_actions, float* d_obs, float* d_reward
   return step_impl(h, d_actions, d_obs, d_reward, d_done, d_flags, h->d.A * h->d.D, false);
 }
 
+int pgd_step_n(pgd_handle h, const float* d_action_ring, int ring_len, int first, int n_steps, float* d_obs, float* d_reward,
+               uint8_t* d_done, uint32_t* d_flags) {
+  if (!h || !d_action_ring || ring_len < 1 || first < 0 || n_steps < 1) return PGD_ERR_ARG;
+  const size_t na = (size_t)h->d.N * h->d.A;
+  for (int k = 0; k < n_steps; ++k) {
+    const float* act = d_action_ring + (size_t)((first + k) % ring_len) * na * 2;
+    const int rc = step_impl(h, act, k == n_steps - 1 ? d_obs : (float*)nullptr, d_reward + (size_t)k * na, d_done + (size_t)k * na,
+                             d_flags + (size_t)k * na, h->d.A * h->d.D, false);
+    if (rc) return rc;
+  }
+  return PGD_OK;
+}
+
 int pgd_step_packed(pgd_handle h, const float* d_actions, float* d_rows, int row_stride, float* d_reward, uint8_t* d_done,
                     uint32_t* d_flags) {
   if (!h || !d_rows || row_stride < h->d.A * (h->d.D + 2)) return PGD_ERR_ARG;

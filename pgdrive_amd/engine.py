@@ -21,6 +21,7 @@ _SIGS = {
     "pgd_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pgd_step": (C.c_int, [C.c_void_p] * 6),
     "pgd_step_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pgd_step_n": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgd_state_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pgd_get_state": (C.c_int, [C.c_void_p] * 4),
     "pgd_set_state": (C.c_int, [C.c_void_p] * 4),
@@ -189,6 +190,24 @@ class Engine:
         _chk(self.L.pgd_step_packed(self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(rows.data_ptr()),
                                     int(rows.stride(0)), p_rew, p_done, p_flags), "pgd_step_packed")
         return rows, self.reward, self.done, self.flags
+
+    def step_n(self, action_ring, first, n_steps, want_obs=True):
+        """n_steps steps of `action_ring` [L, N, A, 2] (step k applies ring[(first + k) % L]) in one call (pgd_step_n): returns
+        (obs after the last step or None, reward [n_steps, N, A], done, flags); the intermediate steps skip the observation."""
+        t = self.torch
+        assert action_ring.is_cuda and action_ring.dtype == t.float32 and action_ring.is_contiguous() and action_ring.dim() == 4
+        assert tuple(action_ring.shape[1:]) == (self.N, self.A, 2)
+        cur = t.cuda.current_stream(self.device).cuda_stream
+        if cur != self._bound_stream:
+            _chk(self.L.pgd_set_stream(self.h, C.c_void_p(cur)), "pgd_set_stream")
+            self._bound_stream = cur
+        rew = t.empty((n_steps, self.N, self.A), dtype=t.float32, device=self.obs.device)
+        done = t.empty((n_steps, self.N, self.A), dtype=t.uint8, device=self.obs.device)
+        flags = t.empty((n_steps, self.N, self.A), dtype=t.int32, device=self.obs.device)
+        p_obs = self._own_ptrs[0] if want_obs else None
+        _chk(self.L.pgd_step_n(self.h, C.c_void_p(action_ring.data_ptr()), int(action_ring.shape[0]), int(first), int(n_steps), p_obs,
+                               C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(flags.data_ptr())), "pgd_step_n")
+        return (self.obs if want_obs else None), rew, done, flags
 
     # -- top-down observation (obs/top_down_obs_multi_channel.py) -----------------------------------------------------------
     def enable_topdown(self, td_cfg=None):

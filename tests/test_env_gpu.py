@@ -461,3 +461,51 @@ def test_env_groups_step_like_one_batch(descs):
     assert torch.equal(b.obs[others], before[others])  # the other groups' rows were not touched
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("multi_agent", [False, True])
+def test_step_n_equals_single_steps(multi_agent):
+    """pgd_step_n (K steps of an action ring in one call, observation for the last state only) against K calls of pgd_step:
+    reward / done / flags of every step, the final observation and the final state are bit-identical."""
+    import torch
+    from pgdrive_amd import _abi, bank
+    from pgdrive_amd.engine import Engine
+    from tests import util
+    n = 96
+    if multi_agent:
+        d, mb, sb = util.make_marl_banks(num_agents=8, capacity=8, kind="roundabout")
+        cfg = util.marl_config(n, sb, horizon=60, resample_scenario=1, seed=4)
+        A = sb.A
+    else:
+        descs = bank.load_descriptions()
+        mb, sb = util.make_banks(descs, n_maps=8)
+        cfg = _abi.make_config(n, num_agents=1, num_traffic=16, num_lasers=240, auto_reset=1, resample_scenario=1, seed=4)
+        A = 1
+    ea, eb = Engine(cfg, mb, sb), Engine(cfg, mb, sb)
+    ids = np.arange(n) % len(sb.scenarios)
+    ea.reset(ids); eb.reset(ids)
+    rng = np.random.default_rng(1)
+    L, K = 7, 5
+    n_done = 0
+    for rep in range(30):
+        ring = np.stack([util.marl_actions(rng, n, A) if multi_agent else util.driving_actions(rng, n) for _ in range(L)])
+        if not multi_agent:
+            ring[:, ::3, 0, :] = 1.0  # a third of the envs: hard right at full throttle (episodes end, auto-reset inside the call)
+        ring_d = torch.from_numpy(ring).to(ea.device)
+        first = rep % L
+        obs_n, rew_n, done_n, fl_n = ea.step_n(ring_d, first, K)
+        ea.sync()
+        for k in range(K):
+            o, r, dn, fl = eb.step(ring_d[(first + k) % L])
+            eb.sync()
+            assert torch.equal(rew_n[k], r) and torch.equal(done_n[k], dn) and torch.equal(fl_n[k], fl), (rep, k)
+            n_done += int(dn.sum().item())
+        assert torch.equal(obs_n, o), rep
+        fa, ia, eia = ea.get_state()
+        fb, ib, eib = eb.get_state()
+        ei_near = _abi.EI["NEAR"]
+        assert (ia == ib).all() and (np.delete(eia, ei_near, axis=0) == np.delete(eib, ei_near, axis=0)).all()
+        assert (fa.view(np.int32) == fb.view(np.int32)).all()
+    assert n_done > 20
+    ea.close(); eb.close()
