@@ -12,12 +12,20 @@ struct Fbo {
   bool exist[3];
 };
 
+// (road, index, n_succ, pad = lane count of the road) of a lane: the four int16 behind the geometry, one 8-byte read
+DEV uint2 lane_quad(const MapView& mv, int lane) { return *reinterpret_cast<const uint2*>(&mv.lanes[lane].road); }
+DEV int quad_road(uint2 q) { return (int)(short)(q.x & 0xffffu); }
+DEV int quad_index(uint2 q) { return (int)(short)(q.x >> 16); }
+DEV int quad_count(uint2 q) { return (int)(short)(q.y >> 16); }
+
+// `quad` = lane_quad of `lane`, read by the caller together with its other lane reads (one dependent level less here).
+// own_*: the vehicle's coordinates on `lane` and the lane heading one metre ahead, by-products of the search on the own lane
+// (target 1), handed to every sub-lane: the steering controller needs exactly these when it steers along `lane`.
 DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int base, int V, int self, unsigned long long objs,
-                         int lane, float max_dist, bool with_ref, Fbo& r) {
-  const pgd_lane& L = mv.lanes[lane];
-  const int idx = L.index;  // the lanes of a road are consecutive; the device copy of the lane carries its road's lane count
+                         int lane, uint2 quad, float max_dist, bool with_ref, Fbo& r, float& own_lon, float& own_lat, float& own_head) {
+  const int idx = quad_index(quad);  // the lanes of a road are consecutive; the device copy of the lane carries its road's lane count
   const int l0 = (with_ref && idx > 0) ? lane - 1 : -1;
-  const int l2 = (with_ref && idx + 1 < L.pad) ? lane + 1 : -1;
+  const int l2 = (with_ref && idx + 1 < quad_count(quad)) ? lane + 1 : -1;
   const float px = S.x[base + self], py = S.y[base + self];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -33,6 +41,7 @@ DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int bas
     const pgd_lane& li = mv.lanes[tl];
     float cur, lat;
     lane_local(li, px, py, cur, lat);
+    if (t == 1) { own_lon = cur; own_lat = lat; own_head = lane_heading_at(li, cur + 1.0f); }
     const float left_long = li.length - cur;
     const int4 lsucc = *reinterpret_cast<const int4*>(li.succ);
     // one pass, five running minima (FrontBackObjects.get_find_front_back_objs, idm_policy.py:107-131):
@@ -81,6 +90,10 @@ DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int bas
     r.fd[i] = __shfl(r.fd[i], src);
     r.bd[i] = __shfl(r.bd[i], src);
   }
+  {
+    const int src = g.lead + (1 % g.SUB);
+    own_lon = __shfl(own_lon, src); own_lat = __shfl(own_lat, src); own_head = __shfl(own_head, src);
+  }
 }
 
 template <bool OBJ>
@@ -91,8 +104,10 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
   int rt = r.rlane;
   // the current road and its lanes come from the record's route context; the two lane reads are independent
   const int cur_road = r.road_cur;
-  const int vl_road = mv.lanes[vlane].road;
-  const int rt_road = rt < 0 ? vl_road : (int)mv.lanes[rt].road;
+  const uint2 q_vl = lane_quad(mv, vlane), q_r0 = lane_quad(mv, rt < 0 ? vlane : rt);  // independent reads, one round trip
+  const int rt0 = rt;
+  const int vl_road = quad_road(q_vl);
+  const int rt_road = quad_road(q_r0);
   struct { int first_lane, n_lanes; } const CR{r.cur_first, r.cur_n};
   bool success;
   // move_to_next_road (idm_policy.py:222-242)
@@ -150,10 +165,13 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
   // not in ref lanes although move_to_next_road succeeded) falls back to "no front object, distance 5"
   const bool search = !success || in_cur;
   Fbo fb;
-  if (search) find_front_back(mv, g, S, base, V, s, objs, rt, MAXD, success, fb);
+  // the routing lane is almost always the old one or the vehicle's lane: its index / lane count are then already here
+  const uint2 q_rt = rt == vlane ? q_vl : (rt == rt0 ? q_r0 : lane_quad(mv, rt));
+  float own_lon = 0.0f, own_lat = 0.0f, own_head = 0.0f;
+  if (search) find_front_back(mv, g, S, base, V, s, objs, rt, q_rt, MAXD, success, fb, own_lon, own_lat, own_head);
   PHASE_MARK(10);  // idm: front/back search
   if (success && in_cur) {
-    int idx = mv.lanes[rt].index;
+    int idx = quad_index(q_rt);
     int n_cur = CR.n_lanes;
     int avail_lo = 0, avail_hi = n_cur - 1;
     bool decided = false;
@@ -215,10 +233,14 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
   PHASE_MARK(11);  // idm: lane-change logic
 
   // steering_control (idm_policy.py:244-252)
-  const pgd_lane& SL = mv.lanes[steer_lane];
-  float lon, lat;
-  lane_local(SL, px, py, lon, lat);
-  float lane_heading = lane_heading_at(SL, lon + 1.0f);
+  float lon, lat, lane_heading;
+  if (search && steer_lane == rt) {  // the search on the own lane has evaluated exactly this (same routine, same inputs)
+    lon = own_lon; lat = own_lat; lane_heading = own_head;
+  } else {
+    const pgd_lane& SL = mv.lanes[steer_lane];
+    lane_local(SL, px, py, lon, lat);
+    lane_heading = lane_heading_at(SL, lon + 1.0f);
+  }
   float steering = pid_update(r.php, r.phi, 1.7f, 0.01f, 3.5f, wrap_to_pi(lane_heading - r.th));
   steering += pid_update(r.plp, r.pli, 0.3f, 0.002f, 0.05f, -lat);
   // acceleration / desired_gap (idm_policy.py:254-271)
