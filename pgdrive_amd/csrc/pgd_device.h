@@ -12,6 +12,7 @@
 
 #define PGD_PI 3.14159265358979323846f
 #define DEV __device__ __forceinline__
+#define DEV_HOST __host__ __device__ inline
 
 // ---------------------------------------------------------------------------------------------------------------------
 // device-side view of the engine

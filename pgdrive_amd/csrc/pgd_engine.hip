@@ -857,10 +857,10 @@ __global__ __launch_bounds__(BLOCK == WAVE ? WAVE * OBS_RPB : BLOCK) void k_obse
 // are at least four passes (A >= 4 * (WAVE / V)), else 1.
 // NW = 4 when the pair phase has at least four passes (A >= 4 * (WAVE / V)), else 1.
 template <int NW>
-__global__ __launch_bounds__(WAVE * NW) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags) {
+__global__ __launch_bounds__(WAVE * NW) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags, int G) {
   extern __shared__ unsigned s_minb_dyn[];
   __shared__ ObsEnvLds<NW> M;
-  observe_env_body<NW>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, WAVE / d.V);
+  observe_env_body<NW>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1187,13 +1187,19 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
   const int rows = (n_envs > 0 ? n_envs : h->d.N) * h->d.A;
   const bool oth = (h->d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && h->d.cfg.num_others > 0;
   const int envs = n_envs > 0 ? n_envs : h->d.N;
-  const size_t minb = sizeof(unsigned) * (size_t)(WAVE / h->d.V) * (size_t)(h->d.cfg.num_lasers > 0 ? h->d.cfg.num_lasers : 0);
-  if (h->d.A > 1 && !oth && h->d.epw == 1 && 4 * minb <= 49152 && !h->row_observe) {  // all rows of an env by one block
-    const bool four = h->d.A >= 4 * (WAVE / h->d.V);  // at least four passes of the pair phase
-    if (four) hipLaunchKernelGGL(k_observe_env<4>, dim3(envs), dim3(WAVE * 4), 4 * minb, stream, D, d_obs, d_flags);
-    else hipLaunchKernelGGL(k_observe_env<1>, dim3(envs), dim3(WAVE), minb, stream, D, d_obs, d_flags);
-    HIPCHK(hipGetLastError());
-    return PGD_OK;
+  if (h->d.A > 1 && !oth && h->d.epw == 1 && !h->row_observe) {  // all rows of an env by one block
+    const int A = h->d.A, V = h->d.V, NL = h->d.cfg.num_lasers;
+    const bool four = A >= 4 * (WAVE / V);  // many observers, few per pass: four waves per env, each with its own range
+    const int nw = four ? 4 : 1, per_wave = (A + nw - 1) / nw;
+    int G = per_wave;  // observers per round of a wave: the whole range if its LDS fits (48 KB per block)
+    while (G > 1 && (size_t)nw * observe_env_words(G, NL, V) * 4 > 49152) --G;
+    const size_t dyn = (size_t)nw * observe_env_words(G, NL, V) * 4;
+    if (dyn <= 49152) {
+      if (four) hipLaunchKernelGGL(k_observe_env<4>, dim3(envs), dim3(WAVE * 4), dyn, stream, D, d_obs, d_flags, G);
+      else hipLaunchKernelGGL(k_observe_env<1>, dim3(envs), dim3(WAVE), dyn, stream, D, d_obs, d_flags, G);
+      HIPCHK(hipGetLastError());
+      return PGD_OK;
+    }
   }
   const bool wide = h->d.cfg.num_lasers > 128;  // up to 128 beams one wave does it in two rounds: 4x fewer waves than 256-thread blocks
   void (*kern)(PgdDev, float*, const uint32_t*, int) =
@@ -1242,7 +1248,11 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   PgdDev dv = h->d;  // this launch's output addressing
   dv.ostride = ostride;
   dv.prow = packed ? d_obs : nullptr;
-  dv.obs_g = std::min(WAVE / h->d.V, STEP_MINB_WORDS / std::max(h->d.cfg.num_lasers, 1));  // fused multi-agent observation
+  {  // fused multi-agent observation: observers per round = what the step's LDS holds
+    int G = h->d.A;
+    while (G > 1 && observe_env_words(G, h->d.cfg.num_lasers, h->d.V) > STEP_MINB_WORDS) --G;
+    dv.obs_g = G;
+  }
   // env group: the blocks (and the stream) of envs [group * N / G, (group + 1) * N / G); -1 = all envs on the engine stream
   hipStream_t stream = h->stream;
   int n_env_launch = h->d.N;
@@ -1258,7 +1268,7 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   const bool oth_rows = (h->d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && h->d.cfg.num_others > 0;
   const bool fuse_env = d_obs && marl && h->d.epw == 1 && h->d.A > 1 && !oth_rows && !h->no_fuse && !h->row_observe &&
                         h->d.A < 4 * (WAVE / h->d.V) &&  // else the four-wave k_observe_env is the faster one
-                        h->d.cfg.num_lasers <= STEP_MINB_WORDS;  // at least one observer per pass
+                        observe_env_words(1, h->d.cfg.num_lasers, h->d.V) <= STEP_MINB_WORDS;  // at least one observer per round
   const bool fuse_state = d_obs && !marl && h->d.epw > 1 && h->d.cfg.num_lasers <= 0 && !h->no_fuse;  // state-only rows, several envs per wave
   const bool fuse = (d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse) || fuse_env || fuse_state;
   bool prof = h->prof_ev && h->prof_n < h->prof_cap && group < 0;

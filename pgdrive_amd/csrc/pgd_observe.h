@@ -319,6 +319,9 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
 // are at least four passes (A >= 4 * (WAVE / V)), else 1.
 // NW waves per env: the state blocks get NW * WAVE / A lanes per agent and the passes of the pair phase are dealt out to the waves
 // (wave w takes passes w, w + NW, ...; each wave has its own scratch and synchronises with itself only).
+// LDS words one wave needs for rounds of g observers
+DEV_HOST int observe_env_words(int g, int num_lasers, int V) { return g * ((num_lasers > 0 ? num_lasers : 0) + 2 * V); }
+
 template <int NW>
 struct ObsEnvLds {
   float bX[WAVE], bY[WAVE], bUX[WAVE], bUY[WAVE], bHL[WAVE], bHW[WAVE], bV[WAVE], bAID[WAVE];
@@ -329,8 +332,9 @@ struct ObsEnvLds {
   float pDist[NW][WAVE];
   int pPref[NW][WAVE + 1], pI0[NW][WAVE];
 };
-// `G` observers per pass (at most WAVE / V; fewer when the LDS for the per-beam minima is short);
-// `s_minb_all`: [NW][G * num_lasers] words of LDS: nearest hit fraction per (observer of the pass, beam), float bits
+// `G` observers per round of a wave (as many as the LDS holds, see observe_env_words);
+// `s_minb_all`: per wave G * (num_lasers + 2 V) words of LDS: nearest hit fraction per (observer of the round, beam) as float
+// bits, then centre distance and speed of every pair of the round
 template <int NW>
 DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const uint32_t* flags, ObsEnvLds<NW>& M,
                           unsigned* s_minb_all, const int G) {
@@ -398,123 +402,142 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   }
   if (NL <= 0) return;
   __syncthreads();
-  // ---- pairs: G observers per pass, lane = (observer pa of the pass, body o)
+  // ---- pairs.  Every wave owns a contiguous range of observers and works through it in rounds of at most `G` observers (what
+  // the LDS for the per-beam minima holds); the (observer, body) pairs of a round are packed into the lanes 64 at a time,
+  // whatever V is (V = 40: 25 passes for 40 observers instead of 40 passes with 40 busy lanes each).
   const bool toll = (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;
   const int o_oth = (d.cfg.side_lasers > 0 ? d.cfg.side_lasers : 2) + 6 + d.cfg.lane_line_lasers + (d.cfg.random_agent_model ? 2 : 0) + (toll ? 0 : 10);
   const float R = d.cfg.lidar_dist;
-  const int pa = lane / V, o = lane - pa * V;
-  unsigned* s_minb = s_minb_all + (size_t)wv * G * NL;
-  float* pDist = pDist_all[wv];
+  const int per_wave = (A + NW - 1) / NW;
+  const int a_lo = min(wv * per_wave, A), a_hi = min(a_lo + per_wave, A);
+  unsigned* s_minb = s_minb_all + (size_t)wv * ((size_t)G * NL + 2 * (size_t)G * V);  // [G * NL] minima | [G * V] distance | [G * V] speed
+  float* rDist = reinterpret_cast<float*>(s_minb + (size_t)G * NL);
+  float* rSpd = rDist + (size_t)G * V;
+  int* pAO = reinterpret_cast<int*>(pDist_all[wv]);  // (observer of the round << 8) | body, per lane of the pass
   int* pPref = pPref_all[wv];
   int* pI0 = pI0_all[wv];
-  for (int g0 = wv * G; g0 < A; g0 += G * NW) {
-    const int a = g0 + pa;
-    const bool pv = pa < G && a < A && aWant[a < A ? a : 0] != 0;
-    const int ac = pv ? a : 0;
-    const float px = bX[ac], py = bY[ac], hx = bUX[ac], hy = bUY[ac];
-    bool in = false, is_vehicle = true;
-    float dist = 0.0f, spd = 0.0f;
-    int i0 = 0, cnt = 0;
-    if (pv) {
-      const int stt = bST[o] & 0xff, kind = bST[o] >> 8;
-      bool present = stt == ST_PENDING || stt == ST_ACTIVE || stt == ST_DYING;
-      bool still = stt == ST_DYING;  // a finished agent is a static body (zero velocity)
-      if (flags && o < A) {
-        // multi-agent step: rows of agents that drove this step show the world before the finishes / respawns
-        // (base_env.py:303-344 runs before multi_agent_pgdrive.py:128-141); an agent spawned this step sees the world at
-        // its spawn time, i.e. the earlier spawns of the step only
-        const uint32_t fa = bFL[a], fo = bFL[o];
-        if (fa & PGD_F_RESET) {
-        } else if (fa & PGD_F_NEW) {
-          present = present && (!(fo & PGD_F_NEW) || bAID[o] < bAID[a]);
-        } else {
-          present = (fo & PGD_F_REPORT) || (present && !(fo & PGD_F_NEW));
-          still = still && !(fo & PGD_F_REPORT);
+  for (int g0 = a_lo; g0 < a_hi; g0 += G) {
+    const int g1 = min(g0 + G, a_hi);
+    const int P = (g1 - g0) * V;
+    for (int k = lane; k < (g1 - g0) * NL; k += WAVE) s_minb[k] = __float_as_uint(1.0f);
+    row_sync<true>();  // the round belongs to this wave alone
+    for (int q0 = 0; q0 < P; q0 += WAVE) {
+      const int pq = q0 + lane;
+      const int al = pq / V, o = pq - al * V, a = g0 + al;
+      const bool pv = pq < P && aWant[pq < P ? a : 0] != 0;
+      const int ac = pv ? a : 0;
+      const float px = bX[ac], py = bY[ac], hx = bUX[ac], hy = bUY[ac];
+      bool in = false, is_vehicle = true;
+      float dist = 0.0f, spd = 0.0f;
+      int i0 = 0, cnt = 0;
+      if (pv) {
+        const int stt = bST[o] & 0xff, kind = bST[o] >> 8;
+        bool present = stt == ST_PENDING || stt == ST_ACTIVE || stt == ST_DYING;
+        bool still = stt == ST_DYING;  // a finished agent is a static body (zero velocity)
+        if (flags && o < A) {
+          // multi-agent step: rows of agents that drove this step show the world before the finishes / respawns
+          // (base_env.py:303-344 runs before multi_agent_pgdrive.py:128-141); an agent spawned this step sees the world at
+          // its spawn time, i.e. the earlier spawns of the step only
+          const uint32_t fa = bFL[a], fo = bFL[o];
+          if (fa & PGD_F_RESET) {
+          } else if (fa & PGD_F_NEW) {
+            present = present && (!(fo & PGD_F_NEW) || bAID[o] < bAID[a]);
+          } else {
+            present = (fo & PGD_F_REPORT) || (present && !(fo & PGD_F_NEW));
+            still = still && !(fo & PGD_F_REPORT);
+          }
         }
-      }
-      is_vehicle = kind == PGD_OBJ_VEHICLE;
-      const float x = bX[o], y = bY[o], hl = bHL[o], hw = bHW[o];
-      in = present && o != a && shape_point_dist<true>(Obb{x, y, bUX[o], bUY[o], hl, hw}, px, py) <= R;
-      if (in) {  // the arithmetic of obs_compact
-        spd = still ? 0.0f : speed_kmh(bV[o]);
-        dist = norm2(px - x, py - y);
-        const float rad = (hw < 0.0f ? hl : norm2(hl, hw)) * 1.02f + 0.01f;
-        i0 = 0; cnt = NL;
-        if (dist > rad) {
-          const float rx = (x - px) * hx + (y - py) * hy, ry = (y - py) * hx - (x - px) * hy;
-          const float inv_unit = (float)NL * (0.5f / PGD_PI);
-          const float q = rad / dist;
-          const float ic = atan2f(ry, rx) * inv_unit, hb = (q + 0.5708f * q * q * q) * inv_unit + 1.5f;
-          const int lo = (int)floorf(ic - hb), hi = (int)ceilf(ic + hb);
-          if (hi - lo + 1 < NL) {
-            cnt = hi - lo + 1;
-            i0 = lo % NL;
-            if (i0 < 0) i0 += NL;
+        is_vehicle = kind == PGD_OBJ_VEHICLE;
+        const float x = bX[o], y = bY[o], hl = bHL[o], hw = bHW[o];
+        in = present && o != a && shape_point_dist<true>(Obb{x, y, bUX[o], bUY[o], hl, hw}, px, py) <= R;
+        if (in) {  // the arithmetic of obs_compact
+          spd = still ? 0.0f : speed_kmh(bV[o]);
+          dist = norm2(px - x, py - y);
+          const float rad = (hw < 0.0f ? hl : norm2(hl, hw)) * 1.02f + 0.01f;
+          i0 = 0; cnt = NL;
+          if (dist > rad) {
+            const float rx = (x - px) * hx + (y - py) * hy, ry = (y - py) * hx - (x - px) * hy;
+            const float inv_unit = (float)NL * (0.5f / PGD_PI);
+            const float q = rad / dist;
+            const float ic = atan2f(ry, rx) * inv_unit, hb = (q + 0.5708f * q * q * q) * inv_unit + 1.5f;
+            const int lo = (int)floorf(ic - hb), hi = (int)ceilf(ic + hb);
+            if (hi - lo + 1 < NL) {
+              cnt = hi - lo + 1;
+              i0 = lo % NL;
+              if (i0 < 0) i0 += NL;
+            }
           }
         }
       }
-    }
-    // neighbour ranks inside the observer's segment of the wave (lidar.py:55-77: by centre distance, stable in slot order)
-    const float dk = (in && is_vehicle) ? dist : __builtin_inff();
-    pDist[lane] = dk;
-    pI0[lane] = i0;
-    int inc = cnt;  // inclusive prefix sum of the window sizes over the wave
+      if (pq < P && NO > 0) {  // kept for the neighbour ranks of the round
+        rDist[pq] = (in && is_vehicle) ? dist : __builtin_inff();
+        rSpd[pq] = spd;
+      }
+      pAO[lane] = (al << 8) | o;
+      pI0[lane] = i0;
+      int inc = cnt;  // inclusive prefix sum of the window sizes over the wave
 #pragma unroll
-    for (int sh = 1; sh < WAVE; sh <<= 1) {
-      const int up = __shfl_up(inc, sh);
-      if (lane >= sh) inc += up;
-    }
-    pPref[lane + 1] = inc;
-    if (lane == 0) pPref[0] = 0;
-    for (int k = lane; k < G * NL; k += WAVE) s_minb[k] = __float_as_uint(1.0f);
-    row_sync<true>();  // the pass belongs to this wave alone
-    const int T = pPref[WAVE];
-    if (pv && NO > 0) {  // (the multi-agent default observes no neighbour rows: nothing to rank)
-      int rank = 0, nveh = 0;
-      for (int j = 0; j < V; ++j) {
-        const float dj = pDist[pa * V + j];
-        nveh += dj < __builtin_inff() ? 1 : 0;
-        rank += (dj < dk || (dj == dk && j < o)) ? 1 : 0;
+      for (int sh = 1; sh < WAVE; sh <<= 1) {
+        const int up = __shfl_up(inc, sh);
+        if (lane >= sh) inc += up;
       }
-      float* nb = obs + (size_t)e * d.ostride + (size_t)a * D + o_oth;
-      if (dk < __builtin_inff() && rank < NO) {
-        const float ms = aMS[a], sp_me = speed_kmh(bV[a]);
-        float ph, ps;
-        projection(hx, hy, bX[o] - px, bY[o] - py, ph, ps);
-        float* w = nb + rank * 4;
-        w[0] = clipf((ph / R + 1.0f) * 0.5f, 0.0f, 1.0f);
-        w[1] = clipf((ps / R + 1.0f) * 0.5f, 0.0f, 1.0f);
-        projection(hx, hy, spd * bUX[o] - sp_me * hx, spd * bUY[o] - sp_me * hy, ph, ps);
-        w[2] = clipf((ph / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
-        w[3] = clipf((ps / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
-      }
-      for (int r = nveh + o; r < NO; r += V) {  // absent neighbours -> zeros
-        float* w = nb + r * 4;
-        w[0] = w[1] = w[2] = w[3] = 0.0f;
-      }
-    }
-    // lidar (distance_detector.py:65-94, cutils.pyx:60-142): incidence t belongs to the pair p with pPref[p] <= t < pPref[p + 1]
-    for (int t = lane; t < T; t += WAVE) {
-      int p = 0;
+      pPref[lane + 1] = inc;
+      if (lane == 0) pPref[0] = 0;
+      row_sync<true>();
+      const int T = pPref[WAVE];
+      // lidar (distance_detector.py:65-94, cutils.pyx:60-142): incidence t belongs to the pair p with pPref[p] <= t < pPref[p + 1]
+      for (int t = lane; t < T; t += WAVE) {
+        int pl = 0;
 #pragma unroll
-      for (int sh = WAVE / 2; sh > 0; sh >>= 1)
-        if (pPref[p + sh] <= t) p += sh;
-      const int qa = p / V, qo = p - qa * V, ga = g0 + qa;
-      int i = pI0[p] + (t - pPref[p]);
-      i -= i >= NL ? NL : 0;
-      const float ax = bX[ga], ay = bY[ga], ahx = bUX[ga], ahy = bUY[ga];
-      const float2 bd = d.beam[i];  // (cos, sin)(i * 2 pi / NL); rotated by the heading
-      const float dx = R * (bd.x * ahx - bd.y * ahy), dy = R * (bd.y * ahx + bd.x * ahy);
-      const float f = shape_ray<true>(Obb{bX[qo], bY[qo], bUX[qo], bUY[qo], bHL[qo], bHW[qo]}, ax, ay, dx, dy);
-      atomicMin(&s_minb[qa * NL + i], __float_as_uint(f));
+        for (int sh = WAVE / 2; sh > 0; sh >>= 1)
+          if (pPref[pl + sh] <= t) pl += sh;
+        const int ao = pAO[pl], qa = ao >> 8, qo = ao & 0xff, ga = g0 + qa;
+        int i = pI0[pl] + (t - pPref[pl]);
+        i -= i >= NL ? NL : 0;
+        const float ax = bX[ga], ay = bY[ga], ahx = bUX[ga], ahy = bUY[ga];
+        const float2 bd = d.beam[i];  // (cos, sin)(i * 2 pi / NL); rotated by the heading
+        const float dx = R * (bd.x * ahx - bd.y * ahy), dy = R * (bd.y * ahx + bd.x * ahy);
+        const float f = shape_ray<true>(Obb{bX[qo], bY[qo], bUX[qo], bUY[qo], bHL[qo], bHW[qo]}, ax, ay, dx, dy);
+        atomicMin(&s_minb[qa * NL + i], __float_as_uint(f));
+      }
+      row_sync<true>();
     }
-    row_sync<true>();  // the pass belongs to this wave alone
-    for (int k = lane; k < G * NL; k += WAVE) {
+    // neighbour rows (lidar.py:55-77: by centre distance, stable in slot order); the multi-agent default observes none
+    if (NO > 0)
+      for (int pq = lane; pq < P; pq += WAVE) {
+        const int al = pq / V, o = pq - al * V, a = g0 + al;
+        if (!aWant[a]) continue;
+        const float dk = rDist[pq];
+        int rank = 0, nveh = 0;
+        for (int j = 0; j < V; ++j) {
+          const float dj = rDist[al * V + j];
+          nveh += dj < __builtin_inff() ? 1 : 0;
+          rank += (dj < dk || (dj == dk && j < o)) ? 1 : 0;
+        }
+        float* nb = obs + (size_t)e * d.ostride + (size_t)a * D + o_oth;
+        if (dk < __builtin_inff() && rank < NO) {
+          const float px = bX[a], py = bY[a], hx = bUX[a], hy = bUY[a], spd = rSpd[pq];
+          const float ms = aMS[a], sp_me = speed_kmh(bV[a]);
+          float ph, ps;
+          projection(hx, hy, bX[o] - px, bY[o] - py, ph, ps);
+          float* w = nb + rank * 4;
+          w[0] = clipf((ph / R + 1.0f) * 0.5f, 0.0f, 1.0f);
+          w[1] = clipf((ps / R + 1.0f) * 0.5f, 0.0f, 1.0f);
+          projection(hx, hy, spd * bUX[o] - sp_me * hx, spd * bUY[o] - sp_me * hy, ph, ps);
+          w[2] = clipf((ph / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
+          w[3] = clipf((ps / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
+        }
+        for (int r = nveh + o; r < NO; r += V) {  // absent neighbours -> zeros
+          float* w = nb + r * 4;
+          w[0] = w[1] = w[2] = w[3] = 0.0f;
+        }
+      }
+    for (int k = lane; k < (g1 - g0) * NL; k += WAVE) {
       const int qa = k / NL, i = k - qa * NL, ga = g0 + qa;
-      if (ga < A && aWant[ga])
+      if (aWant[ga])
         obs[(size_t)e * d.ostride + (size_t)ga * D + o_oth + 4 * NO + i] = lidar_noise(d, e, ga, tick, i, __uint_as_float(s_minb[k]));
     }
-    row_sync<true>();  // the pass belongs to this wave alone
+    row_sync<true>();
   }
 }
 
