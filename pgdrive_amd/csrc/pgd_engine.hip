@@ -995,7 +995,7 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   if (marl && (cfg->respawn_places < 0 || cfg->respawn_dests < 0)) return PGD_ERR_ARG;
   h->d.sstride = V + (marl ? cfg->respawn_places * cfg->respawn_dests : 0);
   h->d.sub = WAVE / V < 16 ? WAVE / V : 16;  // sub-lanes per vehicle
-  h->d.epw = WAVE / (V * h->d.sub);          // whole environments per wave
+  h->d.epw = marl ? 1 : WAVE / (V * h->d.sub);  // whole environments per wave (the multi-agent tail needs the env alone in its wave)
   if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }
   else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
   HIPCHK(hipEventCreate(&h->ev0));

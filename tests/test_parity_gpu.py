@@ -391,7 +391,7 @@ def test_empty_and_edge_slots(descs):
     assert (obs[:, 0, 34:] == 1.0).all()  # empty scene -> every beam 1.0 (known answer)
 
 
-@pytest.mark.parametrize("num_agents,capacity", [(8, 8), (12, 16), (40, 40)])
+@pytest.mark.parametrize("num_agents,capacity", [(2, 2), (3, 4), (8, 8), (12, 16), (40, 40)])
 def test_marl_roundabout_parity(num_agents, capacity, kind="roundabout", **cfg_kw):
     """BASELINE config 5: multi-agent roundabout (envs/marl_envs/marl_inout_roundabout.py) — per-agent done, delay-done
     queue, respawn into free 8 m x 3 m places, __all__, agent ids; teacher-forced against the oracle."""
