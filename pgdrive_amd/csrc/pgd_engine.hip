@@ -58,7 +58,8 @@ __shared__ long long s_prof_t0, s_prof_w0;
 #define PHASE_INIT()
 #define PHASE_END()
 #define PHASE_END_AT(k)
-#define XMARK(k) do { if (d.dbg_exit == (k)) return; } while (0)
+#define XMARK(k) do { if ((d.dbg_exit & 0xff) == (k)) return; } while (0)
+#define PGD_DBG_SKIP(bit) ((d.dbg_exit >> (8 + (bit))) & 1)  /* timing-only ablations of the IDM policy (tools/idm_ablation.py) */
 #else
 #define PHASE_MARK(k)
 #define PHASE_INIT()
@@ -987,7 +988,7 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->d.NV = h->d.N * V;
   h->d.ostride = h->d.A * h->d.D;
   h->d.prow = nullptr;
-  h->d.dbg_exit = -1;
+  h->d.dbg_exit = 255;  // no exit mark, no ablation bits (exit-profile builds only)
   h->d.unit_off = 0;
   h->n_groups = 1;
   const bool marl = (cfg->marl_flags & PGD_MA_ENABLED) != 0;
@@ -1538,7 +1539,7 @@ int pgd_debug_phase_cycles(pgd_handle h, unsigned long long* out64, int reset) {
 #endif
 
 #ifdef PGD_EXITAT
-int pgd_debug_exit_at(pgd_handle h, int k) { h->d.dbg_exit = k; return PGD_OK; }
+int pgd_debug_exit_at(pgd_handle h, int k) { h->d.dbg_exit = k < 0 ? 255 : k; return PGD_OK; }
 // n back-to-back steps launched from C (the Python call costs ~7 us per step: longer than the early exit points)
 int pgd_debug_step_many(pgd_handle h, const float* a, float* o, float* r, uint8_t* dn, uint32_t* f, int n) {
   for (int k = 0; k < n; ++k) { int rc = pgd_step(h, a, o, r, dn, f); if (rc) return rc; }

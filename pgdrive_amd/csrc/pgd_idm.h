@@ -143,6 +143,9 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
   unsigned long long objs = 0ull;
   // the sub-lanes of the vehicle split the slots (o = sub, sub + SUB, ...) and merge their bit sets: ceil(V / SUB) distance
   // tests per lane whatever the number of bodies in the world
+#ifdef PGD_EXITAT
+  if (!PGD_DBG_SKIP(0))
+#endif
   for (int o = g.sub; o < V; o += g.SUB) {
     const Obb ob = snap_obb(S, base + o);
     const bool in = o != s && S.present[base + o] && shape_point_dist<OBJ>(ob, px, py) <= 50.0f;
@@ -168,8 +171,14 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
   // the routing lane is almost always the old one or the vehicle's lane: its index / lane count are then already here
   const uint2 q_rt = rt == vlane ? q_vl : (rt == rt0 ? q_r0 : lane_quad(mv, rt));
   float own_lon = 0.0f, own_lat = 0.0f, own_head = 0.0f;
+#ifdef PGD_EXITAT
+  if (PGD_DBG_SKIP(1)) { for (int i = 0; i < 3; ++i) { fb.front[i] = fb.back[i] = -1; fb.fd[i] = fb.bd[i] = MAXD; fb.exist[i] = true; } } else
+#endif
   if (search) find_front_back(mv, g, S, base, V, s, objs, rt, q_rt, MAXD, success, fb, own_lon, own_lat, own_head);
   PHASE_MARK(10);  // idm: front/back search
+#ifdef PGD_EXITAT
+  if (PGD_DBG_SKIP(2)) { } else
+#endif
   if (success && in_cur) {
     int idx = quad_index(q_rt);
     int n_cur = CR.n_lanes;
@@ -233,6 +242,9 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
   PHASE_MARK(11);  // idm: lane-change logic
 
   // steering_control (idm_policy.py:244-252)
+#ifdef PGD_EXITAT
+  if (PGD_DBG_SKIP(3)) { out_steer = 0.0f; out_acc = 0.0f; return; }
+#endif
   float lon, lat, lane_heading;
   if (search && steer_lane == rt) {  // the search on the own lane has evaluated exactly this (same routine, same inputs)
     lon = own_lon; lat = own_lat; lane_heading = own_head;
