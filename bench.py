@@ -19,9 +19,10 @@ the timed steps.  --exact turns the floors off.
 
 N > 1.  Environments are independent: the step itself has no exchange.  The north star adds ONE gather of
 (obs, reward, done) per step over xGMI; both are measured in the same invocation: `value` is WITH the per-step gather
-(pgd_step_packed writes the packed row straight into the rank's slice of the receive buffer, one in-place RCCL
-all_gather_into_tensor per step, double-buffered), `value_replicas` is without it (a data-parallel learner that consumes
-its own shard).  --transport peer uses direct peer writes instead of the RCCL collective (pgdrive_amd/peer.py).
+(pgd_step_packed writes the packed row straight into the send buffer, one RCCL gather to rank 0 per step -- the learner's GPU;
+RCCL runs it as seven point-to-point transfers over seven different xGMI links -- double-buffered), `value_replicas` is without it
+(a data-parallel learner that consumes its own shard).  --transport collective gathers to EVERY rank instead
+(all_gather_into_tensor), --transport peer uses direct peer writes over HIP IPC (pgdrive_amd/peer.py).
 """
 import argparse
 import json
@@ -132,8 +133,8 @@ def parse_args(argv=None):
                     help="N>1: time the step with the per-step gather (value), without it (value_replicas), or both")
     ap.add_argument("--gather", action="store_true", help="(old flag) same as --mode gather")
     ap.add_argument("--no-gather", action="store_true", help="(old flag) same as --mode replicas")
-    ap.add_argument("--transport", default="collective", choices=["collective", "peer"],
-                    help="the per-step gather: RCCL all_gather_into_tensor (default) or direct peer writes over HIP IPC")
+    ap.add_argument("--transport", default="root", choices=["root", "collective", "peer"],
+                    help="the per-step gather: RCCL gather to rank 0 (default), RCCL all_gather_into_tensor, or direct peer writes over HIP IPC")
     ap.add_argument("--actions", default="uniform", choices=["uniform", "straight"],
                     help="uniform(-1,1) (the metric's stream) or drive straight [0,1] with small steering noise (SURVEY 8d)")
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"],

@@ -5,6 +5,10 @@ The reference has no distributed layer (one env per process, engine_utils.py:8-1
 env, [A*D obs | A reward | A done].  The engine writes that row itself (pgd_step_packed) straight into this rank's slice of
 the receive buffer, so nothing is packed or copied before the exchange.  Two transports:
 
+  "root"        torch.distributed gather to rank 0 (the learner): what the north star names, "a single RCCL gather of (obs, reward,
+                done) per step".  RCCL runs it as grouped point-to-point transfers: every peer sends its 4.5 MB slice over its own
+                direct xGMI link to GPU 0, the seven transfers run in parallel, nobody receives what it does not need.  The result
+                is valid on rank 0 only.
   "collective"  torch.distributed all_gather_into_tensor, in place (send = own slice of the receive buffer).  Backend "nccl"
                 is RCCL over xGMI on the GPU box; "gloo" serves the CPU / one-GPU plumbing tests (not in place there).
   "peer"        direct peer writes (pgd_gather_* in include/pgdrive_hip.h): every rank maps the receive buffers of its
@@ -81,6 +85,15 @@ class StepGather:
             self.recv = self.peer.recv
             self.send = [r[lo:lo + n_local] for r in self.recv]
             self.inplace = True
+        elif self.transport == "root":
+            self.peer = None
+            self.inplace = False
+            # the full buffer exists on the root only; the root's own rows are produced into a separate send buffer and copied
+            # into their slice by the gather itself (send and receive memory never alias)
+            n_recv = self.world * n_local if self.rank == 0 else n_local
+            self.recv = [torch.empty((n_recv, self.W), dtype=torch.float32, device=device) for _ in range(nbuf)]
+            self.send = [torch.empty((n_local, self.W), dtype=torch.float32, device=device) if self.rank == 0 else r for r in self.recv]
+            self.parts = [[r[q * n_local:(q + 1) * n_local] for q in range(self.world)] if self.rank == 0 else None for r in self.recv]
         else:
             self.peer = None
             self.recv = [torch.empty((self.world * n_local, self.W), dtype=torch.float32, device=device) for _ in range(nbuf)]
@@ -94,6 +107,9 @@ class StepGather:
             return "direct peer writes over HIP IPC (1 push kernel + sequence flags per step, all xGMI links at once)"
         if self.transport == "local":
             return "single rank: rows written in place, no exchange"
+        if self.transport == "root":
+            return "1 %s gather(obs|reward|done) to rank 0 per step (grouped point-to-point: one direct xGMI link per peer)" % (
+                "RCCL" if self.backend == "nccl" else self.backend)
         return "1 %s all_gather_into_tensor(obs|reward|done) per step%s" % (
             "RCCL" if self.backend == "nccl" else self.backend, ", in place" if self.inplace else "")
 
@@ -105,6 +121,8 @@ class StepGather:
         produce(self.send[b])
         if self.transport == "collective":
             self.pending[b] = self.dist.all_gather_into_tensor(self.recv[b], self.send[b], async_op=True)
+        elif self.transport == "root":
+            self.pending[b] = self.dist.gather(self.send[b], gather_list=self.parts[b], dst=0, async_op=True)
         elif self.transport == "peer":
             self.peer.push(b, self.k + 1)
             self.pending[b] = self.k + 1
@@ -126,6 +144,7 @@ class StepGather:
             self.wait(b)
 
     def result(self, b):
+        """(obs, reward, done) of all ranks' envs; with transport "root" on rank 0 only (the other ranks get their own rows)."""
         self.wait(b)
         return unpack(self.recv[b], self.D, self.A)
 

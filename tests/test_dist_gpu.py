@@ -112,7 +112,7 @@ def _run_world(world, n_total, steps, transport, port):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("transport", ["collective", "peer"])
+@pytest.mark.parametrize("transport", ["root", "collective", "peer"])
 def test_two_rank_engine_gather_matches_single_process(transport):
     """Two processes, each with its own engine over half of the envs (sharing the box's one GPU), exchange packed rows every
     step through StepGather -- the code path of `bench.py --gpus 2` -- and rank 0 sees exactly the rows one process
@@ -120,7 +120,7 @@ def test_two_rank_engine_gather_matches_single_process(transport):
     (pgd_config.env_base), so the comparison is bit-exact."""
     n_total, steps = 64, 200
     one = _run_world(1, n_total, steps, "collective", 29711)
-    two = _run_world(2, n_total, steps, transport, 29713 if transport == "collective" else 29715)
+    two = _run_world(2, n_total, steps, transport, dict(root=29717, collective=29713, peer=29715)[transport])
     n_done = 0
     for (o1, r1, d1), (o2, r2, d2) in zip(one, two):
         assert o1.shape == o2.shape == (n_total, 1, 274)
@@ -143,7 +143,7 @@ def test_bench_spawns_its_own_ranks():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 24 and d["steps_timed"] == 24
     assert d["value_mode"] == "gather" and d["value"] == d["value_gather"] and d["value_replicas"] > 0
-    assert d["config"]["global_envs"] == 512 and "all_gather" in d["config"]["parallelism"]
+    assert d["config"]["global_envs"] == 512 and "gather(obs|reward|done) to rank 0" in d["config"]["parallelism"]
     assert d["roofline"]["k_step_ms"] > 0  # measured in the replicas pass
 
 

@@ -9,7 +9,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n_total, q):
+def _worker(rank, world, port, n_total, q, transport="collective"):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -28,7 +28,7 @@ def _worker(rank, world, port, n_total, q):
     o = orc.Oracle(cfg, mb, sb)  # the oracle stands in for the engine: this test is about sharding + the collective
     o.reset(pdist.scenario_ids_for(lo, hi, 4))
     D = _abi.obs_dim(cfg)
-    g = pdist.StepGather(torch, dist, n, D)  # the class bench.py and the GPU world-size-2 test drive with the real engine
+    g = pdist.StepGather(torch, dist, n, D, transport=transport)  # the class bench.py and the GPU world-size-2 test drive with the real engine
     rng = np.random.default_rng(0)
     outs = []
     for t in range(5):
@@ -48,15 +48,16 @@ def _worker(rank, world, port, n_total, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gather_matches_single_process():
+@pytest.mark.parametrize("transport", ["root", "collective"])
+def test_two_rank_gather_matches_single_process(transport):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     n_total = 8
     res = {}
     for world in (1, 2):
         q = ctx.Queue()
-        port = 29611 + world
-        procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+        port = (29611 if transport == "collective" else 29631) + world
+        procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q, transport)) for r in range(world)]
         for p in procs:
             p.start()
         res[world] = q.get(timeout=240)
