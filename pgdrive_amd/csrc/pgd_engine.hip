@@ -129,6 +129,7 @@ template <bool ONE_ENV, bool MARL, bool OBJ, bool STD = false>
 __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
                                                 float* __restrict__ obs) {
+
   __shared__ StepUnion U;
   Snap& S = U.step.S;
   ObsScratch& OU = U.step.OU;  // sub-step poses (contact test), then the observation's compaction scratch
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // them visible to the whole workgroup); the step's LDS is free by now
   if (ONE_ENV && MARL && obs != nullptr) {
     __syncthreads();
-    observe_env_body<1>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
+    observe_env_body<1, false>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
   }
   // several envs per wave (small V) and an observation without a lidar (BASELINE config 2: dynamics + reward + state vector):
   // the row is the state block alone, written by the sub-lanes of the agent that has just been stepped
@@ -861,7 +862,7 @@ template <int NW>
 __global__ __launch_bounds__(WAVE * NW) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags, int G) {
   extern __shared__ unsigned s_minb_dyn[];
   __shared__ ObsEnvLds<NW> M;
-  observe_env_body<NW>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);
+  observe_env_body<NW, true>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1188,13 +1189,14 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
   const int rows = (n_envs > 0 ? n_envs : h->d.N) * h->d.A;
   const bool oth = (h->d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && h->d.cfg.num_others > 0;
   const int envs = n_envs > 0 ? n_envs : h->d.N;
-  if (h->d.A > 1 && !oth && h->d.epw == 1 && !h->row_observe) {  // all rows of an env by one block
+  if (h->d.A > 1 && h->d.epw == 1 && !h->row_observe) {  // all rows of an env by one block
     const int A = h->d.A, V = h->d.V, NL = h->d.cfg.num_lasers;
     const bool four = A >= 4 * (WAVE / V);  // many observers, few per pass: four waves per env, each with its own range
     const int nw = four ? 4 : 1, per_wave = (A + nw - 1) / nw;
     int G = per_wave;  // observers per round of a wave: the whole range if its LDS fits (48 KB per block)
-    while (G > 1 && (size_t)nw * observe_env_words(G, NL, V) * 4 > 49152) --G;
-    const size_t dyn = (size_t)nw * observe_env_words(G, NL, V) * 4;
+    const size_t oth_bytes = (size_t)observe_env_oth_words(A, h->d.cfg.num_others, oth) * 4;
+    while (G > 1 && (size_t)nw * observe_env_words(G, NL, V) * 4 + oth_bytes > 49152) --G;
+    const size_t dyn = (size_t)nw * observe_env_words(G, NL, V) * 4 + oth_bytes;
     if (dyn <= 49152) {
       if (four) hipLaunchKernelGGL(k_observe_env<4>, dim3(envs), dim3(WAVE * 4), dyn, stream, D, d_obs, d_flags, G);
       else hipLaunchKernelGGL(k_observe_env<1>, dim3(envs), dim3(WAVE), dyn, stream, D, d_obs, d_flags, G);

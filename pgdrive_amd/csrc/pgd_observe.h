@@ -321,6 +321,8 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
 // (wave w takes passes w, w + NW, ...; each wave has its own scratch and synchronises with itself only).
 // LDS words one wave needs for rounds of g observers
 DEV_HOST int observe_env_words(int g, int num_lasers, int V) { return g * ((num_lasers > 0 ? num_lasers : 0) + 2 * V); }
+// ... and behind the waves' areas, with PGD_MA_OTHERS_STATE: slot and speed of every observer's ranked neighbours
+DEV_HOST int observe_env_oth_words(int A, int num_others, bool oth) { return oth ? 2 * A * num_others : 0; }
 
 template <int NW>
 struct ObsEnvLds {
@@ -335,7 +337,9 @@ struct ObsEnvLds {
 // `G` observers per round of a wave (as many as the LDS holds, see observe_env_words);
 // `s_minb_all`: per wave G * (num_lasers + 2 V) words of LDS: nearest hit fraction per (observer of the round, beam) as float
 // bits, then centre distance and speed of every pair of the round
-template <int NW>
+// ALLOW_OTH = false compiles the neighbour-state-vector phase (PGD_MA_OTHERS_STATE) out: the copy appended to k_step stays as small
+// as it was (every addition to that kernel costs SGPR spills across the whole step)
+template <int NW, bool ALLOW_OTH = true>
 DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const uint32_t* flags, ObsEnvLds<NW>& M,
                           unsigned* s_minb_all, const int G) {
   float (&bX)[WAVE] = M.bX; float (&bY)[WAVE] = M.bY; float (&bUX)[WAVE] = M.bUX; float (&bUY)[WAVE] = M.bUY;
@@ -395,12 +399,21 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     if ((d.cfg.marl_flags & PGD_MA_TOLLGATE) && st == 0) {  // TollGateObservation.observe (marl_tollgate.py:84-96)
       const int KS = d.cfg.side_lasers, KM = d.cfg.lane_line_lasers, RAM = d.cfg.random_agent_model ? 2 : 0;
       const bool in_toll = ag.blk == '$';
-      float* t2 = row + (KS > 0 ? KS : 2) + 6 + KM + RAM + 4 * NO + NL;
+      const int sl = (KS > 0 ? KS : 2) + 6 + KM + RAM;  // state block of the tollgate row (no navigation floats)
+      const bool oth_s = ALLOW_OTH && (d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && NO > 0;
+      float* t2 = row + sl + (oth_s ? sl : 4) * NO + NL;
       t2[0] = in_toll ? 1.0f : 0.0f;
       t2[1] = (in_toll && ag.toll_time > (float)d.cfg.min_pass_steps) ? 1.0f : 0.0f;
     }
   }
   if (NL <= 0) return;
+  // PGD_MA_OTHERS_STATE (LidarStateObservationMARound): a neighbour row is the neighbour's own state vector; the ranks found by
+  // the pair phase are parked in LDS (slot, speed as the observer sees it) and the vectors are written by a last phase below
+  const bool oth = ALLOW_OTH && (d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && NO > 0;
+  int* nbSlot = reinterpret_cast<int*>(s_minb_all + (size_t)NW * ((size_t)G * NL + 2 * (size_t)G * V));
+  float* nbSpd = reinterpret_cast<float*>(nbSlot + A * NO);
+  if (oth)
+    for (int k = tid; k < A * NO; k += WAVE * NW) nbSlot[k] = -1;
   __syncthreads();
   // ---- pairs.  Every wave owns a contiguous range of observers and works through it in rounds of at most `G` observers (what
   // the LDS for the per-beam minima holds); the (observer, body) pairs of a round are packed into the lanes 64 at a time,
@@ -515,6 +528,10 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
           rank += (dj < dk || (dj == dk && j < o)) ? 1 : 0;
         }
         float* nb = obs + (size_t)e * d.ostride + (size_t)a * D + o_oth;
+        if (oth) {
+          if (dk < __builtin_inff() && rank < NO) { nbSlot[a * NO + rank] = o; nbSpd[a * NO + rank] = rSpd[pq]; }
+          continue;
+        }
         if (dk < __builtin_inff() && rank < NO) {
           const float px = bX[a], py = bY[a], hx = bUX[a], hy = bUY[a], spd = rSpd[pq];
           const float ms = aMS[a], sp_me = speed_kmh(bV[a]);
@@ -535,9 +552,23 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     for (int k = lane; k < (g1 - g0) * NL; k += WAVE) {
       const int qa = k / NL, i = k - qa * NL, ga = g0 + qa;
       if (aWant[ga])
-        obs[(size_t)e * d.ostride + (size_t)ga * D + o_oth + 4 * NO + i] = lidar_noise(d, e, ga, tick, i, __uint_as_float(s_minb[k]));
+        obs[(size_t)e * d.ostride + (size_t)ga * D + o_oth + (oth ? o_oth : 4) * NO + i] = lidar_noise(d, e, ga, tick, i, __uint_as_float(s_minb[k]));
     }
     row_sync<true>();
+  }
+  if (oth) {  // the neighbours' state vectors, every observer at once (the lane groups of the state phase)
+    __syncthreads();
+    if (want)
+      for (int rk = 0; rk < NO; ++rk) {
+        const int o = nbSlot[sa * NO + rk];
+        float* dst = row + o_oth + rk * o_oth;
+        if (o < 0) {
+          for (int k = st; k < o_oth; k += LPA) dst[k] = 0.0f;
+        } else {
+          const AgentView oa = view_of_slot(d, mv, recs, spb, o, nbSpd[sa * NO + rk], e, tick);
+          state_block<false>(d, mv, spb[recs[o].spawn], oa, dst, st, LPA);
+        }
+      }
   }
 }
 

@@ -839,6 +839,8 @@ def test_contacts_inside_the_sub_steps(descs):
     ("roundabout", 40, 40, dict(num_others=2, lidar_gaussian_noise=0.05, lidar_dropout_prob=0.1)),
     ("tollgate", 12, 12, dict(TOLL, num_others=4)),
     ("bottleneck", 20, 20, dict(plain_reward=True, side_lasers=4, side_dist=50.0, lane_line_lasers=4, lane_line_dist=20.0)),
+    ("roundabout", 12, 16, dict(num_others=4, others_state=True)),  # neighbour rows = the neighbours' own state vectors
+    ("intersection", 30, 30, dict(num_others=8, others_state=True)),
 ])
 def test_env_observation_kernel_equals_row_kernel(kind, num_agents, capacity, kw):
     """The multi-agent observation comes from k_observe_env (one wave per env: all agents' state blocks at once, lidar
