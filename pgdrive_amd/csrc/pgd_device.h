@@ -108,27 +108,28 @@ struct __attribute__((aligned(16))) LaneNav {
   float pad;
 };
 
+// The hot tables (lanes, grid cells and their boxes) are carried as pointers; the road table and the per-lane navigation extract
+// are touched once or twice per step and are addressed from the engine view where they are used (`roads()`, `lnav()`): every
+// pointer carried through the whole kernel costs two SGPRs, and k_step spills SGPRs.
 struct MapView {
+  const PgdDev* dv;
   const pgd_map* m;
   const pgd_lane* lanes;
-  const pgd_road* roads;
-  const pgd_box* boxes;
   const int32_t* cstart;
   const LaneExt* cext;
   const pgd_box* cbox;
-  const LaneNav* lnav;
+  DEV const pgd_road* roads() const { return dv->roads + m->road_off; }
+  DEV const LaneNav* lnav() const { return dv->lane_nav + m->lane_off; }
 };
 
 DEV MapView map_view_of(const PgdDev& d, const pgd_map* m) {
   MapView v;
+  v.dv = &d;
   v.m = m;
   v.lanes = d.lanes + m->lane_off;
-  v.roads = d.roads + m->road_off;
-  v.boxes = d.boxes + m->box_off;
   v.cstart = d.cell_start + m->cell_off;
   v.cext = d.cell_ext + m->item_off;
   v.cbox = d.cell_boxes + m->item_off;
-  v.lnav = d.lane_nav + m->lane_off;
   return v;
 }
 DEV MapView map_view(const PgdDev& d, int map) { return map_view_of(d, d.maps + map); }

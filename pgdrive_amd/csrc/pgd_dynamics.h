@@ -106,7 +106,7 @@ DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, c
   if (mflags & PGD_MA_TOLLGATE) {  // MultiAgentTollgateEnv.reward_function (marl_tollgate.py:195-232)
     if (r.blk == '$') {
       // BaseVehicle.overspeed (base_vehicle.py:759-761): lane.speed_limit (3 on toll lanes, 1000 elsewhere) < speed [km/h]
-      const bool lane_toll = mv.roads[mv.lanes[r.lane].road].block_id == '$';
+      const bool lane_toll = mv.roads()[mv.lanes[r.lane].road].block_id == '$';
       if (lane_toll && 3.0f < speed_kmh(r.v)) reward = -g.overspeed_penalty * speed_kmh(r.v) / sp.max_speed;
     } else reward += g.speed_reward * (speed_kmh(r.v) / sp.max_speed);
   } else

@@ -106,11 +106,11 @@ DEV void route_refresh(const MapView& mv, const pgd_spawn& sp, Veh& r) {
   r.road_cur = (uint32_t)rc; r.road_next = (uint32_t)rn;  // -1 (no road) becomes 0xfff, which no map uses (<= 4095 roads)
   r.blk = 0; r.cur_first = 0; r.cur_n = 0; r.next_first = 0; r.next_n = 0;
   if (rc >= 0) {
-    const pgd_road& CR = mv.roads[rc];
+    const pgd_road& CR = mv.roads()[rc];
     r.blk = CR.block_id; r.cur_first = CR.first_lane; r.cur_n = CR.n_lanes;
   }
   if (rn >= 0) {
-    const pgd_road& NR = mv.roads[rn];
+    const pgd_road& NR = mv.roads()[rn];
     r.next_first = NR.first_lane; r.next_n = NR.n_lanes;
   }
 }
@@ -120,7 +120,7 @@ DEV void update_checkpoints(const MapView& mv, const Grp& g, const pgd_spawn& sp
   if (r.ck0 == r.ck1) return;
   if (!(lon < 5.0f)) return;
   int n = sp.n_ckpt;
-  int start_node = mv.roads[mv.lanes[r.lane].road].from;
+  int start_node = mv.roads()[mv.lanes[r.lane].road].from;
   // checkpoints[ck1:].index(start_node) with index < len - 1 (navigation.py:270-277): the first match decides, and a match
   // on the last node alone changes nothing.  The sub-lanes of the vehicle split the tail, four independent reads each per
   // round (a whole route in one round trip), and take the lowest hit.
@@ -308,7 +308,7 @@ DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp&
       float l0, t0;
       lane_local(in_ref ? VL : L0, r.lastx, r.lasty, l0, t0);
       const float l1 = in_ref ? lon_v : lon, t1 = in_ref ? lat_v : lat;
-      ctx.positive = (in_ref || (cfg.marl_flags & PGD_MA_PLAIN_REWARD)) ? 1.0f : (mv.roads[VL.road].negative ? -1.0f : 1.0f);
+      ctx.positive = (in_ref || (cfg.marl_flags & PGD_MA_PLAIN_REWARD)) ? 1.0f : (mv.roads()[VL.road].negative ? -1.0f : 1.0f);
       const float lateral_factor = cfg.use_lateral ? clipf(1.0f - 2.0f * fabsf(t1) / w, 0.0f, 1.0f) : 1.0f;
       ctx.drive = cfg.driving_reward * (l1 - l0) * lateral_factor * ctx.positive;
     }

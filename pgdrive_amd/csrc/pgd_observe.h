@@ -125,7 +125,7 @@ DEV void state_block(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, co
     pgd_lane ml;  // only the heading_diff lane needs the 64-byte lane record
     LaneNav nv;
     if (q == 2) ml = mv.lanes[lid];
-    if (q >= 8) nv = mv.lnav[lid];
+    if (q >= 8) nv = mv.lnav()[lid];
     const float max_speed = sp.max_speed;
     float v = 0.0f;
     int col = -1;
