@@ -125,6 +125,10 @@ union StepUnion {
   } obs;
 };
 
+// A block of k_step is ONE wave: the lanes only have to see each other's LDS traffic in order, which the hardware guarantees for
+// a wave; a workgroup-scope barrier would also wait for every global load and store in flight (release / acquire fences).
+DEV void step_sync() { row_sync<true>(); }
+
 template <bool ONE_ENV, bool MARL, bool OBJ, bool STD = false>
 __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
@@ -198,12 +202,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // (0) AgentManager.before_step (agent_manager.py:191-199): finished agents count down, then leave the world
     if (marl && r.status == ST_DYING && --r.timer == 0) r.status = ST_EMPTY;
   }
-  __syncthreads();
+  step_sync();
   if (valid) {
     // (1) TrafficManager.before_step trigger (traffic_manager.py:76-85)
     if (s < A && r.status == ST_ACTIVE && ng < sc->n_groups && mv.lanes[r.lane].road == sc->trigger_road[ng]) s_flag[el] = 1;
   }
-  __syncthreads();
+  step_sync();
   PHASE_MARK(0);  // load
   XMARK(0);
   const bool trig = ONE_ENV ? (__ballot(s_flag[0] != 0) != 0ull) : (valid && s_flag[el] != 0);
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       }
     }
   }
-  __syncthreads();
+  step_sync();
   PHASE_MARK(1);  // trigger + snapshot
   XMARK(1);
   const bool acting = valid && r.status == ST_ACTIVE;
@@ -276,9 +280,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0, tb, leader ? &SUBP : nullptr, slot, near_env && V <= PGD_SUBV && n_mid_enabled);
     PHASE_MARK(3);  // dynamics
   }
-  __syncthreads();
+  step_sync();
   if (acting && leader) { S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy; }
-  __syncthreads();
+  step_sync();
   // (5) contacts (collision_callback.py:7-36).  The reference's callback runs inside each of the decision_repeat doPhysics
   // calls (engine_core.py:276-278): two bodies are in contact when they overlap after ANY sub-step, not only at the end of
   // the 0.1 s step.  Every body in the world tests itself against each agent of its env (A x V pair tests in parallel lanes):
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       }
       if (OBJ && touched && my_kind != PGD_OBJ_VEHICLE && my_kind != PGD_OBJ_BUILDING) r.vflags |= (int)PGD_F_OBJECT_HIT;  // all sub-lanes
     }
-    __syncthreads();
+    step_sync();
     if (acting && s < A) {
       if (s_hit[slot] & 1) r.vflags |= PGD_F_CRASH_VEHICLE;
       if (OBJ && (s_hit[slot] & 2)) r.vflags |= PGD_F_CRASH_OBJECT;
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_MARK(25);  // after_step: per-vehicle part
   if (one_env && A == 1) {  // line / sidewalk test of the agent by the whole wave (base_vehicle.py:615-644)
     if (leader && valid && s < A) s_flag[A + s] = (acting && !ctx.clear) ? 1 : 0;  // clear: provably no contact (after_step)
-    __syncthreads();
+    step_sync();
     for (int a = 0; a < A; ++a) {
       if (!s_flag[A + a]) continue;
       unsigned fl = state_check_wave(mv, snap_obb(S, a));
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   steps_total += 1;
   // (7) reward / done (base_env.py:303-344)
   s_flag[lane] = 0;
-  __syncthreads();
+  step_sync();
   unsigned my_fl = 0;
   bool fresh = false;  // multi-agent: this lane's slot received a new agent in this step
   bool my_dn = false;
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     const bool toll = (gcf.marl_flags & PGD_MA_TOLLGATE) != 0;
     const bool parking = (gcf.marl_flags & PGD_MA_PARKING) != 0;
     if (parking && lane == 0) s_aux = d.ei[(size_t)e * PGD_NEI + EI_AUX];  // parking_space_available
-    if (parking) __syncthreads();
+    if (parking) step_sync();
     if (valid && s < A && was_active) {
       if (toll && r.blk == '$') r.php += 1.0f;  // TollGateObservation.observe counts its calls inside the toll block
       my_rew = reward_done<true>(d, mv, *sp, r, ctx, my_fl, my_dn);
@@ -414,13 +418,13 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     }
     PHASE_MARK(26);  // marl: reward / done / finish
     // the world after the finishes (leaders publish, everybody reads)
-    __syncthreads();
+    step_sync();
     if (valid && leader) {
       S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
       S.hl[slot] = 0.5f * sp->length; S.hw[slot] = 0.5f * sp->width;
       S.present[slot] = (r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING) ? 1 : 0;
     }
-    __syncthreads();
+    step_sync();
     const bool is_lead_agent = valid && leader && s < A;
     int alive = __popcll(__ballot(is_lead_agent && (r.status == ST_ACTIVE || r.status == ST_DYING)));
     int next_agent = d.ei[(size_t)e * PGD_NEI + EI_NEXT_AGENT];
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
           dest = 0;
           for (int b = 0; b < 32; ++b)
             if (mask & (1u << b)) { if (pick-- == 0) { dest = b; break; } }
-          __syncthreads();  // everybody has read the pool before lane 0 takes the space out
+          step_sync();  // everybody has read the pool before lane 0 takes the space out
           if (lane == 0) s_aux &= ~(1 << dest);
         }
         if (valid && s == tslot) {
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
           }
         }
         next_agent += 1;
-        __syncthreads();
+        step_sync();
       }
     }
     if (fresh) route_refresh(mv, *sp, r);  // the toll bookkeeping below reads the new agent's block id
@@ -490,11 +494,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     }
     if (lane == 0) d.ei[(size_t)e * PGD_NEI + EI_NEXT_AGENT] = next_agent;
     if (parking) {
-      __syncthreads();
+      step_sync();
       if (lane == 0) d.ei[(size_t)e * PGD_NEI + EI_AUX] = s_aux;
     }
   }
-  __syncthreads();
+  step_sync();
   PHASE_MARK(6);  // reward/done
   XMARK(6);
   // (8) auto reset (base_env.py:269-301): the whole env restarts from its (possibly re-drawn) scenario
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // (9) observation of the new state, fused: the wave already holds every vehicle of the env (obs/state_obs.py:132-170)
   bool near_next = true;  // EI_NEAR of the next step: only the fused observation can clear it
   if (ONE_ENV && !MARL && obs != nullptr) {  // host passes obs only when one_env && !marl && A <= FUSE_MAX_AGENTS
-    __syncthreads();
+    step_sync();
     if (valid && leader) {
       const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
       S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         ag.env = e; ag.slot = s; ag.tick = steps_total;
       }
     }
-    __syncthreads();
+    step_sync();
     // only launched with one env per wave: `scen` / `mv` are wave-uniform and already those of the new episode after a reset
     const int scen_now = scen;
     const MapView& mvo = mv;
@@ -603,11 +607,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
                   S.ux[lane], S.uy[lane], S.hl[lane], S.hw[lane], S.spd[lane], ag.x, ag.y, d.cfg.lidar_dist, ag.hx, ag.hy,
                   d.cfg.num_lasers, S.hl[a] + S.hw[a] + (fabsf(ag.v) + 1.0f) * 0.105f, &near_a);
       near_any = near_any || near_a;
-      __syncthreads();
+      step_sync();
       PHASE_MARK(21);  // obs: compaction
       observe_agent<OBJ, STD>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + (size_t)e * d.ostride + (size_t)a * d.D, lane,
                     WAVE);
-      __syncthreads();
+      step_sync();
     }
     // hint for the next step's contact tests (EI_NEAR); without a lidar the compaction looked at nothing: always test
     near_next = d.cfg.num_lasers > 0 ? (__ballot(near_any) != 0ull) : true;
