@@ -118,8 +118,9 @@ struct MapView {
   const int32_t* cstart;
   const LaneExt* cext;
   const pgd_box* cbox;
-  DEV const pgd_road* roads() const { return dv->roads + m->road_off; }
-  DEV const LaneNav* lnav() const { return dv->lane_nav + m->lane_off; }
+  int road_off, lane_off;  // (two SGPRs instead of four: the bases come from the kernel arguments at the point of use)
+  DEV const pgd_road* roads() const { return dv->roads + road_off; }
+  DEV const LaneNav* lnav() const { return dv->lane_nav + lane_off; }
 };
 
 DEV MapView map_view_of(const PgdDev& d, const pgd_map* m) {
@@ -127,6 +128,7 @@ DEV MapView map_view_of(const PgdDev& d, const pgd_map* m) {
   v.dv = &d;
   v.m = m;
   v.lanes = d.lanes + m->lane_off;
+  v.road_off = m->road_off; v.lane_off = m->lane_off;
   v.cstart = d.cell_start + m->cell_off;
   v.cext = d.cell_ext + m->item_off;
   v.cbox = d.cell_boxes + m->item_off;
