@@ -277,6 +277,16 @@ int pgd_step_group(pgd_handle h, int group, const float* d_actions /*[N,A,2]*/, 
 int pgd_group_stream(pgd_handle h, int group, void** hip_stream);
 int pgd_group_sync(pgd_handle h, int group);
 
+/* Scripted lane-keeping policy for the controlled agent of a single-agent engine -- what the reference's examples use their
+ * trained PPO expert for (examples/ppo_expert, tests/test_functionality/test_expert_performance.py): an action stream that
+ * keeps the ego DRIVING, for benchmarks and soak runs.  One launch on the engine stream; reads the rows pgd_step wrote
+ * (default state layout, side_lasers == 0: [0] [1] distances to the left / right road edge, [2] heading alignment, [3] speed):
+ *   steering = clip(k_lat * 18 * (o[0] - o[1]) / 10 + k_head * (2 o[2] - 1) + noise * n1, -1, 1)
+ *   throttle = clip(0.3 * (v_target_kmh - v_kmh) + noise * n2, -1, 1)      n1, n2 ~ U(-1, 1) from the counter RNG (seed, env, tick)
+ * d_actions [N, 1, 2] is then handed to pgd_step.  Not part of the reference's env.step: a convenience of this library. */
+int pgd_lane_keep_actions(pgd_handle h, const float* d_obs /*[N,1,D]*/, float* d_actions /*[N,1,2]*/, float k_lat, float k_head,
+                          float v_target_kmh, float noise, uint32_t tick);
+
 /* Checkpoint / resume (BaseVehicle.get_state/set_state, base_vehicle.py:683-698): raw SoA state blobs.
  * Layout: nf float fields then ni int fields, each [N*V]; query sizes with pgd_state_dims. HOST buffers. */
 int pgd_state_dims(pgd_handle h, int* n_float_fields, int* n_int_fields, int* n_env_int_fields);

@@ -869,7 +869,107 @@ def gen_maround(maps):
           sum(1 for c in cases for r in c["rows"] if r["n_detected"] > NO), "with more than num_others neighbours")
 
 
+def gen_stepinfo():
+    """BaseVehicle.before_step (base_vehicle.py:238-253: last pose, action deque, _set_action / _set_incremental_action /
+    _apply_throttle_brake, :343-376) and _update_energy_consumption + the step-info floats of after_step (:255-290), run by
+    the reference's own methods on a duck-typed vehicle whose Bullet `system` only records what it is handed.
+    Own rng, own file (tests/golden/stepinfo_v0.json)."""
+    from collections import deque
+    rng = np.random.default_rng(20260928)
+
+    class Recorder:
+        def __init__(self):
+            self.steer, self.force, self.brake = {}, {}, {}
+
+        def setSteeringValue(self, v, i):
+            self.steer[i] = float(v)
+
+        def applyEngineForce(self, v, i):
+            self.force[i] = float(v)
+
+        def setBrake(self, v, i):
+            self.brake[i] = float(v)
+
+    class V(FakeVehicle):
+        STEERING_INCREMENT = BaseVehicle.STEERING_INCREMENT
+        before_step = BaseVehicle.before_step
+        _init_step_info = BaseVehicle._init_step_info
+        init_state_info = BaseVehicle.init_state_info
+        _preprocess_action = BaseVehicle._preprocess_action
+        _set_action = BaseVehicle._set_action
+        _set_incremental_action = BaseVehicle._set_incremental_action
+        _apply_throttle_brake = BaseVehicle._apply_throttle_brake
+        _update_energy_consumption = BaseVehicle._update_energy_consumption
+
+    before = []
+    for k in range(64):
+        x, y, th = rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(-math.pi, math.pi)
+        speed = float(rng.choice([0.0, rng.uniform(0, 79), rng.uniform(80, 120)]))
+        v = V(x, y, th, speed, 4.51, 1.852, max_speed=80.0)
+        v.config = dict(action_check=False, max_engine_force=float(rng.uniform(750, 850)), max_brake_force=float(rng.uniform(80, 180)))
+        v.max_steering = float(rng.choice([40.0, 50.0, 35.0]))
+        v.enable_reverse = bool(k % 8 == 7)
+        v.increment_steering = bool(k % 3 == 2)
+        v.steering = float(rng.uniform(-1, 1))
+        v.system = Recorder()
+        prev = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)))
+        v.last_current_action = deque([(0.0, 0.0), prev], maxlen=2)
+        v.last_position = Vector((x - 1.0, y + 2.0))
+        v.last_heading_dir = Vector((1.0, 0.0))
+        action = (float(rng.uniform(-1, 1)), float(rng.choice([rng.uniform(-1, 1), 0.0, 1.0, -1.0])))
+        steering0 = v.steering
+        info = V.before_step(v, action)
+        before.append(dict(
+            x=x, y=y, theta=th, speed_kmh=speed, max_speed=80.0, max_engine_force=v.config["max_engine_force"],
+            max_brake_force=v.config["max_brake_force"], max_steering_deg=v.max_steering, enable_reverse=v.enable_reverse,
+            increment_steering=v.increment_steering, steering0=steering0, prev_action=list(prev), action=list(action),
+            raw_action=list(info["raw_action"]), steering=float(v.steering), throttle_brake=float(v.throttle_brake),
+            last_position=[float(v.last_position[0]), float(v.last_position[1])],
+            last_heading_dir=[float(v.last_heading_dir[0]), float(v.last_heading_dir[1])],
+            deque=[list(a) for a in v.last_current_action],
+            steer_value_deg=[v.system.steer[0], v.system.steer[1]],
+            engine_force=[v.system.force[i] for i in range(4)], brake=[v.system.brake[i] for i in range(4)]))
+
+    energy = []
+    for k in range(64):
+        x, y = rng.uniform(-200, 200), rng.uniform(-200, 200)
+        speed = float(rng.uniform(0, 120)) if k % 5 else 0.0
+        d = rng.uniform(0, 3.5)
+        a = rng.uniform(-math.pi, math.pi)
+        v = V(x, y, 0.0, speed, 4.51, 1.852)
+        v.last_position = Vector((x - d * math.cos(a), y - d * math.sin(a)))
+        v.energy_consumption = float(rng.uniform(0, 30)) if k % 2 else 0.0
+        e0 = v.energy_consumption
+        step, total = V._update_energy_consumption(v)
+        energy.append(dict(pos=[x, y], last=[float(v.last_position[0]), float(v.last_position[1])], speed_kmh=speed, e0=e0,
+                           step_energy=float(step), episode_energy=float(total)))
+
+    # a trajectory: the running sum over 200 steps of a car that accelerates, cruises and brakes
+    v = V(0.0, 0.0, 0.3, 0.0, 4.51, 1.852)
+    v.energy_consumption = 0
+    traj = []
+    for t in range(200):
+        acc = 2.0 if t < 80 else (0.0 if t < 150 else -4.0)
+        v.last_position = v.position
+        v.speed = max(0.0, v.speed + acc * 0.1 * 3.6)
+        ds = v.speed / 3.6 * 0.1
+        v.heading_theta += 0.002 * t * 0.1
+        v.position = Vector((v.position[0] + ds * math.cos(v.heading_theta), v.position[1] + ds * math.sin(v.heading_theta)))
+        step, total = V._update_energy_consumption(v)
+        # the step-info floats of after_step (base_vehicle.py:262-270)
+        traj.append(dict(pos=[float(v.position[0]), float(v.position[1])], speed_kmh=float(v.speed), step_energy=float(step),
+                         episode_energy=float(total), velocity=float(v.speed), steering=float(v.steering),
+                         acceleration=float(v.throttle_brake)))
+    gd = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(gd, "stepinfo_v0.json"), "w") as f:
+        json.dump(dict(before_step=before, energy=energy, trajectory=traj), f)
+    print("stepinfo golden:", len(before), "before_step,", len(energy), "energy samples,", len(traj), "trajectory steps")
+
+
 def main():
+    if "--stepinfo-only" in sys.argv:
+        gen_stepinfo()
+        return
     if "--random-lane-only" in sys.argv:
         gen_random_lane()
         return
@@ -886,6 +986,7 @@ def main():
     gen_objects()
     gen_random_lane()
     gen_maround(maps)
+    gen_stepinfo()
     if "--detectors-only" in sys.argv or "--side-files-only" in sys.argv:
         return
     gen_scalar(rng, out)

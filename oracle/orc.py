@@ -45,6 +45,10 @@ def lib():
         L.orc_obb_overlap.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_bicycle.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_idm_acc.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_energy_step.restype = C.c_double
+        L.orc_energy_step.argtypes = [C.c_double] * 3
+        L.orc_action_forces.argtypes = [C.c_double] * 5 + [C.c_int, C.c_void_p]
+        L.orc_before_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
         L.orc_navi_info.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_heading_diff.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_localize.argtypes = [C.c_void_p, C.c_int, C.c_int]

@@ -869,6 +869,20 @@ __global__ __launch_bounds__(WAVE * NW) void k_observe_env(PgdDev d, float* __re
   observe_env_body<NW, true>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);
 }
 
+// scripted lane-keeping policy (pgd_lane_keep_actions): one thread per env
+__global__ __launch_bounds__(256) void k_lane_keep(PgdDev d, const float* __restrict__ obs, float* __restrict__ act, float k_lat,
+                                                  float k_head, float v_target, float noise, uint32_t tick) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.N) return;
+  const float* o = obs + (size_t)e * d.D;
+  const float o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3];
+  const uint32_t r = pgd_rng(d.cfg.seed ^ 0x1a7e5eedu, (uint32_t)(d.cfg.env_base + e), 0x900dcafeu, tick);
+  const float n1 = (float)(r & 0xffffu) * (2.0f / 65535.0f) - 1.0f, n2 = (float)(r >> 16) * (2.0f / 65535.0f) - 1.0f;
+  const float v_kmh = o3 * 81.0f - 1.0f;  // state_obs.py:82: (speed + 1) / (max_speed + 1), max_speed 80 km/h
+  act[(size_t)e * 2 + 0] = clipf(k_lat * 1.8f * (o0 - o1) + k_head * (2.0f * o2 - 1.0f) + noise * n1, -1.0f, 1.0f);
+  act[(size_t)e * 2 + 1] = clipf(0.3f * (v_target - v_kmh) + noise * n2, -1.0f, 1.0f);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1376,6 +1390,17 @@ int pgd_group_stream(pgd_handle h, int group, void** hip_stream) {
 int pgd_group_sync(pgd_handle h, int group) {
   if (!h || group < 0 || group >= h->n_groups || !h->gstreams) return PGD_ERR_ARG;
   HIPCHK(hipStreamSynchronize(h->gstreams[group]));
+  return PGD_OK;
+}
+
+int pgd_lane_keep_actions(pgd_handle h, const float* d_obs, float* d_actions, float k_lat, float k_head, float v_target_kmh,
+                          float noise, uint32_t tick) {
+  if (!h || !d_obs || !d_actions) return PGD_ERR_ARG;
+  if (h->d.A != 1 || h->d.cfg.side_lasers != 0 || h->d.D < 4) return PGD_ERR_STATE;  // reads columns 0..3 of the default layout
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_lane_keep, dim3((h->d.N + 255) / 256), dim3(256), 0, h->stream, h->d, d_obs, d_actions, k_lat, k_head,
+                     v_target_kmh, noise, tick);
+  HIPCHK(hipGetLastError());
   return PGD_OK;
 }
 

@@ -26,6 +26,7 @@ _SIGS = {
     "pgd_get_state": (C.c_int, [C.c_void_p] * 4),
     "pgd_set_state": (C.c_int, [C.c_void_p] * 4),
     "pgd_observe": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pgd_lane_keep_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32]),
     "pgd_topdown_channels": (C.c_int, [C.POINTER(_abi.TopDownConfig)]),
     "pgd_topdown_enable": (C.c_int, [C.c_void_p, C.POINTER(_abi.TopDownConfig)]),
     "pgd_observe_topdown": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -208,6 +209,19 @@ class Engine:
         _chk(self.L.pgd_step_n(self.h, C.c_void_p(action_ring.data_ptr()), int(action_ring.shape[0]), int(first), int(n_steps), p_obs,
                                C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(flags.data_ptr())), "pgd_step_n")
         return (self.obs if want_obs else None), rew, done, flags
+
+    def lane_keep_actions(self, out, tick, obs=None, k_lat=1.0, k_head=2.0, v_target_kmh=30.0, noise=0.05):
+        """Scripted lane-keeping actions for the ego from the last observation (pgd_lane_keep_actions): an action stream that
+        keeps the ego driving (bench.py --actions expert).  `out` = float32 cuda tensor [N, 1, 2]."""
+        assert out.is_cuda and out.dtype == self.torch.float32 and out.is_contiguous() and out.numel() == self.N * 2
+        cur = self.torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self._bound_stream:
+            _chk(self.L.pgd_set_stream(self.h, C.c_void_p(cur)), "pgd_set_stream")
+            self._bound_stream = cur
+        o = self.obs if obs is None else obs
+        _chk(self.L.pgd_lane_keep_actions(self.h, C.c_void_p(o.data_ptr()), C.c_void_p(out.data_ptr()), k_lat, k_head,
+                                          v_target_kmh, noise, int(tick) & 0xffffffff), "pgd_lane_keep_actions")
+        return out
 
     # -- top-down observation (obs/top_down_obs_multi_channel.py) -----------------------------------------------------------
     def enable_topdown(self, td_cfg=None):

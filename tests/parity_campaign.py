@@ -18,7 +18,7 @@ for mode, steps in (("driving", 1500), ("uniform", 600), ("straight", 900)):
     assert np.abs(g0-o0).max()<OBS_TOL
     rng=np.random.default_rng(17)
     st=dict(steps=0,flag_mismatch=0,obs=0.0,rew=0.0,pose=0.0,beams=0,grazing=0,int_mismatch=0,done=0,active_traffic=0)
-    t0=time.time()
+    t0=time.time(); worst={}
     for t in range(steps):
         if mode=="driving": act=util.driving_actions(rng,n_envs)
         elif mode=="uniform": act=rng.uniform(-1,1,size=(n_envs,1,2)).astype(np.float32)
@@ -52,7 +52,9 @@ for mode, steps in (("driving", 1500), ("uniform", 600), ("straight", 900)):
             dd=np.abs(gf[_abi.SF[fld]].astype(np.float64)-f[_abi.SF[fld]])[agree&~tie]
             if fld=="THETA": dd=np.minimum(dd,np.abs(dd-2*np.pi))
             st["pose"]=max(st["pose"],float(dd.max()))
+        util.compare_state(gf,f,agree&~tie,worst)  # all 26 float fields (tests/util.py STATE_TOL), in units of their tolerance
         f32=util.round_state_f32(f); ora.set_state(f32,i,ei); eng.set_state(f32,i,ei)
+    st["state_fields_x_tol"]={k:round(v,3) for k,v in worst.items()}
     st["mode"]=mode; st["seconds"]=round(time.time()-t0,1)
     print(json.dumps(st)); out.append(st); eng.close()
 open('gpurun_out/campaign.json','w').write(json.dumps(out,indent=1))

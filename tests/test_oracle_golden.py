@@ -93,6 +93,66 @@ def test_bicycle(L, gold):
             assert np.abs(np.array(s[:]) - traj[t + 1]).max() < 1e-9
 
 
+def test_before_step_and_energy(L, descs):
+    """BaseVehicle.before_step / _set_action / _set_incremental_action / _apply_throttle_brake (base_vehicle.py:238-253,
+    343-376) and _update_energy_consumption + the step-info floats of after_step (:255-290): the reference's own methods on
+    a recording `system` (tests/golden/stepinfo_v0.json, oracle/gen_golden.py::gen_stepinfo) against the oracle's
+    before_step_vehicle, action_forces (what `dynamics` applies) and energy_step (what after_step_vehicle accumulates)."""
+    from oracle import orc
+    with open(os.path.join(GOLD, "stepinfo_v0.json")) as f:
+        g = json.load(f)
+    SF = _abi.SF
+    d = descs[0]
+    mb = mapdata.MapBank([d])
+    sb = scenario.ScenarioBank([d], [d["seed"]], num_agents=1, num_traffic=0)
+    o = orc.Oracle(_abi.make_config(1, num_agents=1, num_traffic=0, num_lasers=0), mb, sb)
+    o.reset(np.zeros(1, dtype=np.int32))
+    out2 = (C.c_double * 2)()
+    for c in g["before_step"]:
+        f, i, ei = o.get_state()
+        f[SF["X"], 0, 0], f[SF["Y"], 0, 0], f[SF["THETA"], 0, 0] = c["x"], c["y"], c["theta"]
+        f[SF["SPEED"], 0, 0] = c["speed_kmh"] / 3.6
+        f[SF["STEER"], 0, 0] = c["steering0"]
+        f[SF["ACT1S"], 0, 0], f[SF["ACT1T"], 0, 0] = c["prev_action"]
+        o.set_state(f, i, ei)
+        L.orc_before_step(o.h, 0, 0, c["action"][0], c["action"][1], int(c["increment_steering"]))
+        f, i, ei = o.get_state()
+        got = lambda k: f[SF[k], 0, 0]  # noqa: E731
+        assert abs(got("STEER") - c["steering"]) < 1e-12 and abs(got("THROTTLE") - c["throttle_brake"]) < 1e-12
+        assert [got("LASTX"), got("LASTY")] == pytest.approx(c["last_position"], abs=1e-12)
+        assert [got("LASTHX"), got("LASTHY")] == pytest.approx(c["last_heading_dir"], abs=1e-12)
+        assert [[got("ACT0S"), got("ACT0T")], [got("ACT1S"), got("ACT1T")]] == c["deque"]
+        assert c["raw_action"] == c["action"]
+        # what Bullet's raycast vehicle is handed: the steering angle on both front wheels, engine force and brake on all four
+        assert c["steer_value_deg"][0] == c["steer_value_deg"][1] == pytest.approx(c["steering"] * c["max_steering_deg"], abs=1e-12)
+        L.orc_action_forces(c["max_engine_force"], c["max_brake_force"], c["max_speed"], c["speed_kmh"] / 3.6,
+                            c["throttle_brake"], int(c["enable_reverse"]), out2)
+        assert all(abs(v - out2[0]) < 1e-9 for v in c["engine_force"]) and all(abs(v - out2[1]) < 1e-9 for v in c["brake"])
+    for c in g["energy"]:
+        step = L.orc_energy_step(c["speed_kmh"], c["last"][0] - c["pos"][0], c["last"][1] - c["pos"][1])
+        assert abs(step - c["step_energy"]) < 1e-12 * max(1.0, c["step_energy"])
+        assert abs(c["e0"] + step - c["episode_energy"]) < 1e-9
+    # the running sum over a trajectory, through the oracle's real after_step (orc_refresh = engine.after_step on a state):
+    # the golden displacement and speed of every step placed at the spawn point of a real map
+    f0, i0, ei0 = o.get_state()
+    x0, y0 = f0[SF["X"], 0, 0], f0[SF["Y"], 0, 0]
+    total, last = 0.0, (0.0, 0.0)
+    for c in g["trajectory"]:
+        f, i, ei = o.get_state()
+        f[SF["X"], 0, 0], f[SF["Y"], 0, 0] = x0, y0
+        f[SF["LASTX"], 0, 0], f[SF["LASTY"], 0, 0] = x0 - (c["pos"][0] - last[0]), y0 - (c["pos"][1] - last[1])
+        f[SF["SPEED"], 0, 0] = c["speed_kmh"] / 3.6
+        f[SF["ENERGY"], 0, 0] = total
+        o.set_state(f, i, ei)
+        o.refresh()
+        f, i, ei = o.get_state()
+        assert abs(f[SF["ENERGY"], 0, 0] - total - c["step_energy"]) < 1e-9
+        total = f[SF["ENERGY"], 0, 0]
+        last = c["pos"]
+        assert abs(total - c["episode_energy"]) < 1e-7 and c["velocity"] == c["speed_kmh"]
+    o.close()
+
+
 def test_ray_box_known_answers(L):
     """SURVEY §8c known answers: empty -> 1.0; a box straight ahead at distance d -> (d - L_other/2)/50 on beam 0."""
     f = L.orc_ray_box(20.0, 0.0, 0.0, 2.25, 0.9, 0.0, 0.0, 50.0, 0.0)

@@ -102,23 +102,35 @@ def test_teacher_forced_parity(descs, num_traffic, num_lasers):
     rng = np.random.default_rng(0)
     stats = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
     pose = 0.0
+    worst = {}  # every float field of the state, in units of its tolerance (tests/util.py STATE_TOL)
+    idm_ties = active = 0
     for t in range(400):
         act = util.driving_actions(rng, n_envs)
         _compare_step(torch, eng, ora, act, stats)
         f, i, ei = ora.get_state()
         gf, gi, gei = eng.get_state()
         agree = (gi == i).all(axis=0) & (gei == ei).all(axis=0)[:, None]
+        # an IDM leader exactly MAX_DIST = 30 m ahead on the 10 m spawn grid is found / not found by the last bit of a lane
+        # coordinate: that vehicle gets another throttle on the two sides (counted and bounded, as in the campaign)
+        tie = np.abs(gf[_abi.SF["ACT1T"]].astype(np.float64) - f[_abi.SF["ACT1T"]]) > 1e-3
+        tie[:, :cfg.num_agents] = False
+        idm_ties += int((tie & agree).sum())
+        active += int((i[_abi.SI["STATUS"]][:, cfg.num_agents:] == _abi.ST_ACTIVE).sum())
         if agree.any():
             for fld in ("X", "Y", "THETA", "SPEED"):
-                dlt = np.abs(gf[_abi.SF[fld]].astype(np.float64) - f[_abi.SF[fld]])[agree]
+                dlt = np.abs(gf[_abi.SF[fld]].astype(np.float64) - f[_abi.SF[fld]])[agree & ~tie]
                 if fld == "THETA":  # heading_theta lives in [-3 pi / 2, pi / 2): a value on the seam may wrap on one side only
                     dlt = np.minimum(dlt, np.abs(dlt - 2 * np.pi))
                 pose = max(pose, float(dlt.max()))
+        util.compare_state(gf, f, agree & ~tie, worst)
         f32 = util.round_state_f32(f)
         ora.set_state(f32, i, ei)
         eng.set_state(f32, i, ei)
-    print("teacher-forced parity:", stats, "pose", pose)
+    print("teacher-forced parity:", stats, "pose", pose, "idm ties", idm_ties, "of", active,
+          "state fields (x tolerance):", {k: round(v, 3) for k, v in worst.items()})
     assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and pose < 1e-3
+    assert not util.state_failures(worst), util.state_failures(worst)
+    assert idm_ties <= 2e-3 * max(active, 1) + 2
     assert stats["flag_mismatch"] == 0  # done / flags bit-exact (north star); no tie class occurs on these 8 maps
     assert stats.get("grazing", 0) <= 1e-5 * stats.get("beams", 1) + 2
 
@@ -372,6 +384,70 @@ def test_free_running_rollout(descs):
     assert worst < 5e-4
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("num_traffic,num_lasers", [(0, 0), (16, 240)])
+def test_free_running_1000_steps(descs, num_traffic, num_lasers):
+    """pose after 1000 steps with identical actions, NO teacher forcing -- the fp32 engine integrates its own
+    state (heading vector advanced by rotations and renormalised, PID sums, own-lane coordinates carried in the record) for
+    1000 steps next to the fp64 oracle.  auto_reset = 0; the actions come from a lane-keeping controller on the ORACLE's
+    observation (road-centre offset + heading error -> steering, 5-9 km/h cruise -> throttle, seeded noise and a per-env
+    lateral target), the same float32 action for both sides, slow enough that no episode ends on these maps.
+    An env counts until its first discrete disagreement: a flag / done / integer-state difference, or an IDM leader exactly
+    on the 30 m search range (the enumerated tie class of the campaigns; such a vehicle gets another throttle on the two
+    sides and the env's traffic then evolves differently).  Bars: positions <= 1e-2 m, headings <= 1e-3 rad on every slot of
+    every env that still agrees; >= 97 % of the envs agree to the end without traffic (with traffic the 30 m ties thin the
+    set out: the fraction is printed and bounded below)."""
+    n_envs = 64
+    torch, eng, ora, cfg = _engines(descs, n_envs, num_traffic=num_traffic, num_lasers=num_lasers, auto_reset=0)
+    scen_ids = np.arange(n_envs) % 8
+    obs = ora.reset(scen_ids)
+    eng.reset(scen_ids)
+    rng = np.random.default_rng(3)
+    v_target = rng.uniform(5.0, 9.0, size=n_envs)
+    lat_target = rng.uniform(-2.5, 2.5, size=n_envs)
+    alive = np.ones(n_envs, dtype=bool)
+    pos_err = th_err = spd_err = 0.0
+    ties = n_done = moved = 0
+    SF, SI = _abi.SF, _abi.SI
+    for t in range(1000):
+        ob = obs[:, 0]
+        lat = (ob[:, 0] - ob[:, 1]) * 18.0 - 2.0 * lat_target      # left minus right road-edge distance [m]
+        head = (ob[:, 2] - 0.5) * 2.0
+        steer = np.clip(0.1 * lat + 2.0 * head + rng.normal(0, 0.05, size=n_envs), -1, 1)
+        thr = np.clip(0.3 * (v_target - (ob[:, 3] * 81.0 - 1.0)) + rng.normal(0, 0.1, size=n_envs), -1, 1)
+        act = np.stack([steer, thr], axis=-1).astype(np.float32)[:, None, :]
+        obs, o_rew, o_done, o_flags = ora.step(act)
+        g_obs, g_rew, g_done, g_flags = eng.step(torch.from_numpy(act).to(eng.device))
+        eng.sync()
+        n_done += int(o_done.sum())
+        same = (g_flags.cpu().numpy().astype(np.uint32) == o_flags)[:, 0] & (g_done.cpu().numpy() == o_done)[:, 0]
+        f, i, ei = ora.get_state()
+        gf, gi, gei = eng.get_state()
+        ints = (gi == i).all(axis=(0, 2)) & (gei == ei).all(axis=0)
+        tie = np.abs(gf[SF["ACT1T"]].astype(np.float64) - f[SF["ACT1T"]])[:, cfg.num_agents:] > 1e-3
+        tie &= (i[SI["STATUS"]][:, cfg.num_agents:] == _abi.ST_ACTIVE)
+        ties += int((tie.any(axis=1) & alive).sum())
+        alive &= same & ints & ~tie.any(axis=1)
+        if alive.any():
+            dx = gf[SF["X"]].astype(np.float64)[alive] - f[SF["X"]][alive]
+            dy = gf[SF["Y"]].astype(np.float64)[alive] - f[SF["Y"]][alive]
+            dth = np.abs(gf[SF["THETA"]].astype(np.float64)[alive] - f[SF["THETA"]][alive])
+            dth = np.minimum(dth, np.abs(dth - 2 * np.pi))
+            pos_err = max(pos_err, float(np.hypot(dx, dy).max()))
+            th_err = max(th_err, float(dth.max()))
+            spd_err = max(spd_err, float(np.abs(gf[SF["SPEED"]].astype(np.float64)[alive] - f[SF["SPEED"]][alive]).max()))
+    f, i, ei = ora.get_state()
+    moved = float(np.hypot(f[SF["X"]][:, 0] - ora.scen_bank.spawns.reshape(-1, cfg.num_agents + cfg.num_traffic)["x"][scen_ids, 0],
+                           f[SF["Y"]][:, 0] - ora.scen_bank.spawns.reshape(-1, cfg.num_agents + cfg.num_traffic)["y"][scen_ids, 0]).mean())
+    active = int((i[SI["STATUS"]][:, cfg.num_agents:] == _abi.ST_ACTIVE).sum())
+    print("free-running 1000 steps, traffic %d: %d of %d envs agree to the end (first disagreements by a 30 m IDM tie: %d), "
+          "pose error %.2e m / %.2e rad, speed %.2e m/s; episodes ended %d, ego displacement %.0f m, traffic driving at the end %d"
+          % (num_traffic, int(alive.sum()), n_envs, ties, pos_err, th_err, spd_err, n_done, moved, active))
+    assert pos_err <= 1e-2 and th_err <= 1e-3
+    assert n_done == 0 and moved > 60.0
+    assert alive.mean() >= (0.97 if num_traffic == 0 else 0.5)
+
+
 def test_empty_and_edge_slots(descs):
     """Scenario with zero traffic slots used (density 0) and a NaN action: obs stay finite and in [0,1]."""
     n_envs = 16
@@ -411,6 +487,7 @@ def test_marl_roundabout_parity(num_agents, capacity, kind="roundabout", **cfg_k
     A = sb.A
     stats = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
     seen = dict(new=0, dying=0, all_done=0, report=0)
+    worst = {}
     for t in range(300):
         act = util.marl_actions(rng, n_envs, A)
         _compare_step(torch, eng, ora, act, stats)
@@ -421,10 +498,12 @@ def test_marl_roundabout_parity(num_agents, capacity, kind="roundabout", **cfg_k
         seen["int_mismatch"] = seen.get("int_mismatch", 0) + int((gi != i).any(axis=0).sum()) + int((gei != ei).any(axis=0).sum())
         seen["id_mismatch"] = seen.get("id_mismatch", 0) + int((gf[_abi.SF["AGENT_ID"]] != f[_abi.SF["AGENT_ID"]].astype(np.float32)).sum())
         seen["dying"] += int((i[_abi.SI["STATUS"]] == _abi.ST_DYING).sum())
+        util.compare_state(gf, f, (gi == i).all(axis=0) & (gei == ei).all(axis=0)[:, None], worst)
         f32 = util.round_state_f32(f)
         ora.set_state(f32, i, ei)
         eng.set_state(f32, i, ei)
-    print("marl parity:", stats, seen)
+    print("marl parity:", stats, seen, "state fields (x tolerance):", {k: round(v, 3) for k, v in worst.items()})
+    assert not util.state_failures(worst), util.state_failures(worst)
     assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL
     # the only tie class seen in the multi-agent runs: a car whose box touches a line box exactly (fp32 vs fp64 SAT), one
     # agent-step in 153,600 of the 12-of-16 configuration; every other configuration is bit-exact

@@ -53,6 +53,7 @@ def test_all_maps_campaign(mode, steps):
     rng = np.random.default_rng(17)
     st = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0, pose=0.0, beams=0, grazing=0, int_mismatch=0, done=0, active=0,
               radius_rows=0, idm_ties=0)
+    worst = {}
     for t in range(steps):
         act = _actions(mode, rng, n_envs)
         oo, orw, od, ofl = ora.step(act, threads=THREADS)
@@ -87,11 +88,13 @@ def test_all_maps_campaign(mode, steps):
             if fld == "THETA":
                 dd = np.minimum(dd, np.abs(dd - 2 * np.pi))
             st["pose"] = max(st["pose"], float(dd.max()))
+        util.compare_state(gf, f, agree & ~tie, worst)  # all 26 float fields, not the pose alone
         f32 = util.round_state_f32(f)
         ora.set_state(f32, i, ei)
         eng.set_state(f32, i, ei)
-    print("campaign", mode, st)
+    print("campaign", mode, st, "state fields (x tolerance):", {k: round(v, 3) for k, v in worst.items()})
     eng.close()
+    assert not util.state_failures(worst), util.state_failures(worst)
     assert st["flag_mismatch"] == 0  # bit-exact done / collision / line / sidewalk / arrive flags
     assert st["int_mismatch"] <= 1   # lane picks on a box edge (1 in 3.07 M in the round-1 campaign)
     assert st["obs"] < OBS_TOL and st["rew"] < REW_TOL and st["pose"] < 1e-3
@@ -121,6 +124,7 @@ def test_c2_1024_envs_parity():
     stats = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
     pose = 0.0
     n_done = 0
+    worst = {}
     for t in range(220):
         act = util.driving_actions(rng, n_envs) if t % 2 else _actions("straight", rng, n_envs)
         n_done += int(_compare_step(torch, eng, ora, act, stats).sum())
@@ -129,11 +133,13 @@ def test_c2_1024_envs_parity():
         assert (gi == i).all() and (gei == ei).all()
         for fld in ("X", "Y", "SPEED"):
             pose = max(pose, float(np.abs(gf[_abi.SF[fld]].astype(np.float64) - f[_abi.SF[fld]]).max()))
+        util.compare_state(gf, f, np.ones(gi.shape[1:], dtype=bool), worst)
         f32 = util.round_state_f32(f)
         ora.set_state(f32, i, ei)
         eng.set_state(f32, i, ei)
-    print("C2 parity:", stats, "pose", pose, "episodes", n_done)
+    print("C2 parity:", stats, "pose", pose, "episodes", n_done, "state fields (x tolerance):", {k: round(v, 3) for k, v in worst.items()})
     eng.close()
+    assert not util.state_failures(worst), util.state_failures(worst)
     assert stats["flag_mismatch"] == 0 and stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and pose < 1e-3 and n_done > 300
 
 

@@ -55,3 +55,53 @@ def marl_actions(rng, n, a):
     act[..., 0] = np.clip(rng.normal(0, 0.25, size=(n, a)), -1, 1)
     act[..., 1] = np.clip(rng.normal(0.6, 0.4, size=(n, a)), -1, 1)
     return act
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# every float field of the state (include/pgd_state_layout.h), GPU (fp32) vs oracle (fp64) after ONE teacher-forced step from
+# an identical fp32 state: |gpu - oracle| <= atol + rtol * |oracle|
+# ---------------------------------------------------------------------------------------------------------------------
+STATE_TOL = {
+    "X": (1e-3, 0.0), "Y": (1e-3, 0.0),            # lane coordinates <= 1e-3 m on maps of <= 500 m extent
+    "THETA": (1e-4, 0.0), "SPEED": (1e-4, 0.0),
+    # the applied action: agents copy the clipped input (exact); traffic stores the PID / IDM-law output, whose inputs are
+    # differences of ~100 m lane coordinates in fp32 (steering up to ~10, acceleration down to ~ -100)
+    "STEER": (1e-4, 2e-4), "THROTTLE": (1e-4, 2e-4), "ACT1S": (1e-4, 2e-4), "ACT1T": (1e-4, 2e-4),
+    "ACT0S": (1e-6, 0.0), "ACT0T": (1e-6, 0.0),    # the older deque entry is a copy of the previous state's newer one
+    "LASTX": (1e-6, 0.0), "LASTY": (1e-6, 0.0),    # copies of the pose the step started from
+    "LASTHX": (1e-6, 0.0), "LASTHY": (1e-6, 0.0),
+    "PID_HP": (2e-5, 0.0), "PID_LP": (2e-5, 0.0),  # the errors themselves: a heading difference [rad], a lateral offset [m]
+    "PID_HI": (2e-5, 1e-4), "PID_LI": (2e-5, 1e-4),  # their running sums
+    "TARGET_SPEED": (0.0, 0.0),                    # 30 / 5 km/h
+    "ENERGY": (1e-6, 1e-5),
+    "DIST_LEFT": (1e-4, 0.0), "DIST_RIGHT": (1e-4, 0.0),
+    "EP_REWARD": (2e-4, 1e-5),
+    "AGENT_ID": (0.0, 0.0),
+    "HX": (5e-6, 0.0), "HY": (5e-6, 0.0),          # carried unit heading vector vs cos / sin of the oracle's angle
+}
+
+
+def compare_state(gf, f, mask, worst, skip=()):
+    """All PGD_NF float fields of `gf` (engine) against `f` (oracle) on the slots selected by `mask` [N, V].  `worst` maps
+    field -> largest error seen so far in units of its tolerance (<= 1 passes); returns it."""
+    if not mask.any():
+        return worst
+    for name, k in _abi.SF.items():
+        if name in skip:
+            continue
+        atol, rtol = STATE_TOL[name]
+        a, b = gf[k].astype(np.float64)[mask], np.asarray(f[k], dtype=np.float64)[mask]
+        d = np.abs(a - b)
+        if name == "THETA":  # heading_theta lives in [-3 pi / 2, pi / 2): a value on the seam may wrap on one side only
+            d = np.minimum(d, np.abs(d - 2 * np.pi))
+        tol = atol + rtol * np.abs(b)
+        if atol == 0.0 and rtol == 0.0:
+            err = float((d != 0).any()) * 2.0
+        else:
+            err = float((d / tol).max())
+        worst[name] = max(worst.get(name, 0.0), err)
+    return worst
+
+
+def state_failures(worst):
+    return {k: round(v, 3) for k, v in worst.items() if v > 1.0}
