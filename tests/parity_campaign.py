@@ -46,7 +46,7 @@ for mode, steps in (("driving", 1500), ("uniform", 600), ("straight", 900)):
         # IDM neighbour search: traffic spawns on a 10 m grid, so a leader exactly MAX_DIST = 30 m ahead is "found" or "not
         # found" by the last bit of the lane coordinate (also in the reference's fp64); such a vehicle gets a different
         # throttle on the two sides: counted, excluded from the pose statistic
-        tie=np.abs(gf[_abi.SF["ACT1T"]].astype(np.float64)-f[_abi.SF["ACT1T"]])>1e-3
+        tie=util.idm_tie(gf,f)
         st["idm_30m_ties"]=st.get("idm_30m_ties",0)+int((tie&agree).sum())
         for fld in ("X","Y","THETA","SPEED"):
             dd=np.abs(gf[_abi.SF[fld]].astype(np.float64)-f[_abi.SF[fld]])[agree&~tie]

@@ -81,7 +81,7 @@ def test_all_maps_campaign(mode, steps):
         agree = (gi == i).all(axis=0) & (gei == ei).all(axis=0)[:, None]
         st["int_mismatch"] += int((~agree).sum())
         st["active"] += int((i[0, :, 1:] == 2).sum())
-        tie = np.abs(gf[_abi.SF["ACT1T"]].astype(np.float64) - f[_abi.SF["ACT1T"]]) > 1e-3
+        tie = util.idm_tie(gf, f)
         st["idm_ties"] += int((tie & agree).sum())
         for fld in ("X", "Y", "THETA", "SPEED"):
             dd = np.abs(gf[_abi.SF[fld]].astype(np.float64) - f[_abi.SF[fld]])[agree & ~tie]

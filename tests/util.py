@@ -81,6 +81,15 @@ STATE_TOL = {
 }
 
 
+def idm_tie(gf, f):
+    """Slots whose applied throttle differs between engine and oracle by more than rounding: an IDM leader exactly MAX_DIST =
+    30 m ahead on the 10 m spawn grid is found / not found by the last bit of a lane coordinate (also in the reference's
+    fp64), and the vehicle then gets another acceleration on the two sides.  The enumerated tie class of the campaigns
+    (profiles/r01_parity_campaign.md): counted and bounded by the callers, excluded from the per-field comparison."""
+    a, b = gf[_abi.SF["ACT1T"]].astype(np.float64), np.asarray(f[_abi.SF["ACT1T"]], dtype=np.float64)
+    return np.abs(a - b) > 1e-3 + 1e-3 * np.abs(b)
+
+
 def compare_state(gf, f, mask, worst, skip=()):
     """All PGD_NF float fields of `gf` (engine) against `f` (oracle) on the slots selected by `mask` [N, V].  `worst` maps
     field -> largest error seen so far in units of its tolerance (<= 1 passes); returns it."""
