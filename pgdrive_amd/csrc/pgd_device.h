@@ -22,6 +22,7 @@ struct PgdDev {
   int N, A, T, V, D, NV;
   int epw;        // whole environments per wave in k_step
   int sub;        // sub-lanes cooperating on one vehicle
+  int sub2;       // k_step2: sub-lanes per traffic slot in the traffic wave
   int sstride;    // pgd_spawn records per scenario: V slots + respawn_places * respawn_dests (multi-agent)
   const pgd_map* maps;
   const pgd_lane* lanes;

@@ -75,11 +75,11 @@ DEV void reset_vehicle(const pgd_spawn& p, const float2 hv, Veh& r, int spawn_in
   memset(&r, 0, sizeof(Veh));
   // agents have no PID state: under PGD_MA_TOLLGATE the fields carry in_toll_time = 0 and entry / exit / last block = none
   // (marl_tollgate.py:36-60,76-96); harmless otherwise
-  if (is_agent) { r.php = (float)p.aux; r.phi = -1.0f; r.plp = -1.0f; r.pli = -1.0f; }  // php: parking destination / toll time
   r.spawn = spawn_index;
   r.rlane = is_agent ? 0 : -1;  // agents: episode length; traffic: IDMPolicy.routing_target_lane = None
   r.hx = 1.0f;
   if (p.lane < 0) { r.status = ST_EMPTY; return; }
+  if (is_agent) { r.php = (float)p.aux; r.phi = -1.0f; r.plp = -1.0f; r.pli = -1.0f; }  // php: parking destination / toll time
   r.status = p.group == -1 ? ST_ACTIVE : ST_PENDING;  // PGD_GROUP_NEVER (-2): in the world, never driven
   r.x = p.x; r.y = p.y; r.th = heading_wrap(p.heading);
   r.lastx = p.x; r.lasty = p.y;

@@ -61,12 +61,21 @@ struct AgentView {  // what the observation needs from the observing vehicle
 
 // one wave compacts the candidates: lane `o` brings vehicle o of the env (present = in the physics world)
 // `near_out` (optional): set when body o can reach the observing agent during the NEXT step -- centre distance within the two
-// sizes (half length + half width bounds the circumradius) plus the longest paths both can drive in 0.1 s (speed + 1 m/s of
-// acceleration, 5 % slack).  k_step skips its contact tests in envs where no body is near any agent.
+// sizes (half length + half width bounds the circumradius) plus the longest paths both can drive in one step of
+// t_step = dt * decision_repeat seconds (speed + 10 m/s^2 of acceleration -- three times what the strongest engine gives --
+// 5 % slack: near_reach).  k_step skips its contact tests in envs where no body is near any agent.  The test only sees bodies
+// inside the lidar broad phase, so the hint is used only while the lidar range covers every possible reach (near_hint_usable).
+DEV float near_reach(float speed_ms, float t_step) { return (fabsf(speed_ms) + 10.0f * t_step) * t_step * 1.05f; }
+DEV bool near_hint_usable(const pgd_config& c) {
+  const float t_step = c.dt * (float)c.decision_repeat;
+  // two bodies at 150 km/h (nothing drives faster: the engine force is cut above max_speed <= 80 km/h) + the two largest
+  // circumradius bounds (MAX_LENGTH 10 / 2 + MAX_WIDTH 2.5 / 2 each, base_vehicle.py:83-84)
+  return c.num_lasers > 0 && c.lidar_dist >= 2.0f * near_reach(150.0f / 3.6f, t_step) + 12.6f;
+}
 template <bool OBJ>
 DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, float x, float y, float ux, float uy, float hl,
                      float hw, float spd, float px, float py, float R, float hx, float hy, int NL, float ag_reach = 0.0f,
-                     bool* near_out = nullptr) {
+                     bool* near_out = nullptr, float t_step = 0.1f) {
   if (!OBJ) is_vehicle = true;
   bool in = present && o != a && shape_point_dist<OBJ>(Obb{x, y, ux, uy, hl, hw}, px, py) <= R;
   if (near_out) *near_out = false;
@@ -77,7 +86,7 @@ DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, flo
     const float dist = norm2(px - x, py - y);
     L.bdist[k] = is_vehicle ? dist : __builtin_inff();
     // (a body that can reach the agent within a step is inside the lidar broad phase a fortiori: R >= 20 m in every config)
-    if (near_out) *near_out = dist <= ag_reach + hl + (hw < 0.0f ? 0.0f : hw) + (spd * (1.0f / 3.6f) + 1.0f) * 0.105f + 0.05f;
+    if (near_out) *near_out = dist <= ag_reach + hl + (hw < 0.0f ? 0.0f : hw) + near_reach(spd * (1.0f / 3.6f), t_step) + 0.05f;
     // the body lies inside the circle of radius rad around its centre: only beams within asin(rad / dist) of the centre
     // direction can reach it.  asin(q) <= q + (pi/2 - 1) q^3 on [0, 1]; 1.5 beams of slack cover the fp32 rounding of the
     // angle, so the culling never removes a hit and the cloud stays bit-identical to the all-pairs test.

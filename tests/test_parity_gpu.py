@@ -34,7 +34,8 @@ def _engines(descs, n_envs, n_maps=8, **kw):
                            random_agent_model=kw.get("random_agent_model", False),
                            lidar_gaussian_noise=kw.get("lidar_gaussian_noise", 0.0),
                            lidar_dropout_prob=kw.get("lidar_dropout_prob", 0.0), seed=kw.get("seed", 0),
-                           resample_scenario=kw.get("resample_scenario", 0))
+                           resample_scenario=kw.get("resample_scenario", 0), decision_repeat=kw.get("decision_repeat", 5),
+                           lidar_dist=kw.get("lidar_dist", 50.0))
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
     ora.map_bank, ora.scen_bank = mb, sb
@@ -95,6 +96,43 @@ def _compare_step(torch, eng, ora, act, stats):
 @pytest.mark.parametrize("num_traffic,num_lasers", [(16, 240), (0, 0)])
 def test_teacher_forced_parity(descs, num_traffic, num_lasers):
     """Each step starts from the same fp32-rounded state on both sides; outputs and the next state must agree."""
+    _teacher_forced(descs, num_traffic, num_lasers)
+
+
+def test_two_wave_kernel_parity(descs, monkeypatch):
+    """k_step2 (two waves per env: ego wave + traffic wave that returns early when nothing drives; opt-in, PGD_TWO_WAVE=1 --
+    it lost the A/B of profiles/r03_notes.md and is not the default) through the same teacher-forced comparison, and
+    free-running against the one-wave kernel: flags, done and the integer state bit-identical over 300 steps with resets."""
+    monkeypatch.setenv("PGD_TWO_WAVE", "1")
+    _teacher_forced(descs, 16, 240)
+    n_envs = 128
+    torch, two, _, cfg = _engines(descs, n_envs, seed=9, resample_scenario=1)
+    monkeypatch.setenv("PGD_TWO_WAVE", "0")
+    _, one, _, _ = _engines(descs, n_envs, seed=9, resample_scenario=1)
+    ids = np.arange(n_envs) % 8
+    two.reset(ids); one.reset(ids)
+    rng = np.random.default_rng(6)
+    n_done = 0
+    for t in range(300):
+        act = util.driving_actions(rng, n_envs)
+        if t % 3 == 0:
+            act[::2, 0, :] = 1.0
+        f, i, ei = one.get_state()
+        two.set_state(f, i, ei)
+        a = torch.from_numpy(act).to(one.device)
+        o1, r1, d1, f1 = [x.clone() for x in one.step(a)]
+        o2, r2, d2, f2 = [x.clone() for x in two.step(a)]
+        one.sync(); two.sync()
+        assert torch.equal(d1, d2) and torch.equal(f1, f2), "flags differ at step %d" % t
+        assert float((o1 - o2).abs().max()) < 2e-6 and float((r1 - r2).abs().max()) < 2e-5
+        _, i1, e1 = one.get_state()
+        _, i2, e2 = two.get_state()
+        assert (i1 == i2).all() and (e1 == e2).all(), "integer state differs at step %d" % t
+        n_done += int(d1.sum().item())
+    assert n_done > 50
+
+
+def _teacher_forced(descs, num_traffic, num_lasers):
     n_envs = 64
     torch, eng, ora, cfg = _engines(descs, n_envs, num_traffic=num_traffic, num_lasers=num_lasers)
     scen_ids = np.arange(n_envs) % 8
@@ -143,7 +181,7 @@ def test_random_lane_width_and_num_maps_parity():
     from pgdrive_amd import bank
     maps = bank.get_descriptions(range(1000, 1008), random_lane_width=True, random_lane_num=True)
     assert all(m["lane_num"] == 2 for m in maps) and len({round(m["lane_width"], 6) for m in maps}) == 8
-    test_teacher_forced_parity(maps, 16, 240)
+    _teacher_forced(maps, 16, 240)
 
 
 @pytest.mark.parametrize("side,lane_line,num_lasers", [((12, 50.0), (6, 20.0), 240), ((2, 50.0), (2, 50.0), 0),
@@ -774,6 +812,39 @@ def test_record_cache_matches_plain_records(descs, num_traffic):
         n_done += int(ga[2].sum().item())
     print("record cache: episodes ended", n_done, "waiting-traffic rows seen", n_pending_rows)
     assert n_done > 50 and n_pending_rows > 10000
+
+
+@pytest.mark.parametrize("decision_repeat,lidar_dist", [(20, 50.0), (10, 50.0), (5, 8.0)])
+def test_contact_hint_with_long_steps_and_short_lidar(descs, decision_repeat, lidar_dist):
+    """The fused observation leaves a per-env hint "no body can reach an agent during the next step" that lets k_step skip its
+    contact tests.  Its reach is t_step = dt * decision_repeat seconds of driving, and it only sees bodies inside the lidar
+    range: with decision_repeat = 10 (0.2 s steps) or a lidar shorter than two reaches the round-2 constant (0.105 s, any
+    range) let fast closing vehicles collide unnoticed.  Engine A runs freely with the hint; engine B gets A's state through
+    set_state before every step (which forces the contact tests on): crash flags, done and state must be bit-identical."""
+    n_envs = 96
+    kw = dict(seed=5, decision_repeat=decision_repeat, lidar_dist=lidar_dist, density=0.3)
+    torch, eng_a, ora, cfg = _engines(descs, n_envs, **kw)
+    _, eng_b, _, _ = _engines(descs, n_envs, **kw)
+    scen_ids = np.arange(n_envs) % 8
+    eng_a.reset(scen_ids)
+    eng_b.reset(scen_ids)
+    rng = np.random.default_rng(4)
+    n_crash = n_done = 0
+    for t in range(300):
+        act = util.driving_actions(rng, n_envs)
+        act[:, 0, 0] *= 0.2
+        act[:, 0, 1] = 1.0  # straight on at full throttle: the ego runs into the traffic ahead of it at speed
+        f, i, ei = eng_a.get_state()
+        eng_b.set_state(f, i, ei)
+        ga = [x.clone() for x in eng_a.step(torch.from_numpy(act).to(eng_a.device))]
+        gb = [x.clone() for x in eng_b.step(torch.from_numpy(act).to(eng_b.device))]
+        eng_a.sync(); eng_b.sync()
+        for xa, xb, name in zip(ga, gb, ("obs", "reward", "done", "flags")):
+            assert torch.equal(xa.cpu(), xb.cpu()), "%s differs at step %d" % (name, t)
+        n_crash += int(((ga[3].cpu().numpy().astype(np.uint32) & _abi.F_CRASH_VEHICLE) != 0).sum())
+        n_done += int(ga[2].sum().item())
+    print("contact hint A/B, decision_repeat %d, lidar %.0f m: crashes %d, episodes %d" % (decision_repeat, lidar_dist, n_crash, n_done))
+    assert n_crash > 30
 
 
 def test_config_combinations_fuzz(descs):
