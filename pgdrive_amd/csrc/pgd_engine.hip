@@ -146,6 +146,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   __shared__ uint8_t s_kind[WAVE]; // PGD_OBJ_* of every slot (fused observation: objects are lidar targets, not neighbours)
   const int V = d.V, A = d.A, N = d.N;
   const int lane = threadIdx.x;
+  const bool sub_ok = (ONE_ENV ? V : d.epw * V) <= PGD_SUBV;  // every slot of the wave has a place for its sub-step poses
   const int unit = (int)blockIdx.x + d.unit_off;  // pgd_step_group launches only the blocks of one env group
   const LaneMap lm = lane_map(d, unit, N);
   const int el = ONE_ENV ? 0 : lm.el, s = lm.s, e = ONE_ENV ? unit : lm.e, base = ONE_ENV ? 0 : lm.base;
@@ -183,9 +184,10 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // scenario's reset image: its lane reads the image -- shared by every env of the scenario, cache resident -- instead of the
   // env's own record in HBM.  One env per wave only; the records in memory stay complete either way.
   unsigned long long im = 0ull;
-  if (ONE_ENV && d.use_imask) im = d.imask[e];
+  const bool packed = !ONE_ENV && d.pack_obs != 0;  // throughput mode: whole envs side by side in the wave, one vehicle per lane
+  if ((ONE_ENV || (packed && valid)) && d.use_imask) im = d.imask[e];
   if (one_env || valid) scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
-  if (valid) load_rec((ONE_ENV && ((im >> s) & 1ull)) ? d.reset_img + (size_t)scen * V + s : d.rec + (size_t)e * V + s, r);
+  if (valid) load_rec(((ONE_ENV || packed) && ((im >> s) & 1ull)) ? d.reset_img + (size_t)scen * V + s : d.rec + (size_t)e * V + s, r);
   const int key0 = valid ? (r.status ^ (r.vflags << 3)) : 0;  // what a vehicle that does not drive can change: status, flags
   if (one_env || valid) {
     sc = d.scen + scen;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     ng = d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP];
     ep_steps = d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS];
     steps_total = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
-    if (ONE_ENV) near_env = d.ei[(size_t)(e) * PGD_NEI + EI_NEAR] != 0;
+    if (ONE_ENV || packed) near_env = d.ei[(size_t)(e) * PGD_NEI + EI_NEAR] != 0;
   }
   PHASE_MARK(13);  // load: scenario + table staging
   XMARK(13);
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // _set_action / _set_incremental_action (base_vehicle.py:343-358)
     r.steer = (s < A && d.cfg.increment_steering) ? clipf(r.steer + st * 0.05f, -1.0f, 1.0f) : st;
     // (4) physics
-    dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0, tb, leader ? &SUBP : nullptr, slot, near_env && V <= PGD_SUBV && n_mid_enabled);
+    dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0, tb, leader ? &SUBP : nullptr, slot, near_env && sub_ok && n_mid_enabled);
     PHASE_MARK(3);  // dynamics
   }
   step_sync();
@@ -291,13 +293,13 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
 #ifdef PGD_NO_SUBSTEP
   const int n_mid = 0;
 #else
-  const int n_mid = (d.cfg.decision_repeat <= PGD_MAX_SUB && V <= PGD_SUBV) ? d.cfg.decision_repeat - 1 : 0;
+  const int n_mid = (d.cfg.decision_repeat <= PGD_MAX_SUB && sub_ok) ? d.cfg.decision_repeat - 1 : 0;
 #endif
   if (near_env) {
     const int my_kind = (OBJ && valid) ? s_kind[slot] : PGD_OBJ_VEHICLE;
     if (valid && S.present[slot]) {  // a vehicle's sub-lanes split the agents; object sub-lanes all keep their copy of the bit
       const Obb me = snap_obb(S, slot);
-      const float my_trav = V <= PGD_SUBV ? SUBP.trav[slot] : 0.0f;
+      const float my_trav = sub_ok ? SUBP.trav[slot] : 0.0f;
       const float my_rad = me.hl + (me.hw < 0.0f ? 0.0f : me.hw);  // >= the circumradius
       // a traffic object reports only its first contact (TrafficObject.crashed / COST_ONCE, collision_callback.py:27-32)
       const bool live = !OBJ || my_kind == PGD_OBJ_VEHICLE || !(r.vflags & (int)PGD_F_OBJECT_HIT);
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       for (int a = split ? g.sub : 0; a < A; a += split ? g.SUB : 1) {
         if (a == s || (OBJ && !S.present[base + a])) continue;
         const Obb ag = snap_obb(S, base + a);
-        const float ag_trav = V <= PGD_SUBV ? SUBP.trav[base + a] : 0.0f;
+        const float ag_trav = sub_ok ? SUBP.trav[base + a] : 0.0f;
         const float reach = my_rad + ag.hl + ag.hw + my_trav + ag_trav + 0.01f;
         const float ddx = ag.cx - me.cx, ddy = ag.cy - me.cy;
         if (ddx * ddx + ddy * ddy > reach * reach) continue;
@@ -568,6 +570,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     const unsigned long long full = V >= 64 ? ~0ull : ((1ull << V) - 1ull);
     const unsigned long long nm = resetting ? full : (im & ~cleared);
     if (lane == 0 && nm != im && d.use_imask) d.imask[e] = nm;
+  } else if (packed) {  // one lane per slot: the env's bits of the ballot are its slots
+    const unsigned long long sb = __ballot(stored);
+    const unsigned long long full = (1ull << V) - 1ull;
+    const unsigned long long nm = resetting ? full : (im & ~((sb >> base) & full));
+    if (valid && s == 0 && nm != im && d.use_imask) d.imask[e] = nm;
   }
   PHASE_MARK(8);  // store
   XMARK(8);
@@ -618,15 +625,68 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     near_next = near_hint_usable(d.cfg) ? (__ballot(near_any) != 0ull) : true;
   }
   if (ONE_ENV && lane == 0 && (int)near_next != (int)near_env) d.ei[(size_t)e * PGD_NEI + EI_NEAR] = near_next ? 1 : 0;
+  if (packed && obs == nullptr && valid && s == 0 && leader && !near_env) d.ei[(size_t)e * PGD_NEI + EI_NEAR] = 1;  // no row, no hint
   // multi-agent engine: the rows of all agents, from the records and flags this wave has just written (the barrier makes
   // them visible to the whole workgroup); the step's LDS is free by now
   if (ONE_ENV && MARL && obs != nullptr) {
     __syncthreads();
     observe_env_body<1, false>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
   }
+  // throughput mode (several envs per wave, one ego each, lidar): the rows of the wave's envs one after the other, each by the
+  // whole wave -- same routine as the fused observation above, the env's scenario and map view read with wave-uniform addresses
+  if (!ONE_ENV && !MARL && obs != nullptr && d.pack_obs) {
+    step_sync();
+    if (valid && leader) {
+      const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
+      S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
+      S.spd[slot] = speed_kmh(r.v);
+      S.hl[slot] = 0.5f * sp->length;
+      S.hw[slot] = (OBJ && sp->kind == PGD_OBJ_CYLINDER) ? -1.0f : 0.5f * sp->width;
+      if (OBJ) s_kind[slot] = sp->kind;
+      S.present[slot] = present ? 1 : 0;
+      if (s == 0) {
+        AgentView& ag = s_ag[el];
+        ag.x = r.x; ag.y = r.y; ag.th = r.th; ag.hx = r.hx; ag.hy = r.hy; ag.dl = r.dl; ag.dr = r.dr; ag.v = r.v;
+        ag.steer = r.steer; ag.a0s = r.a0s; ag.a0t = r.a0t; ag.lhx = r.lasthx; ag.lhy = r.lasthy;
+        ag.cur_first = r.cur_first; ag.cur_n = r.cur_n; ag.next_first = r.next_first;
+        ag.blk = r.blk; ag.toll_time = r.php;
+        ag.env = e; ag.slot = 0; ag.tick = steps_total;
+        ag.cur_n |= scen << 8;  // the env's (possibly re-drawn) scenario travels with the view
+      }
+    }
+    step_sync();
+    if (valid) {  // the state blocks of all envs of the wave at once: the V lanes of an env share the 18 floats of its row
+      AgentView ag = s_ag[el];
+      ag.cur_n &= 0xff;
+      state_block<STD>(d, mv, d.spawns[(size_t)scen * d.sstride], ag, obs + (size_t)e * d.ostride, s, V);
+    }
+    for (int q = 0; q < d.epw; ++q) {
+      const int eq = unit * d.epw + q;  // wave-uniform
+      if (eq >= N) break;
+      AgentView ag = s_ag[q];
+      const int scen_q = ag.cur_n >> 8;
+      ag.cur_n &= 0xff;
+      const MapView mvq = map_view_of(d, d.scen_map + scen_q);
+      const int bq = q * V;
+      const bool have = lane < V && d.cfg.num_lasers > 0;
+      const int sl = bq + (lane < V ? lane : 0);
+      const float t_step = d.cfg.dt * (float)d.cfg.decision_repeat;
+      bool near_a = false;
+      obs_compact<OBJ>(OL, lane, 0, have && S.present[sl], OBJ ? (have && s_kind[sl] == PGD_OBJ_VEHICLE) : true, S.x[sl], S.y[sl],
+                       S.ux[sl], S.uy[sl], S.hl[sl], S.hw[sl], S.spd[sl], ag.x, ag.y, d.cfg.lidar_dist, ag.hx, ag.hy, d.cfg.num_lasers,
+                       S.hl[bq] + S.hw[bq] + near_reach(ag.v, t_step), &near_a, t_step);
+      {  // hint for the next step's contact tests of this env (EI_NEAR)
+        const bool near_q = near_hint_usable(d.cfg) ? (__ballot(near_a) != 0ull) : true;
+        if (lane == 0) d.ei[(size_t)eq * PGD_NEI + EI_NEAR] = near_q ? 1 : 0;
+      }
+      step_sync();
+      observe_agent<OBJ, STD, false, false>(d, mvq, d.spawns[(size_t)scen_q * d.sstride], ag, OL, obs + (size_t)eq * d.ostride, lane, WAVE);
+      step_sync();
+    }
+  }
   // several envs per wave (small V) and an observation without a lidar (BASELINE config 2: dynamics + reward + state vector):
   // the row is the state block alone, written by the sub-lanes of the agent that has just been stepped
-  if (!ONE_ENV && !MARL && obs != nullptr && valid && s < A) {
+  if (!ONE_ENV && !MARL && obs != nullptr && !d.pack_obs && valid && s < A) {
     float* row = obs + (size_t)e * d.ostride + (size_t)s * d.D;
     if (r.status != ST_ACTIVE) {
       for (int k = g.sub; k < d.D; k += g.SUB) row[k] = 0.0f;
@@ -1005,7 +1065,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restr
   if (s == 0) {
     d.env_map[e] = d.scen_map[scen];
     if (d.bev_fill) d.bev_fill[e] = 1;
-    d.imask[e] = (d.epw == 1 && d.use_imask) ? (d.V >= 64 ? ~0ull : ((1ull << d.V) - 1ull)) : 0ull;  // every record equals the image now
+    d.imask[e] = ((d.epw == 1 || d.pack_obs) && d.use_imask) ? (d.V >= 64 ? ~0ull : ((1ull << d.V) - 1ull)) : 0ull;  // every record equals the image now
     d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_AGENT] = A == 1 ? 1 : __popcll(am);
     d.ei[(size_t)(e) * PGD_NEI + EI_AUX] = d.scen[scen].aux;  // parking: free spaces of the new episode
     d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
@@ -1328,6 +1388,17 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->d.sub = WAVE / V < 16 ? WAVE / V : 16;  // sub-lanes per vehicle
   h->d.epw = marl ? 1 : WAVE / (V * h->d.sub);  // whole environments per wave (the multi-agent tail needs the env alone in its wave)
   h->d.sub2 = cfg->num_traffic > 0 ? std::min(4, WAVE / cfg->num_traffic) : 1;
+  // Throughput mode: at large N the step is bound by instruction issue, not by the latency of one wave (profiles/r02_sweep.md:
+  // 4.2 ns per env-step from 32768 envs on), and the SUB lanes of a vehicle run its scalar phases redundantly.  Engines with
+  // >= 24576 single-ego envs (PGD_PACK=1 / 0 overrides; measured: 16384 envs lose 4 %, 32768 win 17 %, 262144 win 33 %) carry one vehicle per lane and as many whole envs per wave as fit --
+  // three at V = 17 -- with the lidar observation of each env appended to the same launch.
+  {
+    const char* pk = getenv("PGD_PACK");
+    const int epw1 = std::min(WAVE / V, FUSE_MAX_AGENTS);
+    const bool can = !marl && cfg->num_agents == 1 && cfg->num_traffic >= 1 && epw1 >= 2 && epw1 * V <= PGD_SUBV && cfg->num_lasers > 0;
+    const bool want = pk ? atoi(pk) != 0 : cfg->num_envs >= 24576;
+    if (can && want) { h->d.sub = 1; h->d.epw = epw1; h->d.pack_obs = 1; }
+  }
   if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }
   else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
   HIPCHK(hipEventCreate(&h->ev0));
@@ -1603,7 +1674,8 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
                         h->d.A < 4 * (WAVE / h->d.V) &&  // else the four-wave k_observe_env is the faster one
                         observe_env_words(1, h->d.cfg.num_lasers, h->d.V) <= STEP_MINB_WORDS;  // at least one observer per round
   const bool fuse_state = d_obs && !marl && h->d.epw > 1 && h->d.cfg.num_lasers <= 0 && !h->no_fuse;  // state-only rows, several envs per wave
-  const bool fuse = (d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse) || fuse_env || fuse_state;
+  const bool fuse_pack = d_obs && h->d.pack_obs;  // throughput mode: the rows of the wave's envs appended to k_step
+  const bool fuse = (d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse) || fuse_env || fuse_state || fuse_pack;
   bool prof = h->prof_ev && h->prof_n < h->prof_cap && group < 0;
   // strided profile: with the observation fused (one kernel per step) events [0] / [1] bracket a GROUP of `stride`
   // back-to-back launches and the group time is divided by the stride; otherwise every stride-th step is bracketed
@@ -1628,6 +1700,12 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
     kern = h->has_objects ? k_step<true, false, true> : (std_obs ? k_step<true, false, false, true> : k_step<true, false, false>);
   }
   else if (h->has_objects) kern = k_step<false, false, true>;
+  else if (h->d.pack_obs) {
+    const pgd_config& c = h->d.cfg;
+    const bool std_obs = c.side_lasers == 0 && c.lane_line_lasers == 0 && !c.random_agent_model &&
+                         c.lidar_gaussian_noise <= 0.0f && c.lidar_dropout_prob <= 0.0f;
+    if (std_obs) kern = k_step<false, false, false, true>;
+  }
   // two waves per env (k_step2): one ego, at least one traffic slot, no traffic objects, the observation fused or not wanted
   const bool two = h->two_wave && !marl && h->d.epw == 1 && h->d.A == 1 && h->d.T >= 1 && h->d.T <= 60 && !h->has_objects &&
                    (fuse || !d_obs);

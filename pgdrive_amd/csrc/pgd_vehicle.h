@@ -47,8 +47,8 @@ DEV Obb snap_obb(const Snap& S, int k) { return Obb{S.x[k], S.y[k], S.ux[k], S.u
 // ObsLds (union ObsScratch, pgd_observe.h): the contact test is over before the observation scratch is first written.
 #define PGD_MAX_SUB 5
 #ifndef PGD_SUBV
-#define PGD_SUBV 48  // slots with sub-step poses (the largest shipped env: 40 agents + 8 toll booths); engines with more slots
-                     // test contacts at the end pose only
+#define PGD_SUBV 52  // slots of a wave with sub-step poses (the largest shipped env: 40 agents + 8 toll booths; three packed
+                     // envs of 17 slots); waves with more slots test contacts at the end pose only
 #endif
 struct SubPose {
   float4 p[PGD_MAX_SUB - 1][PGD_SUBV];  // (x, y, unit vector of the MOTION direction) of the slot after sub-step k + 1

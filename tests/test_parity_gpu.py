@@ -132,6 +132,57 @@ def test_two_wave_kernel_parity(descs, monkeypatch):
     assert n_done > 50
 
 
+def test_throughput_mode_parity(descs, monkeypatch):
+    """Throughput mode (engines with >= 16384 envs, or PGD_PACK=1): one vehicle per lane, three whole envs of 17 slots per wave,
+    the lidar rows of the wave's envs appended to the same launch (k_step<ONE_ENV = false> + pack_obs).  Same teacher-forced
+    comparison against the oracle, with an env count that leaves the last wave partly empty, auto-reset with re-drawn
+    scenarios; then free-running against the default kernel: flags / done / integer state bit-identical."""
+    monkeypatch.setenv("PGD_PACK", "1")
+    n_envs = 65
+    torch, eng, ora, cfg = _engines(descs, n_envs, seed=3, resample_scenario=1)
+    ids = np.arange(n_envs) % 8
+    assert np.abs(eng.reset(ids).cpu().numpy() - ora.reset(ids)).max() < OBS_TOL
+    rng = np.random.default_rng(12)
+    stats = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
+    worst = {}
+    n_done = 0
+    for t in range(300):
+        act = util.driving_actions(rng, n_envs)
+        if t % 4 == 0:
+            act[::3, 0, :] = 1.0
+        n_done += int(_compare_step(torch, eng, ora, act, stats).sum())
+        f, i, ei = ora.get_state()
+        gf, gi, gei = eng.get_state()
+        agree = (gi == i).all(axis=0) & (gei == ei).all(axis=0)[:, None]
+        tie = util.idm_tie(gf, f)
+        tie[:, :1] = False
+        util.compare_state(gf, f, agree & ~tie, worst)
+        assert (~agree).sum() == 0
+        f32 = util.round_state_f32(f)
+        ora.set_state(f32, i, ei)
+        eng.set_state(f32, i, ei)
+    print("throughput mode parity:", stats, "episodes", n_done, "state fields (x tolerance):", {k: round(v, 3) for k, v in worst.items()})
+    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] == 0 and n_done > 20
+    assert not util.state_failures(worst), util.state_failures(worst)
+    assert stats.get("grazing", 0) <= 1e-5 * stats.get("beams", 1) + 2
+    monkeypatch.setenv("PGD_PACK", "0")
+    _, one, _, _ = _engines(descs, n_envs, seed=3, resample_scenario=1)
+    eng.reset(ids); one.reset(ids)
+    for t in range(200):
+        act = util.driving_actions(rng, n_envs)
+        f, i, ei = one.get_state()
+        eng.set_state(f, i, ei)
+        a = torch.from_numpy(act).to(one.device)
+        o1, r1, d1, f1 = [x.clone() for x in one.step(a)]
+        o2, r2, d2, f2 = [x.clone() for x in eng.step(a)]
+        one.sync(); eng.sync()
+        assert torch.equal(d1, d2) and torch.equal(f1, f2), "flags differ at step %d" % t
+        assert float((o1 - o2).abs().max()) < 2e-6 and float((r1 - r2).abs().max()) < 2e-5
+        _, i1, e1 = one.get_state()
+        _, i2, e2 = eng.get_state()
+        assert (i1 == i2).all() and (e1 == e2).all(), "integer state differs at step %d" % t
+
+
 def _teacher_forced(descs, num_traffic, num_lasers):
     n_envs = 64
     torch, eng, ora, cfg = _engines(descs, n_envs, num_traffic=num_traffic, num_lasers=num_lasers)
