@@ -46,6 +46,7 @@ struct PgdDev {
   int use_imask;       // 0: every slot is read from the env's own record (small N: one dependent load level less)
   unsigned long long* imask;  // [N] bit s: slot s of the env still equals its scenario's reset image (never stored since)
   const struct Veh* reset_img;  // [n_scen][V] every slot right after a reset of its scenario (k_reset_image)
+  const struct Veh* respawn_img;  // [n_scen][sstride - V] multi-agent: an agent right after it was spawned from respawn record V + k
   const float2* beam;  // [num_lasers] (cos, sin) of the beam angle i * 2 pi / num_lasers in the vehicle frame
   // output addressing of one launch: the observation row of (env e, agent a) starts at obs + e * ostride + a * D.
   // pgd_step: ostride = A * D (dense [N, A, D]).  pgd_step_packed: ostride = the caller's row stride and `prow` = the same

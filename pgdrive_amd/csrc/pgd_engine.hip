@@ -345,9 +345,13 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (acting) {
     // several agents: each tests its own box against the lines with its sub-lanes (all agents at once) instead of the
     // whole wave working through the agents one after the other
-    after_step_vehicle(d.cfg, mv, g, *sp, r, s < A, !one_env || A > 1, ctx);
+    // several agents: the line / sidewalk test runs as a phase of its own (below), where the localisation's boxes and lane
+    // records are no longer live -- inside after_step it pushed the multi-agent kernel 66 registers over the 128 it may use
+    after_step_vehicle(d.cfg, mv, g, *sp, r, s < A, !one_env, ctx);
     if (s >= A && (r.vflags & PGD_F_OFF_LANE)) r.status = ST_REMOVED;
   }
+  if (one_env && A > 1 && acting && s < A && !ctx.clear)
+    r.vflags |= (int)state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sp->length, 0.5f * sp->width});
   PHASE_MARK(25);  // after_step: per-vehicle part
   if (one_env && A == 1) {  // line / sidewalk test of the agent by the whole wave (base_vehicle.py:615-644)
     if (leader && valid && s < A) s_flag[A + s] = (acting && !ctx.clear) ? 1 : 0;  // clear: provably no contact (after_step)
@@ -367,6 +371,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   step_sync();
   unsigned my_fl = 0;
   bool fresh = false;  // multi-agent: this lane's slot received a new agent in this step
+  int fresh_idx = 0, fresh_id = 0;  // ... from this respawn record, with this agent id
   bool my_dn = false;
   float my_rew = 0.0f;
   const bool was_active = acting;  // status at the start of the step (after the delay-done countdown)
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         const bool blocks = lane < V && S.present[lane] && obb_overlap(region, snap_obb(S, lane));
         if (__ballot(blocks) != 0ull) continue;
         // lowest empty slot that did not report this step (its terminal row must survive)
-        unsigned long long em = __ballot(is_lead_agent && r.status == ST_EMPTY && !(my_fl & PGD_F_REPORT));
+        unsigned long long em = __ballot(is_lead_agent && r.status == ST_EMPTY && !fresh && !(my_fl & PGD_F_REPORT));
         if (em == 0ull) break;
         const int src = __builtin_ffsll((long long)em) - 1;
         const int tslot = (src / d.sub) % V;
@@ -460,15 +465,17 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
           if (lane == 0) s_aux &= ~(1 << dest);
         }
         if (valid && s == tslot) {
-          const int sidx = V + p * gcf.respawn_dests + dest;
-          sp = d.spawns + (size_t)scen * d.sstride + sidx;
-          reset_vehicle(*sp, d.spawn_hv[(size_t)scen * d.sstride + sidx], r, sidx, true);
-          r.agent_id = (float)next_agent;
+          // only the choice is recorded here; the record itself is rebuilt once, after the loop (rewriting `r` inside it kept
+          // two copies of the 32 record registers alive around the place test: 139 VGPRs, 66 spilled)
+          fresh_idx = V + p * gcf.respawn_dests + dest;
+          fresh_id = next_agent;
           fresh = true;
           my_fl |= PGD_F_NEW;
           if (leader) {
-            S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
-            S.hl[slot] = 0.5f * sp->length; S.hw[slot] = 0.5f * sp->width;
+            const pgd_spawn& nsp = d.spawns[(size_t)scen * d.sstride + fresh_idx];
+            const float2 nhv = d.spawn_hv[(size_t)scen * d.sstride + fresh_idx];
+            S.x[slot] = nsp.x; S.y[slot] = nsp.y; S.ux[slot] = nhv.x; S.uy[slot] = nhv.y;
+            S.hl[slot] = 0.5f * nsp.length; S.hw[slot] = 0.5f * nsp.width;
             S.present[slot] = 1;
           }
         }
@@ -476,7 +483,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         step_sync();
       }
     }
-    if (fresh) route_refresh(mv, *sp, r);  // the toll bookkeeping below reads the new agent's block id
+    if (fresh) {  // the new agent's record, first localisation included, from the respawn image (k_respawn_image)
+      sp = d.spawns + (size_t)scen * d.sstride + fresh_idx;
+      load_rec(d.respawn_img + (size_t)scen * (d.sstride - V) + (fresh_idx - V), r);
+      r.agent_id = (float)fresh_id;
+    }
     PHASE_MARK(27);  // marl: respawn
     // StayTimeManager.record(active_agents, episode_steps) after the step (marl_tollgate.py:36-60,276-279)
     if (toll && valid && s < A && r.status == ST_ACTIVE) {
@@ -549,9 +560,6 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   PHASE_MARK(7);  // reset
   XMARK(7);
-  // first localisation of the agents that entered in this step: all of them at once, at the point of the kernel where
-  // nothing but the record itself is still needed (the place loop reads spawn poses only; a restart discards the agent)
-  if (marl && fresh && !resetting) after_step_vehicle(d.cfg, mv, g, *sp, r, true, true, ctx);
   bool stored = false;
   if (valid && leader) {
     // a slot that neither drove, restarted, counted down (delay-done) nor changed status / flags still holds its record:
@@ -1049,6 +1057,28 @@ __global__ __launch_bounds__(WAVE) void k_reset_image(PgdDev d, VehRec* __restri
   if (lm.sub == 0) store_rec(img + (size_t)lm.e * d.V + lm.s, r);
 }
 
+// multi-agent: the record of an agent right after it was (re)spawned from respawn record V + k of a scenario (spawn state, route
+// context, first localisation, side distances, line / sidewalk flags) is a function of the scenario alone: built once per
+// upload, one thread per record; the respawn of k_step copies it and sets the agent id (was: a second after_step + line test
+// inside the step whenever any agent of the env entered, 7 k cycles of the wave)
+__global__ __launch_bounds__(256) void k_respawn_image(PgdDev d, VehRec* __restrict__ img) {
+  const int n_extra = d.sstride - d.V;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d.n_scen * n_extra) return;
+  const int scen = k / n_extra, idx = d.V + k % n_extra;
+  const Grp g{0, 1, (int)(threadIdx.x & (WAVE - 1))};
+  const pgd_spawn* sp = d.spawns + (size_t)scen * d.sstride + idx;
+  MapView mv = map_view(d, d.scen[scen].map);
+  Veh r;
+  reset_vehicle(*sp, d.spawn_hv[(size_t)scen * d.sstride + idx], r, idx, true);
+  RouteCtx ctx;
+  if (r.status != ST_EMPTY) {
+    route_refresh(mv, *sp, r);
+    after_step_vehicle(d.cfg, mv, g, *sp, r, true, true, ctx);
+  }
+  store_rec(img + k, r);
+}
+
 // reset of selected envs; same lane mapping as k_step, unit = position in the id list
 __global__ __launch_bounds__(WAVE) void k_reset(PgdDev d, const int32_t* __restrict__ env_ids,
                                                  const int32_t* __restrict__ scen_ids, int n) {
@@ -1275,6 +1305,7 @@ struct pgd_engine {
   pgd_map* scen_map;  // per scenario: copy of its map header (saves one dependent load per block)
   float2* beam;       // lidar beam directions in the vehicle frame
   VehRec* reset_img;  // [n_scen][V], rebuilt after every map / scenario upload
+  VehRec* respawn_img;  // [n_scen][sstride - V] (multi-agent), rebuilt with it
   bool img_dirty;
   std::vector<pgd_map>* h_maps;
   std::vector<pgd_scenario>* h_scen;
@@ -1346,6 +1377,15 @@ static int build_reset_image(pgd_engine* h) {
   const int blocks = (h->d.n_scen + h->d.epw - 1) / h->d.epw;
   hipLaunchKernelGGL(k_reset_image, dim3(blocks), dim3(WAVE), 0, h->stream, h->d, h->reset_img);
   HIPCHK(hipGetLastError());
+  if (h->respawn_img) { HIPCHK(hipFree(h->respawn_img)); h->respawn_img = nullptr; }
+  h->d.respawn_img = nullptr;
+  if (h->d.sstride > h->d.V) {
+    const size_t n = (size_t)h->d.n_scen * (h->d.sstride - h->d.V);
+    HIPCHK(hipMalloc(&h->respawn_img, sizeof(VehRec) * n));
+    h->d.respawn_img = h->respawn_img;
+    hipLaunchKernelGGL(k_respawn_image, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d, h->respawn_img);
+    HIPCHK(hipGetLastError());
+  }
   h->img_dirty = false;
   return PGD_OK;
 }
@@ -2007,7 +2047,7 @@ int pgd_destroy(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->d.rec, h->d.ei, h->d.imask, h->d.env_map, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
-                  h->cell_items, h->cell_boxes, h->cell_ext, h->lane_nav, h->scen_map, h->scen, h->spawns, h->spawn_hv, h->beam, h->reset_img};
+                  h->cell_items, h->cell_boxes, h->cell_ext, h->lane_nav, h->scen_map, h->scen, h->spawns, h->spawn_hv, h->beam, h->reset_img, h->respawn_img};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   (void)hipEventDestroy(h->ev0);
