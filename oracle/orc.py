@@ -45,6 +45,8 @@ def lib():
         L.orc_obb_overlap.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_bicycle.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_idm_acc.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_topdown_snap.restype = C.c_double
+        L.orc_topdown_snap.argtypes = [C.c_double]
         L.orc_energy_step.restype = C.c_double
         L.orc_energy_step.argtypes = [C.c_double] * 3
         L.orc_action_forces.argtypes = [C.c_double] * 5 + [C.c_int, C.c_void_p]

@@ -153,6 +153,101 @@ def test_before_step_and_energy(L, descs):
     o.close()
 
 
+def test_topdown_reference_arithmetic(L, descs):
+    """The arithmetic of the reference's top-down observation, recorded from its own Python under a pygame that only records
+    (oracle/gen_topdown.py -> tests/golden/topdown_v0.json), against the oracle's top-down restatement (which the GPU rasteriser
+    is compared with pixel by pixel in tests/test_topdown_gpu.py): frame / past-position history and stack order, grey levels,
+    window scale, heading snap, the past-position transform.  pygame's rasterisation rules themselves stay unpinned."""
+    from oracle import orc
+    with open(os.path.join(GOLD, "topdown_v0.json")) as f:
+        g = json.load(f)
+    c = g["config"]
+    R, DIST, FS, PS, SKIP = c["resolution"], c["distance"], c["frame_stack"], c["post_stack"], c["frame_skip"]
+    SF, SI = _abi.SF, _abi.SI
+    # (1) history lengths and which entries are shown: ages 0, skip, 2 skip ... of what has been recorded so far
+    assert g["deque_maxlen"] == dict(traffic=(FS - 1) * SKIP + 1, past_pos=(PS - 1) * SKIP + 1)
+    for case in g["stack_indices"]:
+        n, k = case["length"], case["frame_skip"]
+        ages = [n - 1 - i for i in case["indices"]]
+        assert ages == [q * k for q in range(n) if q * k < n]
+    # (2) grey levels: the engine's three constants are the reference's _transform of its own colours (road channel doubled)
+    gr = g["grey"]
+    TD_LINE, TD_NAVI, TD_VEH = 2 * 35 / 255, 2 * 64 / 255, (0.299 * 100 + 0.587 * 200 + 0.114 * 255) / 255
+    assert abs(2 * gr["lane_line_clip"] - TD_LINE) < 1e-7 and abs(2 * gr["navigation_clip"] - TD_NAVI) < 1e-7
+    assert abs(gr["vehicle_blue_clip"] - TD_VEH) < 1e-7 and g["geometry"][0]["navigation_color"] == [64, 64, 64]
+    assert all(s["road"] == pytest.approx(TD_LINE, abs=1e-7) for s in g["observe"]["steps"])  # road_network * 2 of a (35, 35, 35) canvas
+    # (3) window scale: px per metre of the cropped, rotated, zoomed window on the reference's own road networks
+    for geo in g["geometry"]:
+        for ch in ("traffic", "road"):
+            assert abs(R / (2.0 * DIST) / geo["window_px_per_m"][ch] - 1.0) < 0.006  # int() truncations of the canvas sizes: < 0.6 %
+        assert all(abs(rz["angle"] - (np.rad2deg(geo["heading"]) + 90.0)) < 1e-9 for rz in geo["rotozoom"])
+        assert geo["crop"][1][2:] == [R, R] and geo["crop"][1][0] == geo["crop"][1][1]  # centre crop
+    # (4) heading snap: others and past positions snapped at 2 degrees, the window rotation is not
+    for sc in g["scene"]:
+        fr = sc["frames"][0]
+        assert [L.orc_topdown_snap(h) for h in sc["other_headings"]] == fr["vehicle_headings"]
+        assert fr["window_heading"] == sc["ego_heading"] and fr["vehicle_color"] == [100, 200, 255]
+        assert all(r["angle"] == pytest.approx(np.rad2deg(L.orc_topdown_snap(sc["ego_heading"])) + 90.0) for f_ in sc["frames"] for r in f_["rotate"])
+        assert sc["past_pos_scaling"] == R / DIST
+    # the oracle itself, one env on a real map
+    d = descs[0]
+    mb = mapdata.MapBank([d])
+    sb = scenario.ScenarioBank([d], [d["seed"]], num_agents=1, num_traffic=1, density=0.0)
+    o = orc.Oracle(_abi.make_config(1, num_agents=1, num_traffic=1, num_lasers=0, auto_reset=0), mb, sb)
+    o.enable_topdown(_abi.make_topdown_config(R, float(DIST), FS, PS, SKIP))
+    o.reset(np.zeros(1, dtype=np.int32))
+    f0, i0, ei0 = o.get_state()
+    ex, ey, eth = f0[SF["X"], 0, 0], f0[SF["Y"], 0, 0], f0[SF["THETA"], 0, 0]
+
+    def place(f, i, slot, x, y, th):
+        f[SF["X"], 0, slot], f[SF["Y"], 0, slot], f[SF["THETA"], 0, slot] = x, y, th
+        f[SF["HX"], 0, slot] = f[SF["HY"], 0, slot] = 0.0
+        i[SI["STATUS"], 0, slot] = _abi.ST_PENDING if slot else _abi.ST_ACTIVE
+        i[SI["SPAWN"], 0, slot] = slot
+
+    # (5) frame history through the images: the traffic vehicle stands d(t) metres ahead of a standing ego at step t; the row of
+    # its box in channel 2 + k tells which step's frame the channel shows -- the table the reference's observe() produced
+    sb.spawns["length"][1], sb.spawns["width"][1], sb.spawns["lane"][1] = 4.5, 1.8, sb.spawns["lane"][0]
+    o.L.orc_upload_scenarios(o.h, sb.scenarios.ctypes.data_as(C.c_void_p), len(sb.scenarios), sb.spawns.ctypes.data_as(C.c_void_p))
+    dist_of = lambda t: 4.0 + 1.5 * (t % 16)  # noqa: E731
+    spx = R / (2.0 * DIST)
+    for st in g["observe"]["steps"]:
+        t = st["t"]
+        if st["reset"]:
+            o.reset(np.zeros(1, dtype=np.int32))
+        f, i, ei = o.get_state()
+        place(f, i, 0, ex, ey, eth)
+        dd = dist_of(t)
+        place(f, i, 1, ex + dd * np.cos(eth), ey + dd * np.sin(eth), eth)
+        o.set_state(f, i, ei)
+        img = o.observe_topdown()[0]
+        for k in range(FS):
+            rows = np.nonzero(img[:, R // 2, 2 + k])[0]
+            assert len(rows) > 0 and abs(img[rows[0], R // 2, 2 + k] - TD_VEH) < 1e-12
+            d_est = (R / 2 - 0.5 - rows.mean()) / spx
+            cands = [s_ for s_ in range(max(0, t - (FS - 1) * SKIP), t + 1)]
+            src = min(cands, key=lambda s_: abs(dist_of(s_) - d_est))
+            assert abs(dist_of(src) - d_est) < 0.6 and src == st["traffic_source"][k], (t, k, src, st["traffic_source"])
+    # (6) past positions: the ego along the fixture's track, heading -90 / +90 degrees (rotation by 0 / 180 degrees)
+    for sc in g["scene"][:2]:
+        o.reset(np.zeros(1, dtype=np.int32))
+        for fr in sc["frames"]:
+            f, i, ei = o.get_state()
+            # (the fixture's track is in free space: moved onto the map by the offset of its first point)
+            x = ex + fr["ego"][0] - sc["frames"][0]["ego"][0]
+            y = ey + fr["ego"][1] - sc["frames"][0]["ego"][1]
+            place(f, i, 0, x, y, sc["ego_heading"])
+            place(f, i, 1, ex + 500.0, ey + 500.0, 0.0)
+            o.set_state(f, i, ei)
+            img = o.observe_topdown()[0]
+            want = {(int(np.floor(p[1])), int(np.floor(p[0]))) for p in fr["filled"]
+                    if 0 <= p[0] < R and 0 <= p[1] < R}  # surface (x, y) -> image [row = y][col = x]
+            got = {(int(a), int(b)) for a, b in zip(*np.nonzero(img[:, :, 1]))}
+            assert got == want, (sc["label"], fr["ego"], got, want)
+            assert len(fr["filled"]) == len([q for q in range(PS) if q * SKIP < fr["deque_len"]])
+    o.close()
+
+
 def test_ray_box_known_answers(L):
     """SURVEY §8c known answers: empty -> 1.0; a box straight ahead at distance d -> (d - L_other/2)/50 on beam 0."""
     f = L.orc_ray_box(20.0, 0.0, 0.0, 2.25, 0.9, 0.0, 0.0, 50.0, 0.0)
