@@ -400,7 +400,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         my_dn = true;
         my_fl |= PGD_F_OUT_OF_ROAD;
       }
-      r.rlane += 1;  // episode_length
+      if (r.rlane < 0x7fff) r.rlane += 1;  // episode_length (a 16-bit field: saturates; pgd_create rejects longer horizons)
       if (gcf.horizon > 0 && r.rlane >= gcf.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
       r.eprew += my_rew;
       my_fl |= PGD_F_REPORT;
@@ -1424,6 +1424,7 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   const bool marl = (cfg->marl_flags & PGD_MA_ENABLED) != 0;
   // multi-agent engines have no IDM traffic; num_traffic slots may hold static bodies (toll booths, group PGD_GROUP_NEVER)
   if (marl && (cfg->respawn_places < 0 || cfg->respawn_dests < 0)) return PGD_ERR_ARG;
+  if (marl && cfg->horizon > 0x7fff) return PGD_ERR_ARG;  // the per-agent episode length is a 16-bit field of the record
   h->d.sstride = V + (marl ? cfg->respawn_places * cfg->respawn_dests : 0);
   h->d.sub = WAVE / V < 16 ? WAVE / V : 16;  // sub-lanes per vehicle
   h->d.epw = marl ? 1 : WAVE / (V * h->d.sub);  // whole environments per wave (the multi-agent tail needs the env alone in its wave)

@@ -103,7 +103,14 @@ int pgd_gather_create(int device, int world, int rank, int n_rows, int row_float
   g->buf_bytes = (size_t)world * n_rows * row_floats * 4;
   g->ctl_off = ((size_t)nbuf * g->buf_bytes + 255) & ~(size_t)255;
   g->total_bytes = g->ctl_off + sizeof(GatherCtl);
-  HIPCHK(hipMalloc((void**)&g->base, g->total_bytes));
+  // Peers write the rows and the flag / ack words of this block over xGMI while kernels of this device poll and read them:
+  // fine-grained (device-coherent across agents) memory, as RCCL uses for its own buffers -- ordinary coarse-grained hipMalloc
+  // memory is only guaranteed coherent at kernel boundaries, so a polling kernel could keep seeing a stale flag line.
+  // PGD_GATHER_COARSE=1 forces plain hipMalloc (A/B); a runtime that refuses the flag falls back to it as well.
+  if (getenv("PGD_GATHER_COARSE") || hipExtMallocWithFlags((void**)&g->base, g->total_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    HIPCHK(hipMalloc((void**)&g->base, g->total_bytes));
+  }
   HIPCHK(hipMemset(g->base, 0, g->total_bytes));
   HIPCHK(hipMalloc((void**)&g->counters, sizeof(int) * 4 * PGD_GATHER_MAX_WORLD));
   HIPCHK(hipMemset(g->counters, 0, sizeof(int) * 4 * PGD_GATHER_MAX_WORLD));

@@ -316,6 +316,16 @@ static int topdown_build_rasters(pgd_engine* h) {
   }
   if (s->tex) { HIPCHK(hipFree(s->tex)); s->tex = nullptr; }
   if (s->tex_off) { HIPCHK(hipFree(s->tex_off)); s->tex_off = nullptr; }
+  {  // one raster per scenario, 16 bytes per square metre of map extent (1-2 MB per PGDrive-v0 map): a bank of a thousand
+     // scenarios is gigabytes -- refuse with a message instead of failing inside hipMalloc
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    if ((size_t)total > free_b / 2) {
+      fprintf(stderr, "[pgdrive_hip] top-down rasters of %d scenarios need %.1f GB (%.1f GB free): use fewer scenarios per engine\n",
+              n_scen, (double)total / 1e9, (double)free_b / 1e9);
+      return PGD_ERR_STATE;
+    }
+  }
   HIPCHK(hipMalloc(&s->tex, (size_t)(total > 0 ? total : 1)));
   HIPCHK(hipMalloc(&s->tex_off, sizeof(long long) * (size_t)n_scen));
   HIPCHK(hipMemcpyAsync(s->tex_off, off.data(), sizeof(long long) * (size_t)n_scen, hipMemcpyHostToDevice, h->stream));

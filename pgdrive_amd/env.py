@@ -31,8 +31,13 @@ class PGDriveEnv:
     def __init__(self, config=None):
         cfg = dict(config or {})
         cfg["num_envs"] = 1
-        cfg.setdefault("auto_reset", False)
-        cfg.setdefault("resample_scenario", False)
+        # the step info (step_reward, velocity, energy) is read from the engine state AFTER the step: with an in-kernel
+        # auto-reset that state would already be the next episode's on exactly the terminal steps.  The single-env surface
+        # resets through reset(), like the reference's gym.Env.
+        if cfg.get("auto_reset") or cfg.get("resample_scenario"):
+            raise ValueError("PGDriveEnv resets through reset(): auto_reset / resample_scenario belong to PGDriveVecEnv")
+        cfg["auto_reset"] = False
+        cfg["resample_scenario"] = False
         self.vec = PGDriveVecEnv(cfg)
         self.config = self.vec.config
         self.observation_space = self.vec.single_observation_space
@@ -63,14 +68,14 @@ class PGDriveEnv:
         self._done = d
         self.episode_reward += r
         fl = int(flags[0].item()) & 0xFFFFFFFF
-        f, i, _ = self.vec.engine.get_state()
+        f, i, ei = self.vec.engine.get_state()
         info = {k: bool(np.asarray(v).reshape(-1)[0]) for k, v in self.vec.info_from_flags(np.array([fl])).items()}
         cost = float(self.vec.cost_from_flags(np.array([fl]))[0])  # cost_function (pgdrive_env.py:197-207)
         energy = float(f[_abi.SF["ENERGY"], 0, 0])
         # step_reward is the shaping reward BEFORE the terminal override (pgdrive_env.py:236-246); a terminal step's is
         # re-derived on the host from the state the engine left (single env: a few lane formulas)
         shaping = r if not (info["arrive_dest"] or info["out_of_road"] or info["crash_vehicle"] or info["crash_object"]) \
-            else self._shaping_reward(f, i)
+            else self._shaping_reward(f, i, ei)
         raw = np.asarray(action, dtype=np.float64).reshape(-1)
         # the keys of BaseVehicle.after_step (base_vehicle.py:255-273), _preprocess_action (:231-236), reward / cost / done
         # functions (pgdrive_env.py:162-258) and _get_step_return (base_env.py:303-344)
@@ -83,11 +88,11 @@ class PGDriveEnv:
         self._last_energy = energy
         return obs[0].cpu().numpy(), r, d, info
 
-    def _shaping_reward(self, f, i):
+    def _shaping_reward(self, f, i, ei):
         """PGDriveEnv.reward_function up to `step_info["step_reward"] = reward` (pgdrive_env.py:209-236) from the state."""
         from . import mapdata
         SF, SI, c = _abi.SF, _abi.SI, self.config
-        scen = int(self.vec.engine.get_state()[2][_abi.EI["SCEN"], 0])
+        scen = int(ei[_abi.EI["SCEN"], 0])
         sb, mb = self.vec.scen_bank, self.vec.map_bank
         d = mb.descs[int(sb.scenarios["map"][scen])]
         sp = sb.spawns[scen * sb.V]

@@ -67,3 +67,78 @@ def test_two_rank_gather_matches_single_process(transport):
     for (o1, r1, d1), (o2, r2, d2) in zip(res[1], res[2]):
         assert o1.shape == o2.shape == (n_total, 1, 8 + 10 + 16 + 24)
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
+
+
+def _fake_world8(rank, q):
+    """One rank of a world-8 'fake' process group (torch.testing._internal.distributed.fake_pg: collectives are no-ops, the
+    Python argument checks of torch.distributed run): the StepGather of BASELINE C4's shape on that rank."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from torch.testing._internal.distributed.fake_pg import FakeStore
+    from pgdrive_amd import dist as pdist
+    world, n_local, D, A = 8, 4096, 274, 1
+    dist.init_process_group(backend="fake", rank=rank, world_size=world, store=FakeStore())
+
+    class AsNccl:  # the same group, reporting the backend name RCCL has: StepGather then lays its buffers out as for RCCL
+        def __getattr__(self, k):
+            return getattr(dist, k)
+
+        def get_backend(self):
+            return "nccl"
+
+    out = {}
+    for transport in ("root", "collective"):
+        g = pdist.StepGather(torch, AsNccl(), n_local, D, A, transport=transport)
+        W = pdist.pack_width(D, A)
+        assert g.world == world and g.rank == rank and g.W == W == 276
+        for b in range(g.nbuf):
+            send, recv = g.send[b], g.recv[b]
+            assert send.shape == (n_local, W) and send.is_contiguous() and send.dtype == torch.float32
+            if transport == "collective":
+                # RCCL / NCCL all-gather in place: the input must be exactly this rank's slice of the output
+                assert g.inplace and recv.shape == (world * n_local, W) and recv.is_contiguous()
+                assert send.data_ptr() == recv.data_ptr() + rank * n_local * W * 4
+                assert send.untyped_storage().data_ptr() == recv.untyped_storage().data_ptr()
+            else:
+                if rank == 0:
+                    # gather to the root: the receive list is world contiguous views of ONE buffer, in rank order, and the
+                    # root's own rows come from a separate send buffer (send and receive memory must not alias)
+                    assert recv.shape == (world * n_local, W) and len(g.parts[b]) == world
+                    for q_, part in enumerate(g.parts[b]):
+                        assert part.is_contiguous() and part.shape == (n_local, W)
+                        assert part.data_ptr() == recv.data_ptr() + q_ * n_local * W * 4
+                    assert send.untyped_storage().data_ptr() != recv.untyped_storage().data_ptr()
+                else:
+                    assert g.parts[b] is None and recv.shape == (n_local, W) and send.data_ptr() == recv.data_ptr()
+        calls = []
+        for t in range(5):  # double-buffered: the exchange of step t is waited for when its buffer comes round again
+            b = g.step(lambda rows: (calls.append(rows.data_ptr()), rows.fill_(float(t)))[0])
+            assert b == t % g.nbuf and calls[-1] == g.send[b].data_ptr()
+        g.drain()
+        obs, rew, done = g.result((5 - 1) % g.nbuf)
+        n_rows = world * n_local if (transport == "collective" or rank == 0) else n_local
+        assert obs.shape == (n_rows, A, D) and rew.shape == (n_rows, A) and done.shape == (n_rows, A)
+        out[transport] = g.describe()
+        g.close()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_step_gather_world8_buffer_layout_under_a_fake_process_group():
+    """RCCL readiness without hardware (the RCCL backend itself has never run: one GPU per box here).  For the shapes of BASELINE
+    C4 (8 ranks x 4096 envs x 276 floats) on the root and on a middle rank: the buffers StepGather hands to
+    `dist.gather(gather_list=...)` and to the in-place `dist.all_gather_into_tensor` obey the aliasing rules RCCL requires, the
+    double buffering addresses the right slices, and torch.distributed's own argument checks accept every call."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fake_world8, args=(r, q)) for r in (0, 3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "RCCL gather" in got[0]["root"] and "RCCL all_gather_into_tensor" in got[3]["collective"] and "in place" in got[3]["collective"]
