@@ -66,7 +66,10 @@ STATE_TOL = {
     "THETA": (1e-4, 0.0), "SPEED": (1e-4, 0.0),
     # the applied action: agents copy the clipped input (exact); traffic stores the PID / IDM-law output, whose inputs are
     # differences of ~100 m lane coordinates in fp32 (steering up to ~10, acceleration down to ~ -100)
-    "STEER": (1e-4, 2e-4), "THROTTLE": (1e-4, 2e-4), "ACT1S": (1e-4, 2e-4), "ACT1T": (1e-4, 2e-4),
+    "STEER": (1e-4, 2e-4), "ACT1S": (1e-4, 2e-4),
+    # the IDM law divides by the gap to the leader (floored at 1 cm, idm_policy.py:254-271): behind a vehicle a few cm ahead the
+    # acceleration is -(d* / gap)^2 ~ -1e5 and twice as ill-conditioned as the gap, a difference of two fp32 lane coordinates
+    "THROTTLE": (1e-4, 1e-3), "ACT1T": (1e-4, 1e-3),
     "ACT0S": (1e-6, 0.0), "ACT0T": (1e-6, 0.0),    # the older deque entry is a copy of the previous state's newer one
     "LASTX": (1e-6, 0.0), "LASTY": (1e-6, 0.0),    # copies of the pose the step started from
     "LASTHX": (1e-6, 0.0), "LASTHY": (1e-6, 0.0),
