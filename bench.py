@@ -62,7 +62,8 @@ def load_traffic(N, args):
             t = json.load(open(p))
         except Exception:
             continue
-        if (t.get("envs"), t.get("traffic"), t.get("lasers")) == (N, args.traffic, args.lasers):
+        if (t.get("envs"), t.get("traffic"), t.get("lasers"), t.get("actions", "uniform"), t.get("traffic_mode", "trigger")) == \
+                (N, args.traffic, args.lasers, args.actions, args.traffic_mode):
             return t.get("bytes_per_launch"), os.path.basename(p)
     return None, None
 

@@ -9,6 +9,9 @@ import json
 import sys
 
 O = sys.argv[1]
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096            # envs of the profiled run
+ACTIONS = sys.argv[3] if len(sys.argv) > 3 else "uniform"      # bench.py --actions
+MODE = sys.argv[4] if len(sys.argv) > 4 else "trigger"         # bench.py --traffic-mode
 
 
 def pmc(d, steady_only=False):
@@ -29,12 +32,12 @@ rc_f = sum(cf["rec_copy"]) / len(cf["rec_copy"])
 rc_w = sum(cw["rec_copy"]) / len(cw["rec_copy"])
 rw_w = sum(cw["row_write"]) / len(cw["row_write"])
 c_f, c_w = rec_bytes / (rc_f * 1024.0), rec_bytes / (rc_w * 1024.0)
-out = dict(envs=4096, traffic=16, lasers=240, kernel=kname, FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk,
+out = dict(envs=N, traffic=16, lasers=240, actions=ACTIONS, traffic_mode=MODE, kernel=kname, FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk,
            dispatches_averaged=len(steady(fetch[kname])),
            calibration=dict(rec_copy_bytes=rec_bytes, rec_copy_FETCH_SIZE_KB=rc_f, rec_copy_WRITE_SIZE_KB=rc_w, row_write_bytes=row_bytes,
                             row_write_WRITE_SIZE_KB=rw_w, fetch_correction=c_f, write_correction_records=c_w,
                             write_correction_rows=row_bytes / (rw_w * 1024.0)),
-           bytes_per_launch=(fk * c_f + wk * c_w) * 1024.0, bytes_per_env_step=(fk * c_f + wk * c_w) * 1024.0 / 4096,
+           bytes_per_launch=(fk * c_f + wk * c_w) * 1024.0, bytes_per_env_step=(fk * c_f + wk * c_w) * 1024.0 / N,
            note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --exact --steps 200 --warmup 1500` "
                 "(KB per dispatch, last quarter of the k_step dispatches = steady state). Corrections as MI355X_MICROARCH.md (HBM "
                 "section) prescribes, measured on the engine's own record pattern with profiles/r01_calib.hip.")
