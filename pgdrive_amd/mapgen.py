@@ -1,7 +1,14 @@
 """Host-side procedural map generator: our own block-incremental generation (BIG) of PGDrive maps.
 
 Runs once per map seed on the host and yields the flat *map description* consumed by `mapdata.MapBank` (lanes, roads,
-block metadata) — no dependency on the reference at run time.  It restates, in float64 like the reference:
+block metadata) — no dependency on the reference at run time.
+
+This module is NOT a re-design and does not claim to be one: the maps must come out bit-identical to the reference's (same
+topology, same coordinates, same RNG draw order), so every block class below follows the reference's construction step by
+step -- the same tool lanes, the same sequence of `rng` draws, the same radii and magic numbers -- on its own data model
+(tuple roads, `SLane` / `CLane`, `Net`).  The similarity to `component/blocks/*.py` is by necessity; what is ours is the
+flat description format, the host / device split (generation once on the host, immutable tables on the GPU) and the checks
+against the reference's exports.  It restates, in float64 like the reference:
 
 * BIG search (forward / destruct / sibling / back, MAX_TRIAL = 2)      component/algorithm/BIG.py:27-151
 * block type distribution V2                                            component/algorithm/blocks_prob_dist.py:31-49
