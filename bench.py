@@ -246,7 +246,9 @@ def run_rank(args, rank, world, local_rank):
 
     warm = args.warmup if args.exact else max(args.warmup, PREROLL_MIN)
     timed = args.steps if args.exact else max(args.steps, TIMED_MIN)
-    modes = ["replicas"] if world == 1 else (["gather", "replicas"] if args.mode == "both" else [args.mode])
+    # N > 1: the replicas pass first (no collective inside its timed loop), then the pass with the per-step gather -- if the
+    # gather transport fails on hardware it has never run on, the line still carries the replicas number and says why
+    modes = ["replicas"] if world == 1 else (["replicas", "gather"] if args.mode == "both" else [args.mode])
     gatherer = None
     if "gather" in modes:
         gatherer = pdist.StepGather(torch, dist, N, D, A, device=dev, transport=args.transport, engine_lib=eng.L)
@@ -299,14 +301,22 @@ def run_rank(args, rank, world, local_rank):
         for k in range(warm):  # pre-roll to steady-state traffic, once, shared by both modes
             step_replica(counter)
             counter += 1
+        gather_error = None
         for mode in modes:
             one_step = step_gather if mode == "gather" else step_replica
-            for k in range(16 if not args.exact else min(16, args.warmup)):  # the mode's own buffers / communicator warm-up
-                one_step(counter)
-                counter += 1
-            if gatherer is not None:
-                gatherer.drain()
-            fence()
+            try:
+                for k in range(16 if not args.exact else min(16, args.warmup)):  # the mode's own buffers / communicator warm-up
+                    one_step(counter)
+                    counter += 1
+                if gatherer is not None and mode == "gather":
+                    gatherer.drain()
+                fence()
+            except Exception as ex:  # noqa: BLE001  (a transport that does not come up: report it, keep the other pass)
+                if mode != "gather" or "replicas" not in results:
+                    raise
+                gather_error = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+                print("bench.py: the per-step gather failed on rank %d: %s" % (rank, gather_error), file=sys.stderr, flush=True)
+                break
             # HIP events bracket groups of PROF_STRIDE consecutive k_step launches over the whole timed region; the average
             # launch duration is group time / PROF_STRIDE (two event packets around EVERY launch leave the command processor
             # idle between back-to-back kernels and slow the thing being measured)
@@ -373,6 +383,8 @@ def run_rank(args, rank, world, local_rank):
         }
         if world > 1:
             out["value_mode"] = head
+            if gather_error:
+                out["gather_error"] = gather_error
             for m in results:
                 out["value_" + m] = per_step_units * timed / results[m]["elapsed"]
                 out["ms_per_step_" + m] = results[m]["elapsed"] / timed * 1e3
