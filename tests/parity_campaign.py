@@ -38,6 +38,7 @@ for mode, steps in (("driving", 1500), ("uniform", 600), ("straight", 900)):
         flip=(head[:,18:].max(axis=1)>OBS_TOL)&(head[:,:18].max(axis=1)<=OBS_TOL)
         st["neighbour_boundary_rows"]=st.get("neighbour_boundary_rows",0)+int(flip.sum())
         st["obs"]=max(st["obs"],float(head[~flip].max()), float(nb[~graze].max()))
+        st["obs_state"]=max(st.get("obs_state",0.0),float(head[~flip].max()))  # non-ray columns alone (asserted < 1e-5 in the suite)
         st["rew"]=max(st["rew"],float(np.abs(grw-orw)[same].max()))
         f,i,ei=ora.get_state(); gf,gi,gei=eng.get_state()
         agree=(gi==i).all(axis=0)&(gei==ei).all(axis=0)[:,None]

@@ -509,3 +509,39 @@ def test_step_n_equals_single_steps(multi_agent):
         assert (fa.view(np.int32) == fb.view(np.int32)).all()
     assert n_done > 20
     ea.close(); eb.close()
+
+
+def test_scripted_lane_keeping_policy_drives_to_the_destination(descs):
+    """pgd_lane_keep_actions (the library's scripted stand-in for the reference's shipped PPO expert: road-centre offset +
+    heading error -> steering, cruise control -> throttle, from the rows pgd_step wrote): 256 envs on 8 maps without traffic --
+    the ego keeps driving (mean speed near the 30 km/h target), stays on the road and most episodes end by ARRIVAL; actions are
+    reproducible (counter RNG) and inside [-1, 1]."""
+    import torch
+    from pgdrive_amd import _abi
+    from pgdrive_amd.engine import Engine
+    from tests import util
+    n = 256
+    mb, sb = util.make_banks(descs, n_maps=8, density=0.0)
+    cfg = _abi.make_config(n, num_agents=1, num_traffic=16, num_lasers=240, auto_reset=1, seed=5)
+    eng = Engine(cfg, mb, sb)
+    eng.reset(np.arange(n) % 8)
+    act = torch.zeros((n, 1, 2), dtype=torch.float32, device=eng.device)
+    act2 = torch.zeros_like(act)
+    arrive = out = steps = 0
+    speed = []
+    for t in range(900):
+        eng.lane_keep_actions(act, t)
+        if t == 10:
+            eng.lane_keep_actions(act2, t)
+            eng.sync()
+            assert torch.equal(act, act2) and float(act.abs().max()) <= 1.0
+        obs, rew, done, flags = eng.step(act)
+        eng.sync()
+        fl = flags.cpu().numpy().astype(np.uint32)[:, 0]
+        arrive += int(((fl & _abi.F_ARRIVE) != 0).sum())
+        out += int(((fl & _abi.F_OUT_OF_ROAD) != 0).sum())
+        if t % 50 == 49:
+            speed.append(float(obs[:, 0, 3].mean().item()) * 81.0 - 1.0)
+    print("scripted policy: arrivals %d, out of road %d, mean speed %.1f km/h" % (arrive, out, float(np.mean(speed))))
+    assert arrive >= 200 and out <= 0.25 * arrive and 20.0 < np.mean(speed) < 35.0
+    eng.close()

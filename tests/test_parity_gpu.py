@@ -14,7 +14,8 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
-OBS_TOL = 2.5e-5  # ray fractions: SURVEY 8c's 0.5 mm at the shortest fan range in the suite (20 m); state floats stay < 1e-5
+OBS_TOL = 2.5e-5  # ray-cast columns (lidar, side / lane-line fans): SURVEY 8c's 0.5 mm at the shortest fan range in the suite (20 m)
+STATE_OBS_TOL = 1e-5  # every other column (ego state, navigation, neighbour rows): SURVEY 8c's 1e-5, asserted separately
 REW_TOL = 2e-4
 
 
@@ -72,6 +73,7 @@ def _compare_step(torch, eng, ora, act, stats):
         if nl:
             fan[-nl:] = True
         stats["obs"] = max(stats["obs"], float(d[:, ~fan].max()))
+        stats["obs_state"] = max(stats.get("obs_state", 0.0), float(d[:, ~fan].max()))  # the non-ray columns on their own
         if ks + km:  # same treatment as the lidar beams below, plus origin-on-a-line-edge flips
             n_det = int(fan.sum()) - (nl if nl else 0)
             beams = d[:, fan][:, :n_det]
@@ -162,7 +164,8 @@ def test_throughput_mode_parity(descs, monkeypatch):
         ora.set_state(f32, i, ei)
         eng.set_state(f32, i, ei)
     print("throughput mode parity:", stats, "episodes", n_done, "state fields (x tolerance):", {k: round(v, 3) for k, v in worst.items()})
-    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] == 0 and n_done > 20
+    assert stats["obs"] < OBS_TOL and stats["obs_state"] < STATE_OBS_TOL and stats["rew"] < REW_TOL
+    assert stats["flag_mismatch"] == 0 and n_done > 20
     assert not util.state_failures(worst), util.state_failures(worst)
     assert stats.get("grazing", 0) <= 1e-5 * stats.get("beams", 1) + 2
     monkeypatch.setenv("PGD_PACK", "0")
@@ -219,7 +222,7 @@ def _teacher_forced(descs, num_traffic, num_lasers):
         eng.set_state(f32, i, ei)
     print("teacher-forced parity:", stats, "pose", pose, "idm ties", idm_ties, "of", active,
           "state fields (x tolerance):", {k: round(v, 3) for k, v in worst.items()})
-    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and pose < 1e-3
+    assert stats["obs"] < OBS_TOL and stats["obs_state"] < STATE_OBS_TOL and stats["rew"] < REW_TOL and pose < 1e-3
     assert not util.state_failures(worst), util.state_failures(worst)
     assert idm_ties <= 2e-3 * max(active, 1) + 2
     assert stats["flag_mismatch"] == 0  # done / flags bit-exact (north star); no tie class occurs on these 8 maps
