@@ -405,6 +405,10 @@ def run_rank(args, rank, world, local_rank):
                         "of different engines overlap (asynchronous vector-env groups)" % (args.engines, N)}
                if args.engines > 1 else {}),
             **({"active_vehicles_mean": 1.0 + work["driving_traffic_mean"], **work} if work else {}),
+            "step_kernel": ("throughput mode: one vehicle per lane, 3 envs per wave (pgd_create picks it from 16384 envs per engine)"
+                            if (args.workload == "c3" and args.traffic >= 1 and args.lasers > 0 and (64 // (1 + args.traffic)) >= 2 and
+                                (os.environ.get("PGD_PACK", "1" if N >= 16384 else "0") != "0")) else
+                            "one env per wave") if args.workload == "c3" else "multi-agent: one env per wave",
             "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
             "engines_per_gpu": max(1, args.engines), "env_groups": args.groups,
             **({"open_loop": "pgd_step_n: %d steps of the action ring per call, one observation per call -- NOT the metric's closed "
