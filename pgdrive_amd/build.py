@@ -19,6 +19,11 @@ def hipcc():
 
 
 FAST_FP = ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero", "-freciprocal-math"]
+# Optimisation level, measured on the step kernel (profiles/r03_notes.md): -O3 23.65 us, -O2 23.16, -O1 23.56, -Oz 24.16,
+# -Os 22.92, -Os without SLP vectorisation (packed f32 VALU is slower than two scalar ops on this hardware) 22.72.  -Os hoists and
+# batches less: 105 instead of 126 VGPRs, 34.6 instead of 36.6 KB of code for the benchmark kernel; every other kernel is as fast
+# or faster with it (C5 +1 %, 32768 envs +1 %, dense traffic +1 %, top-down unchanged).
+OPT = ["-Os", "-fno-slp-vectorize"]
 
 
 def needs_build():
@@ -34,7 +39,7 @@ def build(force=False, verbose=False, extra=()):
     # the kernel is issue-bound and the parity tolerances are 1e-5 and looser: fp32 `/` compiles to rcp * x and sqrtf to
     # the rsq sequence (2.5 ulp) instead of the correctly rounded, denormal-safe expansions (about ten VALU instructions
     # each); sin / cos / atan2 / exp keep their full-precision library versions
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", *FAST_FP, "-shared", "-fPIC", "-o", LIB, SRC] + list(extra)
+    cmd = [hipcc(), "--offload-arch=gfx950", *OPT, "-std=c++17", *FAST_FP, "-shared", "-fPIC", "-o", LIB, SRC] + list(extra)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

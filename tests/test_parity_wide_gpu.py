@@ -213,7 +213,7 @@ def test_ieee_build_gives_the_same_discrete_outcomes(descs):
     from pgdrive_amd import build, engine
     td = tempfile.mkdtemp(prefix="pgd_ieee_")
     lib = os.path.join(td, "libpgdrive_hip_ieee.so")
-    subprocess.check_call([build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", lib, build.SRC])
+    subprocess.check_call([build.hipcc(), "--offload-arch=gfx950", *build.OPT, "-std=c++17", "-shared", "-fPIC", "-o", lib, build.SRC])
     L_ieee = engine.load_library(path=lib)
     n_envs = 256
     mb, sb = util.make_banks(descs, n_maps=8)

@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 import torch
 from pgdrive_amd import _abi, mapdata, scenario, build, mapgen
 lib = os.path.join("gpurun_out", "libpgd_prof.so")
-subprocess.check_call([build.hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', *build.FAST_FP, '-shared', '-fPIC', '-DPGD_PROF', '-o', lib, build.SRC] + os.environ.get('PGD_EXTRA', '').split())
+subprocess.check_call([build.hipcc(), '--offload-arch=gfx950', *build.OPT, '-std=c++17', *build.FAST_FP, '-shared', '-fPIC', '-DPGD_PROF', '-o', lib, build.SRC] + os.environ.get('PGD_EXTRA', '').split())
 from pgdrive_amd import engine
 engine._LIBH = None
 L = engine.load_library(path=lib); engine._LIBH = L

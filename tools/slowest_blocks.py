@@ -3,7 +3,7 @@ sys.path.insert(0,'.')
 import torch
 from pgdrive_amd import _abi, bank, mapdata, scenario, build
 lib = os.path.join("gpurun_out", "libpgd_prof.so")
-subprocess.check_call([build.hipcc(), '--offload-arch=gfx950','-O3','-std=c++17',*build.FAST_FP,'-shared','-fPIC','-DPGD_PROF','-o',lib, build.SRC])
+subprocess.check_call([build.hipcc(), '--offload-arch=gfx950',*build.OPT,'-std=c++17',*build.FAST_FP,'-shared','-fPIC','-DPGD_PROF','-o',lib, build.SRC])
 from pgdrive_amd import engine
 L = engine.load_library(path=lib); engine._LIBH = L
 descs = bank.load_descriptions()
