@@ -160,8 +160,11 @@ DEV void state_block(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, co
     else if (q == 7) {
       // acos(clip(cos_beta, 0, 1)) (state_obs.py:87-92) evaluated as atan2(|cross|, dot): identical for unit vectors,
       // but well-conditioned in fp32 near beta = 0 where 1 - cos(beta) underflows the mantissa
+      // ... and only beta <= 0.1 rad survives the clip below: there atan(z) = z - z^3 / 3 + z^5 / 5 to 1.4e-8 (z <= 0.1004), six
+      // instructions instead of the library atan2f's 55; anything larger is 1 after the clip whatever its exact value
       float dot = hx * ag.lhx + hy * ag.lhy, cross = hx * ag.lhy - hy * ag.lhx;
-      float beta = dot <= 0.0f ? 0.5f * PGD_PI : atan2f(fabsf(cross), dot);
+      const float z = dot > 0.0f ? fabsf(cross) / dot : 1.0f, q = z * z;
+      float beta = z > 0.11f ? 1.0f : z * (1.0f + q * (-1.0f / 3.0f + q * 0.2f));
       v = clipf(beta / 0.1f, 0.0f, 1.0f);
       col = o_ego + 5;
     } else {  // lanes 8..12 -> checkpoint 1, 13..17 -> checkpoint 2
