@@ -146,6 +146,7 @@ DEV float clipf(float a, float lo, float hi) { return fminf(fmaxf(a, lo), hi); }
 DEV float norm2(float x, float y) { return sqrtf(x * x + y * y); }
 DEV float wrap_to_pi(float x) {  // ((x + pi) % (2 pi)) - pi with Python's sign-of-divisor modulo: result in [-pi, pi)
 #pragma clang fp contract(off)
+#pragma clang fp reassociate(off)
   float y = x + PGD_PI;
   float r = y - 2.0f * PGD_PI * floorf(y * (0.5f / PGD_PI));
   r = r < 0.0f ? r + 2.0f * PGD_PI : (r >= 2.0f * PGD_PI ? r - 2.0f * PGD_PI : r);
@@ -170,8 +171,9 @@ DEV uint32_t pgd_rng(uint32_t seed, uint32_t a, uint32_t b, uint32_t c) {
 // ---------------------------------------------------------------------------------------------------------------------
 DEV void lane_local(const pgd_lane& l, float px, float py, float& lon, float& lat) {
   // no fp contraction inside: the own-lane coordinate is carried in the vehicle record AND re-derived by k_derive after
-  // pgd_set_state; both must give the same bits, whatever the compiler fuses around the inlined copy
+  // pgd_set_state; both must give the same bits, whatever the compiler fuses or re-associates around the inlined copy
 #pragma clang fp contract(off)
+#pragma clang fp reassociate(off)
   float dx = px - l.ax, dy = py - l.ay;
   if (l.dir == 0.0f) {
     lon = dx * l.bx + dy * l.by;
