@@ -41,6 +41,7 @@ struct ObsLds {  // bodies inside the lidar broad phase of the observing agent, 
   float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV];
   float bdist[MAXV];  // centre distance; +inf for traffic objects, which are never ranked as neighbour vehicles
   int bi0[MAXV], bcnt[MAXV];  // lidar beams [bi0, bi0 + bcnt) mod num_lasers that can reach the body (conservative)
+  unsigned bsec[MAXV];        // bit q: that window meets the beams [64 q, 64 q + 63] -- what one wave casts in one round
   int bslot[MAXV];            // slot of the body in its env
   int rank_slot[16];          // PGD_MA_OTHERS_STATE: slot of the neighbour of rank r (-1 = none) ...
   float rank_spd[16];         // ... and its speed [km/h] as the observer sees it (0 for a static finished agent)
@@ -117,6 +118,19 @@ DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, flo
       }
     }
     L.bi0[k] = i0; L.bcnt[k] = cnt;
+    {  // sectors of 64 consecutive beams the window reaches (more than 32 sectors: every one)
+      unsigned sec = 0xffffffffu;
+      if (cnt < NL && NL <= 2048) {
+        sec = 0u;
+        const int last = i0 + cnt - 1;  // the window is [i0, last], possibly past NL - 1 (wraps)
+        for (int q = 0; q * 64 < NL; ++q) {
+          const int lo = q * 64, hi = min(lo + 63, NL - 1);
+          const bool hit = (i0 <= hi && last >= lo) || (last >= NL && last - NL >= lo);
+          sec |= hit ? (1u << q) : 0u;
+        }
+      }
+      L.bsec[k] = sec;
+    }
     L.bslot[k] = o;
   }
   if (o == 0) { L.n = __popcll(m); L.nveh = __popcll(mv_); }
@@ -312,18 +326,27 @@ DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, 
   }
   PHASE_MARK(23);  // obs: neighbours
   // lidar (distance_detector.py:65-94, cutils.pyx:60-142): beam i at theta + i*2pi/N, nearest hit fraction
-  for (int i = tid; i < NL; i += nt) {
-    const float2 bd = d.beam[i];  // (cos, sin)(i * 2 pi / NL); rotated by the heading
+  // every lane of the row takes part in every round (the ballot below needs the body lanes), beams past the fan are not stored
+  for (int i0 = 0; i0 < NL; i0 += nt) {
+    const int i = i0 + tid;
+    const bool on = i < NL;
+    const float2 bd = d.beam[on ? i : 0];  // (cos, sin)(i * 2 pi / NL); rotated by the heading
     const float dx = R * (bd.x * hx - bd.y * hy), dy = R * (bd.y * hx + bd.x * hy);
     float best = 1.0f;
-    for (int k = 0; k < n; ++k) {
+    // the beams a wave casts in one round lie in one sector of 64 (nt is a multiple of 64): bodies whose window misses the sector
+    // are skipped for the whole wave -- a scalar walk over the set bits of a ballot -- the others take the per-beam window test
+    const int lane64 = tid & (WAVE - 1);
+    const int sec = (i0 + (tid & ~(WAVE - 1))) >> 6;
+    unsigned long long todo = __ballot(lane64 < n && ((L.bsec[lane64 < n ? lane64 : 0] >> (sec & 31)) & 1u) != 0u);
+    for (; todo != 0ull; todo &= todo - 1ull) {
+      const int k = __builtin_ctzll(todo);
       int off = i - L.bi0[k];
       off += off < 0 ? NL : 0;
-      if (off < L.bcnt[k])
+      if (on && off < L.bcnt[k])
         best = fminf(best, shape_ray<OBJ>(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
     }
     if (!STD) best = lidar_noise(d, ag.env, ag.slot, ag.tick, i, best);
-    row[o_oth + per_other * NO + i] = best;
+    if (on) row[o_oth + per_other * NO + i] = best;
   }
   PHASE_MARK(24);  // obs: lidar
 }
