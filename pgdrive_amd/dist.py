@@ -66,7 +66,9 @@ class StepGather:
         obs, reward, done = g.result(b)                              # [world * n_local, ...] once the exchange has landed
     """
     def __init__(self, torch, dist, n_local, obs_dim, num_agents=1, device="cpu", transport="collective", nbuf=2,
-                 engine_lib=None):
+                 engine_lib=None, exchange_when_alone=False):
+        """exchange_when_alone: run the collective even in a world of one rank (the single-GPU box's RCCL check: communicator
+        set-up, in-place all_gather / gather launches, stream ordering against k_step); by default one rank exchanges nothing."""
         self.torch, self.dist = torch, dist
         on = dist is not None and dist.is_initialized()
         self.world = dist.get_world_size() if on else 1
@@ -74,7 +76,7 @@ class StepGather:
         self.n_local, self.D, self.A = n_local, obs_dim, num_agents
         self.W = pack_width(obs_dim, num_agents)
         self.nbuf = nbuf
-        self.transport = transport if self.world > 1 else "local"
+        self.transport = transport if (self.world > 1 or (on and exchange_when_alone and transport != "peer")) else "local"
         self.backend = dist.get_backend() if on else "none"
         self.k = 0
         self.pending = [None] * nbuf

@@ -54,7 +54,7 @@ def test_packed_rows_equal_the_plain_outputs(descs):
         b.close()
 
 
-def _worker(rank, world, port, n_total, steps, transport, q):
+def _worker(rank, world, port, n_total, steps, transport, q, backend="gloo"):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -65,8 +65,10 @@ def _worker(rank, world, port, n_total, steps, transport, q):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
-    if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    on = world > 1 or backend == "nccl"
+    if on:
+        kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     descs = bank.get_descriptions(range(1000, 1004))
     mb = mapdata.MapBank(descs)
     sb = scenario.ScenarioBank(descs, [d["seed"] for d in descs], num_traffic=16)
@@ -75,8 +77,10 @@ def _worker(rank, world, port, n_total, steps, transport, q):
     cfg = _abi.make_config(n, num_traffic=16, num_lasers=240, seed=5, env_base=lo)  # RNG streams keyed by the GLOBAL env index
     eng = Engine(cfg, mb, sb, device=0)
     eng.reset(pdist.scenario_ids_for(lo, hi, 4))
-    g = pdist.StepGather(torch, dist if world > 1 else None, n, eng.D, eng.A, device=eng.device, transport=transport,
-                         engine_lib=eng.L)
+    g = pdist.StepGather(torch, dist if on else None, n, eng.D, eng.A, device=eng.device, transport=transport,
+                         engine_lib=eng.L, exchange_when_alone=backend == "nccl")
+    if backend == "nccl":
+        assert g.transport == transport and g.backend == "nccl" and "RCCL" in g.describe()
     rng = np.random.default_rng(0)
     outs = []
     with torch.cuda.stream(eng.stream):
@@ -91,17 +95,17 @@ def _worker(rank, world, port, n_total, steps, transport, q):
     if rank == 0:
         q.put(outs)
     g.close()
-    if world > 1:
+    if on:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
 
 
-def _run_world(world, n_total, steps, transport, port):
+def _run_world(world, n_total, steps, transport, port, backend="gloo"):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, steps, transport, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, steps, transport, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=500)
@@ -127,6 +131,19 @@ def test_two_rank_engine_gather_matches_single_process(transport):
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
         n_done += int(d1.sum())
     assert n_done > 0
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("transport", ["collective", "root"])
+def test_rccl_executes_the_step_exchange_on_one_rank(transport):
+    """The box has one GPU and RCCL refuses two ranks on one device, so the most that can run here is a world of ONE rank with
+    backend "nccl": communicator set-up bound to the device, the in-place all_gather_into_tensor / the gather to rank 0 launched
+    by RCCL after every k_step on the engine's stream, double-buffered as in the N > 1 bench.  Rows must equal the engine's own."""
+    n_total, steps = 64, 60
+    one = _run_world(1, n_total, steps, "collective", 29721)
+    rccl = _run_world(1, n_total, steps, transport, dict(collective=29723, root=29725)[transport], backend="nccl")
+    for (o1, r1, d1), (o2, r2, d2) in zip(one, rccl):
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
 
 
 @pytest.mark.timeout(900)

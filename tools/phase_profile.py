@@ -10,7 +10,7 @@ engine._LIBH = None
 L = engine.load_library(path=lib); engine._LIBH = L
 L.pgd_debug_phase_cycles.argtypes=[C.c_void_p, C.c_void_p, C.c_int]
 descs = bank.load_descriptions()
-mb = mapdata.MapBank(descs); sb = scenario.ScenarioBank(descs,[d['seed'] for d in descs])
+mb = mapdata.MapBank(descs); sb = scenario.ScenarioBank(descs,[d['seed'] for d in descs], traffic_mode=os.environ.get('TRAFFIC','trigger'))
 N=int(sys.argv[2]) if len(sys.argv)>2 else 4096
 mode = sys.argv[1] if len(sys.argv)>1 else 'uniform'
 cfg=_abi.make_config(N)
