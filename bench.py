@@ -339,6 +339,7 @@ def run_rank(args, rank, world, local_rank):
                 elapsed = float(t.item())
             results[mode] = dict(elapsed=elapsed, prof=prof)
 
+    step_kernel = eng.describe_step()  # which k_step instantiation the timed launches were (pgd_describe_step)
     # how much work a step does at this point of the run: 5 snapshots of the state, 50 untimed steps apart
     work = None
     if args.workload == "c3":
@@ -405,10 +406,7 @@ def run_rank(args, rank, world, local_rank):
                         "of different engines overlap (asynchronous vector-env groups)" % (args.engines, N)}
                if args.engines > 1 else {}),
             **({"active_vehicles_mean": 1.0 + work["driving_traffic_mean"], **work} if work else {}),
-            "step_kernel": ("throughput mode: one vehicle per lane, 3 envs per wave (pgd_create picks it from 16384 envs per engine)"
-                            if (args.workload == "c3" and args.traffic >= 1 and args.lasers > 0 and (64 // (1 + args.traffic)) >= 2 and
-                                (os.environ.get("PGD_PACK", "1" if N >= 16384 else "0") != "0")) else
-                            "one env per wave") if args.workload == "c3" else "multi-agent: one env per wave",
+            "step_kernel": step_kernel,
             "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
             "engines_per_gpu": max(1, args.engines), "env_groups": args.groups,
             **({"open_loop": "pgd_step_n: %d steps of the action ring per call, one observation per call -- NOT the metric's closed "

@@ -287,6 +287,11 @@ int pgd_group_sync(pgd_handle h, int group);
 int pgd_lane_keep_actions(pgd_handle h, const float* d_obs /*[N,1,D]*/, float* d_actions /*[N,1,2]*/, float k_lat, float k_head,
                           float v_target_kmh, float noise, uint32_t tick);
 
+/* Which step kernel the last pgd_step / pgd_step_packed / pgd_step_group call of this engine launched, as text ("" before the
+ * first step): one env per wave, several envs per wave, throughput mode, two waves per env, and whether it is the instantiation
+ * specialised for the reference's default single-agent configuration.  For benchmark lines and tests; no reference counterpart. */
+int pgd_describe_step(pgd_handle h, char* buf, int cap);
+
 /* Checkpoint / resume (BaseVehicle.get_state/set_state, base_vehicle.py:683-698): raw SoA state blobs.
  * Layout: nf float fields then ni int fields, each [N*V]; query sizes with pgd_state_dims. HOST buffers. */
 int pgd_state_dims(pgd_handle h, int* n_float_fields, int* n_int_fields, int* n_env_int_fields);

@@ -129,10 +129,44 @@ union StepUnion {
 // a wave; a workgroup-scope barrier would also wait for every global load and store in flight (release / acquire fences).
 DEV void step_sync() { row_sync<true>(); }
 
-template <bool ONE_ENV, bool MARL, bool OBJ, bool STD = false>
+// FIX: the engine runs the reference's default single-agent configuration (PGDriveEnv defaults, pgdrive_env.py:22-109: 1 ego + 16
+// traffic slots, 240 beams over 50 m, 4 neighbours, 5 x 0.02 s, continuous actions, the default reward scheme) through plain
+// pgd_step.  The instantiation writes those values over its copy of the kernel argument: every read of such a field folds to a
+// constant (loop bounds, row offsets, divisors, dead branches) instead of being fetched from the kernel-argument segment at each
+// use -- the scalar registers are full, and a fetch right before its use costs its whole latency (profiles/r03_notes.md).
+// pgd_step picks the instantiation only when fix_config_matches() holds, so its results are those of the general kernel.
+#define PGD_FIX_V 17
+// one list for the device (assignment) and the host (test): F(field, value)
+#define PGD_FIX_FIELDS(F, d, c, one_env)                                                                                            \
+  F(d.V, PGD_FIX_V) F(d.A, 1) F(d.T, PGD_FIX_V - 1) F(d.D, 274) F(d.sstride, PGD_FIX_V) F(d.use_imask, 1)                            \
+  F(d.sub, (one_env ? WAVE / PGD_FIX_V : 1)) F(d.epw, (one_env ? 1 : WAVE / PGD_FIX_V)) F(d.pack_obs, (one_env ? 0 : 1))             \
+  F(d.ostride, 274) F(d.prow, nullptr) F(d.unit_off, 0)                                                                             \
+  F(c.num_agents, 1) F(c.num_traffic, PGD_FIX_V - 1) F(c.num_lasers, 240) F(c.num_others, 4) F(c.lidar_dist, 50.0f)                 \
+  F(c.dt, 0.02f) F(c.decision_repeat, 5) F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0)                     \
+  F(c.enable_reverse, 0) F(c.marl_flags, 0) F(c.use_lateral, 0) F(c.out_of_route_done, 0) F(c.success_reward, 10.0f)                \
+  F(c.out_of_road_penalty, 5.0f) F(c.crash_vehicle_penalty, 5.0f) F(c.crash_object_penalty, 5.0f)                                   \
+  F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f) F(c.side_lasers, 0) F(c.lane_line_lasers, 0)                                    \
+  F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f)
+template <bool ONE_ENV>
+DEV void write_fixed_config(PgdDev& d) {
+  pgd_config& c = d.cfg;
+#define PGD_F_SET(f, v) f = v;
+  PGD_FIX_FIELDS(PGD_F_SET, d, c, ONE_ENV)
+#undef PGD_F_SET
+}
+static bool fix_config_matches(const PgdDev& d, bool one_env) {
+  const pgd_config& c = d.cfg;
+  bool ok = true;
+#define PGD_F_TEST(f, v) ok = ok && (f == v);
+  PGD_FIX_FIELDS(PGD_F_TEST, d, c, one_env)
+#undef PGD_F_TEST
+  return ok;
+}
+template <bool ONE_ENV, bool MARL, bool OBJ, bool STD = false, bool FIX = false>
 __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
                                                 float* __restrict__ obs) {
+  if (FIX) write_fixed_config<ONE_ENV>(d);
 
   __shared__ StepUnion U;
   Snap& S = U.step.S;
@@ -1323,6 +1357,8 @@ struct pgd_engine {
   bool has_objects;  // some spawn record is a traffic object (pgd_upload_scenarios): selects the OBJ kernels
   bool step_timing;  // record ev0 / ev1 around every step (pgd_last_step_ms)
   bool row_observe;  // PGD_ROW_OBSERVE was set when the engine was created (debug / A-B: k_observe per row instead of k_observe_env)
+  const char* last_step_kernel;  // what the last pgd_step* call launched (pgd_describe_step)
+  bool no_fix;       // PGD_NO_FIX: never pick the kernel specialised for the default configuration (A/B, debugging)
   bool no_fuse;      // PGD_NO_FUSE was set when the engine was created (debug: always run the stand-alone k_observe)
   bool prof_fused;
   int two_wave;      // k_step2 (two waves per env) for single-ego engines without traffic objects: PGD_TWO_WAVE = 0 / 1
@@ -1410,6 +1446,7 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   pgd_engine* h = (pgd_engine*)calloc(1, sizeof(pgd_engine));
   h->device = device;
   h->no_fuse = getenv("PGD_NO_FUSE") != nullptr;
+  h->no_fix = getenv("PGD_NO_FIX") != nullptr;
   h->row_observe = getenv("PGD_ROW_OBSERVE") != nullptr;
   h->two_wave = getenv("PGD_TWO_WAVE") ? atoi(getenv("PGD_TWO_WAVE")) : 0;
   h->d.cfg = *cfg;
@@ -1733,12 +1770,18 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   int blocks = (n_env_launch + h->d.epw - 1) / h->d.epw;
   if (marl && h->d.epw != 1) return PGD_ERR_STATE;  // the multi-agent tail needs the env in one wave (V >= 33 or SUB split)
   void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*) = k_step<false, false, false>;
+  const char* kname = h->d.pack_obs ? "k_step: whole envs side by side in a wave, one vehicle per lane (throughput mode)"
+                                    : (h->d.epw == 1 ? "k_step: one env per wave" : "k_step: several envs per wave");
   if (marl) kern = h->has_objects ? k_step<true, true, true> : k_step<true, true, false>;  // objects = toll booths
   else if (h->d.epw == 1) {
     const pgd_config& c = h->d.cfg;
     const bool std_obs = c.side_lasers == 0 && c.lane_line_lasers == 0 && !c.random_agent_model &&
                          c.lidar_gaussian_noise <= 0.0f && c.lidar_dropout_prob <= 0.0f;
     kern = h->has_objects ? k_step<true, false, true> : (std_obs ? k_step<true, false, false, true> : k_step<true, false, false>);
+    if (!h->has_objects && std_obs && !h->no_fix && fix_config_matches(dv, true)) {
+      kern = k_step<true, false, false, true, true>;
+      kname = "k_step: one env per wave, specialised for the default single-agent configuration";
+    }
   }
   else if (h->has_objects) kern = k_step<false, false, true>;
   else if (h->d.pack_obs) {
@@ -1746,10 +1789,15 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
     const bool std_obs = c.side_lasers == 0 && c.lane_line_lasers == 0 && !c.random_agent_model &&
                          c.lidar_gaussian_noise <= 0.0f && c.lidar_dropout_prob <= 0.0f;
     if (std_obs) kern = k_step<false, false, false, true>;
+    if (std_obs && !h->no_fix && fix_config_matches(dv, false)) {
+      kern = k_step<false, false, false, true, true>;
+      kname = "k_step: whole envs side by side in a wave (throughput mode), specialised for the default single-agent configuration";
+    }
   }
   // two waves per env (k_step2): one ego, at least one traffic slot, no traffic objects, the observation fused or not wanted
   const bool two = h->two_wave && !marl && h->d.epw == 1 && h->d.A == 1 && h->d.T >= 1 && h->d.T <= 60 && !h->has_objects &&
                    (fuse || !d_obs);
+  h->last_step_kernel = two ? "k_step2: two waves per env" : kname;
   if (two) {
     const pgd_config& c = h->d.cfg;
     const bool std_obs = c.side_lasers == 0 && c.lane_line_lasers == 0 && !c.random_agent_model &&
@@ -1831,6 +1879,12 @@ int pgd_group_stream(pgd_handle h, int group, void** hip_stream) {
 int pgd_group_sync(pgd_handle h, int group) {
   if (!h || group < 0 || group >= h->n_groups || !h->gstreams) return PGD_ERR_ARG;
   HIPCHK(hipStreamSynchronize(h->gstreams[group]));
+  return PGD_OK;
+}
+
+int pgd_describe_step(pgd_handle h, char* buf, int cap) {
+  if (!h || !buf || cap <= 0) return PGD_ERR_ARG;
+  snprintf(buf, (size_t)cap, "%s", h->last_step_kernel ? h->last_step_kernel : "");
   return PGD_OK;
 }
 

@@ -26,6 +26,7 @@ _SIGS = {
     "pgd_get_state": (C.c_int, [C.c_void_p] * 4),
     "pgd_set_state": (C.c_int, [C.c_void_p] * 4),
     "pgd_observe": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pgd_describe_step": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "pgd_lane_keep_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32]),
     "pgd_topdown_channels": (C.c_int, [C.POINTER(_abi.TopDownConfig)]),
     "pgd_topdown_enable": (C.c_int, [C.c_void_p, C.POINTER(_abi.TopDownConfig)]),
@@ -209,6 +210,12 @@ class Engine:
         _chk(self.L.pgd_step_n(self.h, C.c_void_p(action_ring.data_ptr()), int(action_ring.shape[0]), int(first), int(n_steps), p_obs,
                                C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(flags.data_ptr())), "pgd_step_n")
         return (self.obs if want_obs else None), rew, done, flags
+
+    def describe_step(self):
+        """Which step kernel the last step call launched (pgd_describe_step)."""
+        buf = C.create_string_buffer(256)
+        _chk(self.L.pgd_describe_step(self.h, buf, 256), "pgd_describe_step")
+        return buf.value.decode()
 
     def lane_keep_actions(self, out, tick, obs=None, k_lat=1.0, k_head=2.0, v_target_kmh=30.0, noise=0.05):
         """Scripted lane-keeping actions for the ego from the last observation (pgd_lane_keep_actions): an action stream that

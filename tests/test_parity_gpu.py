@@ -186,6 +186,48 @@ def test_throughput_mode_parity(descs, monkeypatch):
         assert (i1 == i2).all() and (e1 == e2).all(), "integer state differs at step %d" % t
 
 
+@pytest.mark.parametrize("pack", ["0", "1"])
+@pytest.mark.parametrize("traffic_mode", ["trigger", "respawn"])
+def test_default_configuration_kernel_matches_the_general_kernel(descs, monkeypatch, pack, traffic_mode):
+    """pgd_step launches an instantiation of k_step specialised for the reference's default single-agent configuration (the
+    configuration values are compile-time constants in it) whenever the engine's configuration is exactly that; PGD_NO_FIX=1
+    keeps the general kernel.  Same state, same actions: flags, done and the integer state are bit-identical, observation and
+    reward agree to rounding (constant folding reorders a few fp32 operations).  Any other configuration gets the general kernel."""
+    monkeypatch.setenv("PGD_PACK", pack)
+    n_envs = 65
+    monkeypatch.delenv("PGD_NO_FIX", raising=False)
+    torch, fix, _, _ = _engines(descs, n_envs, seed=3, resample_scenario=1, traffic_mode=traffic_mode)
+    _, other, _, _ = _engines(descs, n_envs, seed=3, resample_scenario=1, traffic_mode=traffic_mode, num_lasers=120)
+    monkeypatch.setenv("PGD_NO_FIX", "1")
+    _, gen, _, _ = _engines(descs, n_envs, seed=3, resample_scenario=1, traffic_mode=traffic_mode)
+    ids = np.arange(n_envs) % 8
+    fix.reset(ids); gen.reset(ids); other.reset(ids)
+    rng = np.random.default_rng(21)
+    n_done = 0
+    for t in range(300):
+        act = util.driving_actions(rng, n_envs)
+        if t % 4 == 0:
+            act[::3, 0, :] = 1.0
+        f, i, ei = gen.get_state()
+        fix.set_state(f, i, ei)
+        a = torch.from_numpy(act).to(gen.device)
+        o1, r1, d1, f1 = [x.clone() for x in gen.step(a)]
+        o2, r2, d2, f2 = [x.clone() for x in fix.step(a)]
+        gen.sync(); fix.sync()
+        assert torch.equal(d1, d2) and torch.equal(f1, f2), "flags differ at step %d" % t
+        assert float((o1 - o2).abs().max()) < 2e-6 and float((r1 - r2).abs().max()) < 2e-5
+        g1, i1, e1 = gen.get_state()
+        g2, i2, e2 = fix.get_state()
+        assert (i1 == i2).all() and (e1 == e2).all(), "integer state differs at step %d" % t
+        assert np.abs(g1 - g2).max() < 1e-4
+        n_done += int(d1.sum())
+    assert n_done > 20
+    other.step(torch.from_numpy(util.driving_actions(rng, n_envs)).to(other.device)); other.sync()
+    assert "specialised for the default" in fix.describe_step()
+    assert "specialised" not in gen.describe_step() and "specialised" not in other.describe_step()
+    assert ("throughput mode" in fix.describe_step()) == (pack == "1")
+
+
 def _teacher_forced(descs, num_traffic, num_lasers):
     n_envs = 64
     torch, eng, ora, cfg = _engines(descs, n_envs, num_traffic=num_traffic, num_lasers=num_lasers)
