@@ -101,6 +101,18 @@ DEV LaneMap lane_map(const PgdDev& d, int unit, int n_units) {
 
 
 #define FUSE_MAX_AGENTS 8
+// first 64 bytes of a spawn record (everything but the route arrays) into a local copy; the copy is only ever read by field, so it
+// lives in registers and the fields nobody reads cost nothing
+DEV void spawn_head_load(const pgd_spawn* sp, pgd_spawn& out) {
+  static_assert(offsetof(pgd_spawn, ckpt) == 64 && sizeof(pgd_spawn) % 16 == 0, "spawn record head = 4 x 16 bytes");
+  const float4* q = reinterpret_cast<const float4*>(sp);
+  float4* o = reinterpret_cast<float4*>(&out);
+  const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+  o[0] = a; o[1] = b; o[2] = c; o[3] = e;
+}
+template <bool REG> DEV const pgd_spawn& spawn_ref(const pgd_spawn& regs, const pgd_spawn* mem) {
+  if constexpr (REG) return regs; else return *mem;
+}
 #ifndef PGD_WAVES_PER_SIMD
 #define PGD_WAVES_PER_SIMD 4  // <=128 VGPRs: 4096 envs = 4096 waves are then all resident at once (16 per CU)
 #endif
@@ -130,8 +142,8 @@ union StepUnion {
 DEV void step_sync() { row_sync<true>(); }
 
 // FIX: the engine runs the reference's default single-agent configuration (PGDriveEnv defaults, pgdrive_env.py:22-109: 1 ego + 16
-// traffic slots, 240 beams over 50 m, 4 neighbours, 5 x 0.02 s, continuous actions, the default reward scheme) through plain
-// pgd_step.  The instantiation writes those values over its copy of the kernel argument: every read of such a field folds to a
+// traffic slots, 240 beams over 50 m, 4 neighbours, 5 x 0.02 s, continuous actions, the default reward scheme).
+// The instantiation writes those values over its copy of the kernel argument: every read of such a field folds to a
 // constant (loop bounds, row offsets, divisors, dead branches) instead of being fetched from the kernel-argument segment at each
 // use -- the scalar registers are full, and a fetch right before its use costs its whole latency (profiles/r03_notes.md).
 // pgd_step picks the instantiation only when fix_config_matches() holds, so its results are those of the general kernel.
@@ -140,7 +152,6 @@ DEV void step_sync() { row_sync<true>(); }
 #define PGD_FIX_FIELDS(F, d, c, one_env)                                                                                            \
   F(d.V, PGD_FIX_V) F(d.A, 1) F(d.T, PGD_FIX_V - 1) F(d.D, 274) F(d.sstride, PGD_FIX_V) F(d.use_imask, 1)                            \
   F(d.sub, (one_env ? WAVE / PGD_FIX_V : 1)) F(d.epw, (one_env ? 1 : WAVE / PGD_FIX_V)) F(d.pack_obs, (one_env ? 0 : 1))             \
-  F(d.ostride, 274) F(d.prow, nullptr) F(d.unit_off, 0)                                                                             \
   F(c.num_agents, 1) F(c.num_traffic, PGD_FIX_V - 1) F(c.num_lasers, 240) F(c.num_others, 4) F(c.lidar_dist, 50.0f)                 \
   F(c.dt, 0.02f) F(c.decision_repeat, 5) F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0)                     \
   F(c.enable_reverse, 0) F(c.marl_flags, 0) F(c.use_lateral, 0) F(c.out_of_route_done, 0) F(c.success_reward, 10.0f)                \
@@ -194,6 +205,13 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   RouteCtx ctx{0.0f, 1.0f, 0};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
   MapView mv;
   const pgd_spawn* sp = nullptr;
+  // The scalar part of the slot's spawn record (dimensions, drive parameters, trigger group, destination: its first 64 bytes) is
+  // read ONCE, four 16-byte loads in one round trip, when the record's address is known; the phases used to fetch its fields one
+  // by one where they needed them, each time for a whole memory latency (profiles/r03_notes.md).  Kernels with one env per wave
+  // only: the multi-env instantiations have no registers to spare.
+  constexpr bool REGSP = ONE_ENV && !MARL;
+  pgd_spawn sl;
+#define SPV spawn_ref<REGSP>(sl, sp)
   const pgd_scenario* sc = nullptr;
   int ng = 0, ep_steps = 0;
   uint32_t steps_total = 0;
@@ -235,6 +253,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   XMARK(13);
   if (valid) {
     sp = d.spawns + (size_t)scen * d.sstride + r.spawn;
+    if (REGSP) spawn_head_load(sp, sl);
     // (0) AgentManager.before_step (agent_manager.py:191-199): finished agents count down, then leave the world
     if (marl && r.status == ST_DYING && --r.timer == 0) r.status = ST_EMPTY;
   }
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_MARK(0);  // load
   XMARK(0);
   const bool trig = ONE_ENV ? (__ballot(s_flag[0] != 0) != 0ull) : (valid && s_flag[el] != 0);
-  if (valid && trig && r.status == ST_PENDING && sp->group == ng) r.status = ST_ACTIVE;
+  if (valid && trig && r.status == ST_PENDING && SPV.group == ng) r.status = ST_ACTIVE;
   if (trig) ng += 1;  // every lane of the env keeps the same copy
   // the own-lane coordinate / lane length / successor list of a vehicle are read by the IDM neighbour search alone: an
   // env without a driving IDM vehicle in this step (most envs, most steps) skips them
@@ -257,9 +276,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (leader) {
       S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
       S.spd[slot] = speed_kmh(r.v);
-      const int kind = OBJ ? (int)sp->kind : PGD_OBJ_VEHICLE;
+      const int kind = OBJ ? (int)SPV.kind : PGD_OBJ_VEHICLE;
       if (OBJ) s_kind[slot] = kind;
-      S.hl[slot] = 0.5f * sp->length; S.hw[slot] = kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * sp->width;
+      S.hl[slot] = 0.5f * SPV.length; S.hw[slot] = kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * SPV.width;
       S.lane[slot] = r.lane;
       const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
       S.present[slot] = present ? 1 : 0;
@@ -300,7 +319,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
 #ifdef PGD_NO_IDM
       st = 0.0f; tb = 0.0f;
 #else
-      idm_act<OBJ>(d, mv, g, *sp, S, base, V, s, e, steps_total, r, st, tb);
+      idm_act<OBJ>(d, mv, g, SPV, S, base, V, s, e, steps_total, r, st, tb);
 #endif
     }
     PHASE_MARK(2);  // policy (IDM)
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // _set_action / _set_incremental_action (base_vehicle.py:343-358)
     r.steer = (s < A && d.cfg.increment_steering) ? clipf(r.steer + st * 0.05f, -1.0f, 1.0f) : st;
     // (4) physics
-    dynamics(d, *sp, r, s < A && d.cfg.enable_reverse != 0, tb, leader ? &SUBP : nullptr, slot, near_env && sub_ok && n_mid_enabled);
+    dynamics(d, SPV, r, s < A && d.cfg.enable_reverse != 0, tb, leader ? &SUBP : nullptr, slot, near_env && sub_ok && n_mid_enabled);
     PHASE_MARK(3);  // dynamics
   }
   step_sync();
@@ -381,11 +400,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // whole wave working through the agents one after the other
     // several agents: the line / sidewalk test runs as a phase of its own (below), where the localisation's boxes and lane
     // records are no longer live -- inside after_step it pushed the multi-agent kernel 66 registers over the 128 it may use
-    after_step_vehicle(d.cfg, mv, g, *sp, r, s < A, !one_env, ctx);
+    after_step_vehicle<ONE_ENV>(d.cfg, mv, g, *sp, SPV, r, s < A, !one_env, ctx);
     if (s >= A && (r.vflags & PGD_F_OFF_LANE)) r.status = ST_REMOVED;
   }
   if (one_env && A > 1 && acting && s < A && !ctx.clear)
-    r.vflags |= (int)state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sp->length, 0.5f * sp->width});
+    r.vflags |= (int)state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * SPV.length, 0.5f * SPV.width});
   PHASE_MARK(25);  // after_step: per-vehicle part
   if (one_env && A == 1) {  // line / sidewalk test of the agent by the whole wave (base_vehicle.py:615-644)
     if (leader && valid && s < A) s_flag[A + s] = (acting && !ctx.clear) ? 1 : 0;  // clear: provably no contact (after_step)
@@ -410,7 +429,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   float my_rew = 0.0f;
   const bool was_active = acting;  // status at the start of the step (after the delay-done countdown)
   if (valid && s < A && !marl) {
-    if (r.status == ST_ACTIVE) my_rew = reward_done<false>(d, mv, *sp, r, ctx, my_fl, my_dn);
+    if (r.status == ST_ACTIVE) my_rew = reward_done<false>(d, mv, SPV, r, ctx, my_fl, my_dn);
     if (d.cfg.horizon > 0 && ep_steps >= d.cfg.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
     if (sc->max_steps > 0 && ep_steps >= sc->max_steps) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }  // auto_termination
     r.eprew += my_rew;
@@ -426,7 +445,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (parking) step_sync();
     if (valid && s < A && was_active) {
       if (toll && r.blk == '$') r.php += 1.0f;  // TollGateObservation.observe counts its calls inside the toll block
-      my_rew = reward_done<true>(d, mv, *sp, r, ctx, my_fl, my_dn);
+      my_rew = reward_done<true>(d, mv, SPV, r, ctx, my_fl, my_dn);
       const bool arrive = my_fl & PGD_F_ARRIVE, oor = my_fl & PGD_F_OUT_OF_ROAD, crash = my_fl & PGD_F_CRASH_VEHICLE;
       if (crash && !(gcf.marl_flags & PGD_MA_CRASH_DONE) && !(arrive || oor)) my_dn = false;
       if (oor && !(gcf.marl_flags & PGD_MA_OUT_ROAD_DONE) && !arrive) my_dn = false;
@@ -462,7 +481,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     step_sync();
     if (valid && leader) {
       S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
-      S.hl[slot] = 0.5f * sp->length; S.hw[slot] = 0.5f * sp->width;
+      S.hl[slot] = 0.5f * SPV.length; S.hw[slot] = 0.5f * SPV.width;
       S.present[slot] = (r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING) ? 1 : 0;
     }
     step_sync();
@@ -519,6 +538,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     }
     if (fresh) {  // the new agent's record, first localisation included, from the respawn image (k_respawn_image)
       sp = d.spawns + (size_t)scen * d.sstride + fresh_idx;
+      if (REGSP) spawn_head_load(sp, sl);
       load_rec(d.respawn_img + (size_t)scen * (d.sstride - V) + (fresh_idx - V), r);
       r.agent_id = (float)fresh_id;
     }
@@ -563,6 +583,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   if (valid && resetting) {
     sp = d.spawns + (size_t)scen * d.sstride + s;
+    if (REGSP) spawn_head_load(sp, sl);
     // the slot right after a reset is a function of the scenario alone (spawn pose, first localisation, side distances,
     // agent id): read from the image k_reset_image built at upload instead of localising every vehicle again
     load_rec(d.reset_img + (size_t)scen * V + s, r);
@@ -628,9 +649,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
       S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
       S.spd[slot] = r.status == ST_DYING ? 0.0f : speed_kmh(r.v);
-      S.hl[slot] = 0.5f * sp->length;  // the scenario may have changed on reset
-      S.hw[slot] = (OBJ && sp->kind == PGD_OBJ_CYLINDER) ? -1.0f : 0.5f * sp->width;
-      if (OBJ) s_kind[slot] = sp->kind;
+      S.hl[slot] = 0.5f * SPV.length;  // the scenario may have changed on reset
+      S.hw[slot] = (OBJ && SPV.kind == PGD_OBJ_CYLINDER) ? -1.0f : 0.5f * SPV.width;
+      if (OBJ) s_kind[slot] = SPV.kind;
       S.present[slot] = present ? 1 : 0;
       if (s < A) {
         AgentView& ag = s_ag[s];
@@ -682,9 +703,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
       S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy;
       S.spd[slot] = speed_kmh(r.v);
-      S.hl[slot] = 0.5f * sp->length;
-      S.hw[slot] = (OBJ && sp->kind == PGD_OBJ_CYLINDER) ? -1.0f : 0.5f * sp->width;
-      if (OBJ) s_kind[slot] = sp->kind;
+      S.hl[slot] = 0.5f * SPV.length;
+      S.hw[slot] = (OBJ && SPV.kind == PGD_OBJ_CYLINDER) ? -1.0f : 0.5f * SPV.width;
+      if (OBJ) s_kind[slot] = SPV.kind;
       S.present[slot] = present ? 1 : 0;
       if (s == 0) {
         AgentView& ag = s_ag[el];
@@ -739,7 +760,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       ag.cur_first = r.cur_first; ag.cur_n = r.cur_n; ag.next_first = r.next_first;
       ag.blk = r.blk; ag.toll_time = r.php;
       ag.env = e; ag.slot = s; ag.tick = steps_total;
-      state_block<false>(d, mv, *sp, ag, row, g.sub, g.SUB);
+      state_block<false>(d, mv, SPV, ag, row, g.sub, g.SUB);
     }
   }
   PHASE_MARK(14);  // fused observation
@@ -766,6 +787,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
 struct Post {
   float x[WAVE], y[WAVE], ux[WAVE], uy[WAVE], spd[WAVE];  // pose / km/h of every slot after the physics of this step
 };
+#undef SPV
+
 // LDS-only ordering + workgroup barrier (a fence without the address space would also wait for every global access in flight)
 DEV void blk_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -894,7 +917,7 @@ __global__ __launch_bounds__(2 * WAVE, PGD_WAVES_PER_SIMD) void k_step2(PgdDev d
     blk_sync();  // C
     if (acting) {
       RouteCtx c;
-      after_step_vehicle(d.cfg, mv, g, *sp, r, false, true, c);
+      after_step_vehicle(d.cfg, mv, g, *sp, *sp, r, false, true, c);
       if (r.vflags & PGD_F_OFF_LANE) {  // traffic off the lanes is removed (traffic_manager.py:91-109)
         r.status = ST_REMOVED;
         if (leader) S.present[s] = 0;
@@ -955,7 +978,7 @@ __global__ __launch_bounds__(2 * WAVE, PGD_WAVES_PER_SIMD) void k_step2(PgdDev d
   blk_sync();  // C
   if (acting) {
     if (s_hit0 & 1) r.vflags |= PGD_F_CRASH_VEHICLE;
-    after_step_vehicle(d.cfg, mv, g, *sp, r, true, false, ctx);
+    after_step_vehicle(d.cfg, mv, g, *sp, *sp, r, true, false, ctx);
   }
   if (__ballot(acting && !ctx.clear) != 0ull) {  // line / sidewalk test of the ego by the whole wave (base_vehicle.py:615-644)
     const unsigned fl = state_check_wave(mv, Obb{P.x[0], P.y[0], P.ux[0], P.uy[0], S.hl[0], S.hw[0]});
@@ -1075,7 +1098,7 @@ DEV unsigned long long reset_slot(const PgdDev& d, const LaneMap& lm, int scen, 
   RouteCtx ctx;
   if (r.status != ST_EMPTY) {
     route_refresh(mv, *sp, r);
-    after_step_vehicle(d.cfg, mv, g, *sp, r, s < A, true, ctx);
+    after_step_vehicle(d.cfg, mv, g, *sp, *sp, r, s < A, true, ctx);
   }
   const unsigned long long am = __ballot(lm.sub == 0 && s < A && r.status == ST_ACTIVE);  // epw == 1 whenever A > 1
   if (s < A && r.status == ST_ACTIVE) r.agent_id = A == 1 ? 0.0f : (float)__popcll(am & ((1ull << lm.lead) - 1ull));
@@ -1108,7 +1131,7 @@ __global__ __launch_bounds__(256) void k_respawn_image(PgdDev d, VehRec* __restr
   RouteCtx ctx;
   if (r.status != ST_EMPTY) {
     route_refresh(mv, *sp, r);
-    after_step_vehicle(d.cfg, mv, g, *sp, r, true, true, ctx);
+    after_step_vehicle(d.cfg, mv, g, *sp, *sp, r, true, true, ctx);
   }
   store_rec(img + k, r);
 }
@@ -1179,7 +1202,7 @@ __global__ __launch_bounds__(WAVE) void k_refresh(PgdDev d) {
   int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
   MapView mv = map_view(d, d.scen[scen].map);
   RouteCtx ctx;
-  after_step_vehicle(d.cfg, mv, g, d.spawns[(size_t)scen * d.sstride + r.spawn], r, s < A, true, ctx);
+  after_step_vehicle(d.cfg, mv, g, d.spawns[(size_t)scen * d.sstride + r.spawn], d.spawns[(size_t)scen * d.sstride + r.spawn], r, s < A, true, ctx);
   if (lm.sub == 0) store_veh(d, e, s, r);
 }
 

@@ -143,7 +143,9 @@ DEV void update_checkpoints(const MapView& mv, const Grp& g, const pgd_spawn& sp
 }
 
 // Navigation.update_localization (navigation.py:155-183)
-DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, float& lon_out, float& lat_out) {
+// `PL` = the record of r.lane, read by the caller (ahead of time, together with its other lane reads)
+DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, float& lon_out, float& lat_out,
+                             const pgd_lane& PL) {
   const float s = r.hy, c = r.hx;
   const int road_cur = (int)r.road_cur;  // the record's route context: no spawn-record read
   const int road_next = (r.ck0 == r.ck1) ? -1 : (int)r.road_next;
@@ -155,9 +157,8 @@ DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& s
   // can reach it) and heads along it.  Margins of 5 cm keep the decision away from the fp32 rounding of either form.
   float lon = 0.0f, lat = 0.0f;
   bool stay = false;
-  const int cell = cell_entry(mv, r.x, r.y);  // in flight together with the lane record below
+  const int cell = cell_entry(mv, r.x, r.y);  // in flight together with the lane records of the caller
   {
-    const pgd_lane& PL = mv.lanes[r.lane];
     if (PL.road == road_cur) {
       lane_local(PL, r.x, r.y, lon, lat);
       const float hw = 0.5f * PL.width;
@@ -265,28 +266,39 @@ struct RouteCtx {   // per-step by-products of an agent's after_step, consumed b
 
 // BaseVehicle.after_step (base_vehicle.py:255-290).  `with_state_check` = false lets the caller run the line / sidewalk
 // test wave-cooperatively afterwards (k_step with one env per wave) and OR the result into vflags.
-DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, bool is_agent,
-                            bool with_state_check, RouteCtx& ctx) {
+// AHEAD: read the lane records of the step before the localisation (16 more registers live across it: kernels with one env per wave)
+template <bool AHEAD = false>
+// `sp`: the slot's spawn record in memory (route arrays); `sv`: where its scalar fields are read from (the same record, or the
+// caller's register copy of its head)
+DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp& g, const pgd_spawn& sp, const pgd_spawn& sv, Veh& r,
+                            bool is_agent, bool with_state_check, RouteCtx& ctx) {
   float lon_v, lat_v;
-  update_localization(mv, g, sp, r, lon_v, lat_v);
+  // the two lane records every agent's after_step reads -- its lane of the previous step (almost always still its lane) and the
+  // first reference lane -- go out together, before the localisation: one memory round trip where there were three in a row
+  const int lane0 = r.lane, first0 = (int)r.cur_first;
+  const pgd_lane PL = mv.lanes[lane0];
+  pgd_lane L0;
+  if (AHEAD && is_agent) L0 = mv.lanes[first0];
+  update_localization(mv, g, sp, r, lon_v, lat_v, PL);
   if (is_agent) {
     ctx = RouteCtx{0.0f, 1.0f, 0};
+    pgd_lane VL = PL;
+    if (!AHEAD || r.lane != lane0) VL = mv.lanes[r.lane];
+    if (!AHEAD || (int)r.cur_first != first0) L0 = mv.lanes[r.cur_first];  // AHEAD: only when a checkpoint was passed
     {
       // line / sidewalk contacts (base_vehicle.py:615-644) need no grid walk while the car's box stays inside the strip of
       // its straight lane that no such box reaches (`ex` of the device lane copy, pgd_upload_maps)
-      const pgd_lane& VL = mv.lanes[r.lane];
       if (VL.dir == 0.0f && VL.ex > 0.0f) {
         const float ca = fabsf(r.hx * VL.bx + r.hy * VL.by), sa = fabsf(r.hy * VL.bx - r.hx * VL.by);
-        const float hl = 0.5f * sp.length, hw = 0.5f * sp.width;
+        const float hl = 0.5f * sv.length, hw = 0.5f * sv.width;
         const float e_lat = hw * ca + hl * sa, e_lon = hl * ca + hw * sa;
         ctx.clear = (fabsf(lat_v) + e_lat <= VL.ex && lon_v - e_lon >= 0.0f && lon_v + e_lon <= VL.length) ? 1 : 0;
       }
     }
     unsigned fl = (unsigned)r.vflags;
     fl &= ~(PGD_F_ON_WHITE | PGD_F_ON_YELLOW | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OUT_OF_ROUTE);
-    if (with_state_check && !ctx.clear) fl |= state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sp.length, 0.5f * sp.width});
+    if (with_state_check && !ctx.clear) fl |= state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sv.length, 0.5f * sv.width});
     float lon, lat;
-    const pgd_lane& L0 = mv.lanes[r.cur_first];
     lane_local(L0, r.x, r.y, lon, lat);
     float w = mv.m->lane_width;
     r.dl = lat + w * 0.5f;
@@ -303,7 +315,6 @@ DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp&
       // the driving term of the reward (pgdrive_env.py:209-232): longitudinal progress on the vehicle's own lane when that
       // lane belongs to the current reference road, else on the first reference lane.  Both coordinate pairs of the new
       // position were just evaluated, so the term is formed here; reward_done adds the speed term and the terminal cases.
-      const pgd_lane& VL = mv.lanes[r.lane];
       const bool in_ref = VL.road == (int)r.road_cur;
       float l0, t0;
       lane_local(in_ref ? VL : L0, r.lastx, r.lasty, l0, t0);
