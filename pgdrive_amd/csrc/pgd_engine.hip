@@ -158,18 +158,31 @@ DEV void step_sync() { row_sync<true>(); }
   F(c.out_of_road_penalty, 5.0f) F(c.crash_vehicle_penalty, 5.0f) F(c.crash_object_penalty, 5.0f)                                   \
   F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f) F(c.side_lasers, 0) F(c.lane_line_lasers, 0)                                    \
   F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f)
-template <bool ONE_ENV>
+// Multi-agent engines: the scalar fields of MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG (multi_agent_pgdrive.py:12-55: 72 beams x 40 m, no
+// neighbour rows, penalties 10, delay-done 25 steps, crash / out-of-road done, respawn; the roundabout / intersection / bottleneck
+// envs run it unchanged) -- the number of agents, the spawn places and the horizon stay run-time values.
+#define PGD_FIXM_FIELDS(F, d, c)                                                                                                    \
+  F(d.T, 0) F(d.D, 90) F(d.epw, 1) F(d.pack_obs, 0)                                                                                 \
+  F(c.num_traffic, 0) F(c.num_lasers, 72) F(c.num_others, 0) F(c.lidar_dist, 40.0f) F(c.dt, 0.02f) F(c.decision_repeat, 5)          \
+  F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0) F(c.enable_reverse, 0)                                     \
+  F(c.marl_flags, (PGD_MA_ENABLED | PGD_MA_CRASH_DONE | PGD_MA_OUT_ROAD_DONE | PGD_MA_ALLOW_RESPAWN)) F(c.use_lateral, 0)           \
+  F(c.out_of_route_done, 0) F(c.success_reward, 10.0f) F(c.out_of_road_penalty, 10.0f) F(c.crash_vehicle_penalty, 10.0f)            \
+  F(c.crash_object_penalty, 10.0f) F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f) F(c.side_lasers, 0) F(c.lane_line_lasers, 0)   \
+  F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f) F(c.delay_done, 25)
+template <bool ONE_ENV, bool MARL>
 DEV void write_fixed_config(PgdDev& d) {
   pgd_config& c = d.cfg;
 #define PGD_F_SET(f, v) f = v;
-  PGD_FIX_FIELDS(PGD_F_SET, d, c, ONE_ENV)
+  if (MARL) { PGD_FIXM_FIELDS(PGD_F_SET, d, c) }
+  else { PGD_FIX_FIELDS(PGD_F_SET, d, c, ONE_ENV) }
 #undef PGD_F_SET
 }
-static bool fix_config_matches(const PgdDev& d, bool one_env) {
+static bool fix_config_matches(const PgdDev& d, bool one_env, bool marl = false) {
   const pgd_config& c = d.cfg;
   bool ok = true;
 #define PGD_F_TEST(f, v) ok = ok && (f == v);
-  PGD_FIX_FIELDS(PGD_F_TEST, d, c, one_env)
+  if (marl) { PGD_FIXM_FIELDS(PGD_F_TEST, d, c) }
+  else { PGD_FIX_FIELDS(PGD_F_TEST, d, c, one_env) }
 #undef PGD_F_TEST
   return ok;
 }
@@ -177,7 +190,7 @@ template <bool ONE_ENV, bool MARL, bool OBJ, bool STD = false, bool FIX = false>
 __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
                                                 float* __restrict__ obs) {
-  if (FIX) write_fixed_config<ONE_ENV>(d);
+  if (FIX) write_fixed_config<ONE_ENV, MARL>(d);
 
   __shared__ StepUnion U;
   Snap& S = U.step.S;
@@ -1795,7 +1808,13 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*) = k_step<false, false, false>;
   const char* kname = h->d.pack_obs ? "k_step: whole envs side by side in a wave, one vehicle per lane (throughput mode)"
                                     : (h->d.epw == 1 ? "k_step: one env per wave" : "k_step: several envs per wave");
-  if (marl) kern = h->has_objects ? k_step<true, true, true> : k_step<true, true, false>;  // objects = toll booths
+  if (marl) {
+    kern = h->has_objects ? k_step<true, true, true> : k_step<true, true, false>;  // objects = toll booths
+    if (!h->has_objects && !h->no_fix && fix_config_matches(dv, true, true)) {
+      kern = k_step<true, true, false, false, true>;
+      kname = "k_step: one env per wave, specialised for the default multi-agent configuration";
+    }
+  }
   else if (h->d.epw == 1) {
     const pgd_config& c = h->d.cfg;
     const bool std_obs = c.side_lasers == 0 && c.lane_line_lasers == 0 && !c.random_agent_model &&

@@ -228,6 +228,45 @@ def test_default_configuration_kernel_matches_the_general_kernel(descs, monkeypa
     assert ("throughput mode" in fix.describe_step()) == (pack == "1")
 
 
+def test_default_multi_agent_kernel_matches_the_general_kernel(monkeypatch):
+    """Multi-agent engines with the scalar fields of MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG get their own instantiation of k_step (those
+    fields are compile-time constants in it; agent count, spawn places and horizon stay run-time values).  Against the general
+    kernel (PGD_NO_FIX=1) from the same state with the same actions: flags, done, integer state identical, floats to rounding."""
+    import torch
+    from pgdrive_amd.engine import Engine
+    d, mb, sb = util.make_marl_banks(num_agents=8, capacity=12, kind="roundabout")
+    n_envs = 32
+    cfg = util.marl_config(n_envs, sb, horizon=120)
+    monkeypatch.delenv("PGD_NO_FIX", raising=False)
+    fix = Engine(cfg, mb, sb)
+    other = Engine(util.marl_config(n_envs, sb, horizon=120, delay_done=10), mb, sb)
+    monkeypatch.setenv("PGD_NO_FIX", "1")
+    gen = Engine(cfg, mb, sb)
+    ids = np.arange(n_envs) % 8
+    fix.reset(ids); gen.reset(ids); other.reset(ids)
+    rng = np.random.default_rng(5)
+    n_done = n_new = 0
+    for t in range(300):
+        act = util.marl_actions(rng, n_envs, sb.A)
+        f, i, ei = gen.get_state()
+        fix.set_state(f, i, ei)
+        a = torch.from_numpy(act).to(gen.device)
+        o1, r1, d1, f1 = [x.clone() for x in gen.step(a)]
+        o2, r2, d2, f2 = [x.clone() for x in fix.step(a)]
+        gen.sync(); fix.sync()
+        assert torch.equal(d1, d2) and torch.equal(f1, f2), "flags differ at step %d" % t
+        rep = ((f1 & (_abi.F_REPORT | _abi.F_NEW)) != 0)
+        assert float(((o1 - o2).abs() * rep[..., None]).max()) < 2e-6 and float(((r1 - r2).abs() * rep).max()) < 2e-5
+        g1, i1, e1 = gen.get_state()
+        g2, i2, e2 = fix.get_state()
+        assert (i1 == i2).all() and (e1 == e2).all(), "integer state differs at step %d" % t
+        n_done += int(d1.sum()); n_new += int(((f1 & _abi.F_NEW) != 0).sum())
+    assert n_done > 20 and n_new > 20
+    other.step(torch.from_numpy(util.marl_actions(rng, n_envs, sb.A)).to(other.device)); other.sync()
+    assert "specialised for the default multi-agent" in fix.describe_step()
+    assert "specialised" not in gen.describe_step() and "specialised" not in other.describe_step()
+
+
 def _teacher_forced(descs, num_traffic, num_lasers):
     n_envs = 64
     torch, eng, ora, cfg = _engines(descs, n_envs, num_traffic=num_traffic, num_lasers=num_lasers)
