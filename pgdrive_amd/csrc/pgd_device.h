@@ -114,9 +114,23 @@ struct __attribute__((aligned(16))) LaneNav {
 // The hot tables (lanes, grid cells and their boxes) are carried as pointers; the road table and the per-lane navigation extract
 // are touched once or twice per step and are addressed from the engine view where they are used (`roads()`, `lnav()`): every
 // pointer carried through the whole kernel costs two SGPRs, and k_step spills SGPRs.
+// the scalars of the map header the step uses after its first store (grid geometry, lane width): read once with the header, at the
+// start of the kernel -- a read of the header later on is a vector-memory read (the compiler may not assume the table unchanged
+// once the kernel has stored anything), waited for on the spot
+struct MapGrid {
+  int gx, gy;
+  float ox, oy, cell, lane_width;
+};
 struct MapView {
   const PgdDev* dv;
   const pgd_map* m;
+  // the header's scalars, read in place where they are used (the general kernels have no scalar registers left to hold them)
+  DEV int gx() const { return m->gx; }
+  DEV int gy() const { return m->gy; }
+  DEV float ox() const { return m->ox; }
+  DEV float oy() const { return m->oy; }
+  DEV float cell() const { return m->cell; }
+  DEV float lane_width() const { return m->lane_width; }
   const pgd_lane* lanes;
   const int32_t* cstart;
   const LaneExt* cext;
@@ -135,6 +149,26 @@ DEV MapView map_view_of(const PgdDev& d, const pgd_map* m) {
   v.cstart = d.cell_start + m->cell_off;
   v.cext = d.cell_ext + m->item_off;
   v.cbox = d.cell_boxes + m->item_off;
+  return v;
+}
+// the same view with the header's scalars read ahead, with the header itself (kernels specialised for a default configuration:
+// their configuration constants leave scalar registers free).  Routines that read those scalars take the view type as a template
+// parameter; everything else takes the base.
+struct MapViewPre : MapView {
+  MapGrid grid;
+  DEV int gx() const { return grid.gx; }
+  DEV int gy() const { return grid.gy; }
+  DEV float ox() const { return grid.ox; }
+  DEV float oy() const { return grid.oy; }
+  DEV float cell() const { return grid.cell; }
+  DEV float lane_width() const { return grid.lane_width; }
+};
+template <class MV> DEV MV map_view_as(const PgdDev& d, const pgd_map* m);
+template <> DEV MapView map_view_as<MapView>(const PgdDev& d, const pgd_map* m) { return map_view_of(d, m); }
+template <> DEV MapViewPre map_view_as<MapViewPre>(const PgdDev& d, const pgd_map* m) {
+  MapViewPre v;
+  static_cast<MapView&>(v) = map_view_of(d, m);
+  v.grid = MapGrid{m->gx, m->gy, m->ox, m->oy, m->cell, m->lane_width};
   return v;
 }
 DEV MapView map_view(const PgdDev& d, int map) { return map_view_of(d, d.maps + map); }

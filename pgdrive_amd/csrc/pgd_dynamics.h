@@ -94,14 +94,14 @@ DEV void reset_vehicle(const pgd_spawn& p, const float2 hv, Veh& r, int spawn_in
 
 // reward / done: envs/pgdrive_env.py:162-258, base_vehicle.py:738-745
 // MARL = false: the single-agent env; none of the multi-agent reward / out-of-road variants (marl_flags == 0) is compiled in.
-template <bool MARL>
-DEV float reward_done(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const Veh& r, const RouteCtx& ctx,
+template <bool MARL, class MV>
+DEV float reward_done(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const Veh& r, const RouteCtx& ctx,
                       unsigned& flags_out, bool& done_out) {
   const pgd_config& g = d.cfg;
   const int mflags = MARL ? g.marl_flags : 0;
   unsigned vf = (unsigned)r.vflags;
   const float positive = ctx.positive;
-  float w = mv.m->lane_width;
+  float w = mv.lane_width();
   float reward = ctx.drive;  // formed by after_step_vehicle from the coordinates it had just evaluated
   if (mflags & PGD_MA_TOLLGATE) {  // MultiAgentTollgateEnv.reward_function (marl_tollgate.py:195-232)
     if (r.blk == '$') {

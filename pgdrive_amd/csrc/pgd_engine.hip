@@ -216,7 +216,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   XMARK(99);
   Veh r;
   RouteCtx ctx{0.0f, 1.0f, 0};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
-  MapView mv;
+  using MV = typename std::conditional<FIX, MapViewPre, MapView>::type;
+  MV mv;
   const pgd_spawn* sp = nullptr;
   // The scalar part of the slot's spawn record (dimensions, drive parameters, trigger group, destination: its first 64 bytes) is
   // read ONCE, four 16-byte loads in one round trip, when the record's address is known; the phases used to fetch its fields one
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   const int key0 = valid ? (r.status ^ (r.vflags << 3)) : 0;  // what a vehicle that does not drive can change: status, flags
   if (one_env || valid) {
     sc = d.scen + scen;
-    mv = map_view_of(d, d.env_map + e);  // per-env header copy: address known at kernel start
+    mv = map_view_as<MV>(d, d.env_map + e);  // per-env header copy: address known at kernel start
     ng = d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP];
     ep_steps = d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS];
     steps_total = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (d.cfg.resample_scenario)
       scen = (int)(pgd_rng(d.cfg.seed, (uint32_t)(d.cfg.env_base + e), 0x5ce9a210u, (uint32_t)episodes) % (uint32_t)d.n_scen);
     sc = d.scen + scen;
-    mv = map_view_of(d, d.scen_map + scen);  // the header of the new episode's map (the per-env copy is rewritten below)
+    mv = map_view_as<MV>(d, d.scen_map + scen);  // the header of the new episode's map (the per-env copy is rewritten below)
     ng = 0;
     ep_steps = 0;
   }
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       AgentView ag = s_ag[q];
       const int scen_q = ag.cur_n >> 8;
       ag.cur_n &= 0xff;
-      const MapView mvq = map_view_of(d, d.scen_map + scen_q);
+      const MV mvq = map_view_as<MV>(d, d.scen_map + scen_q);
       const int bq = q * V;
       const bool have = lane < V && d.cfg.num_lasers > 0;
       const int sl = bq + (lane < V ? lane : 0);

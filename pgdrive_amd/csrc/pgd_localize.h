@@ -16,27 +16,27 @@ DEV int cell_mid(int c) { return (c & 0xffffff) + (int)((unsigned)c >> 24); }
 
 // nearest hit fraction of the segment p + t d (t in [0,1]) against the map's boxes whose kind is in `kinds`: Amanatides-Woo
 // walk over the uniform grid; a cell is skipped once its entry parameter is beyond the best hit so far
-DEV float ray_grid(const MapView& mv, float px, float py, float dx, float dy, unsigned kinds) {
-  const pgd_map& m = *mv.m;
-  const float inv = 1.0f / m.cell;
-  int ix = (int)floorf((px - m.ox) * inv), iy = (int)floorf((py - m.oy) * inv);
+template <class MV>
+DEV float ray_grid(const MV& mv, float px, float py, float dx, float dy, unsigned kinds) {
+  const float inv = 1.0f / mv.cell();
+  int ix = (int)floorf((px - mv.ox()) * inv), iy = (int)floorf((py - mv.oy()) * inv);
   const int sx = dx > 0.0f ? 1 : -1, sy = dy > 0.0f ? 1 : -1;
   const float big = 3.0e38f;
-  const float tdx = dx != 0.0f ? fabsf(m.cell / dx) : big, tdy = dy != 0.0f ? fabsf(m.cell / dy) : big;
-  float tmx = dx != 0.0f ? ((m.ox + (ix + (dx > 0.0f ? 1 : 0)) * m.cell) - px) / dx : big;
-  float tmy = dy != 0.0f ? ((m.oy + (iy + (dy > 0.0f ? 1 : 0)) * m.cell) - py) / dy : big;
+  const float tdx = dx != 0.0f ? fabsf(mv.cell() / dx) : big, tdy = dy != 0.0f ? fabsf(mv.cell() / dy) : big;
+  float tmx = dx != 0.0f ? ((mv.ox() + (ix + (dx > 0.0f ? 1 : 0)) * mv.cell()) - px) / dx : big;
+  float tmy = dy != 0.0f ? ((mv.oy() + (iy + (dy > 0.0f ? 1 : 0)) * mv.cell()) - py) / dy : big;
   float best = 1.0f, t_enter = 0.0f;
   for (int it = 0; it < 64; ++it) {
     if (t_enter > best + 0.02f) break;  // boxes are registered with a 5 cm margin: keep a little slack
-    if (ix >= 0 && iy >= 0 && ix < m.gx && iy < m.gy) {
-      const int cell = iy * m.gx + ix;
+    if (ix >= 0 && iy >= 0 && ix < mv.gx() && iy < mv.gy()) {
+      const int cell = iy * mv.gx() + ix;
       const int k1 = cell_first(mv.cstart[cell + 1]);
       for (int k = cell_mid(mv.cstart[cell]); k < k1; ++k) {
         const pgd_box b = mv.cbox[k];
         if (!((1u << b.kind) & kinds)) continue;
         best = fminf(best, ray_obb(obb_of(b), px, py, dx, dy));
       }
-    } else if ((sx > 0 ? ix >= m.gx : ix < 0) || (sy > 0 ? iy >= m.gy : iy < 0)) {
+    } else if ((sx > 0 ? ix >= mv.gx() : ix < 0) || (sy > 0 ? iy >= mv.gy() : iy < 0)) {
       break;  // left the grid for good
     }
     if (tmx < tmy) { t_enter = tmx; tmx += tdx; ix += sx; }
@@ -48,10 +48,10 @@ DEV float ray_grid(const MapView& mv, float px, float py, float dx, float dy, un
 
 
 // cell_start entry of the grid cell under (px, py); 0 (an empty range) outside the grid
-DEV int cell_entry(const MapView& mv, float px, float py) {
-  const pgd_map& m = *mv.m;
-  int cx = (int)floorf((px - m.ox) / m.cell), cy = (int)floorf((py - m.oy) / m.cell);
-  return (cx >= 0 && cy >= 0 && cx < m.gx && cy < m.gy) ? mv.cstart[cy * m.gx + cx] : 0;
+template <class MV>
+DEV int cell_entry(const MV& mv, float px, float py) {
+  int cx = (int)floorf((px - mv.ox()) / mv.cell()), cy = (int)floorf((py - mv.oy()) / mv.cell());
+  return (cx >= 0 && cy >= 0 && cx < mv.gx() && cy < mv.gy()) ? mv.cstart[cy * mv.gx() + cx] : 0;
 }
 
 // `c` = cell_entry(mv, px, py), read by the caller ahead of time
@@ -144,7 +144,8 @@ DEV void update_checkpoints(const MapView& mv, const Grp& g, const pgd_spawn& sp
 
 // Navigation.update_localization (navigation.py:155-183)
 // `PL` = the record of r.lane, read by the caller (ahead of time, together with its other lane reads)
-DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, float& lon_out, float& lat_out,
+template <class MV>
+DEV void update_localization(const MV& mv, const Grp& g, const pgd_spawn& sp, Veh& r, float& lon_out, float& lat_out,
                              const pgd_lane& PL) {
   const float s = r.hy, c = r.hx;
   const int road_cur = (int)r.road_cur;  // the record's route context: no spawn-record read
@@ -208,11 +209,11 @@ DEV void update_localization(const MapView& mv, const Grp& g, const pgd_spawn& s
 // BaseVehicle._state_check (base_vehicle.py:615-644): the car's box against the line / sidewalk boxes of the grid cells under
 // it.  The (<= 2 x 2) cells are flattened into one index range (their four start offsets are read at once: one dependent
 // level for the whole neighbourhood) that the sub-lanes of the vehicle stride through, two boxes in flight per lane.
-DEV unsigned state_check(const MapView& mv, const Grp& g, const Obb& car) {
-  const pgd_map& m = *mv.m;
+template <class MV>
+DEV unsigned state_check(const MV& mv, const Grp& g, const Obb& car) {
   float ex = fabsf(car.ux) * car.hl + fabsf(car.uy) * car.hw, ey = fabsf(car.uy) * car.hl + fabsf(car.ux) * car.hw;
-  int cx0 = max((int)floorf((car.cx - ex - m.ox) / m.cell), 0), cx1 = min((int)floorf((car.cx + ex - m.ox) / m.cell), m.gx - 1);
-  int cy0 = max((int)floorf((car.cy - ey - m.oy) / m.cell), 0), cy1 = min((int)floorf((car.cy + ey - m.oy) / m.cell), m.gy - 1);
+  int cx0 = max((int)floorf((car.cx - ex - mv.ox()) / mv.cell()), 0), cx1 = min((int)floorf((car.cx + ex - mv.ox()) / mv.cell()), mv.gx() - 1);
+  int cy0 = max((int)floorf((car.cy - ey - mv.oy()) / mv.cell()), 0), cy1 = min((int)floorf((car.cy + ey - mv.oy()) / mv.cell()), mv.gy() - 1);
   unsigned fl = 0;
   for (int cyb = cy0; cyb <= cy1; cyb += 2)
     for (int cxb = cx0; cxb <= cx1; cxb += 2) {  // blocks of up to 2x2 cells (a car spans at most 2 cells per axis)
@@ -222,7 +223,7 @@ DEV unsigned state_check(const MapView& mv, const Grp& g, const Obb& car) {
       for (int q = 0; q < 4; ++q) {
         int cx = cxb + (q & 1), cy = cyb + (q >> 1);
         bool in = cx <= cx1 && cy <= cy1;
-        int cell = in ? cy * m.gx + cx : 0;
+        int cell = in ? cy * mv.gx() + cx : 0;
         int a = cell_mid(mv.cstart[cell]), b = cell_first(mv.cstart[cell + 1]);
         k0[q] = a;
         pre[q + 1] = pre[q] + (in ? b - a : 0);
@@ -267,10 +268,10 @@ struct RouteCtx {   // per-step by-products of an agent's after_step, consumed b
 // BaseVehicle.after_step (base_vehicle.py:255-290).  `with_state_check` = false lets the caller run the line / sidewalk
 // test wave-cooperatively afterwards (k_step with one env per wave) and OR the result into vflags.
 // AHEAD: read the lane records of the step before the localisation (16 more registers live across it: kernels with one env per wave)
-template <bool AHEAD = false>
 // `sp`: the slot's spawn record in memory (route arrays); `sv`: where its scalar fields are read from (the same record, or the
 // caller's register copy of its head)
-DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp& g, const pgd_spawn& sp, const pgd_spawn& sv, Veh& r,
+template <bool AHEAD = false, class MV>
+DEV void after_step_vehicle(const pgd_config& cfg, const MV& mv, const Grp& g, const pgd_spawn& sp, const pgd_spawn& sv, Veh& r,
                             bool is_agent, bool with_state_check, RouteCtx& ctx) {
   float lon_v, lat_v;
   // the two lane records every agent's after_step reads -- its lane of the previous step (almost always still its lane) and the
@@ -300,7 +301,7 @@ DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp&
     if (with_state_check && !ctx.clear) fl |= state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * sv.length, 0.5f * sv.width});
     float lon, lat;
     lane_local(L0, r.x, r.y, lon, lat);
-    float w = mv.m->lane_width;
+    float w = mv.lane_width();
     r.dl = lat + w * 0.5f;
     float range = w * (float)r.cur_n;
     if (r.blk == 'y' || r.blk == 'Y') {
@@ -332,12 +333,12 @@ DEV void after_step_vehicle(const pgd_config& cfg, const MapView& mv, const Grp&
 }
 
 // the same test with the whole wave on one car: the (<= 2x2) grid cells under the car are flattened into one index range
-DEV unsigned state_check_wave(const MapView& mv, const Obb& car) {
-  const pgd_map& m = *mv.m;
+template <class MV>
+DEV unsigned state_check_wave(const MV& mv, const Obb& car) {
   const int lane = threadIdx.x;
   float ex = fabsf(car.ux) * car.hl + fabsf(car.uy) * car.hw, ey = fabsf(car.uy) * car.hl + fabsf(car.ux) * car.hw;
-  int cx0 = max((int)floorf((car.cx - ex - m.ox) / m.cell), 0), cx1 = min((int)floorf((car.cx + ex - m.ox) / m.cell), m.gx - 1);
-  int cy0 = max((int)floorf((car.cy - ey - m.oy) / m.cell), 0), cy1 = min((int)floorf((car.cy + ey - m.oy) / m.cell), m.gy - 1);
+  int cx0 = max((int)floorf((car.cx - ex - mv.ox()) / mv.cell()), 0), cx1 = min((int)floorf((car.cx + ex - mv.ox()) / mv.cell()), mv.gx() - 1);
+  int cy0 = max((int)floorf((car.cy - ey - mv.oy()) / mv.cell()), 0), cy1 = min((int)floorf((car.cy + ey - mv.oy()) / mv.cell()), mv.gy() - 1);
   unsigned fl = 0;
   for (int cyb = cy0; cyb <= cy1; cyb += 2)
     for (int cxb = cx0; cxb <= cx1; cxb += 2) {  // blocks of up to 2x2 cells (a car spans at most 2 cells per axis)
@@ -347,7 +348,7 @@ DEV unsigned state_check_wave(const MapView& mv, const Obb& car) {
       for (int q = 0; q < 4; ++q) {
         int cx = cxb + (q & 1), cy = cyb + (q >> 1);
         bool in = cx <= cx1 && cy <= cy1;
-        int cell = in ? cy * m.gx + cx : 0;
+        int cell = in ? cy * mv.gx() + cx : 0;
         int a = cell_mid(mv.cstart[cell]), b = cell_first(mv.cstart[cell + 1]);
         k0[q] = a;
         pre[q + 1] = pre[q] + (in ? b - a : 0);

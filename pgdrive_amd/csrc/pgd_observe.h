@@ -138,8 +138,8 @@ DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, flo
 
 // StateObservation.observe of one vehicle (state_obs.py:42-106): ego state + detector fans + navigation info, written to
 // row[0 .. state length) by threads tid in [0, nt)
-template <bool STD>
-DEV void state_block(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const AgentView& ag, float* __restrict__ row,
+template <bool STD, class MV>
+DEV void state_block(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const AgentView& ag, float* __restrict__ row,
                      int tid, int nt) {
   const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
   // StateObservation.vehicle_state (state_obs.py:58-106) + navi info (navigation.py:185-197): one lane per float.
@@ -184,7 +184,7 @@ DEV void state_block(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, co
     } else {  // lanes 8..12 -> checkpoint 1, 13..17 -> checkpoint 2
       int which = (q - 8) / 5, comp = (q - 8) - which * 5;
       float out[5];
-      navi_info_for(nv, mv.m->lane_width, ag.cur_n, px, py, hx, hy, out);
+      navi_info_for(nv, mv.lane_width(), ag.cur_n, px, py, hx, hy, out);
       v = comp == 0 ? out[0] : comp == 1 ? out[1] : comp == 2 ? out[2] : comp == 3 ? out[3] : out[4];
       col = toll ? -1 : o_navi + (q - 8);
     }
@@ -253,8 +253,8 @@ DEV void row_sync() {
 
 // STATE = false: the caller has written the state block (and the toll floats' inputs are unchanged) already
 // WAVE_ROW: see row_sync
-template <bool OBJ, bool STD = false, bool OTH = false, bool STATE = true, bool WAVE_ROW = false>
-DEV void observe_agent(const PgdDev& d, const MapView& mv, const pgd_spawn& sp, const AgentView& ag, ObsLds& L,
+template <bool OBJ, bool STD = false, bool OTH = false, bool STATE = true, bool WAVE_ROW = false, class MV>
+DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const AgentView& ag, ObsLds& L,
                        float* __restrict__ row, int tid, int nt, const VehRec* recs = nullptr, const pgd_spawn* spb = nullptr) {
   const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
   const float R = d.cfg.lidar_dist;

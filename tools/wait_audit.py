@@ -6,13 +6,23 @@ maxd = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 lines = open(src).read().split('\n')
 i0 = next(i for i, l in enumerate(lines) if l.startswith('_Z') and pat in l and ':' in l)
 body = []
+files = {}
+for l in lines:
+    m = re.match(r'\s*\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', l)
+    if m: files[int(m.group(1))] = m.group(2).split('/')[-1]
+    else:
+        m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]+)"', l)
+        if m: files[int(m.group(1))] = m.group(2).split('/')[-1]
+loc = ''
 for l in lines[i0 + 1:]:
     t = l.strip()
+    m = re.match(r'\.loc\s+(\d+)\s+(\d+)', t)
+    if m: loc = '%s:%s' % (files.get(int(m.group(1)), m.group(1)), m.group(2)); continue
     if t.startswith('s_endpgm'): body.append(t); break
     if not t or t.startswith(';') or t.startswith('.'): 
         if t.startswith('.LBB') or re.match(r'^\.?L?BB\d+_\d+:', t): body.append(t)
         continue
-    body.append(t)
+    body.append(t + '   ; ' + loc)
 last = {'vm': None, 'lgkm_s': None, 'lgkm_l': None}
 n = 0; tight = []
 for t in body:
@@ -36,4 +46,4 @@ from collections import Counter
 c = Counter(k for _, k, _, _ in tight)
 print('tight waits (<= %d instructions after the load):' % maxd, dict(c))
 for n_, k, dist, ld in tight:
-    print('%6d %-7s +%d  %s' % (n_, k, dist, ld[:90]))
+    print('%6d %-7s +%d  %s' % (n_, k, dist, ld[:120]))
