@@ -208,15 +208,19 @@ DEV void lane_local(const pgd_lane& l, float px, float py, float& lon, float& la
   // pgd_set_state; both must give the same bits, whatever the compiler fuses or re-associates around the inlined copy
 #pragma clang fp contract(off)
 #pragma clang fp reassociate(off)
-  float dx = px - l.ax, dy = py - l.ay;
-  if (l.dir == 0.0f) {
-    lon = dx * l.bx + dy * l.by;
-    lat = dy * l.bx - dx * l.by;
+  // everything either branch reads goes out before the branch: read field by field a record in memory costs one wait for `dir` and
+  // a second one for the fields of the branch taken
+  const float4 h = *reinterpret_cast<const float4*>(&l.ax);  // (ax, ay, bx, by)
+  const float dir = l.dir;
+  float dx = px - h.x, dy = py - h.y;
+  if (dir == 0.0f) {
+    lon = dx * h.z + dy * h.w;
+    lat = dy * h.z - dx * h.w;
   } else {
-    float R = l.bx, p0 = l.by;
+    float R = h.z, p0 = h.w;
     float phi = p0 + wrap_to_pi(atan2f(dy, dx) - p0);
-    lon = l.dir * (phi - p0) * R;
-    lat = l.dir * (R - sqrtf(dx * dx + dy * dy));
+    lon = dir * (phi - p0) * R;
+    lat = dir * (R - sqrtf(dx * dx + dy * dy));
   }
 }
 DEV void lane_position(const pgd_lane& l, float lon, float lat, float& x, float& y) {

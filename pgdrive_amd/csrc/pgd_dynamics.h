@@ -95,7 +95,8 @@ DEV void reset_vehicle(const pgd_spawn& p, const float2 hv, Veh& r, int spawn_in
 // reward / done: envs/pgdrive_env.py:162-258, base_vehicle.py:738-745
 // MARL = false: the single-agent env; none of the multi-agent reward / out-of-road variants (marl_flags == 0) is compiled in.
 template <bool MARL, class MV>
-DEV float reward_done(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const Veh& r, const RouteCtx& ctx,
+// `fl` = the record of the destination lane sp.dest_lane (the caller may have read it ahead of time)
+DEV float reward_done(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const pgd_lane& fl, const Veh& r, const RouteCtx& ctx,
                       unsigned& flags_out, bool& done_out) {
   const pgd_config& g = d.cfg;
   const int mflags = MARL ? g.marl_flags : 0;
@@ -113,7 +114,6 @@ DEV float reward_done(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const 
   reward += g.speed_reward * (speed_kmh(r.v) / sp.max_speed) * positive;
   unsigned out = vf & (PGD_F_ON_YELLOW | PGD_F_ON_WHITE | PGD_F_ON_BROKEN | PGD_F_CRASH_SIDEWALK | PGD_F_OFF_LANE |
                        PGD_F_OUT_OF_ROUTE | PGD_F_CRASH_VEHICLE | PGD_F_CRASH_OBJECT | PGD_F_CRASH_BUILDING);
-  const pgd_lane& fl = mv.lanes[sp.dest_lane];
   float lon, lat;
   lane_local(fl, r.x, r.y, lon, lat);
   bool arrive = (fl.length - 5.0f < lon && lon < fl.length + 5.0f) && (w * 0.5f >= lat && lat >= (0.5f - (float)r.cur_n) * w);

@@ -110,6 +110,9 @@ DEV void spawn_head_load(const pgd_spawn* sp, pgd_spawn& out) {
   const float4 a = q[0], b = q[1], c = q[2], e = q[3];
   o[0] = a; o[1] = b; o[2] = c; o[3] = e;
 }
+template <bool REG> DEV const pgd_lane& dest_lane_ref(const pgd_lane& regs, const pgd_lane* lanes, int id) {
+  if constexpr (REG) return regs; else return lanes[id];
+}
 template <bool REG> DEV const pgd_spawn& spawn_ref(const pgd_spawn& regs, const pgd_spawn* mem) {
   if constexpr (REG) return regs; else return *mem;
 }
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // only: the multi-env instantiations have no registers to spare.
   constexpr bool REGSP = ONE_ENV && !MARL;
   pgd_spawn sl;
+  pgd_lane FL;  // REGSP && FIX (registers to spare): the agent's destination lane record, read ahead
 #define SPV spawn_ref<REGSP>(sl, sp)
   const pgd_scenario* sc = nullptr;
   int ng = 0, ep_steps = 0;
@@ -271,15 +275,20 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // (0) AgentManager.before_step (agent_manager.py:191-199): finished agents count down, then leave the world
     if (marl && r.status == ST_DYING && --r.timer == 0) r.status = ST_EMPTY;
   }
-  step_sync();
-  if (valid) {
-    // (1) TrafficManager.before_step trigger (traffic_manager.py:76-85)
-    if (s < A && r.status == ST_ACTIVE && ng < sc->n_groups && mv.lanes[r.lane].road == sc->trigger_road[ng]) s_flag[el] = 1;
+  // (1) TrafficManager.before_step trigger (traffic_manager.py:76-85): an agent of the env stands on the trigger road of the next
+  // group.  One env per wave: a ballot over the wave's lanes (no trip through LDS); several envs per wave: a flag per env.
+  const bool on_trigger = valid && s < A && r.status == ST_ACTIVE && ng < sc->n_groups && mv.lanes[r.lane].road == sc->trigger_road[ng];
+  bool trig;
+  if (ONE_ENV) {
+    trig = __ballot(on_trigger) != 0ull;
+  } else {
+    step_sync();
+    if (on_trigger) s_flag[el] = 1;
+    step_sync();
+    trig = valid && s_flag[el] != 0;
   }
-  step_sync();
   PHASE_MARK(0);  // load
   XMARK(0);
-  const bool trig = ONE_ENV ? (__ballot(s_flag[0] != 0) != 0ull) : (valid && s_flag[el] != 0);
   if (valid && trig && r.status == ST_PENDING && SPV.group == ng) r.status = ST_ACTIVE;
   if (trig) ng += 1;  // every lane of the env keeps the same copy
   // the own-lane coordinate / lane length / successor list of a vehicle are read by the IDM neighbour search alone: an
@@ -414,6 +423,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // whole wave working through the agents one after the other
     // several agents: the line / sidewalk test runs as a phase of its own (below), where the localisation's boxes and lane
     // records are no longer live -- inside after_step it pushed the multi-agent kernel 66 registers over the 128 it may use
+    // the destination lane of an agent (arrive test of reward_done) is known from its spawn record: read before the localisation
+    if (REGSP && FIX && s < A) FL = mv.lanes[SPV.dest_lane];
     after_step_vehicle<ONE_ENV>(d.cfg, mv, g, *sp, SPV, r, s < A, !one_env, ctx);
     if (s >= A && (r.vflags & PGD_F_OFF_LANE)) r.status = ST_REMOVED;
   }
@@ -421,21 +432,23 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     r.vflags |= (int)state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * SPV.length, 0.5f * SPV.width});
   PHASE_MARK(25);  // after_step: per-vehicle part
   if (one_env && A == 1) {  // line / sidewalk test of the agent by the whole wave (base_vehicle.py:615-644)
-    if (leader && valid && s < A) s_flag[A + s] = (acting && !ctx.clear) ? 1 : 0;  // clear: provably no contact (after_step)
-    step_sync();
-    for (int a = 0; a < A; ++a) {
-      if (!s_flag[A + a]) continue;
-      unsigned fl = state_check_wave(mv, snap_obb(S, a));
-      if (valid && s == a) r.vflags |= (int)fl;
+    // clear: provably no contact (after_step); the agent's lanes tell the wave by ballot
+    if (__ballot(leader && valid && s < A && acting && !ctx.clear) != 0ull) {
+      unsigned fl = state_check_wave(mv, snap_obb(S, 0));
+      if (valid && s == 0) r.vflags |= (int)fl;
     }
   }
   PHASE_MARK(5);  // after_step
   XMARK(5);
   ep_steps += 1;
   steps_total += 1;
-  // (7) reward / done (base_env.py:303-344)
-  s_flag[lane] = 0;
-  step_sync();
+  // (7) reward / done (base_env.py:303-344).  "The env restarts": one env per wave -> a ballot over the lanes that ask for it;
+  // several envs per wave -> a flag per env in LDS
+  bool want_reset = false;
+  if (!ONE_ENV) {
+    s_flag[lane] = 0;
+    step_sync();
+  }
   unsigned my_fl = 0;
   bool fresh = false;  // multi-agent: this lane's slot received a new agent in this step
   int fresh_idx = 0, fresh_id = 0;  // ... from this respawn record, with this agent id
@@ -443,12 +456,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   float my_rew = 0.0f;
   const bool was_active = acting;  // status at the start of the step (after the delay-done countdown)
   if (valid && s < A && !marl) {
-    if (r.status == ST_ACTIVE) my_rew = reward_done<false>(d, mv, SPV, r, ctx, my_fl, my_dn);
+    if (r.status == ST_ACTIVE) my_rew = reward_done<false>(d, mv, SPV, dest_lane_ref<REGSP && FIX>(FL, mv.lanes, SPV.dest_lane), r, ctx, my_fl, my_dn);
     if (d.cfg.horizon > 0 && ep_steps >= d.cfg.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
     if (sc->max_steps > 0 && ep_steps >= sc->max_steps) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }  // auto_termination
     r.eprew += my_rew;
     bool will_reset = my_dn && d.cfg.auto_reset && A == 1;
-    if (will_reset) { my_fl |= PGD_F_RESET; s_flag[el] = 1; }
+    if (will_reset) { my_fl |= PGD_F_RESET; want_reset = true; if (!ONE_ENV) s_flag[el] = 1; }
   }
   if (marl && one_env) {
     // ---- multi-agent tail: multi_agent_pgdrive.py:109-213, agent_manager.py:134-175, spawn_manager.py:160-215 ----
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (parking) step_sync();
     if (valid && s < A && was_active) {
       if (toll && r.blk == '$') r.php += 1.0f;  // TollGateObservation.observe counts its calls inside the toll block
-      my_rew = reward_done<true>(d, mv, SPV, r, ctx, my_fl, my_dn);
+      my_rew = reward_done<true>(d, mv, SPV, dest_lane_ref<REGSP && FIX>(FL, mv.lanes, SPV.dest_lane), r, ctx, my_fl, my_dn);
       const bool arrive = my_fl & PGD_F_ARRIVE, oor = my_fl & PGD_F_OUT_OF_ROAD, crash = my_fl & PGD_F_CRASH_VEHICLE;
       if (crash && !(gcf.marl_flags & PGD_MA_CRASH_DONE) && !(arrive || oor)) my_dn = false;
       if (oor && !(gcf.marl_flags & PGD_MA_OUT_ROAD_DONE) && !arrive) my_dn = false;
@@ -571,7 +584,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     const bool all_done = n_active == 0 || (gcf.horizon > 0 && ep_steps >= 5 * gcf.horizon);
     if (all_done) {
       my_fl |= PGD_F_ALL_DONE;
-      if (gcf.auto_reset) { my_fl |= PGD_F_RESET; s_flag[el] = 1; }
+      if (gcf.auto_reset) { my_fl |= PGD_F_RESET; want_reset = true; }
     }
     if (lane == 0) d.ei[(size_t)e * PGD_NEI + EI_NEXT_AGENT] = next_agent;
     if (parking) {
@@ -579,13 +592,13 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       if (lane == 0) d.ei[(size_t)e * PGD_NEI + EI_AUX] = s_aux;
     }
   }
-  step_sync();
+  if (!ONE_ENV) step_sync();
   PHASE_MARK(6);  // reward/done
   XMARK(6);
   // (8) auto reset (base_env.py:269-301): the whole env restarts from its (possibly re-drawn) scenario
   int episodes = 0;
-  // ONE_ENV: s_flag[0] is the env's reset flag, the same for every lane: a scalar branch keeps scen / mv in SGPRs
-  const bool resetting = ONE_ENV ? (__ballot(s_flag[0] != 0) != 0ull) : (valid && s_flag[el]);
+  // ONE_ENV: the same for every lane: a scalar branch keeps scen / mv in SGPRs
+  const bool resetting = ONE_ENV ? (__ballot(want_reset) != 0ull) : (valid && s_flag[el]);
   if (resetting) {
     episodes = d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] + 1;
     if (d.cfg.resample_scenario)
@@ -1005,7 +1018,7 @@ __global__ __launch_bounds__(2 * WAVE, PGD_WAVES_PER_SIMD) void k_step2(PgdDev d
   bool my_dn = false;
   float my_rew = 0.0f;
   if (is_ego) {
-    if (r.status == ST_ACTIVE) my_rew = reward_done<false>(d, mv, *sp, r, ctx, my_fl, my_dn);
+    if (r.status == ST_ACTIVE) my_rew = reward_done<false>(d, mv, *sp, mv.lanes[sp->dest_lane], r, ctx, my_fl, my_dn);
     if (d.cfg.horizon > 0 && ep_steps >= d.cfg.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
     if (sc->max_steps > 0 && ep_steps >= sc->max_steps) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }  // auto_termination
     r.eprew += my_rew;
