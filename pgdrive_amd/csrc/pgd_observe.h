@@ -265,6 +265,14 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
   const int o_oth = (KS > 0 ? KS : 2) + 6 + KM + RAM + (toll ? 0 : 10);  // = length of the state block
   const int NO = d.cfg.num_others;
   const int per_other = OTH ? o_oth : 4;
+  // the beam directions of this thread's first four rounds (the whole fan when NL <= 4 nt: 240 beams, one wave) are read here, at
+  // addresses that depend on nothing, and arrive while the state block is worked out; read inside the round loop each one is
+  // waited for on the spot, behind the previous round's row store
+  float2 bd0 = make_float2(0.0f, 0.0f), bd1 = bd0, bd2 = bd0, bd3 = bd0;
+  if (NL > 0) {
+    bd0 = d.beam[min(tid, NL - 1)]; bd1 = d.beam[min(nt + tid, NL - 1)];
+    bd2 = d.beam[min(2 * nt + tid, NL - 1)]; bd3 = d.beam[min(3 * nt + tid, NL - 1)];
+  }
   if (STATE) state_block<STD>(d, mv, sp, ag, row, tid, nt);
   if (toll && tid == 0) {  // TollGateObservation.observe (marl_tollgate.py:84-96)
     const bool in_toll = ag.blk == '$';
@@ -327,10 +335,9 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
   PHASE_MARK(23);  // obs: neighbours
   // lidar (distance_detector.py:65-94, cutils.pyx:60-142): beam i at theta + i*2pi/N, nearest hit fraction
   // every lane of the row takes part in every round (the ballot below needs the body lanes), beams past the fan are not stored
-  for (int i0 = 0; i0 < NL; i0 += nt) {
+  auto cast_round = [&](const int i0, const float2 bd) {  // bd = (cos, sin)(i * 2 pi / NL); rotated by the heading
     const int i = i0 + tid;
     const bool on = i < NL;
-    const float2 bd = d.beam[on ? i : 0];  // (cos, sin)(i * 2 pi / NL); rotated by the heading
     const float dx = R * (bd.x * hx - bd.y * hy), dy = R * (bd.y * hx + bd.x * hy);
     float best = 1.0f;
     // the beams a wave casts in one round lie in one sector of 64 (nt is a multiple of 64): bodies whose window misses the sector
@@ -347,7 +354,12 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
     }
     if (!STD) best = lidar_noise(d, ag.env, ag.slot, ag.tick, i, best);
     if (on) row[o_oth + per_other * NO + i] = best;
-  }
+  };
+  if (0 < NL) cast_round(0, bd0);
+  if (nt < NL) cast_round(nt, bd1);
+  if (2 * nt < NL) cast_round(2 * nt, bd2);
+  if (3 * nt < NL) cast_round(3 * nt, bd3);
+  for (int i0 = 4 * nt; i0 < NL; i0 += nt) cast_round(i0, d.beam[min(i0 + tid, NL - 1)]);
   PHASE_MARK(24);  // obs: lidar
 }
 
