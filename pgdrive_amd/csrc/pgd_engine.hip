@@ -692,7 +692,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     step_sync();
     // only launched with one env per wave: `scen` / `mv` are wave-uniform and already those of the new episode after a reset
     const int scen_now = scen;
-    const MapView& mvo = mv;
+    const MV& mvo = mv;
     PHASE_MARK(20);  // obs: publish
   XMARK(20);
     bool near_any = false;
@@ -701,6 +701,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       const AgentView ag = s_ag[a];
       const bool have = lane < V && d.cfg.num_lasers > 0;
       bool near_a = false;
+      ObsPre pre;  // the row's memory reads go out before the compaction and arrive under it
+      obs_preload(d, mvo, ag, lane, WAVE, pre);
       obs_compact<OBJ>(OL, lane, a, have && S.present[lane], OBJ ? (have && s_kind[lane] == PGD_OBJ_VEHICLE) : true, S.x[lane], S.y[lane],
                   S.ux[lane], S.uy[lane], S.hl[lane], S.hw[lane], S.spd[lane], ag.x, ag.y, d.cfg.lidar_dist, ag.hx, ag.hy,
                   d.cfg.num_lasers, S.hl[a] + S.hw[a] + near_reach(ag.v, t_step), &near_a, t_step);
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       step_sync();
       PHASE_MARK(21);  // obs: compaction
       observe_agent<OBJ, STD>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + (size_t)e * d.ostride + (size_t)a * d.D, lane,
-                    WAVE);
+                    WAVE, nullptr, nullptr, &pre);
       step_sync();
     }
     // hint for the next step's contact tests (EI_NEAR); without a lidar the compaction looked at nothing: always test

@@ -136,11 +136,36 @@ DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, flo
   if (o == 0) { L.n = __popcll(m); L.nveh = __popcll(mv_); }
 }
 
+// What a thread of a row reads from memory at addresses the observing vehicle's view fixes: the lane record (heading_diff) or the
+// navigation extract its state float needs, and the beam directions of its first four lidar rounds.  obs_preload issues the reads;
+// a caller that has other work to do first (the fused observation of k_step: the compaction of the bodies) calls it before that
+// work and hands the result to observe_agent -- read where they are used, each of them is waited for on the spot.
+struct ObsPre {
+  pgd_lane ml;
+  LaneNav nv;
+  float2 bd0, bd1, bd2, bd3;
+};
+DEV int state_lane_of(const AgentView& ag, int q) {  // heading_diff -> last lane of the current road; navi -> first lanes
+  return q < 8 ? ag.cur_first + ag.cur_n - 1 : (q < 13 ? ag.cur_first : ag.next_first);
+}
+template <class MV>
+DEV void obs_preload(const PgdDev& d, const MV& mv, const AgentView& ag, int tid, int nt, ObsPre& p) {
+  const int NL = d.cfg.num_lasers;
+  const int lid = state_lane_of(ag, tid);
+  if (tid == 2) p.ml = mv.lanes[lid];
+  if (tid >= 8 && tid < 18) p.nv = mv.lnav()[lid];
+  p.bd0 = p.bd1 = p.bd2 = p.bd3 = make_float2(0.0f, 0.0f);
+  if (NL > 0) {
+    p.bd0 = d.beam[min(tid, NL - 1)]; p.bd1 = d.beam[min(nt + tid, NL - 1)];
+    p.bd2 = d.beam[min(2 * nt + tid, NL - 1)]; p.bd3 = d.beam[min(3 * nt + tid, NL - 1)];
+  }
+}
+
 // StateObservation.observe of one vehicle (state_obs.py:42-106): ego state + detector fans + navigation info, written to
-// row[0 .. state length) by threads tid in [0, nt)
+// row[0 .. state length) by threads tid in [0, nt).  `pre`: obs_preload's result for this thread (its float q = tid), or null
 template <bool STD, class MV>
 DEV void state_block(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const AgentView& ag, float* __restrict__ row,
-                     int tid, int nt) {
+                     int tid, int nt, const ObsPre* pre = nullptr) {
   const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
   // StateObservation.vehicle_state (state_obs.py:58-106) + navi info (navigation.py:185-197): one lane per float.
   // Row layout: [side fan k | 2 lateral distances][6 ego floats][lane-line fan m][10 navi][4*NO neighbours][NL beams]
@@ -156,11 +181,16 @@ DEV void state_block(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const A
   for (int q = tid; q < 18; q += nt) {
     // every lane fetches the one lane record its float needs BEFORE the branch ladder, so the reads overlap instead of
     // queueing behind each other branch by branch: heading_diff -> last lane of the current road; navi -> first lanes
-    const int lid = q < 8 ? ag.cur_first + ag.cur_n - 1 : (q < 13 ? ag.cur_first : ag.next_first);
+    const int lid = state_lane_of(ag, q);
     pgd_lane ml;  // only the heading_diff lane needs the 64-byte lane record
     LaneNav nv;
-    if (q == 2) ml = mv.lanes[lid];
-    if (q >= 8) nv = mv.lnav()[lid];
+    if (pre && q == tid) {
+      if (q == 2) ml = pre->ml;
+      if (q >= 8) nv = pre->nv;
+    } else {
+      if (q == 2) ml = mv.lanes[lid];
+      if (q >= 8) nv = mv.lnav()[lid];
+    }
     const float max_speed = sp.max_speed;
     float v = 0.0f;
     int col = -1;
@@ -255,7 +285,8 @@ DEV void row_sync() {
 // WAVE_ROW: see row_sync
 template <bool OBJ, bool STD = false, bool OTH = false, bool STATE = true, bool WAVE_ROW = false, class MV>
 DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const AgentView& ag, ObsLds& L,
-                       float* __restrict__ row, int tid, int nt, const VehRec* recs = nullptr, const pgd_spawn* spb = nullptr) {
+                       float* __restrict__ row, int tid, int nt, const VehRec* recs = nullptr, const pgd_spawn* spb = nullptr,
+                       const ObsPre* pre = nullptr) {
   const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
   const float R = d.cfg.lidar_dist;
   const int NL = d.cfg.num_lasers;
@@ -265,15 +296,16 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
   const int o_oth = (KS > 0 ? KS : 2) + 6 + KM + RAM + (toll ? 0 : 10);  // = length of the state block
   const int NO = d.cfg.num_others;
   const int per_other = OTH ? o_oth : 4;
-  // the beam directions of this thread's first four rounds (the whole fan when NL <= 4 nt: 240 beams, one wave) are read here, at
-  // addresses that depend on nothing, and arrive while the state block is worked out; read inside the round loop each one is
-  // waited for on the spot, behind the previous round's row store
+  // the beam directions of this thread's first four rounds (the whole fan when NL <= 4 nt: 240 beams, one wave): read before the
+  // state block (or earlier still, by the caller: obs_preload); read inside the round loop each one is waited for on the spot,
+  // behind the previous round's row store
   float2 bd0 = make_float2(0.0f, 0.0f), bd1 = bd0, bd2 = bd0, bd3 = bd0;
-  if (NL > 0) {
+  if (pre) { bd0 = pre->bd0; bd1 = pre->bd1; bd2 = pre->bd2; bd3 = pre->bd3; }
+  else if (NL > 0) {
     bd0 = d.beam[min(tid, NL - 1)]; bd1 = d.beam[min(nt + tid, NL - 1)];
     bd2 = d.beam[min(2 * nt + tid, NL - 1)]; bd3 = d.beam[min(3 * nt + tid, NL - 1)];
   }
-  if (STATE) state_block<STD>(d, mv, sp, ag, row, tid, nt);
+  if (STATE) state_block<STD>(d, mv, sp, ag, row, tid, nt, pre);
   if (toll && tid == 0) {  // TollGateObservation.observe (marl_tollgate.py:84-96)
     const bool in_toll = ag.blk == '$';
     float* t2 = row + o_oth + per_other * NO + NL;
