@@ -146,10 +146,17 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
 #ifdef PGD_EXITAT
   if (!PGD_DBG_SKIP(0))
 #endif
-  for (int o = g.sub; o < V; o += g.SUB) {
-    const Obb ob = snap_obb(S, base + o);
-    const bool in = o != s && S.present[base + o] && shape_point_dist<OBJ>(ob, px, py) <= 50.0f;
-    objs |= in ? (1ull << o) : 0ull;
+  // a trip count that does not depend on the sub-lane (a constant in the kernels specialised for a default configuration): the
+  // rounds unroll, their LDS reads go out together and the distance tests of different slots overlap
+  {
+    const int rounds = (V + g.SUB - 1) / g.SUB;
+#pragma unroll 6
+    for (int j = 0; j < rounds; ++j) {
+      const int o = g.sub + j * g.SUB, oc = min(o, V - 1);
+      const Obb ob = snap_obb(S, base + oc);
+      const bool in = o < V && o != s && S.present[base + oc] && shape_point_dist<OBJ>(ob, px, py) <= 50.0f;
+      objs |= in ? (1ull << oc) : 0ull;
+    }
   }
   {
     unsigned lo = (unsigned)objs, hi = (unsigned)(objs >> 32);
