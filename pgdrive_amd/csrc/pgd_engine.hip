@@ -1520,13 +1520,13 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->d.sub2 = cfg->num_traffic > 0 ? std::min(4, WAVE / cfg->num_traffic) : 1;
   // Throughput mode: at large N the step is bound by instruction issue, not by the latency of one wave (profiles/r02_sweep.md:
   // 4.2 ns per env-step from 32768 envs on), and the SUB lanes of a vehicle run its scalar phases redundantly.  Engines with
-  // >= 16384 single-ego envs (PGD_PACK=1 / 0 overrides; measured against the one-env kernel: +6 % at 16384 envs, +26 % at 32768, +40 % at 262144) carry one vehicle per lane and as many whole envs per wave as fit --
+  // >= 32768 single-ego envs (PGD_PACK=1 / 0 overrides; measured against the one-env kernel, profiles/r03_sweep.md: -7 % at 16384 envs, +6 % at 32768, +18 % at 262144) carry one vehicle per lane and as many whole envs per wave as fit --
   // three at V = 17 -- with the lidar observation of each env appended to the same launch.
   {
     const char* pk = getenv("PGD_PACK");
     const int epw1 = std::min(WAVE / V, FUSE_MAX_AGENTS);
     const bool can = !marl && cfg->num_agents == 1 && cfg->num_traffic >= 1 && epw1 >= 2 && epw1 * V <= PGD_SUBV && cfg->num_lasers > 0;
-    const bool want = pk ? atoi(pk) != 0 : cfg->num_envs >= 16384;
+    const bool want = pk ? atoi(pk) != 0 : cfg->num_envs >= 32768;
     if (can && want) { h->d.sub = 1; h->d.epw = epw1; h->d.pack_obs = 1; }
   }
   if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }

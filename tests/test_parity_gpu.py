@@ -135,7 +135,7 @@ def test_two_wave_kernel_parity(descs, monkeypatch):
 
 
 def test_throughput_mode_parity(descs, monkeypatch):
-    """Throughput mode (engines with >= 16384 envs, or PGD_PACK=1): one vehicle per lane, three whole envs of 17 slots per wave,
+    """Throughput mode (engines with >= 32768 envs, or PGD_PACK=1): one vehicle per lane, three whole envs of 17 slots per wave,
     the lidar rows of the wave's envs appended to the same launch (k_step<ONE_ENV = false> + pack_obs).  Same teacher-forced
     comparison against the oracle, with an env count that leaves the last wave partly empty, auto-reset with re-drawn
     scenarios; then free-running against the default kernel: flags / done / integer state bit-identical."""
