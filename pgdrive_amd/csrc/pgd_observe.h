@@ -367,6 +367,8 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
   PHASE_MARK(23);  // obs: neighbours
   // lidar (distance_detector.py:65-94, cutils.pyx:60-142): beam i at theta + i*2pi/N, nearest hit fraction
   // every lane of the row takes part in every round (the ballot below needs the body lanes), beams past the fan are not stored
+  const int lane64 = tid & (WAVE - 1);
+  const unsigned my_sec = L.bsec[lane64 < n ? lane64 : 0];  // sectors reached by the body this lane stands for (same in every round)
   auto cast_round = [&](const int i0, const float2 bd) {  // bd = (cos, sin)(i * 2 pi / NL); rotated by the heading
     const int i = i0 + tid;
     const bool on = i < NL;
@@ -374,15 +376,16 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
     float best = 1.0f;
     // the beams a wave casts in one round lie in one sector of 64 (nt is a multiple of 64): bodies whose window misses the sector
     // are skipped for the whole wave -- a scalar walk over the set bits of a ballot -- the others take the per-beam window test
-    const int lane64 = tid & (WAVE - 1);
     const int sec = (i0 + (tid & ~(WAVE - 1))) >> 6;
-    unsigned long long todo = __ballot(lane64 < n && ((L.bsec[lane64 < n ? lane64 : 0] >> (sec & 31)) & 1u) != 0u);
+    unsigned long long todo = __ballot(lane64 < n && ((my_sec >> (sec & 31)) & 1u) != 0u);
     for (; todo != 0ull; todo &= todo - 1ull) {
       const int k = __builtin_ctzll(todo);
-      int off = i - L.bi0[k];
+      // window and box of body k in one round trip (the box is needed by some beam of the round: that is what the sector bit says)
+      const int bi0 = L.bi0[k], bcnt = L.bcnt[k];
+      const Obb box{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]};
+      int off = i - bi0;
       off += off < 0 ? NL : 0;
-      if (on && off < L.bcnt[k])
-        best = fminf(best, shape_ray<OBJ>(Obb{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]}, px, py, dx, dy));
+      if (on && off < bcnt) best = fminf(best, shape_ray<OBJ>(box, px, py, dx, dy));
     }
     if (!STD) best = lidar_noise(d, ag.env, ag.slot, ag.tick, i, best);
     if (on) row[o_oth + per_other * NO + i] = best;
