@@ -50,8 +50,10 @@ enum {
   EI_STEPS_TOTAL,             /* steps since pgd_reset (RNG counter) */
   EI_NEXT_AGENT,              /* next "agent{k}" id (AgentManager.next_agent_count) */
   EI_AUX,                     /* PGD_MA_PARKING: ParkingLotSpawnManager.parking_space_available as a bit mask */
-  EI_NEAR,                    /* device-private hint (pgd_get_state returns 0, pgd_set_state ignores it): left by the fused
-                                 observation, 0 = no body can reach an agent during the next step (contact tests skipped) */
+  EI_NEAR,                    /* device-private hints (pgd_get_state returns 0, pgd_set_state ignores it and resets it to "unknown"):
+                                 bit 0, left by the fused observation: 0 = no body can reach an agent during the next step (contact
+                                 tests skipped); bits 1-2, single-agent one-env waves: 1 / 2 = the agent does not / does stand on the
+                                 trigger road of the next traffic group (the next step's trigger test), 0 = unknown */
   PGD_NEI
 };
 enum { ST_EMPTY = 0, ST_PENDING = 1, ST_ACTIVE = 2, ST_REMOVED = 3, ST_DYING = 4 /* finished agent, static, counting down */ };

@@ -236,6 +236,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // EI_NEAR, left by the observation of the previous step: 0 = no body of the env can reach an agent during this step, so no
   // sub-step pose is kept and no contact test runs; anything else (and every engine without the fused observation) tests
   bool near_env = true;
+  // bits 1-2 of the same word, left by the previous step of a single-agent one-env wave: 1 = the agent does NOT stand on the
+  // trigger road of the next traffic group, 2 = it does, 0 = unknown (after a reset, pgd_set_state, other kernels): evaluate it here
+  int trig_hint = 0;
 #ifdef PGD_NO_SUBSTEP
   constexpr bool n_mid_enabled = false;
 #else
@@ -265,7 +268,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     ng = d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP];
     ep_steps = d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS];
     steps_total = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
-    if (ONE_ENV || packed) near_env = d.ei[(size_t)(e) * PGD_NEI + EI_NEAR] != 0;
+    if (ONE_ENV || packed) {
+      const int hint = d.ei[(size_t)(e) * PGD_NEI + EI_NEAR];
+      near_env = (hint & 1) != 0;
+      trig_hint = (hint >> 1) & 3;
+    }
   }
   PHASE_MARK(13);  // load: scenario + table staging
   XMARK(13);
@@ -277,7 +284,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   // (1) TrafficManager.before_step trigger (traffic_manager.py:76-85): an agent of the env stands on the trigger road of the next
   // group.  One env per wave: a ballot over the wave's lanes (no trip through LDS); several envs per wave: a flag per env.
-  const bool on_trigger = valid && s < A && r.status == ST_ACTIVE && ng < sc->n_groups && mv.lanes[r.lane].road == sc->trigger_road[ng];
+  bool on_trigger;
+  if (ONE_ENV && !MARL && A == 1 && trig_hint != 0) on_trigger = valid && s < A && trig_hint == 2;
+  else on_trigger = valid && s < A && r.status == ST_ACTIVE && ng < sc->n_groups && mv.lanes[r.lane].road == sc->trigger_road[ng];
   bool trig;
   if (ONE_ENV) {
     trig = __ballot(on_trigger) != 0ull;
@@ -428,6 +437,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     after_step_vehicle<ONE_ENV>(d.cfg, mv, g, *sp, SPV, r, s < A, !one_env, ctx);
     if (s >= A && (r.vflags & PGD_F_OFF_LANE)) r.status = ST_REMOVED;
   }
+  // the trigger test of the NEXT step (TrafficManager.before_step looks at the state this step leaves): the road of the agent's lane
+  // is read here, next to after_step's reads of the same record, and the verdict travels in the env's hint word -- the next step
+  // starts without the two dependent reads the test costs
+  int trig_next = 0;
+  if (ONE_ENV && !MARL && A == 1 && valid && s < A)
+    trig_next = (r.status == ST_ACTIVE && ng < sc->n_groups && mv.lanes[r.lane].road == sc->trigger_road[ng]) ? 2 : 1;
   if (one_env && A > 1 && acting && s < A && !ctx.clear)
     r.vflags |= (int)state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * SPV.length, 0.5f * SPV.width});
   PHASE_MARK(25);  // after_step: per-vehicle part
@@ -716,7 +731,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // hint for the next step's contact tests (EI_NEAR); without a lidar the compaction looked at nothing: always test
     near_next = near_hint_usable(d.cfg) ? (__ballot(near_any) != 0ull) : true;
   }
-  if (ONE_ENV && lane == 0 && (int)near_next != (int)near_env) d.ei[(size_t)e * PGD_NEI + EI_NEAR] = near_next ? 1 : 0;
+  if (ONE_ENV) {
+    // lane 0 is the leader of slot 0, the agent of a single-agent env; a restart leaves the trigger verdict unknown
+    const int hint_next = (near_next ? 1 : 0) | ((!MARL && A == 1 && !resetting) ? (trig_next << 1) : 0);
+    if (lane == 0 && hint_next != ((near_env ? 1 : 0) | (trig_hint << 1))) d.ei[(size_t)e * PGD_NEI + EI_NEAR] = hint_next;
+  }
   if (packed && obs == nullptr && valid && s == 0 && leader && !near_env) d.ei[(size_t)e * PGD_NEI + EI_NEAR] = 1;  // no row, no hint
   // multi-agent engine: the rows of all agents, from the records and flags this wave has just written (the barrier makes
   // them visible to the whole workgroup); the step's LDS is free by now
@@ -885,7 +904,7 @@ __global__ __launch_bounds__(2 * WAVE, PGD_WAVES_PER_SIMD) void k_step2(PgdDev d
   int scen = ei[EI_SCEN];
   int ng = ei[EI_NEXT_GROUP], ep_steps = ei[EI_EP_STEPS];
   uint32_t steps_total = (uint32_t)ei[EI_STEPS_TOTAL];
-  const bool near_env = ei[EI_NEAR] != 0;
+  const bool near_env = (ei[EI_NEAR] & 1) != 0;
   const pgd_scenario* sc = d.scen + scen;
   MapView mv = map_view_of(d, d.env_map + e);
   const Veh* img = d.reset_img + (size_t)scen * V;
@@ -1371,6 +1390,12 @@ __global__ __launch_bounds__(256) void k_lane_keep(PgdDev d, const float* __rest
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
+// the env hint words back to "test contacts, trigger verdict unknown" (upload calls: maps / scenarios of running envs changed)
+__global__ void k_clear_hints(int32_t* ei, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) ei[(size_t)e * PGD_NEI + EI_NEAR] = 1;
+}
+
 struct pgd_engine {
   PgdDev d;
   int device;
@@ -1681,6 +1706,7 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
   h->have_maps = true;
   h->img_dirty = true;  // running envs fall back to their own records until their next reset
   HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
+  hipLaunchKernelGGL(k_clear_hints, dim3((h->d.N + 255) / 256), dim3(256), 0, h->stream, h->d.ei, h->d.N);
   return build_reset_image(h);  // eagerly (needs maps + scenarios): pgd_step never allocates, so it can be graph-captured
 }
 
@@ -1710,6 +1736,7 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   h->have_scen = true;
   h->img_dirty = true;
   HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
+  hipLaunchKernelGGL(k_clear_hints, dim3((h->d.N + 255) / 256), dim3(256), 0, h->stream, h->d.ei, h->d.N);
   return build_reset_image(h);
 }
 

@@ -267,6 +267,41 @@ def test_default_multi_agent_kernel_matches_the_general_kernel(monkeypatch):
     assert "specialised" not in gen.describe_step() and "specialised" not in other.describe_step()
 
 
+@pytest.mark.parametrize("traffic_mode", ["trigger", "hybrid"])
+def test_step_hints_match_the_unhinted_path(descs, traffic_mode):
+    """k_step leaves two verdicts for the env's next step in a device-private word (EI_NEAR): "no body can reach the agent" (contact
+    tests skipped) and whether the agent stands on the trigger road of the next traffic group (the trigger test then needs no
+    reads).  pgd_set_state resets the word to "unknown".  An engine that free-runs with the hints and one that has its own state
+    written back before every step (always the unhinted path) must stay bit-identical: observations, rewards, flags, state --
+    through traffic activations, crashes and auto-resets with re-drawn scenarios."""
+    n_envs = 96
+    torch, a, _, _ = _engines(descs, n_envs, seed=9, resample_scenario=1, traffic_mode=traffic_mode)
+    _, b, _, _ = _engines(descs, n_envs, seed=9, resample_scenario=1, traffic_mode=traffic_mode)
+    ids = np.arange(n_envs) % 8
+    a.reset(ids); b.reset(ids)
+    rng = np.random.default_rng(33)
+    n_done = activations = 0
+    prev_pending = None
+    for t in range(600):
+        act = util.driving_actions(rng, n_envs)
+        at = torch.from_numpy(act).to(a.device)
+        f, i, ei = b.get_state()
+        b.set_state(f, i, ei)  # hint word back to "unknown"
+        o1, r1, d1, f1 = [x.clone() for x in a.step(at)]
+        o2, r2, d2, f2 = [x.clone() for x in b.step(at)]
+        a.sync(); b.sync()
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(f1, f2), "step %d" % t
+        fa, ia, ea = a.get_state()
+        fb, ib, eb = b.get_state()
+        assert (ia == ib).all() and (ea == eb).all() and np.array_equal(fa, fb), "state differs at step %d" % t
+        pending = (ia[_abi.SI["STATUS"]] == _abi.ST_PENDING).sum()
+        if prev_pending is not None and pending < prev_pending:
+            activations += 1
+        prev_pending = pending
+        n_done += int(d1.sum())
+    assert n_done > 30 and activations > 10
+
+
 def _teacher_forced(descs, num_traffic, num_lasers):
     n_envs = 64
     torch, eng, ora, cfg = _engines(descs, n_envs, num_traffic=num_traffic, num_lasers=num_lasers)
