@@ -226,7 +226,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // read ONCE, four 16-byte loads in one round trip, when the record's address is known; the phases used to fetch its fields one
   // by one where they needed them, each time for a whole memory latency (profiles/r03_notes.md).  Kernels with one env per wave
   // only: the multi-env instantiations have no registers to spare.
-  constexpr bool REGSP = ONE_ENV && !MARL;
+  constexpr bool REGSP = ONE_ENV;
   pgd_spawn sl;
   pgd_lane FL;  // REGSP && FIX (registers to spare): the agent's destination lane record, read ahead
 #define SPV spawn_ref<REGSP>(sl, sp)
