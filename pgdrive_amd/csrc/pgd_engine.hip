@@ -741,6 +741,15 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // them visible to the whole workgroup); the step's LDS is free by now
   if (ONE_ENV && MARL && obs != nullptr) {
     __syncthreads();
+    // engines without traffic slots and with the lanes of an agent laid out as the routine lays out its state block (always, when
+    // V == A: both split the wave into A groups) hand over what the wave holds; else the routine reads the env back from memory
+    if (FIX) {  // the default multi-agent configuration has no traffic slots (T == 0 is one of its constants)
+      const MapView mvb = mv;
+      const unsigned lead_fl = (unsigned)__shfl((int)my_fl, g.lead);  // the step flags are complete in the slot's first lane only
+      const EnvInWave in_wave{&r, &SPV, &mvb, lead_fl, scen, steps_total, valid ? s : A, g.sub};  // lanes past the last slot: no agent
+      if (V == A && d.sub == WAVE / A) observe_env_body<1, false, true>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g, &in_wave);
+      else observe_env_body<1, false>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
+    } else
     observe_env_body<1, false>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
   }
   // throughput mode (several envs per wave, one ego each, lidar): the rows of the wave's envs one after the other, each by the

@@ -433,9 +433,21 @@ struct ObsEnvLds {
 // bits, then centre distance and speed of every pair of the round
 // ALLOW_OTH = false compiles the neighbour-state-vector phase (PGD_MA_OTHERS_STATE) out: the copy appended to k_step stays as small
 // as it was (every addition to that kernel costs SGPR spills across the whole step)
-template <int NW, bool ALLOW_OTH = true>
+// What the wave that has just stepped the env still holds of it (k_step's multi-agent tail, engines without traffic slots: the
+// lanes of agent `slot` are exactly the lanes observe_env_body gives its state block): with it the routine starts from registers
+// instead of reading back from memory the records, flags, env words, map header and spawn records the wave has just written or used.
+struct EnvInWave {
+  const Veh* me;          // this lane's vehicle
+  const pgd_spawn* sp;    // its spawn record (scalar head)
+  const MapView* mv;
+  uint32_t fl;            // its step flags
+  int scen;
+  uint32_t tick;
+  int slot, sub;
+};
+template <int NW, bool ALLOW_OTH = true, bool FUSED = false>
 DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const uint32_t* flags, ObsEnvLds<NW>& M,
-                          unsigned* s_minb_all, const int G) {
+                          unsigned* s_minb_all, const int G, const EnvInWave* in_wave = nullptr) {
   float (&bX)[WAVE] = M.bX; float (&bY)[WAVE] = M.bY; float (&bUX)[WAVE] = M.bUX; float (&bUY)[WAVE] = M.bUY;
   float (&bHL)[WAVE] = M.bHL; float (&bHW)[WAVE] = M.bHW; float (&bV)[WAVE] = M.bV; float (&bAID)[WAVE] = M.bAID;
   int (&bST)[WAVE] = M.bST; uint32_t (&bFL)[WAVE] = M.bFL; float (&aMS)[WAVE] = M.aMS; int (&aWant)[WAVE] = M.aWant;
@@ -446,29 +458,48 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   // ---- loads whose addresses follow from the block index: body `lane` (first half of its record), the agent of this lane's
   // state group (whole record), step flags, scenario, step count, the env's map header
   const int LPA = WAVE * NW / A;  // lanes per agent in the state phase (A <= WAVE)
-  const int sa = tid / LPA, st = tid - sa * LPA;
+  const int sa = FUSED ? in_wave->slot : tid / LPA, st = FUSED ? in_wave->sub : tid - (tid / LPA) * LPA;
   const bool s_on = sa < A;
   Veh me;
-  load_rec(recs + (s_on ? sa : 0), me);
   Veh body;  // only the first 64 bytes are filled
+  uint32_t f_me, f_body = 0u;
+  int scen;
+  uint32_t tick;
+  MapView mv;
+  if (FUSED) {
+    me = *in_wave->me;
+    f_me = s_on ? in_wave->fl : 0u;
+    scen = in_wave->scen; tick = in_wave->tick; mv = *in_wave->mv;
+  } else {
+    load_rec(recs + (s_on ? sa : 0), me);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) reinterpret_cast<uint4*>(&body)[k] = reinterpret_cast<const uint4*>(recs + (tid < V ? tid : 0))[k];
-  const uint32_t f_me = (flags && s_on) ? flags[(size_t)e * A + sa] : 0u;
-  const uint32_t f_body = (flags && tid < A) ? flags[(size_t)e * A + tid] : 0u;
-  const int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
-  const uint32_t tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
-  const MapView mv = map_view_of(d, d.env_map + e);
+    for (int k = 0; k < 4; ++k) reinterpret_cast<uint4*>(&body)[k] = reinterpret_cast<const uint4*>(recs + (tid < V ? tid : 0))[k];
+    f_me = (flags && s_on) ? flags[(size_t)e * A + sa] : 0u;
+    f_body = (flags && tid < A) ? flags[(size_t)e * A + tid] : 0u;
+    scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
+    tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
+    mv = map_view_of(d, d.env_map + e);
+  }
   const pgd_spawn* spb = d.spawns + (size_t)scen * d.sstride;
-  const pgd_spawn& msp = spb[me.spawn];
-  const pgd_spawn& so = spb[body.spawn];
-  const float so_len = so.length, so_wid = so.width;
-  const int so_kind = so.kind;
+  const pgd_spawn& msp = FUSED ? *in_wave->sp : spb[me.spawn];
   // which slots get a row: after a multi-agent step the ones that reported or were (re)spawned, else the active ones
   bool want = me.status == ST_ACTIVE;
   if (flags) want = (f_me & PGD_F_RESET) ? want : (f_me & (PGD_F_REPORT | PGD_F_NEW)) != 0;
   want = want && s_on;
   // ---- publish the bodies and the observers
-  if (tid < V) {
+  if (FUSED) {  // V == A: the first lane of every agent publishes its own vehicle
+    if (s_on && st == 0) {
+      const int so_kind = msp.kind;
+      bX[sa] = me.x; bY[sa] = me.y; bUX[sa] = me.hx; bUY[sa] = me.hy;
+      bHL[sa] = 0.5f * msp.length; bHW[sa] = so_kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * msp.width;
+      bV[sa] = me.v; bAID[sa] = me.agent_id;
+      bST[sa] = (int)me.status | (so_kind << 8);
+      bFL[sa] = f_me;
+    }
+  } else if (tid < V) {
+    const pgd_spawn& so = spb[body.spawn];
+    const float so_len = so.length, so_wid = so.width;
+    const int so_kind = so.kind;
     bX[tid] = body.x; bY[tid] = body.y; bUX[tid] = body.hx; bUY[tid] = body.hy;
     bHL[tid] = 0.5f * so_len; bHW[tid] = so_kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * so_wid;
     bV[tid] = body.v; bAID[tid] = body.agent_id;
