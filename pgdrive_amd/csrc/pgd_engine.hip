@@ -161,12 +161,14 @@ DEV void step_sync() { row_sync<true>(); }
   F(c.out_of_road_penalty, 5.0f) F(c.crash_vehicle_penalty, 5.0f) F(c.crash_object_penalty, 5.0f)                                   \
   F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f) F(c.side_lasers, 0) F(c.lane_line_lasers, 0)                                    \
   F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f)
-// Multi-agent engines: the scalar fields of MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG (multi_agent_pgdrive.py:12-55: 72 beams x 40 m, no
+// Multi-agent engines: the scalar fields of MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG (multi_agent_pgdrive.py:12-55: a 40 m lidar without
 // neighbour rows, penalties 10, delay-done 25 steps, crash / out-of-road done, respawn; the roundabout / intersection / bottleneck
-// envs run it unchanged) -- the number of agents, the spawn places and the horizon stay run-time values.
+// envs run it unchanged) -- the number of agents, the spawn places, the horizon AND the number of beams stay run-time values (the
+// reference's 72 beams and BASELINE config 5's 240 run the same instantiation: as a constant the beam count gave the 72-beam row
+// 0.8 % and cost the 240-beam row 6 %, which then fell back to the general kernel).
 #define PGD_FIXM_FIELDS(F, d, c)                                                                                                    \
-  F(d.T, 0) F(d.D, 90) F(d.epw, 1) F(d.pack_obs, 0)                                                                                 \
-  F(c.num_traffic, 0) F(c.num_lasers, 72) F(c.num_others, 0) F(c.lidar_dist, 40.0f) F(c.dt, 0.02f) F(c.decision_repeat, 5)          \
+  F(d.T, 0) F(d.epw, 1) F(d.pack_obs, 0)                                                                                 \
+  F(c.num_traffic, 0) F(c.num_others, 0) F(c.lidar_dist, 40.0f) F(c.dt, 0.02f) F(c.decision_repeat, 5)          \
   F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0) F(c.enable_reverse, 0)                                     \
   F(c.marl_flags, (PGD_MA_ENABLED | PGD_MA_CRASH_DONE | PGD_MA_OUT_ROAD_DONE | PGD_MA_ALLOW_RESPAWN)) F(c.use_lateral, 0)           \
   F(c.out_of_route_done, 0) F(c.success_reward, 10.0f) F(c.out_of_road_penalty, 10.0f) F(c.crash_vehicle_penalty, 10.0f)            \
