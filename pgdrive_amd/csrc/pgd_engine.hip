@@ -174,19 +174,31 @@ DEV void step_sync() { row_sync<true>(); }
   F(c.out_of_route_done, 0) F(c.success_reward, 10.0f) F(c.out_of_road_penalty, 10.0f) F(c.crash_vehicle_penalty, 10.0f)            \
   F(c.crash_object_penalty, 10.0f) F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f) F(c.side_lasers, 0) F(c.lane_line_lasers, 0)   \
   F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f) F(c.delay_done, 25)
-template <bool ONE_ENV, bool MARL>
+// BASELINE config 2: the ego alone, no lidar (dynamics + reward + the 18-float state vector), otherwise the single-agent defaults --
+// four envs per wave, 16 sub-lanes per ego, the row written by k_step itself.
+#define PGD_FIXE_FIELDS(F, d, c)                                                                                                    \
+  F(d.V, 1) F(d.A, 1) F(d.T, 0) F(d.D, 18) F(d.sstride, 1) F(d.sub, 16) F(d.epw, 4) F(d.pack_obs, 0)                                 \
+  F(c.num_agents, 1) F(c.num_traffic, 0) F(c.num_lasers, 0) F(c.num_others, 0) F(c.dt, 0.02f) F(c.decision_repeat, 5)                \
+  F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0) F(c.enable_reverse, 0) F(c.marl_flags, 0)                  \
+  F(c.use_lateral, 0) F(c.out_of_route_done, 0) F(c.success_reward, 10.0f) F(c.out_of_road_penalty, 5.0f)                           \
+  F(c.crash_vehicle_penalty, 5.0f) F(c.crash_object_penalty, 5.0f) F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f)               \
+  F(c.side_lasers, 0) F(c.lane_line_lasers, 0) F(c.random_agent_model, 0)
+enum { FIXK_DEFAULT = 0, FIXK_MARL = 1, FIXK_EGO_ONLY = 2 };
+template <bool ONE_ENV, bool MARL, bool STD>
 DEV void write_fixed_config(PgdDev& d) {
   pgd_config& c = d.cfg;
 #define PGD_F_SET(f, v) f = v;
   if (MARL) { PGD_FIXM_FIELDS(PGD_F_SET, d, c) }
+  else if (!ONE_ENV && !STD) { PGD_FIXE_FIELDS(PGD_F_SET, d, c) }
   else { PGD_FIX_FIELDS(PGD_F_SET, d, c, ONE_ENV) }
 #undef PGD_F_SET
 }
-static bool fix_config_matches(const PgdDev& d, bool one_env, bool marl = false) {
+static bool fix_config_matches(const PgdDev& d, bool one_env, int kind = FIXK_DEFAULT) {
   const pgd_config& c = d.cfg;
   bool ok = true;
 #define PGD_F_TEST(f, v) ok = ok && (f == v);
-  if (marl) { PGD_FIXM_FIELDS(PGD_F_TEST, d, c) }
+  if (kind == FIXK_MARL) { PGD_FIXM_FIELDS(PGD_F_TEST, d, c) }
+  else if (kind == FIXK_EGO_ONLY) { PGD_FIXE_FIELDS(PGD_F_TEST, d, c) }
   else { PGD_FIX_FIELDS(PGD_F_TEST, d, c, one_env) }
 #undef PGD_F_TEST
   return ok;
@@ -195,7 +207,7 @@ template <bool ONE_ENV, bool MARL, bool OBJ, bool STD = false, bool FIX = false>
 __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
                                                 float* __restrict__ obs) {
-  if (FIX) write_fixed_config<ONE_ENV, MARL>(d);
+  if (FIX) write_fixed_config<ONE_ENV, MARL, STD>(d);
 
   __shared__ StepUnion U;
   Snap& S = U.step.S;
@@ -1864,7 +1876,7 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
                                     : (h->d.epw == 1 ? "k_step: one env per wave" : "k_step: several envs per wave");
   if (marl) {
     kern = h->has_objects ? k_step<true, true, true> : k_step<true, true, false>;  // objects = toll booths
-    if (!h->has_objects && !h->no_fix && fix_config_matches(dv, true, true)) {
+    if (!h->has_objects && !h->no_fix && fix_config_matches(dv, true, FIXK_MARL)) {
       kern = k_step<true, true, false, false, true>;
       kname = "k_step: one env per wave, specialised for the default multi-agent configuration";
     }
@@ -1880,6 +1892,10 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
     }
   }
   else if (h->has_objects) kern = k_step<false, false, true>;
+  else if (!h->d.pack_obs && !h->no_fix && fix_config_matches(dv, false, FIXK_EGO_ONLY)) {
+    kern = k_step<false, false, false, false, true>;
+    kname = "k_step: several envs per wave, specialised for the ego-only configuration without a lidar";
+  }
   else if (h->d.pack_obs) {
     const pgd_config& c = h->d.cfg;
     const bool std_obs = c.side_lasers == 0 && c.lane_line_lasers == 0 && !c.random_agent_model &&

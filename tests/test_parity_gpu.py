@@ -302,6 +302,36 @@ def test_step_hints_match_the_unhinted_path(descs, traffic_mode):
     assert n_done > 30 and activations > 10
 
 
+def test_ego_only_kernel_matches_the_general_kernel(descs, monkeypatch):
+    """BASELINE config 2 (the ego alone, no lidar: dynamics + reward + the 18-float state vector) has its own instantiation of k_step
+    too (four envs per wave, configuration compiled in).  Against the general kernel from the same state with the same actions."""
+    n_envs = 130  # the last wave is partly empty
+    monkeypatch.delenv("PGD_NO_FIX", raising=False)
+    torch, fix, _, _ = _engines(descs, n_envs, seed=3, resample_scenario=1, num_traffic=0, num_lasers=0)
+    monkeypatch.setenv("PGD_NO_FIX", "1")
+    _, gen, _, _ = _engines(descs, n_envs, seed=3, resample_scenario=1, num_traffic=0, num_lasers=0)
+    ids = np.arange(n_envs) % 8
+    fix.reset(ids); gen.reset(ids)
+    rng = np.random.default_rng(4)
+    n_done = 0
+    for t in range(400):
+        act = util.driving_actions(rng, n_envs)
+        f, i, ei = gen.get_state()
+        fix.set_state(f, i, ei)
+        a = torch.from_numpy(act).to(gen.device)
+        o1, r1, d1, f1 = [x.clone() for x in gen.step(a)]
+        o2, r2, d2, f2 = [x.clone() for x in fix.step(a)]
+        gen.sync(); fix.sync()
+        assert torch.equal(d1, d2) and torch.equal(f1, f2), "flags differ at step %d" % t
+        assert float((o1 - o2).abs().max()) < 2e-6 and float((r1 - r2).abs().max()) < 2e-5
+        g1, i1, e1 = gen.get_state()
+        g2, i2, e2 = fix.get_state()
+        assert (i1 == i2).all() and (e1 == e2).all() and np.abs(g1 - g2).max() < 1e-4
+        n_done += int(d1.sum())
+    assert n_done > 20 and o1.shape[-1] == 18
+    assert "specialised for the ego-only" in fix.describe_step() and "specialised" not in gen.describe_step()
+
+
 def _teacher_forced(descs, num_traffic, num_lasers):
     n_envs = 64
     torch, eng, ora, cfg = _engines(descs, n_envs, num_traffic=num_traffic, num_lasers=num_lasers)
