@@ -1389,11 +1389,13 @@ __global__ __launch_bounds__(BLOCK == WAVE ? WAVE * OBS_RPB : BLOCK) void k_obse
 // (wave w takes passes w, w + NW, ...; each wave has its own scratch and synchronises with itself only).  NW = 4 when there
 // are at least four passes (A >= 4 * (WAVE / V)), else 1.
 // NW = 4 when the pair phase has at least four passes (A >= 4 * (WAVE / V)), else 1.
-template <int NW>
+// FIX: the engine runs the default multi-agent configuration (same constants as k_step's instantiation for it, PGD_FIXM_FIELDS)
+template <int NW, bool FIX = false>
 __global__ __launch_bounds__(WAVE * NW) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags, int G) {
+  if (FIX) write_fixed_config<true, true, false>(d);
   extern __shared__ unsigned s_minb_dyn[];
   __shared__ ObsEnvLds<NW> M;
-  observe_env_body<NW, true>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);
+  observe_env_body<NW, !FIX>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);
 }
 
 // scripted lane-keeping policy (pgd_lane_keep_actions): one thread per env
@@ -1779,8 +1781,10 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
     while (G > 1 && (size_t)nw * observe_env_words(G, NL, V) * 4 + oth_bytes > 49152) --G;
     const size_t dyn = (size_t)nw * observe_env_words(G, NL, V) * 4 + oth_bytes;
     if (dyn <= 49152) {
-      if (four) hipLaunchKernelGGL(k_observe_env<4>, dim3(envs), dim3(WAVE * 4), dyn, stream, D, d_obs, d_flags, G);
-      else hipLaunchKernelGGL(k_observe_env<1>, dim3(envs), dim3(WAVE), dyn, stream, D, d_obs, d_flags, G);
+      const bool fix = !h->no_fix && !h->has_objects && fix_config_matches(D, true, FIXK_MARL);
+      void (*ke)(PgdDev, float*, const uint32_t*, int) = four ? k_observe_env<4> : k_observe_env<1>;
+      if (fix) ke = four ? k_observe_env<4, true> : k_observe_env<1, true>;
+      hipLaunchKernelGGL(ke, dim3(envs), dim3(WAVE * nw), dyn, stream, D, d_obs, d_flags, G);
       HIPCHK(hipGetLastError());
       return PGD_OK;
     }
