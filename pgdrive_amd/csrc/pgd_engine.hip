@@ -203,10 +203,22 @@ static bool fix_config_matches(const PgdDev& d, bool one_env, int kind = FIXK_DE
 #undef PGD_F_TEST
   return ok;
 }
+// What only the rare paths of a step read (an env restarting, a multi-agent respawn): a second by-value argument that is never
+// written, so its fields are fetched from the argument segment where they are used -- in the specialised kernels `d` is a local
+// copy whose every used field is an entry load and stays live in a scalar register (or a spill lane) to the end.
+struct PgdCold {
+  const pgd_map* scen_map;
+  uint8_t* bev_fill;
+  const float2* spawn_hv;
+  const struct Veh* respawn_img;
+  int n_scen;
+  uint32_t seed;
+  int env_base;
+};
 template <bool ONE_ENV, bool MARL, bool OBJ, bool STD = false, bool FIX = false>
 __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
-                                                float* __restrict__ obs) {
+                                                float* __restrict__ obs, const PgdCold cold) {
   if (FIX) write_fixed_config<ONE_ENV, MARL, STD>(d);
 
   __shared__ StepUnion U;
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       const pgd_spawn* rbase = d.spawns + (size_t)scen * d.sstride + V;
       for (int p = 0; p < gcf.respawn_places; ++p) {
         const pgd_spawn& place = rbase[p * gcf.respawn_dests];
-        const float2 phv = d.spawn_hv[(size_t)scen * d.sstride + V + p * gcf.respawn_dests];
+        const float2 phv = cold.spawn_hv[(size_t)scen * d.sstride + V + p * gcf.respawn_dests];
         const float pc = phv.x, ps = phv.y;
         const Obb region{place.x, place.y, pc, ps, 4.0f, 1.5f};  // RESPAWN_REGION 8 m x 3 m (spawn_manager.py:27-28)
         const bool blocks = lane < V && S.present[lane] && obb_overlap(region, snap_obb(S, lane));
@@ -582,7 +594,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
           my_fl |= PGD_F_NEW;
           if (leader) {
             const pgd_spawn& nsp = d.spawns[(size_t)scen * d.sstride + fresh_idx];
-            const float2 nhv = d.spawn_hv[(size_t)scen * d.sstride + fresh_idx];
+            const float2 nhv = cold.spawn_hv[(size_t)scen * d.sstride + fresh_idx];
             S.x[slot] = nsp.x; S.y[slot] = nsp.y; S.ux[slot] = nhv.x; S.uy[slot] = nhv.y;
             S.hl[slot] = 0.5f * nsp.length; S.hw[slot] = 0.5f * nsp.width;
             S.present[slot] = 1;
@@ -595,7 +607,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (fresh) {  // the new agent's record, first localisation included, from the respawn image (k_respawn_image)
       sp = d.spawns + (size_t)scen * d.sstride + fresh_idx;
       if (REGSP) spawn_head_load(sp, sl);
-      load_rec(d.respawn_img + (size_t)scen * (d.sstride - V) + (fresh_idx - V), r);
+      load_rec(cold.respawn_img + (size_t)scen * (d.sstride - V) + (fresh_idx - V), r);
       r.agent_id = (float)fresh_id;
     }
     PHASE_MARK(27);  // marl: respawn
@@ -631,9 +643,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (resetting) {
     episodes = d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] + 1;
     if (d.cfg.resample_scenario)
-      scen = (int)(pgd_rng(d.cfg.seed, (uint32_t)(d.cfg.env_base + e), 0x5ce9a210u, (uint32_t)episodes) % (uint32_t)d.n_scen);
+      scen = (int)(pgd_rng(cold.seed, (uint32_t)(cold.env_base + e), 0x5ce9a210u, (uint32_t)episodes) % (uint32_t)cold.n_scen);
     sc = d.scen + scen;
-    mv = map_view_as<MV>(d, d.scen_map + scen);  // the header of the new episode's map (the per-env copy is rewritten below)
+    mv = map_view_as<MV>(d, cold.scen_map + scen);  // the header of the new episode's map (the per-env copy is rewritten below)
     ng = 0;
     ep_steps = 0;
   }
@@ -647,13 +659,13 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (marl && s < A && r.status == ST_ACTIVE) my_fl |= PGD_F_NEW;
     if (s == 0 && d.cfg.resample_scenario)  // the env's header copy follows the scenario (any number of sub-lanes)
       for (int q = g.sub; q < (int)(sizeof(pgd_map) / 16); q += g.SUB)
-        reinterpret_cast<uint4*>(d.env_map + e)[q] = reinterpret_cast<const uint4*>(d.scen_map + scen)[q];
+        reinterpret_cast<uint4*>(d.env_map + e)[q] = reinterpret_cast<const uint4*>(cold.scen_map + scen)[q];
     if (s == 0 && leader) {
       d.ei[(size_t)(e) * PGD_NEI + EI_SCEN] = scen;
       d.ei[(size_t)(e) * PGD_NEI + EI_EPISODES] = episodes;
       d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_AGENT] = A == 1 ? 1 : __popcll(am);
       d.ei[(size_t)(e) * PGD_NEI + EI_AUX] = sc->aux;  // parking: the pool of the new episode
-      if (d.bev_fill) d.bev_fill[e] = 1;
+      if (cold.bev_fill) cold.bev_fill[e] = 1;
     }
   }
   if (valid && leader && s < A) {
@@ -800,7 +812,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       AgentView ag = s_ag[q];
       const int scen_q = ag.cur_n >> 8;
       ag.cur_n &= 0xff;
-      const MV mvq = map_view_as<MV>(d, d.scen_map + scen_q);
+      const MV mvq = map_view_as<MV>(d, cold.scen_map + scen_q);
       const int bq = q * V;
       const bool have = lane < V && d.cfg.num_lasers > 0;
       const int sl = bq + (lane < V ? lane : 0);
@@ -1875,7 +1887,7 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   if (prof || timing || g_open) HIPCHK(hipEventRecord((prof || g_open) ? pe[0] : h->ev0, h->stream));
   int blocks = (n_env_launch + h->d.epw - 1) / h->d.epw;
   if (marl && h->d.epw != 1) return PGD_ERR_STATE;  // the multi-agent tail needs the env in one wave (V >= 33 or SUB split)
-  void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*) = k_step<false, false, false>;
+  void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*, PgdCold) = k_step<false, false, false>;
   const char* kname = h->d.pack_obs ? "k_step: whole envs side by side in a wave, one vehicle per lane (throughput mode)"
                                     : (h->d.epw == 1 ? "k_step: one env per wave" : "k_step: several envs per wave");
   if (marl) {
@@ -1922,7 +1934,8 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
                        d_done, d_flags, fuse ? d_obs : (float*)nullptr);
   } else
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), 0, stream, dv, d_actions, d_reward, d_done,
-                     d_flags, fuse ? d_obs : (float*)nullptr);
+                     d_flags, fuse ? d_obs : (float*)nullptr,
+                     PgdCold{dv.scen_map, dv.bev_fill, dv.spawn_hv, dv.respawn_img, dv.n_scen, dv.cfg.seed, dv.cfg.env_base});
   HIPCHK(hipGetLastError());
   if (prof || g_close) HIPCHK(hipEventRecord(pe[1], h->stream));
   if (g_close) h->prof_n += 1;
