@@ -36,7 +36,8 @@ def _engines(descs, n_envs, n_maps=8, **kw):
                            lidar_gaussian_noise=kw.get("lidar_gaussian_noise", 0.0),
                            lidar_dropout_prob=kw.get("lidar_dropout_prob", 0.0), seed=kw.get("seed", 0),
                            resample_scenario=kw.get("resample_scenario", 0), decision_repeat=kw.get("decision_repeat", 5),
-                           lidar_dist=kw.get("lidar_dist", 50.0))
+                           lidar_dist=kw.get("lidar_dist", 50.0),
+                           **{k: kw[k] for k in ("success_reward", "use_lateral", "speed_reward", "driving_reward", "out_of_road_penalty") if k in kw})
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
     ora.map_bank, ora.scen_bank = mb, sb
@@ -330,6 +331,37 @@ def test_ego_only_kernel_matches_the_general_kernel(descs, monkeypatch):
         n_done += int(d1.sum())
     assert n_done > 20 and o1.shape[-1] == 18
     assert "specialised for the ego-only" in fix.describe_step() and "specialised" not in gen.describe_step()
+
+
+def test_run_time_reward_kernel_matches_the_general_kernel_and_the_oracle(descs, monkeypatch):
+    """Default geometry, own reward scheme (what training set-ups change first): k_step runs the instantiation with the geometry
+    compiled in and the reward scheme read at run time.  Teacher-forced against the oracle, and against the general kernel."""
+    kw = dict(success_reward=20.0, use_lateral=True, speed_reward=0.3, out_of_road_penalty=7.0)
+    n_envs = 64
+    monkeypatch.delenv("PGD_NO_FIX", raising=False)
+    torch, eng, ora, cfg = _engines(descs, n_envs, seed=5, **kw)
+    monkeypatch.setenv("PGD_NO_FIX", "1")
+    _, gen, _, _ = _engines(descs, n_envs, seed=5, **kw)
+    ids = np.arange(n_envs) % 8
+    assert np.abs(eng.reset(ids).cpu().numpy() - ora.reset(ids)).max() < OBS_TOL
+    gen.reset(ids)
+    rng = np.random.default_rng(8)
+    stats = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
+    n_done = 0
+    for t in range(300):
+        act = util.driving_actions(rng, n_envs)
+        f, i, ei = ora.get_state()
+        f32 = util.round_state_f32(f)
+        gen.set_state(f32, i, ei)
+        r_gen = gen.step(torch.from_numpy(act).to(gen.device))[1].clone()
+        n_done += int(_compare_step(torch, eng, ora, act, stats).sum())
+        gen.sync()
+        assert float((r_gen - eng.reward).abs().max()) < 2e-5
+        f, i, ei = ora.get_state()
+        f32 = util.round_state_f32(f)
+        ora.set_state(f32, i, ei); eng.set_state(f32, i, ei)
+    assert stats["flag_mismatch"] == 0 and stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and n_done > 10
+    assert "run-time reward scheme" in eng.describe_step() and "specialised" not in gen.describe_step()
 
 
 def _teacher_forced(descs, num_traffic, num_lasers):
