@@ -23,7 +23,7 @@ run c3_groups2_8192 --envs 8192 --groups 2
 run c3_step_n16 --envs 4096 --step-n 16
 run c2_1024 --envs 1024 --traffic 0 --lasers 0
 run c2_65536 --envs 65536 --traffic 0 --lasers 0 --steps 500 --warmup 500 --exact
-run c5_4096x8 --workload c5 --envs 4096 --agents 8 --steps 500 --warmup 500 --exact
-run c5_4096x8_240beams --workload c5 --envs 4096 --agents 8 --lasers 240 --steps 300 --warmup 300 --exact
+run c5_4096x8 --workload c5 --envs 4096 --agents 8 --steps 1500 --warmup 1000 --exact
+run c5_4096x8_240beams --workload c5 --envs 4096 --agents 8 --lasers 240 --steps 1500 --warmup 1000 --exact
 run c5_4096x40 --workload c5 --envs 4096 --agents 40 --steps 200 --warmup 200 --exact
 run c3_topdown --envs 4096 --topdown --steps 400 --warmup 300 --exact
