@@ -427,6 +427,7 @@ struct ObsEnvLds {
   int aWant[WAVE];
   float pDist[NW][WAVE];
   int pPref[NW][WAVE + 1], pI0[NW][WAVE];
+  unsigned long long pMask[NW][32];  // per round of 64 incidences: the positions at which a pair's window starts
 };
 // `G` observers per round of a wave (as many as the LDS holds, see observe_env_words);
 // `s_minb_all`: per wave G * (num_lasers + 2 V) words of LDS: nearest hit fraction per (observer of the round, beam) as float
@@ -545,7 +546,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   // whatever V is (V = 40: 25 passes for 40 observers instead of 40 passes with 40 busy lanes each).
   const bool toll = (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;
   const int o_oth = (d.cfg.side_lasers > 0 ? d.cfg.side_lasers : 2) + 6 + d.cfg.lane_line_lasers + (d.cfg.random_agent_model ? 2 : 0) + (toll ? 0 : 10);
-  const float R = d.cfg.lidar_dist;
+  const float R = d.cfg.lidar_dist, R_lidar = R;
   const int per_wave = (A + NW - 1) / NW;
   const int a_lo = min(wv * per_wave, A), a_hi = min(a_lo + per_wave, A);
   unsigned* s_minb = s_minb_all + (size_t)wv * ((size_t)G * NL + 2 * (size_t)G * V);  // [G * NL] minima | [G * V] distance | [G * V] speed
@@ -611,32 +612,64 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
         rDist[pq] = (in && is_vehicle) ? dist : __builtin_inff();
         rSpd[pq] = spd;
       }
-      pAO[lane] = (al << 8) | o;
-      pI0[lane] = i0;
       int inc = cnt;  // inclusive prefix sum of the window sizes over the wave
 #pragma unroll
       for (int sh = 1; sh < WAVE; sh <<= 1) {
         const int up = __shfl_up(inc, sh);
         if (lane >= sh) inc += up;
       }
-      pPref[lane + 1] = inc;
-      if (lane == 0) pPref[0] = 0;
-      row_sync<true>();
-      const int T = pPref[WAVE];
-      // lidar (distance_detector.py:65-94, cutils.pyx:60-142): incidence t belongs to the pair p with pPref[p] <= t < pPref[p + 1]
-      for (int t = lane; t < T; t += WAVE) {
-        int pl = 0;
-#pragma unroll
-        for (int sh = WAVE / 2; sh > 0; sh >>= 1)
-          if (pPref[pl + sh] <= t) pl += sh;
-        const int ao = pAO[pl], qa = ao >> 8, qo = ao & 0xff, ga = g0 + qa;
-        int i = pI0[pl] + (t - pPref[pl]);
+      const int T = __shfl(inc, WAVE - 1);
+      const int R = (T + WAVE - 1) / WAVE;  // rounds of 64 incidences
+      // lidar (distance_detector.py:65-94, cutils.pyx:60-142): incidence t belongs to the pair whose window covers it
+      auto cast = [&](const int ao, const int i0w, const int start, const int t) {
+        const int qa = ao >> 8, qo = ao & 0xff, ga = g0 + qa;
+        int i = i0w + (t - start);
         i -= i >= NL ? NL : 0;
         const float ax = bX[ga], ay = bY[ga], ahx = bUX[ga], ahy = bUY[ga];
         const float2 bd = d.beam[i];  // (cos, sin)(i * 2 pi / NL); rotated by the heading
-        const float dx = R * (bd.x * ahx - bd.y * ahy), dy = R * (bd.y * ahx + bd.x * ahy);
+        const float dx = R_lidar * (bd.x * ahx - bd.y * ahy), dy = R_lidar * (bd.y * ahx + bd.x * ahy);
         const float f = shape_ray<true>(Obb{bX[qo], bY[qo], bUX[qo], bUY[qo], bHL[qo], bHW[qo]}, ax, ay, dx, dy);
         atomicMin(&s_minb[qa * NL + i], __float_as_uint(f));
+      };
+      if (R <= 32) {
+        // Owner of an incidence without a search: the non-empty pairs are compacted (window start, first beam, observer | body),
+        // and a 64-bit mask per round marks the positions at which a window starts.  Incidence t of round r then belongs to
+        // compacted pair (pairs that start before the round) + (starts at or before t's position in the round) - 1: one
+        // uniform mask read and a population count instead of a six-step binary search through LDS per incidence.
+        unsigned long long* pMask = M.pMask[wv];
+        const unsigned long long nz = __ballot(cnt > 0);
+        if (lane < R) pMask[lane] = 0ull;
+        row_sync<true>();
+        if (cnt > 0) {
+          const int k = __popcll(nz & ((1ull << lane) - 1ull));
+          const int start = inc - cnt;
+          pAO[k] = (al << 8) | o;
+          pI0[k] = i0;
+          pPref[k] = start;
+          atomicOr(&pMask[start >> 6], 1ull << (start & 63));
+        }
+        row_sync<true>();
+        int before = 0;  // non-empty pairs whose window starts before the round
+        for (int r = 0; r < R; ++r) {
+          const unsigned long long m = pMask[r];
+          const int t = r * WAVE + lane;
+          const int k = before + __popcll(m & ((2ull << lane) - 1ull)) - 1;
+          before += __popcll(m);
+          if (t < T) cast(pAO[k], pI0[k], pPref[k], t);
+        }
+      } else {
+        pAO[lane] = (al << 8) | o;
+        pI0[lane] = i0;
+        pPref[lane + 1] = inc;
+        if (lane == 0) pPref[0] = 0;
+        row_sync<true>();
+        for (int t = lane; t < T; t += WAVE) {  // pPref[p] <= t < pPref[p + 1]
+          int pl = 0;
+#pragma unroll
+          for (int sh = WAVE / 2; sh > 0; sh >>= 1)
+            if (pPref[pl + sh] <= t) pl += sh;
+          cast(pAO[pl], pI0[pl], pPref[pl], t);
+        }
       }
       row_sync<true>();
     }
