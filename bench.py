@@ -36,9 +36,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROF_STRIDE = 16      # k_step launches per HIP-event group
+PROF_STRIDE = 64      # k_step launches per HIP-event group (an event pair costs a launch gap: 16 per group took 0.4 us off every step)
 PREROLL_MIN = 1500    # steps before the timed region (steady-state traffic)
-TIMED_MIN = 2000      # timed steps (>= 64 event groups of PROF_STRIDE launches)
+TIMED_MIN = 4096      # timed steps (>= 64 event groups of PROF_STRIDE launches)
 
 
 # Algorithmic HBM bytes per env-step for this build's record layout:
@@ -321,8 +321,10 @@ def run_rank(args, rank, world, local_rank):
             # launch duration is group time / PROF_STRIDE (two event packets around EVERY launch leave the command processor
             # idle between back-to-back kernels and slow the thing being measured)
             profiled = mode == "replicas" and args.step_n == 1  # (the open-loop variant mixes launches with and without the observation)
+            # short --exact runs (tests, sweeps of a few hundred steps): smaller groups, so that several of them complete
+            stride = PROF_STRIDE if timed >= 8 * PROF_STRIDE else (16 if timed >= 16 else 1)
             if profiled:
-                eng.profile_begin(timed // PROF_STRIDE + 1, stride=PROF_STRIDE)
+                eng.profile_begin(timed // stride + 1, stride=stride)
             t0 = time.perf_counter()
             for k in range(timed):
                 one_step(counter)
@@ -441,7 +443,7 @@ def run_rank(args, rank, world, local_rank):
                     "frac_active": (b_step - 2 * 128 * (args.traffic - work["driving_traffic_mean"])) * N / (dom_ms * 1e-3) / 8e12}
                    if (work and dom == "k_step" and dom_ms > 0) else {}),
                 "k_step_ms": prof["k_step_ms"], "k_observe_ms": prof["k_observe_ms"], "events": prof["count"],
-                "launches_per_event_group": PROF_STRIDE if fused else 1,
+                "launches_per_event_group": stride if fused else 1,
             }
         else:
             out["roofline"] = None
