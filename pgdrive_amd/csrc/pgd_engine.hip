@@ -254,7 +254,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_INIT();
   XMARK(99);
   Veh r;
-  RouteCtx ctx{0.0f, 1.0f, 0};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
+  RouteCtx ctx{0.0f, 1.0f, 0, -1};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
   using MV = typename std::conditional<FIX != 0, MapViewPre, MapView>::type;
   MV mv;
   const pgd_spawn* sp = nullptr;
@@ -336,6 +336,10 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   XMARK(0);
   if (valid && trig && r.status == ST_PENDING && SPV.group == ng) r.status = ST_ACTIVE;
   if (trig) ng += 1;  // every lane of the env keeps the same copy
+  // the trigger road of the next group, for the verdict the step leaves for its successor (below): a scalar read while no store of
+  // the kernel has happened yet, long done when it is used
+  int next_trigger_road = -1;
+  if (ONE_ENV && !MARL && A == 1) next_trigger_road = ng < sc->n_groups ? (int)sc->trigger_road[ng] : -1;
   // the own-lane coordinate / lane length / successor list of a vehicle are read by the IDM neighbour search alone: an
   // env without a driving IDM vehicle in this step (most envs, most steps) skips them
   const bool idm_runs = ONE_ENV ? (__ballot(valid && s >= A && r.status == ST_ACTIVE) != 0ull) : true;
@@ -474,11 +478,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (s >= A && (r.vflags & PGD_F_OFF_LANE)) r.status = ST_REMOVED;
   }
   // the trigger test of the NEXT step (TrafficManager.before_step looks at the state this step leaves): the road of the agent's lane
-  // is read here, next to after_step's reads of the same record, and the verdict travels in the env's hint word -- the next step
-  // starts without the two dependent reads the test costs
+  // comes with after_step's own read of that lane record (RouteCtx::lane_road), and the verdict travels in the env's hint word --
+  // the next step starts without the two dependent reads the test costs
   int trig_next = 0;
   if (ONE_ENV && !MARL && A == 1 && valid && s < A)
-    trig_next = (r.status == ST_ACTIVE && ng < sc->n_groups && mv.lanes[r.lane].road == sc->trigger_road[ng]) ? 2 : 1;
+    trig_next = (r.status == ST_ACTIVE && next_trigger_road >= 0 && ctx.lane_road == next_trigger_road) ? 2 : 1;
   if (one_env && A > 1 && acting && s < A && !ctx.clear)
     r.vflags |= (int)state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * SPV.length, 0.5f * SPV.width});
   PHASE_MARK(25);  // after_step: per-vehicle part
@@ -1029,7 +1033,7 @@ __global__ __launch_bounds__(2 * WAVE, PGD_WAVES_PER_SIMD) void k_step2(PgdDev d
   const bool valid = is_ego || body;
   const int s = is_ego ? 0 : bs;
   Veh r;
-  RouteCtx ctx{0.0f, 1.0f, 0};
+  RouteCtx ctx{0.0f, 1.0f, 0, -1};
   if (valid) load_rec(((im >> s) & 1ull) ? img + s : recs + s, r);
   const pgd_spawn* sp = nullptr;
   if (lane == 0) { s_hit0 = 0; s_reset = 0; }

@@ -263,6 +263,7 @@ struct RouteCtx {   // per-step by-products of an agent's after_step, consumed b
   float drive;     // driving_reward * (long_now - long_last) * lateral_factor * positive_road of the step (pgdrive_env.py:209-258)
   float positive;  // +1 / -1: the sign the reference gives the speed reward on a negative road
   int clear;       // the car's box lies inside the line-free strip of its (straight) lane: no line / sidewalk contact possible
+  int lane_road;   // road of the vehicle's lane after the step (the next step's trigger test reads it from here)
 };
 
 // BaseVehicle.after_step (base_vehicle.py:255-290).  `with_state_check` = false lets the caller run the line / sidewalk
@@ -282,9 +283,10 @@ DEV void after_step_vehicle(const pgd_config& cfg, const MV& mv, const Grp& g, c
   if (AHEAD && is_agent) L0 = mv.lanes[first0];
   update_localization(mv, g, sp, r, lon_v, lat_v, PL);
   if (is_agent) {
-    ctx = RouteCtx{0.0f, 1.0f, 0};
+    ctx = RouteCtx{0.0f, 1.0f, 0, -1};
     pgd_lane VL = PL;
     if (!AHEAD || r.lane != lane0) VL = mv.lanes[r.lane];
+    ctx.lane_road = VL.road;
     if (!AHEAD || (int)r.cur_first != first0) L0 = mv.lanes[r.cur_first];  // AHEAD: only when a checkpoint was passed
     {
       // line / sidewalk contacts (base_vehicle.py:615-644) need no grid walk while the car's box stays inside the strip of
