@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "pgd_engine.hip")
 DEPS = [SRC] + [os.path.join(HERE, "csrc", h) for h in ("pgd_device.h", "pgd_vehicle.h", "pgd_localize.h", "pgd_idm.h",
                                                          "pgd_dynamics.h", "pgd_observe.h", "pgd_gather.h", "pgd_topdown.h")] + \
-    [os.path.join(HERE, "..", "include", "pgdrive_hip.h"), os.path.join(HERE, "..", "include", "pgd_state_layout.h")]
+    [os.path.join(HERE, "..", "include", "pgdrive_hip.h"), os.path.join(HERE, "..", "include", "pgd_state_layout.h"),
+     os.path.abspath(__file__)]  # the flags below are part of the build: a change of this file rebuilds
 LIB = os.path.join(HERE, "libpgdrive_hip.so")
 
 
@@ -40,9 +41,12 @@ def build(force=False, verbose=False, extra=()):
         return LIB
     # the kernel is issue-bound and the parity tolerances are 1e-5 and looser: fp32 `/` compiles to rcp * x and sqrtf to
     # the rsq sequence (2.5 ulp) instead of the correctly rounded, denormal-safe expansions (about ten VALU instructions
-    # each); sin / cos / atan2 / exp keep their full-precision library versions.  -funsafe-math-optimizations adds
-    # re-association (no finite-math assumption: the NaN test of the action input stays): another 2 % (22.33 -> 21.89 us);
-    # lane_local and wrap_to_pi, whose bits a checkpoint round trip relies on, switch it off for themselves
+    # each).  -funsafe-math-optimizations adds re-association (no finite-math assumption: the NaN test of the action input
+    # stays): another 2 % (22.33 -> 21.89 us); lane_local and wrap_to_pi, whose bits a checkpoint round trip relies on, switch
+    # it off for themselves.  The flag also implies -fapprox-func (hipcc links oclc_unsafe_math_on): expf -- the energy term of
+    # after_step, its only user -- compiles to the 9-instruction v_exp_f32 form (1 ulp of 2^x plus the input scaling) instead of
+    # the 26-instruction library version; sinf / cosf / atan2f compile to the same code either way.  SF_ENERGY is held to
+    # 2e-6 + 2e-5 rel against the fp64 oracle after every teacher-forced step (tests/util.py), measured 0.56 of that.
     cmd = [hipcc(), "--offload-arch=gfx950", *OPT, "-std=c++17", *FAST_FP, "-shared", "-fPIC", "-o", LIB, SRC] + list(extra)
     if verbose:
         print(" ".join(cmd))

@@ -22,7 +22,6 @@ struct PgdDev {
   int N, A, T, V, D, NV;
   int epw;        // whole environments per wave in k_step
   int sub;        // sub-lanes cooperating on one vehicle
-  int sub2;       // k_step2: sub-lanes per traffic slot in the traffic wave
   int pack_obs;   // several envs per wave (throughput mode): k_step appends the lidar observation of every env of the wave
   int sstride;    // pgd_spawn records per scenario: V slots + respawn_places * respawn_dests (multi-agent)
   const pgd_map* maps;

@@ -865,315 +865,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_END();
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// k_step2: the same step with TWO waves per environment (single-agent engines, one ego, no traffic objects).
-//   wave 0  the ego in lanes 0-3 (four sub-lanes): policy input, dynamics, localisation, line / sidewalk test (whole wave),
-//           reward, auto-reset and the fused observation (whole wave).  Lanes 4 .. 3 + T ("body lanes") hold the records of
-//           the traffic slots for what a STANDING body needs: the snapshot entry that contacts and lidar read, the contact
-//           test against the ego, the copy of the reset image when the episode restarts.
-//   wave 1  the traffic, 4 sub-lanes per slot: IDM policy, dynamics, contacts against the ego, localisation, removal, stores.
-//           It returns right after the trigger test when no traffic vehicle drives in this step (most envs of the trigger
-//           mode): its registers are free again within the first microseconds of the launch.
-// Both waves read the env's counters and evaluate the trigger themselves (same inputs, same result: no exchange), so "does
-// wave 1 run" needs no communication.  They meet at four LDS-only barriers: A snapshot complete (what the IDM search reads),
-// B poses after the physics and the sub-step poses complete, C contact flag complete, D restart decision (wave 0) and
-// removals (wave 1) published.  A wave that has returned no longer counts at a barrier.  The poses after the physics live
-// in their own arrays (Post), so no wave waits for the other to finish READING the snapshot before it publishes.
-// Same device routines as k_step, same results up to the contraction of multiply-adds by the compiler.
-// ---------------------------------------------------------------------------------------------------------------------
-struct Post {
-  float x[WAVE], y[WAVE], ux[WAVE], uy[WAVE], spd[WAVE];  // pose / km/h of every slot after the physics of this step
-};
 #undef SPV
-
-// LDS-only ordering + workgroup barrier (a fence without the address space would also wait for every global access in flight)
-DEV void blk_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-DEV void publish_slot(Snap& S, Post& P, SubPose& SUBP, const MapView& mv, const Veh& r, const pgd_spawn& sp, int slot, bool with_lon) {
-  const float kmh = speed_kmh(r.v);
-  S.x[slot] = r.x; S.y[slot] = r.y; S.ux[slot] = r.hx; S.uy[slot] = r.hy; S.spd[slot] = kmh;
-  P.x[slot] = r.x; P.y[slot] = r.y; P.ux[slot] = r.hx; P.uy[slot] = r.hy; P.spd[slot] = kmh;
-  S.hl[slot] = 0.5f * sp.length; S.hw[slot] = 0.5f * sp.width;
-  S.lane[slot] = r.lane;
-  const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
-  S.present[slot] = present ? 1 : 0;
-  if (slot < PGD_SUBV) SUBP.trav[slot] = 0.0f;
-  if (present && with_lon) {
-    const pgd_lane& ml = mv.lanes[r.lane];
-    S.lon[slot] = r.lon;  // carried in the record since the vehicle's last localisation
-    S.llen[slot] = ml.length;
-    S.succ[slot] = *reinterpret_cast<const int4*>(ml.succ);
-  }
-}
-// contact of body `slot` with the ego (slot 0) at the pose after ANY sub-step (collision_callback.py:7-36 inside each doPhysics call)
-DEV bool touches_ego(const Snap& S, const Post& P, const SubPose& SUBP, int slot, int n_mid, bool sub_ok) {
-  const Obb me{P.x[slot], P.y[slot], P.ux[slot], P.uy[slot], S.hl[slot], S.hw[slot]};
-  const Obb ag{P.x[0], P.y[0], P.ux[0], P.uy[0], S.hl[0], S.hw[0]};
-  const float my_trav = sub_ok ? SUBP.trav[slot] : 0.0f, ag_trav = sub_ok ? SUBP.trav[0] : 0.0f;
-  const float reach = me.hl + me.hw + ag.hl + ag.hw + my_trav + ag_trav + 0.01f;
-  const float ddx = ag.cx - me.cx, ddy = ag.cy - me.cy;
-  if (ddx * ddx + ddy * ddy > reach * reach) return false;
-  bool hit = obb_overlap(ag, me);
-  for (int k = 0; k < n_mid && !hit; ++k) {
-    Obb ak = ag, mk = me;
-    if (ag_trav > 0.0f) {  // heading = motion direction rotated back by the slip angle (unit up to rounding)
-      const float4 q = SUBP.p[k][0]; const float2 b = SUBP.beta[0];
-      ak.cx = q.x; ak.cy = q.y; ak.ux = q.z * b.x + q.w * b.y; ak.uy = q.w * b.x - q.z * b.y;
-    }
-    if (my_trav > 0.0f) {
-      const float4 q = SUBP.p[k][slot]; const float2 b = SUBP.beta[slot];
-      mk.cx = q.x; mk.cy = q.y; mk.ux = q.z * b.x + q.w * b.y; mk.uy = q.w * b.x - q.z * b.y;
-    }
-    hit = obb_overlap(ak, mk);
-  }
-  return hit;
-}
-
-template <bool STD>
-__global__ __launch_bounds__(2 * WAVE, PGD_WAVES_PER_SIMD) void k_step2(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
-                                                                     uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
-                                                                     float* __restrict__ obs) {
-  __shared__ Snap S;
-  __shared__ Post P;
-  __shared__ ObsScratch OU;  // sub-step poses (contact test), then the observation's compaction scratch
-  __shared__ AgentView s_ag;
-  __shared__ int s_hit0, s_reset;
-  ObsLds& OL = OU.ol;
-  SubPose& SUBP = OU.sp;
-  const int lane = (int)threadIdx.x & (WAVE - 1);
-  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int V = d.V, T = V - 1;
-  const int e = (int)blockIdx.x + d.unit_off;
-  // env counters, scenario, map view: wave-uniform, read by both waves
-  const int32_t* ei = d.ei + (size_t)e * PGD_NEI;
-  const unsigned long long im = d.use_imask ? d.imask[e] : 0ull;
-  int scen = ei[EI_SCEN];
-  int ng = ei[EI_NEXT_GROUP], ep_steps = ei[EI_EP_STEPS];
-  uint32_t steps_total = (uint32_t)ei[EI_STEPS_TOTAL];
-  const bool near_env = (ei[EI_NEAR] & 1) != 0;
-  const pgd_scenario* sc = d.scen + scen;
-  MapView mv = map_view_of(d, d.env_map + e);
-  const Veh* img = d.reset_img + (size_t)scen * V;
-  const Veh* recs = d.rec + (size_t)e * V;
-  const bool sub_ok = V <= PGD_SUBV;
-#ifdef PGD_NO_SUBSTEP
-  const int n_mid = 0;
-  const bool keep = false;
-#else
-  const int n_mid = (d.cfg.decision_repeat <= PGD_MAX_SUB && sub_ok) ? d.cfg.decision_repeat - 1 : 0;
-  const bool keep = near_env && sub_ok;
-#endif
-
-  if (wv == 1) {
-    // ------------------------------------------------------------------------------------------------ traffic wave
-    const int SUB1 = d.sub2;
-    const int gi = lane / SUB1;
-    const bool valid = gi < T;
-    const int s = 1 + gi;
-    const Grp g{lane - gi * SUB1, SUB1, gi * SUB1};
-    const bool leader = g.sub == 0;
-    Veh r;
-    if (valid) load_rec(((im >> s) & 1ull) ? img + s : recs + s, r);
-    // the trigger test of TrafficManager.before_step (traffic_manager.py:76-85) needs the ego's lane and status: the third
-    // 16 bytes of its record, the same for every lane
-    const uint4 ew = reinterpret_cast<const uint4*>((im & 1ull) ? img : recs)[2];  // {lane | spawn, rlane | timer, vflags | status | ck, roads}
-    const int ego_lane = (int)(ew.x & 0xffffu), ego_status = (int)((ew.z >> 16) & 0xfu);
-    const bool trig = ego_status == ST_ACTIVE && ng < sc->n_groups && mv.lanes[ego_lane].road == sc->trigger_road[ng];
-    const pgd_spawn* sp = nullptr;
-    if (valid) {
-      sp = d.spawns + (size_t)scen * d.sstride + r.spawn;
-      if (trig && r.status == ST_PENDING && sp->group == ng) r.status = ST_ACTIVE;
-    }
-    if (__ballot(valid && r.status == ST_ACTIVE) == 0ull) return;  // nobody drives: wave 0 does what standing bodies need
-    if (valid && leader) publish_slot(S, P, SUBP, mv, r, *sp, s, true);
-    blk_sync();  // A
-    const bool acting = valid && r.status == ST_ACTIVE;
-    {
-      const int nact = __popcll(__ballot(acting && leader));
-      if (nact >= 4) __builtin_amdgcn_s_setprio(3);
-      else if (nact >= 2) __builtin_amdgcn_s_setprio(2);
-      else __builtin_amdgcn_s_setprio(1);
-    }
-    if (acting) {
-      float st, tb;
-      idm_act<false>(d, mv, g, *sp, S, 0, V, s, e, steps_total, r, st, tb);
-      r.vflags &= ~(PGD_F_CRASH_VEHICLE | PGD_F_CRASH_OBJECT | PGD_F_CRASH_BUILDING);
-      r.lastx = r.x; r.lasty = r.y;
-      r.lasthx = r.hx; r.lasthy = r.hy;
-      r.a0s = r.a1s; r.a0t = r.a1t;
-      r.a1s = st; r.a1t = tb;
-      r.steer = st;
-      dynamics(d, *sp, r, false, tb, leader ? &SUBP : nullptr, s, keep);
-      if (leader) { P.x[s] = r.x; P.y[s] = r.y; P.ux[s] = r.hx; P.uy[s] = r.hy; P.spd[s] = speed_kmh(r.v); }
-    }
-    blk_sync();  // B
-    if (near_env && valid && leader && S.present[s] && S.present[0] && touches_ego(S, P, SUBP, s, n_mid, sub_ok)) s_hit0 = 1;
-    blk_sync();  // C
-    if (acting) {
-      RouteCtx c;
-      after_step_vehicle(d.cfg, mv, g, *sp, *sp, r, false, true, c);
-      if (r.vflags & PGD_F_OFF_LANE) {  // traffic off the lanes is removed (traffic_manager.py:91-109)
-        r.status = ST_REMOVED;
-        if (leader) S.present[s] = 0;
-      }
-    }
-    blk_sync();  // D
-    if (acting && leader && !s_reset) store_veh(d, e, s, r);  // a restarting env is written by wave 0 (reset image)
-    return;
-  }
-
-  // -------------------------------------------------------------------------------------------------------- ego wave
-  const bool is_ego = lane < 4;
-  const Grp g{lane & 3, 4, 0};
-  const int bs = lane - 3;                     // body lanes: traffic slot bs
-  const bool body = lane >= 4 && bs < V;
-  const bool valid = is_ego || body;
-  const int s = is_ego ? 0 : bs;
-  Veh r;
-  RouteCtx ctx{0.0f, 1.0f, 0, -1};
-  if (valid) load_rec(((im >> s) & 1ull) ? img + s : recs + s, r);
-  const pgd_spawn* sp = nullptr;
-  if (lane == 0) { s_hit0 = 0; s_reset = 0; }
-  const bool trig = __ballot(is_ego && r.status == ST_ACTIVE && ng < sc->n_groups &&
-                             mv.lanes[r.lane].road == sc->trigger_road[ng]) != 0ull;
-  if (valid) {
-    sp = d.spawns + (size_t)scen * d.sstride + r.spawn;
-    if (body && trig && r.status == ST_PENDING && sp->group == ng) r.status = ST_ACTIVE;  // (this lane's copy: wave 1 stores it)
-  }
-  const unsigned long long drv = __ballot(body && r.status == ST_ACTIVE);  // traffic slots that drive in this step, by lane
-  const bool idm_runs = drv != 0ull;
-  if (trig) ng += 1;
-  // snapshot: the ego always; the standing traffic when wave 1 is not there to do it
-  if (lane == 0 || (body && !idm_runs)) publish_slot(S, P, SUBP, mv, r, *sp, s, lane == 0 && idm_runs);
-  blk_sync();  // A
-  const bool acting = is_ego && r.status == ST_ACTIVE;
-  if (acting) {
-    // EnvInputPolicy.act (env_input_policy.py:17-26); NaN made harmless (test_ego_vehicle.py:78-84)
-    float a0 = act[(size_t)e * 2 + 0], a1 = act[(size_t)e * 2 + 1];
-    if (a0 != a0) a0 = 0.0f;
-    if (a1 != a1) a1 = 0.0f;
-    float st = clipf(a0, -1.0f, 1.0f), tb = clipf(a1, -1.0f, 1.0f);
-    if (d.cfg.discrete_action) {  // convert_to_continuous_action on the CLIPPED action (env_input_policy.py:17-31)
-      st = st * (2.0f / (float)(d.cfg.discrete_steering_dim - 1)) - 1.0f;
-      tb = tb * (2.0f / (float)(d.cfg.discrete_throttle_dim - 1)) - 1.0f;
-    }
-    // BaseVehicle.before_step (base_vehicle.py:238-253)
-    r.vflags &= ~(PGD_F_CRASH_VEHICLE | PGD_F_CRASH_OBJECT | PGD_F_CRASH_BUILDING);
-    r.lastx = r.x; r.lasty = r.y;
-    r.lasthx = r.hx; r.lasthy = r.hy;
-    r.a0s = r.a1s; r.a0t = r.a1t;
-    r.a1s = st; r.a1t = tb;
-    r.steer = d.cfg.increment_steering ? clipf(r.steer + st * 0.05f, -1.0f, 1.0f) : st;
-    dynamics(d, *sp, r, d.cfg.enable_reverse != 0, tb, lane == 0 ? &SUBP : nullptr, 0, keep);
-    if (lane == 0) { P.x[0] = r.x; P.y[0] = r.y; P.ux[0] = r.hx; P.uy[0] = r.hy; P.spd[0] = speed_kmh(r.v); }
-  }
-  blk_sync();  // B
-  if (near_env && !idm_runs && body && S.present[bs] && S.present[0] && touches_ego(S, P, SUBP, bs, n_mid, sub_ok)) s_hit0 = 1;
-  blk_sync();  // C
-  if (acting) {
-    if (s_hit0 & 1) r.vflags |= PGD_F_CRASH_VEHICLE;
-    after_step_vehicle(d.cfg, mv, g, *sp, *sp, r, true, false, ctx);
-  }
-  if (__ballot(acting && !ctx.clear) != 0ull) {  // line / sidewalk test of the ego by the whole wave (base_vehicle.py:615-644)
-    const unsigned fl = state_check_wave(mv, Obb{P.x[0], P.y[0], P.ux[0], P.uy[0], S.hl[0], S.hw[0]});
-    if (acting) r.vflags |= (int)fl;
-  }
-  ep_steps += 1;
-  steps_total += 1;
-  // reward / done (base_env.py:303-344)
-  unsigned my_fl = 0;
-  bool my_dn = false;
-  float my_rew = 0.0f;
-  if (is_ego) {
-    if (r.status == ST_ACTIVE) my_rew = reward_done<false>(d, mv, *sp, mv.lanes[sp->dest_lane], r, ctx, my_fl, my_dn);
-    if (d.cfg.horizon > 0 && ep_steps >= d.cfg.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
-    if (sc->max_steps > 0 && ep_steps >= sc->max_steps) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }  // auto_termination
-    r.eprew += my_rew;
-    if (my_dn && d.cfg.auto_reset) my_fl |= PGD_F_RESET;
-  }
-  const bool resetting = __ballot(lane == 0 && (my_fl & PGD_F_RESET)) != 0ull;
-  if (lane == 0) s_reset = resetting ? 1 : 0;
-  blk_sync();  // D
-  // auto reset (base_env.py:269-301): every slot restarts from the reset image of the (possibly re-drawn) scenario
-  int episodes = 0;
-  if (resetting) {
-    episodes = ei[EI_EPISODES] + 1;
-    if (d.cfg.resample_scenario)
-      scen = (int)(pgd_rng(d.cfg.seed, (uint32_t)(d.cfg.env_base + e), 0x5ce9a210u, (uint32_t)episodes) % (uint32_t)d.n_scen);
-    sc = d.scen + scen;
-    mv = map_view_of(d, d.scen_map + scen);
-    ng = 0;
-    ep_steps = 0;
-    if (valid) {
-      sp = d.spawns + (size_t)scen * d.sstride + s;
-      load_rec(d.reset_img + (size_t)scen * V + s, r);
-    }
-    if (is_ego && d.cfg.resample_scenario)  // the env's header copy follows the scenario
-      for (int q = g.sub; q < (int)(sizeof(pgd_map) / 16); q += 4)
-        reinterpret_cast<uint4*>(d.env_map + e)[q] = reinterpret_cast<const uint4*>(d.scen_map + scen)[q];
-  }
-  int32_t* eiw = d.ei + (size_t)e * PGD_NEI;
-  if (lane == 0) {
-    if (resetting) {
-      eiw[EI_SCEN] = scen;
-      eiw[EI_EPISODES] = episodes;
-      eiw[EI_NEXT_AGENT] = 1;
-      eiw[EI_AUX] = sc->aux;
-      if (d.bev_fill) d.bev_fill[e] = 1;
-    }
-    flags[e] = my_fl;
-    reward[e] = my_rew;
-    done[e] = my_dn ? 1 : 0;
-    if (d.prow) {  // pgd_step_packed: [D obs | reward | done] per env
-      float* tail = d.prow + (size_t)e * d.ostride + (size_t)d.D;
-      tail[0] = my_rew;
-      tail[1] = my_dn ? 1.0f : 0.0f;
-    }
-    eiw[EI_NEXT_GROUP] = ng;
-    eiw[EI_EP_STEPS] = ep_steps;
-    eiw[EI_STEPS_TOTAL] = (int)steps_total;
-  }
-  // stores: the ego when it drove; on a restart every slot (the records in memory stay complete)
-  if (resetting ? (lane == 0 || body) : (acting && lane == 0)) store_veh(d, e, s, r);
-  {  // written slots leave the reset image; a restart puts every slot back on it
-    const unsigned long long cleared = (__ballot(acting && lane == 0) != 0ull ? 1ull : 0ull) | ((drv >> 3) & ~1ull);
-    const unsigned long long full = V >= 64 ? ~0ull : ((1ull << V) - 1ull);
-    const unsigned long long nm = resetting ? full : (im & ~cleared);
-    if (lane == 0 && nm != im && d.use_imask) d.imask[e] = nm;
-  }
-  // observation of the new state (obs/state_obs.py:132-170)
-  bool near_next = true;
-  if (obs != nullptr) {
-    if (resetting && valid && (lane == 0 || body)) {  // the new episode's bodies
-      P.x[s] = r.x; P.y[s] = r.y; P.ux[s] = r.hx; P.uy[s] = r.hy; P.spd[s] = speed_kmh(r.v);
-      S.hl[s] = 0.5f * sp->length; S.hw[s] = 0.5f * sp->width;
-      S.present[s] = (r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING) ? 1 : 0;
-    }
-    if (lane == 0) {
-      AgentView& ag = s_ag;
-      ag.x = r.x; ag.y = r.y; ag.th = r.th; ag.hx = r.hx; ag.hy = r.hy; ag.dl = r.dl; ag.dr = r.dr; ag.v = r.v;
-      ag.steer = r.steer; ag.a0s = r.a0s; ag.a0t = r.a0t; ag.lhx = r.lasthx; ag.lhy = r.lasthy;
-      ag.cur_first = r.cur_first; ag.cur_n = r.cur_n; ag.next_first = r.next_first;
-      ag.blk = r.blk; ag.toll_time = r.php;
-      ag.env = e; ag.slot = 0; ag.tick = steps_total;
-    }
-    row_sync<true>();
-    const AgentView ag = s_ag;
-    const bool have = lane < V && d.cfg.num_lasers > 0;
-    const float t_step = d.cfg.dt * (float)d.cfg.decision_repeat;
-    bool near_a = false;
-    obs_compact<false>(OL, lane, 0, have && S.present[lane], true, P.x[lane], P.y[lane], P.ux[lane], P.uy[lane], S.hl[lane], S.hw[lane],
-                       P.spd[lane], ag.x, ag.y, d.cfg.lidar_dist, ag.hx, ag.hy, d.cfg.num_lasers,
-                       S.hl[0] + S.hw[0] + near_reach(ag.v, t_step), &near_a, t_step);
-    row_sync<true>();
-    observe_agent<false, STD>(d, mv, d.spawns[(size_t)scen * d.sstride], ag, OL, obs + (size_t)e * d.ostride, lane, WAVE);
-    near_next = near_hint_usable(d.cfg) ? (__ballot(near_a) != 0ull) : true;
-  }
-  if (lane == 0 && (int)near_next != (int)near_env) eiw[EI_NEAR] = near_next ? 1 : 0;
-}
 
 // heading vectors of the spawn poses, once per upload (the restart of a vehicle then evaluates no sincosf)
 __global__ void k_spawn_hv(const pgd_spawn* __restrict__ sp, float2* __restrict__ hv, size_t n) {
@@ -1489,7 +1181,6 @@ struct pgd_engine {
   bool no_fix;       // PGD_NO_FIX: never pick the kernel specialised for the default configuration (A/B, debugging)
   bool no_fuse;      // PGD_NO_FUSE was set when the engine was created (debug: always run the stand-alone k_observe)
   bool prof_fused;
-  int two_wave;      // k_step2 (two waves per env) for single-ego engines without traffic objects: PGD_TWO_WAVE = 0 / 1
 };
 
 static void topdown_free(pgd_engine* h);
@@ -1576,7 +1267,6 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->no_fuse = getenv("PGD_NO_FUSE") != nullptr;
   h->no_fix = getenv("PGD_NO_FIX") != nullptr;
   h->row_observe = getenv("PGD_ROW_OBSERVE") != nullptr;
-  h->two_wave = getenv("PGD_TWO_WAVE") ? atoi(getenv("PGD_TWO_WAVE")) : 0;
   h->d.cfg = *cfg;
   h->d.N = cfg->num_envs; h->d.A = cfg->num_agents; h->d.T = cfg->num_traffic; h->d.V = V;
   h->d.D = pgd_obs_dim(cfg);
@@ -1593,7 +1283,6 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->d.sstride = V + (marl ? cfg->respawn_places * cfg->respawn_dests : 0);
   h->d.sub = WAVE / V < 16 ? WAVE / V : 16;  // sub-lanes per vehicle
   h->d.epw = marl ? 1 : WAVE / (V * h->d.sub);  // whole environments per wave (the multi-agent tail needs the env alone in its wave)
-  h->d.sub2 = cfg->num_traffic > 0 ? std::min(4, WAVE / cfg->num_traffic) : 1;
   // Throughput mode: at large N the step is bound by instruction issue, not by the latency of one wave (profiles/r02_sweep.md:
   // 4.2 ns per env-step from 32768 envs on), and the SUB lanes of a vehicle run its scalar phases redundantly.  Engines with
   // >= 32768 single-ego envs (PGD_PACK=1 / 0 overrides; measured against the one-env kernel, profiles/r03_sweep.md: -7 % at 16384 envs, +6 % at 32768, +18 % at 262144) carry one vehicle per lane and as many whole envs per wave as fit --
@@ -1758,6 +1447,7 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
   h->img_dirty = true;  // running envs fall back to their own records until their next reset
   HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
   hipLaunchKernelGGL(k_clear_hints, dim3((h->d.N + 255) / 256), dim3(256), 0, h->stream, h->d.ei, h->d.N);
+  HIPCHK(hipGetLastError());
   return build_reset_image(h);  // eagerly (needs maps + scenarios): pgd_step never allocates, so it can be graph-captured
 }
 
@@ -1788,6 +1478,7 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   h->img_dirty = true;
   HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
   hipLaunchKernelGGL(k_clear_hints, dim3((h->d.N + 255) / 256), dim3(256), 0, h->stream, h->d.ei, h->d.N);
+  HIPCHK(hipGetLastError());
   return build_reset_image(h);
 }
 
@@ -1939,17 +1630,7 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
       kname = "k_step: whole envs side by side in a wave (throughput mode), specialised for the default single-agent configuration";
     }
   }
-  // two waves per env (k_step2): one ego, at least one traffic slot, no traffic objects, the observation fused or not wanted
-  const bool two = h->two_wave && !marl && h->d.epw == 1 && h->d.A == 1 && h->d.T >= 1 && h->d.T <= 60 && !h->has_objects &&
-                   (fuse || !d_obs);
-  h->last_step_kernel = two ? "k_step2: two waves per env" : kname;
-  if (two) {
-    const pgd_config& c = h->d.cfg;
-    const bool std_obs = c.side_lasers == 0 && c.lane_line_lasers == 0 && !c.random_agent_model &&
-                         c.lidar_gaussian_noise <= 0.0f && c.lidar_dropout_prob <= 0.0f;
-    hipLaunchKernelGGL(std_obs ? k_step2<true> : k_step2<false>, dim3(blocks), dim3(2 * WAVE), 0, stream, dv, d_actions, d_reward,
-                       d_done, d_flags, fuse ? d_obs : (float*)nullptr);
-  } else
+  h->last_step_kernel = kname;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), 0, stream, dv, d_actions, d_reward, d_done,
                      d_flags, fuse ? d_obs : (float*)nullptr,
                      PgdCold{dv.scen_map, dv.bev_fill, dv.spawn_hv, dv.respawn_img, dv.n_scen, dv.cfg.seed, dv.cfg.env_base});
@@ -1995,7 +1676,17 @@ int pgd_step_packed(pgd_handle h, const float* d_actions, float* d_rows, int row
 /* ---- env groups: asynchronous vector-env groups inside one handle ---------------------------------------------------- */
 int pgd_set_groups(pgd_handle h, int n_groups) {
   if (!h || n_groups < 1 || n_groups > 64) return PGD_ERR_ARG;
-  if (h->d.N % n_groups != 0 || (h->d.N / n_groups) % h->d.epw != 0) return PGD_ERR_ARG;  // equal groups of whole waves
+  if (h->d.N % n_groups != 0) return PGD_ERR_ARG;  // equal groups
+  if ((h->d.N / n_groups) % h->d.epw != 0) {
+    // groups are launched as whole waves.  Throughput mode (pgd_create picks it from 32768 envs on: three envs of 17 slots per
+    // wave) does not divide a power-of-two group size: such an engine goes back to one env per wave -- the record, image and
+    // mask layouts do not depend on the lane mapping, so the switch is a change of launch geometry only
+    if (!h->d.pack_obs) return PGD_ERR_ARG;
+    h->d.pack_obs = 0;
+    h->d.sub = WAVE / h->d.V < 16 ? WAVE / h->d.V : 16;
+    h->d.epw = WAVE / (h->d.V * h->d.sub);
+    if ((h->d.N / n_groups) % h->d.epw != 0) return PGD_ERR_ARG;
+  }
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->gstreams) {

@@ -302,206 +302,11 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t, ui
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The same image in two launches (opt-in, PGD_TD_SPLIT=1; measured SLOWER than k_topdown: 15.8 + 166.6 us against 138 us,
-// profiles/r03_notes.md).  In k_topdown every block runs prologue (history shift, cull: reads), gather (raster reads) and
-// stream-out (writes only) one after the other; the idea was that four times as many, shorter blocks mix these phases on a CU:
-//   k_topdown_pro   one wave per env: history shift + insertion, per stacked frame the visible boxes in that frame's ego
-//                   coordinates, the past-position pixels -> a small per-env record (TdPre) in global memory
-//   k_topdown_img   TD_BANDS blocks per env, each a band of image rows: gather the band's texel classes, stream the band out,
-//                   stamp the vehicle boxes and past positions that fall into the band.  Four times as many, shorter blocks:
-//                   on every CU some blocks gather while others write.
-// ---------------------------------------------------------------------------------------------------------------------
-#define TD_BANDS 4
-// per env, in float4 units: [0] current ego pose (x, y, hx, hy); [1] visible boxes per frame (4 ints); [2][3] past-position pixel
-// indices (8 ints, -1 = none); then 4 * V box centres / axes; then 2 * V float4 = 4 * V half extents (hl, hw) pairs
-DEV_HOST int td_pre_stride(int V) { return 4 + 6 * V; }
-
-__global__ __launch_bounds__(WAVE) void k_topdown_pro(PgdDev d, TopDown t, uint8_t* __restrict__ fill, float4* __restrict__ pre) {
-  extern __shared__ float4 s_dyn4[];  // pose history after this step's insertion [n_frames][V]
-  __shared__ float2 s_pos[64];
-  __shared__ float s_hl[MAXV], s_hw[MAXV];
-  const int e = blockIdx.x, lane = threadIdx.x, V = d.V;
-  float4* s_pose = s_dyn4;
-  const VehRec* recs = d.rec + (size_t)e * V;
-  const int scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
-  const pgd_spawn* spb = d.spawns + (size_t)scen * d.sstride;
-  const bool refill = fill[e] != 0;
-  float4* hp = t.pose + (size_t)e * t.n_frames * V;
-  float2* pp = t.pos + (size_t)e * t.n_pos;
-  float4* out = pre + (size_t)e * td_pre_stride(V);
-  for (int k = lane; k < t.n_frames * V; k += WAVE) {
-    const int f = k / V, s = k - f * V;
-    float4 q;
-    if (f == 0 || refill) {
-      const VehRec& rc = recs[s];
-      const bool drawn = (rc.status == ST_PENDING || rc.status == ST_ACTIVE || rc.status == ST_DYING) && spb[rc.spawn].kind == PGD_OBJ_VEHICLE;
-      float hx = rc.hx, hy = rc.hy;
-      if (s != 0 && fabsf(rc.th) <= 2.0f * PGD_PI / 180.0f) { hx = 1.0f; hy = 0.0f; }  // the reference snaps small headings of the others
-      q = drawn ? make_float4(rc.x, rc.y, hx, hy) : make_float4(0.f, 0.f, 0.f, 0.f);
-    } else q = hp[(size_t)(f - 1) * V + s];
-    s_pose[f * V + s] = q;
-  }
-  for (int k = lane; k < t.n_pos; k += WAVE) s_pos[k] = (k == 0 || refill) ? make_float2(recs[0].x, recs[0].y) : pp[k - 1];
-  if (lane < V) { const pgd_spawn& so = spb[recs[lane].spawn]; s_hl[lane] = 0.5f * so.length; s_hw[lane] = 0.5f * so.width; }
-  const int nhist = refill ? 1 : min(t.n_hist[e] + 1, t.n_pos);
-  __syncthreads();
-  for (int k = lane; k < t.n_frames * V; k += WAVE) hp[k] = s_pose[k];
-  for (int k = lane; k < t.n_pos; k += WAVE) pp[k] = s_pos[k];
-  if (lane == 0) { t.n_hist[e] = nhist; fill[e] = 0; out[0] = s_pose[0]; }
-  // per stacked frame: the vehicles that can show up in the window, in the ego frame of that time
-  int nv[4] = {0, 0, 0, 0};
-  for (int f = 0; f < t.frame_stack && f < 4; ++f) {
-    const int fi = f * t.frame_skip;
-    const float4 eg = s_pose[fi * V];
-    bool vis = false;
-    float4 vc = make_float4(0.f, 0.f, 1.f, 0.f);
-    if (lane >= 1 && lane < V) {
-      const float4 q = s_pose[fi * V + lane];
-      if (!(q.z == 0.0f && q.w == 0.0f)) {
-        const float dx = q.x - eg.x, dy = q.y - eg.y;
-        vc = make_float4(dx * eg.z + dy * eg.w, dy * eg.z - dx * eg.w, q.z * eg.z + q.w * eg.w, q.w * eg.z - q.z * eg.w);
-        const float reach = t.distance + s_hl[lane] + s_hw[lane];
-        vis = fabsf(vc.x) <= reach && fabsf(vc.y) <= reach;
-      }
-    }
-    const unsigned long long m = __ballot(vis);
-    if (vis) {
-      const int k = __popcll(m & ((1ull << lane) - 1ull));
-      out[4 + f * V + k] = vc;
-      reinterpret_cast<float2*>(out + 4 + 4 * V)[f * V + k] = make_float2(s_hl[lane], s_hw[lane]);
-    }
-    nv[f] = __popcll(m);
-  }
-  if (lane == 0) out[1] = make_float4(__int_as_float(nv[0]), __int_as_float(nv[1]), __int_as_float(nv[2]), __int_as_float(nv[3]));
-  // past positions of the ego, newest first, in the current ego frame (top_down_obs_multi_channel.py:152-170) -> pixel index
-  if (lane < 8) {
-    int pixel = -1;
-    const int k = lane * t.frame_skip;
-    if (lane < t.post_stack && k < nhist) {
-      const float4 eg = s_pose[0];
-      const bool snap = fabsf(recs[0].th) <= 2.0f * PGD_PI / 180.0f;  // the reference rotates by the snapped ego heading here
-      const float ehx = snap ? 1.0f : eg.z, ehy = snap ? 0.0f : eg.w;
-      const float dx = s_pos[k].x - eg.x, dy = s_pos[k].y - eg.y, sc = (float)t.R / t.distance;
-      float u = (dy * ehx - dx * ehy) * sc + (float)t.R * 0.5f, vv = -(dx * ehx + dy * ehy) * sc + (float)t.R * 0.5f;
-      u = clipf(u, -(float)t.R, (float)t.R); vv = clipf(vv, -(float)t.R, (float)t.R);
-      const int jj = (int)floorf(u), ii = (int)floorf(vv);
-      if (ii >= 0 && jj >= 0 && ii < t.R && jj < t.R) pixel = ii * t.R + jj;
-    }
-    reinterpret_cast<int*>(out + 2)[lane] = pixel;
-  }
-}
-
-#define TD_BCHUNK 2048  /* pixels per gather / write chunk of a band (84 x 21 = 1764 fit in one) */
-__global__ __launch_bounds__(256) void k_topdown_img(PgdDev d, TopDown t, const float4* __restrict__ pre, float* __restrict__ img) {
-  __shared__ uint8_t s_cls[TD_BCHUNK];
-  __shared__ float s_out[256 * 8];
-  const int e = (int)blockIdx.x / TD_BANDS, band = (int)blockIdx.x - e * TD_BANDS, tid = threadIdx.x, V = d.V;
-  const int R = t.R, C = t.C;
-  const int rows_per = (R + TD_BANDS - 1) / TD_BANDS;
-  const int row0 = band * rows_per, row1 = min(row0 + rows_per, R);
-  if (row0 >= row1) return;
-  const float4* pr = pre + (size_t)e * td_pre_stride(V);
-  const int scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
-  const pgd_map& m = d.scen_map[scen];
-  const float s_px = (float)R / (2.0f * t.distance), inv_s = 1.0f / s_px;
-  const int tw = (int)((float)m.gx * m.cell / TD_TEXEL), th = (int)((float)m.gy * m.cell / TD_TEXEL);
-  const uint8_t* tex = t.tex + t.tex_off[scen];
-  float* out = img + (size_t)e * R * R * C;
-  const int wv = tid >> 6, lane = tid & 63;
-  float* so = s_out + wv * 64 * 8;
-  for (int k = lane; k < 64 * 8; k += 64) so[k] = 0.0f;
-  const float4 eg0 = pr[0];
-  const float m_ox = m.ox, m_oy = m.oy;
-  const int tbw = (tw + 7) >> 3;
-  const int rows_c = max(1, TD_BCHUNK / R);  // image rows per chunk
-  for (int r0 = row0; r0 < row1; r0 += rows_c) {
-    const int r1 = min(r0 + rows_c, row1);
-    const int c0 = r0 * R, c1 = r1 * R;
-    const bool vec_ok = ((c0 * C) & 3) == 0 && (((c1 - c0) * C) & 3) == 0 && ((64 * C) & 3) == 0;
-    {  // gather the chunk's texel classes: 8 x 8 pixel tiles, lane = pixel of the tile, 4 tiles in flight per wave
-      const int txn = (R + 7) >> 3, n_tiles = ((r1 - r0 + 7) >> 3) * txn;
-      constexpr int NK = 4;
-      for (int q0 = wv; q0 < n_tiles; q0 += 4 * NK) {
-        int v[NK], pix[NK];
-#pragma unroll
-        for (int u = 0; u < NK; ++u) {
-          const int q = q0 + 4 * u;
-          const int ty = q / txn, tx = q - ty * txn;
-          const int i = r0 + ty * 8 + (lane >> 3), j = tx * 8 + (lane & 7);
-          const bool on = q < n_tiles && i < r1 && j < R;
-          const float fw = ((float)R * 0.5f - (float)i - 0.5f) * inv_s, rg = ((float)j + 0.5f - (float)R * 0.5f) * inv_s;
-          const float wx = eg0.x + fw * eg0.z - rg * eg0.w, wy = eg0.y + fw * eg0.w + rg * eg0.z;
-          const int ix = (int)floorf((wx - m_ox) * (1.0f / TD_TEXEL)), iy = (int)floorf((wy - m_oy) * (1.0f / TD_TEXEL));
-          const bool in = on && ix >= 0 && iy >= 0 && ix < tw && iy < th;
-          v[u] = tex[in ? td_tiled(ix, iy, tbw) : 0ll];
-          if (!in) v[u] = 0;
-          pix[u] = on ? i * R + j - c0 : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < NK; ++u)
-          if (pix[u] >= 0) s_cls[pix[u]] = (uint8_t)v[u];
-      }
-    }
-    __syncthreads();
-    auto store_loop = [&](auto vec_tag) {  // no global read in this loop (loads and stores share one completion counter)
-      constexpr bool VEC = decltype(vec_tag)::value;
-      for (int p0 = c0 + wv * 64; p0 < c1; p0 += 256) {
-        const int n_here = min(64, c1 - p0);
-        const int cls = lane < n_here ? (int)s_cls[p0 - c0 + lane] : 0;
-        so[lane * C] = cls == 2 ? TD_LINE : (cls == 1 ? TD_NAVI : 0.0f);
-        row_sync<true>();
-        const int nf = n_here * C;
-        float* dst = out + (size_t)p0 * C;
-        if (VEC) {
-          const int n4 = nf >> 2;
-          if (lane < n4) reinterpret_cast<float4*>(dst)[lane] = reinterpret_cast<const float4*>(so)[lane];
-          if (lane + 64 < n4) reinterpret_cast<float4*>(dst)[lane + 64] = reinterpret_cast<const float4*>(so)[lane + 64];
-        } else {
-          for (int k = lane; k < nf; k += 64) dst[k] = so[k];
-        }
-        row_sync<true>();
-      }
-    };
-    if (vec_ok) store_loop(std::true_type{});
-    else store_loop(std::false_type{});
-    __syncthreads();
-  }
-  const int c0 = row0 * R, c1 = row1 * R;
-  // the other vehicles of every stacked frame: the part of each box's pixel rectangle that lies in this band
-  const float4 nvf = pr[1];
-  const int nvis[4] = {__float_as_int(nvf.x), __float_as_int(nvf.y), __float_as_int(nvf.z), __float_as_int(nvf.w)};
-  for (int q = wv; q < 4 * MAXV; q += 4) {
-    const int f = q / MAXV, k = q - f * MAXV;
-    if (f >= t.frame_stack || k >= (f == 0 ? nvis[0] : f == 1 ? nvis[1] : f == 2 ? nvis[2] : nvis[3])) continue;
-    const float4 b = pr[4 + f * V + k];
-    const float2 hh = reinterpret_cast<const float2*>(pr + 4 + 4 * V)[f * V + k];
-    const float rad = (hh.x + hh.y) * s_px + 1.5f;
-    const float ci = (float)R * 0.5f - 0.5f - b.x * s_px, cj = b.y * s_px + (float)R * 0.5f - 0.5f;
-    const int ia = max((int)floorf(ci - rad), row0), ib = min((int)ceilf(ci + rad), row1 - 1);
-    const int ja = max((int)floorf(cj - rad), 0), jb = min((int)ceilf(cj + rad), R - 1);
-    for (int ti = ia; ti <= ib; ti += 8)
-      for (int tj = ja; tj <= jb; tj += 8) {
-        const int pi = ti + (lane >> 3), pj = tj + (lane & 7);
-        if (pi > ib || pj > jb) continue;
-        const float fwd = ((float)R * 0.5f - (float)pi - 0.5f) * inv_s, rgt = ((float)pj + 0.5f - (float)R * 0.5f) * inv_s;
-        const float dx = fwd - b.x, dy = rgt - b.y;
-        if (fabsf(dx * b.z + dy * b.w) <= hh.x && fabsf(dy * b.z - dx * b.w) <= hh.y) out[((size_t)pi * R + pj) * C + 2 + f] = TD_VEH;
-      }
-  }
-  if (tid < 8) {  // past positions that fall into this band
-    const int pixel = reinterpret_cast<const int*>(pr + 2)[tid];
-    if (pixel >= c0 && pixel < c1) out[(size_t)pixel * C + 1] = 1.0f;
-  }
-}
-
 struct pgd_topdown_state {
   TopDown t;
   uint8_t* tex;          // device rasters
   long long* tex_off;    // device offsets
   bool tex_dirty;        // maps / scenarios were uploaded since the rasters were built
-  float4* pre;           // [N][td_pre_stride(V)] what k_topdown_pro hands to k_topdown_img
-  bool one_kernel;       // the default; PGD_TD_SPLIT=1 selects the two-launch version (measured slower: profiles/r03_notes.md)
 };
 
 // (re)build the road-network rasters of every scenario (needs maps + scenarios on the device)
@@ -576,9 +381,6 @@ int pgd_topdown_enable(pgd_handle h, const pgd_topdown_config* c) {
     HIPCHK(hipMalloc(&h->d.bev_fill, N));
   }
   HIPCHK(hipMemsetAsync(h->d.bev_fill, 1, N, h->stream));  // every env starts with a filled history
-  if (s->pre) { (void)hipFree(s->pre); s->pre = nullptr; }
-  HIPCHK(hipMalloc(&s->pre, sizeof(float4) * N * td_pre_stride(h->d.V)));
-  s->one_kernel = getenv("PGD_TD_SPLIT") == nullptr;
   return PGD_OK;
 }
 
@@ -587,14 +389,8 @@ int pgd_observe_topdown(pgd_handle h, float* d_img) {
   if (!h->topdown || !h->have_maps || !h->have_scen) return PGD_ERR_STATE;
   HIPCHK(hipSetDevice(h->device));
   if (h->topdown->tex_dirty) { int rc = topdown_build_rasters(h); if (rc) return rc; }
-  if (h->topdown->one_kernel) {
-    const size_t dyn = sizeof(float4) * ((size_t)h->topdown->t.n_frames + 4) * h->d.V + sizeof(float2) * 4 * (size_t)h->d.V;
-    hipLaunchKernelGGL(k_topdown, dim3(h->d.N), dim3(256), dyn, h->stream, h->d, h->topdown->t, h->d.bev_fill, d_img);
-  } else {
-    hipLaunchKernelGGL(k_topdown_pro, dim3(h->d.N), dim3(WAVE), sizeof(float4) * (size_t)h->topdown->t.n_frames * h->d.V, h->stream,
-                       h->d, h->topdown->t, h->d.bev_fill, h->topdown->pre);
-    hipLaunchKernelGGL(k_topdown_img, dim3(h->d.N * TD_BANDS), dim3(256), 0, h->stream, h->d, h->topdown->t, h->topdown->pre, d_img);
-  }
+  const size_t dyn = sizeof(float4) * ((size_t)h->topdown->t.n_frames + 4) * h->d.V + sizeof(float2) * 4 * (size_t)h->d.V;
+  hipLaunchKernelGGL(k_topdown, dim3(h->d.N), dim3(256), dyn, h->stream, h->d, h->topdown->t, h->d.bev_fill, d_img);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }
@@ -608,7 +404,6 @@ static void topdown_free(pgd_engine* h) {
   if (h->topdown->t.pos) { (void)hipFree(h->topdown->t.pos); (void)hipFree(h->topdown->t.pose); (void)hipFree(h->topdown->t.n_hist); }
   if (h->topdown->tex) (void)hipFree(h->topdown->tex);
   if (h->topdown->tex_off) (void)hipFree(h->topdown->tex_off);
-  if (h->topdown->pre) (void)hipFree(h->topdown->pre);
   if (h->d.bev_fill) (void)hipFree(h->d.bev_fill);
   free(h->topdown);
   h->topdown = nullptr;

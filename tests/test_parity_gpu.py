@@ -102,39 +102,6 @@ def test_teacher_forced_parity(descs, num_traffic, num_lasers):
     _teacher_forced(descs, num_traffic, num_lasers)
 
 
-def test_two_wave_kernel_parity(descs, monkeypatch):
-    """k_step2 (two waves per env: ego wave + traffic wave that returns early when nothing drives; opt-in, PGD_TWO_WAVE=1 --
-    it lost the A/B of profiles/r03_notes.md and is not the default) through the same teacher-forced comparison, and
-    free-running against the one-wave kernel: flags, done and the integer state bit-identical over 300 steps with resets."""
-    monkeypatch.setenv("PGD_TWO_WAVE", "1")
-    _teacher_forced(descs, 16, 240)
-    n_envs = 128
-    torch, two, _, cfg = _engines(descs, n_envs, seed=9, resample_scenario=1)
-    monkeypatch.setenv("PGD_TWO_WAVE", "0")
-    _, one, _, _ = _engines(descs, n_envs, seed=9, resample_scenario=1)
-    ids = np.arange(n_envs) % 8
-    two.reset(ids); one.reset(ids)
-    rng = np.random.default_rng(6)
-    n_done = 0
-    for t in range(300):
-        act = util.driving_actions(rng, n_envs)
-        if t % 3 == 0:
-            act[::2, 0, :] = 1.0
-        f, i, ei = one.get_state()
-        two.set_state(f, i, ei)
-        a = torch.from_numpy(act).to(one.device)
-        o1, r1, d1, f1 = [x.clone() for x in one.step(a)]
-        o2, r2, d2, f2 = [x.clone() for x in two.step(a)]
-        one.sync(); two.sync()
-        assert torch.equal(d1, d2) and torch.equal(f1, f2), "flags differ at step %d" % t
-        assert float((o1 - o2).abs().max()) < 2e-6 and float((r1 - r2).abs().max()) < 2e-5
-        _, i1, e1 = one.get_state()
-        _, i2, e2 = two.get_state()
-        assert (i1 == i2).all() and (e1 == e2).all(), "integer state differs at step %d" % t
-        n_done += int(d1.sum().item())
-    assert n_done > 50
-
-
 def test_throughput_mode_parity(descs, monkeypatch):
     """Throughput mode (engines with >= 32768 envs, or PGD_PACK=1): one vehicle per lane, three whole envs of 17 slots per wave,
     the lidar rows of the wave's envs appended to the same launch (k_step<ONE_ENV = false> + pack_obs).  Same teacher-forced

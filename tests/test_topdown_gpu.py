@@ -24,15 +24,11 @@ def _setup(descs, n_envs, td=None, **kw):
     return torch, eng, ora, mb, sb
 
 
-@pytest.mark.parametrize("split", [False, True])
-def test_topdown_parity_with_the_oracle(descs, split, monkeypatch):
-    """(split: the opt-in two-launch version, PGD_TD_SPLIT=1 -- prologue kernel + four band blocks per image.)
-    84 x 84 x 5 images (TopDownPGDriveEnv defaults) of 48 envs over 70 teacher-forced steps incl. auto-resets: every pixel is one
+def test_topdown_parity_with_the_oracle(descs):
+    """84 x 84 x 5 images (TopDownPGDriveEnv defaults) of 48 envs over 70 teacher-forced steps incl. auto-resets: every pixel is one
     of the channel's two or three exact values, so the comparison is exact except where a pixel centre sits on an edge (fp32 vs
     fp64 inside / outside); such pixels are counted."""
     n = 32
-    if split:
-        monkeypatch.setenv("PGD_TD_SPLIT", "1")
     torch, eng, ora, mb, sb = _setup(descs, n)
     ids = np.arange(n) % 8
     ora.reset(ids)
