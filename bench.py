@@ -17,6 +17,14 @@ the timed region and times at least TIMED_MIN steps, whatever --warmup / --steps
 counts ("steps", "warmup") and the counts actually run ("steps_timed", "warmup_run"); `ms_per_step` and `value` refer to
 the timed steps.  --exact turns the floors off.
 
+Rows.  At N = 1 the same invocation also times the LOADED workloads next to the metric's (whose uniform(-1,1) stream leaves the
+ego crawling and most traffic parked): the scripted lane-keeping ego, respawn-mode traffic (every IDM vehicle drives), BASELINE
+config 5 (multi-agent roundabout, 8 agents, 240 and 72 beams; 40 agents = the reference's default), and 32768 envs on the one GPU
+(config 4's per-node size) -- printed as `rows: [...]`, each with its own roofline (shorter windows: 1500 + 2048 steps;
+--no-rows skips them).  `roofline.frac` is charged for the bytes that MOVE: the HBM bytes the rocprofv3 counters saw for that
+row (profiles/r*_pmc_*.json, matched by workload) or, without a counter file, the record bytes of the vehicles that drove
+(`frac_active`); the nominal formula that charges all V records read + written stays next to it as `frac_nominal`.
+
 N > 1.  Environments are independent: the step itself has no exchange.  The north star adds ONE gather of
 (obs, reward, done) per step over xGMI; both are measured in the same invocation: `value` is WITH the per-step gather
 (pgd_step_packed writes the packed row straight into the send buffer, one RCCL gather to rank 0 per step -- the learner's GPU;
@@ -35,6 +43,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+HOST_THREADS = len(os.sched_getaffinity(0))  # read before any OpenMP runtime binds the main thread to one core (OMP_PROC_BIND)
 
 PROF_STRIDE = 64      # k_step launches per HIP-event group (an event pair costs a launch gap: 16 per group took 0.4 us off every step)
 PREROLL_MIN = 1500    # steps before the timed region (steady-state traffic)
@@ -62,15 +71,20 @@ def load_traffic(N, args):
             t = json.load(open(p))
         except Exception:
             continue
-        if (t.get("envs"), t.get("traffic"), t.get("lasers"), t.get("actions", "uniform"), t.get("traffic_mode", "trigger")) == \
-                (N, args.traffic, args.lasers, args.actions, args.traffic_mode):
+        if (t.get("envs"), t.get("traffic"), t.get("lasers"), t.get("actions", "uniform"), t.get("traffic_mode", "trigger"),
+                t.get("workload", "c3"), t.get("agents", 1)) == \
+                (N, args.traffic, args.lasers, args.actions, args.traffic_mode, args.workload, args.agents if args.workload == "c5" else 1):
             return t.get("bytes_per_launch"), os.path.basename(p)
     return None, None
 
 
-def cpu_baseline(descs, args, seconds=10.0):
-    """Oracle (scalar C restatement) on a bounded sample of the same workload: 1 thread (the reported baseline) and, in
-    `all_cores`, OpenMP over envs on every host core."""
+def cpu_baseline(descs, args, seconds=6.0):
+    """Oracle (scalar C restatement) on a bounded sample of the same workload: 1 thread (the reported baseline: 256 envs, three
+    windows, median) and `threads_curve`: the full 4096-env workload with OpenMP over envs on 1 / 8 / 32 / all host threads
+    (pinned: OMP_PROC_BIND / OMP_PLACES are set in main() before libgomp loads; one window of >= 5 s each, best of two for
+    the all-threads point).  `all_cores` is the last point of that curve; when it is less than a quarter of what its thread
+    count would give at the 8-thread efficiency, the line says so ("host oversubscribed") instead of presenting it as a
+    baseline."""
     from oracle import orc
     from pgdrive_amd import _abi, mapdata, scenario
     n = 256
@@ -95,9 +109,15 @@ def cpu_baseline(descs, args, seconds=10.0):
         rates.append(n * (k - k0) / (time.perf_counter() - t0))
     rate1 = float(np.median(rates))
     o.close()
-    # all host cores: the full 4096-env workload, OpenMP over envs inside one parallel region
-    cores = min(len(os.sched_getaffinity(0)), 128)
-    allc = None
+    avail = HOST_THREADS
+    quota = None
+    try:  # cgroup v2 CPU quota ("max 100000" = none)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    cores = min(avail, 128)
+    allc, curve = None, []
     if cores > 1:
         n2 = args.envs
         cfg2 = _abi.make_config(n2, num_agents=1, num_traffic=args.traffic, num_lasers=args.lasers)
@@ -105,17 +125,29 @@ def cpu_baseline(descs, args, seconds=10.0):
         o2.reset(np.arange(n2) % len(sel))
         ring = rng.uniform(-1, 1, size=(8, n2, 1, 2)).astype(np.float32)
         o2.run(ring, 2, cores)
-        rates2, k2 = [], 0
-        for w in range(3):
-            t1 = time.perf_counter()
-            k20 = k2
-            while time.perf_counter() - t1 < seconds / 6:
-                o2.run(ring, 8, cores)
-                k2 += 8
-            rates2.append(n2 * (k2 - k20) / (time.perf_counter() - t1))
+        for th in sorted(set(t for t in (1, 8, 32, cores) if t <= cores)):
+            best = 0.0
+            for rep in range(2 if th == cores else 1):
+                t1 = time.perf_counter()
+                k2 = 0
+                while time.perf_counter() - t1 < (5.0 if th > 1 else 3.0):
+                    o2.run(ring, 4 if th < 8 else 16, th)
+                    k2 += 4 if th < 8 else 16
+                best = max(best, n2 * k2 / (time.perf_counter() - t1))
+            curve.append(dict(threads=th, value=round(best), speedup_vs_1=None))
         o2.close()
-        allc = dict(value=float(np.median(rates2)), unit="env-steps/s", cores=cores, windows=[round(r) for r in rates2],
-                    sample="%d envs x %d steps in 3 windows (median), OpenMP static over envs" % (n2, k2))
+        for c in curve:
+            c["speedup_vs_1"] = round(c["value"] / curve[0]["value"], 2)
+        last = curve[-1]
+        eff8 = next((c["speedup_vs_1"] / c["threads"] for c in curve if c["threads"] == 8), 1.0)
+        oversub = last["threads"] > 8 and last["speedup_vs_1"] < 0.25 * eff8 * last["threads"]
+        allc = dict(value=float(last["value"]), unit="env-steps/s", cores=last["threads"], host_threads_available=avail,
+                    cgroup_cpu_quota=quota, threads_curve=curve, host_oversubscribed=bool(oversub),
+                    sample="%d envs, OpenMP dynamic over envs, threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores), one "
+                           ">= 5 s window per point (best of two at all threads)" % n2,
+                    **({"note": "host oversubscribed: %d threads give %.1fx of one thread (8 threads: %.1fx) -- the box's cores are "
+                                "shared with other tenants; not a usable all-cores baseline" % (
+                                    last["threads"], last["speedup_vs_1"], eff8 * 8)} if oversub else {}))
     return dict(value=rate1, unit="env-steps/s", cores=1, kind="port", windows=[round(r) for r in rates],
                 sample="%d envs x %d steps of the C3 workload (16 maps) in 3 windows (median), oracle/pgd_oracle.c fp64 (bicycle "
                        "restatement, not Bullet), 1 thread" % (n, k),
@@ -137,6 +169,10 @@ def parse_args(argv=None):
                     help="lidar beams: default 240 for c3; for c5 72 x 40 m (the reference's multi-agent default) unless given "
                          "(BASELINE.md C5 is --lasers 240)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rows", action="store_true",
+                    help="N = 1: only the metric's workload, without the loaded rows (expert / respawn / C5 / 32768 envs)")
+    ap.add_argument("--rows", default=None,
+                    help="comma-separated subset of the rows to run (names as printed in `rows`), default all")
     ap.add_argument("--mode", default="both", choices=["both", "gather", "replicas"],
                     help="N>1: time the step with the per-step gather (value), without it (value_replicas), or both")
     ap.add_argument("--gather", action="store_true", help="(old flag) same as --mode gather")
@@ -168,6 +204,8 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="plumbing tests: allow more ranks than GPUs (ranks share devices; needs --backend gloo)")
+    ap.add_argument("--corrupt-gather", action="store_true",
+                    help="tests only: flip one value of the received rows before the gather's self-check (gather_ok must read false)")
     args = ap.parse_args(argv)
     if args.gather:
         args.mode = "gather"
@@ -178,27 +216,33 @@ def parse_args(argv=None):
     return args
 
 
-def run_rank(args, rank, world, local_rank):
+# The loaded rows timed next to the metric's workload at N = 1 (name, overrides of the command line).  Windows: 1500 + 2048 steps
+# (C5: 1000 + 1536: the roundabout fills up over the first thousand steps).
+ROWS = [
+    ("c3_expert", dict(actions="expert")),
+    ("c3_respawn", dict(traffic_mode="respawn")),
+    ("c3_expert_respawn", dict(actions="expert", traffic_mode="respawn")),
+    ("c5_8x240", dict(workload="c5", agents=8, lasers=240, warmup=1000, steps=1536)),
+    ("c5_8x72", dict(workload="c5", agents=8, lasers=72, warmup=1000, steps=1536)),
+    ("c5_40x72", dict(workload="c5", agents=40, lasers=72, warmup=1000, steps=512)),
+    ("c3_32768", dict(envs=32768, warmup=1500, steps=512)),
+]
+
+XGMI_LINK_GBPS = 153.0  # per direction and link (MI355X_MICROARCH.md); 7 links per GPU, point to point
+
+
+def measure(args, rank, world, local_rank, with_cpu_baseline=True):
+    """One workload: build the engine, pre-roll, time, read the work statistics back; returns the JSON line as a dict on rank 0
+    (None elsewhere).  The process group, if any, already exists."""
     import torch
     import torch.distributed as dist
     from pgdrive_amd import _abi, bank, mapdata, scenario
     from pgdrive_amd import dist as pdist
     from pgdrive_amd.engine import Engine
 
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     n_dev = torch.cuda.device_count()
-    if n_dev < 1:
-        raise RuntimeError("bench.py needs a GPU: the step engine has no CPU path")
-    if world > n_dev and not args.oversubscribe:
-        raise RuntimeError("%d ranks but only %d GPUs visible (use --oversubscribe --backend gloo for plumbing tests)" % (world, n_dev))
     local_rank = local_rank % n_dev
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        kw = dict(device_id=dev) if args.backend == "nccl" else {}  # binds the RCCL communicator to this rank's GPU
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
 
     N = args.envs
     if args.workload == "c5":  # BASELINE config 5: multi-agent roundabout (reported next to the metric, never as the metric)
@@ -235,7 +279,7 @@ def run_rank(args, rank, world, local_rank):
         extra.append(ej)
 
     rng = np.random.default_rng(rank)  # rank 0 == default_rng(0)
-    CYC = 64
+    CYC = 64 if N <= 8192 else 8
     if args.actions in ("uniform", "expert"):  # (expert: the ring only feeds the pre-roll of engines without an observation yet)
         acts = rng.uniform(-1, 1, size=(CYC, N, A, 2)).astype(np.float32)
     else:  # "drive straight" (profile_pgdrive.py:16): full throttle, a little steering noise so that episodes differ
@@ -297,6 +341,7 @@ def run_rank(args, rank, world, local_rank):
 
     results = {}
     counter = 0
+    gather_check = None
     with torch.cuda.stream(eng.stream):
         for k in range(warm):  # pre-roll to steady-state traffic, once, shared by both modes
             step_replica(counter)
@@ -329,6 +374,7 @@ def run_rank(args, rank, world, local_rank):
             for k in range(timed):
                 one_step(counter)
                 counter += 1
+            t_enq = time.perf_counter()  # every launch of the timed region has been enqueued: the host's share of the loop
             if mode == "gather":
                 gatherer.drain()
             fence()
@@ -339,12 +385,24 @@ def run_rank(args, rank, world, local_rank):
                 t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 elapsed = float(t.item())
-            results[mode] = dict(elapsed=elapsed, prof=prof)
+            results[mode] = dict(elapsed=elapsed, prof=prof, host_enqueue_s=t_enq - t0)
+            if mode == "gather":
+                # self-check of the exchange, after the timed loop: every rank's checksum of the rows it produced against the
+                # checksum of what arrived for it (a transport that delivers wrong rows would otherwise still print a number)
+                a_chk = actions[counter % CYC]
+                corrupt = None
+                if args.corrupt_gather:
+                    def corrupt(buf):
+                        if buf.shape[0] > N or world == 1:  # the rank that holds the gathered rows
+                            buf[buf.shape[0] - 1, 3] += 1.0
+                ok, detail = gatherer.validate(lambda rows: eng.step_packed(a_chk, rows), corrupt=corrupt)
+                counter += 1
+                gather_check = dict(ok=ok, **detail)
 
     step_kernel = eng.describe_step()  # which k_step instantiation the timed launches were (pgd_describe_step)
     # how much work a step does at this point of the run: 5 snapshots of the state, 50 untimed steps apart
     work = None
-    if args.workload == "c3":
+    if args.workload == "c3" and N <= 65536:
         from pgdrive_amd import _abi as abi
         act_n, with_t, ep = [], [], []
         with torch.cuda.stream(eng.stream):
@@ -361,6 +419,13 @@ def run_rank(args, rank, world, local_rank):
         spd = float(np.abs(f_[abi.SF["SPEED"]][:, 0]).mean() * 3.6)
         work = dict(driving_traffic_mean=float(np.mean(act_n)), envs_with_traffic_frac=float(np.mean(with_t)),
                     episode_step_mean=float(np.mean(ep)), ego_speed_kmh_mean=spd)
+    elif args.workload == "c5":
+        from pgdrive_amd import _abi as abi
+        fence()
+        f_, i_, ei_ = eng.get_state()
+        st_ = i_[abi.SI["STATUS"]][:, :A]
+        work = dict(active_agents_mean=float((st_ == abi.ST_ACTIVE).sum(axis=1).mean()),
+                    present_agents_mean=float(((st_ == abi.ST_ACTIVE) | (st_ == abi.ST_DYING)).sum(axis=1).mean()))
 
     ranks_ran = world
     rccl_ranks = None
@@ -372,6 +437,7 @@ def run_rank(args, rank, world, local_rank):
         dist.all_reduce(t)
         ranks_ran = int(round(t.item()))
 
+    out = None
     if rank == 0:
         per_step_units = float(N) * world * max(1, args.engines)
         head = "gather" if "gather" in results else "replicas"
@@ -391,6 +457,30 @@ def run_rank(args, rank, world, local_rank):
             for m in results:
                 out["value_" + m] = per_step_units * timed / results[m]["elapsed"]
                 out["ms_per_step_" + m] = results[m]["elapsed"] / timed * 1e3
+            if gather_check is not None:
+                out["gather_ok"] = gather_check["ok"]
+                out["gather_check"] = gather_check
+            if "gather" in results:
+                # what the exchange can cost by construction: each peer's slice over its own xGMI link into
+                # the root (transport root / peer: the links work in parallel, the slowest is one slice), the all-gather as a ring
+                # (per-link bound: (n - 1) slices through every link), and the host's enqueue time per step of this very loop
+                slice_bytes = N * pdist.pack_width(D, A) * 4
+                link_us = slice_bytes / (XGMI_LINK_GBPS * 1e9) * 1e6
+                ring_us = (world - 1) * slice_bytes / (XGMI_LINK_GBPS * 1e9) * 1e6
+                k_us = (results.get("replicas", {}).get("prof") or {}).get("k_step_ms", 0.0) * 1e3 or None
+                host_us = results["gather"]["host_enqueue_s"] / timed * 1e6
+                bound_us = ring_us if args.transport == "collective" else link_us
+                cands = [x for x in (k_us, bound_us, host_us) if x]
+                out["gather_model"] = {
+                    "slice_bytes_per_rank_per_step": slice_bytes, "xgmi_link_GBps": XGMI_LINK_GBPS,
+                    "link_bound_us": link_us, "ring_allgather_bound_us": ring_us, "k_step_us": k_us,
+                    "host_enqueue_us_per_step": host_us,
+                    "host_enqueue_us_per_step_replicas": (results["replicas"]["host_enqueue_s"] / timed * 1e6) if "replicas" in results else None,
+                    "predicted_floor_us_per_step": max(cands) if cands else None,
+                    "predicted_ceiling_env_steps_per_s": per_step_units / (max(cands) * 1e-6) if cands else None,
+                    "note": "the exchange of step t overlaps the kernels of step t + 1 (double-buffered): the step rate is bounded by the "
+                            "slowest of kernel, link and host enqueue, not by their sum",
+                }
         if head == "gather":
             par = "env-sharded dp%d + %s, double-buffered" % (world, gatherer.describe())
         else:
@@ -407,7 +497,8 @@ def run_rank(args, rank, world, local_rank):
             **({"note": "%d independent engines x %d envs on their own streams, stepped round-robin: consecutive steps "
                         "of different engines overlap (asynchronous vector-env groups)" % (args.engines, N)}
                if args.engines > 1 else {}),
-            **({"active_vehicles_mean": 1.0 + work["driving_traffic_mean"], **work} if work else {}),
+            **({"active_vehicles_mean": 1.0 + work["driving_traffic_mean"]} if work and "driving_traffic_mean" in work else {}),
+            **(work or {}),
             "step_kernel": step_kernel,
             "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
             "engines_per_gpu": max(1, args.engines), "env_groups": args.groups,
@@ -428,32 +519,109 @@ def run_rank(args, rank, world, local_rank):
             dom = "k_observe" if prof["k_observe_ms"] >= prof["k_step_ms"] else "k_step"
             dom_ms = max(prof["k_observe_ms"], prof["k_step_ms"])
             dom_bytes = (b_obs if dom == "k_observe" else b_step) * N
-            achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            nominal = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
             traffic, traffic_src = load_traffic(N, args)
+            # bytes that MOVE per launch: the counters' figure when a pass of this workload is committed, else the formula
+            # charged only for the records of vehicles that drove (waiting / removed slots are neither rewritten nor re-read
+            # from HBM: reset image); the nominal formula charges all V records read + written
+            moved, moved_src = None, None
+            if traffic and dom == "k_step":
+                moved, moved_src = float(traffic), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (%s)" % traffic_src
+            elif work and "driving_traffic_mean" in work and dom == "k_step":
+                moved = (b_step - 2 * 128 * (args.traffic - work["driving_traffic_mean"])) * N
+                moved_src = "algorithmic bytes charged for the records of driving vehicles only (no counter pass of this workload committed)"
+            elif work and "present_agents_mean" in work and dom == "k_step":
+                moved = (b_step - 2 * 128 * (A - work["present_agents_mean"])) * N
+                moved_src = "algorithmic bytes charged for the records of present agents only (no counter pass of this workload committed)"
+            achieved = (moved / (dom_ms * 1e-3) / 1e9) if (moved and dom_ms > 0) else nominal
             out["roofline"] = {
                 "bound": "hbm", "kernel": dom + (" (observation fused)" if fused else ""), "achieved": achieved,
-                "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                # the same ratio with the HBM bytes the counters saw instead of the algorithmic bytes
-                "frac_traffic": (traffic / (dom_ms * 1e-3) / 8e12) if (traffic and dom_ms > 0) else None,
-                "traffic_source": traffic_src,
+                "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "frac_source": moved_src or "nominal algorithmic bytes",
+                "bytes_per_launch": moved if moved else dom_bytes,
+                "traffic": traffic, "traffic_source": traffic_src,
+                # the nominal formula (every record read + written, whether it moved or not)
+                "achieved_nominal": nominal, "frac_nominal": nominal / 8000.0,
                 "bytes_per_env_step": {"k_step": b_step, "k_observe": b_obs},
-                # the same formula charged only for the records of vehicles that DROVE (read + rewritten) at this point of the
-                # run: waiting / removed slots are neither rewritten nor re-read from HBM (reset image)
                 **({"bytes_per_env_step_active": b_step - 2 * 128 * (args.traffic - work["driving_traffic_mean"]),
                     "frac_active": (b_step - 2 * 128 * (args.traffic - work["driving_traffic_mean"])) * N / (dom_ms * 1e-3) / 8e12}
-                   if (work and dom == "k_step" and dom_ms > 0) else {}),
+                   if (work and "driving_traffic_mean" in work and dom == "k_step" and dom_ms > 0) else {}),
                 "k_step_ms": prof["k_step_ms"], "k_observe_ms": prof["k_observe_ms"], "events": prof["count"],
                 "launches_per_event_group": stride if fused else 1,
             }
         else:
             out["roofline"] = None
-        if not args.no_cpu_baseline and world == 1:
+        if with_cpu_baseline and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(descs, args) if args.workload == "c3" else None
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
     if gatherer is not None:
         gatherer.close()
+    for ej in extra:
+        ej.close()
+    eng.close()
+    del actions, act_buf
+    torch.cuda.empty_cache()
+    return out
+
+
+def row_summary(name, line):
+    """The part of a row's line that goes into `rows` of the headline."""
+    r = line.get("roofline") or {}
+    c = line["config"]
+    keep = ("driving_traffic_mean", "envs_with_traffic_frac", "ego_speed_kmh_mean", "episode_step_mean", "active_agents_mean",
+            "present_agents_mean", "step_kernel", "obs_dim", "envs_per_gpu")
+    return {
+        "row": name, "workload": c["workload"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+        "steps_timed": line["steps_timed"], "warmup_run": line["warmup_run"],
+        **{k: c[k] for k in keep if k in c},
+        "roofline": {k: r.get(k) for k in ("kernel", "achieved", "frac", "frac_source", "frac_nominal", "frac_active", "traffic",
+                                           "traffic_source", "bytes_per_launch", "k_step_ms", "k_observe_ms")} if r else None,
+    }
+
+
+def run_rank(args, rank, world, local_rank):
+    import copy
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise RuntimeError("bench.py needs a GPU: the step engine has no CPU path")
+    if world > n_dev and not args.oversubscribe:
+        raise RuntimeError("%d ranks but only %d GPUs visible (use --oversubscribe --backend gloo for plumbing tests)" % (world, n_dev))
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device("cuda", local_rank % n_dev)
+    if world > 1:
+        kw = dict(device_id=dev) if args.backend == "nccl" else {}  # binds the RCCL communicator to this rank's GPU
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
+
+    out = measure(args, rank, world, local_rank)
+    # the loaded rows, in the same invocation (N = 1, the default command only: any flag that changes the workload of the
+    # headline -- other actions, env counts, groups ... -- is a single-workload run)
+    default_cmd = (args.workload == "c3" and args.actions == "uniform" and args.traffic_mode == "trigger" and args.envs == 4096 and
+                   args.traffic == 16 and args.lasers == 240 and args.maps == 100 and args.groups == 1 and args.engines == 1 and
+                   args.step_n == 1 and not args.topdown and not args.exact)
+    if world == 1 and rank == 0 and not args.no_rows and (default_cmd or args.rows):
+        want = None if not args.rows else set(args.rows.split(","))
+        rows = []
+        for name, over in ROWS:
+            if want is not None and name not in want:
+                continue
+            ra = copy.copy(args)
+            ra.exact, ra.warmup, ra.steps = True, 1500, 2048
+            for k, v in over.items():
+                setattr(ra, k, v)
+            try:
+                rows.append(row_summary(name, measure(ra, 0, 1, local_rank, with_cpu_baseline=False)))
+            except Exception as ex:  # noqa: BLE001  (a row that fails must not take the metric's line with it)
+                rows.append({"row": name, "error": "%s: %s" % (type(ex).__name__, str(ex)[:200])})
+        out["rows"] = rows
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -471,6 +639,9 @@ def _spawned(local_rank, args, world, port):
 
 def main(argv=None):
     args = parse_args(argv)
+    # the CPU baseline's OpenMP threads stay where they start (set before libgomp is loaded by liborc.so / torch)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) >= 1 and "RANK" in os.environ:
         # launched by torch.distributed.run (or any launcher that sets the rendezvous environment)
         world = int(os.environ["WORLD_SIZE"])

@@ -150,6 +150,46 @@ class StepGather:
         self.wait(b)
         return unpack(self.recv[b], self.D, self.A)
 
+    # -- self-check of the exchange (bench.py: `gather_ok`) ------------------------------------------------------------------
+    @staticmethod
+    def row_checksum(torch, rows):
+        """Two exact, order-independent 64-bit integer sums over the BIT PATTERNS of `rows` [n, W] fp32 (plain and weighted by
+        position; int64 wrap-around is deterministic): equal rows give equal sums, a flipped bit, a swapped pair of rows or
+        a slice that landed at the wrong offset changes them."""
+        bits = rows.contiguous().view(torch.int32).to(torch.int64).reshape(-1)
+        w = (torch.arange(bits.numel(), dtype=torch.int64, device=bits.device) % 65521) + 1
+        return torch.stack([bits.sum(), (bits * w).sum()])
+
+    def validate(self, produce, corrupt=None):
+        """One more step + exchange, then every rank's checksum of the rows it PRODUCED is compared with the checksum of the slice
+        that ARRIVED for it (on rank 0 with transport "root", on every rank otherwise).  Returns (ok, detail) on every rank
+        (the verdict is all-reduced).  `corrupt(recv_buffer)` lets a test damage what arrived before the comparison."""
+        t, dist = self.torch, self.dist
+        b = self.step(produce)
+        self.wait(b)
+        dev = self.recv[b].device
+        if dev.type == "cuda":
+            t.cuda.synchronize(dev)
+        mine = self.row_checksum(t, self.send[b])  # (before the test hook: in-place transports send from the receive buffer)
+        if corrupt is not None:
+            corrupt(self.recv[b])
+        if self.transport == "local":
+            got = self.row_checksum(t, self.recv[b][:self.n_local])
+            ok = bool(t.equal(mine, got))
+            return ok, dict(ranks_checked=1, mismatched_ranks=[] if ok else [0])
+        sums = [t.zeros(2, dtype=t.int64, device=dev) for _ in range(self.world)]
+        dist.all_gather(sums, mine)
+        bad = []
+        if self.transport != "root" or self.rank == 0:
+            for q in range(self.world):
+                got = self.row_checksum(t, self.recv[b][q * self.n_local:(q + 1) * self.n_local])
+                if not bool(t.equal(got, sums[q])):
+                    bad.append(q)
+        flag = t.tensor([len(bad)], dtype=t.int64, device=dev)
+        dist.all_reduce(flag)
+        return int(flag.item()) == 0, dict(ranks_checked=self.world, mismatched_ranks=bad,
+                                           checked_on="rank 0" if self.transport == "root" else "every rank")
+
     def close(self):
         if self.peer is not None:
             self.peer.close()

@@ -162,15 +162,48 @@ def test_bench_spawns_its_own_ranks():
     assert d["value_mode"] == "gather" and d["value"] == d["value_gather"] and d["value_replicas"] > 0
     assert d["config"]["global_envs"] == 512 and "gather(obs|reward|done) to rank 0" in d["config"]["parallelism"]
     assert d["roofline"]["k_step_ms"] > 0  # measured in the replicas pass
+    # the exchange checks itself after the timed loop and the line carries what bounds it by construction
+    assert d["gather_ok"] is True and d["gather_check"]["ranks_checked"] == 2 and d["gather_check"]["mismatched_ranks"] == []
+    m = d["gather_model"]
+    assert m["slice_bytes_per_rank_per_step"] == 256 * 276 * 4 and m["link_bound_us"] > 0 and m["host_enqueue_us_per_step"] > 0
+    assert m["predicted_floor_us_per_step"] >= m["link_bound_us"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("transport", ["root", "collective"])
+def test_bench_gather_self_check_sees_a_damaged_row(transport):
+    """A transport that delivers wrong rows must not print a clean line: one value of the received rows is changed before the
+    self-check (--corrupt-gather) and `gather_ok` reads false, naming the rank whose slice differs."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--backend", "gloo",
+                          "--exact", "--steps", "16", "--warmup", "8", "--envs", "128", "--no-cpu-baseline", "--mode", "gather",
+                          "--transport", transport, "--corrupt-gather"],
+                         capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["gather_ok"] is False and d["gather_check"]["mismatched_ranks"] == [1]
 
 
 def test_bench_default_run_is_steady_state_and_reproducible_from_events():
     """--steps 20 (what the driver passes) still pre-rolls and times the floors; the roofline time comes from >= 64 event groups."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--no-cpu-baseline", "--rows", "c3_respawn,c5_8x72"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["steps"] == 20 and d["warmup"] == 5 and d["steps_timed"] >= 2000 and d["warmup_run"] >= 1500
     assert d["n_gpus"] == 1 and d["roofline"]["events"] >= 64
     # launch-to-launch time (wall / steps) and the event time of the kernel agree: same workload phase
     assert abs(d["ms_per_step"] - d["roofline"]["k_step_ms"]) < 0.15 * d["ms_per_step"]
+    # `frac` is charged for the bytes that move (counter pass of this workload or the driving vehicles' records), never more than
+    # the nominal formula that charges every record
+    r = d["roofline"]
+    assert 0 < r["frac"] <= r["frac_nominal"] < 1 and r["frac_source"] != "nominal algorithmic bytes"
+    # the loaded rows of the same invocation: their own workload, kernel time and roofline
+    rows = {x["row"]: x for x in d["rows"]}
+    assert set(rows) == {"c3_respawn", "c5_8x72"} and all("error" not in x for x in rows.values())
+    assert "traffic mode respawn" in rows["c3_respawn"]["workload"] and rows["c3_respawn"]["driving_traffic_mean"] > 5
+    assert rows["c3_respawn"]["roofline"]["k_step_ms"] > r["k_step_ms"]  # every traffic vehicle drives: a heavier step
+    assert rows["c5_8x72"]["workload"].startswith("C5: 4096 envs/GPU x 8 agents") and rows["c5_8x72"]["active_agents_mean"] > 1
+    assert all(0 < x["roofline"]["frac"] <= x["roofline"]["frac_nominal"] for x in rows.values())

@@ -41,8 +41,29 @@ def _worker(rank, world, port, n_total, q, transport="collective"):
         b = g.step(produce)
         go, gr, gd = g.result(b)
         outs.append((go.numpy().copy(), gr.numpy().copy(), gd.numpy().copy()))
+    # the exchange's self-check (bench.py prints it as `gather_ok`): clean rows pass, one damaged value among the rows that ARRIVED
+    # from the last rank fails -- on every rank, since the verdict is all-reduced
+    act = rng.uniform(-1, 1, size=(n_total, 1, 2)).astype(np.float32)[lo:hi]
+
+    def produce(rows):
+        obs, rew, done, flags = o.step(act)
+        pdist.pack(torch, torch.from_numpy(obs.astype(np.float32)), torch.from_numpy(rew.astype(np.float32)),
+                   torch.from_numpy(done), out=rows)
+    ok_clean, detail = g.validate(produce)
+
+    def damage(buf):
+        if buf.shape[0] == n_total:  # a rank that holds the gathered rows
+            buf[n_total - 1, 5] += 0.25
+    ok_bad, detail_bad = g.validate(produce, corrupt=damage)
+
+    def swap(buf):  # two rows of the last rank's slice exchanged: the plain sum does not see it, the weighted one does
+        if buf.shape[0] == n_total:
+            tmp = buf[n_total - 1].clone()
+            buf[n_total - 1] = buf[n_total - 2]
+            buf[n_total - 2] = tmp
+    ok_swap, _ = g.validate(produce, corrupt=swap)
     if rank == 0:
-        q.put(outs)
+        q.put((outs, (ok_clean, ok_bad, ok_swap, detail, detail_bad)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,7 +81,12 @@ def test_two_rank_gather_matches_single_process(transport):
         procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q, transport)) for r in range(world)]
         for p in procs:
             p.start()
-        res[world] = q.get(timeout=240)
+        res[world], checks = q.get(timeout=240)
+        ok_clean, ok_bad, ok_swap, detail, detail_bad = checks
+        assert ok_clean and not detail["mismatched_ranks"], detail
+        assert not ok_bad and not ok_swap
+        if world == 2:
+            assert detail_bad["mismatched_ranks"] == [1] and detail_bad["ranks_checked"] == 2
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0
