@@ -37,6 +37,15 @@ def lib():
         L.orc_clip.argtypes = [C.c_double] * 3
         L.orc_lane_heading.argtypes = [C.c_void_p, C.c_double]
         L.orc_lane_distance.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        for name in ("orc_lane_heading_f64", "orc_lane_distance_f64"):
+            getattr(L, name).restype = C.c_double
+        L.orc_lane_heading_f64.argtypes = [C.c_void_p, C.c_double]
+        L.orc_lane_distance_f64.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_lane_local_f64.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.orc_lane_position_f64.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.orc_upload_tables_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_upload_spawns_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_upload_config_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_lane_local.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         L.orc_lane_position.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         L.orc_pid.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
@@ -79,7 +88,11 @@ def _p(a):
 
 class Oracle:
     """Same call surface as pgdrive_amd.engine.Engine, float64 on the CPU."""
-    def __init__(self, cfg, bank, scen):
+    def __init__(self, cfg, bank, scen, f64=False):
+        """f64: the tables keep the float64 values of the map description (bank.lanes64 / boxes64 / maps64) and, when the scenario
+        bank carries them (scen.spawns64 [n, 12]), of the spawn records, instead of the ABI's float32 records -- the path the
+        reference-generated goldens are held to at 1e-9 (tests/test_oracle_golden.py).  Default: the float32 records, i.e. the
+        very numbers the engine is given (GPU parity tests)."""
         self.L = lib()
         self.cfg = cfg
         self.N, self.A, self.V = cfg.num_envs, cfg.num_agents, cfg.num_agents + cfg.num_traffic
@@ -93,6 +106,20 @@ class Oracle:
             len(bank.cell_items)
         )
         self.L.orc_upload_scenarios(self.h, _p(scen.scenarios), len(scen.scenarios), _p(scen.spawns))
+        if f64:
+            # the float fields of the config as the reference holds them: a float32 field that is the rounding of a short decimal
+            # (0.1f, 0.02f) is taken as that decimal
+            names = ("lidar_dist", "dt", "success_reward", "out_of_road_penalty", "crash_vehicle_penalty", "crash_object_penalty",
+                     "driving_reward", "speed_reward", "side_dist", "lane_line_dist", "overspeed_penalty")
+            cd = np.array([float(np.format_float_positional(np.float32(getattr(cfg, k)), unique=True, trim="-")) for k in names],
+                          dtype=np.float64)
+            assert self.L.orc_upload_config_f64(self.h, _p(cd), len(cd)) == 0
+            assert self.L.orc_upload_tables_f64(self.h, _p(bank.lanes64), len(bank.lanes64), _p(bank.boxes64), len(bank.boxes64),
+                                                _p(bank.maps64), len(bank.maps64)) == 0
+            sp64 = getattr(scen, "spawns64", None)
+            if sp64 is not None:
+                sp64 = np.ascontiguousarray(sp64, dtype=np.float64)
+                assert sp64.shape == (len(scen.spawns), 12) and self.L.orc_upload_spawns_f64(self.h, _p(sp64), len(sp64)) == 0
 
     def reset(self, scen_ids, env_ids=None):
         scen_ids = np.ascontiguousarray(scen_ids, dtype=np.int32)

@@ -18,6 +18,10 @@ int orc_upload_maps(orc_handle h, const pgd_map* maps, int n_maps, const pgd_lan
                     const pgd_road* roads, int n_roads, const pgd_box* boxes, int n_boxes, const int32_t* cs, int n_cs,
                     const int32_t* ci, int n_ci);
 int orc_upload_scenarios(orc_handle h, const pgd_scenario* scen, int n_scen, const pgd_spawn* spawns);
+/* float64 values of the float fields of the tables / spawn records uploaded before (see pgd_oracle.c) */
+int orc_upload_tables_f64(orc_handle h, const double* lanes, int n_lanes, const double* boxes, int n_boxes, const double* maps, int n_maps);
+int orc_upload_spawns_f64(orc_handle h, const double* spawns, int n);
+int orc_upload_config_f64(orc_handle h, const double* values, int n);
 void orc_destroy(orc_handle h);
 void orc_state_dims(int* nf, int* ni, int* nei);
 void orc_get_state(orc_handle h, double* f, int32_t* i, int32_t* ei);

@@ -357,6 +357,19 @@ def pack_lanes(desc, succ, truncate_succ=False):
     return out
 
 
+def pack_lanes_f64(desc):
+    """The ten float fields of every lane record in float64, same choice of parameters as pack_lanes (test infrastructure: the
+    CPU oracle's float64 table path, oracle/pgd_oracle.c::orc_upload_tables_f64)."""
+    out = np.zeros((len(desc["lanes"]), 10), dtype=np.float64)
+    for i, l in enumerate(desc["lanes"]):
+        if l["type"] == 0:
+            out[i, :6] = [l["start"][0], l["start"][1], l["direction"][0], l["direction"][1], l["heading"], 0.0]
+        else:
+            out[i, :6] = [l["center"][0], l["center"][1], l["radius"], l["start_phase"], l["end_phase"], float(l["direction"])]
+        out[i, 6:] = [l["length"], l["width"], l["end"][0], l["end"][1]]
+    return out
+
+
 def pack_roads(desc):
     out = np.zeros(len(desc["roads"]), dtype=ROAD_DT)
     for i, r in enumerate(desc["roads"]):
@@ -384,6 +397,7 @@ class MapBank:
         self.descs = list(descs)
         maps = np.zeros(len(self.descs), dtype=MAP_DT)
         lanes, roads, boxes, cstart, citems = [], [], [], [], []
+        lanes64, boxes64, maps64 = [], [], []  # the same float fields before their rounding to float32 (oracle pinning only)
         lo = ro = bo = co = io = 0
         self.succ = []
         for m, d in enumerate(self.descs):
@@ -402,6 +416,10 @@ class MapBank:
             h["gx"], h["gy"], h["ox"], h["oy"], h["cell"] = g["gx"], g["gy"], g["ox"], g["oy"], g["cell"]
             h["lane_width"] = d["lane_width"]
             lanes.append(L), roads.append(R), boxes.append(B), cstart.append(g["start"]), citems.append(g["items"])
+            lanes64.append(pack_lanes_f64(d))
+            boxes64.append(np.stack([bx[:, 1], bx[:, 2], np.cos(bx[:, 3]), np.sin(bx[:, 3]), bx[:, 4], bx[:, 5]], axis=1)
+                           if len(bx) else np.zeros((0, 6)))
+            maps64.append([g["ox"], g["oy"], g["cell"], d["lane_width"]])
             lo += len(L)
             ro += len(R)
             bo += len(B)
@@ -413,6 +431,9 @@ class MapBank:
         self.boxes = np.concatenate(boxes)
         self.cell_start = np.concatenate(cstart).astype(np.int32)
         self.cell_items = np.concatenate(citems).astype(np.int32)
+        self.lanes64 = np.ascontiguousarray(np.concatenate(lanes64), dtype=np.float64)
+        self.boxes64 = np.ascontiguousarray(np.concatenate(boxes64), dtype=np.float64)
+        self.maps64 = np.ascontiguousarray(np.array(maps64, dtype=np.float64).reshape(-1, 4))
 
     def nbytes(self):
         return sum(a.nbytes for a in (self.maps, self.lanes, self.roads, self.boxes, self.cell_start, self.cell_items))
