@@ -1378,8 +1378,26 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
           clear = clear > 1e8 ? 0.0 : std::max(0.0, clear - 0.03);  // 3 cm of slack for the fp32 forms on the device
         }
         L.ex = (float)clear;
-        L.ey = 0.0f;
+        L.ey = 0.0f;  // (the bits of the related-lanes mask, below)
       }
+    // device-private use of `ey`: the 32-bit set { id & 31 } over the lane itself, its successors and its predecessors (the lanes
+    // whose successor list holds it) -- every lane an object must be on to count in the IDM front / back search of this lane
+    // (FrontBackObjects: same lane, successor lane, predecessor lane; idm_policy.py:107-131).  find_front_back drops the other
+    // bodies of the broad phase with one shift per body before its search loop; a superset (ids collide mod 32) keeps it exact.
+    for (int m = 0; m < n_maps; ++m) {
+      std::vector<uint32_t> rel((size_t)maps[m].n_lanes, 0u);
+      for (int k = 0; k < maps[m].n_lanes; ++k) {
+        const pgd_lane& L = dl[(size_t)maps[m].lane_off + k];
+        rel[(size_t)k] |= 1u << (k & 31);
+        for (int q = 0; q < PGD_MAX_SUCC; ++q) {
+          const int sid = L.succ[q];
+          if (sid < 0 || sid >= maps[m].n_lanes) continue;
+          rel[(size_t)k] |= 1u << (sid & 31);
+          rel[(size_t)sid] |= 1u << (k & 31);
+        }
+      }
+      for (int k = 0; k < maps[m].n_lanes; ++k) memcpy(&dl[(size_t)maps[m].lane_off + k].ey, &rel[(size_t)k], 4);
+    }
     if ((rc = upload(&h->lanes, dl.data(), n_lanes, h->stream))) return rc;
     std::vector<LaneNav> nav((size_t)(n_lanes > 0 ? n_lanes : 1));
     for (int k = 0; k < n_lanes; ++k) {

@@ -6,6 +6,9 @@
 // ---------------------------------------------------------------------------------------------------------------------
 // IDM: policy/idm_policy.py:82-133 (FrontBackObjects), :190-353 (act, lane change), :244-271 (PID + IDM law)
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef PGD_RELMASK_MIN
+#define PGD_RELMASK_MIN 3  // bodies in some vehicle's broad phase from which the related-lane pass of find_front_back runs
+#endif
 struct Fbo {
   int front[3], back[3];
   float fd[3], bd[3];
@@ -49,8 +52,29 @@ DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int bas
     float same_f = max_dist, same_b = max_dist, succ_f = max_dist, pred_b = max_dist, pred_bx = max_dist;
     int o_same_f = -1, o_same_b = -1, o_succ_f = -1, o_pred_b = -1, o_pred_bx = -1;
     bool found_f = false, found_b = false;
+    // Only a body on the target lane, on one of its successors or on one of its predecessors can count; the device copy of the
+    // lane carries that set as a 32-bit mask over (lane id & 31) (pgd_upload_maps).  One uniform pass over the slots -- every
+    // lane of the wave reads the same S.lane[o]: broadcasts, no dependent chain -- leaves the few bodies the search proper
+    // has to look at: the loop below costs ~60 instructions and four LDS reads per body, and the wave pays for the longest
+    // list among its lanes (dense traffic: the broad phase holds 8 - 16 bodies, 1 - 3 of them on a related lane).
+    unsigned long long rel_objs = objs;
+#ifndef PGD_NO_RELMASK
+    // (wave-uniform switch: with short lists everywhere -- the metric's workload -- the pass would cost more than it saves)
+    if (__ballot(__popcll(objs) >= PGD_RELMASK_MIN) != 0ull) {
+      const unsigned rel = __float_as_uint(li.ey);
+      unsigned lo_m = 0u, hi_m = 0u;
+      const int v_lo = V < 32 ? V : 32;
+      for (int o0 = 0; o0 < v_lo; o0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)  // (slots past the last one repeat it: their bits are not in `objs`)
+          lo_m |= ((rel >> (S.lane[base + min(o0 + j, V - 1)] & 31)) & 1u) << ((o0 + j) & 31);
+      }
+      for (int o = 32; o < V; ++o) hi_m |= ((rel >> (S.lane[base + o] & 31)) & 1u) << (o - 32);
+      rel_objs &= ((unsigned long long)hi_m << 32) | lo_m;
+    }
+#endif
     // only the vehicles inside the broad phase, in slot order (ties keep the first one like the reference's loop)
-    for (unsigned long long m = objs; m != 0ull; m &= m - 1ull) {
+    for (unsigned long long m = rel_objs; m != 0ull; m &= m - 1ull) {
       const int o = __builtin_ctzll(m);
       const int ol = S.lane[base + o];
       const float olon = S.lon[base + o], ollen = S.llen[base + o];

@@ -1,5 +1,5 @@
 """Launch time of k_step up to each top-level point of the step (build -DPGD_EXITAT: every wave returns at the chosen mark,
-nothing is stored, so the state stays the steady-state snapshot reached by the warm-up).  usage: exit_profile.py [N] [mode]"""
+nothing is stored, so the state stays the steady-state snapshot reached by the warm-up).  usage: [TRAFFIC=respawn] exit_profile.py [N] [uniform|straight|expert]"""
 import sys, os, ctypes as C, numpy as np, subprocess, time
 sys.path.insert(0, '.')
 import torch
@@ -14,19 +14,27 @@ L.pgd_debug_step_many.argtypes = [C.c_void_p] * 6 + [C.c_int]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 mode = sys.argv[2] if len(sys.argv) > 2 else 'uniform'
 descs = bank.get_descriptions(range(1000, 1100))
-mb = mapdata.MapBank(descs); sb = scenario.ScenarioBank(descs, [d['seed'] for d in descs])
+mb = mapdata.MapBank(descs); sb = scenario.ScenarioBank(descs, [d['seed'] for d in descs], traffic_mode=os.environ.get('TRAFFIC', 'trigger'))
 eng = engine.Engine(_abi.make_config(N, seed=1234), mb, sb)
 eng.reset(np.arange(N) % 100)
 rng = np.random.default_rng(0)
-if mode == 'uniform':
+if mode in ('uniform', 'expert'):
     acts = torch.from_numpy(rng.uniform(-1, 1, size=(64, N, 1, 2)).astype(np.float32)).cuda()
 else:
     a = np.zeros((64, N, 1, 2), np.float32); a[..., 1] = 1.0; a[..., 0] = rng.normal(0, 0.05, size=(64, N, 1)); acts = torch.from_numpy(a).cuda()
 names = {99: 'entry', 13: 'loads issued+staged', 0: 'trigger', 1: 'snapshot', 4: 'policy+dynamics+crash', 5: 'after_step+state_check',
          6: 'reward/done', 7: 'reset', 8: 'store', 20: 'obs publish', 14: 'obs done', -1: 'full'}
 with torch.cuda.stream(eng.stream):
-    for k in range(1500): eng.step(acts[k % 64])
+    abuf = torch.zeros((N, 1, 2), dtype=torch.float32, device='cuda')
+    for k in range(1500):
+        if mode == 'expert' and k > 0:
+            eng.lane_keep_actions(abuf, k); eng.step(abuf)
+        else:
+            eng.step(acts[k % 64])
     eng.sync()
+    if mode == 'expert': acts[0].copy_(abuf)
+    f, i, ei = eng.get_state()
+    print('driving traffic per env %.2f, ego km/h %.1f' % ((i[0, :, 1:] == 2).sum(1).mean(), abs(f[3, :, 0]).mean() * 3.6))
     prev = 0.0
     for pt in (99, 13, 0, 1, 4, 5, 6, 7, 8, 20, 14, -1):
         L.pgd_debug_exit_at(eng.h, pt)

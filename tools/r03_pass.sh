@@ -5,7 +5,7 @@
 R=$GRAFT_REPO_ROOT; TAG=$1; N=$2; ACT=$3; MODE=$4; shift 4
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/$TAG; mkdir -p $O
-ARGS="--envs $N --actions $ACT --traffic-mode $MODE $@"
+ARGS="--no-rows --envs $N --actions $ACT --traffic-mode $MODE $@"
 [ -x /tmp/pgd_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/profiles/r01_calib.hip -o /tmp/pgd_calib 2>/dev/null
 timeout 600 python $R/bench.py $ARGS > $O/bench.json 2> $O/bench.err < /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py $ARGS --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err < /dev/null
