@@ -140,6 +140,11 @@ union StepUnion {
   } obs;
 };
 
+// the per-beam minima of the fused lidar (observe_agent, incidence form) live where the IDM search kept its per-vehicle lane data:
+// own-lane coordinate, lane length and successor list are dead once the policies have run
+static_assert(offsetof(Snap, llen) == offsetof(Snap, lon) + sizeof(float) * WAVE && offsetof(Snap, succ) == offsetof(Snap, llen) + sizeof(float) * WAVE,
+              "lon / llen / succ of the snapshot are one contiguous area");
+DEV unsigned* lidar_minb(Snap& S) { return reinterpret_cast<unsigned*>(&S.lon[0]); }  // 6 * WAVE words >= 4 * WAVE beams
 // A block of k_step is ONE wave: the lanes only have to see each other's LDS traffic in order, which the hardware guarantees for
 // a wave; a workgroup-scope barrier would also wait for every global load and store in flight (release / acquire fences).
 DEV void step_sync() { row_sync<true>(); }
@@ -764,8 +769,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       near_any = near_any || near_a;
       step_sync();
       PHASE_MARK(21);  // obs: compaction
-      observe_agent<OBJ, STD>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL, obs + (size_t)e * d.ostride + (size_t)a * d.D, lane,
-                    WAVE, nullptr, nullptr, &pre);
+      observe_agent<OBJ, STD, false, true, true>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL,
+                                                 obs + (size_t)e * d.ostride + (size_t)a * d.D, lane, WAVE, nullptr, nullptr, &pre, lidar_minb(S));
       step_sync();
     }
     // hint for the next step's contact tests (EI_NEAR); without a lidar the compaction looked at nothing: always test
@@ -840,7 +845,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         if (lane == 0) d.ei[(size_t)eq * PGD_NEI + EI_NEAR] = near_q ? 1 : 0;
       }
       step_sync();
-      observe_agent<OBJ, STD, false, false>(d, mvq, d.spawns[(size_t)scen_q * d.sstride], ag, OL, obs + (size_t)eq * d.ostride, lane, WAVE);
+      observe_agent<OBJ, STD, false, false, true>(d, mvq, d.spawns[(size_t)scen_q * d.sstride], ag, OL, obs + (size_t)eq * d.ostride, lane, WAVE,
+                                                  nullptr, nullptr, nullptr, lidar_minb(S));
       step_sync();
     }
   }

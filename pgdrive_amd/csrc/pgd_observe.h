@@ -37,6 +37,9 @@ DEV float heading_diff(const pgd_lane& l, float px, float py, float fx, float fy
   return clipf((fx * lx + fy * ly) / (ln * fn), -1.0f, 1.0f) * 0.5f + 0.5f;
 }
 
+#ifndef PGD_LIDAR_INC_MIN
+#define PGD_LIDAR_INC_MIN 2  // bodies in the lidar broad phase from which a one-wave row casts incidences instead of rounds
+#endif
 struct ObsLds {  // bodies inside the lidar broad phase of the observing agent, compacted
   float bx[MAXV], by[MAXV], bux[MAXV], buy[MAXV], bhl[MAXV], bhw[MAXV], bspd[MAXV];
   float bdist[MAXV];  // centre distance; +inf for traffic objects, which are never ranked as neighbour vehicles
@@ -286,7 +289,7 @@ DEV void row_sync() {
 template <bool OBJ, bool STD = false, bool OTH = false, bool STATE = true, bool WAVE_ROW = false, class MV>
 DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const AgentView& ag, ObsLds& L,
                        float* __restrict__ row, int tid, int nt, const VehRec* recs = nullptr, const pgd_spawn* spb = nullptr,
-                       const ObsPre* pre = nullptr) {
+                       const ObsPre* pre = nullptr, unsigned* minb = nullptr) {
   const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
   const float R = d.cfg.lidar_dist;
   const int NL = d.cfg.num_lasers;
@@ -390,6 +393,72 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
     if (!STD) best = lidar_noise(d, ag.env, ag.slot, ag.tick, i, best);
     if (on) row[o_oth + per_other * NO + i] = best;
   };
+  // With several bodies in range a round of 64 beams runs the slab test of every body whose window meets its 96-degree sector for
+  // ALL 64 beams, although a window is 10 - 20 beams wide: three quarters of those tests are masked off.  A row that one wave
+  // produces and whose fan fits the four direction registers (240 beams: the default) instead flattens the (body, beam-inside-its-
+  // window) INCIDENCES by a prefix sum over the window sizes and deals them out to the lanes 64 at a time: a body is tested against
+  // the beams that can reach it and nothing else; the nearest hit per beam is an unsigned min in LDS (fractions are >= 0, so
+  // their bit patterns order like the floats).  Same pairs tested as by the rounds below, same minimum: the same cloud.
+  // `minb` = NL words of LDS nobody else uses during the row.  Wave-uniform switch: a single body is cheaper in the round loop.
+  if (WAVE_ROW && minb != nullptr && nt == WAVE && NL <= 4 * WAVE) {
+    const int n_u = __builtin_amdgcn_readfirstlane(n);
+    if (n_u >= PGD_LIDAR_INC_MIN) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q * WAVE + lane64 < NL) minb[q * WAVE + lane64] = 0x3f800000u;  // 1.0f = no hit
+      // exclusive prefix of the window sizes: lane k < n stands for body k
+      const int cnt = lane64 < n_u ? L.bcnt[lane64] : 0;
+      int incl = cnt;
+      for (int off = 1; off < n_u; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        incl += lane64 >= off ? up : 0;
+      }
+      const int pref = incl - cnt;
+      const int total = __builtin_amdgcn_readlane(incl, n_u - 1);
+      // this lane's own four beams, rotated by the heading: an incidence fetches the direction of its beam from the lane that holds it
+      const float dx0 = R * (bd0.x * hx - bd0.y * hy), dy0 = R * (bd0.y * hx + bd0.x * hy);
+      const float dx1 = R * (bd1.x * hx - bd1.y * hy), dy1 = R * (bd1.y * hx + bd1.x * hy);
+      const float dx2 = R * (bd2.x * hx - bd2.y * hy), dy2 = R * (bd2.y * hx + bd2.x * hy);
+      const float dx3 = R * (bd3.x * hx - bd3.y * hy), dy3 = R * (bd3.y * hx + bd3.x * hy);
+      row_sync<true>();
+      for (int j0 = 0; j0 < total; j0 += WAVE) {
+        const int j = j0 + lane64;
+        // owner = the last body whose window starts at or before incidence j (the starts ascend with k; a scalar read per body)
+        int owner = -1, opref = 0;
+        for (int k = 0; k < n_u; ++k) {
+          const int st = __builtin_amdgcn_readlane(pref, k);
+          const bool ge = j >= st;
+          owner += ge ? 1 : 0;
+          opref = ge ? st : opref;
+        }
+        const bool on = j < total;
+        const int k = on ? owner : 0;
+        int i = L.bi0[k] + (j - opref);
+        i -= i >= NL ? NL : 0;
+        i = on ? i : 0;
+        const Obb box{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]};
+        const int src = i & (WAVE - 1), q = i >> 6;
+        float dx = __shfl(dx0, src), dy = __shfl(dy0, src);
+        if (NL > WAVE) { const float a = __shfl(dx1, src), b = __shfl(dy1, src); dx = q == 1 ? a : dx; dy = q == 1 ? b : dy; }
+        if (NL > 2 * WAVE) { const float a = __shfl(dx2, src), b = __shfl(dy2, src); dx = q == 2 ? a : dx; dy = q == 2 ? b : dy; }
+        if (NL > 3 * WAVE) { const float a = __shfl(dx3, src), b = __shfl(dy3, src); dx = q == 3 ? a : dx; dy = q == 3 ? b : dy; }
+        const float t = shape_ray<OBJ>(box, px, py, dx, dy);
+        if (on && t < 1.0f) atomicMin(&minb[i], __float_as_uint(t));
+      }
+      row_sync<true>();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = q * WAVE + lane64;
+        if (i < NL) {
+          float best = __uint_as_float(minb[i]);
+          if (!STD) best = lidar_noise(d, ag.env, ag.slot, ag.tick, i, best);
+          row[o_oth + per_other * NO + i] = best;
+        }
+      }
+      PHASE_MARK(24);  // obs: lidar
+      return;
+    }
+  }
   if (0 < NL) cast_round(0, bd0);
   if (nt < NL) cast_round(nt, bd1);
   if (2 * nt < NL) cast_round(2 * nt, bd2);
