@@ -37,6 +37,7 @@ DEV float heading_diff(const pgd_lane& l, float px, float py, float fx, float fy
   return clipf((fx * lx + fy * ly) / (ln * fn), -1.0f, 1.0f) * 0.5f + 0.5f;
 }
 
+#define PGD_LIDAR_MINB_WORDS (6 * WAVE)  // LDS words behind `minb` of observe_agent: per-beam minima, then the rounds' start masks
 #ifndef PGD_LIDAR_INC_MIN
 #define PGD_LIDAR_INC_MIN 2  // bodies in the lidar broad phase from which a one-wave row casts incidences instead of rounds
 #endif
@@ -46,6 +47,7 @@ struct ObsLds {  // bodies inside the lidar broad phase of the observing agent, 
   int bi0[MAXV], bcnt[MAXV];  // lidar beams [bi0, bi0 + bcnt) mod num_lasers that can reach the body (conservative)
   unsigned bsec[MAXV];        // bit q: that window meets the beams [64 q, 64 q + 63] -- what one wave casts in one round
   int bslot[MAXV];            // slot of the body in its env
+  int bpref[MAXV];            // incidence form of the lidar: first incidence of the body's window
   int rank_slot[16];          // PGD_MA_OTHERS_STATE: slot of the neighbour of rank r (-1 = none) ...
   float rank_spd[16];         // ... and its speed [km/h] as the observer sees it (0 for a static finished agent)
   int n, nveh;
@@ -415,25 +417,31 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
       }
       const int pref = incl - cnt;
       const int total = __builtin_amdgcn_readlane(incl, n_u - 1);
+      const int rounds = (total + WAVE - 1) / WAVE;
+      // per round of 64 incidences a 64-bit mask of the positions at which a body's window starts (behind the minima, 8-byte
+      // aligned): the owner of an incidence is then (windows started in earlier rounds) + (starts at or below its position) - 1
+      unsigned long long* starts = reinterpret_cast<unsigned long long*>(minb + ((NL + 1) & ~1));
+      const int max_rounds = (PGD_LIDAR_MINB_WORDS - ((NL + 1) & ~1)) / 2;
+      if (rounds <= max_rounds) {
+      if (lane64 < rounds) starts[lane64] = 0ull;
+      if (lane64 < n_u) L.bpref[lane64] = pref;
       // this lane's own four beams, rotated by the heading: an incidence fetches the direction of its beam from the lane that holds it
       const float dx0 = R * (bd0.x * hx - bd0.y * hy), dy0 = R * (bd0.y * hx + bd0.x * hy);
       const float dx1 = R * (bd1.x * hx - bd1.y * hy), dy1 = R * (bd1.y * hx + bd1.x * hy);
       const float dx2 = R * (bd2.x * hx - bd2.y * hy), dy2 = R * (bd2.y * hx + bd2.x * hy);
       const float dx3 = R * (bd3.x * hx - bd3.y * hy), dy3 = R * (bd3.y * hx + bd3.x * hy);
       row_sync<true>();
-      for (int j0 = 0; j0 < total; j0 += WAVE) {
-        const int j = j0 + lane64;
-        // owner = the last body whose window starts at or before incidence j (the starts ascend with k; a scalar read per body)
-        int owner = -1, opref = 0;
-        for (int k = 0; k < n_u; ++k) {
-          const int st = __builtin_amdgcn_readlane(pref, k);
-          const bool ge = j >= st;
-          owner += ge ? 1 : 0;
-          opref = ge ? st : opref;
-        }
+      if (lane64 < n_u) atomicOr(&starts[pref >> 6], 1ull << (pref & 63));
+      row_sync<true>();
+      const int my_round = lane64 < n_u ? (pref >> 6) : 0x7fffffff;
+      for (int rd = 0; rd < rounds; ++rd) {
+        const int j = rd * WAVE + lane64;
+        const unsigned long long sm = starts[rd];
+        const int before = __popcll(__ballot(my_round < rd));
+        const int owner = before + __popcll(sm & ((2ull << lane64) - 1ull)) - 1;
         const bool on = j < total;
         const int k = on ? owner : 0;
-        int i = L.bi0[k] + (j - opref);
+        int i = L.bi0[k] + (j - L.bpref[k]);
         i -= i >= NL ? NL : 0;
         i = on ? i : 0;
         const Obb box{L.bx[k], L.by[k], L.bux[k], L.buy[k], L.bhl[k], L.bhw[k]};
@@ -457,6 +465,7 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
       }
       PHASE_MARK(24);  // obs: lidar
       return;
+      }
     }
   }
   if (0 < NL) cast_round(0, bd0);

@@ -17,17 +17,22 @@ cfg=_abi.make_config(N)
 eng = engine.Engine(cfg, mb, sb)
 eng.reset(np.arange(N)%int(os.environ.get("NMAPS","100")))
 rng=np.random.default_rng(0)
-if mode=='uniform':
+if mode in ('uniform','expert'):
     acts = torch.from_numpy(rng.uniform(-1,1,size=(64,N,1,2)).astype(np.float32)).cuda()
 else:
     a = np.zeros((64,N,1,2),np.float32); a[...,1]=1.0; a[...,0]=rng.normal(0,0.05,size=(64,N,1)); acts=torch.from_numpy(a).cuda()
 names=['load','trig+snap','policy','dynamics','crash','after_step','reward','reset','store','i_route','i_search','i_lc','i_pid','ld_stage','obs','WALL','as_route','as_getlane','as_local','as_side','o_pub','o_compact','o_state','o_neigh','o_lidar']
 out=(C.c_ulonglong*64)()
+abuf = torch.zeros((N,1,2),dtype=torch.float32,device='cuda')
+def one(k):
+    if mode=='expert' and k>0:
+        eng.lane_keep_actions(abuf,k); eng.step(abuf)
+    else: eng.step(acts[k%64])
 with torch.cuda.stream(eng.stream):
-    for k in range(1500): eng.step(acts[k%64])
+    for k in range(1500): one(k)
     L.pgd_debug_phase_cycles(eng.h, out, 1)
     for rep in range(3):
-        for k in range(300): eng.step(acts[k%64])
+        for k in range(300): one(1+k)
         L.pgd_debug_phase_cycles(eng.h, out, 1)
         tot=sum(out[:15])+sum(out[16:25]); nb=300*N
         print(mode, 'cycles/block:', {n:int(out[i]/nb) for i,n in enumerate(names)}, 'total', int(tot/nb), 'wall_ticks(100MHz)/block', round(out[15]/nb,1), '=> us', round(out[15]/nb/100,2), 'MHz', round(tot/max(out[15],1)*100))
