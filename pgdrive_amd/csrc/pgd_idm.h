@@ -15,20 +15,14 @@ struct Fbo {
   bool exist[3];
 };
 
-// (road, index, n_succ, pad = lane count of the road) of a lane: the four int16 behind the geometry, one 8-byte read
-DEV uint2 lane_quad(const MapView& mv, int lane) { return *reinterpret_cast<const uint2*>(&mv.lanes[lane].road); }
-DEV int quad_road(uint2 q) { return (int)(short)(q.x & 0xffffu); }
-DEV int quad_index(uint2 q) { return (int)(short)(q.x >> 16); }
-DEV int quad_count(uint2 q) { return (int)(short)(q.y >> 16); }
-
-// `quad` = lane_quad of `lane`, read by the caller together with its other lane reads (one dependent level less here).
 // own_*: the vehicle's coordinates on `lane` and the lane heading one metre ahead, by-products of the search on the own lane
 // (target 1), handed to every sub-lane: the steering controller needs exactly these when it steers along `lane`.
+// `idx` / `n_road`: index of `lane` in its road and that road's lane count (the lanes of a road are consecutive); only read when
+// `with_ref` holds -- the caller then has both from the vehicle's route context (no lane-table read)
 DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int base, int V, int self, unsigned long long objs,
-                         int lane, uint2 quad, float max_dist, bool with_ref, Fbo& r, float& own_lon, float& own_lat, float& own_head) {
-  const int idx = quad_index(quad);  // the lanes of a road are consecutive; the device copy of the lane carries its road's lane count
+                         int lane, int idx, int n_road, float max_dist, bool with_ref, Fbo& r, float& own_lon, float& own_lat, float& own_head) {
   const int l0 = (with_ref && idx > 0) ? lane - 1 : -1;
-  const int l2 = (with_ref && idx + 1 < quad_count(quad)) ? lane + 1 : -1;
+  const int l2 = (with_ref && idx + 1 < n_road) ? lane + 1 : -1;
   const float px = S.x[base + self], py = S.y[base + self];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -126,19 +120,19 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
   const float NORMAL = 30.0f, CREEP = 5.0f, SAFE = 15.0f, MAXD = 30.0f;
   const int vlane = r.lane;
   int rt = r.rlane;
-  // the current road and its lanes come from the record's route context; the two lane reads are independent
-  const int cur_road = r.road_cur;
-  const uint2 q_vl = lane_quad(mv, vlane), q_r0 = lane_quad(mv, rt < 0 ? vlane : rt);  // independent reads, one round trip
-  const int rt0 = rt;
-  const int vl_road = quad_road(q_vl);
-  const int rt_road = quad_road(q_r0);
+  // "the lane lies on the current road": the lanes of a road are consecutive ids, and the record's route context carries the first
+  // lane and the lane count of the current road -- a range test instead of reading the lanes' road ids from the lane table (two
+  // dependent global reads at the head of every IDM decision; with no current road the count is 0 and the test fails, as the
+  // comparison of road ids did)
   struct { int first_lane, n_lanes; } const CR{r.cur_first, r.cur_n};
+  const bool vl_on_cur = vlane >= CR.first_lane && vlane < CR.first_lane + CR.n_lanes;
+  const bool rt_on_cur = rt >= CR.first_lane && rt < CR.first_lane + CR.n_lanes;
   bool success;
   // move_to_next_road (idm_policy.py:222-242)
   if (rt < 0) {
     rt = vlane;
-    success = vl_road == cur_road;
-  } else if (rt_road != cur_road) {
+    success = vl_on_cur;
+  } else if (!rt_on_cur) {
     // the lowest lane of the current road that follows the routing lane (8 packed successor ids, unused = -1)
     const int4 rs = *reinterpret_cast<const int4*>(mv.lanes[rt].succ);
     const int first = CR.first_lane, nl = CR.n_lanes;
@@ -152,14 +146,14 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
     }
     success = best != 0x7fff;
     if (success) rt = first + best;
-  } else if (vl_road == cur_road && rt != vlane) {
+  } else if (vl_on_cur && rt != vlane) {
     rt = vlane;
     r.timer = (pgd_rng(d.cfg.seed, (uint32_t)(d.cfg.env_base + e), (uint32_t)s, step_count) % 25u);
     success = true;
   } else success = true;
   // is the (new) routing lane on the current road?  first case: the vehicle lane's road; second: only a found lane of
   // CR; third and fourth: established by the branch conditions
-  const bool in_cur = r.rlane < 0 ? (vl_road == cur_road) : (rt_road != cur_road ? success : true);
+  const bool in_cur = r.rlane < 0 ? vl_on_cur : (!rt_on_cur ? success : true);
   r.rlane = rt;
 
   // Lidar.get_surrounding_objects (lidar.py:109-124)
@@ -199,19 +193,18 @@ DEV void idm_act(const PgdDev& d, const MapView& mv, const Grp& g, const pgd_spa
   // not in ref lanes although move_to_next_road succeeded) falls back to "no front object, distance 5"
   const bool search = !success || in_cur;
   Fbo fb;
-  // the routing lane is almost always the old one or the vehicle's lane: its index / lane count are then already here
-  const uint2 q_rt = rt == vlane ? q_vl : (rt == rt0 ? q_r0 : lane_quad(mv, rt));
   float own_lon = 0.0f, own_lat = 0.0f, own_head = 0.0f;
 #ifdef PGD_EXITAT
   if (PGD_DBG_SKIP(1)) { for (int i = 0; i < 3; ++i) { fb.front[i] = fb.back[i] = -1; fb.fd[i] = fb.bd[i] = MAXD; fb.exist[i] = true; } } else
 #endif
-  if (search) find_front_back(mv, g, S, base, V, s, objs, rt, q_rt, MAXD, success, fb, own_lon, own_lat, own_head);
+  // (with the reference lanes -- success -- the search only runs when the routing lane is on the current road: its index there)
+  if (search) find_front_back(mv, g, S, base, V, s, objs, rt, rt - CR.first_lane, CR.n_lanes, MAXD, success, fb, own_lon, own_lat, own_head);
   PHASE_MARK(10);  // idm: front/back search
 #ifdef PGD_EXITAT
   if (PGD_DBG_SKIP(2)) { } else
 #endif
   if (success && in_cur) {
-    int idx = quad_index(q_rt);
+    int idx = rt - CR.first_lane;
     int n_cur = CR.n_lanes;
     int avail_lo = 0, avail_hi = n_cur - 1;
     bool decided = false;
