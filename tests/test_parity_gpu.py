@@ -969,6 +969,90 @@ def test_full_size_properties():
         e.close()
 
 
+def test_throughput_mode_at_32768_envs_properties():
+    """BASELINE config 4's per-node size on one GPU: 32768 envs x 17 slots x 240 beams, where pgd_create picks the throughput mode
+    by itself (three whole envs per wave, one vehicle per lane, rows appended to the launch) -- the instantiation bench.py's
+    `c3_32768` row times.  Size-independent properties: observations finite and inside [0, 1]; done <-> terminal flags <->
+    restart consistent, terminal rewards exact; envs do not influence each other and the mode does not change results -- the
+    first 96 envs (whole waves) and 61 envs starting at an odd offset equal, flag for flag, small engines in the DEFAULT mode
+    (one env per wave) fed the same scenarios, actions and global env indices (rows to the contraction of multiply-adds);
+    the run is reproducible bit for bit; a checkpoint resumes bit-identically; grouped stepping (pgd_set_groups on a
+    power-of-two size leaves throughput mode: ADVICE r03) gives the same rows as whole-engine steps of a default-mode engine."""
+    import torch
+    from pgdrive_amd import bank, mapdata, scenario
+    from pgdrive_amd.engine import Engine
+    descs = bank.get_descriptions(range(1000, 1100))
+    mb = mapdata.MapBank(descs)
+    sb = scenario.ScenarioBank(descs, [d["seed"] for d in descs], num_agents=1, num_traffic=16)
+    N = 32768
+
+    def make(n_envs, base=0):
+        return Engine(_abi.make_config(n_envs, num_agents=1, num_traffic=16, num_lasers=240, auto_reset=1, resample_scenario=1,
+                                       seed=77, env_base=base), mb, sb)
+
+    big, twin = make(N), make(N)
+    windows = [(0, 96), (12345, 61)]
+    small = [make(n, base=lo) for lo, n in windows]
+    ids = (np.arange(N) * 7) % 100
+    big.reset(ids); twin.reset(ids)
+    for (lo, n), e in zip(windows, small):
+        e.reset(ids[lo:lo + n])
+    rng = np.random.default_rng(14)
+    n_done = 0
+    worst = 0.0
+    ckpt, tail = None, []
+    for t in range(90):
+        a = rng.uniform(-1, 1, size=(N, 1, 2)).astype(np.float32)
+        a[:, 0, 1] = np.abs(a[:, 0, 1]) * 0.8
+        act = torch.from_numpy(a).to(big.device)
+        o1, r1, d1, f1 = [x.clone() for x in big.step(act)]
+        o3, r3, d3, f3 = twin.step(act)
+        big.sync(); twin.sync()
+        if t == 0:
+            assert "throughput mode" in big.describe_step() and "throughput mode" not in small[0].describe_step()
+        assert torch.isfinite(o1).all() and float(o1.min()) >= 0.0 and float(o1.max()) <= 1.0
+        assert torch.equal(o1, o3) and torch.equal(r1, r3) and torch.equal(d1, d3) and torch.equal(f1, f3)
+        for (lo, n), e in zip(windows, small):
+            o2, r2, d2, f2 = e.step(act[lo:lo + n].contiguous())
+            e.sync()
+            assert torch.equal(d1[lo:lo + n], d2) and torch.equal(f1[lo:lo + n], f2), "flags differ from the default mode at step %d" % t
+            worst = max(worst, float((o1[lo:lo + n] - o2).abs().max()), float((r1[lo:lo + n] - r2).abs().max()) * 0.05)
+        fl = f1.cpu().numpy().astype(np.uint32)[:, 0]
+        dn = d1.cpu().numpy()[:, 0]
+        term = (fl & (_abi.F_ARRIVE | _abi.F_OUT_OF_ROAD | _abi.F_CRASH_VEHICLE | _abi.F_MAX_STEP)) != 0
+        assert ((dn == 1) == term).all() and (((fl & _abi.F_RESET) != 0) == (dn == 1)).all()
+        rw = r1.cpu().numpy()[:, 0]
+        assert (rw[(fl & _abi.F_ARRIVE) != 0] == 10.0).all()
+        assert (rw[((fl & _abi.F_OUT_OF_ROAD) != 0) & ((fl & _abi.F_ARRIVE) == 0)] == -5.0).all()
+        n_done += int(dn.sum())
+        if t == 50:
+            ckpt = big.get_state()
+        if t > 50:
+            tail.append((act, o1))
+    assert n_done > 3000 and worst < 2e-6, (n_done, worst)
+    resumed = make(N)
+    resumed.reset(ids)
+    resumed.set_state(*ckpt)
+    for act, o_ref in tail:
+        o4 = resumed.step(act)[0]
+        resumed.sync()
+        assert torch.equal(o4, o_ref)
+    # grouped stepping: 32768 / 2 is not a multiple of three envs per wave -> the engine leaves throughput mode (it used to refuse)
+    twin.set_groups(2)
+    a = rng.uniform(-1, 1, size=(N, 1, 2)).astype(np.float32)
+    act = torch.from_numpy(a).to(big.device)
+    for g in range(2):
+        twin.step_group(g, act)
+    for g in range(2):
+        twin.group_sync(g)
+    o_ref, r_ref, d_ref, f_ref = big.step(act)
+    big.sync()
+    assert "throughput" not in twin.describe_step()
+    assert torch.equal(twin.done, d_ref) and torch.equal(twin.flags, f_ref) and float((twin.obs - o_ref).abs().max()) < 2e-6
+    for e in [big, twin, resumed] + small:
+        e.close()
+
+
 @pytest.mark.parametrize("num_traffic", [16, 24, 40])  # 3, 2, 1 sub-lanes per vehicle slot
 def test_record_cache_matches_plain_records(descs, num_traffic):
     """The step kernel skips the write of a record that did not change and reads never-written slots from the scenario's
@@ -1342,3 +1426,77 @@ def test_fused_observation_equals_stand_alone_kernels(descs, case):
     print("fused vs stand-alone observation", case, "worst", worst, "grazing", grazing, "of", beams, "episodes", n_done)
     assert worst < 1e-6 and grazing <= 1e-5 * beams + 2 and n_done > 10
     eng_a.close(); eng_b.close()
+
+
+def test_free_running_timed_path_through_episode_ends(descs):
+    """The path bench.py times, held to the oracle directly (not through self-comparisons): engine defaults -- contact / trigger
+    hints carried from step to step, the reset-image mask, auto-reset from the reset image with a re-drawn scenario
+    (resample_scenario = 1) -- and NO set_state between the steps (teacher forcing resets the hints and the mask).  256 envs x 600
+    steps of driving actions, the same float32 stream on both sides.  Per env the two runs are compared until the env's first
+    DISCRETE divergence (done / flags differ: a contact or a line reached one step apart between fp32 and fp64 -- from there on
+    the two envs play different episodes, also in the reference's own fp64 if a coordinate moves by one ulp):
+      * episode ends in the common prefix agree on the step and on the whole flag set, and they are most of all ends;
+      * a restart is exact: the step that reports F_RESET hands out the first observation of the re-drawn scenario, equal on
+        both sides to the observation tolerance -- no divergence begins at a reset;
+      * observations in the common prefix stay within the teacher-forced tolerance while the env's traffic is parked and
+        within a loose bound after it drives (the IDM traffic is a chaotic closed loop: DESIGN.md section 7)."""
+    n_envs, n_steps = 256, 600
+    torch, eng, ora, cfg = _engines(descs, n_envs, seed=11, resample_scenario=1, auto_reset=1)
+    ids = np.arange(n_envs) % 8
+    o0 = ora.reset(ids)
+    g0 = eng.reset(ids).cpu().numpy()
+    assert np.abs(g0 - o0).max() < OBS_TOL
+    rng = np.random.default_rng(21)
+    alive = np.ones(n_envs, dtype=bool)          # env still in its common prefix
+    ends_agree = ends_oracle = ends_engine_only = 0
+    reset_rows = reset_rows_bad = 0
+    div_at_reset = 0
+    worst_parked = worst_driving = 0.0
+    div_bits = 0
+    SI = _abi.SI
+    for t in range(n_steps):
+        act = util.driving_actions(rng, n_envs)
+        if t % 7 == 0:
+            act[::5, 0, 0] += 0.5  # some envs steer off the road: out-of-road ends next to crashes and arrivals
+        o_obs, o_rew, o_done, o_flags = ora.step(act)
+        g_obs, g_rew, g_done, g_flags = eng.step(torch.from_numpy(act).to(eng.device))
+        eng.sync()
+        g_obs = g_obs.cpu().numpy().astype(np.float64)[:, 0]
+        g_done, g_flags = g_done.cpu().numpy()[:, 0], g_flags.cpu().numpy().astype(np.uint32)[:, 0]
+        o_done, o_flags, o_obs = o_done[:, 0], o_flags[:, 0], o_obs[:, 0]
+        same = (g_done == o_done) & (g_flags == o_flags)
+        # episode ends seen in the common prefix
+        ends_oracle += int((alive & (o_done != 0)).sum())
+        ends_agree += int((alive & (o_done != 0) & same).sum())
+        ends_engine_only += int((alive & (g_done != 0) & (o_done == 0)).sum())
+        # rows where both restarted in agreement: the first observation of the new episode
+        both_reset = alive & same & ((o_flags & _abi.F_RESET) != 0)
+        if both_reset.any():
+            d = np.abs(g_obs[both_reset] - o_obs[both_reset]).max(axis=1)
+            reset_rows += int(both_reset.sum())
+            reset_rows_bad += int((d > OBS_TOL).sum())
+        newly = alive & ~same
+        if newly.any():
+            div_bits |= int(np.bitwise_or.reduce((g_flags ^ o_flags)[newly]))
+        alive &= same
+        # numeric drift inside the common prefix
+        if alive.any():
+            _, gi, _ = eng.get_state()
+            driving = (gi[SI["STATUS"]][:, 1:] == _abi.ST_ACTIVE).any(axis=1)
+            dd = np.abs(g_obs - o_obs).max(axis=1)
+            if (alive & ~driving).any():
+                worst_parked = max(worst_parked, float(dd[alive & ~driving].max()))
+            if (alive & driving).any():
+                worst_driving = max(worst_driving, float(np.quantile(dd[alive & driving], 0.99)))
+    print("free-running timed path: %d episode ends in the common prefixes, %d agree on step and flags (%.1f %%), %d ended on the "
+          "engine only; %d of %d envs still in their common prefix after %d steps (divergence bits 0x%x); %d restarts compared, %d with "
+          "a first observation off by more than %.1e; obs drift: parked traffic %.2e, driving traffic (99th percentile) %.2e"
+          % (ends_oracle, ends_agree, 100.0 * ends_agree / max(1, ends_oracle), ends_engine_only, int(alive.sum()), n_envs, n_steps,
+             div_bits, reset_rows, reset_rows_bad, OBS_TOL, worst_parked, worst_driving))
+    assert ends_oracle >= 300, "the action stream must end at least 300 episodes inside the common prefixes"
+    assert ends_agree >= 0.95 * ends_oracle and ends_engine_only <= 0.05 * ends_oracle
+    assert reset_rows >= 250 and reset_rows_bad == 0, "a restart must reproduce the oracle's first observation"
+    assert worst_parked < 4 * OBS_TOL  # the ego alone: free-running fp32 vs fp64 over an episode
+    assert worst_driving < 5e-2
+    assert alive.mean() > 0.5
+    eng.close()
