@@ -229,7 +229,7 @@ ROWS = [
     ("c3_expert_respawn", dict(actions="expert", traffic_mode="respawn")),
     ("c5_8x240", dict(workload="c5", agents=8, lasers=240, warmup=1000, steps=1536)),
     ("c5_8x72", dict(workload="c5", agents=8, lasers=72, warmup=1000, steps=1536)),
-    ("c5_40x72", dict(workload="c5", agents=40, lasers=72, warmup=1000, steps=512)),
+    ("c5_40x72", dict(workload="c5", agents=40, lasers=72, warmup=1000, steps=2048)),
     ("c3_32768", dict(envs=32768, warmup=1500, steps=512)),
 ]
 
@@ -424,13 +424,21 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
         spd = float(np.abs(f_[abi.SF["SPEED"]][:, 0]).mean() * 3.6)
         work = dict(driving_traffic_mean=float(np.mean(act_n)), envs_with_traffic_frac=float(np.mean(with_t)),
                     episode_step_mean=float(np.mean(ep)), ego_speed_kmh_mean=spd)
-    elif args.workload == "c5":
+    elif args.workload == "c5":  # (the agent population swings with the 1000-step agent horizon: five snapshots, 100 steps apart)
         from pgdrive_amd import _abi as abi
-        fence()
-        f_, i_, ei_ = eng.get_state()
-        st_ = i_[abi.SI["STATUS"]][:, :A]
-        work = dict(active_agents_mean=float((st_ == abi.ST_ACTIVE).sum(axis=1).mean()),
-                    present_agents_mean=float(((st_ == abi.ST_ACTIVE) | (st_ == abi.ST_DYING)).sum(axis=1).mean()))
+        act_a, pres_a = [], []
+        with torch.cuda.stream(eng.stream):
+            for snap in range(5):
+                for k in range(100 if snap else 0):
+                    step_replica(counter)
+                    counter += 1
+                fence()
+                f_, i_, ei_ = eng.get_state()
+                st_ = i_[abi.SI["STATUS"]][:, :A]
+                act_a.append(float((st_ == abi.ST_ACTIVE).sum(axis=1).mean()))
+                pres_a.append(float(((st_ == abi.ST_ACTIVE) | (st_ == abi.ST_DYING)).sum(axis=1).mean()))
+        work = dict(active_agents_mean=float(np.mean(act_a)), present_agents_mean=float(np.mean(pres_a)),
+                    active_agents_snapshots=[round(v, 2) for v in act_a])
 
     ranks_ran = world
     rccl_ranks = None

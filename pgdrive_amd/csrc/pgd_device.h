@@ -56,6 +56,10 @@ struct PgdDev {
   int dbg_exit;  // exit-profile builds only (PGD_EXITAT)
   int unit_off;  // first block unit of this launch (pgd_step_group); 0 for a whole-engine step
   int obs_g;     // multi-agent k_step with the fused observation: observers per pass (what fits the step's LDS)
+  // multi-agent engines: bit a of rowz[e] = row a of env e in the caller's observation buffer (the one the host tracks, see
+  // obs_rows_known) was written as zeros by an earlier call and has not been due since: not written again (40 agent slots, 6 - 30
+  // alive: the zero rows were 46 MB of stores per step at 4096 envs).  Null: every row that is not due is zero-filled.
+  unsigned long long* rowz;
   uint8_t* bev_fill;  // [N] or null: the env was reset -- the top-down observation refills its history (pgd_topdown.h)
 };
 

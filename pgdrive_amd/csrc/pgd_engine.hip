@@ -101,6 +101,9 @@ DEV LaneMap lane_map(const PgdDev& d, int unit, int n_units) {
 
 
 #define FUSE_MAX_AGENTS 8
+#ifndef PGD_LINETEST_WAVE_MAX
+#define PGD_LINETEST_WAVE_MAX 8  // multi-agent line / sidewalk test with fewer than four lanes per agent: up to this many agents one by one by the whole wave
+#endif
 // first 64 bytes of a spawn record (everything but the route arrays) into a local copy; the copy is only ever read by field, so it
 // lives in registers and the fields nobody reads cost nothing
 DEV void spawn_head_load(const pgd_spawn* sp, pgd_spawn& out) {
@@ -427,6 +430,67 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
 #endif
   if (near_env) {
     const int my_kind = (OBJ && valid) ? s_kind[slot] : PGD_OBJ_VEHICLE;
+    // pose-by-pose test of body `bs` against agent `as` (slots of the snapshot); everything comes from LDS
+    auto pair_touch = [&](const int bs, const int as, const Obb& me, const float my_trav, const Obb& ag, const float ag_trav) {
+      bool hit = shape_overlap<OBJ>(ag, me);
+      for (int k = 0; k < n_mid && !hit; ++k) {
+        Obb ak = ag, mk = me;
+        if (ag_trav > 0.0f) {  // heading = motion direction rotated back by the slip angle (unit up to rounding)
+          const float4 q = SUBP.p[k][as]; const float2 b = SUBP.beta[as];
+          ak.cx = q.x; ak.cy = q.y; ak.ux = q.z * b.x + q.w * b.y; ak.uy = q.w * b.x - q.z * b.y;
+        }
+        if (my_trav > 0.0f) {
+          const float4 q = SUBP.p[k][bs]; const float2 b = SUBP.beta[bs];
+          mk.cx = q.x; mk.cy = q.y; mk.ux = q.z * b.x + q.w * b.y; mk.uy = q.w * b.x - q.z * b.y;
+        }
+        hit = shape_overlap<OBJ>(ak, mk);
+      }
+      return hit;
+    };
+    // Multi-agent engines with more agent slots than sub-lanes per slot (a lane would walk several agents; no traffic objects):
+    // only an agent that drove reads its contact bits, so the agents to test against are the ACTIVE ones -- a ballot -- and the
+    // work is laid out by PAIRS.  As a loop over agents inside every body lane an iteration costs the whole wave the pose-by-pose
+    // test (five separating-axis tests) as soon as ONE lane is within reach of that agent: with 30 of 40 agents alive, bunched
+    // around the spawn places, that was 77 k cycles of a 139 k-cycle step (profiles/r04_notes.md).  Now: (1) every body lane
+    // walks the agents with the reach test alone and notes the ones within reach; (2) the (body, agent) pairs within reach go
+    // into a list in LDS; (3) the wave takes the list 64 pairs at a time.  Same pairs pass the same reach test, same verdicts.
+    // Chunks of 12 agents bound the list (64 bodies x 12); it lives where the IDM search keeps its lane data (no IDM traffic here).
+    const bool by_mask = ONE_ENV && MARL && !OBJ && A > g.SUB;
+    if (by_mask) {
+      unsigned short* plist = reinterpret_cast<unsigned short*>(&S.lon[0]);  // <= 768 pairs: (body << 8) | agent
+      const bool body = valid && leader && S.present[slot] != 0;
+      unsigned long long agents_todo = __ballot(leader && valid && s < A && acting);
+      const Obb me = snap_obb(S, slot);
+      const float my_trav = sub_ok ? SUBP.trav[slot] : 0.0f;
+      const float my_rad = me.hl + (me.hw < 0.0f ? 0.0f : me.hw);
+      while (agents_todo != 0ull) {
+        unsigned long long within = 0ull;  // agents of this chunk within reach of my body
+        if (lane == 0) s_aux = 0;  // (the parking pool is loaded into s_aux later in the step)
+        for (int q = 0; q < 12 && agents_todo != 0ull; ++q) {
+          const int a = __builtin_ctzll(agents_todo) / g.SUB;  // the agent's first lane -> its slot (one env per wave)
+          agents_todo &= agents_todo - 1ull;
+          const Obb ag = snap_obb(S, a);  // (the same address in every lane: broadcast reads)
+          const float ag_trav = sub_ok ? SUBP.trav[a] : 0.0f;
+          const float reach = my_rad + ag.hl + ag.hw + my_trav + ag_trav + 0.01f;
+          const float ddx = ag.cx - me.cx, ddy = ag.cy - me.cy;
+          if (body && a != s && !(ddx * ddx + ddy * ddy > reach * reach)) within |= 1ull << a;
+        }
+        step_sync();
+        const int mine = __popcll(within);
+        int at = mine > 0 ? atomicAdd(&s_aux, mine) : 0;
+        for (unsigned long long w = within; w != 0ull; w &= w - 1ull) plist[at++] = (unsigned short)((slot << 8) | __builtin_ctzll(w));
+        step_sync();
+        const int n_pairs = s_aux;
+        for (int p0 = 0; p0 < n_pairs; p0 += WAVE) {
+          const int p = p0 + lane;
+          if (p < n_pairs) {
+            const int pr = plist[p], bs = pr >> 8, as = pr & 0xff;
+            if (pair_touch(bs, as, snap_obb(S, bs), sub_ok ? SUBP.trav[bs] : 0.0f, snap_obb(S, as), sub_ok ? SUBP.trav[as] : 0.0f)) s_hit[as] = 1;
+          }
+        }
+        step_sync();
+      }
+    } else
     if (valid && S.present[slot]) {  // a vehicle's sub-lanes split the agents; object sub-lanes all keep their copy of the bit
       const Obb me = snap_obb(S, slot);
       const float my_trav = sub_ok ? SUBP.trav[slot] : 0.0f;
@@ -442,20 +506,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
         const float reach = my_rad + ag.hl + ag.hw + my_trav + ag_trav + 0.01f;
         const float ddx = ag.cx - me.cx, ddy = ag.cy - me.cy;
         if (ddx * ddx + ddy * ddy > reach * reach) continue;
-        bool hit = shape_overlap<OBJ>(ag, me);
-        for (int k = 0; k < n_mid && !hit; ++k) {
-          Obb ak = ag, mk = me;
-          if (ag_trav > 0.0f) {  // heading = motion direction rotated back by the slip angle (unit up to rounding)
-            const float4 q = SUBP.p[k][base + a]; const float2 b = SUBP.beta[base + a];
-            ak.cx = q.x; ak.cy = q.y; ak.ux = q.z * b.x + q.w * b.y; ak.uy = q.w * b.x - q.z * b.y;
-          }
-          if (my_trav > 0.0f) {
-            const float4 q = SUBP.p[k][slot]; const float2 b = SUBP.beta[slot];
-            mk.cx = q.x; mk.cy = q.y; mk.ux = q.z * b.x + q.w * b.y; mk.uy = q.w * b.x - q.z * b.y;
-          }
-          hit = shape_overlap<OBJ>(ak, mk);
-        }
-        if (!hit) continue;
+        if (!pair_touch(slot, base + a, me, my_trav, ag, ag_trav)) continue;
         touched = true;
         if (!OBJ) s_hit[base + a] = 1;
         else if ((leader || split) && live) atomicOr(&s_hit[base + a], my_kind == PGD_OBJ_VEHICLE ? 1 : (my_kind == PGD_OBJ_BUILDING ? 4 : 2));
@@ -488,8 +539,24 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   int trig_next = 0;
   if (ONE_ENV && !MARL && A == 1 && valid && s < A)
     trig_next = (r.status == ST_ACTIVE && next_trigger_road >= 0 && ctx.lane_road == next_trigger_road) ? 2 : 1;
-  if (one_env && A > 1 && acting && s < A && !ctx.clear)
-    r.vflags |= (int)state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * SPV.length, 0.5f * SPV.width});
+  if (one_env && A > 1) {
+    const bool need = acting && s < A && !ctx.clear;
+    const unsigned long long need_m = __ballot(need && leader);
+    if (d.sub > 3 || __popcll(need_m) > PGD_LINETEST_WAVE_MAX) {
+      // every agent's own lanes stride through the boxes under its car, all agents at once
+      if (need) r.vflags |= (int)state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * SPV.length, 0.5f * SPV.width});
+    } else {
+      // many slots with one to three lanes each (40 agents: one) and few of them to test: a lane alone would walk the 100 - 300
+      // boxes under its car (a roundabout's cells are full of short line segments) one by one while most of the wave idles.  The
+      // whole wave takes the agents one after the other instead -- the same boxes, the same flags (state_check_wave, as for the
+      // single agent); with many agents to test the parallel form above wins again (wave-uniform switch)
+      for (unsigned long long todo = need_m; todo != 0ull; todo &= todo - 1ull) {
+        const int a = __builtin_ctzll(todo) / d.sub;
+        const unsigned fl = state_check_wave(mv, snap_obb(S, a));
+        if (valid && s == a) r.vflags |= (int)fl;
+      }
+    }
+  }
   PHASE_MARK(25);  // after_step: per-vehicle part
   if (one_env && A == 1) {  // line / sidewalk test of the agent by the whole wave (base_vehicle.py:615-644)
     // clear: provably no contact (after_step); the agent's lanes tell the wave by ballot
@@ -1187,7 +1254,20 @@ struct pgd_engine {
   bool no_fix;       // PGD_NO_FIX: never pick the kernel specialised for the default configuration (A/B, debugging)
   bool no_fuse;      // PGD_NO_FUSE was set when the engine was created (debug: always run the stand-alone k_observe)
   bool prof_fused;
+  unsigned long long* rowz;  // multi-agent engines: PgdDev::rowz ...
+  const float* rowz_obs;     // ... describes THIS observation buffer (pointer and row stride of the last call that wrote rows); a
+  int rowz_stride;           // call with another buffer forgets what is known (a caller that alternates buffers pays the zero rows)
 };
+
+// the caller's observation buffer of this call: the zero-row marks hold for one buffer at a time (multi-agent engines)
+static int obs_rows_known(pgd_engine* h, const float* d_obs, int ostride, hipStream_t stream, bool env_rows) {
+  if (!h->rowz || !d_obs) return PGD_OK;
+  if (env_rows && d_obs == h->rowz_obs && ostride == h->rowz_stride) return PGD_OK;
+  HIPCHK(hipMemsetAsync(h->rowz, 0, sizeof(unsigned long long) * (size_t)h->d.N, stream));
+  h->rowz_obs = env_rows ? d_obs : nullptr;  // rows written by another kernel (k_observe): nothing is known afterwards
+  h->rowz_stride = ostride;
+  return PGD_OK;
+}
 
 static void topdown_free(pgd_engine* h);
 
@@ -1313,6 +1393,11 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   HIPCHK(hipMalloc(&h->d_ids, sizeof(int32_t) * (size_t)h->d.N * 2));
   HIPCHK(hipMemsetAsync(h->d.rec, 0, sizeof(VehRec) * nv, h->stream));
   HIPCHK(hipMemsetAsync(h->d.ei, 0, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI, h->stream));
+  if (marl) {
+    HIPCHK(hipMalloc(&h->rowz, sizeof(unsigned long long) * (size_t)h->d.N));
+    HIPCHK(hipMemsetAsync(h->rowz, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
+    h->d.rowz = h->rowz;
+  }
   HIPCHK(hipMalloc(&h->d.env_map, sizeof(pgd_map) * (size_t)h->d.N));
   HIPCHK(hipMemsetAsync(h->d.env_map, 0, sizeof(pgd_map) * (size_t)h->d.N, h->stream));
   // never-written slots are read from the scenario's reset image (cache resident, shared by every env of the scenario) instead
@@ -1522,6 +1607,7 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
     while (G > 1 && (size_t)nw * observe_env_words(G, NL, V) * 4 + oth_bytes > 49152) --G;
     const size_t dyn = (size_t)nw * observe_env_words(G, NL, V) * 4 + oth_bytes;
     if (dyn <= 49152) {
+      { int rc = obs_rows_known(h, d_obs, D.ostride, stream, true); if (rc) return rc; }
       const bool fix = !h->no_fix && !h->has_objects && fix_config_matches(D, true, FIXK_MARL);
       void (*ke)(PgdDev, float*, const uint32_t*, int) = four ? k_observe_env<4> : k_observe_env<1>;
       if (fix) ke = four ? k_observe_env<4, true> : k_observe_env<1, true>;
@@ -1530,6 +1616,7 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
       return PGD_OK;
     }
   }
+  { int rc = obs_rows_known(h, d_obs, D.ostride, stream, false); if (rc) return rc; }
   const bool wide = h->d.cfg.num_lasers > 128;  // up to 128 beams one wave does it in two rounds: 4x fewer waves than 256-thread blocks
   void (*kern)(PgdDev, float*, const uint32_t*, int) =
       wide ? (oth ? k_observe<256, true> : k_observe<256, false>) : (oth ? k_observe<64, true> : k_observe<64, false>);
@@ -1596,7 +1683,8 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   // (all rows of the env) when its per-beam minima fit the step's LDS -- one launch per step either way
   const bool oth_rows = (h->d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && h->d.cfg.num_others > 0;
   const bool fuse_env = d_obs && marl && h->d.epw == 1 && h->d.A > 1 && !oth_rows && !h->no_fuse && !h->row_observe &&
-                        h->d.A < 4 * (WAVE / h->d.V) &&  // else the four-wave k_observe_env is the faster one
+                        h->d.A < 4 * (WAVE / h->d.V) &&  // else the four-wave k_observe_env is the faster one (measured again with the
+                                                          // compacted lists, round 4: 40 slots with 30 agents alive 146 us fused, 58 + 67 apart)
                         observe_env_words(1, h->d.cfg.num_lasers, h->d.V) <= STEP_MINB_WORDS;  // at least one observer per round
   const bool fuse_state = d_obs && !marl && h->d.epw > 1 && h->d.cfg.num_lasers <= 0 && !h->no_fuse;  // state-only rows, several envs per wave
   const bool fuse_pack = d_obs && h->d.pack_obs;  // throughput mode: the rows of the wave's envs appended to k_step
@@ -1615,6 +1703,7 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   const bool timing = h->step_timing && !prof && !grouped && group < 0;
   if (prof || timing || g_open) HIPCHK(hipEventRecord((prof || g_open) ? pe[0] : h->ev0, h->stream));
   int blocks = (n_env_launch + h->d.epw - 1) / h->d.epw;
+  if (fuse_env) { int rc = obs_rows_known(h, d_obs, ostride, stream, true); if (rc) return rc; }
   if (marl && h->d.epw != 1) return PGD_ERR_STATE;  // the multi-agent tail needs the env in one wave (V >= 33 or SUB split)
   void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*, PgdCold) = k_step<false, false, false>;
   const char* kname = h->d.pack_obs ? "k_step: whole envs side by side in a wave, one vehicle per lane (throughput mode)"
@@ -1962,7 +2051,7 @@ int pgd_sync(pgd_handle h) {
 int pgd_destroy(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   (void)hipStreamSynchronize(h->stream);
-  void* bufs[] = {h->d.rec, h->d.ei, h->d.imask, h->d.env_map, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
+  void* bufs[] = {h->rowz, h->d.rec, h->d.ei, h->d.imask, h->d.env_map, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
                   h->cell_items, h->cell_boxes, h->cell_ext, h->lane_nav, h->scen_map, h->scen, h->spawns, h->spawn_hv, h->beam, h->reset_img, h->respawn_img};
   for (void* b : bufs)
     if (b) (void)hipFree(b);

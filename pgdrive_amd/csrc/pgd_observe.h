@@ -503,6 +503,7 @@ struct ObsEnvLds {
   uint32_t bFL[WAVE];  // step flags of agent slot o (0 beyond A or without flags)
   float aMS[WAVE];     // observer: max_speed of its vehicle
   int aWant[WAVE];
+  unsigned char wList[WAVE], bList[WAVE];  // the observers that get a row / the bodies that can be seen by one, ascending
   float pDist[NW][WAVE];
   int pPref[NW][WAVE + 1], pI0[NW][WAVE];
   unsigned long long pMask[NW][32];  // per round of 64 incidences: the positions at which a pair's window starts
@@ -539,6 +540,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   const int LPA = WAVE * NW / A;  // lanes per agent in the state phase (A <= WAVE)
   const int sa = FUSED ? in_wave->slot : tid / LPA, st = FUSED ? in_wave->sub : tid - (tid / LPA) * LPA;
   const bool s_on = sa < A;
+  const unsigned long long known_zero = d.rowz ? d.rowz[e] : 0ull;  // (read by every wave before the first barrier, written behind it)
   Veh me;
   Veh body;  // only the first 64 bytes are filled
   uint32_t f_me, f_body = 0u;
@@ -588,8 +590,6 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   if (s_on && st == 0) { aMS[sa] = msp.max_speed; aWant[sa] = want ? 1 : 0; }
   // ---- state blocks: every agent at once, LPA lanes each
   float* row = obs + (size_t)e * d.ostride + (size_t)(s_on ? sa : 0) * D;
-  if (s_on && !want)
-    for (int k = st; k < D; k += LPA) row[k] = 0.0f;
   if (want) {
     AgentView ag;
     ag.x = me.x; ag.y = me.y; ag.th = me.th;
@@ -610,23 +610,47 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
       t2[1] = (in_toll && ag.toll_time > (float)d.cfg.min_pass_steps) ? 1.0f : 0.0f;
     }
   }
+  __syncthreads();
+  // ---- who observes, what can be seen.  A multi-agent env has as many slots as agents may ever be alive at once (40 on the
+  // reference's roundabout) and, under most policies, far fewer agents in the world: the rows that are due and the bodies that can
+  // show up in one (in the world now, or -- a row of the step shows the world before the step's finishes -- reported this step)
+  // are compacted into two ascending lists, and everything below works on observers x bodies of the LISTS, 64 pairs at a time.
+  // (Every wave builds the same lists: identical bytes to identical places.)
+  unsigned char* wList = M.wList; unsigned char* bList = M.bList;
+  const bool w_l = lane < A && aWant[lane] != 0;
+  const int st_l = bST[lane] & 0xff;
+  const bool b_l = lane < V && (st_l == ST_PENDING || st_l == ST_ACTIVE || st_l == ST_DYING || (lane < A && (bFL[lane] & PGD_F_REPORT) != 0u));
+  const unsigned long long wm = __ballot(w_l), bm = __ballot(b_l);
+  const int nW = __popcll(wm), nB = __popcll(bm);
+  if (w_l) wList[__popcll(wm & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+  if (b_l) bList[__popcll(bm & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+  // rows that are not due read zero: written by the whole block, one row after the other (coalesced), not by the slot's own lanes
+  // -- and only the rows that are not known to be zero already (PgdDev::rowz)
+  const unsigned long long not_due = (A >= 64 ? ~0ull : ((1ull << A) - 1ull)) & ~wm;
+  for (unsigned long long zm = not_due & ~known_zero; zm != 0ull; zm &= zm - 1ull) {
+    float* zr = obs + (size_t)e * d.ostride + (size_t)__builtin_ctzll(zm) * D;
+    for (int k = tid; k < D; k += WAVE * NW) zr[k] = 0.0f;
+  }
+  if (d.rowz && tid == 0 && not_due != known_zero) d.rowz[e] = not_due;
+  row_sync<true>();
   if (NL <= 0) return;
   // PGD_MA_OTHERS_STATE (LidarStateObservationMARound): a neighbour row is the neighbour's own state vector; the ranks found by
   // the pair phase are parked in LDS (slot, speed as the observer sees it) and the vectors are written by a last phase below
   const bool oth = ALLOW_OTH && (d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && NO > 0;
   int* nbSlot = reinterpret_cast<int*>(s_minb_all + (size_t)NW * ((size_t)G * NL + 2 * (size_t)G * V));
   float* nbSpd = reinterpret_cast<float*>(nbSlot + A * NO);
-  if (oth)
+  if (oth) {
     for (int k = tid; k < A * NO; k += WAVE * NW) nbSlot[k] = -1;
-  __syncthreads();
+    __syncthreads();
+  }
   // ---- pairs.  Every wave owns a contiguous range of observers and works through it in rounds of at most `G` observers (what
   // the LDS for the per-beam minima holds); the (observer, body) pairs of a round are packed into the lanes 64 at a time,
   // whatever V is (V = 40: 25 passes for 40 observers instead of 40 passes with 40 busy lanes each).
   const bool toll = (d.cfg.marl_flags & PGD_MA_TOLLGATE) != 0;
   const int o_oth = (d.cfg.side_lasers > 0 ? d.cfg.side_lasers : 2) + 6 + d.cfg.lane_line_lasers + (d.cfg.random_agent_model ? 2 : 0) + (toll ? 0 : 10);
   const float R = d.cfg.lidar_dist, R_lidar = R;
-  const int per_wave = (A + NW - 1) / NW;
-  const int a_lo = min(wv * per_wave, A), a_hi = min(a_lo + per_wave, A);
+  const int per_wave = (nW + NW - 1) / NW;  // positions of the observer list
+  const int a_lo = min(wv * per_wave, nW), a_hi = min(a_lo + per_wave, nW);
   unsigned* s_minb = s_minb_all + (size_t)wv * ((size_t)G * NL + 2 * (size_t)G * V);  // [G * NL] minima | [G * V] distance | [G * V] speed
   float* rDist = reinterpret_cast<float*>(s_minb + (size_t)G * NL);
   float* rSpd = rDist + (size_t)G * V;
@@ -635,14 +659,15 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   int* pI0 = pI0_all[wv];
   for (int g0 = a_lo; g0 < a_hi; g0 += G) {
     const int g1 = min(g0 + G, a_hi);
-    const int P = (g1 - g0) * V;
+    const int P = (g1 - g0) * nB;
     for (int k = lane; k < (g1 - g0) * NL; k += WAVE) s_minb[k] = __float_as_uint(1.0f);
     row_sync<true>();  // the round belongs to this wave alone
     for (int q0 = 0; q0 < P; q0 += WAVE) {
       const int pq = q0 + lane;
-      const int al = pq / V, o = pq - al * V, a = g0 + al;
-      const bool pv = pq < P && aWant[pq < P ? a : 0] != 0;
-      const int ac = pv ? a : 0;
+      const bool pv = pq < P;
+      const int al = pv ? pq / nB : 0, bo = pv ? pq - al * nB : 0;
+      const int a = wList[g0 + al], o = bList[bo];  // observer and body of the pair
+      const int ac = a;
       const float px = bX[ac], py = bY[ac], hx = bUX[ac], hy = bUY[ac];
       bool in = false, is_vehicle = true;
       float dist = 0.0f, spd = 0.0f;
@@ -686,7 +711,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
           }
         }
       }
-      if (pq < P && NO > 0) {  // kept for the neighbour ranks of the round
+      if (pv && NO > 0) {  // kept for the neighbour ranks of the round
         rDist[pq] = (in && is_vehicle) ? dist : __builtin_inff();
         rSpd[pq] = spd;
       }
@@ -700,7 +725,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
       const int R = (T + WAVE - 1) / WAVE;  // rounds of 64 incidences
       // lidar (distance_detector.py:65-94, cutils.pyx:60-142): incidence t belongs to the pair whose window covers it
       auto cast = [&](const int ao, const int i0w, const int start, const int t) {
-        const int qa = ao >> 8, qo = ao & 0xff, ga = g0 + qa;
+        const int qa = ao >> 8, qo = ao & 0xff, ga = wList[g0 + qa];
         int i = i0w + (t - start);
         i -= i >= NL ? NL : 0;
         const float ax = bX[ga], ay = bY[ga], ahx = bUX[ga], ahy = bUY[ga];
@@ -754,14 +779,13 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     // neighbour rows (lidar.py:55-77: by centre distance, stable in slot order); the multi-agent default observes none
     if (NO > 0)
       for (int pq = lane; pq < P; pq += WAVE) {
-        const int al = pq / V, o = pq - al * V, a = g0 + al;
-        if (!aWant[a]) continue;
+        const int al = pq / nB, bo = pq - al * nB, a = wList[g0 + al], o = bList[bo];
         const float dk = rDist[pq];
         int rank = 0, nveh = 0;
-        for (int j = 0; j < V; ++j) {
-          const float dj = rDist[al * V + j];
+        for (int j = 0; j < nB; ++j) {  // (the body list ascends: position order = slot order, the reference's tie rule)
+          const float dj = rDist[al * nB + j];
           nveh += dj < __builtin_inff() ? 1 : 0;
-          rank += (dj < dk || (dj == dk && j < o)) ? 1 : 0;
+          rank += (dj < dk || (dj == dk && j < bo)) ? 1 : 0;
         }
         float* nb = obs + (size_t)e * d.ostride + (size_t)a * D + o_oth;
         if (oth) {
@@ -780,15 +804,14 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
           w[2] = clipf((ph / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
           w[3] = clipf((ps / ms + 1.0f) * 0.5f, 0.0f, 1.0f);
         }
-        for (int r = nveh + o; r < NO; r += V) {  // absent neighbours -> zeros
+        for (int r = nveh + bo; r < NO; r += nB) {  // absent neighbours -> zeros
           float* w = nb + r * 4;
           w[0] = w[1] = w[2] = w[3] = 0.0f;
         }
       }
     for (int k = lane; k < (g1 - g0) * NL; k += WAVE) {
-      const int qa = k / NL, i = k - qa * NL, ga = g0 + qa;
-      if (aWant[ga])
-        obs[(size_t)e * d.ostride + (size_t)ga * D + o_oth + (oth ? o_oth : 4) * NO + i] = lidar_noise(d, e, ga, tick, i, __uint_as_float(s_minb[k]));
+      const int qa = k / NL, i = k - qa * NL, ga = wList[g0 + qa];
+      obs[(size_t)e * d.ostride + (size_t)ga * D + o_oth + (oth ? o_oth : 4) * NO + i] = lidar_noise(d, e, ga, tick, i, __uint_as_float(s_minb[k]));
     }
     row_sync<true>();
   }

@@ -35,4 +35,6 @@ with torch.cuda.stream(eng.stream):
         tot = sum(out[:15]) + sum(out[16:28])
         print('k_observe cycles/block (first 8192 rows):', {n: int(out[i] / (300 * 8192)) for i, n in enumerate(names) if i in (22, 23, 24, 28)}, 'wall us', round(out[29] / (300 * 8192) / 100, 2))
         print('cycles/block:', {n: int(out[i] / nb) for i, n in enumerate(names) if out[i]}, 'total', int(tot / nb), '=> us', round(out[15] / nb / 100, 2))
+        f_, i_, ei_ = eng.get_state(); st_ = i_[_abi.SI['STATUS']][:, :A]
+        print('   active agents per env %.2f, dying %.2f, max active %d' % ((st_ == _abi.ST_ACTIVE).sum(1).mean(), (st_ == _abi.ST_DYING).sum(1).mean(), (st_ == _abi.ST_ACTIVE).sum(1).max()))
         print('   MAX over blocks:', {n: int(out[32 + i] / 300) for i, n in enumerate(names) if out[i]})
