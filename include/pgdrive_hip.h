@@ -198,6 +198,8 @@ typedef struct pgd_config {
   int32_t env_base;         /* global index of this engine's env 0.  The device RNG streams (IDM timers, lidar noise, scenario
                                re-draws, respawn destinations) are keyed by env_base + e, so envs sharded over several engines
                                / GPUs reproduce the single-engine run env for env */
+  int32_t idm_agent;        /* IDM_agent (base_env.py:30, agent_manager.py:79): the ego is driven by IDMPolicy along its route,
+                               the actions handed to pgd_step are ignored.  Single-agent engines only */
 } pgd_config;
 
 #define PGD_MA_ENABLED        1  /* MultiAgentPGDrive semantics: per-agent done, delay-done queue, respawn, __all__ */

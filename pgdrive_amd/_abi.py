@@ -16,7 +16,7 @@ class PgdConfig(C.Structure):
         ("discrete_steering_dim", C.c_int32), ("discrete_throttle_dim", C.c_int32), ("increment_steering", C.c_int32),
         ("safe_rl_env", C.c_int32), ("overspeed_penalty", C.c_float), ("min_pass_steps", C.c_int32),
         ("enable_reverse", C.c_int32), ("lidar_gaussian_noise", C.c_float), ("lidar_dropout_prob", C.c_float),
-        ("random_agent_model", C.c_int32), ("env_base", C.c_int32),
+        ("random_agent_model", C.c_int32), ("env_base", C.c_int32), ("idm_agent", C.c_int32),
     ]
 
 
@@ -39,7 +39,7 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
                 discrete_action=False, discrete_steering_dim=5, discrete_throttle_dim=5, increment_steering=False,
                 safe_rl_env=False, plain_reward=False, cross_yellow_line_done=True, tollgate=False, overspeed_penalty=0.5,
                 min_pass_steps=30, enable_reverse=False, parking=False, others_state=False, random_agent_model=False,
-                lidar_gaussian_noise=0.0, lidar_dropout_prob=0.0, env_base=0):
+                lidar_gaussian_noise=0.0, lidar_dropout_prob=0.0, env_base=0, idm_agent=False):
     """Defaults mirror PGDriveEnv_DEFAULT_CONFIG / BASE_DEFAULT_CONFIG (pgdrive_env.py:22-109, base_env.py:19-90)."""
     c = PgdConfig()
     c.num_envs, c.num_agents, c.num_traffic = num_envs, num_agents, num_traffic
@@ -56,6 +56,7 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
     c.discrete_steering_dim, c.discrete_throttle_dim = int(discrete_steering_dim), int(discrete_throttle_dim)
     c.safe_rl_env = int(bool(safe_rl_env))
     c.env_base = int(env_base)
+    c.idm_agent = int(bool(idm_agent))
     c.enable_reverse = int(bool(enable_reverse))
     c.random_agent_model = int(bool(random_agent_model))
     c.lidar_gaussian_noise, c.lidar_dropout_prob = float(lidar_gaussian_noise), float(lidar_dropout_prob)

@@ -166,7 +166,7 @@ DEV void step_sync() { row_sync<true>(); }
   F(c.num_agents, 1) F(c.num_traffic, PGD_FIX_V - 1) F(c.num_lasers, 240) F(c.num_others, 4) F(c.lidar_dist, 50.0f)                 \
   F(c.dt, 0.02f) F(c.decision_repeat, 5) F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0)                     \
   F(c.enable_reverse, 0) F(c.marl_flags, 0) F(c.side_lasers, 0) F(c.lane_line_lasers, 0)                                            \
-  F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f)
+  F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f) F(c.idm_agent, 0)
 // ... and the default reward scheme (pgdrive_env.py:91-101).  Engines that keep the default geometry but train on their own
 // reward run the instantiation with only the list above compiled in (FIX == 2: 2 % slower than the full one, 6 % faster than the
 // general kernel).
@@ -185,7 +185,7 @@ DEV void step_sync() { row_sync<true>(); }
   F(c.marl_flags, (PGD_MA_ENABLED | PGD_MA_CRASH_DONE | PGD_MA_OUT_ROAD_DONE | PGD_MA_ALLOW_RESPAWN)) F(c.use_lateral, 0)           \
   F(c.out_of_route_done, 0) F(c.success_reward, 10.0f) F(c.out_of_road_penalty, 10.0f) F(c.crash_vehicle_penalty, 10.0f)            \
   F(c.crash_object_penalty, 10.0f) F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f) F(c.side_lasers, 0) F(c.lane_line_lasers, 0)   \
-  F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f) F(c.delay_done, 25)
+  F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f) F(c.delay_done, 25) F(c.idm_agent, 0)
 // BASELINE config 2: the ego alone, no lidar (dynamics + reward + the 18-float state vector), otherwise the single-agent defaults --
 // four envs per wave, 16 sub-lanes per ego, the row written by k_step itself.
 #define PGD_FIXE_FIELDS(F, d, c)                                                                                                    \
@@ -194,7 +194,7 @@ DEV void step_sync() { row_sync<true>(); }
   F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0) F(c.enable_reverse, 0) F(c.marl_flags, 0)                  \
   F(c.use_lateral, 0) F(c.out_of_route_done, 0) F(c.success_reward, 10.0f) F(c.out_of_road_penalty, 5.0f)                           \
   F(c.crash_vehicle_penalty, 5.0f) F(c.crash_object_penalty, 5.0f) F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f)               \
-  F(c.side_lasers, 0) F(c.lane_line_lasers, 0) F(c.random_agent_model, 0)
+  F(c.side_lasers, 0) F(c.lane_line_lasers, 0) F(c.random_agent_model, 0) F(c.idm_agent, 0)
 enum { FIXK_DEFAULT = 0, FIXK_MARL = 1, FIXK_EGO_ONLY = 2, FIXK_GEOMETRY = 3 };
 template <bool ONE_ENV, bool MARL, bool STD, int FIX = 1>
 DEV void write_fixed_config(PgdDev& d) {
@@ -350,7 +350,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (ONE_ENV && !MARL && A == 1) next_trigger_road = ng < sc->n_groups ? (int)sc->trigger_road[ng] : -1;
   // the own-lane coordinate / lane length / successor list of a vehicle are read by the IDM neighbour search alone: an
   // env without a driving IDM vehicle in this step (most envs, most steps) skips them
-  const bool idm_runs = ONE_ENV ? (__ballot(valid && s >= A && r.status == ST_ACTIVE) != 0ull) : true;
+  const bool idm_ego = !MARL && d.cfg.idm_agent != 0;  // IDM_agent: the agent slot is driven by the IDM policy as well
+  const bool idm_runs = ONE_ENV ? (__ballot(valid && (s >= A || idm_ego) && r.status == ST_ACTIVE) != 0ull) : true;
   // snapshot of the world before physics
   if (valid) {
     if (leader) {
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       S.lane[slot] = r.lane;
       const bool present = r.status == ST_PENDING || r.status == ST_ACTIVE || r.status == ST_DYING;
       S.present[slot] = present ? 1 : 0;
-      if (present && V > A && idm_runs) {
+      if (present && (V > A || idm_ego) && idm_runs) {
         const pgd_lane& ml = mv.lanes[r.lane];
         S.lon[slot] = r.lon;  // carried in the record since the vehicle's last localisation
         S.llen[slot] = ml.length;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // (2) policies
   if (acting) {
     float st, tb;
-    if (s < A) {  // EnvInputPolicy.act (env_input_policy.py:17-26); NaN made harmless (test_ego_vehicle.py:78-84)
+    if (s < A && !idm_ego) {  // EnvInputPolicy.act (env_input_policy.py:17-26); NaN made harmless (test_ego_vehicle.py:78-84)
       float a0 = act[((size_t)e * A + s) * 2 + 0], a1 = act[((size_t)e * A + s) * 2 + 1];
       if (a0 != a0) a0 = 0.0f;
       if (a1 != a1) a1 = 0.0f;
@@ -956,7 +957,7 @@ DEV unsigned long long reset_slot(const PgdDev& d, const LaneMap& lm, int scen, 
   const Grp g{lm.sub, d.sub, lm.lead};
   const pgd_spawn* sp = d.spawns + (size_t)scen * d.sstride + s;
   MapView mv = map_view(d, d.scen[scen].map);
-  reset_vehicle(*sp, d.spawn_hv[(size_t)scen * d.sstride + s], r, s, s < A);
+  reset_vehicle(*sp, d.spawn_hv[(size_t)scen * d.sstride + s], r, s, s < A && !d.cfg.idm_agent);
   RouteCtx ctx;
   if (r.status != ST_EMPTY) {
     route_refresh(mv, *sp, r);
@@ -1365,6 +1366,7 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   const bool marl = (cfg->marl_flags & PGD_MA_ENABLED) != 0;
   // multi-agent engines have no IDM traffic; num_traffic slots may hold static bodies (toll booths, group PGD_GROUP_NEVER)
   if (marl && (cfg->respawn_places < 0 || cfg->respawn_dests < 0)) return PGD_ERR_ARG;
+  if (cfg->idm_agent && (marl || cfg->num_agents != 1)) return PGD_ERR_ARG;  // the agent's PID / routing fields double as multi-agent bookkeeping
   if (marl && cfg->horizon > 0x7fff) return PGD_ERR_ARG;  // the per-agent episode length is a 16-bit field of the record
   h->d.sstride = V + (marl ? cfg->respawn_places * cfg->respawn_dests : 0);
   h->d.sub = WAVE / V < 16 ? WAVE / V : 16;  // sub-lanes per vehicle

@@ -289,8 +289,11 @@ def propose_traffic(desc, seed, density, skip_lanes=(), type_draws=0):
 def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=0.1, spawn_lane=None,
                    spawn_longitude=5.0, spawn_lateral=0.0, vehicle_model="default", agent_spawns=None,
                    traffic_mode="trigger", traffic_seed=None, auto_termination=False, accident_prob=0.0,
-                   random_agent_model=False):
-    """One scenario = V = num_agents + num_traffic spawn slots for map `desc` under global seed `seed`."""
+                   random_agent_model=False, idm_agent=False):
+    """One scenario = V = num_agents + num_traffic spawn slots for map `desc` under global seed `seed`.
+    idm_agent: the agents are driven by IDMPolicy (IDM_agent, agent_manager.py:79): their overtake timer starts at
+    randint(0, LANE_CHANGE_FREQ) like every IDMPolicy's (idm_policy.py:185), drawn here from the vehicle's own seed (the
+    reference takes the policy seed from the agent manager's generator: the stream is not reproduced, the range is)."""
     V = num_agents + num_traffic
     scen = np.zeros((), dtype=SCEN_DT)
     spawns = np.zeros(V, dtype=SPAWN_DT)
@@ -328,7 +331,7 @@ def build_scenario(desc, map_index, seed, num_agents=1, num_traffic=16, density=
             dest = choose_destination(desc, seed, road["frm"], negative=road["negative"])
         _fill_route(spawns[a], desc, sp["lane"], dest)
         spawns[a]["group"] = -1
-        spawns[a]["timer0"] = 0
+        spawns[a]["timer0"] = int(get_np_random(obj_seed).randint(0, 50)) if idm_agent else 0
 
     # ---- traffic (traffic_manager.py:239-290) ----
     # the manager RNG is re-seeded with the episode seed unless random_traffic (traffic_manager.py:348-350)

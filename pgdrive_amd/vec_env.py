@@ -65,6 +65,7 @@ DEFAULT_CONFIG = dict(
     # top-down multi-channel image observation instead of the state + lidar vector (TopDownPGDriveEnv, envs/top_down_env.py:8-42,
     # obs/top_down_obs_multi_channel.py); pgdrive_amd/csrc/pgd_topdown.h states what exactly is drawn
     use_topdown=False, frame_stack=3, post_stack=5, frame_skip=5, resolution_size=84, distance=30, rgb_clip=True,
+    IDM_agent=False,  # the ego is driven by IDMPolicy along its route, step()'s actions are ignored (base_env.py:30, agent_manager.py:79)
     map_bank=None,  # path of a pre-generated description bank; None -> generate with our BIG (pgdrive_amd/mapgen.py)
 )
 
@@ -89,7 +90,7 @@ VISUAL_VEHICLE_KEYS = {
 # neutral value is accepted, anything else is refused by name instead of being silently ignored.
 NEUTRAL_KEYS = {
     "use_render": False, "manual_control": False, "offscreen_render": False, "use_saver": False,
-    "record_episode": False, "_debug_crash_object": False, "IDM_agent": False, "is_multi_agent": False, "num_agents": 1,
+    "record_episode": False, "_debug_crash_object": False, "is_multi_agent": False, "num_agents": 1,
     "allow_respawn": False, "delay_done": 0, "gaussian_noise": 0.0, "dropout_prob": 0.0,
 }
 # overtake_stat: BaseVehicle._update_overtake_stat calls Lidar.get_surrounding_vehicles() without its argument in this
@@ -180,7 +181,7 @@ class PGDriveVecEnv:
             spawn_longitude=vc["spawn_longitude"], spawn_lateral=vc["spawn_lateral"], vehicle_model=vc["vehicle_model"],
             spawn_lane_index=vc["spawn_lane_index"], destination_node=vc["destination_node"],
             traffic_mode=c["traffic_mode"], auto_termination=c["auto_termination"], accident_prob=c["accident_prob"],
-            random_agent_model=c["random_agent_model"],
+            random_agent_model=c["random_agent_model"], idm_agent=bool(c["IDM_agent"]),
             traffic_seeds=np.random.RandomState(c["seed"]).randint(0, scenario.MAX_RAND_INT, len(seeds))
             if c["random_traffic"] else None
         )
@@ -206,7 +207,7 @@ class PGDriveVecEnv:
             discrete_action=c["discrete_action"], discrete_steering_dim=c["discrete_steering_dim"],
             discrete_throttle_dim=c["discrete_throttle_dim"], increment_steering=vc["increment_steering"],
             safe_rl_env=c["safe_rl_env"], random_agent_model=c["random_agent_model"], enable_reverse=vc["enable_reverse"],
-            lidar_gaussian_noise=lid["gaussian_noise"], lidar_dropout_prob=lid["dropout_prob"]
+            lidar_gaussian_noise=lid["gaussian_noise"], lidar_dropout_prob=lid["dropout_prob"], idm_agent=bool(c["IDM_agent"])
         )
         from .engine import Engine
         self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])

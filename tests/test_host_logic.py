@@ -116,7 +116,7 @@ def test_reference_config_keys_are_accepted_or_refused_by_name():
     c = merge_config(DEFAULT_CONFIG, strip_reference_only_keys(ref_style))
     assert c["start_seed"] == 5 and c["traffic_density"] == 0.2 and c["vehicle_config"]["lidar"]["num_lasers"] == 120
     assert c["vehicle_config"]["lidar"]["distance"] == 50 and "use_render" not in c and "show_lidar" not in c["vehicle_config"]
-    for bad in (dict(use_render=True), dict(manual_control=True), dict(IDM_agent=True),
+    for bad in (dict(use_render=True), dict(manual_control=True),
                 dict(vehicle_config=dict(overtake_stat=True)), dict(num_agents=4)):
         with pytest.raises(NotImplementedError):
             strip_reference_only_keys(bad)
