@@ -545,3 +545,80 @@ def test_scripted_lane_keeping_policy_drives_to_the_destination(descs):
     print("scripted policy: arrivals %d, out of road %d, mean speed %.1f km/h" % (arrive, out, float(np.mean(speed))))
     assert arrive >= 200 and out <= 0.25 * arrive and 20.0 < np.mean(speed) < 35.0
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's own end-to-end property tests at the Bullet boundary (the only things that pin behaviour there),
+# run on the engine through the gym-shaped wrapper.  Together with the expert band above they are the evidence behind the
+# kinematic-bicycle substitution: steering sign, line / sidewalk contact semantics, vehicle contacts,
+# the side detector against the road edge.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("steering", [-0.01, 0.01])
+@pytest.mark.parametrize("distance", [10, 50, 100])
+def test_reference_out_of_road_property(steering, distance):
+    """tests/test_functionality/test_out_of_road.py:7-36: on eleven straight blocks a slight constant steering (either way) at full
+    throttle ends the episode, and at that moment the nearest continuous line seen by the 120-beam side detector is closer than
+    the vehicle's diagonal (cloud point < sqrt(W^2 + L^2) / distance)."""
+    from pgdrive_amd.env import PGDriveEnv
+    env = PGDriveEnv(dict(map="SSSSSSSSSSS", environment_num=1, start_seed=0,
+                          vehicle_config=dict(side_detector=dict(num_lasers=120, distance=distance))))
+    try:
+        env.reset()
+        tol = np.sqrt(1.852 ** 2 + 4.51 ** 2) / distance  # DefaultVehicle WIDTH / LENGTH (vehicle_type.py:9-16)
+        for t in range(3000):
+            o, r, d, info = env.step([steering, 1.0])
+            if d:
+                break
+        assert d and info["out_of_road"] and not info["arrive_dest"], (t, info)
+        side = o[:120]
+        assert side.min() < tol, (float(side.min()), tol)
+    finally:
+        env.close()
+
+
+def test_reference_collision_with_vehicle():
+    """tests/test_functionality/test_collision.py:4-21: traffic density 1.0 on three straights, full throttle straight ahead:
+    the ego runs into a traffic vehicle within 500 steps."""
+    from pgdrive_amd.env import PGDriveEnv
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # (density 1.0 asks for more vehicles than the slot cap holds: said so by name)
+        env = PGDriveEnv(dict(traffic_density=1.0, map="SSS", environment_num=1, start_seed=0, max_traffic_vehicles=62))
+    try:
+        env.reset()
+        hit = False
+        for t in range(1, 500):
+            o, r, d, info = env.step([0.0, 1.0])
+            if info["crash_vehicle"]:
+                hit = True
+                break
+        assert hit, "no vehicle contact in 500 steps at traffic density 1.0"
+        assert d and r == -5.0  # crash_vehicle_penalty, terminal (pgdrive_env.py:162-258)
+    finally:
+        env.close()
+
+
+def test_reference_line_contact_and_sidewalk():
+    """tests/test_functionality/test_collision.py:24-50: without traffic, steering -0.5 at full throttle for 99 steps (the
+    reference keeps stepping after done) -- the car crosses BROKEN lines and reaches the WHITE continuous side line, and it
+    crashes into the sidewalk.  From the left-most lane that is a turn to the RIGHT: the test also pins the sign of the
+    steering input against the reference (the other way the car would meet the yellow centre line first)."""
+    from pgdrive_amd import _abi
+    from pgdrive_amd.env import PGDriveEnv
+    env = PGDriveEnv(dict(traffic_density=0.0, environment_num=1, start_seed=0))
+    try:
+        env.reset()
+        seen = 0
+        first_done = None
+        for t in range(1, 100):
+            o, r, d, info = env.step([-0.5, 1.0])
+            _, i, _ = env.vec.engine.get_state()
+            seen |= int(i[_abi.SI["VFLAGS"], 0, 0])
+            if d and first_done is None:
+                first_done = dict(info)
+        assert seen & _abi.F_ON_BROKEN and seen & _abi.F_ON_WHITE, hex(seen)
+        assert seen & _abi.F_CRASH_SIDEWALK, hex(seen)
+        assert not (seen & _abi.F_ON_YELLOW), "steering -0.5 must turn away from the centre line"
+        assert first_done is not None and first_done["out_of_road"]
+    finally:
+        env.close()
