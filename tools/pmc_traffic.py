@@ -12,6 +12,9 @@ O = sys.argv[1]
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096            # envs of the profiled run
 ACTIONS = sys.argv[3] if len(sys.argv) > 3 else "uniform"      # bench.py --actions
 MODE = sys.argv[4] if len(sys.argv) > 4 else "trigger"         # bench.py --traffic-mode
+WORKLOAD = sys.argv[5] if len(sys.argv) > 5 else "c3"          # bench.py --workload
+AGENTS = int(sys.argv[6]) if len(sys.argv) > 6 else 1          # bench.py --agents (c5)
+LASERS = int(sys.argv[7]) if len(sys.argv) > 7 else (240 if WORKLOAD == "c3" else 72)
 
 
 def pmc(d, steady_only=False):
@@ -32,7 +35,8 @@ rc_f = sum(cf["rec_copy"]) / len(cf["rec_copy"])
 rc_w = sum(cw["rec_copy"]) / len(cw["rec_copy"])
 rw_w = sum(cw["row_write"]) / len(cw["row_write"])
 c_f, c_w = rec_bytes / (rc_f * 1024.0), rec_bytes / (rc_w * 1024.0)
-out = dict(envs=N, traffic=16, lasers=240, actions=ACTIONS, traffic_mode=MODE, kernel=kname, FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk,
+out = dict(envs=N, traffic=16 if WORKLOAD == "c3" else 0, lasers=LASERS, actions=ACTIONS, traffic_mode=MODE, workload=WORKLOAD,
+           agents=AGENTS if WORKLOAD == "c5" else 1, kernel=kname, FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk,
            dispatches_averaged=len(steady(fetch[kname])),
            calibration=dict(rec_copy_bytes=rec_bytes, rec_copy_FETCH_SIZE_KB=rc_f, rec_copy_WRITE_SIZE_KB=rc_w, row_write_bytes=row_bytes,
                             row_write_WRITE_SIZE_KB=rw_w, fetch_correction=c_f, write_correction_records=c_w,

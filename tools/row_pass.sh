@@ -1,0 +1,22 @@
+#!/bin/bash
+# Profile pass of one workload row of bench.py: the row's bench line, rocprofv3 --kernel-trace --stats of the same command,
+# FETCH_SIZE / WRITE_SIZE in SEPARATE --pmc passes (+ the calibration kernels), summarised by tools/pmc_traffic.py into the
+# traffic record bench.py matches by workload (profiles/rNN_<row>_pmc_traffic.json).
+# usage: row_pass.sh TAG WORKLOAD(c3|c5) ENVS ACTIONS MODE AGENTS LASERS [more bench args]     outputs under gpurun_out/TAG
+R=$GRAFT_REPO_ROOT; TAG=$1; WL=$2; N=$3; ACT=$4; MODE=$5; AG=$6; NL=$7; shift 7
+cd /tmp && export TMPDIR=/tmp
+O=$R/gpurun_out/$TAG; mkdir -p $O
+ARGS="--no-rows --no-cpu-baseline --workload $WL --envs $N --actions $ACT --traffic-mode $MODE --agents $AG --lasers $NL $@"
+[ -x /tmp/pgd_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/profiles/r01_calib.hip -o /tmp/pgd_calib 2>/dev/null
+timeout 600 python $R/bench.py $ARGS > $O/bench.json 2> $O/bench.err < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py $ARGS > $O/bench_under_rocprof.json 2> $O/stats.err < /dev/null
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python $R/bench.py $ARGS --exact --steps 200 --warmup 1500 > /dev/null 2> $O/fetch.err < /dev/null
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python $R/bench.py $ARGS --exact --steps 200 --warmup 1500 > /dev/null 2> $O/write.err < /dev/null
+timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_fetch -- /tmp/pgd_calib > $O/calib.txt 2> $O/cal.err < /dev/null
+timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cal_write -- /tmp/pgd_calib > /dev/null 2>> $O/cal.err < /dev/null
+for f in $(find $O/stats -name "*kernel_stats.csv"); do cp $f $O/kernel_stats.csv; head -3 $f; done
+python $R/tools/pmc_traffic.py $O $N $ACT $MODE $WL $AG $NL > $O/pmc_traffic.json; grep -E "bytes_per_env_step|FETCH_SIZE_KB|WRITE_SIZE_KB|fetch_correction" $O/pmc_traffic.json
+tail -c 400 $O/bench.json; echo
+# keep only the summaries (the raw traces are large)
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -delete
+rm -rf $O/fetch $O/write $O/cal_fetch $O/cal_write $O/stats
