@@ -338,6 +338,10 @@ typedef struct pgd_topdown_config {
   int32_t frame_stack;      /* 3 traffic frames */
   int32_t post_stack;       /* 5 past positions */
   int32_t frame_skip;       /* 5 steps between stacked entries */
+  int32_t mode;             /* 0: TopDownMultiChannel [R, R, 2 + frame_stack] (TopDownPGDriveEnv / V2, top_down_env.py:28-60);
+                               1: TopDownObservation, one RGB frame [R, R, 3] / 255 -- lane lines (35, 35, 35), the ego GREEN
+                               (50, 200, 0), the other vehicles BLUE (100, 200, 255) (TopDownSingleFramePGDriveEnv,
+                               top_down_env.py:8-26, obs/top_down_obs.py:22-240; the stack / skip fields are not read) */
 } pgd_topdown_config;
 int pgd_topdown_channels(const pgd_topdown_config* cfg);
 int pgd_topdown_enable(pgd_handle h, const pgd_topdown_config* cfg);

@@ -141,7 +141,7 @@ class Oracle:
         assert self.L.orc_topdown_enable(self.h, C.byref(td_cfg)) == 0
 
     def observe_topdown(self):
-        R, Cn = self.td_cfg.resolution, 2 + self.td_cfg.frame_stack
+        R, Cn = self.td_cfg.resolution, (3 if self.td_cfg.mode == 1 else 2 + self.td_cfg.frame_stack)
         img = np.zeros((self.N, R, R, Cn), dtype=np.float64)
         assert self.L.orc_observe_topdown(self.h, _p(img)) == 0
         return img

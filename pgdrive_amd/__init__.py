@@ -10,7 +10,7 @@ def __getattr__(name):
     if name == "PGDriveVecEnv":
         from .vec_env import PGDriveVecEnv
         return PGDriveVecEnv
-    if name in ("PGDriveEnv", "SafePGDriveEnv", "make"):
+    if name in ("PGDriveEnv", "SafePGDriveEnv", "TopDownPGDriveEnv", "TopDownPGDriveEnvV2", "TopDownSingleFramePGDriveEnv", "make"):
         from . import env
         return getattr(env, name)
     if name.startswith("MultiAgent"):  # MultiAgent{Roundabout,Intersection,Bottleneck,Tollgate,ParkingLot}[Vec]Env, MultiAgentPGDrive[VecEnv]

@@ -23,11 +23,12 @@ class PgdConfig(C.Structure):
 class TopDownConfig(C.Structure):
     """pgd_topdown_config; defaults = TopDownPGDriveEnv (envs/top_down_env.py:8-42)."""
     _fields_ = [("resolution", C.c_int32), ("distance", C.c_float), ("frame_stack", C.c_int32), ("post_stack", C.c_int32),
-                ("frame_skip", C.c_int32)]
+                ("frame_skip", C.c_int32), ("mode", C.c_int32)]
 
 
-def make_topdown_config(resolution=84, distance=30.0, frame_stack=3, post_stack=5, frame_skip=5):
-    return TopDownConfig(int(resolution), float(distance), int(frame_stack), int(post_stack), int(frame_skip))
+def make_topdown_config(resolution=84, distance=30.0, frame_stack=3, post_stack=5, frame_skip=5, mode=0):
+    """mode 1: the single RGB frame of TopDownObservation (obs/top_down_obs.py; reference default resolution 200)."""
+    return TopDownConfig(int(resolution), float(distance), int(frame_stack), int(post_stack), int(frame_skip), int(mode))
 
 
 def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_others=4, lidar_dist=50.0, dt=0.02,

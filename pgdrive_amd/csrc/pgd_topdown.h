@@ -46,7 +46,9 @@ struct TopDown {
   const uint8_t* tex;        // all rasters back to back
   const long long* tex_off;  // [n_scen] offset of the scenario's raster
   float line_r;
+  int rgb;  // pgd_topdown_config.mode == 1: one RGB frame (C = 3): lines grey, the ego green, the others blue; no route, no history
 };
+#define TD_RGB_LINE (35.0f / 255.0f)
 #define TD_TEXEL 0.25f
 
 #define TD_LINE 0.27450980392156865f   // 2 * 35 / 255
@@ -246,7 +248,8 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t, ui
       for (int p0 = c0 + wv * 64; p0 < c1; p0 += 256) {
         const int n_here = min(64, c1 - p0);
         const int cls = lane < n_here ? (int)s_cls[p0 - c0 + lane] : 0;
-        so[lane * C] = cls == 2 ? TD_LINE : (cls == 1 ? TD_NAVI : 0.0f);
+        if (t.rgb) { const float g = cls == 2 ? TD_RGB_LINE : 0.0f; so[lane * 3] = g; so[lane * 3 + 1] = g; so[lane * 3 + 2] = g; }
+        else so[lane * C] = cls == 2 ? TD_LINE : (cls == 1 ? TD_NAVI : 0.0f);
         row_sync<true>();  // the wave's own LDS traffic only
         const int nf = n_here * C;
         float* dst = out + (size_t)p0 * C;
@@ -268,6 +271,29 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t, ui
   // ch 2..: the other vehicles at t, t - skip, ...: the pixels whose centre (fwd, rgt) lies inside a box, in that frame's ego
   // coordinates.  One wave per (frame, box) pair in turn; its lanes walk the pixel rectangle around the box (circumradius + a
   // pixel of slack), 8 x 8 at a time, with the exact point-in-box test.
+  // (RGB frame: the ego first -- VehicleGraphics.GREEN, its heading snapped below 2 degrees like everybody's while the window
+  // turns with the true one -- then the others over it, VehicleGraphics.BLUE; obs/top_down_obs.py:150-166)
+  auto paint = [&](float* px, int f) {
+    if (!t.rgb) { px[2 + f] = TD_VEH; return; }
+    px[0] = f < 0 ? 50.0f / 255.0f : 100.0f / 255.0f; px[1] = 200.0f / 255.0f; px[2] = f < 0 ? 0.0f : 1.0f;
+  };
+  if (t.rgb) {
+    if (wv == 0 && !(eg0.z == 0.0f && eg0.w == 0.0f)) {
+      const bool snap = fabsf(recs[0].th) <= 2.0f * PGD_PI / 180.0f;
+      const float ax = snap ? eg0.z : 1.0f, ay = snap ? -eg0.w : 0.0f;  // (1, 0) turned into the window's frame; unsnapped: straight up
+      const float hl = s_hl[0], hw = s_hw[0];
+      const float rad = (hl + hw) * s_px + 1.5f, cc = (float)R * 0.5f - 0.5f;
+      const int ia = max((int)floorf(cc - rad), 0), ib = min((int)ceilf(cc + rad), R - 1);
+      for (int ti = ia; ti <= ib; ti += 8)
+        for (int tj = ia; tj <= ib; tj += 8) {
+          const int pi = ti + (lane >> 3), pj = tj + (lane & 7);
+          if (pi > ib || pj > ib) continue;
+          const float fwd = ((float)R * 0.5f - (float)pi - 0.5f) * inv_s, rgt = ((float)pj + 0.5f - (float)R * 0.5f) * inv_s;
+          if (fabsf(fwd * ax + rgt * ay) <= hl && fabsf(rgt * ax - fwd * ay) <= hw) paint(out + ((size_t)pi * R + pj) * C, -1);
+        }
+    }
+    __syncthreads();
+  }
   for (int q = wv; q < 4 * MAXV; q += 4) {
     const int f = q / MAXV, k = q - f * MAXV;
     if (f >= t.frame_stack || k >= s_nvis[f]) continue;
@@ -283,9 +309,10 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t, ui
         if (pi > ib || pj > jb) continue;
         const float fwd = ((float)R * 0.5f - (float)pi - 0.5f) * inv_s, rgt = ((float)pj + 0.5f - (float)R * 0.5f) * inv_s;
         const float dx = fwd - b.x, dy = rgt - b.y;
-        if (fabsf(dx * b.z + dy * b.w) <= hh.x && fabsf(dy * b.z - dx * b.w) <= hh.y) out[((size_t)pi * R + pj) * C + 2 + f] = TD_VEH;
+        if (fabsf(dx * b.z + dy * b.w) <= hh.x && fabsf(dy * b.z - dx * b.w) <= hh.y) paint(out + ((size_t)pi * R + pj) * C, f);
       }
   }
+  if (t.rgb) return;
   // ch 1: past positions of the ego, newest first, in the current ego frame (top_down_obs_multi_channel.py:152-170)
   if (tid < t.post_stack) {
     const int k = tid * t.frame_skip;
@@ -354,7 +381,7 @@ static int topdown_build_rasters(pgd_engine* h) {
 
 extern "C" {
 
-int pgd_topdown_channels(const pgd_topdown_config* c) { return c ? 2 + c->frame_stack : 0; }
+int pgd_topdown_channels(const pgd_topdown_config* c) { return c ? (c->mode == 1 ? 3 : 2 + c->frame_stack) : 0; }
 
 int pgd_topdown_enable(pgd_handle h, const pgd_topdown_config* c) {
   if (!h || !c || c->resolution < 8 || c->resolution > 512 || !(c->distance > 0.0f) || c->frame_stack < 1 || c->post_stack < 1 ||
@@ -362,14 +389,16 @@ int pgd_topdown_enable(pgd_handle h, const pgd_topdown_config* c) {
     return PGD_ERR_ARG;
   if (c->frame_stack > 4) return PGD_ERR_ARG;  // one wave of the block per stacked frame; s_out holds 256 pixels x (2 + 4) channels
   if (h->d.A != 1) return PGD_ERR_ARG;  // "Don't support multi-agent top-down observation yet" (top_down_obs_multi_channel.py:130)
-  const int n_pos = (c->post_stack - 1) * c->frame_skip + 1, n_frames = (c->frame_stack - 1) * c->frame_skip + 1;
+  if (c->mode != 0 && c->mode != 1) return PGD_ERR_ARG;
+  const bool rgb = c->mode == 1;  // one frame of the present state: no history beyond it
+  const int n_pos = rgb ? 1 : (c->post_stack - 1) * c->frame_skip + 1, n_frames = rgb ? 1 : (c->frame_stack - 1) * c->frame_skip + 1;
   if (n_pos > 64 || n_frames > 16) return PGD_ERR_ARG;
   HIPCHK(hipSetDevice(h->device));
   if (!h->topdown) h->topdown = (pgd_topdown_state*)calloc(1, sizeof(pgd_topdown_state));
   pgd_topdown_state* s = h->topdown;
   if (s->t.pos) { (void)hipFree(s->t.pos); (void)hipFree(s->t.pose); (void)hipFree(s->t.n_hist); }
-  s->t = TopDown{c->resolution, 2 + c->frame_stack, c->frame_stack, c->post_stack, c->frame_skip, n_pos, n_frames, c->distance,
-                 nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f};
+  s->t = TopDown{c->resolution, rgb ? 3 : 2 + c->frame_stack, rgb ? 1 : c->frame_stack, rgb ? 1 : c->post_stack, rgb ? 1 : c->frame_skip,
+                 n_pos, n_frames, c->distance, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, rgb ? 1 : 0};
   s->t.line_r = fmaxf(0.25f, 0.5f * (2.0f * c->distance) / (float)c->resolution);
   s->tex_dirty = true;
   const size_t N = (size_t)h->d.N;

@@ -162,6 +162,19 @@ class TopDownPGDriveEnv(PGDriveEnv):
         super().__init__(cfg)
 
 
+class TopDownPGDriveEnvV2(TopDownPGDriveEnv):
+    """pgdrive/envs/top_down_env.py:44-72: the same observation and defaults as TopDownPGDriveEnv, derived from PGDriveEnv directly
+    upstream (its lidar entry is replaced instead of updated: the remaining lidar keys do not reach the observation)."""
+
+
+class TopDownSingleFramePGDriveEnv(TopDownPGDriveEnv):
+    """pgdrive/envs/top_down_env.py:8-26: PGDriveEnv with TopDownObservation (obs/top_down_obs.py): ONE RGB frame [200, 200, 3]
+    float32 in [0, 1] -- lane lines (35, 35, 35), the ego green (50, 200, 0), the other vehicles blue (100, 200, 255), +-30 m
+    around the ego, ego heading up; frame_stack / post_stack / frame_skip are config keys upstream that this observation
+    never reads.  What is drawn exactly: pgdrive_amd/csrc/pgd_topdown.h (pygame's rasterisation is unpinned)."""
+    DEFAULTS = dict(TopDownPGDriveEnv.DEFAULTS, topdown_single_frame=True)
+
+
 def make(env_id, **kw):
     cfg = dict(ENV_IDS[env_id])
     cfg.update(kw)

@@ -156,3 +156,85 @@ def test_topdown_env_class():
         assert tot > 1.0
     finally:
         env.close()
+
+
+def test_topdown_rgb_single_frame(descs):
+    """TopDownObservation (obs/top_down_obs.py:22-240; TopDownSingleFramePGDriveEnv, top_down_env.py:8-26): one RGB frame
+    [200, 200, 3] / 255 -- lane lines (35, 35, 35), the ego GREEN (50, 200, 0) at the centre heading up, the other vehicles BLUE
+    (100, 200, 255) over it, +-30 m, no route colouring, no history.  GPU vs the oracle's brute-force restatement over teacher-forced
+    steps with resets (edge pixels counted), known answers, and the env classes."""
+    n = 24
+    td = _abi.make_topdown_config(resolution=200, distance=30.0, mode=1)
+    torch, eng, ora, mb, sb = _setup(descs, n, td=td)
+    assert eng.img.shape == (n, 200, 200, 3)
+    ids = np.arange(n) % 8
+    ora.reset(ids); eng.reset(ids)
+    rng = np.random.default_rng(5)
+    f, i, ei = ora.get_state()
+    SF, SI = _abi.SF, _abi.SI
+    for k in range(1, 6):  # some waiting traffic moved into view, one of them overlapping the ego's box
+        th = f[SF["THETA"], :, 0]
+        fw, lt = (rng.uniform(6, 26, n), rng.uniform(-9, 9, n)) if k > 1 else (np.full(n, 3.0), np.full(n, 1.0))
+        f[SF["X"], :, k] = f[SF["X"], :, 0] + fw * np.cos(th) - lt * np.sin(th)
+        f[SF["Y"], :, k] = f[SF["Y"], :, 0] + fw * np.sin(th) + lt * np.cos(th)
+        f[SF["THETA"], :, k] = th + rng.uniform(-3.0, 3.0, n) * (k % 2)
+        f[SF["HX"], :, k] = f[SF["HY"], :, k] = 0.0
+        i[SI["STATUS"], :, k] = _abi.ST_PENDING
+    f32 = util.round_state_f32(f)
+    ora.set_state(f32, i, ei); eng.set_state(f32, i, ei)
+    GREEN, BLUE, LINE = (50 / 255, 200 / 255, 0.0), (100 / 255, 200 / 255, 1.0), (35 / 255,) * 3
+    tot = diff = 0
+    seen = dict(green=0, blue=0, line=0, resets=0)
+
+    def compare():
+        nonlocal tot, diff
+        g = eng.observe_topdown().cpu().numpy().astype(np.float64)
+        o = ora.observe_topdown()
+        px = np.round(g.reshape(-1, 3), 5)
+        allowed = {tuple(np.round(c, 5)) for c in (GREEN, BLUE, LINE, (0.0, 0.0, 0.0))}
+        assert {tuple(c) for c in np.unique(px, axis=0)} <= allowed
+        d = (np.abs(g - o) > 1e-6).any(axis=-1)
+        tot += d.size; diff += int(d.sum())
+        seen["green"] += int((np.abs(o - GREEN) < 1e-9).all(-1).sum()); seen["blue"] += int((np.abs(o - BLUE) < 1e-9).all(-1).sum())
+        seen["line"] += int((np.abs(o - LINE) < 1e-9).all(-1).sum())
+        return g
+
+    g = compare()
+    # the ego: a green box of its size at the centre, long axis up (3.33 px / m), partly covered by the blue vehicle 3 m ahead
+    c = 100
+    assert (np.abs(g[:, c + 4:c + 6, c - 2:c + 2] - GREEN) < 1e-6).all()  # behind the centre: ego only
+    area_g = (np.abs(g - GREEN) < 1e-6).all(-1).sum(axis=(1, 2))
+    sp0 = sb.spawns[ids * sb.V]
+    full = sp0["length"] * sp0["width"] * (200 / 60.0) ** 2
+    assert np.all(area_g < full + 8) and np.all(area_g > 0.3 * full)  # never more than its own box, some of it hidden by the other
+    for t in range(40):
+        act = util.driving_actions(rng, n)
+        act[:, 0, 1] = np.abs(act[:, 0, 1]) * 0.7 + 0.3
+        if t % 4 == 0:
+            act[::3, 0, 0] = 1.0
+        o_out = ora.step(act)
+        eng.step(torch.from_numpy(act).to(eng.device)); eng.sync()
+        seen["resets"] += int(o_out[2].sum())
+        f, i, ei = ora.get_state()
+        f32 = util.round_state_f32(f)
+        ora.set_state(f32, i, ei); eng.set_state(f32, i, ei)
+        compare()
+    print("top-down RGB frame: pixels", tot, "edge pixels that differ", diff, seen)
+    assert diff <= 2e-5 * tot and seen["green"] > 20000 and seen["blue"] > 5000 and seen["line"] > 100000 and seen["resets"] > 3
+    eng.close()
+    from pgdrive_amd.env import TopDownSingleFramePGDriveEnv, TopDownPGDriveEnvV2
+    env = TopDownSingleFramePGDriveEnv(dict(start_seed=1000, environment_num=2))
+    try:
+        assert env.observation_space.shape == (200, 200, 3)
+        o = env.reset()
+        assert o.shape == (200, 200, 3) and o.dtype == np.float32 and (np.abs(o[100, 100] - GREEN) < 1e-6).all()
+        for t in range(5):
+            o, r, d, info = env.step([0.0, 1.0])
+            assert env.observation_space.contains(o)
+    finally:
+        env.close()
+    env = TopDownPGDriveEnvV2(dict(start_seed=1000, environment_num=2))
+    try:
+        assert env.observation_space.shape == (84, 84, 5) and env.reset().shape == (84, 84, 5)
+    finally:
+        env.close()
