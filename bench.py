@@ -209,6 +209,10 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="plumbing tests: allow more ranks than GPUs (ranks share devices; needs --backend gloo)")
+    ap.add_argument("--graph", action="store_true",
+                    help="N > 1, gather pass: capture step + exchange of a whole action cycle (64 steps) in ONE HIP graph per rank and "
+                         "replay it (transport peer: device-side sequence numbers; RCCL transports: torch captures the collectives) -- "
+                         "the host then costs one launch per 64 steps instead of several calls per step")
     ap.add_argument("--corrupt-gather", action="store_true",
                     help="tests only: flip one value of the received rows before the gather's self-check (gather_ok must read false)")
     args = ap.parse_args(argv)
@@ -300,7 +304,8 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
     modes = ["replicas"] if world == 1 else (["replicas", "gather"] if args.mode == "both" else [args.mode])
     gatherer = None
     if "gather" in modes:
-        gatherer = pdist.StepGather(torch, dist, N, D, A, device=dev, transport=args.transport, engine_lib=eng.L)
+        gatherer = pdist.StepGather(torch, dist, N, D, A, device=dev, transport=args.transport, engine_lib=eng.L,
+                                    device_seq=bool(args.graph and args.transport == "peer"))
 
     if args.groups > 1:
         eng.set_groups(args.groups)
@@ -375,10 +380,23 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
             stride = PROF_STRIDE if timed >= 8 * PROF_STRIDE else (16 if timed >= 16 else 1)
             if profiled:
                 eng.profile_begin(timed // stride + 1, stride=stride)
+            graph, cyc = None, 0
+            if mode == "gather" and args.graph:
+                import math
+                cyc = math.gcd(timed, CYC)
+                if cyc % gatherer.nbuf == 0 and cyc >= gatherer.nbuf:
+                    graph = gatherer.capture_cycle([(lambda rows, a=actions[i]: eng.step_packed(a, rows)) for i in range(cyc)])
+                    fence()
             t0 = time.perf_counter()
-            for k in range(timed):
-                one_step(counter)
-                counter += 1
+            if graph is not None:  # one host call per cycle of `cyc` steps
+                for c in range(timed // cyc):
+                    graph.replay()
+                    gatherer.replayed()
+                counter += timed
+            else:
+                for k in range(timed):
+                    one_step(counter)
+                    counter += 1
             t_enq = time.perf_counter()  # every launch of the timed region has been enqueued: the host's share of the loop
             if mode == "gather":
                 gatherer.drain()
@@ -390,7 +408,7 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
                 t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 elapsed = float(t.item())
-            results[mode] = dict(elapsed=elapsed, prof=prof, host_enqueue_s=t_enq - t0)
+            results[mode] = dict(elapsed=elapsed, prof=prof, host_enqueue_s=t_enq - t0, graph_cycle=cyc if graph is not None else 0)
             if mode == "gather":
                 # self-check of the exchange, after the timed loop: every rank's checksum of the rows it produced against the
                 # checksum of what arrived for it (a transport that delivers wrong rows would otherwise still print a number)
@@ -489,6 +507,7 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
                     "link_bound_us": link_us, "ring_allgather_bound_us": ring_us, "k_step_us": k_us,
                     "host_enqueue_us_per_step": host_us,
                     "host_enqueue_us_per_step_replicas": (results["replicas"]["host_enqueue_s"] / timed * 1e6) if "replicas" in results else None,
+                    "hip_graph_steps_per_replay": results["gather"]["graph_cycle"] or None,
                     "predicted_floor_us_per_step": max(cands) if cands else None,
                     "predicted_ceiling_env_steps_per_s": per_step_units / (max(cands) * 1e-6) if cands else None,
                     "note": "the exchange of step t overlaps the kernels of step t + 1 (double-buffered): the step rate is bounded by the "

@@ -357,7 +357,10 @@ int pgd_observe_topdown(pgd_handle h, float* d_img /*[N,R,R,C]*/);
  *   create  -> export (handle blob, exchanged by the host, e.g. torch.distributed.all_gather_object) -> connect per peer
  *   per step: pgd_step_packed(d_rows = own slice of pgd_gather_buffer(buf)) ; pgd_gather_push(buf, seq)
  *   consumer: pgd_gather_wait(buf, seq) ... read the buffer ... pgd_gather_release(buf, seq)
- * All three are asynchronous on the given stream; a peer that never arrives sets the status word instead of hanging. */
+ * All three are asynchronous on the given stream; a peer that never arrives sets the status word instead of hanging.
+ * seq == 0 takes the sequence number from a per-buffer counter on the device (advanced by pgd_gather_release): the calls of a step
+ * are then identical every time, and  wait, release, pgd_step_packed, push  of a multiple of nbuf consecutive steps can be captured
+ * in one HIP graph (a handle uses either host-counted or device-side sequences, not both). */
 #define PGD_GATHER_HANDLE_BYTES 64
 typedef struct pgd_gather* pgd_gather_handle;
 int pgd_gather_create(int device, int world, int rank, int n_rows, int row_floats, int nbuf, pgd_gather_handle* out);

@@ -10,6 +10,10 @@
 //   k_peer_wait (consumer side) spins until flags[buf][p] >= seq for every peer p (system-scope loads);
 //   k_peer_release tells every peer that this rank has finished reading buffer `buf` (acks[buf][rank] = seq on the peer);
 //     a sender does not overwrite a peer's buffer before that ack (checked at the start of k_peer_push).
+// Sequence numbers either come with the call (seq > 0) or -- seq == 0 -- from a per-buffer counter on the device that the release
+// call advances (buf + 1, then + nbuf per use: what a host that counts steps would pass).  With device-side sequences the calls of a
+// step are the same every time, so  wait, release, pgd_step_packed, push  of nbuf (or any multiple of nbuf) consecutive steps can be
+// captured in ONE HIP graph and replayed: the host then costs one graph launch per cycle instead of four calls per step.
 // Spins are bounded: a peer that never arrives raises the error word instead of hanging the queue.
 #ifndef PGD_GATHER_H
 #define PGD_GATHER_H
@@ -31,6 +35,7 @@ struct pgd_gather {
   char* peer_base[PGD_GATHER_MAX_WORLD];   // mapped blocks (own entry = base)
   bool connected[PGD_GATHER_MAX_WORLD];
   int* counters;                           // [nbuf][world] block-arrival counters of k_peer_push (own, device)
+  int* dseq;                               // [4] device-side sequence of each buffer (seq == 0 calls): its last push, 0 = never used
   char** d_peer_base;                      // device copy of peer_base
 };
 
@@ -39,7 +44,9 @@ DEV void sys_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, _
 
 // grid = (blocks_per_peer, world); block (x, p) copies chunk x of the own slice into peer p's buffer
 __global__ __launch_bounds__(256) void k_peer_push(char* const* __restrict__ peer_base, char* base, int world, int rank, int buf, int nbuf,
-                                                    int seq, size_t buf_bytes, size_t slice_bytes, size_t ctl_off, int* counters) {
+                                                    int seq_arg, size_t buf_bytes, size_t slice_bytes, size_t ctl_off, int* counters,
+                                                    const int* __restrict__ dseq) {
+  const int seq = seq_arg > 0 ? seq_arg : dseq[buf];
   const int p = blockIdx.y;
   if (p == rank || peer_base[p] == nullptr) return;
   GatherCtl* my_ctl = reinterpret_cast<GatherCtl*>(base + ctl_off);
@@ -73,7 +80,8 @@ __global__ __launch_bounds__(256) void k_peer_push(char* const* __restrict__ pee
   }
 }
 
-__global__ void k_peer_wait(char* base, size_t ctl_off, int world, int rank, int buf, int seq) {
+__global__ void k_peer_wait(char* base, size_t ctl_off, int world, int rank, int buf, int seq_arg, const int* __restrict__ dseq) {
+  const int seq = seq_arg > 0 ? seq_arg : dseq[buf];  // (0: the buffer has never been pushed: nothing to wait for)
   GatherCtl* ctl = reinterpret_cast<GatherCtl*>(base + ctl_off);
   const int p = threadIdx.x;
   if (p >= world || p == rank) return;
@@ -83,11 +91,18 @@ __global__ void k_peer_wait(char* base, size_t ctl_off, int world, int rank, int
   __threadfence_system();  // acquire: the rows are read by later kernels of this stream
 }
 
-__global__ void k_peer_release(char* const* __restrict__ peer_base, size_t ctl_off, int world, int rank, int buf, int seq) {
+__global__ void k_peer_release(char* const* __restrict__ peer_base, size_t ctl_off, int world, int rank, int buf, int seq_arg, int nbuf,
+                               int* dseq) {
   const int p = threadIdx.x;
-  if (p >= world || p == rank || peer_base[p] == nullptr) return;
-  GatherCtl* peer_ctl = reinterpret_cast<GatherCtl*>(peer_base[p] + ctl_off);
-  sys_store(&peer_ctl->acks[buf][rank], seq);
+  const int seq = seq_arg > 0 ? seq_arg : dseq[buf];
+  if (seq > 0 && p < world && p != rank && peer_base[p] != nullptr) {
+    GatherCtl* peer_ctl = reinterpret_cast<GatherCtl*>(peer_base[p] + ctl_off);
+    sys_store(&peer_ctl->acks[buf][rank], seq);
+  }
+  if (seq_arg <= 0) {  // device-side sequences: this buffer's next use is its next generation
+    __syncthreads();
+    if (threadIdx.x == 0) dseq[buf] = seq == 0 ? buf + 1 : seq + nbuf;
+  }
 }
 
 extern "C" {
@@ -114,6 +129,8 @@ int pgd_gather_create(int device, int world, int rank, int n_rows, int row_float
   HIPCHK(hipMemset(g->base, 0, g->total_bytes));
   HIPCHK(hipMalloc((void**)&g->counters, sizeof(int) * 4 * PGD_GATHER_MAX_WORLD));
   HIPCHK(hipMemset(g->counters, 0, sizeof(int) * 4 * PGD_GATHER_MAX_WORLD));
+  HIPCHK(hipMalloc((void**)&g->dseq, sizeof(int) * 4));
+  HIPCHK(hipMemset(g->dseq, 0, sizeof(int) * 4));
   HIPCHK(hipMalloc((void**)&g->d_peer_base, sizeof(char*) * PGD_GATHER_MAX_WORLD));
   g->peer_base[rank] = g->base;
   g->connected[rank] = true;
@@ -154,31 +171,31 @@ int pgd_gather_connect(pgd_gather_handle g, int peer, const void* handle_bytes) 
 }
 
 int pgd_gather_push(pgd_gather_handle g, int buf, int seq, void* hip_stream) {
-  if (!g || buf < 0 || buf >= g->nbuf || seq <= 0) return PGD_ERR_ARG;
+  if (!g || buf < 0 || buf >= g->nbuf || seq < 0) return PGD_ERR_ARG;
   if (g->world == 1) return PGD_OK;
   const size_t slice = (size_t)g->n_rows * g->row_floats * 4;
   int bpp = (int)((slice / 16 + 256 * 8 - 1) / (256 * 8));  // ~8 x 16 B per thread
   bpp = bpp < 1 ? 1 : (bpp > 64 ? 64 : bpp);
   hipLaunchKernelGGL(k_peer_push, dim3(bpp, g->world), dim3(256), 0, (hipStream_t)hip_stream, g->d_peer_base, g->base, g->world,
-                     g->rank, buf, g->nbuf, seq, g->buf_bytes, slice, g->ctl_off, g->counters);
+                     g->rank, buf, g->nbuf, seq, g->buf_bytes, slice, g->ctl_off, g->counters, g->dseq);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }
 
 int pgd_gather_wait(pgd_gather_handle g, int buf, int seq, void* hip_stream) {
-  if (!g || buf < 0 || buf >= g->nbuf || seq <= 0) return PGD_ERR_ARG;
+  if (!g || buf < 0 || buf >= g->nbuf || seq < 0) return PGD_ERR_ARG;
   if (g->world == 1) return PGD_OK;
   hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(PGD_GATHER_MAX_WORLD), 0, (hipStream_t)hip_stream, g->base, g->ctl_off, g->world, g->rank,
-                     buf, seq);
+                     buf, seq, g->dseq);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }
 
 int pgd_gather_release(pgd_gather_handle g, int buf, int seq, void* hip_stream) {
-  if (!g || buf < 0 || buf >= g->nbuf || seq <= 0) return PGD_ERR_ARG;
+  if (!g || buf < 0 || buf >= g->nbuf || seq < 0) return PGD_ERR_ARG;
   if (g->world == 1) return PGD_OK;
   hipLaunchKernelGGL(k_peer_release, dim3(1), dim3(PGD_GATHER_MAX_WORLD), 0, (hipStream_t)hip_stream, g->d_peer_base, g->ctl_off,
-                     g->world, g->rank, buf, seq);
+                     g->world, g->rank, buf, seq, g->nbuf, g->dseq);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }
@@ -198,6 +215,7 @@ int pgd_gather_destroy(pgd_gather_handle g) {
     if (p != g->rank && g->peer_base[p]) (void)hipIpcCloseMemHandle(g->peer_base[p]);
   (void)hipFree(g->base);
   (void)hipFree(g->counters);
+  (void)hipFree(g->dseq);
   (void)hipFree(g->d_peer_base);
   free(g);
   return PGD_OK;

@@ -66,9 +66,12 @@ class StepGather:
         obs, reward, done = g.result(b)                              # [world * n_local, ...] once the exchange has landed
     """
     def __init__(self, torch, dist, n_local, obs_dim, num_agents=1, device="cpu", transport="collective", nbuf=2,
-                 engine_lib=None, exchange_when_alone=False):
+                 engine_lib=None, exchange_when_alone=False, device_seq=False):
         """exchange_when_alone: run the collective even in a world of one rank (the single-GPU box's RCCL check: communicator
-        set-up, in-place all_gather / gather launches, stream ordering against k_step); by default one rank exchanges nothing."""
+        set-up, in-place all_gather / gather launches, stream ordering against k_step); by default one rank exchanges nothing.
+        device_seq (transport "peer"): the sequence numbers of the exchange live on the device, so the calls of a step are the
+        same every time and capture_cycle() can put whole cycles of steps into one HIP graph."""
+        self.device_seq = bool(device_seq)
         self.torch, self.dist = torch, dist
         on = dist is not None and dist.is_initialized()
         self.world = dist.get_world_size() if on else 1
@@ -118,7 +121,9 @@ class StepGather:
     def step(self, produce):
         b = self.k % self.nbuf
         self.wait(b)  # buffer b is about to be overwritten: its previous exchange must have completed
-        if self.transport == "peer" and self.k >= self.nbuf:
+        if self.transport == "peer" and self.device_seq:
+            self.peer.release(b, 0)  # ack of the buffer's previous generation (none yet: only the counter moves on)
+        elif self.transport == "peer" and self.k >= self.nbuf:
             self.peer.release(b, self.k + 1 - self.nbuf)  # the readers of the previous generation were enqueued before this
         produce(self.send[b])
         if self.transport == "collective":
@@ -126,8 +131,8 @@ class StepGather:
         elif self.transport == "root":
             self.pending[b] = self.dist.gather(self.send[b], gather_list=self.parts[b], dst=0, async_op=True)
         elif self.transport == "peer":
-            self.peer.push(b, self.k + 1)
-            self.pending[b] = self.k + 1
+            self.peer.push(b, 0 if self.device_seq else self.k + 1)
+            self.pending[b] = 0 if self.device_seq else self.k + 1
         self.k += 1
         return b
 
@@ -144,6 +149,34 @@ class StepGather:
     def drain(self):
         for b in range(self.nbuf):
             self.wait(b)
+
+    def capture_cycle(self, produces):
+        """One HIP graph over len(produces) consecutive steps (a multiple of nbuf; `produces[i]` writes the rows of step i, e.g.
+        `lambda rows: eng.step_packed(actions[i], rows)` with a STATIC action tensor): step kernel, exchange and the waits between
+        them are enqueued by one `graph.replay()` per cycle instead of four or five host calls per step -- at 18 us per step the
+        host is otherwise the slowest stage of the pipeline (bench.py `gather_model.host_enqueue_us_per_step`).  Transport "peer"
+        with device_seq=True (kernels only), or an RCCL collective (torch captures NCCL / RCCL collectives; every exchange of the
+        cycle is complete when the graph ends, so cycles do not overlap each other).  Returns the graph; the step counter moves on
+        by one cycle per replay."""
+        t = self.torch
+        n = len(produces)
+        assert n > 0 and n % self.nbuf == 0 and self.k % self.nbuf == 0, "whole buffer rounds only"
+        assert self.transport != "peer" or self.device_seq, "transport peer: construct with device_seq=True"
+        self.drain()
+        dev = self.recv[0].device
+        t.cuda.synchronize(dev)
+        g = t.cuda.CUDAGraph()
+        with t.cuda.graph(g):
+            for pr in produces:
+                self.step(pr)
+            if self.transport != "peer":
+                self.drain()  # the collectives' own streams rejoin the capture
+        self._cycle = n
+        return g
+
+    def replayed(self, n_cycles=1):
+        """Bookkeeping after `graph.replay()`: the captured steps ran again."""
+        self.k += n_cycles * self._cycle
 
     def result(self, b):
         """(obs, reward, done) of all ranks' envs; with transport "root" on rank 0 only (the other ranks get their own rows)."""

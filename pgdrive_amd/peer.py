@@ -53,7 +53,10 @@ class PeerGather:
     def release(self, buf, seq):
         """Tell the senders that this rank has finished with generation `seq` of buffer `buf`.  Called on the consumer's stream
         after its reads have been enqueued (StepGather does it when the buffer is about to be reused): stream order makes the
-        ack follow the reads."""
+        ack follow the reads.  seq = 0: device-side sequences (the call also advances the buffer's counter; see pgd_gather.h)."""
+        if seq == 0:
+            self._chk(self.L.pgd_gather_release(self.h, buf, 0, self._stream()), "pgd_gather_release")
+            return
         if seq > self.released[buf]:
             self._chk(self.L.pgd_gather_release(self.h, buf, seq, self._stream()), "pgd_gather_release")
             self.released[buf] = seq

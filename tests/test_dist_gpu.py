@@ -170,6 +170,23 @@ def test_bench_spawns_its_own_ranks():
 
 
 @pytest.mark.timeout(900)
+def test_bench_gather_in_a_hip_graph():
+    """`bench.py --gpus 2 --transport peer --graph`: the gather pass replays one HIP graph per 8 steps (gcd of the 24 timed steps and
+    the 64-step action cycle) on every rank; the self-check after the timed loop passes and the line says how the steps were launched."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--backend", "gloo",
+                          "--exact", "--steps", "24", "--warmup", "8", "--envs", "256", "--no-cpu-baseline", "--transport", "peer", "--graph"],
+                         capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value_mode"] == "gather" and d["gather_ok"] is True
+    assert d["gather_model"]["hip_graph_steps_per_replay"] == 8
+    assert "direct peer writes" in d["config"]["parallelism"]
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("transport", ["root", "collective"])
 def test_bench_gather_self_check_sees_a_damaged_row(transport):
     """A transport that delivers wrong rows must not print a clean line: one value of the received rows is changed before the
@@ -207,3 +224,147 @@ def test_bench_default_run_is_steady_state_and_reproducible_from_events():
     assert rows["c3_respawn"]["roofline"]["k_step_ms"] > r["k_step_ms"]  # every traffic vehicle drives: a heavier step
     assert rows["c5_8x72"]["workload"].startswith("C5: 4096 envs/GPU x 8 agents") and rows["c5_8x72"]["active_agents_mean"] > 1
     assert all(0 < x["roofline"]["frac"] <= x["roofline"]["frac_nominal"] for x in rows.values())
+
+
+def _graph_worker(rank, world, port, n_total, cycle, n_cycles, q, use_graph):
+    """`n_cycles` cycles of `cycle` steps with fixed per-position actions; rank 0 reports the rows of the last nbuf steps of every
+    cycle.  use_graph: peer transport with device-side sequences, every cycle ONE graph replay; else eager steps."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from pgdrive_amd import bank, mapdata, scenario
+    from pgdrive_amd import dist as pdist
+    from pgdrive_amd.engine import Engine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    descs = bank.get_descriptions(range(1000, 1004))
+    mb = mapdata.MapBank(descs)
+    sb = scenario.ScenarioBank(descs, [d["seed"] for d in descs], num_traffic=16)
+    lo, hi = pdist.shard_range(n_total, rank, world)
+    n = hi - lo
+    cfg = _abi.make_config(n, num_traffic=16, num_lasers=240, seed=5, env_base=lo)
+    eng = Engine(cfg, mb, sb, device=0)
+    eng.reset(pdist.scenario_ids_for(lo, hi, 4))
+    g = pdist.StepGather(torch, dist if world > 1 else None, n, eng.D, eng.A, device=eng.device, transport="peer", engine_lib=eng.L,
+                         device_seq=use_graph)
+    rng = np.random.default_rng(0)
+    a = rng.normal(0.0, 0.3, size=(cycle, n_total, 1, 2)).astype(np.float32)
+    a[..., 1] = 1.0
+    acts = [torch.from_numpy(a[i, lo:hi].copy()).to(eng.device) for i in range(cycle)]  # static tensors: the graph keeps their addresses
+    produces = [(lambda rows, t=t: eng.step_packed(t, rows)) for t in acts]
+    outs = []
+    with torch.cuda.stream(eng.stream):
+        graph = g.capture_cycle(produces) if use_graph else None
+        for c in range(n_cycles):
+            if use_graph:
+                graph.replay()
+                g.replayed()
+            else:
+                for pr in produces:
+                    g.step(pr)
+            last = []
+            for j in range(g.nbuf):  # the buffers hold the last nbuf steps of the cycle
+                b = (cycle - g.nbuf + j) % g.nbuf
+                obs, rew, done = g.result(b)
+                torch.cuda.synchronize()
+                last.append((obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), done.cpu().numpy().copy()))
+            outs.append(last)
+        ok, detail = g.validate(produces[0])  # the eager path on the same handle, after the replays (a step of its own)
+    if rank == 0:
+        q.put((outs, ok, g.peer.status() if g.peer is not None else 0))
+    g.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+@pytest.mark.timeout(900)
+def test_peer_gather_cycle_in_one_hip_graph():
+    """Device-side sequence numbers make the calls of a step identical every time: wait, release, pgd_step_packed and push of a
+    whole cycle of steps (8 = 4 x nbuf) are captured in ONE HIP graph per rank and replayed; two ranks (sharing the box's GPU, HIP IPC
+    between them) then deliver exactly the rows a single eager process computes, cycle after cycle -- flow control (acks), flags and
+    double buffering included -- and the eager self-check still passes on the same handle afterwards."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    n_total, cycle, n_cycles = 64, 8, 6
+    res = {}
+    for world, use_graph, port in ((1, False, 29741), (2, True, 29743)):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_graph_worker, args=(r, world, port, n_total, cycle, n_cycles, q, use_graph)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res[world] = q.get(timeout=600)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    (one, ok1, _), (two, ok2, status) = res[1], res[2]
+    assert ok1 and ok2 and status == 0
+    n_done = 0
+    for c1, c2 in zip(one, two):
+        for (o1, r1, d1), (o2, r2, d2) in zip(c1, c2):
+            assert o1.shape == o2.shape == (n_total, 1, 274)
+            assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
+            n_done += int(d1.sum())
+    assert n_done > 0
+
+
+def _rccl_graph_worker(port, transport, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from pgdrive_amd import bank, mapdata, scenario
+    from pgdrive_amd import dist as pdist
+    from pgdrive_amd.engine import Engine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    descs = bank.get_descriptions(range(1000, 1004))
+    mb = mapdata.MapBank(descs)
+    sb = scenario.ScenarioBank(descs, [d["seed"] for d in descs], num_traffic=16)
+    n = 128
+    cfg = _abi.make_config(n, num_traffic=16, num_lasers=240, seed=5)
+    eng, ref = Engine(cfg, mb, sb, device=0), Engine(cfg, mb, sb, device=0)
+    eng.reset(np.arange(n) % 4)
+    ref.reset(np.arange(n) % 4)
+    g = pdist.StepGather(torch, dist, n, eng.D, eng.A, device=eng.device, transport=transport, engine_lib=eng.L, exchange_when_alone=True)
+    rng = np.random.default_rng(0)
+    acts = [torch.from_numpy(rng.uniform(-1, 1, size=(n, 1, 2)).astype(np.float32)).cuda() for _ in range(8)]
+    with torch.cuda.stream(eng.stream):
+        graph = g.capture_cycle([(lambda rows, t=t: eng.step_packed(t, rows)) for t in acts])
+        for c in range(4):
+            graph.replay()
+            g.replayed()
+        torch.cuda.synchronize()
+        obs, rew, done = g.result(1)
+    for c in range(4):
+        for t in acts:
+            o_ref, r_ref, d_ref, _ = ref.step(t)
+    ref.sync()
+    q.put((bool(torch.equal(obs[:n], o_ref)), bool(torch.equal(rew[:n], r_ref)), bool(torch.equal(done[:n], d_ref > 0)), g.describe()))
+    g.close()
+    eng.close()
+    ref.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("transport", ["collective", "root"])
+def test_rccl_exchange_captured_in_a_hip_graph_on_one_rank(transport):
+    """`bench.py --graph` with the RCCL transports: torch captures the collective launched by RCCL together with pgd_step_packed --
+    eight steps per graph, replayed four times in a world of one rank (all the box allows); the rows of the last step equal an
+    eager engine's."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_graph_worker, args=(dict(collective=29751, root=29753)[transport], transport, q))
+    p.start()
+    same_obs, same_rew, same_done, desc = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert same_obs and same_rew and same_done and "RCCL" in desc
