@@ -208,8 +208,12 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t, ui
   const int tbw = (tw + 7) >> 3;
   // texel class under pixel (pi, pj): the road network around the CURRENT ego pose (right = heading rotated by +90 deg in the
   // engine's x / y frame), nearest texel of the scenario's raster
-  auto texel_addr = [&](int pi, int pj, bool on, bool& in) -> long long {
-    const float fw = ((float)R * 0.5f - (float)pi - 0.5f) * inv_s, rg = ((float)pj + 0.5f - (float)R * 0.5f) * inv_s;
+  // (multi-channel mode: the reference renders the road channel at 2 R and pygame.transform.smoothscale halves it,
+  // top_down_obs_multi_channel.py:214-217 -- for an exact halving that filter is the 2 x 2 area average -- so a pixel is the mean of
+  // four samples at (+-1/4, +-1/4) pixel around its centre: anti-aliased greys on the edges of lines and route lanes instead of a
+  // three-valued channel.  The RGB frame is not rescaled upstream: one sample at the centre.)
+  auto texel_addr = [&](int pi, int pj, bool on, bool& in, float oi = 0.0f, float oj = 0.0f) -> long long {
+    const float fw = ((float)R * 0.5f - (float)pi - 0.5f - oi) * inv_s, rg = ((float)pj + 0.5f + oj - (float)R * 0.5f) * inv_s;
     const float wx = eg0.x + fw * eg0.z - rg * eg0.w, wy = eg0.y + fw * eg0.w + rg * eg0.z;
     const int ix = (int)floorf((wx - m_ox) * (1.0f / TD_TEXEL)), iy = (int)floorf((wy - m_oy) * (1.0f / TD_TEXEL));
     in = on && ix >= 0 && iy >= 0 && ix < tw && iy < th;
@@ -232,8 +236,18 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t, ui
           const int i = row0 + ty * 8 + (lane >> 3), j = tx * 8 + (lane & 7);
           const bool on = q < n_tiles && i < row1 && j < R;
           bool in;
-          v[u] = tex[texel_addr(i, j, on, in)];
-          if (!in) v[u] = 0;
+          if (t.rgb) {
+            v[u] = tex[texel_addr(i, j, on, in)];
+            if (!in) v[u] = 0;
+          } else {  // four sub-samples: low nibble = how many hit a line, high nibble = how many a route lane
+            int acc = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int c = tex[texel_addr(i, j, on, in, (q & 2) ? 0.25f : -0.25f, (q & 1) ? 0.25f : -0.25f)];
+              acc += !in ? 0 : (c == 2 ? 1 : (c == 1 ? 16 : 0));
+            }
+            v[u] = acc;
+          }
           pix[u] = on ? i * R + j - c0 : -1;
         }
 #pragma unroll
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t, ui
         const int n_here = min(64, c1 - p0);
         const int cls = lane < n_here ? (int)s_cls[p0 - c0 + lane] : 0;
         if (t.rgb) { const float g = cls == 2 ? TD_RGB_LINE : 0.0f; so[lane * 3] = g; so[lane * 3 + 1] = g; so[lane * 3 + 2] = g; }
-        else so[lane * C] = cls == 2 ? TD_LINE : (cls == 1 ? TD_NAVI : 0.0f);
+        else so[lane * C] = (float)(cls & 15) * (0.25f * TD_LINE) + (float)(cls >> 4) * (0.25f * TD_NAVI);
         row_sync<true>();  // the wave's own LDS traffic only
         const int nf = n_here * C;
         float* dst = out + (size_t)p0 * C;

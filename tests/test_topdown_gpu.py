@@ -57,13 +57,16 @@ def test_topdown_parity_with_the_oracle(descs):
         g = eng.observe_topdown().cpu().numpy().astype(np.float64)
         o = ora.observe_topdown()
         assert g.shape == o.shape == (n, 84, 84, 5)
-        assert set(np.unique(np.round(g[..., 0], 6))) <= {0.0, round(TD_LINE, 6), round(TD_NAVI, 6)}
+        # road channel: the 2 x 2 area average of four samples, each line / route lane / nothing
+        levels = {round((k * TD_LINE + j * TD_NAVI) / 4, 6) for k in range(5) for j in range(5 - k)}
+        assert set(np.unique(np.round(g[..., 0], 6))) <= levels
         assert set(np.unique(g[..., 1])) <= {0.0, 1.0}
         assert set(np.unique(np.round(g[..., 2:], 6))) <= {0.0, round(TD_VEH, 6)}
         d = np.abs(g - o) > 1e-6
         tot += d.size
         diff += int(d.sum())
-        seen["line"] += int((o[..., 0] == TD_LINE).sum()); seen["navi"] += int((o[..., 0] == TD_NAVI).sum())
+        seen["line"] += int((np.abs(o[..., 0] - TD_LINE) < 1e-9).sum()); seen["navi"] += int((np.abs(o[..., 0] - TD_NAVI) < 1e-9).sum())
+        seen["edge"] = seen.get("edge", 0) + int(((o[..., 0] > 0) & (np.abs(o[..., 0] - TD_LINE) > 1e-9) & (np.abs(o[..., 0] - TD_NAVI) > 1e-9)).sum())
         seen["veh"] += int((o[..., 2] > 0).sum()); seen["past"] += int(o[..., 1].sum())
         seen["old_frames"] += int((np.abs(o[..., 2] - o[..., 4]) > 0).any(axis=(1, 2)).sum())
         return g
@@ -85,7 +88,7 @@ def test_topdown_parity_with_the_oracle(descs):
         compare()
     print("top-down parity: pixels", tot, "edge pixels that differ", diff, seen)
     assert diff <= 2e-5 * tot
-    assert seen["line"] > 100000 and seen["navi"] > 500000 and seen["veh"] > 5000 and seen["past"] > 2000
+    assert seen["line"] > 20000 and seen["navi"] > 400000 and seen["edge"] > 100000 and seen["veh"] > 5000 and seen["past"] > 2000
     assert seen["old_frames"] > 100 and seen["resets"] > 5
     eng.close()
 
@@ -102,7 +105,7 @@ def test_topdown_known_answers(descs):
     ora.reset(ids)
     g = eng.observe_topdown().cpu().numpy()
     c = 42
-    assert np.allclose(g[:, c, c, 0], TD_NAVI, atol=1e-6) or (np.isin(np.round(g[:, c, c, 0], 5), [round(TD_NAVI, 5), round(TD_LINE, 5)])).all()
+    assert (g[:, c, c, 0] >= 0.25 * TD_LINE - 1e-6).all()  # on its route: route grey, or a mix with a lane line under the car
     assert (g[:, c - 1:c + 1, c - 1:c + 1, 2:] == 0).all()
     assert (g[..., 2] == g[..., 3]).all() and (g[..., 3] == g[..., 4]).all()
     assert (g[..., 1].sum(axis=(1, 2)) == 1).all() and (g[:, c, c, 1] == 1).all()
