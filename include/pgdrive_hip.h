@@ -244,7 +244,11 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* h_scen, int n_scen, c
  * env e starts scenario h_scen_ids[i]; writes the first observation.  d_obs may be NULL. */
 int pgd_reset(pgd_handle h, const int32_t* h_env_ids, const int32_t* h_scen_ids, int n, float* d_obs /*[N,A,D]*/);
 
-/* Replaces env.step(action) (envs/base_env.py:184-224, 303-344) for all N envs.  Asynchronous on the stream. */
+/* Replaces env.step(action) (envs/base_env.py:184-224, 303-344) for all N envs.  Asynchronous on the stream.
+ * Multi-agent engines: the row of a slot that is not due in this step (no agent, or an agent that did not report) reads zero.  The
+ * engine writes such a row once and remembers that it did, per observation buffer (pointer and row stride of the last call that
+ * wrote rows: the same rule for pgd_reset / pgd_observe / pgd_step_packed); a caller that scribbles over rows it was handed must not
+ * expect them to be zeroed again while it keeps passing the same buffer -- pass another buffer, or clear the rows itself. */
 int pgd_step(pgd_handle h, const float* d_actions /*[N,A,2]*/, float* d_obs /*[N,A,D]*/, float* d_reward /*[N,A]*/,
              uint8_t* d_done /*[N,A]*/, uint32_t* d_flags /*[N,A]*/);
 
