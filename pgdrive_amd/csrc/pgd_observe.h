@@ -182,8 +182,19 @@ DEV void state_block(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const A
     row[o_ego + 6 + KM] = clipf(sp.length / 10.0f, 0.0f, 1.0f);
     row[o_ego + 6 + KM + 1] = clipf(sp.width / 2.5f, 0.0f, 1.0f);
   }
-  // one lane per float; fewer than 18 cooperating threads (k_observe_env: a few lanes per agent) take several floats each
-  for (int q = tid; q < 18; q += nt) {
+  // one lane per float.  Fewer than 18 cooperating threads (the multi-agent observation: 64 / A lanes per agent) would run the
+  // whole branch ladder below once per round of nt floats; they take the eight ego floats in the loop and the navigation block as
+  // two whole check points (thread 0 and 1, five floats each: one evaluation instead of ten that keep one value each)
+  const int n_loop = nt < 18 ? 8 : 18;
+  if (nt < 18 && !toll)
+    for (int which = tid; which < 2; which += nt) {
+      const LaneNav nvw = mv.lnav()[state_lane_of(ag, 8 + 5 * which)];
+      float out[5];
+      navi_info_for(nvw, mv.lane_width(), ag.cur_n, px, py, hx, hy, out);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) row[o_navi + 5 * which + c] = out[c];
+    }
+  for (int q = tid; q < n_loop; q += nt) {
     // every lane fetches the one lane record its float needs BEFORE the branch ladder, so the reads overlap instead of
     // queueing behind each other branch by branch: heading_diff -> last lane of the current road; navi -> first lanes
     const int lid = state_lane_of(ag, q);
@@ -633,6 +644,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   }
   if (d.rowz && tid == 0 && not_due != known_zero) d.rowz[e] = not_due;
   row_sync<true>();
+  PHASE_MARK(20);  // env obs: loads, publish, state blocks, lists, zero rows
   if (NL <= 0) return;
   // PGD_MA_OTHERS_STATE (LidarStateObservationMARound): a neighbour row is the neighbour's own state vector; the ranks found by
   // the pair phase are parked in LDS (slot, speed as the observer sees it) and the vectors are written by a last phase below
@@ -662,6 +674,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     const int P = (g1 - g0) * nB;
     for (int k = lane; k < (g1 - g0) * NL; k += WAVE) s_minb[k] = __float_as_uint(1.0f);
     row_sync<true>();  // the round belongs to this wave alone
+    PHASE_MARK(21);  // env obs: per-beam minima initialised
     for (int q0 = 0; q0 < P; q0 += WAVE) {
       const int pq = q0 + lane;
       const bool pv = pq < P;
@@ -715,6 +728,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
         rDist[pq] = (in && is_vehicle) ? dist : __builtin_inff();
         rSpd[pq] = spd;
       }
+      PHASE_MARK(22);  // env obs: pairs (broad phase, windows)
       int inc = cnt;  // inclusive prefix sum of the window sizes over the wave
 #pragma unroll
       for (int sh = 1; sh < WAVE; sh <<= 1) {
@@ -776,6 +790,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
       }
       row_sync<true>();
     }
+    PHASE_MARK(23);  // env obs: incidences cast
     // neighbour rows (lidar.py:55-77: by centre distance, stable in slot order); the multi-agent default observes none
     if (NO > 0)
       for (int pq = lane; pq < P; pq += WAVE) {
@@ -814,6 +829,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
       obs[(size_t)e * d.ostride + (size_t)ga * D + o_oth + (oth ? o_oth : 4) * NO + i] = lidar_noise(d, e, ga, tick, i, __uint_as_float(s_minb[k]));
     }
     row_sync<true>();
+    PHASE_MARK(24);  // env obs: neighbour rows, lidar rows written
   }
   if (oth) {  // the neighbours' state vectors, every observer at once (the lane groups of the state phase)
     __syncthreads();

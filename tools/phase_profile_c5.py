@@ -23,7 +23,7 @@ eng.reset(np.arange(N) % len(sb.scenarios))
 rng = np.random.default_rng(0)
 acts = torch.from_numpy(rng.uniform(-1, 1, size=(64, N, A, 2)).astype(np.float32)).cuda()
 names = ['load', 'trig+snap', 'policy', 'dynamics', 'crash', 'linetest', 'tail_end', 'reset', 'store', 'i_route', 'i_search', 'i_lc', 'i_pid', 'ld_stage', 'obs',
-         'WALL', 'as_route', 'as_getlane', 'as_local', 'as_side', 'o_pub', 'o_compact', 'o_state', 'o_neigh', 'o_lidar', 'as_rest', 'm_reward', 'm_respawn', 'ko_load', 'KO_WALL']
+         'WALL', 'as_route', 'as_getlane', 'as_local', 'as_side', 'eo_head', 'eo_init', 'eo_pairs', 'eo_cast', 'eo_rows', 'as_rest', 'm_reward', 'm_respawn', 'ko_load', 'KO_WALL']
 out = (C.c_ulonglong * 64)()
 with torch.cuda.stream(eng.stream):
     for k in range(1500): eng.step(acts[k % 64])
