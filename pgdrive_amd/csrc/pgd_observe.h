@@ -824,6 +824,13 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
           w[0] = w[1] = w[2] = w[3] = 0.0f;
         }
       }
+    if (NL >= 2 * WAVE) {  // long fans observer by observer: no division per element (240 beams: 116 -> 123 M env-steps/s at 8 agents)
+      for (int qa = 0; qa < g1 - g0; ++qa) {
+        const int ga = wList[g0 + qa];
+        float* dst = obs + (size_t)e * d.ostride + (size_t)ga * D + o_oth + (oth ? o_oth : 4) * NO;
+        for (int i = lane; i < NL; i += WAVE) dst[i] = lidar_noise(d, e, ga, tick, i, __uint_as_float(s_minb[qa * NL + i]));
+      }
+    } else  // short fans flat over (observer, beam): a round per observer would leave most lanes of its second round idle
     for (int k = lane; k < (g1 - g0) * NL; k += WAVE) {
       const int qa = k / NL, i = k - qa * NL, ga = wList[g0 + qa];
       obs[(size_t)e * d.ostride + (size_t)ga * D + o_oth + (oth ? o_oth : 4) * NO + i] = lidar_noise(d, e, ga, tick, i, __uint_as_float(s_minb[k]));
