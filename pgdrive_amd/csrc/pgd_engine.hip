@@ -1187,6 +1187,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_observe_env(PgdDev d, float* __re
   if (FIX) write_fixed_config<true, true, false>(d);
   extern __shared__ unsigned s_minb_dyn[];
   __shared__ ObsEnvLds<NW> M;
+  PHASE_INIT();  // (profile builds: the marks of observe_env_body count from here)
   observe_env_body<NW, !FIX>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);
 }
 
