@@ -101,9 +101,6 @@ DEV LaneMap lane_map(const PgdDev& d, int unit, int n_units) {
 
 
 #define FUSE_MAX_AGENTS 8
-#ifndef PGD_LINETEST_WAVE_MAX
-#define PGD_LINETEST_WAVE_MAX 8  // multi-agent line / sidewalk test with fewer than four lanes per agent: up to this many agents one by one by the whole wave
-#endif
 // first 64 bytes of a spawn record (everything but the route arrays) into a local copy; the copy is only ever read by field, so it
 // lives in registers and the fields nobody reads cost nothing
 DEV void spawn_head_load(const pgd_spawn* sp, pgd_spawn& out) {
@@ -458,38 +455,60 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // Chunks of 12 agents bound the list (64 bodies x 12); it lives where the IDM search keeps its lane data (no IDM traffic here).
     const bool by_mask = ONE_ENV && MARL && !OBJ && A > g.SUB;
     if (by_mask) {
-      unsigned short* plist = reinterpret_cast<unsigned short*>(&S.lon[0]);  // <= 768 pairs: (body << 8) | agent
+      // UNORDERED pairs of the bodies in the world: (i, j) is needed when either drove as an agent this step, and one verdict
+      // serves both (the reach test and the separating-axis test are symmetric).  The bodies are compacted into a list of n;
+      // round r pairs position i with position (i + r) mod n, r = 1 .. n / 2 (every unordered pair once; the last round of an
+      // even n only for i < n / 2), and 64 / n rounds run side by side in the wave: 30 bodies take 8 iterations of the reach
+      // test where a loop over the agents inside every body lane took 30.
+      constexpr int CAP = 736;  // pairs the list holds (the LDS of the IDM search's lane data, unused here; the body list behind it)
+      unsigned short* plist = reinterpret_cast<unsigned short*>(&S.lon[0]);
+      unsigned char* bl = reinterpret_cast<unsigned char*>(plist + CAP);  // [64]: slot | drove-as-agent << 7
       const bool body = valid && leader && S.present[slot] != 0;
-      unsigned long long agents_todo = __ballot(leader && valid && s < A && acting);
-      const Obb me = snap_obb(S, slot);
-      const float my_trav = sub_ok ? SUBP.trav[slot] : 0.0f;
-      const float my_rad = me.hl + (me.hw < 0.0f ? 0.0f : me.hw);
-      while (agents_todo != 0ull) {
-        unsigned long long within = 0ull;  // agents of this chunk within reach of my body
-        if (lane == 0) s_aux = 0;  // (the parking pool is loaded into s_aux later in the step)
-        for (int q = 0; q < 12 && agents_todo != 0ull; ++q) {
-          const int a = __builtin_ctzll(agents_todo) / g.SUB;  // the agent's first lane -> its slot (one env per wave)
-          agents_todo &= agents_todo - 1ull;
-          const Obb ag = snap_obb(S, a);  // (the same address in every lane: broadcast reads)
-          const float ag_trav = sub_ok ? SUBP.trav[a] : 0.0f;
-          const float reach = my_rad + ag.hl + ag.hw + my_trav + ag_trav + 0.01f;
-          const float ddx = ag.cx - me.cx, ddy = ag.cy - me.cy;
-          if (body && a != s && !(ddx * ddx + ddy * ddy > reach * reach)) within |= 1ull << a;
-        }
+      const unsigned long long bm = __ballot(body);
+      const int n = __popcll(bm);
+      const bool any_agent = __ballot(body && s < A && acting) != 0ull;
+      if (n >= 2 && any_agent) {
+        if (body) bl[__popcll(bm & ((1ull << lane) - 1ull))] = (unsigned char)(slot | ((s < A && acting) ? 0x80 : 0));
         step_sync();
-        const int mine = __popcll(within);
-        int at = mine > 0 ? atomicAdd(&s_aux, mine) : 0;
-        for (unsigned long long w = within; w != 0ull; w &= w - 1ull) plist[at++] = (unsigned short)((slot << 8) | __builtin_ctzll(w));
-        step_sync();
-        const int n_pairs = s_aux;
-        for (int p0 = 0; p0 < n_pairs; p0 += WAVE) {
-          const int p = p0 + lane;
-          if (p < n_pairs) {
-            const int pr = plist[p], bs = pr >> 8, as = pr & 0xff;
-            if (pair_touch(bs, as, snap_obb(S, bs), sub_ok ? SUBP.trav[bs] : 0.0f, snap_obb(S, as), sub_ok ? SUBP.trav[as] : 0.0f)) s_hit[as] = 1;
+        const int K = n <= WAVE / 2 ? WAVE / n : 1, half = n / 2;
+        const int k = lane / n, i = lane - k * n;
+        const bool lane_on = k < K;
+        const int ei = bl[lane_on ? i : 0], bi = ei & 0x3f;
+        const Obb me = snap_obb(S, bi);
+        const float my_trav = sub_ok ? SUBP.trav[bi] : 0.0f;
+        const float my_reach = me.hl + (me.hw < 0.0f ? 0.0f : me.hw) + my_trav + 0.01f;
+        int count = 0;  // pairs in the list (uniform)
+        auto flush = [&]() {
+          step_sync();
+          for (int p0 = 0; p0 < count; p0 += WAVE) {
+            const int p = p0 + lane;
+            if (p < count) {
+              const int pr = plist[p], bs = pr >> 8, as = pr & 0xff;
+              if (pair_touch(bs, as, snap_obb(S, bs), sub_ok ? SUBP.trav[bs] : 0.0f, snap_obb(S, as), sub_ok ? SUBP.trav[as] : 0.0f)) {
+                s_hit[bs] = 1; s_hit[as] = 1;
+              }
+            }
           }
+          step_sync();
+          count = 0;
+        };
+        for (int r0 = 1; r0 <= half; r0 += K) {
+          const int r = r0 + k;
+          int j = i + r;
+          j -= j >= n ? n : 0;
+          const bool pair_on = lane_on && r <= half && !(2 * r == n && i >= half);
+          const int ej = bl[pair_on ? j : 0], bj = ej & 0x3f;
+          const float ox = S.x[bj], oy = S.y[bj], ohl = S.hl[bj], ohw = S.hw[bj];
+          const float o_trav = sub_ok ? SUBP.trav[bj] : 0.0f;
+          const float reach = my_reach + ohl + (ohw < 0.0f ? 0.0f : ohw) + o_trav;
+          const float ddx = ox - me.cx, ddy = oy - me.cy;
+          const bool within = pair_on && ((ei | ej) & 0x80) != 0 && !(ddx * ddx + ddy * ddy > reach * reach);
+          const unsigned long long wm = __ballot(within);
+          if (within) plist[count + __popcll(wm & ((1ull << lane) - 1ull))] = (unsigned short)((bi << 8) | bj);
+          count += __popcll(wm);
+          if (count > CAP - WAVE) flush();
         }
-        step_sync();
+        if (count > 0) flush();
       }
     } else
     if (valid && S.present[slot]) {  // a vehicle's sub-lanes split the agents; object sub-lanes all keep their copy of the bit
@@ -543,19 +562,29 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (one_env && A > 1) {
     const bool need = acting && s < A && !ctx.clear;
     const unsigned long long need_m = __ballot(need && leader);
-    if (d.sub > 3 || __popcll(need_m) > PGD_LINETEST_WAVE_MAX) {
+    if (d.sub > 3) {
       // every agent's own lanes stride through the boxes under its car, all agents at once
       if (need) r.vflags |= (int)state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * SPV.length, 0.5f * SPV.width});
-    } else {
-      // many slots with one to three lanes each (40 agents: one) and few of them to test: a lane alone would walk the 100 - 300
-      // boxes under its car (a roundabout's cells are full of short line segments) one by one while most of the wave idles.  The
-      // whole wave takes the agents one after the other instead -- the same boxes, the same flags (state_check_wave, as for the
-      // single agent); with many agents to test the parallel form above wins again (wave-uniform switch)
-      for (unsigned long long todo = need_m; todo != 0ull; todo &= todo - 1ull) {
-        const int a = __builtin_ctzll(todo) / d.sub;
-        const unsigned fl = state_check_wave(mv, snap_obb(S, a));
-        if (valid && s == a) r.vflags |= (int)fl;
+    } else if (need_m != 0ull) {
+      // many slots with one to three lanes each (40 agents: one): a lane alone would walk the 100 - 300 boxes under its car (a
+      // roundabout's cells are full of short line segments) one by one while the lanes of the agents with nothing to test idle.
+      // The wave is dealt out to the agents that DO need the test instead: 64 / n lanes each (one agent: the whole wave), the
+      // shares ORed through LDS -- the same boxes, the same flags.  (The lane data of the IDM search is dead by now: the list of
+      // the agents to test and their flag words live there.)
+      unsigned char* nl = reinterpret_cast<unsigned char*>(&S.lon[0]);
+      unsigned* fo = reinterpret_cast<unsigned*>(&S.llen[0]);
+      const int n_need = __popcll(need_m);
+      const int my_pos = __popcll(need_m & ((1ull << (need ? g.lead : 0)) - 1ull));  // of my slot's leader lane among the set bits
+      if (need && leader) nl[my_pos] = (unsigned char)slot;
+      fo[lane] = 0u;
+      step_sync();
+      const int G = WAVE / n_need, gi = lane / G;
+      if (gi < n_need) {
+        const unsigned part = state_check_part(mv, lane - gi * G, G, snap_obb(S, nl[gi]));
+        if (part != 0u) atomicOr(&fo[gi], part);
       }
+      step_sync();
+      if (need) r.vflags |= (int)fo[my_pos];  // (every sub-lane of the slot: they keep equal copies of the record)
     }
   }
   PHASE_MARK(25);  // after_step: per-vehicle part
@@ -1594,6 +1623,9 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   return build_reset_image(h);
 }
 
+#ifndef PGD_OBS_ENV_LDS
+#define PGD_OBS_ENV_LDS 16384  // dynamic LDS a block of k_observe_env may take for its rounds of observers (40 slots x 72 beams: 53.2 us with 16 KB, 55.2 with 12, 55.8 with 48)
+#endif
 static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, const PgdDev* dv = nullptr, hipStream_t stream = nullptr,
                           int n_envs = 0) {
   const PgdDev& D = dv ? *dv : h->d;
@@ -1607,8 +1639,8 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
     const int nw = four ? 4 : 1, per_wave = (A + nw - 1) / nw;
     int G = per_wave;  // observers per round of a wave: the whole range if its LDS fits (48 KB per block)
     const size_t oth_bytes = (size_t)observe_env_oth_words(A, h->d.cfg.num_others, oth) * 4;
-    while (G > 1 && (size_t)nw * observe_env_words(G, NL, V) * 4 + oth_bytes > 49152) --G;
-    const size_t dyn = (size_t)nw * observe_env_words(G, NL, V) * 4 + oth_bytes;
+    while (G > 1 && (size_t)nw * observe_env_words(G, NL, V, h->d.cfg.num_others) * 4 + oth_bytes > PGD_OBS_ENV_LDS) --G;
+    const size_t dyn = (size_t)nw * observe_env_words(G, NL, V, h->d.cfg.num_others) * 4 + oth_bytes;
     if (dyn <= 49152) {
       { int rc = obs_rows_known(h, d_obs, D.ostride, stream, true); if (rc) return rc; }
       const bool fix = !h->no_fix && !h->has_objects && fix_config_matches(D, true, FIXK_MARL);
@@ -1669,7 +1701,7 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   dv.prow = packed ? d_obs : nullptr;
   {  // fused multi-agent observation: observers per round = what the step's LDS holds
     int G = h->d.A;
-    while (G > 1 && observe_env_words(G, h->d.cfg.num_lasers, h->d.V) > STEP_MINB_WORDS) --G;
+    while (G > 1 && observe_env_words(G, h->d.cfg.num_lasers, h->d.V, h->d.cfg.num_others) > STEP_MINB_WORDS) --G;
     dv.obs_g = G;
   }
   // env group: the blocks (and the stream) of envs [group * N / G, (group + 1) * N / G); -1 = all envs on the engine stream
@@ -1688,7 +1720,7 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   const bool fuse_env = d_obs && marl && h->d.epw == 1 && h->d.A > 1 && !oth_rows && !h->no_fuse && !h->row_observe &&
                         h->d.A < 4 * (WAVE / h->d.V) &&  // else the four-wave k_observe_env is the faster one (measured again with the
                                                           // compacted lists, round 4: 40 slots with 30 agents alive 146 us fused, 58 + 67 apart)
-                        observe_env_words(1, h->d.cfg.num_lasers, h->d.V) <= STEP_MINB_WORDS;  // at least one observer per round
+                        observe_env_words(1, h->d.cfg.num_lasers, h->d.V, h->d.cfg.num_others) <= STEP_MINB_WORDS;  // at least one observer per round
   const bool fuse_state = d_obs && !marl && h->d.epw > 1 && h->d.cfg.num_lasers <= 0 && !h->no_fuse;  // state-only rows, several envs per wave
   const bool fuse_pack = d_obs && h->d.pack_obs;  // throughput mode: the rows of the wave's envs appended to k_step
   const bool fuse = (d_obs && !marl && h->d.epw == 1 && h->d.A <= FUSE_MAX_AGENTS && !h->no_fuse) || fuse_env || fuse_state || fuse_pack;

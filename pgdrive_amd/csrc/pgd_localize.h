@@ -209,8 +209,9 @@ DEV void update_localization(const MV& mv, const Grp& g, const pgd_spawn& sp, Ve
 // BaseVehicle._state_check (base_vehicle.py:615-644): the car's box against the line / sidewalk boxes of the grid cells under
 // it.  The (<= 2 x 2) cells are flattened into one index range (their four start offsets are read at once: one dependent
 // level for the whole neighbourhood) that the sub-lanes of the vehicle stride through, two boxes in flight per lane.
+// state_check_part: the share of lane `sub` of `SUB` (any SUB >= 1, the lanes need not be neighbours); the caller ORs the shares
 template <class MV>
-DEV unsigned state_check(const MV& mv, const Grp& g, const Obb& car) {
+DEV unsigned state_check_part(const MV& mv, const int g_sub, const int g_SUB, const Obb& car) {
   float ex = fabsf(car.ux) * car.hl + fabsf(car.uy) * car.hw, ey = fabsf(car.uy) * car.hl + fabsf(car.ux) * car.hw;
   int cx0 = max((int)floorf((car.cx - ex - mv.ox()) / mv.cell()), 0), cx1 = min((int)floorf((car.cx + ex - mv.ox()) / mv.cell()), mv.gx() - 1);
   int cy0 = max((int)floorf((car.cy - ey - mv.oy()) / mv.cell()), 0), cy1 = min((int)floorf((car.cy + ey - mv.oy()) / mv.cell()), mv.gy() - 1);
@@ -229,12 +230,12 @@ DEV unsigned state_check(const MV& mv, const Grp& g, const Obb& car) {
         pre[q + 1] = pre[q] + (in ? b - a : 0);
       }
       const int n = pre[4];
-      for (int f = g.sub; f < n; f += 2 * g.SUB) {
+      for (int f = g_sub; f < n; f += 2 * g_SUB) {
         pgd_box b[2];
         bool have[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int fj = f + j * g.SUB;
+          const int fj = f + j * g_SUB;
           have[j] = fj < n;
           const int ff = have[j] ? fj : f;
           const int q = (ff >= pre[1]) + (ff >= pre[2]) + (ff >= pre[3]);
@@ -252,8 +253,10 @@ DEV unsigned state_check(const MV& mv, const Grp& g, const Obb& car) {
         }
       }
     }
-  return group_or(fl, g);
+  return fl;
 }
+template <class MV>
+DEV unsigned state_check(const MV& mv, const Grp& g, const Obb& car) { return group_or(state_check_part(mv, g.sub, g.SUB, car), g); }
 
 // What the later phases need from the agent's route position (Navigation.current_ref_lanes / next_ref_lanes,
 // navigation.py:155-183): looked up once per step after the checkpoint update, then reused by the side distances, the

@@ -503,7 +503,11 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
 // NW waves per env: the state blocks get NW * WAVE / A lanes per agent and the passes of the pair phase are dealt out to the waves
 // (wave w takes passes w, w + NW, ...; each wave has its own scratch and synchronises with itself only).
 // LDS words one wave needs for rounds of g observers
-DEV_HOST int observe_env_words(int g, int num_lasers, int V) { return g * ((num_lasers > 0 ? num_lasers : 0) + 2 * V); }
+// per observer of a round: the per-beam minima, the candidate pairs (two to a word), and -- engines that observe neighbour rows --
+// centre distance and speed of every pair
+DEV_HOST int observe_env_words(int g, int num_lasers, int V, int num_others) {
+  return g * ((num_lasers > 0 ? num_lasers : 0) + (V + 1) / 2 + (num_others > 0 ? 2 * V : 0));
+}
 // ... and behind the waves' areas, with PGD_MA_OTHERS_STATE: slot and speed of every observer's ranked neighbours
 DEV_HOST int observe_env_oth_words(int A, int num_others, bool oth) { return oth ? 2 * A * num_others : 0; }
 
@@ -649,7 +653,8 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   // PGD_MA_OTHERS_STATE (LidarStateObservationMARound): a neighbour row is the neighbour's own state vector; the ranks found by
   // the pair phase are parked in LDS (slot, speed as the observer sees it) and the vectors are written by a last phase below
   const bool oth = ALLOW_OTH && (d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && NO > 0;
-  int* nbSlot = reinterpret_cast<int*>(s_minb_all + (size_t)NW * ((size_t)G * NL + 2 * (size_t)G * V));
+  const size_t wave_words = (size_t)observe_env_words(G, NL, V, NO);
+  int* nbSlot = reinterpret_cast<int*>(s_minb_all + (size_t)NW * wave_words);
   float* nbSpd = reinterpret_cast<float*>(nbSlot + A * NO);
   if (oth) {
     for (int k = tid; k < A * NO; k += WAVE * NW) nbSlot[k] = -1;
@@ -663,8 +668,9 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   const float R = d.cfg.lidar_dist, R_lidar = R;
   const int per_wave = (nW + NW - 1) / NW;  // positions of the observer list
   const int a_lo = min(wv * per_wave, nW), a_hi = min(a_lo + per_wave, nW);
-  unsigned* s_minb = s_minb_all + (size_t)wv * ((size_t)G * NL + 2 * (size_t)G * V);  // [G * NL] minima | [G * V] distance | [G * V] speed
-  float* rDist = reinterpret_cast<float*>(s_minb + (size_t)G * NL);
+  unsigned* s_minb = s_minb_all + (size_t)wv * wave_words;  // [G * NL] minima | [G * V] candidates (u16) | [G * V] distance | [G * V] speed
+  unsigned short* cand = reinterpret_cast<unsigned short*>(s_minb + (size_t)G * NL);
+  float* rDist = reinterpret_cast<float*>(s_minb + (size_t)G * (NL + (V + 1) / 2));  // (the last two only with neighbour rows)
   float* rSpd = rDist + (size_t)G * V;
   int* pAO = reinterpret_cast<int*>(pDist_all[wv]);  // (observer of the round << 8) | body, per lane of the pass
   int* pPref = pPref_all[wv];
@@ -675,16 +681,20 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     for (int k = lane; k < (g1 - g0) * NL; k += WAVE) s_minb[k] = __float_as_uint(1.0f);
     row_sync<true>();  // the round belongs to this wave alone
     PHASE_MARK(21);  // env obs: per-beam minima initialised
+    // stage 1, all pairs of the round: which bodies are within the lidar's reach of which observer (the reference's broad phase);
+    // the few that are go into a list, and only the list pays for beam windows, prefix sums and casting -- two thirds of the
+    // pairs of a 30-agent roundabout fail this test, and a pass of 64 pairs cost the same whether one lane passed or all
+    // (a round of at most 64 pairs -- 8 agents -- is its own list: the verdicts stay in the lanes)
+    const bool direct = P <= WAVE;
+    bool in_d = false;
+    int ao_d = 0;
+    int n_cand = 0;  // (uniform)
     for (int q0 = 0; q0 < P; q0 += WAVE) {
       const int pq = q0 + lane;
       const bool pv = pq < P;
       const int al = pv ? pq / nB : 0, bo = pv ? pq - al * nB : 0;
       const int a = wList[g0 + al], o = bList[bo];  // observer and body of the pair
-      const int ac = a;
-      const float px = bX[ac], py = bY[ac], hx = bUX[ac], hy = bUY[ac];
-      bool in = false, is_vehicle = true;
-      float dist = 0.0f, spd = 0.0f;
-      int i0 = 0, cnt = 0;
+      bool in = false;
       if (pv) {
         const int stt = bST[o] & 0xff, kind = bST[o] >> 8;
         bool present = stt == ST_PENDING || stt == ST_ACTIVE || stt == ST_DYING;
@@ -702,33 +712,51 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
             still = still && !(fo & PGD_F_REPORT);
           }
         }
-        is_vehicle = kind == PGD_OBJ_VEHICLE;
+        const float px = bX[a], py = bY[a];
+        const float x = bX[o], y = bY[o];
+        in = present && o != a && shape_point_dist<true>(Obb{x, y, bUX[o], bUY[o], bHL[o], bHW[o]}, px, py) <= R;
+        if (NO > 0) {  // kept for the neighbour ranks of the round
+          rDist[pq] = (in && kind == PGD_OBJ_VEHICLE) ? norm2(px - x, py - y) : __builtin_inff();
+          rSpd[pq] = (in && !still) ? speed_kmh(bV[o]) : 0.0f;
+        }
+      }
+      const unsigned long long im = __ballot(in);
+      if (direct) {
+        in_d = in; ao_d = (al << 8) | o;
+        n_cand = im != 0ull ? 1 : 0;
+      } else {
+        if (in) cand[n_cand + __popcll(im & ((1ull << lane) - 1ull))] = (unsigned short)((al << 8) | o);
+        n_cand += __popcll(im);
+      }
+    }
+    if (!direct) row_sync<true>();
+    PHASE_MARK(22);  // env obs: pairs (broad phase)
+    // stage 2, the pairs within reach, 64 at a time: beam window of the body (the arithmetic of obs_compact), then its incidences
+    for (int q0 = 0; q0 < n_cand; q0 += WAVE) {
+      const bool pv = direct ? in_d : q0 + lane < n_cand;
+      const int ao_c = direct ? ao_d : (pv ? (int)cand[q0 + lane] : 0);
+      const int al = ao_c >> 8, o = ao_c & 0xff;
+      const int a = wList[g0 + al];
+      int i0 = 0, cnt = 0;
+      if (pv) {
+        const float px = bX[a], py = bY[a], hx = bUX[a], hy = bUY[a];
         const float x = bX[o], y = bY[o], hl = bHL[o], hw = bHW[o];
-        in = present && o != a && shape_point_dist<true>(Obb{x, y, bUX[o], bUY[o], hl, hw}, px, py) <= R;
-        if (in) {  // the arithmetic of obs_compact
-          spd = still ? 0.0f : speed_kmh(bV[o]);
-          dist = norm2(px - x, py - y);
-          const float rad = (hw < 0.0f ? hl : norm2(hl, hw)) * 1.02f + 0.01f;
-          i0 = 0; cnt = NL;
-          if (dist > rad) {
-            const float rx = (x - px) * hx + (y - py) * hy, ry = (y - py) * hx - (x - px) * hy;
-            const float inv_unit = (float)NL * (0.5f / PGD_PI);
-            const float q = rad / dist;
-            const float ic = atan2_window(ry, rx) * inv_unit, hb = (q + 0.5708f * q * q * q) * inv_unit + 1.5f;
-            const int lo = (int)floorf(ic - hb), hi = (int)ceilf(ic + hb);
-            if (hi - lo + 1 < NL) {
-              cnt = hi - lo + 1;
-              i0 = lo % NL;
-              if (i0 < 0) i0 += NL;
-            }
+        const float dist = norm2(px - x, py - y);
+        const float rad = (hw < 0.0f ? hl : norm2(hl, hw)) * 1.02f + 0.01f;
+        i0 = 0; cnt = NL;
+        if (dist > rad) {
+          const float rx = (x - px) * hx + (y - py) * hy, ry = (y - py) * hx - (x - px) * hy;
+          const float inv_unit = (float)NL * (0.5f / PGD_PI);
+          const float q = rad / dist;
+          const float ic = atan2_window(ry, rx) * inv_unit, hb = (q + 0.5708f * q * q * q) * inv_unit + 1.5f;
+          const int lo = (int)floorf(ic - hb), hi = (int)ceilf(ic + hb);
+          if (hi - lo + 1 < NL) {
+            cnt = hi - lo + 1;
+            i0 = lo % NL;
+            if (i0 < 0) i0 += NL;
           }
         }
       }
-      if (pv && NO > 0) {  // kept for the neighbour ranks of the round
-        rDist[pq] = (in && is_vehicle) ? dist : __builtin_inff();
-        rSpd[pq] = spd;
-      }
-      PHASE_MARK(22);  // env obs: pairs (broad phase, windows)
       int inc = cnt;  // inclusive prefix sum of the window sizes over the wave
 #pragma unroll
       for (int sh = 1; sh < WAVE; sh <<= 1) {
