@@ -36,6 +36,11 @@
 #define MAXV 64
 
 // Optional per-phase cycle counters of k_step (build with -DPGD_PROF; never enabled in the shipped library)
+#ifndef PGD_MA_PRIO3
+#define PGD_MA_PRIO3 7  // issue priority of a multi-agent env's wave from this many tenths of its slots alive
+#define PGD_MA_PRIO2 5
+#define PGD_MA_PRIO1 3
+#endif
 #ifdef PGD_PROF
 #define PROF_BLOCKS 8192
 __device__ unsigned long long g_phase_cycles[PROF_BLOCKS * 32];  // per block, no atomics (they would serialise)
@@ -376,6 +381,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // every wave of a 4096-env launch is resident at once and the kernel ends with its slowest wave: the envs with the
     // most driving IDM vehicles get the issue priority, the light ones fill the gaps
     const int nact = __popcll(__ballot(acting && leader && s >= A));
+    if (MARL && V == A) {  // multi-agent engines without traffic: the envs with the most agents alive are the long ones
+      const int nag = __popcll(__ballot(acting && leader));
+      if (nag * 10 >= A * PGD_MA_PRIO3) __builtin_amdgcn_s_setprio(3);
+      else if (nag * 10 >= A * PGD_MA_PRIO2) __builtin_amdgcn_s_setprio(2);
+      else if (nag * 10 >= A * PGD_MA_PRIO1) __builtin_amdgcn_s_setprio(1);
+    } else
     if (nact >= 4) __builtin_amdgcn_s_setprio(3);
     else if (nact >= 2) __builtin_amdgcn_s_setprio(2);
     else if (nact > 0) __builtin_amdgcn_s_setprio(1);
