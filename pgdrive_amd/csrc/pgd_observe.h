@@ -78,8 +78,7 @@ DEV bool near_hint_usable(const pgd_config& c) {
   // circumradius bounds (MAX_LENGTH 10 / 2 + MAX_WIDTH 2.5 / 2 each, base_vehicle.py:83-84)
   return c.num_lasers > 0 && c.lidar_dist >= 2.0f * near_reach(150.0f / 3.6f, t_step) + 12.6f;
 }
-// atan2 for the beam windows only: minimax polynomial of atan on [0, 1] (error < 2e-5 rad = 1e-3 of a beam at 240 beams, inside the
-// 1.5 beams of slack the window carries), a third of the library routine's instructions.  Never used for an observed value.
+// atan2 for the beam windows only: minimax polynomial of atan on [0, 1] (error < 2e-5 rad = 1e-3 of a beam at 240 beams: see beam_window), a third of the library routine's instructions.  Never used for an observed value.
 DEV float atan2_window(float y, float x) {
   const float ax = fabsf(x), ay = fabsf(y);
   const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
@@ -88,6 +87,28 @@ DEV float atan2_window(float y, float x) {
   r = ay > ax ? 0.5f * PGD_PI - r : r;
   r = x < 0.0f ? PGD_PI - r : r;
   return y < 0.0f ? -r : r;
+}
+
+// The beams that can reach a body: it lies inside the circle of radius `rad` around its centre (rad = 1.02 x circumradius + 1 cm),
+// so only beams within asin(rad / dist) of the centre direction can hit it; asin(q) <= q + (pi/2 - 1) q^3 on [0, 1].  The window
+// is the INTEGER beams of [ic - hb, ic + hb]: ceil / floor, not floor / ceil.  What has to be covered is the error of the centre
+// angle -- atan2_window's 2e-5 rad and the fp32 rounding of (rx, ry), together < 1e-4 rad -- and the 2 % + 1 cm on the radius
+// already widen the half angle by >= 6e-4 rad at any distance inside the lidar range; PGD_WINDOW_SLACK beams are added on top.
+// (Rounds 1 - 4 carried 1.5 beams of slack AND rounded outwards: 3 - 5 beams per window that no ray of which could hit, half of
+// all incidences of a 72-beam fan.)  The culling never removes a hit: the cloud stays bit-identical to the all-pairs test.
+#ifndef PGD_WINDOW_SLACK
+#define PGD_WINDOW_SLACK 0.05f
+#endif
+DEV void beam_window(const float rx, const float ry, const float q, const int NL, int& i0, int& cnt) {
+  const float inv_unit = (float)NL * (0.5f / PGD_PI);
+  const float ic = atan2_window(ry, rx) * inv_unit, hb = (q + 0.5708f * q * q * q) * inv_unit + PGD_WINDOW_SLACK;
+  const int lo = (int)ceilf(ic - hb);
+  const int hi = max((int)floorf(ic + hb), lo);  // (never empty: the owner lookup of the incidence paths wants distinct starts)
+  if (hi - lo + 1 < NL) {
+    cnt = hi - lo + 1;
+    i0 = lo % NL;
+    if (i0 < 0) i0 += NL;
+  }
 }
 
 template <bool OBJ>
@@ -105,22 +126,12 @@ DEV void obs_compact(ObsLds& L, int o, int a, bool present, bool is_vehicle, flo
     L.bdist[k] = is_vehicle ? dist : __builtin_inff();
     // (a body that can reach the agent within a step is inside the lidar broad phase a fortiori: R >= 20 m in every config)
     if (near_out) *near_out = dist <= ag_reach + hl + (hw < 0.0f ? 0.0f : hw) + near_reach(spd * (1.0f / 3.6f), t_step) + 0.05f;
-    // the body lies inside the circle of radius rad around its centre: only beams within asin(rad / dist) of the centre
-    // direction can reach it.  asin(q) <= q + (pi/2 - 1) q^3 on [0, 1]; 1.5 beams of slack cover the fp32 rounding of the
-    // angle, so the culling never removes a hit and the cloud stays bit-identical to the all-pairs test.
+    // the body lies inside the circle of radius rad around its centre: the beams that can reach it (beam_window)
     const float rad = (hw < 0.0f ? hl : norm2(hl, hw)) * 1.02f + 0.01f;
     int i0 = 0, cnt = NL;
     if (dist > rad && NL > 0) {
       const float rx = (x - px) * hx + (y - py) * hy, ry = (y - py) * hx - (x - px) * hy;  // centre in the vehicle frame
-      const float inv_unit = (float)NL * (0.5f / PGD_PI);
-      const float q = rad / dist;
-      const float ic = atan2_window(ry, rx) * inv_unit, hb = (q + 0.5708f * q * q * q) * inv_unit + 1.5f;
-      const int lo = (int)floorf(ic - hb), hi = (int)ceilf(ic + hb);
-      if (hi - lo + 1 < NL) {
-        cnt = hi - lo + 1;
-        i0 = lo % NL;
-        if (i0 < 0) i0 += NL;
-      }
+      beam_window(rx, ry, rad / dist, NL, i0, cnt);
     }
     L.bi0[k] = i0; L.bcnt[k] = cnt;
     {  // sectors of 64 consecutive beams the window reaches (more than 32 sectors: every one)
@@ -746,15 +757,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
         i0 = 0; cnt = NL;
         if (dist > rad) {
           const float rx = (x - px) * hx + (y - py) * hy, ry = (y - py) * hx - (x - px) * hy;
-          const float inv_unit = (float)NL * (0.5f / PGD_PI);
-          const float q = rad / dist;
-          const float ic = atan2_window(ry, rx) * inv_unit, hb = (q + 0.5708f * q * q * q) * inv_unit + 1.5f;
-          const int lo = (int)floorf(ic - hb), hi = (int)ceilf(ic + hb);
-          if (hi - lo + 1 < NL) {
-            cnt = hi - lo + 1;
-            i0 = lo % NL;
-            if (i0 < 0) i0 += NL;
-          }
+          beam_window(rx, ry, rad / dist, NL, i0, cnt);
         }
       }
       int inc = cnt;  // inclusive prefix sum of the window sizes over the wave
