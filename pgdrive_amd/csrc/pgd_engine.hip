@@ -900,10 +900,10 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       const MapView mvb = mv;
       const unsigned lead_fl = (unsigned)__shfl((int)my_fl, g.lead);  // the step flags are complete in the slot's first lane only
       const EnvInWave in_wave{&r, &SPV, &mvb, lead_fl, scen, steps_total, valid ? s : A, g.sub};  // lanes past the last slot: no agent
-      if (V == A && d.sub == WAVE / A) observe_env_body<1, false, true>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g, &in_wave);
-      else observe_env_body<1, false>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
+      if (V == A && d.sub == WAVE / A) observe_env_body<1, false, true, OBJ>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g, &in_wave);
+      else observe_env_body<1, false, false, OBJ>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
     } else
-    observe_env_body<1, false>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
+    observe_env_body<1, false, false, OBJ>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
   }
   // throughput mode (several envs per wave, one ego each, lidar): the rows of the wave's envs one after the other, each by the
   // whole wave -- same routine as the fused observation above, the env's scenario and map view read with wave-uniform addresses
@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_observe_env(PgdDev d, float* __re
   extern __shared__ unsigned s_minb_dyn[];
   __shared__ ObsEnvLds<NW> M;
   PHASE_INIT();  // (profile builds: the marks of observe_env_body count from here)
-  observe_env_body<NW, !FIX>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);
+  observe_env_body<NW, !FIX, false, !FIX>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);  // (the fixed-config kernel: no traffic objects)
 }
 
 // scripted lane-keeping policy (pgd_lane_keep_actions): one thread per env
@@ -1486,9 +1486,13 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
         if (R.first_lane + L.index != k) return PGD_ERR_ARG;
         L.pad = R.n_lanes;
         // device-private use of `ex` (the end point is not read on the device): half-width of the strip around a straight
-        // lane's axis that no line / sidewalk box of the map reaches (between 6 m before and after the lane).  The lateral
-        // coordinate is linear over a box, so its extremes sit at the corners; a box with corners on both sides crosses.
-        // A car whose box stays inside that strip touches nothing: k_step then skips the line / sidewalk test.
+        // lane's axis that no line / sidewalk box of the map reaches.  The lateral coordinate is linear over a box, so its
+        // extremes sit at the corners; a box with corners on both sides crosses.  A car whose box stays inside that strip AND
+        // between the lane's ends touches nothing: k_step then skips the line / sidewalk test.  Boxes that lie wholly before the
+        // lane's start or behind its end (5 cm of slack for the fp32 coordinate on the device) cannot reach such a car -- the lane's
+        // direction separates them -- and do not count: rounds 2 - 4 counted everything within 6 m of the ends, and the first
+        // piece of a curved line behind a junction then voided the strip of a QUARTER of the straight lane length of the
+        // PGDrive-v0 maps and of every entry road of the multi-agent roundabout (where most agents of a random policy live).
         double clear = 0.0;
         if (L.dir == 0.0f) {
           clear = 1e9;
@@ -1505,7 +1509,7 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
               lo_lon = std::min(lo_lon, lon); hi_lon = std::max(hi_lon, lon);
               lo_lat = std::min(lo_lat, lat); hi_lat = std::max(hi_lat, lat);
             }
-            if (hi_lon < -6.0 || lo_lon > (double)L.length + 6.0) continue;
+            if (hi_lon < -0.05 || lo_lon > (double)L.length + 0.05) continue;  // (the car lies within [0, length]: see below)
             if (lo_lat <= 0.0 && hi_lat >= 0.0) clear = 0.0;
             else clear = std::min(clear, std::min(std::fabs(lo_lat), std::fabs(hi_lat)));
           }

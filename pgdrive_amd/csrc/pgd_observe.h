@@ -551,7 +551,11 @@ struct EnvInWave {
   uint32_t tick;
   int slot, sub;
 };
-template <int NW, bool ALLOW_OTH = true, bool FUSED = false>
+// x / n for 0 <= x < 4096, n <= 128 without the integer division (~25 instructions): (x + 0.5) / n is at least 0.5 / n away from an
+// integer and the fp32 product is off by < 1e-3 of one
+DEV int div_small(const int x, const float inv_n) { return (int)(((float)x + 0.5f) * inv_n); }
+// OBJ = false: engines whose scenarios hold no traffic objects (no circles among the bodies)
+template <int NW, bool ALLOW_OTH = true, bool FUSED = false, bool OBJ = true>
 DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const uint32_t* flags, ObsEnvLds<NW>& M,
                           unsigned* s_minb_all, const int G, const EnvInWave* in_wave = nullptr) {
   float (&bX)[WAVE] = M.bX; float (&bY)[WAVE] = M.bY; float (&bUX)[WAVE] = M.bUX; float (&bUY)[WAVE] = M.bUY;
@@ -697,13 +701,14 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     // pairs of a 30-agent roundabout fail this test, and a pass of 64 pairs cost the same whether one lane passed or all
     // (a round of at most 64 pairs -- 8 agents -- is its own list: the verdicts stay in the lanes)
     const bool direct = P <= WAVE;
+    const float inv_nB = 1.0f / (float)(nB > 0 ? nB : 1);
     bool in_d = false;
     int ao_d = 0;
     int n_cand = 0;  // (uniform)
     for (int q0 = 0; q0 < P; q0 += WAVE) {
       const int pq = q0 + lane;
       const bool pv = pq < P;
-      const int al = pv ? pq / nB : 0, bo = pv ? pq - al * nB : 0;
+      const int al = pv ? div_small(pq, inv_nB) : 0, bo = pv ? pq - al * nB : 0;
       const int a = wList[g0 + al], o = bList[bo];  // observer and body of the pair
       bool in = false;
       if (pv) {
@@ -725,7 +730,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
         }
         const float px = bX[a], py = bY[a];
         const float x = bX[o], y = bY[o];
-        in = present && o != a && shape_point_dist<true>(Obb{x, y, bUX[o], bUY[o], bHL[o], bHW[o]}, px, py) <= R;
+        in = present && o != a && shape_point_dist<OBJ>(Obb{x, y, bUX[o], bUY[o], bHL[o], bHW[o]}, px, py) <= R;
         if (NO > 0) {  // kept for the neighbour ranks of the round
           rDist[pq] = (in && kind == PGD_OBJ_VEHICLE) ? norm2(px - x, py - y) : __builtin_inff();
           rSpd[pq] = (in && !still) ? speed_kmh(bV[o]) : 0.0f;
@@ -776,7 +781,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
         const float ax = bX[ga], ay = bY[ga], ahx = bUX[ga], ahy = bUY[ga];
         const float2 bd = d.beam[i];  // (cos, sin)(i * 2 pi / NL); rotated by the heading
         const float dx = R_lidar * (bd.x * ahx - bd.y * ahy), dy = R_lidar * (bd.y * ahx + bd.x * ahy);
-        const float f = shape_ray<true>(Obb{bX[qo], bY[qo], bUX[qo], bUY[qo], bHL[qo], bHW[qo]}, ax, ay, dx, dy);
+        const float f = shape_ray<OBJ>(Obb{bX[qo], bY[qo], bUX[qo], bUY[qo], bHL[qo], bHW[qo]}, ax, ay, dx, dy);
         atomicMin(&s_minb[qa * NL + i], __float_as_uint(f));
       };
       if (R <= 32) {
@@ -825,7 +830,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     // neighbour rows (lidar.py:55-77: by centre distance, stable in slot order); the multi-agent default observes none
     if (NO > 0)
       for (int pq = lane; pq < P; pq += WAVE) {
-        const int al = pq / nB, bo = pq - al * nB, a = wList[g0 + al], o = bList[bo];
+        const int al = div_small(pq, inv_nB), bo = pq - al * nB, a = wList[g0 + al], o = bList[bo];
         const float dk = rDist[pq];
         int rank = 0, nveh = 0;
         for (int j = 0; j < nB; ++j) {  // (the body list ascends: position order = slot order, the reference's tie rule)
@@ -863,7 +868,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
       }
     } else  // short fans flat over (observer, beam): a round per observer would leave most lanes of its second round idle
     for (int k = lane; k < (g1 - g0) * NL; k += WAVE) {
-      const int qa = k / NL, i = k - qa * NL, ga = wList[g0 + qa];
+      const int qa = div_small(k, 1.0f / (float)NL), i = k - qa * NL, ga = wList[g0 + qa];
       obs[(size_t)e * d.ostride + (size_t)ga * D + o_oth + (oth ? o_oth : 4) * NO + i] = lidar_noise(d, e, ga, tick, i, __uint_as_float(s_minb[k]));
     }
     row_sync<true>();
