@@ -1503,6 +1503,76 @@ def test_free_running_timed_path_through_episode_ends(descs):
     eng.close()
 
 
+def test_marl_free_running_through_finishes_and_respawns():
+    """The reference-default multi-agent configuration (40 slots on the roundabout) as bench.py times it -- the fixed-config
+    kernels, the four-wave observation on compacted lists with the zero-row marks (PgdDev::rowz), contacts by unordered pairs, the
+    line test dealt out to the agents that need it, auto-reset -- held to the oracle WITHOUT set_state between the steps (teacher
+    forcing goes through pgd_set_state, which drops the marks and the hints).  Per env the two runs are compared until the env's
+    first discrete divergence (a contact or a line reached one step apart between fp32 and fp64: from there the agents of that env
+    play different episodes); inside the common prefixes every agent's flags / done agree by construction, and
+      * the finishes, respawns and env restarts seen there are most of all that the oracle sees;
+      * every row handed out there -- also the first row of a respawned agent and the zero rows of empty slots -- is the oracle's:
+        the state / navigation floats to a few observation tolerances of free-running drift, the beams except the few whose ray
+        passes a box corner within that drift (counted, bounded)."""
+    import torch
+    from oracle import orc
+    from pgdrive_amd.engine import Engine
+    d, mb, sb = util.make_marl_banks(num_agents=40, capacity=40, kind="roundabout")
+    n_envs, n_steps = 48, 400
+    cfg = util.marl_config(n_envs, sb, horizon=150, resample_scenario=1, seed=7)
+    eng = Engine(cfg, mb, sb)
+    ora = orc.Oracle(cfg, mb, sb)
+    ids = np.arange(n_envs) % 8
+    o0 = ora.reset(ids)
+    g0 = eng.reset(ids).cpu().numpy()
+    assert np.abs(g0 - o0).max() < OBS_TOL
+    rng = np.random.default_rng(9)
+    A = sb.A
+    alive = np.ones(n_envs, dtype=bool)
+    n_fin = n_fin_alive = n_new = n_new_alive = n_reset = n_reset_alive = 0
+    rows = beams = beams_off = 0
+    worst = 0.0
+    div_bits = 0
+    first_div = []
+    for t in range(n_steps):
+        act = util.marl_actions(rng, n_envs, A)
+        o_obs, o_rew, o_done, o_flags = ora.step(act)
+        g_obs, g_rew, g_done, g_flags = eng.step(torch.from_numpy(act).to(eng.device))
+        eng.sync()
+        g_obs = g_obs.cpu().numpy().astype(np.float64)
+        g_done, g_flags, g_rew = g_done.cpu().numpy(), g_flags.cpu().numpy().astype(np.uint32), g_rew.cpu().numpy().astype(np.float64)
+        same = ((g_done == o_done) & (g_flags == o_flags)).all(axis=1)
+        fin = (o_done != 0) & ((o_flags & _abi.F_REPORT) != 0)
+        new = (o_flags & _abi.F_NEW) != 0
+        rst = (o_flags[:, 0] & _abi.F_RESET) != 0
+        n_fin += int(fin.sum()); n_fin_alive += int(fin[alive & same].sum())
+        n_new += int(new.sum()); n_new_alive += int(new[alive & same].sum())
+        n_reset += int(rst.sum()); n_reset_alive += int(rst[alive & same].sum())
+        newly = alive & ~same
+        if newly.any():
+            div_bits |= int(np.bitwise_or.reduce((g_flags ^ o_flags)[newly].ravel()))
+            first_div += [t] * int(newly.sum())
+        alive &= same
+        if alive.any():
+            dd = np.abs(g_obs - o_obs)[alive]                    # every row of the env, due or zero
+            n_state = dd.shape[2] - cfg.num_lasers
+            rows += dd.shape[0] * dd.shape[1]
+            worst = max(worst, float(dd[:, :, :n_state].max()))  # state + navigation floats: no ray in them
+            beams += dd.shape[0] * dd.shape[1] * cfg.num_lasers
+            beams_off += int((dd[:, :, n_state:] > 4 * OBS_TOL).sum())
+            assert np.abs(g_rew - o_rew)[alive].max() < 50 * REW_TOL
+    print("multi-agent free run, 40 slots: %d of %d envs in their common prefix after %d steps (first divergences at steps %s, bits "
+          "0x%x); in the prefixes %d of %d finishes, %d of %d respawns, %d of %d env restarts; %d rows compared: state / navigation "
+          "floats off by at most %.2e, %d of %d beams off by more than %.0e (%.2e of them: rays past a box corner, free-running "
+          "fp32 against fp64)"
+          % (int(alive.sum()), n_envs, n_steps, sorted(first_div)[:8], div_bits, n_fin_alive, n_fin, n_new_alive, n_new, n_reset_alive,
+             n_reset, rows, worst, beams_off, beams, 4 * OBS_TOL, beams_off / max(1, beams)))
+    assert n_fin_alive >= 300 and n_new_alive >= 300 and n_reset_alive >= 20
+    assert alive.mean() >= 0.5
+    assert worst < 10 * OBS_TOL and beams_off <= 3e-4 * beams
+    eng.close()
+
+
 @pytest.mark.parametrize("traffic_mode", ["trigger", "respawn"])
 def test_idm_agent_parity_and_arrivals(descs, traffic_mode):
     """IDM_agent = True (base_env.py:30, agent_manager.py:79): the ego's policy is IDMPolicy -- routing along its checkpoints,
