@@ -74,8 +74,8 @@ def load_traffic(N, args):
         if (t.get("envs"), t.get("traffic"), t.get("lasers"), t.get("actions", "uniform"), t.get("traffic_mode", "trigger"),
                 t.get("workload", "c3"), t.get("agents", 1)) == \
                 (N, args.traffic, args.lasers, args.actions, args.traffic_mode, args.workload, args.agents if args.workload == "c5" else 1):
-            return t.get("bytes_per_launch"), os.path.basename(p)
-    return None, None
+            return t.get("bytes_per_launch"), os.path.basename(p), t.get("bytes_per_launch_k_observe")
+    return None, None, None
 
 
 def cpu_baseline(descs, args, seconds=6.0):
@@ -552,12 +552,14 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
             dom_ms = max(prof["k_observe_ms"], prof["k_step_ms"])
             dom_bytes = (b_obs if dom == "k_observe" else b_step) * N
             nominal = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-            traffic, traffic_src = load_traffic(N, args)
+            traffic, traffic_src, traffic_obs = load_traffic(N, args)
+            if dom == "k_observe":
+                traffic = traffic_obs  # the counters' figure of the observation kernel (multi-agent engines with many slots)
             # bytes that MOVE per launch: the counters' figure when a pass of this workload is committed, else the formula
             # charged only for the records of vehicles that drove (waiting / removed slots are neither rewritten nor re-read
             # from HBM: reset image); the nominal formula charges all V records read + written
             moved, moved_src = None, None
-            if traffic and dom == "k_step":
+            if traffic:
                 moved, moved_src = float(traffic), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (%s)" % traffic_src
             elif work and "driving_traffic_mean" in work and dom == "k_step":
                 moved = (b_step - 2 * 128 * (args.traffic - work["driving_traffic_mean"])) * N

@@ -45,4 +45,11 @@ out = dict(envs=N, traffic=16 if WORKLOAD == "c3" else 0, lasers=LASERS, actions
            note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --exact --steps 200 --warmup 1500` "
                 "(KB per dispatch, last quarter of the k_step dispatches = steady state). Corrections as MI355X_MICROARCH.md (HBM "
                 "section) prescribes, measured on the engine's own record pattern with profiles/r01_calib.hip.")
+# engines whose observation is a kernel of its own (multi-agent, many slots): the same figure for k_observe_env
+ko = [k for k in fetch if "k_observe_env" in k]
+if ko and ko[0] in write:
+    fo = sum(steady(fetch[ko[0]])) / len(steady(fetch[ko[0]]))
+    wo = sum(steady(write[ko[0]])) / len(steady(write[ko[0]]))
+    out.update(k_observe_kernel=ko[0], k_observe_FETCH_SIZE_KB=fo, k_observe_WRITE_SIZE_KB=wo,
+               bytes_per_launch_k_observe=(fo * c_f + wo * out["calibration"]["write_correction_rows"]) * 1024.0)
 print(json.dumps(out, indent=1))

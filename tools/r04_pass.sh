@@ -11,3 +11,4 @@ bash tools/row_pass.sh $TAG/expert_respawn c3 4096 expert respawn 1 240
 bash tools/row_pass.sh $TAG/c5_8x240 c5 4096 uniform trigger 8 240
 bash tools/row_pass.sh $TAG/c5_8x72 c5 4096 uniform trigger 8 72
 bash tools/row_pass.sh $TAG/c3_32768 c3 32768 uniform trigger 1 240
+bash tools/row_pass.sh $TAG/c5_40x72 c5 4096 uniform trigger 40 72
