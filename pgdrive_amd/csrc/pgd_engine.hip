@@ -1494,7 +1494,11 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
         // piece of a curved line behind a junction then voided the strip of a QUARTER of the straight lane length of the
         // PGDrive-v0 maps and of every entry road of the multi-agent roundabout (where most agents of a random policy live).
         double clear = 0.0;
+#ifdef PGD_NO_STRIP
+        if (false) {
+#else
         if (L.dir == 0.0f) {
+#endif
           clear = 1e9;
           const pgd_map& M = maps[m];
           for (int b = 0; b < M.n_boxes && clear > 0.0; ++b) {

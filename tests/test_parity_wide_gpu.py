@@ -249,3 +249,45 @@ def test_ieee_build_gives_the_same_discrete_outcomes(descs):
           "max |obs_fast - obs_ieee| (state block)", worst, "episodes", n_done)
     fast.close(); ieee.close()
     assert diff_flags == 0 and diff_ints == 0 and vs_oracle == 0 and worst < 5e-6 and n_done > 100
+
+
+@pytest.mark.timeout(900)
+def test_culling_is_result_neutral(descs):
+    """The lidar's beam windows (pgd_observe.h beam_window: which beams can reach a body) and the line-free strips of straight lanes
+    (pgd_upload_maps: when the line / sidewalk test can be skipped) are pure culling: a build with both switched off -- every body
+    tested against every beam (-DPGD_WINDOW_SLACK=1e6f), every agent's box against the boxes of its cells every step
+    (-DPGD_NO_STRIP) -- must hand out the same bits.  Free-running, the same actions on both sides: single-agent envs with every
+    traffic vehicle driving (respawn mode, 240 beams) and the 40-slot roundabout (72 beams, four-wave observation)."""
+    import torch
+    from pgdrive_amd import build, engine
+    td = tempfile.mkdtemp(prefix="pgd_nocull_")
+    lib = os.path.join(td, "libpgdrive_hip_nocull.so")
+    subprocess.check_call([build.hipcc(), "--offload-arch=gfx950", *build.OPT, "-std=c++17", *build.FAST_FP, "-shared", "-fPIC",
+                           "-DPGD_WINDOW_SLACK=1e6f", "-DPGD_NO_STRIP", "-o", lib, build.SRC])
+    L_all = engine.load_library(path=lib)
+    cases = []
+    mb, sb = util.make_banks(descs, n_maps=8, traffic_mode="respawn")
+    cases.append(("respawn traffic", _abi.make_config(192, num_agents=1, num_traffic=16, num_lasers=240, auto_reset=1, seed=4), mb, sb, 1, 200))
+    d, mmb, msb = util.make_marl_banks(num_agents=40, capacity=40, kind="roundabout")
+    cases.append(("40 slots", util.marl_config(64, msb, horizon=150, seed=3), mmb, msb, msb.A, 250))
+    for name, cfg, mb_, sb_, A, steps in cases:
+        n = cfg.num_envs
+        a_eng = engine.Engine(cfg, mb_, sb_)
+        b_eng = engine.Engine(cfg, mb_, sb_, lib=L_all)
+        ids = np.arange(n) % 8
+        assert torch.equal(a_eng.reset(ids), b_eng.reset(ids))
+        rng = np.random.default_rng(12)
+        hits = lines = 0
+        for t in range(steps):
+            act = util.driving_actions(rng, n) if A == 1 else util.marl_actions(rng, n, A)
+            a = torch.from_numpy(act).to(a_eng.device)
+            ra = [x.clone() for x in a_eng.step(a)]
+            rb = [x.clone() for x in b_eng.step(a)]
+            a_eng.sync(); b_eng.sync()
+            for x, y, what in zip(ra, rb, ("obs", "reward", "done", "flags")):
+                assert torch.equal(x, y), "%s: %s differs at step %d" % (name, what, t)
+            hits += int((ra[0][..., -cfg.num_lasers:] < 1.0).sum().item())
+            lines += int((ra[3].to(torch.int64) & (_abi.F_ON_BROKEN | _abi.F_ON_WHITE | _abi.F_ON_YELLOW | _abi.F_CRASH_SIDEWALK) != 0).sum().item())
+        print("culling off vs on, %s: %d steps x %d envs bit-identical (%d beam hits, %d line / sidewalk contacts on the way)" % (name, steps, n, hits, lines))
+        assert hits > 1000 and lines > 10
+        a_eng.close(); b_eng.close()
