@@ -268,6 +268,8 @@ def test_culling_is_result_neutral(descs):
     cases = []
     mb, sb = util.make_banks(descs, n_maps=8, traffic_mode="respawn")
     cases.append(("respawn traffic", _abi.make_config(192, num_agents=1, num_traffic=16, num_lasers=240, auto_reset=1, seed=4), mb, sb, 1, 200))
+    mb2, sb2 = util.make_banks(descs, n_maps=8)
+    cases.append(("swerving ego", _abi.make_config(192, num_agents=1, num_traffic=16, num_lasers=240, auto_reset=1, seed=5), mb2, sb2, 1, 300))
     d, mmb, msb = util.make_marl_banks(num_agents=40, capacity=40, kind="roundabout")
     cases.append(("40 slots", util.marl_config(64, msb, horizon=150, seed=3), mmb, msb, msb.A, 250))
     for name, cfg, mb_, sb_, A, steps in cases:
@@ -280,6 +282,8 @@ def test_culling_is_result_neutral(descs):
         hits = lines = 0
         for t in range(steps):
             act = util.driving_actions(rng, n) if A == 1 else util.marl_actions(rng, n, A)
+            if name == "swerving ego":  # crosses lane lines and leaves the road: the single-agent line / sidewalk test
+                act[:, 0, 0] = np.clip(0.6 * np.sin(0.07 * t + np.arange(n)) + rng.normal(0, 0.1, size=n), -1, 1)
             a = torch.from_numpy(act).to(a_eng.device)
             ra = [x.clone() for x in a_eng.step(a)]
             rb = [x.clone() for x in b_eng.step(a)]
@@ -287,7 +291,7 @@ def test_culling_is_result_neutral(descs):
             for x, y, what in zip(ra, rb, ("obs", "reward", "done", "flags")):
                 assert torch.equal(x, y), "%s: %s differs at step %d" % (name, what, t)
             hits += int((ra[0][..., -cfg.num_lasers:] < 1.0).sum().item())
-            lines += int((ra[3].to(torch.int64) & (_abi.F_ON_BROKEN | _abi.F_ON_WHITE | _abi.F_ON_YELLOW | _abi.F_CRASH_SIDEWALK) != 0).sum().item())
+            lines += int(((ra[3].to(torch.int64) & (_abi.F_ON_BROKEN | _abi.F_ON_WHITE | _abi.F_ON_YELLOW | _abi.F_CRASH_SIDEWALK)) != 0).sum().item())
         print("culling off vs on, %s: %d steps x %d envs bit-identical (%d beam hits, %d line / sidewalk contacts on the way)" % (name, steps, n, hits, lines))
-        assert hits > 1000 and lines > 10
+        assert hits > 1000 and (lines > 10 or name == "respawn traffic")  # (dense traffic ends an episode within a few steps: no line is reached)
         a_eng.close(); b_eng.close()
