@@ -170,6 +170,30 @@ def test_bench_spawns_its_own_ranks():
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("transport", ["root", "peer"])
+def test_bench_world_8_under_the_drivers_launcher(transport):
+    """The driver's own command form -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 --steps K --warmup W` -- with the eight ranks sharing the one GPU of the test box (gloo for the
+    collectives, HIP IPC for the peer transport): rendezvous, env sharding by rank, the exchange at world 8 and its self-check."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    port = 29600 + (os.getpid() % 200) + (7 if transport == "peer" else 0)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "40", "--warmup", "20",
+                          "--oversubscribe", "--backend", "gloo", "--transport", transport, "--exact", "--envs", "512", "--no-rows",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints, one line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 40 and d["warmup"] == 20 and d["scaling"] == "weak"
+    assert d["config"]["global_envs"] == 8 * 512 and d["config"]["envs_per_gpu"] == 512
+    assert d["value_mode"] == "gather" and d["value"] > 0 and d["value_replicas"] > 0
+    assert d["gather_ok"] is True and d["gather_check"]["ranks_checked"] == 8 and d["gather_check"]["mismatched_ranks"] == []
+
+
+@pytest.mark.timeout(900)
 def test_bench_gather_in_a_hip_graph():
     """`bench.py --gpus 2 --transport peer --graph`: the gather pass replays one HIP graph per 8 steps (gcd of the 24 timed steps and
     the 64-step action cycle) on every rank; the self-check after the timed loop passes and the line says how the steps were launched."""
