@@ -307,6 +307,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if ((ONE_ENV || (packed && valid)) && d.use_imask) im = d.imask[e];
   if (one_env || valid) scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
   if (valid) load_rec(((ONE_ENV || packed) && ((im >> s) & 1ull)) ? d.reset_img + (size_t)scen * V + s : d.rec + (size_t)e * V + s, r);
+  // the agent's action: its address follows from the block index as well -- read here, used by the policy phase (read there it cost
+  // every wave a memory latency of its own right after the snapshot: 1.5 k cycles of the metric's row).  BEHIND the record's reads:
+  // issued ahead of the mask / scenario / record chain it delays that chain (17.76 -> 17.99 us), and so does a speculative read
+  // of the slot's spawn record next to the vehicle record (18.4 us): the first burst of a wave stays as short as it can be
+  float2 act_in = make_float2(0.0f, 0.0f);
+  if (ONE_ENV && valid && s < A) act_in = *reinterpret_cast<const float2*>(act + ((size_t)e * A + s) * 2);
   const int key0 = valid ? (r.status ^ (r.vflags << 3)) : 0;  // what a vehicle that does not drive can change: status, flags
   if (one_env || valid) {
     sc = d.scen + scen;
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (acting) {
     float st, tb;
     if (s < A && !idm_ego) {  // EnvInputPolicy.act (env_input_policy.py:17-26); NaN made harmless (test_ego_vehicle.py:78-84)
-      float a0 = act[((size_t)e * A + s) * 2 + 0], a1 = act[((size_t)e * A + s) * 2 + 1];
+      float a0 = ONE_ENV ? act_in.x : act[((size_t)e * A + s) * 2 + 0], a1 = ONE_ENV ? act_in.y : act[((size_t)e * A + s) * 2 + 1];
       if (a0 != a0) a0 = 0.0f;
       if (a1 != a1) a1 = 0.0f;
       st = clipf(a0, -1.0f, 1.0f);
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       // every agent's own lanes stride through the boxes under its car, all agents at once
       if (need) r.vflags |= (int)state_check(mv, g, Obb{r.x, r.y, r.hx, r.hy, 0.5f * SPV.length, 0.5f * SPV.width});
     } else if (need_m != 0ull) {
-      // many slots with one to three lanes each (40 agents: one): a lane alone would walk the 100 - 300 boxes under its car (a
+      // many slots with one to three lanes each (40 agents: one): a lane alone would walk the 25 - 90 boxes of the cells under its car (a
       // roundabout's cells are full of short line segments) one by one while the lanes of the agents with nothing to test idle.
       // The wave is dealt out to the agents that DO need the test instead: 64 / n lanes each (one agent: the whole wave), the
       // shares ORed through LDS -- the same boxes, the same flags.  (The lane data of the IDM search is dead by now: the list of
