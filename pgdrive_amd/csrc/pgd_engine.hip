@@ -478,6 +478,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       // even n only for i < n / 2), and 64 / n rounds run side by side in the wave: 30 bodies take 8 iterations of the reach
       // test where a loop over the agents inside every body lane took 30.
       constexpr int CAP = 736;  // pairs the list holds (the LDS of the IDM search's lane data, unused here; the body list behind it)
+      static_assert(2 * CAP + WAVE <= (int)(sizeof(float) * 2 * WAVE + sizeof(int4) * WAVE), "pair list + body list live in Snap::lon .. succ");
       unsigned short* plist = reinterpret_cast<unsigned short*>(&S.lon[0]);
       unsigned char* bl = reinterpret_cast<unsigned char*>(plist + CAP);  // [64]: slot | drove-as-agent << 7
       const bool body = valid && leader && S.present[slot] != 0;
