@@ -197,6 +197,11 @@ DEV void state_block(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const A
   // whole branch ladder below once per round of nt floats; they take the eight ego floats in the loop and the navigation block as
   // two whole check points (thread 0 and 1, five floats each: one evaluation instead of ten that keep one value each)
   const int n_loop = nt < 18 ? 8 : 18;
+  // (few threads: the heading_diff lane of the thread that will take float 2 is read here, together with the check point records
+  // of the loop below -- one memory round trip for the block instead of two in a row)
+  pgd_lane ml_few;
+  const bool few_ml = nt < 18 && !pre && tid == 2 % nt;
+  if (few_ml) ml_few = mv.lanes[state_lane_of(ag, 2)];
   if (nt < 18 && !toll)
     for (int which = tid; which < 2; which += nt) {
       const LaneNav nvw = mv.lnav()[state_lane_of(ag, 8 + 5 * which)];
@@ -215,7 +220,7 @@ DEV void state_block(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const A
       if (q == 2) ml = pre->ml;
       if (q >= 8) nv = pre->nv;
     } else {
-      if (q == 2) ml = mv.lanes[lid];
+      if (q == 2) ml = few_ml ? ml_few : mv.lanes[lid];
       if (q >= 8) nv = mv.lnav()[lid];
     }
     const float max_speed = sp.max_speed;
