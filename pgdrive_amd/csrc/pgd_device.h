@@ -261,9 +261,20 @@ DEV bool point_in_obb(const Obb& o, float px, float py) {
   float dx = px - o.cx, dy = py - o.cy;
   return fabsf(dx * o.ux + dy * o.uy) <= o.hl && fabsf(dy * o.ux - dx * o.uy) <= o.hw;
 }
+// ALL: every axis, no early exit -- for waves whose 64 lanes test 64 different pairs within reach of each other (the contact
+// lists): they leave at every exit anyway, at an exec-mask switch each.  The line / sidewalk tests keep the exits: most boxes of a
+// cell are far from the car and the whole wave leaves at the first axis.
+template <bool ALL = false>
 DEV bool obb_overlap(const Obb& A, const Obb& B) {  // separating axis test, closed rectangles
   float dx = B.cx - A.cx, dy = B.cy - A.cy;
   float ac = fabsf(A.ux * B.ux + A.uy * B.uy), as = fabsf(A.ux * B.uy - A.uy * B.ux);
+  if (ALL) {
+    const bool s0 = fabsf(dx * A.ux + dy * A.uy) > A.hl + B.hl * ac + B.hw * as;
+    const bool s1 = fabsf(dy * A.ux - dx * A.uy) > A.hw + B.hl * as + B.hw * ac;
+    const bool s2 = fabsf(dx * B.ux + dy * B.uy) > B.hl + A.hl * ac + A.hw * as;
+    const bool s3 = fabsf(dy * B.ux - dx * B.uy) > B.hw + A.hl * as + A.hw * ac;
+    return !(s0 | s1 | s2 | s3);
+  }
   if (fabsf(dx * A.ux + dy * A.uy) > A.hl + B.hl * ac + B.hw * as) return false;
   if (fabsf(dy * A.ux - dx * A.uy) > A.hw + B.hl * as + B.hw * ac) return false;
   if (fabsf(dx * B.ux + dy * B.uy) > B.hl + A.hl * ac + A.hw * as) return false;
@@ -281,9 +292,9 @@ DEV float ray_obb(const Obb& o, float px, float py, float dx, float dy);
 // OBJ is a compile-time switch: engines whose scenarios hold no traffic objects run kernels without the circle paths.
 template <bool OBJ>
 DEV bool shape_is_circle(const Obb& o) { return OBJ && o.hw < 0.0f; }
-template <bool OBJ>
+template <bool OBJ, bool ALL = false>
 DEV bool shape_overlap(const Obb& box, const Obb& other) {
-  if (!shape_is_circle<OBJ>(other)) return obb_overlap(box, other);
+  if (!shape_is_circle<OBJ>(other)) return obb_overlap<ALL>(box, other);
   return point_obb_dist(box, other.cx, other.cy) <= other.hl;
 }
 template <bool OBJ>
@@ -313,26 +324,16 @@ DEV float ray_obb(const Obb& o, float px, float py, float dx, float dy) {
   float rx = px - o.cx, ry = py - o.cy;
   float ox = rx * o.ux + ry * o.uy, oy = ry * o.ux - rx * o.uy;
   float vx = dx * o.ux + dy * o.uy, vy = dy * o.ux - dx * o.uy;
-  float t0 = 0.0f, t1 = 1.0f;
-  if (fabsf(vx) < 1e-12f) {
-    if (fabsf(ox) > o.hl) return 1.0f;
-  } else {
-    float inv = 1.0f / vx;
-    float a = (-o.hl - ox) * inv, b = (o.hl - ox) * inv;
-    t0 = fmaxf(t0, fminf(a, b));
-    t1 = fminf(t1, fmaxf(a, b));
-    if (t0 > t1) return 1.0f;
-  }
-  if (fabsf(vy) < 1e-12f) {
-    if (fabsf(oy) > o.hw) return 1.0f;
-  } else {
-    float inv = 1.0f / vy;
-    float a = (-o.hw - oy) * inv, b = (o.hw - oy) * inv;
-    t0 = fmaxf(t0, fminf(a, b));
-    t1 = fminf(t1, fmaxf(a, b));
-    if (t0 > t1) return 1.0f;
-  }
-  return t0 > 0.0f ? t0 : 1.0f;  // origin inside the box: no hit (Bullet's convex ray cast semantics)
+  // the two slabs without a branch (the same operations on the same operands as the branching form: a ray parallel to a slab --
+  // |v| < 1e-12 -- leaves the interval as it is when the origin lies inside the slab and empties it otherwise): a wave that casts
+  // 64 different (ray, box) incidences took every path of the branching form anyway, at four exec-mask switches each
+  const bool par_x = fabsf(vx) < 1e-12f, par_y = fabsf(vy) < 1e-12f;
+  const float ix = 1.0f / (par_x ? 1.0f : vx), iy = 1.0f / (par_y ? 1.0f : vy);
+  const float ax = (-o.hl - ox) * ix, bx = (o.hl - ox) * ix, ay = (-o.hw - oy) * iy, by = (o.hw - oy) * iy;
+  const float lox = par_x ? (fabsf(ox) > o.hl ? 2.0f : 0.0f) : fminf(ax, bx), hix = par_x ? 1.0f : fmaxf(ax, bx);
+  const float loy = par_y ? (fabsf(oy) > o.hw ? 2.0f : 0.0f) : fminf(ay, by), hiy = par_y ? 1.0f : fmaxf(ay, by);
+  const float t0 = fmaxf(fmaxf(0.0f, lox), loy), t1 = fminf(fminf(1.0f, hix), hiy);
+  return (t0 <= t1 && t0 > 0.0f) ? t0 : 1.0f;  // origin inside the box: no hit (Bullet's convex ray cast semantics)
 }
 
 // BaseVehicle.projection (base_vehicle.py:460-475)

@@ -446,8 +446,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (near_env) {
     const int my_kind = (OBJ && valid) ? s_kind[slot] : PGD_OBJ_VEHICLE;
     // pose-by-pose test of body `bs` against agent `as` (slots of the snapshot); everything comes from LDS
+    constexpr bool PAIR_LISTS = ONE_ENV && MARL && !OBJ;  // (the engines that may take the contact-list path below)
     auto pair_touch = [&](const int bs, const int as, const Obb& me, const float my_trav, const Obb& ag, const float ag_trav) {
-      bool hit = shape_overlap<OBJ>(ag, me);
+      bool hit = shape_overlap<OBJ, PAIR_LISTS>(ag, me);
       for (int k = 0; k < n_mid && !hit; ++k) {
         Obb ak = ag, mk = me;
         if (ag_trav > 0.0f) {  // heading = motion direction rotated back by the slip angle (unit up to rounding)
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
           const float4 q = SUBP.p[k][bs]; const float2 b = SUBP.beta[bs];
           mk.cx = q.x; mk.cy = q.y; mk.ux = q.z * b.x + q.w * b.y; mk.uy = q.w * b.x - q.z * b.y;
         }
-        hit = shape_overlap<OBJ>(ak, mk);
+        hit = shape_overlap<OBJ, PAIR_LISTS>(ak, mk);
       }
       return hit;
     };
