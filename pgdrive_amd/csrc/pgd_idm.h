@@ -73,22 +73,23 @@ DEV void find_front_back(const MapView& mv, const Grp& g, const Snap& S, int bas
       const int ol = S.lane[base + o];
       const float olon = S.lon[base + o], ollen = S.llen[base + o];
       const int4 osucc = S.succ[base + o];
-      if (ol == tl) {
-        float lg = olon - cur;
-        if (same_f > lg && lg > 0.0f) { same_f = lg; o_same_f = o; found_f = true; }
-        if (lg < 0.0f && fabsf(lg) < same_b) { same_b = fabsf(lg); o_same_b = o; found_b = true; }
-      } else {
-        const bool is_succ = succ_has(lsucc, ol);
-        if (is_succ) {
-          float lg = olon + left_long;
-          if (succ_f > lg && lg > 0.0f) { succ_f = lg; o_succ_f = o; }
-        }
-        if (succ_has(osucc, tl)) {
-          float lg = ollen - olon + cur;
-          if (pred_b > lg) { pred_b = lg; o_pred_b = o; }
-          if (!is_succ && pred_bx > lg) { pred_bx = lg; o_pred_bx = o; }
-        }
-      }
+      // the five running minima by selects: the search lanes of a wave (three target lanes per vehicle) meet the same body on
+      // different kinds of lane -- its own, a successor, a predecessor, none -- and took every branch of the nested form one after
+      // the other; the same comparisons on the same values, predicated
+      const bool same = ol == tl;
+      const bool is_succ = !same && succ_has(lsucc, ol);
+      const bool is_pred = !same && succ_has(osucc, tl);
+      const float lg_s = olon - cur, lg_f = olon + left_long, lg_p = ollen - olon + cur;
+      const bool u0 = same && same_f > lg_s && lg_s > 0.0f;
+      const bool u1 = same && lg_s < 0.0f && fabsf(lg_s) < same_b;
+      const bool u2 = is_succ && succ_f > lg_f && lg_f > 0.0f;
+      const bool u3 = is_pred && pred_b > lg_p;
+      const bool u4 = is_pred && !is_succ && pred_bx > lg_p;
+      same_f = u0 ? lg_s : same_f; o_same_f = u0 ? o : o_same_f; found_f = found_f || u0;
+      same_b = u1 ? fabsf(lg_s) : same_b; o_same_b = u1 ? o : o_same_b; found_b = found_b || u1;
+      succ_f = u2 ? lg_f : succ_f; o_succ_f = u2 ? o : o_succ_f;
+      pred_b = u3 ? lg_p : pred_b; o_pred_b = u3 ? o : o_pred_b;
+      pred_bx = u4 ? lg_p : pred_bx; o_pred_bx = u4 ? o : o_pred_bx;
     }
     // objects on the lane itself take precedence; an object on a successor lane is only a "front" candidate while no
     // same-lane front object exists, and only then is it barred from being a "back" candidate (the reference's elif)
