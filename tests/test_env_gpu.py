@@ -212,6 +212,55 @@ def test_safe_env_cost_to_reward_and_object_contact():
         env.close()
 
 
+def test_reference_navigation_controller():
+    """tests/test_functionality/test_navigation.py:23-95 (upstream it only has to run): a PID on o[0] -- the lateral distance to the
+    left road edge -- towards 0.375 steers the car (action [-steering, acc]), a second PID on the speed [km/h] holds 30, or 20 while
+    o[12] (lane angle of the first check point) says a curve is ahead; 10 maps of 7 blocks from seed 5.  On this engine
+    the controller must do what it was written to do: keep the car on the road through curves, ramps and junctions and bring it to
+    the destination -- which pins the meaning and the sign of o[0], o[12] and of the steering input at once."""
+    from pgdrive_amd import _abi
+    from pgdrive_amd.env import PGDriveEnv
+
+    class PID:  # component/vehicle_module/PID_controller.py:1-23
+        def __init__(self, kp, ki, kd):
+            self.kp, self.ki, self.kd = kp, ki, kd
+            self.reset()
+
+        def reset(self):
+            self.p = self.i = self.d = 0.0
+
+        def get_result(self, e):
+            self.i += e
+            self.d = e - self.p
+            self.p = e
+            return -(self.kp * self.p + self.ki * self.i + self.kd * self.d)
+
+    env = PGDriveEnv(dict(environment_num=10, traffic_density=0.0, start_seed=5, map=7,
+                          map_config=dict(lane_width=3.5, lane_num=3)))
+    try:
+        steer_c, acc_c = PID(1.6, 0.0008, 27.3), PID(0.1, 0.001, 0.3)
+        o = env.reset()
+        speed = lambda: abs(float(env.vec.engine.get_state()[0][_abi.SF["SPEED"], 0, 0])) * 3.6
+        steering = steer_c.get_result(o[0] - 0.375)
+        acc = acc_c.get_result(speed() - 30.0)
+        ends = []
+        for t in range(1, 6000):  # (upstream: 2000 steps; three times that so that several maps are driven to their end)
+            o, r, d, info = env.step([-steering, acc])
+            steering = steer_c.get_result(o[0] - 0.375)
+            t_speed = 30.0 if abs(o[12] - 0.5) < 0.01 else 20.0
+            acc = acc_c.get_result(speed() - t_speed)
+            if d:
+                ends.append("arrive" if info["arrive_dest"] else ("out_of_road" if info["out_of_road"] else "other"))
+                o = env.reset()
+                steer_c.reset(); acc_c.reset()
+                steering = steer_c.get_result(o[0] - 0.375)
+                acc = acc_c.get_result(speed() - 30.0)
+        print("navigation controller: episodes ended", ends)
+        assert len(ends) >= 2 and all(e == "arrive" for e in ends), ends
+    finally:
+        env.close()
+
+
 @pytest.mark.parametrize("traffic_density", [0.0, 0.1])
 def test_reference_expert_across_the_map_bank(traffic_density):
     """The band evidence behind the kinematic-bicycle substitution (a3), widened from the reference test's one map to the 100
