@@ -70,9 +70,13 @@ class MultiAgentRoundaboutVecEnv:
         self.desc = self._generate_map(c["map_config"])
         descs = self.desc if isinstance(self.desc, (list, tuple)) else [self.desc]
         self.map_bank = mapdata.MapBank(list(descs), truncate_succ=True)  # no IDM traffic on the multi-agent maps
-        cap = c["max_agents"] or c["num_agents"]
+        # num_agents = -1: "as many vehicles as possible" (base_env.py:25) -- every spawn slot at the start, and the respawn rule
+        # stops counting agents (agent_manager.py:316-323).  The reference then grows without bound; here the slot capacity
+        # `max_agents` bounds it (default: the number of spawn slots, at most 64 bodies per env)
+        cap = c["max_agents"] or (c["num_agents"] if c["num_agents"] != -1 else None)
         self.scen_bank = scenario.MarlScenarioBank(self.desc, c["num_agents"], capacity=cap,
                                                    n_variants=c["spawn_variants"], seed=c["seed"], kind=self.MAP_KIND)
+        cap = self.scen_bank.A
         self.num_envs, self.A = int(c["num_envs"]), cap
         self.cfg = _abi.make_config(
             self.num_envs, num_agents=cap, num_traffic=self.scen_bank.B, num_lasers=lid["num_lasers"],
@@ -85,7 +89,7 @@ class MultiAgentRoundaboutVecEnv:
             crash_vehicle_penalty=c["crash_vehicle_penalty"], crash_object_penalty=c["crash_object_penalty"],
             driving_reward=c["driving_reward"], speed_reward=c["speed_reward"], use_lateral=c["use_lateral"],
             multi_agent=True, crash_done=c["crash_done"], out_of_road_done=c["out_of_road_done"],
-            allow_respawn=c["allow_respawn"], delay_done=c["delay_done"], agent_limit=c["num_agents"],
+            allow_respawn=c["allow_respawn"], delay_done=c["delay_done"], agent_limit=cap if self.scen_bank.infinite else c["num_agents"],
             respawn_places=self.scen_bank.P, respawn_dests=self.scen_bank.Dn,
             side_lasers=sd["num_lasers"] if sd["distance"] > 0 else 0, side_dist=sd["distance"],
             lane_line_lasers=ld["num_lasers"] if ld["distance"] > 0 else 0, lane_line_dist=ld["distance"],

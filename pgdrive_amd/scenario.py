@@ -554,11 +554,14 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
     marl_inout_roundabout.py:125-130); followed by the respawn table [safe place][destination].
     `rng` is a numpy RandomState (the reference leaves this manager unseeded).  `kind` selects the spawn roads; the
     destination rule is the same on the intersection map (InterectionSpawnManager, marl_intersection.py:57-62)."""
-    A = capacity or num_agents
     spawn_roads = MARL_SPAWN_ROADS[kind](desc)
     slots, safe = spawn_slots(desc, spawn_roads)
-    if num_agents > len(slots):
-        raise ValueError("Too many agents! We only accept %d agents" % len(slots))
+    infinite = num_agents == -1  # "as many vehicles as possible" (base_env.py:25): every spawn slot, in slot order
+    if infinite:
+        num_agents = len(slots)
+    A = capacity or num_agents
+    if num_agents > len(slots) or num_agents > A:
+        raise ValueError("Too many agents! We only accept %d agents" % min(len(slots), A))
     auto = kind in MARL_AUTO_DEST
 
     def auto_dest(c):  # Navigation.update (navigation.py:99-121): last block's socket, first block's on a negative road
@@ -588,7 +591,8 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
         r["ckpt"][:2] = [road["frm"], road["to"]]
         r["ckpt_road"][0] = lane["road"]
         r["dest_lane"] = road["first_lane"] + road["n_lanes"] - 1
-    pick = rng.choice(len(slots), num_agents, replace=False)
+    # (spawn_manager.py:76-81: all slots in order when the number of agents is -1, else a draw without replacement)
+    pick = np.arange(len(slots)) if infinite else rng.choice(len(slots), num_agents, replace=False)
     lo, la = RESPAWN_REGION_LONGITUDE - MAX_VEHICLE_LENGTH, RESPAWN_REGION_LATERAL - MAX_VEHICLE_WIDTH
     for a, idx in enumerate(pick):
         c = slots[int(idx)]
@@ -630,11 +634,14 @@ def build_parking_scenario(desc, map_index, rng, num_agents, capacity=None, vehi
     destination (distinct spaces), one that starts in a space drives out through a random access road.  The respawn table
     holds [access-road place][parking space]: upstream never re-fills the spaces themselves (its availability test
     compares the out-direction spawn road with the in-direction destination roads and so never succeeds)."""
-    A = capacity or num_agents
     in_roads, out_roads, spaces = parking_lot_roads(desc)
     slots, safe = spawn_slots(desc, in_roads + out_roads)
-    if num_agents > len(slots):
-        raise ValueError("Too many agents! We only accept %d agents" % len(slots))
+    infinite = num_agents == -1
+    if infinite:
+        num_agents = len(slots)
+    A = capacity or num_agents
+    if num_agents > len(slots) or num_agents > A:
+        raise ValueError("Too many agents! We only accept %d agents" % min(len(slots), A))
     S = len(spaces)
     places = [c for c in safe if c["road"] in in_roads]
     P, Dn = len(places), S
@@ -642,7 +649,7 @@ def build_parking_scenario(desc, map_index, rng, num_agents, capacity=None, vehi
     recs["lane"] = -1
     recs["group"] = -1
     avail = list(range(S))
-    pick = rng.choice(len(slots), num_agents, replace=False)
+    pick = np.arange(len(slots)) if infinite else rng.choice(len(slots), num_agents, replace=False)
     lo, la = RESPAWN_REGION_LONGITUDE - MAX_VEHICLE_LENGTH, RESPAWN_REGION_LATERAL - MAX_VEHICLE_WIDTH
     for a, idx in enumerate(pick):
         c = slots[int(idx)]
@@ -697,6 +704,10 @@ class MarlScenarioBank:
                 recs.append(rc)
         self.scenarios = np.array(scens, dtype=SCEN_DT)
         self.spawns = np.concatenate(recs)
+        self.infinite = num_agents == -1  # AgentManager.allow_respawn ignores the agent count then (agent_manager.py:316-323)
+        if self.infinite:  # every spawn slot is filled at the start: the records that hold a lane
+            num_agents = int((recs[0]["lane"][:capacity or len(recs[0])] >= 0).sum()) if capacity else \
+                len(recs[0]) - self.B - self.P * self.Dn
         self.A = capacity or num_agents
         self.V = self.A + self.B  # agents + static bodies (toll booths)
         self.num_agents = num_agents

@@ -152,6 +152,38 @@ def test_marl_dict_protocol(kind):
         env.close()
 
 
+def test_infinite_agents():
+    """tests/test_functionality/test_marl_infinite_agents.py:4-63: num_agents = -1 on the roundabout with short exits (8 spawn slots),
+    delay_done 50 / 0, horizon 50: every agent that finishes has lived at least one step, the population never falls below what a
+    respawn can refill and grows beyond the initial count when the slot capacity allows it (`max_agents`; the reference itself has no
+    cap)."""
+    from pgdrive_amd import marl_env
+    for delay_done, act, steps in ((50, [1.0, 1.0], 600), (0, [0.0, 1.0], 300)):
+        env = marl_env.MultiAgentRoundaboutEnv(dict(map_config=dict(exit_length=20, lane_num=2), num_agents=-1, max_agents=24,
+                                                     delay_done=delay_done, horizon=50, seed=100))
+        try:
+            o = env.reset()
+            old_num = max_num = len(o)
+            assert old_num == 8  # lane_num 2 x 4 spawn roads x floor((20 - 10) / 8) slots (spawn_manager.py:105-112)
+            finished = 0
+            for t in range(1, steps):
+                o, r, d, info = env.step({k: act for k in o})
+                for k, i in info.items():
+                    if d[k]:
+                        assert i["episode_length"] >= 1
+                        finished += 1
+                if d["__all__"]:
+                    o = env.reset()
+                else:
+                    o = {k: v for k, v in o.items() if not d[k]}
+                max_num = max(max_num, len(o))
+            assert finished > 0 and max_num >= old_num
+            if delay_done == 0:
+                assert max_num > old_num  # respawns while the first agents still drive: more agents than spawn slots
+        finally:
+            env.close()
+
+
 def test_safe_env():
     """tests/test_env/test_safe_env.py:4-18 plus the invariants of safe_pgdrive_env.py:7-60: crashes cost instead of ending
     the episode, total_cost accumulates, a traffic object costs only on its first contact."""

@@ -47,6 +47,29 @@ def test_spawn_slots_match_reference():
         scenario.MarlScenarioBank(d, num_agents=49, n_variants=1)
 
 
+def test_infinite_agents_fill_every_spawn_slot_in_order():
+    """num_agents = -1 ("as many vehicles as possible", base_env.py:25): SpawnManager.reset takes every slot in slot order instead of
+    a draw (spawn_manager.py:76-81), and AgentManager.allow_respawn stops counting agents (agent_manager.py:316-323)."""
+    d = _desc()
+    slots, safe = scenario.spawn_slots(d, scenario.roundabout_spawn_roads(d))
+    sb = scenario.MarlScenarioBank(d, num_agents=-1, n_variants=3, seed=4)
+    assert sb.infinite and sb.num_agents == sb.A == len(slots) == 48
+    per = sb.spawns.reshape(3, -1)
+    lo = abs(scenario.RESPAWN_REGION_LONGITUDE - scenario.MAX_VEHICLE_LENGTH)
+    la = abs(scenario.RESPAWN_REGION_LATERAL - scenario.MAX_VEHICLE_WIDTH)
+    for v in range(3):
+        assert (per[v]["lane"][:48] == np.array([c["lane"] for c in slots])).all()  # slot order, every variant
+        # (jittered inside the slot, spawn_manager.py:157-166)
+        for a, c in enumerate(slots):
+            x, y = mapdata.lane_position(d["lanes"][c["lane"]], c["long"], 0.0)
+            assert np.hypot(per[v]["x"][a] - x, per[v]["y"][a] - y) <= np.hypot(0.5 * lo, 0.5 * la) + 1e-4
+    big = scenario.MarlScenarioBank(d, num_agents=-1, capacity=60, n_variants=1)  # room to grow beyond the initial 48
+    assert big.A == 60 and big.num_agents == 48 and (big.spawns["lane"][48:60] == -1).all()
+    import pytest
+    with pytest.raises(ValueError, match="Too many agents"):
+        scenario.MarlScenarioBank(d, num_agents=-1, capacity=40, n_variants=1)
+
+
 def test_oracle_marl_episode_protocol():
     """delay-done queue, respawn ids, horizon, __all__ + auto-reset on the CPU oracle."""
     from oracle import orc
