@@ -23,6 +23,9 @@ MA_DEFAULT_CONFIG = dict(
     num_agents=40,
     map_config=dict(exit_length=60, lane_num=2, lane_width=3.5),  # marl_inout_roundabout.py:23
     max_agents=None,  # slot capacity per env (default: num_agents); the reference has no cap
+    # {"agent{k}": dict(spawn_lane_index=(from, to, lane), spawn_longitude=, spawn_lateral=, destination_node=)}: these agents start
+    # where they are told instead of in a drawn spawn slot (multi_agent_pgdrive.py:96-107, spawn_manager.py:58-69)
+    target_vehicle_configs=None,
     crash_done=True,
     out_of_road_done=True,
     delay_done=25,
@@ -74,8 +77,20 @@ class MultiAgentRoundaboutVecEnv:
         # stops counting agents (agent_manager.py:316-323).  The reference then grows without bound; here the slot capacity
         # `max_agents` bounds it (default: the number of spawn slots, at most 64 bodies per env)
         cap = c["max_agents"] or (c["num_agents"] if c["num_agents"] != -1 else None)
-        self.scen_bank = scenario.MarlScenarioBank(self.desc, c["num_agents"], capacity=cap,
-                                                   n_variants=c["spawn_variants"], seed=c["seed"], kind=self.MAP_KIND)
+        fixed = None
+        if c["target_vehicle_configs"]:
+            if self.PARKING:
+                raise ValueError("target_vehicle_configs: not supported on the parking lot (its spawn manager hands out parking spaces)")
+            fixed = {}
+            for k, v in c["target_vehicle_configs"].items():
+                if not (isinstance(k, str) and k.startswith("agent") and k[5:].isdigit()):
+                    raise KeyError("target_vehicle_configs: agent names are 'agent0', 'agent1', ... (got %r)" % (k, ))
+                unknown = set(v) - {"spawn_lane_index", "spawn_longitude", "spawn_lateral", "destination_node"}
+                if unknown:
+                    raise KeyError("target_vehicle_configs[%r]: unknown keys %s" % (k, sorted(unknown)))
+                fixed[int(k[5:])] = dict(v)
+        self.scen_bank = scenario.MarlScenarioBank(self.desc, c["num_agents"], capacity=cap, n_variants=c["spawn_variants"],
+                                                   seed=c["seed"], kind=self.MAP_KIND, fixed=fixed)
         cap = self.scen_bank.A
         self.num_envs, self.A = int(c["num_envs"]), cap
         self.cfg = _abi.make_config(

@@ -548,12 +548,16 @@ def map_buildings(desc):
     return [b for blk in desc["blocks"] for b in blk.get("buildings", [])]
 
 
-def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle_model="default", kind="roundabout"):
+def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle_model="default", kind="roundabout", fixed=None):
     """SpawnManager.reset (spawn_manager.py:68-101): `num_agents` of the spawn slots without replacement, jittered inside
     the slot, each with a random destination (RoundaboutSpawnManager.update_destination_for,
     marl_inout_roundabout.py:125-130); followed by the respawn table [safe place][destination].
     `rng` is a numpy RandomState (the reference leaves this manager unseeded).  `kind` selects the spawn roads; the
-    destination rule is the same on the intersection map (InterectionSpawnManager, marl_intersection.py:57-62)."""
+    destination rule is the same on the intersection map (InterectionSpawnManager, marl_intersection.py:57-62).
+    `fixed`: {agent index: dict(spawn_lane_index, spawn_longitude, spawn_lateral, destination_node)} -- the agents named in
+    `target_vehicle_configs` keep the placement they were given (`not_randomize`, multi_agent_pgdrive.py:96-107 and
+    spawn_manager.py:58-69,91-100): the slot draw and the jitter still happen for every agent, then the given placement replaces
+    the drawn one; a destination that was not given is still drawn."""
     spawn_roads = MARL_SPAWN_ROADS[kind](desc)
     slots, safe = spawn_slots(desc, spawn_roads)
     infinite = num_agents == -1  # "as many vehicles as possible" (base_env.py:25): every spawn slot, in slot order
@@ -599,8 +603,17 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
         lon = c["long"] + rng.uniform(-lo / 2, lo / 2)
         lat = c["lat"] + rng.uniform(-la / 2, la / 2)
         params = sample_vehicle_params(vehicle_model, int(rng.randint(0, MAX_RAND_INT)))
+        fx = (fixed or {}).get(a)
+        if fx is not None:
+            c = dict(c, lane=resolve_lane_index(desc, fx.get("spawn_lane_index") or (">", ">>", 0)))
+            lon, lat = float(fx.get("spawn_longitude", 5.0)), float(fx.get("spawn_lateral", 0.0))
         _fill_vehicle(recs[a], desc, c["lane"], lon, lat, params)
-        _fill_route(recs[a], desc, c["lane"], auto_dest(c) if auto else dests[int(rng.randint(0, Dn))])
+        if fx is not None and fx.get("destination_node") is not None:
+            if fx["destination_node"] not in desc["nodes"]:
+                raise KeyError("destination_node %r: no such node in the map" % (fx["destination_node"], ))
+            _fill_route(recs[a], desc, c["lane"], desc["nodes"].index(fx["destination_node"]))
+        else:
+            _fill_route(recs[a], desc, c["lane"], auto_dest(c) if auto else dests[int(rng.randint(0, Dn))])
     for p, c in enumerate(safe):
         for dn, dest in enumerate(dests):
             r = recs[A + B + p * Dn + dn]
@@ -682,7 +695,7 @@ def build_parking_scenario(desc, map_index, rng, num_agents, capacity=None, vehi
 
 class MarlScenarioBank:
     """`n_variants` random initial placements over one multi-agent map (scenarios differ only in spawn choice)."""
-    def __init__(self, desc, num_agents, capacity=None, n_variants=16, seed=0, kind="roundabout"):
+    def __init__(self, desc, num_agents, capacity=None, n_variants=16, seed=0, kind="roundabout", fixed=None):
         """`desc`: one map description, or a list of them (kind "pg": the generic multi-agent env over several generated
         maps, `n_variants` placements per map; the respawn table has the same shape on every map)."""
         rng = np.random.RandomState(seed)
@@ -694,7 +707,7 @@ class MarlScenarioBank:
                 if kind == "parking":
                     sc, rc, self.P, self.Dn, self.B = build_parking_scenario(dm, m, rng, num_agents, capacity)
                 else:
-                    sc, rc, self.P, self.Dn, self.B = build_marl_scenario(dm, m, rng, num_agents, capacity, kind=kind)
+                    sc, rc, self.P, self.Dn, self.B = build_marl_scenario(dm, m, rng, num_agents, capacity, kind=kind, fixed=fixed)
                 if shape is None:
                     shape = (self.P, self.Dn, self.B)
                 elif shape != (self.P, self.Dn, self.B):

@@ -152,6 +152,42 @@ def test_marl_dict_protocol(kind):
         env.close()
 
 
+def test_naive_multi_agent_pgdrive():
+    """tests/test_env/test_naive_multi_agent.py:24-66: MultiAgentPGDrive on map "SSS" with four agents whose
+    `target_vehicle_configs` line them up on the first lane at longitudes 0 / 5 / 10 / 15 m: Dict spaces, dict-keyed steps,
+    and the agents start where they were told (upstream checks that none of them is thrown into the air by overlapping spawns;
+    here the first step must report no contact between them and every agent still on its lane)."""
+    from pgdrive_amd import marl_env, _abi, mapdata
+    env = marl_env.MultiAgentPGDrive(dict(map="SSS", num_agents=4, seed=1,
+                                          target_vehicle_configs={"agent%d" % i: dict(spawn_longitude=i * 5) for i in range(4)}))
+    try:
+        o = env.reset()
+        assert isinstance(o, dict) and sorted(o) == ["agent%d" % i for i in range(4)]
+        f, i, _ = env.vec.engine.get_state()
+        d = env.vec.map_bank.descs[0]
+        lane0 = int(i[_abi.SI["LANE"], 0, 0])
+        for k in range(4):
+            # (the spawn lane is the 10 m entrance lane: the agent told to start at 15 m stands on its straight continuation,
+            # and the localisation says so)
+            assert (i[_abi.SI["LANE"], 0, k] == lane0) == (5.0 * k <= d["lanes"][lane0]["length"])
+            lon, lat = mapdata.lane_local_coordinates(d["lanes"][lane0], (float(f[_abi.SF["X"], 0, k]), float(f[_abi.SF["Y"], 0, k])))
+            assert abs(lon - 5.0 * k) < 1e-4 and abs(lat) < 1e-4
+        rng = np.random.default_rng(0)
+        for t in range(100):
+            a = {k: rng.uniform(-1, 1, size=2).astype(np.float32) for k in o}
+            o2, r, dn, info = env.step(a)
+            assert set(o2) == set(r) == set(info) == set(dn) - {"__all__"}
+            for k in o2:
+                assert env.vec.single_observation_space.contains(o2[k]) and isinstance(info[k], dict)
+            if t == 0:
+                assert not any(info[k]["crash_vehicle"] for k in info)
+            o = {k: v for k, v in o2.items() if not dn[k]}
+            if dn["__all__"]:
+                break
+    finally:
+        env.close()
+
+
 def test_infinite_agents():
     """tests/test_functionality/test_marl_infinite_agents.py:4-63: num_agents = -1 on the roundabout with short exits (8 spawn slots),
     delay_done 50 / 0, horizon 50: every agent that finishes has lived at least one step, the population never falls below what a

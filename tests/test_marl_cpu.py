@@ -70,6 +70,39 @@ def test_infinite_agents_fill_every_spawn_slot_in_order():
         scenario.MarlScenarioBank(d, num_agents=-1, capacity=40, n_variants=1)
 
 
+def test_target_vehicle_configs_pin_the_named_agents():
+    """multi_agent_pgdrive.py:96-107 + spawn_manager.py:58-69,91-100: an agent named in `target_vehicle_configs` starts where it is
+    told (lane by node names, longitude, lateral, optionally its destination); the others keep their drawn slots, and the draws of
+    the generator are the same with and without the override (the placement replaces the drawn one afterwards)."""
+    from pgdrive_amd import bank
+    d = bank.get_descriptions([0], 3, 3.5, 50, block_seq="SSS", block_num=None)[0]
+    plain = scenario.MarlScenarioBank([d], num_agents=4, n_variants=2, seed=3, kind="pg")
+    fixed = {k: dict(spawn_longitude=5.0 * k) for k in range(4)}
+    fixed[2]["spawn_lane_index"] = (">", ">>", 1)
+    ref0 = plain.spawns.reshape(2, -1)[0]
+    dest_node = d["nodes"][int(ref0["ckpt"][0][int(ref0["n_ckpt"][0]) - 1])]  # a reachable node: where agent 0 is headed anyway
+    mid_node = d["nodes"][int(ref0["ckpt"][0][int(ref0["n_ckpt"][0]) - 2])]   # ... and one node before it: a shorter route
+    fixed[3]["destination_node"] = mid_node
+    sb = scenario.MarlScenarioBank([d], num_agents=4, n_variants=2, seed=3, kind="pg", fixed=fixed)
+    first = scenario.resolve_lane_index(d, (">", ">>", 0))
+    per, ref = sb.spawns.reshape(2, -1), plain.spawns.reshape(2, -1)
+    for v in range(2):
+        for k in range(4):
+            lane = d["lanes"][first + (1 if k == 2 else 0)]
+            x, y = mapdata.lane_position(lane, 5.0 * k, 0.0)
+            assert per[v]["lane"][k] == first + (1 if k == 2 else 0)
+            assert abs(per[v]["x"][k] - x) < 1e-5 and abs(per[v]["y"][k] - y) < 1e-5
+            # same vehicle parameters as without the override: the generator's stream is untouched
+            assert per[v]["length"][k] == ref[v]["length"][k] and per[v]["max_engine_force"][k] == ref[v]["max_engine_force"][k]
+        n = int(per[v]["n_ckpt"][3])
+        assert d["nodes"][int(per[v]["ckpt"][3][n - 1])] == mid_node != dest_node
+        # the respawn table behind the agent slots is the same
+        assert (per[v][4:] == ref[v][4:]).all()
+    import pytest
+    with pytest.raises(KeyError):
+        scenario.MarlScenarioBank([d], num_agents=4, n_variants=1, kind="pg", fixed={0: dict(destination_node="no such node")})
+
+
 def test_oracle_marl_episode_protocol():
     """delay-done queue, respawn ids, horizon, __all__ + auto-reset on the CPU oracle."""
     from oracle import orc
