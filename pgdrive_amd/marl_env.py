@@ -22,6 +22,7 @@ MA_DEFAULT_CONFIG = dict(
     num_envs=1,
     num_agents=40,
     map_config=dict(exit_length=60, lane_num=2, lane_width=3.5),  # marl_inout_roundabout.py:23
+    neighbours_distance=10,  # defined upstream (multi_agent_pgdrive.py:35) and read nowhere: accepted, without effect
     max_agents=None,  # slot capacity per env (default: num_agents); the reference has no cap
     # {"agent{k}": dict(spawn_lane_index=(from, to, lane), spawn_longitude=, spawn_lateral=, destination_node=)}: these agents start
     # where they are told instead of in a drawn spawn slot (multi_agent_pgdrive.py:96-107, spawn_manager.py:58-69)
