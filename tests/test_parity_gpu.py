@@ -1180,7 +1180,7 @@ def test_marl_config_combinations_fuzz():
     from oracle import orc
     from pgdrive_amd.engine import Engine
     r = np.random.default_rng(1)
-    for trial in range(16):
+    for trial in range(int(os.environ.get("PGD_FUZZ_TRIALS", "16"))):  # (PGD_FUZZ_TRIALS=120: the one-off campaign of the docstring)
         kind = str(r.choice(["roundabout", "intersection", "bottleneck", "parking", "pg"]))
         na = int(r.choice([4, 8, 12]))
         cap = int(r.choice([na, na + 4]))
