@@ -27,6 +27,9 @@ MA_DEFAULT_CONFIG = dict(
     # {"agent{k}": dict(spawn_lane_index=(from, to, lane), spawn_longitude=, spawn_lateral=, destination_node=)}: these agents start
     # where they are told instead of in a drawn spawn slot (multi_agent_pgdrive.py:96-107, spawn_manager.py:58-69)
     target_vehicle_configs=None,
+    # the roads agents are (re)spawned on: None = the env's own list (e.g. MARoundaboutConfig.spawn_roads), else `Road`-like
+    # objects (start_node / end_node) or (from node name, to node name) pairs
+    spawn_roads=None,
     crash_done=True,
     out_of_road_done=True,
     delay_done=25,
@@ -90,8 +93,10 @@ class MultiAgentRoundaboutVecEnv:
                 if unknown:
                     raise KeyError("target_vehicle_configs[%r]: unknown keys %s" % (k, sorted(unknown)))
                 fixed[int(k[5:])] = dict(v)
+        if c["spawn_roads"] is not None and self.PARKING:
+            raise ValueError("spawn_roads: the parking lot takes in_spawn_roads / out_spawn_roads from its map (marl_parking_lot.py:15-24)")
         self.scen_bank = scenario.MarlScenarioBank(self.desc, c["num_agents"], capacity=cap, n_variants=c["spawn_variants"],
-                                                   seed=c["seed"], kind=self.MAP_KIND, fixed=fixed)
+                                                   seed=c["seed"], kind=self.MAP_KIND, fixed=fixed, spawn_roads=c["spawn_roads"])
         cap = self.scen_bank.A
         self.num_envs, self.A = int(c["num_envs"]), cap
         self.cfg = _abi.make_config(

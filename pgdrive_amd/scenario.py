@@ -548,7 +548,22 @@ def map_buildings(desc):
     return [b for blk in desc["blocks"] for b in blk.get("buildings", [])]
 
 
-def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle_model="default", kind="roundabout", fixed=None):
+def resolve_spawn_roads(desc, spawn_roads):
+    """`spawn_roads` of a multi-agent config as (from node, to node) pairs of this map: the reference passes `Road` objects
+    (start_node / end_node); node-name pairs are accepted as well."""
+    out = []
+    for r in spawn_roads:
+        a, b = (r.start_node, r.end_node) if hasattr(r, "start_node") else (r[0], r[1])
+        if a not in desc["nodes"] or b not in desc["nodes"] or (desc["nodes"].index(a), desc["nodes"].index(b)) not in mapdata.road_lookup(desc):
+            raise KeyError("spawn_roads: no road %r -> %r in the map" % (a, b))
+        out.append((desc["nodes"].index(a), desc["nodes"].index(b)))
+    if not out:
+        raise ValueError("spawn_roads must not be empty (spawn_manager.py:107)")
+    return out
+
+
+def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle_model="default", kind="roundabout", fixed=None,
+                        spawn_roads=None):
     """SpawnManager.reset (spawn_manager.py:68-101): `num_agents` of the spawn slots without replacement, jittered inside
     the slot, each with a random destination (RoundaboutSpawnManager.update_destination_for,
     marl_inout_roundabout.py:125-130); followed by the respawn table [safe place][destination].
@@ -558,7 +573,7 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
     `target_vehicle_configs` keep the placement they were given (`not_randomize`, multi_agent_pgdrive.py:96-107 and
     spawn_manager.py:58-69,91-100): the slot draw and the jitter still happen for every agent, then the given placement replaces
     the drawn one; a destination that was not given is still drawn."""
-    spawn_roads = MARL_SPAWN_ROADS[kind](desc)
+    spawn_roads = MARL_SPAWN_ROADS[kind](desc) if spawn_roads is None else resolve_spawn_roads(desc, spawn_roads)
     slots, safe = spawn_slots(desc, spawn_roads)
     infinite = num_agents == -1  # "as many vehicles as possible" (base_env.py:25): every spawn slot, in slot order
     if infinite:
@@ -695,7 +710,7 @@ def build_parking_scenario(desc, map_index, rng, num_agents, capacity=None, vehi
 
 class MarlScenarioBank:
     """`n_variants` random initial placements over one multi-agent map (scenarios differ only in spawn choice)."""
-    def __init__(self, desc, num_agents, capacity=None, n_variants=16, seed=0, kind="roundabout", fixed=None):
+    def __init__(self, desc, num_agents, capacity=None, n_variants=16, seed=0, kind="roundabout", fixed=None, spawn_roads=None):
         """`desc`: one map description, or a list of them (kind "pg": the generic multi-agent env over several generated
         maps, `n_variants` placements per map; the respawn table has the same shape on every map)."""
         rng = np.random.RandomState(seed)
@@ -707,7 +722,8 @@ class MarlScenarioBank:
                 if kind == "parking":
                     sc, rc, self.P, self.Dn, self.B = build_parking_scenario(dm, m, rng, num_agents, capacity)
                 else:
-                    sc, rc, self.P, self.Dn, self.B = build_marl_scenario(dm, m, rng, num_agents, capacity, kind=kind, fixed=fixed)
+                    sc, rc, self.P, self.Dn, self.B = build_marl_scenario(dm, m, rng, num_agents, capacity, kind=kind, fixed=fixed,
+                                                                          spawn_roads=spawn_roads)
                 if shape is None:
                     shape = (self.P, self.Dn, self.B)
                 elif shape != (self.P, self.Dn, self.B):

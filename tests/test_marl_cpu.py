@@ -103,6 +103,33 @@ def test_target_vehicle_configs_pin_the_named_agents():
         scenario.MarlScenarioBank([d], num_agents=4, n_variants=1, kind="pg", fixed={0: dict(destination_node="no such node")})
 
 
+def test_spawn_roads_override():
+    """`spawn_roads` of the multi-agent configs (marl_inout_roundabout.py:15-28): given as Road-like objects or node-name pairs, the
+    slots, the safe respawn places and the destination list follow the given roads."""
+    d = _desc()
+    n = d["nodes"]
+
+    class Road:  # what the reference's Road offers (road.py): start_node / end_node
+        def __init__(self, a, b):
+            self.start_node, self.end_node = a, b
+
+    two = [Road(">>", ">>>"), (n[scenario.roundabout_spawn_roads(d)[1][0]], n[scenario.roundabout_spawn_roads(d)[1][1]])]
+    sb = scenario.MarlScenarioBank(d, num_agents=6, n_variants=2, seed=0, spawn_roads=two)
+    full = scenario.MarlScenarioBank(d, num_agents=6, n_variants=2, seed=0)
+    assert (sb.P, sb.Dn) == (4, 2) and (full.P, full.Dn) == (8, 4)  # 2 lanes x roads safe places; one destination per road
+    lanes_ok = set()
+    for r in scenario.resolve_spawn_roads(d, two):
+        road = d["roads"][mapdata.road_lookup(d)[r]]
+        lanes_ok |= set(range(road["first_lane"], road["first_lane"] + road["n_lanes"]))
+    per = sb.spawns.reshape(2, -1)
+    assert set(per[0]["lane"][:6].tolist()) <= lanes_ok and set(per[0]["lane"][6:].tolist()) <= lanes_ok
+    import pytest
+    with pytest.raises(KeyError):
+        scenario.MarlScenarioBank(d, num_agents=2, n_variants=1, spawn_roads=[(">>", "nowhere")])
+    with pytest.raises(ValueError, match="Too many agents"):
+        scenario.MarlScenarioBank(d, num_agents=13, n_variants=1, spawn_roads=[(">>", ">>>")])  # 2 lanes x 6 slots
+
+
 def test_oracle_marl_episode_protocol():
     """delay-done queue, respawn ids, horizon, __all__ + auto-reset on the CPU oracle."""
     from oracle import orc
