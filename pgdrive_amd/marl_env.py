@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _abi, bank, mapdata, scenario
 from .spaces import Box, Dict
-from .vec_env import merge_config, strip_reference_only_keys
+from .vec_env import merge_config, resolve_map_choice, strip_reference_only_keys
 
 # MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG + MARoundaboutConfig (multi_agent_pgdrive.py:12-55, marl_inout_roundabout.py:15-28)
 MA_DEFAULT_CONFIG = dict(
@@ -334,11 +334,11 @@ class MultiAgentPGDriveVecEnv(MultiAgentRoundaboutVecEnv):
     5 slots x 3 lanes), destinations from Navigation's default rule, respawn into the same slots."""
     MAP_KIND = "pg"
     DEFAULTS = dict(MA_DEFAULT_CONFIG, num_agents=15, start_seed=0, environment_num=1, map=3,
-                    map_config=dict(exit_length=50, lane_num=3, lane_width=3.5))
+                    map_config=dict(exit_length=50, lane_num=3, lane_width=3.5, type="block_num", config=None))
 
     def _generate_map(self, mc):
         c = self.config
-        m = c["map"]
+        m = resolve_map_choice(c)
         kw = dict(block_num=m) if isinstance(m, int) else dict(block_seq=m, block_num=None)
         seeds = range(c["start_seed"], c["start_seed"] + c["environment_num"])
         return bank.get_descriptions(seeds, mc["lane_num"], mc["lane_width"], mc["exit_length"], **kw)

@@ -18,7 +18,9 @@ DEFAULT_CONFIG = dict(
     start_seed=0,  # the reference's defaults (base_env.py:20-21, pgdrive_env.py:24-25); gym ids set their own ranges
     environment_num=1,  # (pgdrive_amd.env.ENV_IDS = register.py:5-38, e.g. PGDrive-v0: start_seed 1000, 100 maps)
     map=3,
-    map_config=dict(lane_width=3.5, lane_num=3, exit_length=50),
+    # `type` / `config`: the long form of `map` (pgdrive_env.py:31-37, base_map.py:16-35): "block_num" + an int or "block_sequence"
+    # + a string of block ids; `config` = None leaves the choice to `map`
+    map_config=dict(lane_width=3.5, lane_num=3, exit_length=50, type="block_num", config=None),
     random_lane_width=False,  # a lane width per map seed, uniform in [3.0, 4.5) (map_manager.py:157-163)
     random_lane_num=False,  # a lane count per map seed, randint(2, 3) as upstream (map_manager.py:164-167)
     traffic_density=0.1,
@@ -130,6 +132,27 @@ def strip_reference_only_keys(user, keep=()):
     return out
 
 
+def resolve_map_choice(c, default_map=3):
+    """parse_map_config (base_map.py:16-35): a `map_config` that names its own `config` wins (and `map` must then be left at its
+    default, as upstream asserts); else `map` -- an int = number of blocks, a str = block sequence -- fills `type` / `config`.
+    Returns the int or str and writes both forms back into the config."""
+    mc = c["map_config"]
+    if mc.get("config") is not None:
+        if c["map"] != default_map and c["map"] != mc["config"]:
+            raise ValueError("give the map either as `map` or as map_config['config'], not both (%r vs %r)" % (c["map"], mc["config"]))
+        m = mc["config"]
+        want = "block_num" if isinstance(m, int) else "block_sequence"
+        if "type" in mc and mc["type"] not in (want, None) and not (mc["type"] == "block_num" and isinstance(m, str)):
+            raise ValueError("map_config: type %r does not fit config %r" % (mc["type"], m))
+    else:
+        m = c["map"]
+    if not isinstance(m, (int, str)) or isinstance(m, bool):
+        raise ValueError("Unkown easy map config: %r" % (m, ))
+    mc["type"] = "block_num" if isinstance(m, int) else "block_sequence"
+    mc["config"] = m
+    return m
+
+
 def merge_config(default, user, path=""):
     """Nested update that rejects unknown keys (utils/config.py:115-125)."""
     out = copy.deepcopy(default)
@@ -163,7 +186,7 @@ class PGDriveVecEnv:
             if missing:
                 raise KeyError("map seeds %s..%s are not in the map bank" % (missing[0], missing[-1]))
         else:  # BIG on the host: `map` is a block count (int) or a block sequence (str) (base_map.py:16-35)
-            m = c["map"]
+            m = resolve_map_choice(c)
             kw = dict(block_num=m) if isinstance(m, int) else dict(block_seq=m, block_num=None)
             by_seed = {d["seed"]: d for d in bank.get_descriptions(seeds, mc["lane_num"], mc["lane_width"],
                                                                    mc["exit_length"], random_lane_width=c["random_lane_width"],

@@ -303,8 +303,9 @@ def test_reference_navigation_controller():
             self.p = e
             return -(self.kp * self.p + self.ki * self.i + self.kd * self.d)
 
-    env = PGDriveEnv(dict(environment_num=10, traffic_density=0.0, start_seed=5, map=7,
-                          map_config=dict(lane_width=3.5, lane_num=3)))
+    env = PGDriveEnv(dict(environment_num=10, traffic_density=0.0, start_seed=5,  # (the map as upstream's test names it)
+                          map_config=dict(type="block_num", config=7, lane_width=3.5, lane_num=3)))
+    assert env.config["map_config"]["config"] == 7 and len(env.vec.map_bank.descs[0]["blocks"]) == 8  # first block + 7
     try:
         steer_c, acc_c = PID(1.6, 0.0008, 27.3), PID(0.1, 0.001, 0.3)
         o = env.reset()

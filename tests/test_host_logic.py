@@ -122,3 +122,20 @@ def test_reference_config_keys_are_accepted_or_refused_by_name():
             strip_reference_only_keys(bad)
     with pytest.raises(KeyError):
         merge_config(DEFAULT_CONFIG, strip_reference_only_keys(dict(not_a_key=1)))
+
+
+def test_map_choice_short_and_long_form():
+    """parse_map_config (base_map.py:16-35) as tests/test_functionality/test_config_consistency.py:13-56 exercises it: `map` (int =
+    number of blocks, str = block sequence) or map_config["config"] (+ "type"); both forms end up in the config."""
+    from pgdrive_amd.vec_env import DEFAULT_CONFIG, merge_config, resolve_map_choice
+    for user, m, typ in (({}, 3, "block_num"), ({"map": 11}, 11, "block_num"), ({"map": "OO"}, "OO", "block_sequence"),
+                         ({"map_config": {"config": 11}}, 11, "block_num"),
+                         ({"map_config": {"config": "OO", "type": "block_sequence"}}, "OO", "block_sequence")):
+        c = merge_config(DEFAULT_CONFIG, user)
+        assert resolve_map_choice(c) == m and c["map_config"]["config"] == m and c["map_config"]["type"] == typ
+    with pytest.raises(ValueError):
+        resolve_map_choice(merge_config(DEFAULT_CONFIG, {"map": 5, "map_config": {"config": 7}}))
+    with pytest.raises(ValueError):
+        resolve_map_choice(merge_config(DEFAULT_CONFIG, {"map_config": {"config": 7, "type": "block_sequence"}}))
+    with pytest.raises(ValueError):
+        resolve_map_choice(merge_config(DEFAULT_CONFIG, {"map": 2.5}))
