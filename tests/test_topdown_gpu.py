@@ -161,6 +161,28 @@ def test_topdown_env_class():
         env.close()
 
 
+def test_top_down_rendering_like_upstream():
+    """tests/test_env/test_top_down_env.py:6-26: the three env classes in the four configurations upstream runs (map "C", traffic
+    density 1.0, frame_stack / post_stack overrides): every observation of 5 episodes x 20 steps shows something."""
+    from pgdrive_amd.env import TopDownSingleFramePGDriveEnv, TopDownPGDriveEnv, TopDownPGDriveEnvV2
+    for cls, cfg, shape in ((TopDownSingleFramePGDriveEnv, dict(environment_num=5, map="C", traffic_density=1.0), (200, 200, 3)),
+                            (TopDownPGDriveEnv, dict(environment_num=5, map="C", traffic_density=1.0), (84, 84, 5)),
+                            (TopDownPGDriveEnv, dict(environment_num=5, map="C", frame_stack=1, post_stack=2), (84, 84, 3)),
+                            (TopDownPGDriveEnvV2, dict(environment_num=5, map="C", frame_stack=1, post_stack=2), (84, 84, 3))):
+        env = cls(cfg)
+        try:
+            assert env.observation_space.shape == shape
+            for _ in range(5):
+                o = env.reset()
+                assert o.shape == shape and np.mean(o) > 0.0
+                for a in ([0, 1], [-0.05, 1]):
+                    for _ in range(10):
+                        o, *_ = env.step(a)
+                        assert np.mean(o) > 0.0
+        finally:
+            env.close()
+
+
 def test_topdown_rgb_single_frame(descs):
     """TopDownObservation (obs/top_down_obs.py:22-240; TopDownSingleFramePGDriveEnv, top_down_env.py:8-26): one RGB frame
     [200, 200, 3] / 255 -- lane lines (35, 35, 35), the ego GREEN (50, 200, 0) at the centre heading up, the other vehicles BLUE
