@@ -908,8 +908,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       const MapView mvb = mv;
       const unsigned lead_fl = (unsigned)__shfl((int)my_fl, g.lead);  // the step flags are complete in the slot's first lane only
       const EnvInWave in_wave{&r, &SPV, &mvb, lead_fl, scen, steps_total, valid ? s : A, g.sub};  // lanes past the last slot: no agent
-      if (V == A && d.sub == WAVE / A) observe_env_body<1, false, true, OBJ>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g, &in_wave);
-      else observe_env_body<1, false, false, OBJ>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
+      // (V == A and WAVE / A lanes per slot: the host launches this instantiation for no other engine -- step_impl -- so the
+      // read-back form of the routine is not compiled into it: 2 k instructions less in a kernel that filled the instruction cache)
+      observe_env_body<1, false, true, OBJ>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g, &in_wave);
     } else
     observe_env_body<1, false, false, OBJ>(d, e, obs, flags, U.obs.m, U.obs.minb, d.obs_g);
   }
@@ -1772,7 +1773,7 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
                                     : (h->d.epw == 1 ? "k_step: one env per wave" : "k_step: several envs per wave");
   if (marl) {
     kern = h->has_objects ? k_step<true, true, true> : k_step<true, true, false>;  // objects = toll booths
-    if (!h->has_objects && !h->no_fix && fix_config_matches(dv, true, FIXK_MARL)) {
+    if (!h->has_objects && !h->no_fix && fix_config_matches(dv, true, FIXK_MARL) && dv.V == dv.A && dv.sub == WAVE / dv.A) {
       kern = k_step<true, true, false, false, 1>;
       kname = "k_step: one env per wave, specialised for the default multi-agent configuration";
     }
