@@ -1442,6 +1442,9 @@ def test_free_running_timed_path_through_episode_ends(descs):
       * observations in the common prefix stay within the teacher-forced tolerance while the env's traffic is parked and
         within a loose bound after it drives (the IDM traffic is a chaotic closed loop: DESIGN.md section 7)."""
     n_envs, n_steps = 256, 600
+    big = os.environ.get("PGD_FREE_RUN")  # "envs,steps": the one-off larger run of profiles/r04_notes.md
+    if big:
+        n_envs, n_steps = (int(x) for x in big.split(","))
     torch, eng, ora, cfg = _engines(descs, n_envs, seed=11, resample_scenario=1, auto_reset=1)
     ids = np.arange(n_envs) % 8
     o0 = ora.reset(ids)
@@ -1453,6 +1456,7 @@ def test_free_running_timed_path_through_episode_ends(descs):
     reset_rows = reset_rows_bad = 0
     div_at_reset = 0
     worst_parked = worst_driving = 0.0
+    parked_beams = parked_flips = parked_nb_rows = parked_ck_rows = 0
     div_bits = 0
     SI = _abi.SI
     for t in range(n_steps):
@@ -1484,9 +1488,25 @@ def test_free_running_timed_path_through_episode_ends(descs):
         if alive.any():
             _, gi, _ = eng.get_state()
             driving = (gi[SI["STATUS"]][:, 1:] == _abi.ST_ACTIVE).any(axis=1)
-            dd = np.abs(g_obs - o_obs).max(axis=1)
+            dall = np.abs(g_obs - o_obs)
+            dd = dall.max(axis=1)
             if (alive & ~driving).any():
-                worst_parked = max(worst_parked, float(dd[alive & ~driving].max()))
+                # (a beam past a box corner flips hit <-> miss within the free-running drift: counted, like the grazing beams of the
+                # teacher-forced tests -- one in ~1e8 beams, seen only in the larger PGD_FREE_RUN runs)
+                pk = dall[alive & ~driving]
+                flips = pk[:, 34:] > 0.01
+                parked_beams += flips.size
+                parked_flips += int(flips.sum())
+                # (and a body whose nearest point sits on the 50 m broad-phase radius is a neighbour on one side only: its row of
+                # neighbour floats differs wholesale -- the campaign's "neighbour boundary rows")
+                nb_flip = pk[:, 18:34].max(axis=1) > 0.01
+                parked_nb_rows += int(nb_flip.sum())
+                # (and a check point passed one step apart -- the 5 m test on the lane coordinate, navigation.py:262-282 -- shows the
+                # navigation floats of the next road for that one step)
+                ck_flip = pk[:, 8:18].max(axis=1) > 0.01
+                parked_ck_rows += int(ck_flip.sum())
+                worst_parked = max(worst_parked, float(pk[:, :8].max()), float(pk[~ck_flip][:, 8:18].max()) if (~ck_flip).any() else 0.0,
+                                   float(pk[~nb_flip][:, 18:34].max()) if (~nb_flip).any() else 0.0, float(np.where(flips, 0.0, pk[:, 34:]).max()))
             if (alive & driving).any():
                 worst_driving = max(worst_driving, float(np.quantile(dd[alive & driving], 0.99)))
     print("free-running timed path: %d episode ends in the common prefixes, %d agree on step and flags (%.1f %%), %d ended on the "
@@ -1498,6 +1518,10 @@ def test_free_running_timed_path_through_episode_ends(descs):
     assert ends_agree >= 0.95 * ends_oracle and ends_engine_only <= 0.05 * ends_oracle
     assert reset_rows >= 250 and reset_rows_bad == 0, "a restart must reproduce the oracle's first observation"
     assert worst_parked < 4 * OBS_TOL  # the ego alone: free-running fp32 vs fp64 over an episode
+    print("   parked-traffic rows: %d beams, %d flipped past a corner, %d rows with a neighbour on the 50 m radius, %d rows with a check "
+          "point passed one step apart" % (parked_beams, parked_flips, parked_nb_rows, parked_ck_rows))
+    n_rows = parked_beams / 240
+    assert parked_flips <= 1e-6 * parked_beams + 1 and parked_nb_rows <= 1e-5 * n_rows + 1 and parked_ck_rows <= 1e-4 * n_rows + 1
     assert worst_driving < 5e-2
     assert alive.mean() > 0.5
     eng.close()
