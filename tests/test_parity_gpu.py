@@ -1543,6 +1543,8 @@ def test_marl_free_running_through_finishes_and_respawns():
     from pgdrive_amd.engine import Engine
     d, mb, sb = util.make_marl_banks(num_agents=40, capacity=40, kind="roundabout")
     n_envs, n_steps = 48, 400
+    if os.environ.get("PGD_FREE_RUN_MA"):  # "envs,steps": the one-off larger run of profiles/r04_notes.md
+        n_envs, n_steps = (int(x) for x in os.environ["PGD_FREE_RUN_MA"].split(","))
     cfg = util.marl_config(n_envs, sb, horizon=150, resample_scenario=1, seed=7)
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
@@ -1554,7 +1556,7 @@ def test_marl_free_running_through_finishes_and_respawns():
     A = sb.A
     alive = np.ones(n_envs, dtype=bool)
     n_fin = n_fin_alive = n_new = n_new_alive = n_reset = n_reset_alive = 0
-    rows = beams = beams_off = 0
+    rows = beams = beams_off = n_div_reward = 0
     worst = 0.0
     div_bits = 0
     first_div = []
@@ -1566,6 +1568,11 @@ def test_marl_free_running_through_finishes_and_respawns():
         g_obs = g_obs.cpu().numpy().astype(np.float64)
         g_done, g_flags, g_rew = g_done.cpu().numpy(), g_flags.cpu().numpy().astype(np.uint32), g_rew.cpu().numpy().astype(np.float64)
         same = ((g_done == o_done) & (g_flags == o_flags)).all(axis=1)
+        # (a lane picked one step apart at a junction, or the engine-force cut-off at max_speed crossed a sub-step apart, shows in the
+        # reward before it shows in a flag: the env leaves its common prefix there as well)
+        rew_ok = (np.abs(g_rew - o_rew) < 50 * REW_TOL).all(axis=1)
+        n_div_reward += int((alive & same & ~rew_ok).sum())
+        same &= rew_ok
         fin = (o_done != 0) & ((o_flags & _abi.F_REPORT) != 0)
         new = (o_flags & _abi.F_NEW) != 0
         rst = (o_flags[:, 0] & _abi.F_RESET) != 0
@@ -1584,12 +1591,11 @@ def test_marl_free_running_through_finishes_and_respawns():
             worst = max(worst, float(dd[:, :, :n_state].max()))  # state + navigation floats: no ray in them
             beams += dd.shape[0] * dd.shape[1] * cfg.num_lasers
             beams_off += int((dd[:, :, n_state:] > 4 * OBS_TOL).sum())
-            assert np.abs(g_rew - o_rew)[alive].max() < 50 * REW_TOL
     print("multi-agent free run, 40 slots: %d of %d envs in their common prefix after %d steps (first divergences at steps %s, bits "
-          "0x%x); in the prefixes %d of %d finishes, %d of %d respawns, %d of %d env restarts; %d rows compared: state / navigation "
+          "0x%x, %d of them by a reward alone); in the prefixes %d of %d finishes, %d of %d respawns, %d of %d env restarts; %d rows compared: state / navigation "
           "floats off by at most %.2e, %d of %d beams off by more than %.0e (%.2e of them: rays past a box corner, free-running "
           "fp32 against fp64)"
-          % (int(alive.sum()), n_envs, n_steps, sorted(first_div)[:8], div_bits, n_fin_alive, n_fin, n_new_alive, n_new, n_reset_alive,
+          % (int(alive.sum()), n_envs, n_steps, sorted(first_div)[:8], div_bits, n_div_reward, n_fin_alive, n_fin, n_new_alive, n_new, n_reset_alive,
              n_reset, rows, worst, beams_off, beams, 4 * OBS_TOL, beams_off / max(1, beams)))
     assert n_fin_alive >= 300 and n_new_alive >= 300 and n_reset_alive >= 20
     assert alive.mean() >= 0.5
