@@ -25,12 +25,20 @@ config 5 (multi-agent roundabout, 8 agents, 240 and 72 beams; 40 agents = the re
 row (profiles/r*_pmc_*.json, matched by workload) or, without a counter file, the record bytes of the vehicles that drove
 (`frac_active`); the nominal formula that charges all V records read + written stays next to it as `frac_nominal`.
 
+Windows.  BASELINE.md section 4 asks for the median of three timed runs: the timed region is --windows (3) consecutive windows of
+the timed step count each, every one bracketed by barrier + synchronize; `value` / `ms_per_step` are the MEDIAN window's,
+`windows` lists all of them and `window_spread` = (max - min) / median.
+
 N > 1.  Environments are independent: the step itself has no exchange.  The north star adds ONE gather of
-(obs, reward, done) per step over xGMI; both are measured in the same invocation: `value` is WITH the per-step gather
-(pgd_step_packed writes the packed row straight into the send buffer, one RCCL gather to rank 0 per step -- the learner's GPU;
-RCCL runs it as seven point-to-point transfers over seven different xGMI links -- double-buffered), `value_replicas` is without it
-(a data-parallel learner that consumes its own shard).  --transport collective gathers to EVERY rank instead
-(all_gather_into_tensor), --transport peer uses direct peer writes over HIP IPC (pgdrive_amd/peer.py).
+(obs, reward, done) per step over xGMI.  One invocation measures, back to back on the same engine state: the step without any
+exchange (`value_replicas`: a data-parallel learner that consumes its own shard) and the step WITH the per-step gather under
+EVERY transport (`value_by_transport`): "root" = one RCCL gather to rank 0 per step (grouped point-to-point: one direct xGMI link
+per peer), eager and captured in a HIP graph per 64-step action cycle ("root+graph"); "peer+graph" / "peer" = direct peer writes
+over HIP IPC (pgdrive_amd/peer.py); "collective" / "collective+graph" = RCCL all_gather_into_tensor (every rank receives every
+row).  Each pass is followed by the exchange's self-check (`gather_ok`).  `value` = the best transport whose self-check passed,
+named in `config.parallelism`; --transport NAME [--graph] runs that one only.  A pass that hangs (a transport that has never run
+on this hardware) is cut off by a watchdog after --transport-timeout seconds: rank 0 then prints the line with what was measured
+up to that point (`aborted` says where) and every rank exits.
 """
 import argparse
 import json
@@ -62,11 +70,11 @@ def algorithmic_bytes(A, T, D):
     return k_step, k_obs, fused
 
 
-def load_traffic(N, args):
-    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate
-    runs of this same command, newest profiles/r*_pmc_traffic.json whose workload matches); null when none matches."""
+def _match_profile(pattern, N, args):
+    """Newest profiles/<pattern> whose recorded workload equals this run's (envs / traffic / beams / actions / traffic mode /
+    workload / agents)."""
     import glob
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
             t = json.load(open(p))
         except Exception:
@@ -74,8 +82,140 @@ def load_traffic(N, args):
         if (t.get("envs"), t.get("traffic"), t.get("lasers"), t.get("actions", "uniform"), t.get("traffic_mode", "trigger"),
                 t.get("workload", "c3"), t.get("agents", 1)) == \
                 (N, args.traffic, args.lasers, args.actions, args.traffic_mode, args.workload, args.agents if args.workload == "c5" else 1):
-            return t.get("bytes_per_launch"), os.path.basename(p), t.get("bytes_per_launch_k_observe")
-    return None, None, None
+            return t, os.path.basename(p)
+    return None, None
+
+
+def load_traffic(N, args):
+    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate
+    runs of this same command, newest profiles/r*_pmc_traffic.json whose workload matches); null when none matches."""
+    t, src = _match_profile("r*_pmc_traffic.json", N, args)
+    if t is None:
+        return None, None, None
+    return t.get("bytes_per_launch"), src, t.get("bytes_per_launch_k_observe")
+
+
+def issue_model():
+    """ns a gfx950 SIMD spends per wave-instruction it retires, by waves per SIMD and instruction mix: profiles/r*_issue_rate.json,
+    the summary of tools/issue_rate.hip run on the GPU box (committed; the microbenchmark itself is not part of a bench run)."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue_rate.json")), reverse=True):
+        try:
+            return json.load(open(p)), os.path.basename(p)
+        except Exception:
+            continue
+    return None, None
+
+
+def make_roofline(prof, stride, work, args, N, A, D):
+    """The `roofline` object of a line.  HBM: algorithmic bytes of the dominant kernel / its mean launch time from the HIP events
+    (`frac`, the contract's figure) and the bytes the counters saw move (`frac_moved`).  `issue`: the instruction-issue bound of the
+    same kernel from its committed SQ_INSTS_* pass and the measured issue rates of tools/issue_rate.hip.  `bound` names what the
+    measurements say limits the kernel."""
+    if prof is None:
+        return None
+    b_step, b_obs, b_fused = algorithmic_bytes(A, args.traffic, D)
+    fused = prof["k_observe_ms"] == 0.0  # pgd_step ran the observation inside k_step (one env per wave)
+    if fused:
+        b_step, b_obs = b_fused, 0
+    dom = "k_observe" if prof["k_observe_ms"] >= prof["k_step_ms"] else "k_step"
+    dom_ms = max(prof["k_observe_ms"], prof["k_step_ms"])
+    dom_bytes = (b_obs if dom == "k_observe" else b_step) * N
+    nominal = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic, traffic_src, traffic_obs = load_traffic(N, args)
+    if dom == "k_observe":
+        traffic = traffic_obs  # the counters' figure of the observation kernel (multi-agent engines with many slots)
+    # bytes that MOVE per launch: the counters' figure when a pass of this workload is committed, else the formula
+    # charged only for the records of vehicles that drove (waiting / removed slots are neither rewritten nor re-read
+    # from HBM: reset image); the nominal formula charges all V records read + written
+    moved, moved_src = None, None
+    if traffic:
+        moved, moved_src = float(traffic), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (%s)" % traffic_src
+    elif work and "driving_traffic_mean" in work and dom == "k_step":
+        moved = (b_step - 2 * 128 * (args.traffic - work["driving_traffic_mean"])) * N
+        moved_src = "algorithmic bytes charged for the records of driving vehicles only (no counter pass of this workload committed)"
+    elif work and "present_agents_mean" in work and dom == "k_step":
+        moved = (b_step - 2 * 128 * (A - work["present_agents_mean"])) * N
+        moved_src = "algorithmic bytes charged for the records of present agents only (no counter pass of this workload committed)"
+    achieved_moved = (moved / (dom_ms * 1e-3) / 1e9) if (moved and dom_ms > 0) else None
+    # instruction issue: instructions per wave of the dominant kernel (committed SQ_INSTS_* pass of this workload) x waves per
+    # SIMD x the time a SIMD needs per wave-instruction at that occupancy and VALU : SALU mix (tools/issue_rate.hip)
+    issue = None
+    insts, insts_src = _match_profile("r*_pmc_insts.json", N, args)
+    model, model_src = issue_model()
+    if insts and model and dom_ms > 0:
+        kk = insts.get("k_observe" if dom == "k_observe" else "k_step") or {}
+        per_wave = kk.get("insts_per_wave")
+        waves = kk.get("waves_per_launch")
+        if per_wave and waves:
+            wps = waves / 1024.0  # 256 CUs x 4 SIMDs; every wave of these launches is resident at once up to the VGPR limit
+            occ = max(1, min(8, int(round(min(wps, kk.get("max_waves_per_simd", 8))))))
+            ratio = kk.get("valu", 0) / max(1.0, kk.get("salu", 1))
+            row = min(model["mixes"], key=lambda m: abs(m["valu_per_salu"] - ratio) if m.get("valu_per_salu") else 1e9)
+            ns = row["ns_per_inst_per_simd"].get(str(occ)) or row["ns_per_inst_per_simd"][max(row["ns_per_inst_per_simd"])]
+            bound_us = wps * per_wave * ns * 1e-3
+            issue = {"insts_per_wave": per_wave, "valu": kk.get("valu"), "salu": kk.get("salu"), "lds": kk.get("lds"),
+                     "vmem": kk.get("vmem"), "smem": kk.get("smem"), "waves_per_simd": wps, "ns_per_inst_per_simd": ns,
+                     "cycles_per_inst": ns * model.get("clock_ghz", 2.4), "mix_row": row["name"],
+                     "bound_us": bound_us, "kernel_us": dom_ms * 1e3, "frac": bound_us / (dom_ms * 1e3),
+                     "source": "%s (SQ_INSTS_* per wave) x %s (measured issue rates)" % (insts_src, model_src)}
+    hbm_frac = nominal / 8000.0
+    if issue is not None:
+        bound = "issue" if issue["frac"] >= 0.7 else ("hbm" if hbm_frac >= 0.7 else "latency")
+        note = ("neither pipe is the limit: %.0f %% of the HBM roofline, %.0f %% of the measured issue bound -- the launch is bound by the "
+                "dependent chain (loads, LDS round trips, exec-dependent VALU) of its slowest waves plus the launch ramp" % (
+                    100 * hbm_frac, 100 * issue["frac"])) if bound == "latency" else None
+    else:
+        bound, note = "hbm", "no committed instruction pass of this workload: only the HBM figure is available"
+    return {
+        "bound": bound, **({"bound_note": note} if note else {}),
+        "kernel": dom + (" (observation fused)" if fused else ""),
+        # the contract's figure: ALGORITHMIC bytes per launch / mean launch duration (DESIGN.md section 4)
+        "achieved": nominal, "peak": 8000.0, "unit": "GB/s", "frac": hbm_frac,
+        "bytes_per_launch": dom_bytes, "bytes_per_env_step": {"k_step": b_step, "k_observe": b_obs},
+        # what the counters saw move (unchanged records are neither rewritten nor re-read from HBM)
+        "traffic": traffic, "traffic_source": traffic_src,
+        "achieved_moved": achieved_moved, "frac_moved": (achieved_moved / 8000.0) if achieved_moved else None, "moved_source": moved_src,
+        "bytes_per_launch_moved": moved,
+        "achieved_nominal": nominal, "frac_nominal": hbm_frac,  # (names of rounds 3 - 4, same numbers as achieved / frac)
+        **({"bytes_per_env_step_active": b_step - 2 * 128 * (args.traffic - work["driving_traffic_mean"]),
+            "frac_active": (b_step - 2 * 128 * (args.traffic - work["driving_traffic_mean"])) * N / (dom_ms * 1e-3) / 8e12}
+           if (work and "driving_traffic_mean" in work and dom == "k_step" and dom_ms > 0) else {}),
+        "issue": issue,
+        "k_step_ms": prof["k_step_ms"], "k_observe_ms": prof["k_observe_ms"], "events": prof["count"],
+        "launches_per_event_group": stride if fused else 1,
+    }
+
+
+class Watchdog:
+    """N > 1: a transport that hangs (RCCL or HIP IPC between devices that have never met) must not cost the whole line.  Every
+    rank arms a timer per transport pass; when it fires, rank 0 prints the line built from what was measured before the pass
+    (`partial`, with `aborted`) and every rank leaves with os._exit(0) -- no clean-up of a communicator that no longer answers."""
+    def __init__(self):
+        self.timer, self.partial, self.rank = None, None, 0
+
+    def arm(self, label, seconds):
+        import threading
+        self.disarm()
+        self.timer = threading.Timer(seconds, self._fire, args=(label, seconds))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _fire(self, label, seconds):
+        sys.stderr.write("bench.py: rank %d: transport %s did not finish within %.0f s -- ending the run\n" % (self.rank, label, seconds))
+        sys.stderr.flush()
+        if self.rank == 0 and self.partial is not None:
+            print(json.dumps(self.partial), flush=True)
+        time.sleep(0.5)
+        os._exit(0)
+
+
+WATCHDOG = Watchdog()
 
 
 def cpu_baseline(descs, args, seconds=6.0):
@@ -182,10 +322,18 @@ def parse_args(argv=None):
                     help="N>1: time the step with the per-step gather (value), without it (value_replicas), or both")
     ap.add_argument("--gather", action="store_true", help="(old flag) same as --mode gather")
     ap.add_argument("--no-gather", action="store_true", help="(old flag) same as --mode replicas")
-    ap.add_argument("--transport", default="root", choices=["root", "collective", "peer"],
-                    help="the per-step gather: RCCL gather to rank 0 (default), RCCL all_gather_into_tensor, or direct peer writes over HIP IPC")
-    ap.add_argument("--actions", default="uniform", choices=["uniform", "straight", "expert"],
-                    help="uniform(-1,1) (the metric's stream), drive straight [0,1] with small steering noise (SURVEY 8d), or "
+    ap.add_argument("--transport", default="all", choices=["all", "root", "collective", "peer"],
+                    help="the per-step gather.  all (default): every transport back to back in this one invocation -- RCCL gather to rank 0 "
+                         "eager and in a HIP graph, direct peer writes over HIP IPC in a HIP graph and eager, RCCL all_gather_into_tensor "
+                         "eager and in a HIP graph -- `value` = the best one whose self-check passed.  A name: that transport only "
+                         "(eager, or captured with --graph)")
+    ap.add_argument("--transport-timeout", type=float, default=150.0,
+                    help="N > 1: seconds one transport's pass may take before the watchdog prints the line measured so far and ends the run")
+    ap.add_argument("--windows", type=int, default=3,
+                    help="timed windows of the timed step count each; value = the median window (BASELINE.md section 4: median of 3)")
+    ap.add_argument("--actions", default="uniform", choices=["uniform", "straight", "straight-noise", "expert"],
+                    help="uniform(-1,1) (the metric's stream), straight: constant [0, 1] (BASELINE.md section 4, profile_pgdrive.py:16), "
+                         "straight-noise: the same with a little steering noise so that episodes differ, or "
                          "expert: the scripted lane-keeping policy of the library (pgd_lane_keep_actions, 30 km/h cruise) on the "
                          "last observation -- the ego keeps driving, traffic gets triggered, episodes end by arrival")
     ap.add_argument("--traffic-mode", default="trigger", choices=["trigger", "respawn", "hybrid"],
@@ -222,17 +370,20 @@ def parse_args(argv=None):
         args.mode = "replicas"
     if args.lasers is None:
         args.lasers = (0 if args.topdown else 240) if args.workload == "c3" else 72
+    args.windows = max(1, args.windows)
     return args
 
 
-# The loaded rows timed next to the metric's workload at N = 1 (name, overrides of the command line).  Windows: 1500 + 2048 steps
-# (C5: 1000 + 1536: the roundabout fills up over the first thousand steps).
+# The rows timed next to the metric's workload at N = 1 (name, overrides of the command line).  Pre-roll 1500 steps (C5: 1000, the
+# roundabout fills up over the first thousand steps), then --windows (3) windows of `steps` (default 1024) each, median reported.
 ROWS = [
+    ("c3_straight", dict(actions="straight")),                       # "a second run with constant [0, 1]"
+    ("c2_1024", dict(envs=1024, traffic=0, lasers=0, steps=4096)),   # BASELINE config 2: dynamics + localisation + reward only
     ("c3_expert", dict(actions="expert")),
     ("c3_respawn", dict(traffic_mode="respawn")),
     ("c3_expert_respawn", dict(actions="expert", traffic_mode="respawn")),
-    ("c5_8x240", dict(workload="c5", agents=8, lasers=240, warmup=1000, steps=1536)),
-    ("c5_8x72", dict(workload="c5", agents=8, lasers=72, warmup=1000, steps=1536)),
+    ("c5_8x240", dict(workload="c5", agents=8, lasers=240, warmup=1000, steps=1024)),
+    ("c5_8x72", dict(workload="c5", agents=8, lasers=72, warmup=1000, steps=1024)),
     ("c5_40x72", dict(workload="c5", agents=40, lasers=72, warmup=1000, steps=2048)),
     ("c3_32768", dict(envs=32768, warmup=1500, steps=512)),
 ]
@@ -291,21 +442,24 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
     CYC = 64 if N <= 8192 else 8
     if args.actions in ("uniform", "expert"):  # (expert: the ring only feeds the pre-roll of engines without an observation yet)
         acts = rng.uniform(-1, 1, size=(CYC, N, A, 2)).astype(np.float32)
-    else:  # "drive straight" (profile_pgdrive.py:16): full throttle, a little steering noise so that episodes differ
+    else:  # "drive straight" (profile_pgdrive.py:16): full throttle; straight-noise: a little steering noise so that episodes differ
         acts = np.zeros((CYC, N, A, 2), dtype=np.float32)
-        acts[..., 0] = rng.normal(0, 0.05, size=(CYC, N, A))
+        if args.actions == "straight-noise":
+            acts[..., 0] = rng.normal(0, 0.05, size=(CYC, N, A))
         acts[..., 1] = 1.0
     actions = torch.from_numpy(acts).to(dev)
 
     warm = args.warmup if args.exact else max(args.warmup, PREROLL_MIN)
     timed = args.steps if args.exact else max(args.steps, TIMED_MIN)
-    # N > 1: the replicas pass first (no collective inside its timed loop), then the pass with the per-step gather -- if the
-    # gather transport fails on hardware it has never run on, the line still carries the replicas number and says why
-    modes = ["replicas"] if world == 1 else (["replicas", "gather"] if args.mode == "both" else [args.mode])
-    gatherer = None
-    if "gather" in modes:
-        gatherer = pdist.StepGather(torch, dist, N, D, A, device=dev, transport=args.transport, engine_lib=eng.L,
-                                    device_seq=bool(args.graph and args.transport == "peer"))
+    n_win = args.windows
+    want_replicas = world == 1 or args.mode in ("both", "replicas")
+    want_gather = world > 1 and args.mode in ("both", "gather")
+    # N > 1: the replicas pass first (no collective inside its timed loop), then the passes with the per-step gather, one per
+    # transport -- a transport that fails on hardware it has never run on leaves the line with the others and says why
+    if args.transport == "all":
+        plan = [("root", False), ("root", True), ("peer", True), ("collective", False), ("peer", False), ("collective", True)]
+    else:
+        plan = [(args.transport, bool(args.graph))]
 
     if args.groups > 1:
         eng.set_groups(args.groups)
@@ -313,7 +467,7 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
         eng.enable_topdown()
 
     expert = args.actions == "expert"
-    if expert and (A != 1 or args.groups > 1 or args.step_n > 1 or args.engines > 1 or args.topdown or "gather" in modes):
+    if expert and (A != 1 or args.groups > 1 or args.step_n > 1 or args.engines > 1 or args.topdown or want_gather):
         raise SystemExit("--actions expert: single-agent closed loop on the rank's own shard only (N > 1: --mode replicas)")
     act_buf = torch.zeros((N, A, 2), dtype=torch.float32, device=dev)
 
@@ -337,10 +491,6 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
             with torch.cuda.stream(ej.stream):
                 ej.step(actions[(k + 7 * (j + 1)) % CYC])
 
-    def step_gather(k):
-        a = actions[k % CYC]
-        gatherer.step(lambda rows: eng.step_packed(a, rows))
-
     def fence():
         for g in range(args.groups if args.groups > 1 else 0):
             eng.group_sync(g)
@@ -349,80 +499,260 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    results = {}
-    counter = 0
-    gather_check = None
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor(x, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    def timed_windows(enqueue_window):
+        """n_win windows of `timed` steps, each bracketed by barrier + synchronize; `enqueue_window()` enqueues one window's steps
+        and returns once they are enqueued (and, for the gather, drained).  Returns the per-window times (max over ranks) and
+        the host's enqueue time per step of the median window."""
+        wins, enq = [], []
+        for w in range(n_win):
+            fence()
+            t0 = time.perf_counter()
+            enqueue_window()
+            t_enq = time.perf_counter()  # every launch of the window has been enqueued: the host's share of the loop
+            fence()
+            t1 = time.perf_counter()
+            wins.append(t1 - t0)
+            enq.append(t_enq - t0)
+        wins = max_over_ranks(wins)
+        med = int(np.argsort(wins)[len(wins) // 2])
+        return wins, med, enq[med]
+
+    results = {}        # "replicas" -> dict(elapsed, windows, prof, host_enqueue_s)
+    by_transport = {}   # "root", "root+graph", ... -> dict (value filled in by make_line)
+    state = dict(counter=0, work=None, aborted=None)
+    watchdog = WATCHDOG if world > 1 else None
+
+    def make_line(by_t, work, aborted):
+        """The JSON line from what has been measured so far (rank 0; also called by the watchdog with work = None)."""
+        per_step_units = float(N) * world * max(1, args.engines)
+        rate = lambda el: per_step_units * timed / el  # noqa: E731
+        k_us = ((results.get("replicas") or {}).get("prof") or {}).get("k_step_ms", 0.0) * 1e3 or None
+        slice_bytes = N * pdist.pack_width(D, A) * 4
+        link_us = slice_bytes / (XGMI_LINK_GBPS * 1e9) * 1e6
+        ring_us = (world - 1) * slice_bytes / (XGMI_LINK_GBPS * 1e9) * 1e6
+        table = {}
+        for name, r in by_t.items():
+            e = dict(transport=r["transport"], hip_graph=r["hip_graph"], describe=r.get("describe"), gather_mem=r.get("gather_mem"))
+            if "elapsed" in r:
+                host_us = r["host_enqueue_s"] / timed * 1e6
+                bound_us = ring_us if r["transport"] == "collective" else link_us
+                cands = [x for x in (k_us, bound_us, host_us) if x]
+                e.update(value=rate(r["elapsed"]), ms_per_step=r["elapsed"] / timed * 1e3,
+                         windows=[rate(w) for w in r["windows"]], gather_ok=r["gather_ok"], gather_check=r["gather_check"],
+                         host_enqueue_us_per_step=host_us, hip_graph_steps_per_replay=r["graph_cycle"] or None,
+                         xgmi_bound_us_per_step=bound_us,
+                         model_floor_us_per_step=max(cands) if cands else None,
+                         model_ceiling_env_steps_per_s=per_step_units / (max(cands) * 1e-6) if cands else None)
+            if "error" in r:
+                e["error"] = r["error"]
+            table[name] = e
+        good = [n for n, e in table.items() if e.get("gather_ok") and "error" not in e]
+        measured = [n for n, e in table.items() if "value" in e]
+        best = max(good, key=lambda n: table[n]["value"]) if good else None
+        # the headline: the best transport whose self-check passed; without one, a measured transport (gather_ok false says so);
+        # without any, the replicas pass
+        head = best or (max(measured, key=lambda n: table[n]["value"]) if measured else None)
+        if head is not None:
+            elapsed, wins = by_t[head]["elapsed"], by_t[head]["windows"]
+        elif "replicas" in results:
+            elapsed, wins = results["replicas"]["elapsed"], results["replicas"]["windows"]
+        else:
+            raise RuntimeError("nothing was measured: " + "; ".join("%s: %s" % (n, e.get("error")) for n, e in table.items()))
+        out = {
+            "metric": "env-steps/sec (whole node) at 4096 envs x 240 lidar beams",
+            "value": rate(elapsed), "unit": "env-steps/s", "n_gpus": state.get("ranks_ran", world), "steps": args.steps, "warmup": args.warmup,
+            "steps_timed": timed, "warmup_run": warm, "steps_effective": timed, "rccl_ranks": state.get("rccl_ranks"),
+            "ms_per_step": elapsed / timed * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "windows": [rate(w) for w in wins], "window_spread": (max(wins) - min(wins)) / elapsed if elapsed > 0 else None,
+            "window_rule": "median of %d windows of %d steps" % (n_win, timed),
+        }
+        if aborted:
+            out["aborted"] = aborted
+        if world > 1:
+            out["value_mode"] = ("gather:" + head) if head is not None else "replicas"
+            if "replicas" in results:
+                out["value_replicas"] = rate(results["replicas"]["elapsed"])
+                out["ms_per_step_replicas"] = results["replicas"]["elapsed"] / timed * 1e3
+                out["windows_replicas"] = [rate(w) for w in results["replicas"]["windows"]]
+            if table:
+                out["value_by_transport"] = table
+                out["transport_chosen"] = head
+                out["gather_mem"] = next((e["gather_mem"] for e in table.values() if e.get("gather_mem")), None)
+            if head is not None:
+                out["value_gather"] = table[head]["value"]
+                out["gather_ok"] = table[head]["gather_ok"]
+                out["gather_check"] = table[head]["gather_check"]
+                # what the exchange can cost by construction (DESIGN.md section 6): each peer's slice over its own xGMI link into
+                # the root (transport root / peer: the links work in parallel, the slowest is one slice), the all-gather as a ring
+                # (per-link bound: (n - 1) slices through every link), and the host's enqueue time per step of this very loop
+                out["gather_model"] = {
+                    "slice_bytes_per_rank_per_step": slice_bytes, "xgmi_link_GBps": XGMI_LINK_GBPS,
+                    "link_bound_us": link_us, "ring_allgather_bound_us": ring_us, "k_step_us": k_us,
+                    "host_enqueue_us_per_step": table[head]["host_enqueue_us_per_step"],
+                    "host_enqueue_us_per_step_replicas": (results["replicas"]["host_enqueue_s"] / timed * 1e6) if "replicas" in results else None,
+                    "hip_graph_steps_per_replay": table[head]["hip_graph_steps_per_replay"],
+                    "predicted_floor_us_per_step": table[head]["model_floor_us_per_step"],
+                    "predicted_ceiling_env_steps_per_s": table[head]["model_ceiling_env_steps_per_s"],
+                    "note": "the exchange of step t overlaps the kernels of step t + 1 (double-buffered): the step rate is bounded by the "
+                            "slowest of kernel, link and host enqueue, not by their sum",
+                }
+            elif table:
+                out["gather_error"] = "; ".join("%s: %s" % (n, e.get("error")) for n, e in table.items())
+        if head is not None:
+            par = "env-sharded dp%d + %s, double-buffered" % (world, table[head]["describe"])
+        else:
+            par = "env-sharded dp%d, no data-path collective" % world
+        c2 = args.workload == "c3" and args.traffic == 0 and args.lasers == 0
+        out["config"] = {
+            "workload": (("C2: %d envs/GPU x 1 ego, no traffic, no lidar (state observation only), PGDrive-v0 maps seeds 1000-1099, "
+                          "%s actions, auto-reset" % (N, args.actions)) if c2 else
+                         ("C3: %d envs/GPU x (1 ego + %d IDM traffic slots) x %d lidar beams, PGDrive-v0 maps "
+                          "seeds 1000-1099, %s actions, auto-reset" % (
+                              N, args.traffic, args.lasers, {"uniform": "uniform(-1,1)", "straight": "constant [0, 1] (drive straight)",
+                                                             "straight-noise": "drive-straight with steering noise",
+                                                             "expert": "scripted lane-keeping (30 km/h)"}[args.actions]) +
+                          ("" if args.traffic_mode == "trigger" else ", traffic mode " + args.traffic_mode)))
+            if args.workload == "c3" else
+            ("C5: %d envs/GPU x %d agents, multi-agent roundabout, %d beams x 40 m, %s actions, respawn, auto-reset; "
+             "agent-steps/s = value x %d" % (N, A, args.lasers, args.actions, A)),
+            **({"note": "%d independent engines x %d envs on their own streams, stepped round-robin: consecutive steps "
+                        "of different engines overlap (asynchronous vector-env groups)" % (args.engines, N)}
+               if args.engines > 1 else {}),
+            **({"active_vehicles_mean": 1.0 + work["driving_traffic_mean"]} if work and "driving_traffic_mean" in work else {}),
+            **(work or {}),
+            "step_kernel": state.get("step_kernel"),
+            "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
+            "engines_per_gpu": max(1, args.engines), "env_groups": args.groups,
+            **({"open_loop": "pgd_step_n: %d steps of the action ring per call, one observation per call -- NOT the metric's closed "
+                             "loop" % args.step_n} if args.step_n > 1 else {}),
+            **({"observation": "top-down image 84 x 84 x 5 float32 (pgd_observe_topdown), %.1f MB written per step" % (
+                N * 84 * 84 * 5 * 4 / 1e6)} if args.topdown else {}),
+            "parallelism": par, "backend": (args.backend if world > 1 else "none"),
+            "steady_state": "pre-roll %d steps, %d x %d timed steps (floors %d / %d%s)" % (
+                warm, n_win, timed, PREROLL_MIN, TIMED_MIN, ", off: --exact" if args.exact else ""),
+        }
+        out["roofline"] = make_roofline((results.get("replicas") or {}).get("prof"), (results.get("replicas") or {}).get("stride", 1),
+                                        work, args, N, A, D)
+        return out
+    make_line_ref = [make_line]
+
     with torch.cuda.stream(eng.stream):
-        for k in range(warm):  # pre-roll to steady-state traffic, once, shared by both modes
-            step_replica(counter)
-            counter += 1
-        gather_error = None
-        for mode in modes:
-            one_step = step_gather if mode == "gather" else step_replica
-            try:
-                for k in range(16 if not args.exact else min(16, args.warmup)):  # the mode's own buffers / communicator warm-up
-                    one_step(counter)
-                    counter += 1
-                if gatherer is not None and mode == "gather":
-                    gatherer.drain()
-                fence()
-            except Exception as ex:  # noqa: BLE001  (a transport that does not come up: report it, keep the other pass)
-                if mode != "gather" or "replicas" not in results:
-                    raise
-                gather_error = "%s: %s" % (type(ex).__name__, str(ex)[:300])
-                print("bench.py: the per-step gather failed on rank %d: %s" % (rank, gather_error), file=sys.stderr, flush=True)
-                break
+        for k in range(warm):  # pre-roll to steady-state traffic, once, shared by every pass
+            step_replica(state["counter"])
+            state["counter"] += 1
+
+        if want_replicas:
+            for k in range(16 if not args.exact else min(16, args.warmup)):
+                step_replica(state["counter"])
+                state["counter"] += 1
             # HIP events bracket groups of PROF_STRIDE consecutive k_step launches over the whole timed region; the average
             # launch duration is group time / PROF_STRIDE (two event packets around EVERY launch leave the command processor
             # idle between back-to-back kernels and slow the thing being measured)
-            profiled = mode == "replicas" and args.step_n == 1  # (the open-loop variant mixes launches with and without the observation)
+            profiled = args.step_n == 1  # (the open-loop variant mixes launches with and without the observation)
             # short --exact runs (tests, sweeps of a few hundred steps): smaller groups, so that several of them complete
             stride = PROF_STRIDE if timed >= 8 * PROF_STRIDE else (16 if timed >= 16 else 1)
             if profiled:
-                eng.profile_begin(timed // stride + 1, stride=stride)
-            graph, cyc = None, 0
-            if mode == "gather" and args.graph:
-                import math
-                cyc = math.gcd(timed, CYC)
-                if cyc % gatherer.nbuf == 0 and cyc >= gatherer.nbuf:
-                    graph = gatherer.capture_cycle([(lambda rows, a=actions[i]: eng.step_packed(a, rows)) for i in range(cyc)])
-                    fence()
-            t0 = time.perf_counter()
-            if graph is not None:  # one host call per cycle of `cyc` steps
-                for c in range(timed // cyc):
-                    graph.replay()
-                    gatherer.replayed()
-                counter += timed
-            else:
+                eng.profile_begin(n_win * (timed // stride + 1) + 1, stride=stride)
+
+            def window_replicas():
                 for k in range(timed):
-                    one_step(counter)
-                    counter += 1
-            t_enq = time.perf_counter()  # every launch of the timed region has been enqueued: the host's share of the loop
-            if mode == "gather":
-                gatherer.drain()
-            fence()
-            t1 = time.perf_counter()
+                    step_replica(state["counter"])
+                    state["counter"] += 1
+            wins, med, enq = timed_windows(window_replicas)
             prof = eng.profile_end() if profiled else None
-            elapsed = t1 - t0
-            if world > 1:
-                t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                elapsed = float(t.item())
-            results[mode] = dict(elapsed=elapsed, prof=prof, host_enqueue_s=t_enq - t0, graph_cycle=cyc if graph is not None else 0)
-            if mode == "gather":
+            results["replicas"] = dict(elapsed=wins[med], windows=wins, prof=prof, host_enqueue_s=enq, stride=stride)
+
+        # ---- the per-step gather, one pass per transport (N > 1) -----------------------------------------------------------------
+        def run_transport(transport, use_graph):
+            res = dict(transport=transport, hip_graph=bool(use_graph))
+            g = None
+            try:
+                if use_graph and transport != "peer" and args.backend != "nccl":
+                    raise RuntimeError("backend %s runs its collectives on the host: they cannot be captured in a HIP graph" % args.backend)
+                if use_graph and (timed % CYC or CYC % 2):
+                    # (ADVICE r04: a shorter cycle would replay actions[0:cyc] only -- another workload than the eager passes)
+                    raise RuntimeError("the timed steps (%d) are not whole %d-step action cycles: no graph pass" % (timed, CYC))
+                g = pdist.StepGather(torch, dist, N, D, A, device=dev, transport=transport, engine_lib=eng.L,
+                                     device_seq=bool(use_graph and transport == "peer"))
+                res["describe"] = g.describe() + (", %d steps per HIP graph replay" % CYC if use_graph else "")
+                res["gather_mem"] = g.gather_mem
+
+                def one_step(k):
+                    a_k = actions[k % CYC]
+                    g.step(lambda rows: eng.step_packed(a_k, rows))
+                for k in range(16 if not args.exact else min(16, max(2, args.warmup))):  # buffers / communicator warm-up
+                    one_step(state["counter"])
+                    state["counter"] += 1
+                if g.k % g.nbuf:
+                    one_step(state["counter"])
+                    state["counter"] += 1
+                g.drain()
+                fence()
+                cycle = None
+                if use_graph:
+                    cycle = g.capture_cycle([(lambda rows, a_i=actions[i]: eng.step_packed(a_i, rows)) for i in range(CYC)])
+
+                def window_gather():
+                    if cycle is not None:  # one host call per cycle of CYC steps
+                        for c in range(timed // CYC):
+                            cycle.replay()
+                    else:
+                        for k in range(timed):
+                            one_step(state["counter"] + k)
+                    state["counter"] += timed
+                    g.drain()
+                wins, med, enq = timed_windows(window_gather)
                 # self-check of the exchange, after the timed loop: every rank's checksum of the rows it produced against the
                 # checksum of what arrived for it (a transport that delivers wrong rows would otherwise still print a number)
-                a_chk = actions[counter % CYC]
+                a_chk = actions[state["counter"] % CYC]
                 corrupt = None
                 if args.corrupt_gather:
                     def corrupt(buf):
                         if buf.shape[0] > N or world == 1:  # the rank that holds the gathered rows
                             buf[buf.shape[0] - 1, 3] += 1.0
-                ok, detail = gatherer.validate(lambda rows: eng.step_packed(a_chk, rows), corrupt=corrupt)
-                counter += 1
-                gather_check = dict(ok=ok, **detail)
+                ok, detail = g.validate(lambda rows: eng.step_packed(a_chk, rows), corrupt=corrupt)
+                state["counter"] += 1
+                res.update(elapsed=wins[med], windows=wins, host_enqueue_s=enq, gather_ok=bool(ok), gather_check=dict(ok=bool(ok), **detail),
+                           graph_cycle=CYC if cycle is not None else 0)
+            except Exception as ex:  # noqa: BLE001  (a transport that does not come up: report it, keep the other passes)
+                res["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+                print("bench.py: transport %s%s failed on rank %d: %s" % (transport, "+graph" if use_graph else "", rank, res["error"]),
+                      file=sys.stderr, flush=True)
+            finally:
+                if g is not None:
+                    try:
+                        g.close()
+                    except Exception as ex:  # noqa: BLE001
+                        res.setdefault("error", "close: %s: %s" % (type(ex).__name__, str(ex)[:200]))
+            return res
+
+        if want_gather:
+            for transport, use_graph in plan:
+                name = transport + ("+graph" if use_graph else "")
+                if watchdog is not None:
+                    if rank == 0 and ("replicas" in results or any("elapsed" in r for r in by_transport.values())):
+                        watchdog.partial = make_line_ref[0](dict(by_transport), None, "transport %s exceeded %.0f s" % (name, args.transport_timeout))
+                    watchdog.arm(name, args.transport_timeout)
+                by_transport[name] = run_transport(transport, use_graph)
+                if watchdog is not None:
+                    watchdog.disarm()
+                # the ranks agree on what happened (an error on one rank is an error of the pass)
+                if world > 1:
+                    bad = torch.tensor([1.0 if "error" in by_transport[name] else 0.0], dtype=torch.float64, device=dev)
+                    dist.all_reduce(bad)
+                    if bad.item() > 0 and "error" not in by_transport[name]:
+                        by_transport[name]["error"] = "failed on %d other rank(s)" % int(bad.item())
 
     step_kernel = eng.describe_step()  # which k_step instantiation the timed launches were (pgd_describe_step)
+    state["step_kernel"] = step_kernel
     # how much work a step does at this point of the run: 5 snapshots of the state, 50 untimed steps apart
     work = None
     if args.workload == "c3" and N <= 65536:
@@ -431,8 +761,8 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
         with torch.cuda.stream(eng.stream):
             for snap in range(5):
                 for k in range(50 if snap else 0):
-                    step_replica(counter)
-                    counter += 1
+                    step_replica(state["counter"])
+                    state["counter"] += 1
                 fence()
                 f_, i_, ei_ = eng.get_state()
                 drv = (i_[abi.SI["STATUS"]][:, A:] == abi.ST_ACTIVE)
@@ -442,14 +772,19 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
         spd = float(np.abs(f_[abi.SF["SPEED"]][:, 0]).mean() * 3.6)
         work = dict(driving_traffic_mean=float(np.mean(act_n)), envs_with_traffic_frac=float(np.mean(with_t)),
                     episode_step_mean=float(np.mean(ep)), ego_speed_kmh_mean=spd)
+        if work["episode_step_mean"] < 5.0:
+            # (expert + respawn traffic -- the reference's respawn mode fills every 10 m slot around the ego's spawn
+            # point, traffic_manager.py:199-202,292-309, and the scripted ego drives into the vehicle 1 m ahead of it at once)
+            work["note"] = ("episodes last %.1f steps on average: this row times reset churn in a jam around the spawn point, not "
+                            "driving" % work["episode_step_mean"])
     elif args.workload == "c5":  # (the agent population swings with the 1000-step agent horizon: five snapshots, 100 steps apart)
         from pgdrive_amd import _abi as abi
         act_a, pres_a = [], []
         with torch.cuda.stream(eng.stream):
             for snap in range(5):
                 for k in range(100 if snap else 0):
-                    step_replica(counter)
-                    counter += 1
+                    step_replica(state["counter"])
+                    state["counter"] += 1
                 fence()
                 f_, i_, ei_ = eng.get_state()
                 st_ = i_[abi.SI["STATUS"]][:, :A]
@@ -458,139 +793,21 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
         work = dict(active_agents_mean=float(np.mean(act_a)), present_agents_mean=float(np.mean(pres_a)),
                     active_agents_snapshots=[round(v, 2) for v in act_a])
 
-    ranks_ran = world
-    rccl_ranks = None
     if world > 1:
         if args.backend == "nccl":  # proves that RCCL itself saw every rank (the first multi-GPU run is a first run)
             assert dist.get_backend() == "nccl"
-            rccl_ranks = dist.get_world_size()
+            state["rccl_ranks"] = dist.get_world_size()
         t = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(t)
-        ranks_ran = int(round(t.item()))
+        state["ranks_ran"] = int(round(t.item()))
 
     out = None
     if rank == 0:
-        per_step_units = float(N) * world * max(1, args.engines)
-        head = "gather" if "gather" in results else "replicas"
-        elapsed = results[head]["elapsed"]
-        value = per_step_units * timed / elapsed
-        out = {
-            "metric": "env-steps/sec (whole node) at 4096 envs x 240 lidar beams",
-            "value": value, "unit": "env-steps/s", "n_gpus": ranks_ran, "steps": args.steps, "warmup": args.warmup,
-            "steps_timed": timed, "warmup_run": warm, "steps_effective": timed, "rccl_ranks": rccl_ranks,
-            "ms_per_step": elapsed / timed * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        }
-        if world > 1:
-            out["value_mode"] = head
-            if gather_error:
-                out["gather_error"] = gather_error
-            for m in results:
-                out["value_" + m] = per_step_units * timed / results[m]["elapsed"]
-                out["ms_per_step_" + m] = results[m]["elapsed"] / timed * 1e3
-            if gather_check is not None:
-                out["gather_ok"] = gather_check["ok"]
-                out["gather_check"] = gather_check
-            if "gather" in results:
-                # what the exchange can cost by construction: each peer's slice over its own xGMI link into
-                # the root (transport root / peer: the links work in parallel, the slowest is one slice), the all-gather as a ring
-                # (per-link bound: (n - 1) slices through every link), and the host's enqueue time per step of this very loop
-                slice_bytes = N * pdist.pack_width(D, A) * 4
-                link_us = slice_bytes / (XGMI_LINK_GBPS * 1e9) * 1e6
-                ring_us = (world - 1) * slice_bytes / (XGMI_LINK_GBPS * 1e9) * 1e6
-                k_us = (results.get("replicas", {}).get("prof") or {}).get("k_step_ms", 0.0) * 1e3 or None
-                host_us = results["gather"]["host_enqueue_s"] / timed * 1e6
-                bound_us = ring_us if args.transport == "collective" else link_us
-                cands = [x for x in (k_us, bound_us, host_us) if x]
-                out["gather_model"] = {
-                    "slice_bytes_per_rank_per_step": slice_bytes, "xgmi_link_GBps": XGMI_LINK_GBPS,
-                    "link_bound_us": link_us, "ring_allgather_bound_us": ring_us, "k_step_us": k_us,
-                    "host_enqueue_us_per_step": host_us,
-                    "host_enqueue_us_per_step_replicas": (results["replicas"]["host_enqueue_s"] / timed * 1e6) if "replicas" in results else None,
-                    "hip_graph_steps_per_replay": results["gather"]["graph_cycle"] or None,
-                    "predicted_floor_us_per_step": max(cands) if cands else None,
-                    "predicted_ceiling_env_steps_per_s": per_step_units / (max(cands) * 1e-6) if cands else None,
-                    "note": "the exchange of step t overlaps the kernels of step t + 1 (double-buffered): the step rate is bounded by the "
-                            "slowest of kernel, link and host enqueue, not by their sum",
-                }
-        if head == "gather":
-            par = "env-sharded dp%d + %s, double-buffered" % (world, gatherer.describe())
-        else:
-            par = "env-sharded dp%d, no data-path collective" % world
-        out["config"] = {
-            "workload": ("C3: %d envs/GPU x (1 ego + %d IDM traffic slots) x %d lidar beams, PGDrive-v0 maps "
-                         "seeds 1000-1099, %s actions, auto-reset" % (
-                             N, args.traffic, args.lasers, {"uniform": "uniform(-1,1)", "straight": "drive-straight",
-                                                            "expert": "scripted lane-keeping (30 km/h)"}[args.actions]) +
-                         ("" if args.traffic_mode == "trigger" else ", traffic mode " + args.traffic_mode))
-            if args.workload == "c3" else
-            ("C5: %d envs/GPU x %d agents, multi-agent roundabout, %d beams x 40 m, %s actions, respawn, auto-reset; "
-             "agent-steps/s = value x %d" % (N, A, args.lasers, args.actions, A)),
-            **({"note": "%d independent engines x %d envs on their own streams, stepped round-robin: consecutive steps "
-                        "of different engines overlap (asynchronous vector-env groups)" % (args.engines, N)}
-               if args.engines > 1 else {}),
-            **({"active_vehicles_mean": 1.0 + work["driving_traffic_mean"]} if work and "driving_traffic_mean" in work else {}),
-            **(work or {}),
-            "step_kernel": step_kernel,
-            "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
-            "engines_per_gpu": max(1, args.engines), "env_groups": args.groups,
-            **({"open_loop": "pgd_step_n: %d steps of the action ring per call, one observation per call -- NOT the metric's closed "
-                             "loop" % args.step_n} if args.step_n > 1 else {}),
-            **({"observation": "top-down image 84 x 84 x 5 float32 (pgd_observe_topdown), %.1f MB written per step" % (
-                N * 84 * 84 * 5 * 4 / 1e6)} if args.topdown else {}),
-            "parallelism": par, "backend": (args.backend if world > 1 else "none"),
-            "steady_state": "pre-roll %d steps, %d timed steps (floors %d / %d%s)" % (
-                warm, timed, PREROLL_MIN, TIMED_MIN, ", off: --exact" if args.exact else ""),
-        }
-        prof = results.get("replicas", {}).get("prof")
-        if prof is not None:
-            b_step, b_obs, b_fused = algorithmic_bytes(A, args.traffic, D)
-            fused = prof["k_observe_ms"] == 0.0  # pgd_step ran the observation inside k_step (one env per wave)
-            if fused:
-                b_step, b_obs = b_fused, 0
-            dom = "k_observe" if prof["k_observe_ms"] >= prof["k_step_ms"] else "k_step"
-            dom_ms = max(prof["k_observe_ms"], prof["k_step_ms"])
-            dom_bytes = (b_obs if dom == "k_observe" else b_step) * N
-            nominal = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-            traffic, traffic_src, traffic_obs = load_traffic(N, args)
-            if dom == "k_observe":
-                traffic = traffic_obs  # the counters' figure of the observation kernel (multi-agent engines with many slots)
-            # bytes that MOVE per launch: the counters' figure when a pass of this workload is committed, else the formula
-            # charged only for the records of vehicles that drove (waiting / removed slots are neither rewritten nor re-read
-            # from HBM: reset image); the nominal formula charges all V records read + written
-            moved, moved_src = None, None
-            if traffic:
-                moved, moved_src = float(traffic), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (%s)" % traffic_src
-            elif work and "driving_traffic_mean" in work and dom == "k_step":
-                moved = (b_step - 2 * 128 * (args.traffic - work["driving_traffic_mean"])) * N
-                moved_src = "algorithmic bytes charged for the records of driving vehicles only (no counter pass of this workload committed)"
-            elif work and "present_agents_mean" in work and dom == "k_step":
-                moved = (b_step - 2 * 128 * (A - work["present_agents_mean"])) * N
-                moved_src = "algorithmic bytes charged for the records of present agents only (no counter pass of this workload committed)"
-            achieved = (moved / (dom_ms * 1e-3) / 1e9) if (moved and dom_ms > 0) else nominal
-            out["roofline"] = {
-                "bound": "hbm", "kernel": dom + (" (observation fused)" if fused else ""), "achieved": achieved,
-                "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "frac_source": moved_src or "nominal algorithmic bytes",
-                "bytes_per_launch": moved if moved else dom_bytes,
-                "traffic": traffic, "traffic_source": traffic_src,
-                # the nominal formula (every record read + written, whether it moved or not)
-                "achieved_nominal": nominal, "frac_nominal": nominal / 8000.0,
-                "bytes_per_env_step": {"k_step": b_step, "k_observe": b_obs},
-                **({"bytes_per_env_step_active": b_step - 2 * 128 * (args.traffic - work["driving_traffic_mean"]),
-                    "frac_active": (b_step - 2 * 128 * (args.traffic - work["driving_traffic_mean"])) * N / (dom_ms * 1e-3) / 8e12}
-                   if (work and "driving_traffic_mean" in work and dom == "k_step" and dom_ms > 0) else {}),
-                "k_step_ms": prof["k_step_ms"], "k_observe_ms": prof["k_observe_ms"], "events": prof["count"],
-                "launches_per_event_group": stride if fused else 1,
-            }
-        else:
-            out["roofline"] = None
+        out = make_line(by_transport, work, None)
         if with_cpu_baseline and not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(descs, args) if args.workload == "c3" else None
+            out["cpu_baseline"] = cpu_baseline(descs, args) if (args.workload == "c3" and args.traffic > 0) else None
         else:
             out["cpu_baseline"] = None
-    if gatherer is not None:
-        gatherer.close()
     for ej in extra:
         ej.close()
     eng.close()
@@ -604,13 +821,17 @@ def row_summary(name, line):
     r = line.get("roofline") or {}
     c = line["config"]
     keep = ("driving_traffic_mean", "envs_with_traffic_frac", "ego_speed_kmh_mean", "episode_step_mean", "active_agents_mean",
-            "present_agents_mean", "step_kernel", "obs_dim", "envs_per_gpu")
+            "present_agents_mean", "step_kernel", "obs_dim", "envs_per_gpu", "note")
+    iss = r.get("issue") or None
     return {
         "row": name, "workload": c["workload"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+        "windows": line.get("windows"), "window_spread": line.get("window_spread"),
         "steps_timed": line["steps_timed"], "warmup_run": line["warmup_run"],
         **{k: c[k] for k in keep if k in c},
-        "roofline": {k: r.get(k) for k in ("kernel", "achieved", "frac", "frac_source", "frac_nominal", "frac_active", "traffic",
-                                           "traffic_source", "bytes_per_launch", "k_step_ms", "k_observe_ms")} if r else None,
+        "roofline": {**{k: r.get(k) for k in ("bound", "kernel", "achieved", "frac", "frac_moved", "moved_source", "frac_active", "traffic",
+                                              "traffic_source", "bytes_per_launch", "k_step_ms", "k_observe_ms")},
+                     "issue": ({k: iss.get(k) for k in ("insts_per_wave", "waves_per_simd", "ns_per_inst_per_simd", "bound_us", "frac")}
+                               if iss else None)} if r else None,
     }
 
 
@@ -633,6 +854,7 @@ def run_rank(args, rank, world, local_rank):
         kw = dict(device_id=dev) if args.backend == "nccl" else {}  # binds the RCCL communicator to this rank's GPU
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
 
+    WATCHDOG.rank = rank
     out = measure(args, rank, world, local_rank)
     # the loaded rows, in the same invocation (N = 1, the default command only: any flag that changes the workload of the
     # headline -- other actions, env counts, groups ... -- is a single-workload run)
@@ -646,7 +868,7 @@ def run_rank(args, rank, world, local_rank):
             if want is not None and name not in want:
                 continue
             ra = copy.copy(args)
-            ra.exact, ra.warmup, ra.steps = True, 1500, 2048
+            ra.exact, ra.warmup, ra.steps = True, 1500, 1024  # (x --windows windows)
             for k, v in over.items():
                 setattr(ra, k, v)
             try:

@@ -375,6 +375,9 @@ int pgd_gather_push(pgd_gather_handle g, int buf, int seq, void* hip_stream);
 int pgd_gather_wait(pgd_gather_handle g, int buf, int seq, void* hip_stream);
 int pgd_gather_release(pgd_gather_handle g, int buf, int seq, void* hip_stream);
 int pgd_gather_status(pgd_gather_handle g, int* err /* 0 = ok, 1 = an ack never came, 2 = rows never came */);
+/* 1: the receive block is fine-grained (device-coherent across agents) memory, as the protocol wants; 0: the runtime refused
+ * hipExtMallocWithFlags(..., hipDeviceMallocFinegrained) or PGD_GATHER_COARSE was set and the block is plain hipMalloc memory. */
+int pgd_gather_mem_kind(pgd_gather_handle g, int* fine_grained);
 int pgd_gather_destroy(pgd_gather_handle g);
 
 #ifdef __cplusplus

@@ -34,6 +34,7 @@ struct pgd_gather {
   char* base;                              // own block
   char* peer_base[PGD_GATHER_MAX_WORLD];   // mapped blocks (own entry = base)
   bool connected[PGD_GATHER_MAX_WORLD];
+  int fine;                                // 1: the block is fine-grained memory, 0: the runtime refused it (or PGD_GATHER_COARSE) and it is plain hipMalloc
   int* counters;                           // [nbuf][world] block-arrival counters of k_peer_push (own, device)
   int* dseq;                               // [4] device-side sequence of each buffer (seq == 0 calls): its last push, 0 = never used
   char** d_peer_base;                      // device copy of peer_base
@@ -122,8 +123,11 @@ int pgd_gather_create(int device, int world, int rank, int n_rows, int row_float
   // fine-grained (device-coherent across agents) memory, as RCCL uses for its own buffers -- ordinary coarse-grained hipMalloc
   // memory is only guaranteed coherent at kernel boundaries, so a polling kernel could keep seeing a stale flag line.
   // PGD_GATHER_COARSE=1 forces plain hipMalloc (A/B); a runtime that refuses the flag falls back to it as well.
+  // The fallback is REPORTED (pgd_gather_mem_kind; bench.py prints `gather_mem`), not silent.
+  g->fine = 1;
   if (getenv("PGD_GATHER_COARSE") || hipExtMallocWithFlags((void**)&g->base, g->total_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
     (void)hipGetLastError();
+    g->fine = 0;
     HIPCHK(hipMalloc((void**)&g->base, g->total_bytes));
   }
   HIPCHK(hipMemset(g->base, 0, g->total_bytes));
@@ -204,6 +208,12 @@ int pgd_gather_status(pgd_gather_handle g, int* err) {
   if (!g || !err) return PGD_ERR_ARG;
   HIPCHK(hipSetDevice(g->device));
   HIPCHK(hipMemcpy(err, g->base + g->ctl_off + offsetof(GatherCtl, err), sizeof(int), hipMemcpyDeviceToHost));
+  return PGD_OK;
+}
+
+int pgd_gather_mem_kind(pgd_gather_handle g, int* fine_grained) {
+  if (!g || !fine_grained) return PGD_ERR_ARG;
+  *fine_grained = g->fine;
   return PGD_OK;
 }
 

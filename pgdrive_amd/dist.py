@@ -153,15 +153,17 @@ class StepGather:
     def capture_cycle(self, produces):
         """One HIP graph over len(produces) consecutive steps (a multiple of nbuf; `produces[i]` writes the rows of step i, e.g.
         `lambda rows: eng.step_packed(actions[i], rows)` with a STATIC action tensor): step kernel, exchange and the waits between
-        them are enqueued by one `graph.replay()` per cycle instead of four or five host calls per step -- at 18 us per step the
+        them are enqueued by one `cycle.replay()` per cycle instead of four or five host calls per step -- at 18 us per step the
         host is otherwise the slowest stage of the pipeline (bench.py `gather_model.host_enqueue_us_per_step`).  Transport "peer"
         with device_seq=True (kernels only), or an RCCL collective (torch captures NCCL / RCCL collectives; every exchange of the
-        cycle is complete when the graph ends, so cycles do not overlap each other).  Returns the graph; the step counter moves on
-        by one cycle per replay."""
+        cycle is complete when the graph ends, so cycles do not overlap each other).  Returns a GraphCycle: its replay() launches the
+        graph AND moves the step counter on by one cycle (the buffer parity of later eager steps depends on it)."""
         t = self.torch
         n = len(produces)
         assert n > 0 and n % self.nbuf == 0 and self.k % self.nbuf == 0, "whole buffer rounds only"
         assert self.transport != "peer" or self.device_seq, "transport peer: construct with device_seq=True"
+        if self.transport in ("root", "collective") and self.backend not in ("nccl", "none"):
+            raise RuntimeError("backend %s runs its collectives on the host: they cannot be captured in a HIP graph" % self.backend)
         self.drain()
         dev = self.recv[0].device
         t.cuda.synchronize(dev)
@@ -171,12 +173,7 @@ class StepGather:
                 self.step(pr)
             if self.transport != "peer":
                 self.drain()  # the collectives' own streams rejoin the capture
-        self._cycle = n
-        return g
-
-    def replayed(self, n_cycles=1):
-        """Bookkeeping after `graph.replay()`: the captured steps ran again."""
-        self.k += n_cycles * self._cycle
+        return GraphCycle(self, g, n)
 
     def result(self, b):
         """(obs, reward, done) of all ranks' envs; with transport "root" on rank 0 only (the other ranks get their own rows)."""
@@ -223,7 +220,24 @@ class StepGather:
         return int(flag.item()) == 0, dict(ranks_checked=self.world, mismatched_ranks=bad,
                                            checked_on="rank 0" if self.transport == "root" else "every rank")
 
+    @property
+    def gather_mem(self):
+        """Memory kind of the peer transport's receive block: "fine" (fine-grained, what the protocol wants) or "coarse" (the
+        runtime refused it: plain hipMalloc); None for the RCCL transports (RCCL owns its staging buffers)."""
+        return self.peer.mem_kind if self.peer is not None else None
+
     def close(self):
         if self.peer is not None:
             self.peer.close()
             self.peer = None
+
+
+class GraphCycle:
+    """A captured cycle of steps (StepGather.capture_cycle).  replay() = graph launch + the gatherer's step bookkeeping, in one call,
+    so that the two cannot drift apart (a forgotten `replayed()` left the buffer parity of later eager steps wrong)."""
+    def __init__(self, gatherer, graph, steps):
+        self.gatherer, self.graph, self.steps = gatherer, graph, steps
+
+    def replay(self):
+        self.graph.replay()
+        self.gatherer.k += self.steps

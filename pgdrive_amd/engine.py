@@ -52,6 +52,7 @@ _SIGS = {
     "pgd_gather_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pgd_gather_release": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pgd_gather_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "pgd_gather_mem_kind": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "pgd_gather_destroy": (C.c_int, [C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS.keys())

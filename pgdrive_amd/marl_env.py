@@ -227,6 +227,85 @@ class MultiAgentParkingLotVecEnv(MultiAgentRoundaboutVecEnv):
         super().__init__(cfg)
 
 
+class VehicleHandle:
+    """What the reference's own multi-agent tests reach for on `env.vehicles[name]` (a BaseVehicle): pose and speed, the contact
+    flags of the last step, `set_position` (a teleport: tests put agents on top of each other or on their destination),
+    `set_static`, and the end of the final lane of the agent's route (`navigation.final_lane.end`).  A host-side convenience over
+    pgd_get_state / pgd_set_state (one round trip per call: single-env test surface, not the batched hot path)."""
+
+    def __init__(self, env, name, slot):
+        self._env, self.name, self.slot = env, name, slot
+
+    def _state(self):
+        return self._env.vec.engine.get_state()
+
+    @property
+    def position(self):
+        f, _, _ = self._state()
+        return np.array([f[_abi.SF["X"], 0, self.slot], f[_abi.SF["Y"], 0, self.slot]], dtype=np.float64)
+
+    @property
+    def heading_theta(self):
+        return float(self._state()[0][_abi.SF["THETA"], 0, self.slot])
+
+    @property
+    def speed(self):
+        """km/h, as BaseVehicle.speed (base_vehicle.py:394-401)."""
+        return abs(float(self._state()[0][_abi.SF["SPEED"], 0, self.slot])) * 3.6
+
+    def _spawn_record(self):
+        _, i, ei = self._state()
+        bank_ = self._env.vec.scen_bank
+        return bank_.spawns[int(ei[_abi.EI["SCEN"], 0]) * bank_.stride + int(i[_abi.SI["SPAWN"], 0, self.slot])]
+
+    @property
+    def length(self):
+        return float(self._spawn_record()["length"])
+
+    @property
+    def width(self):
+        return float(self._spawn_record()["width"])
+
+    @property
+    def final_lane(self):
+        """The lane description the agent's route ends on (Navigation.final_lane, navigation.py:123-148)."""
+        rec = self._spawn_record()
+        descs = self._env.vec.map_bank.descs
+        _, _, ei = self._state()
+        m = int(self._env.vec.scen_bank.scenarios[int(ei[_abi.EI["SCEN"], 0])]["map"])
+        return descs[m]["lanes"][int(rec["dest_lane"])]
+
+    def _flags(self):
+        return int(self._state()[1][_abi.SI["VFLAGS"], 0, self.slot])
+
+    @property
+    def crash_vehicle(self):
+        return bool(self._flags() & _abi.F_CRASH_VEHICLE)
+
+    @property
+    def out_of_road(self):
+        return bool(self._flags() & _abi.F_OUT_OF_ROAD)
+
+    def set_position(self, pos, height=None):
+        """Teleport (BaseVehicle.set_position, base_vehicle.py:418-425): heading and speed stay; the next step localises the
+        vehicle where it now stands."""
+        f, i, ei = self._state()
+        f[_abi.SF["X"], 0, self.slot], f[_abi.SF["Y"], 0, self.slot] = float(pos[0]), float(pos[1])
+        self._env.vec.engine.set_state(f, i, ei)
+
+    def set_static(self, flag=True):
+        """BaseVehicle.set_static: the body no longer moves whatever action it is given.  Here: the env overrides the slot's action
+        with [0, 0] and the speed is zeroed once (a standing car with [0, 0] stays where it is: rolling brake, no reverse)."""
+        if flag:
+            self._env._static.add(self.slot)
+            f, i, ei = self._state()
+            if f[_abi.SF["SPEED"], 0, self.slot] != 0.0:
+                f[_abi.SF["SPEED"], 0, self.slot] = 0.0
+                self._env.vec.engine.set_state(f, i, ei)
+        else:
+            self._env._static.discard(self.slot)
+
+
 class MultiAgentRoundaboutEnv:
     """Dict protocol of the reference: keys "agent{k}"; done has "__all__" (multi_agent_pgdrive.py:126-150)."""
     VEC = MultiAgentRoundaboutVecEnv
@@ -240,7 +319,24 @@ class MultiAgentRoundaboutEnv:
         import torch
         self._torch = torch
         self._slots = {}  # agent name -> slot
+        self._static = set()  # slots frozen by VehicleHandle.set_static
         self.episode_steps = 0
+
+    @property
+    def vehicles(self):
+        """name -> VehicleHandle of the agents that act in the next step (BaseEnv.vehicles)."""
+        return {k: VehicleHandle(self, k, s) for k, s in self._slots.items()}
+
+    def finish(self, agent_name):
+        """AgentManager.finish (agent_manager.py:134-153): the agent stops acting at once; it stays `delay_done` steps as a static
+        body (none with delay_done = 0) and its seat may be respawned into."""
+        s = self._slots.pop(agent_name)
+        f, i, ei = self.vec.engine.get_state()
+        dd = int(self.vec.cfg.delay_done)
+        i[_abi.SI["STATUS"], 0, s] = _abi.ST_DYING if dd > 0 else _abi.ST_EMPTY
+        i[_abi.SI["TIMER"], 0, s] = dd
+        self.vec.engine.set_state(f, i, ei)
+        self._static.discard(s)
 
     @property
     def observation_space(self):
@@ -257,13 +353,14 @@ class MultiAgentRoundaboutEnv:
     def reset(self):
         obs = self.vec.reset()[0].cpu().numpy()
         self._refresh_slots()
+        self._static.clear()
         self.episode_steps = 0
         return {k: obs[s] for k, s in self._slots.items()}
 
     def step(self, actions):
         a = np.zeros((1, self.vec.A, 2), dtype=np.float32)
         for k, s in self._slots.items():  # extra keys are ignored like base_env.py:205-212
-            if k in actions:
+            if k in actions and s not in self._static:
                 a[0, s] = np.asarray(actions[k], dtype=np.float32)
         f0, i0, _ = self.vec.engine.get_state()  # episode_reward / episode_length of the agents that are about to act
         obs, rew, done, flags = self.vec.step(self._torch.from_numpy(a).to(self.vec.engine.device))
@@ -292,6 +389,7 @@ class MultiAgentRoundaboutEnv:
                                acceleration=float(f1[_abi.SF["THROTTLE"], 0, s]))  # the slot still holds this agent
         all_done = bool(fl[0] & _abi.F_ALL_DONE)
         self._refresh_slots()
+        self._static &= set(self._slots.values())  # a seat that changed hands is no longer frozen
         if not all_done:
             status, ids = self.vec.slot_table()
             for s in range(self.vec.A):  # respawned agents: obs of the newcomer, reward 0, not done

@@ -17,17 +17,34 @@ class PeerGather:
         self.device = dev
         h = C.c_void_p()
         rc = lib.pgd_gather_create(dev.index or 0, self.world, self.rank, n_local, row_floats, nbuf, C.byref(h))
-        if rc:
-            raise RuntimeError("pgd_gather_create failed with status %d" % rc)
-        self.h = h
+        self.h = h if rc == 0 else None
+        # Export / connect.  A failure on ONE rank (an IPC handle the runtime refuses, a peer that cannot be mapped) must not leave the
+        # others waiting in a barrier: every rank goes through the same collective calls whatever happened to it, the verdict is
+        # all-reduced, and then EVERY rank drops its handle and raises.
+        err = None if rc == 0 else "pgd_gather_create failed with status %d" % rc
         blob = C.create_string_buffer(HANDLE_BYTES)
-        self._chk(lib.pgd_gather_export(h, blob), "pgd_gather_export")
+        if err is None:
+            rc = lib.pgd_gather_export(h, blob)
+            if rc:
+                err = "pgd_gather_export failed with status %d" % rc
         blobs = [None] * self.world
-        dist.all_gather_object(blobs, bytes(blob.raw))
-        for p, b in enumerate(blobs):
-            if p != self.rank:
-                self._chk(lib.pgd_gather_connect(h, p, C.create_string_buffer(b, HANDLE_BYTES)), "pgd_gather_connect")
-        dist.barrier()  # every rank has mapped every block before the first push
+        dist.all_gather_object(blobs, (bytes(blob.raw), err))
+        for p, (b, e) in enumerate(blobs):
+            if p != self.rank and err is None and e is None:
+                rc = lib.pgd_gather_connect(h, p, C.create_string_buffer(b, HANDLE_BYTES))
+                if rc:
+                    err = "pgd_gather_connect(peer %d) failed with status %d" % (p, rc)
+        verdicts = [None] * self.world
+        dist.all_gather_object(verdicts, err)  # (also the barrier: every rank has mapped every block before the first push)
+        bad = [(q, v) for q, v in enumerate(verdicts) if v]
+        if bad:
+            if self.h:
+                lib.pgd_gather_destroy(h)
+            self.h = None
+            raise RuntimeError("peer gather set-up failed on rank(s) %s" % "; ".join("%d: %s" % qv for qv in bad))
+        fine = C.c_int(-1)
+        lib.pgd_gather_mem_kind(h, C.byref(fine))
+        self.mem_kind = {1: "fine", 0: "coarse"}.get(fine.value, "unknown")
         # torch views of the receive buffers (the memory belongs to the gather handle)
         self.recv = []
         for b in range(nbuf):
