@@ -246,9 +246,12 @@ int pgd_reset(pgd_handle h, const int32_t* h_env_ids, const int32_t* h_scen_ids,
 
 /* Replaces env.step(action) (envs/base_env.py:184-224, 303-344) for all N envs.  Asynchronous on the stream.
  * Multi-agent engines: the row of a slot that is not due in this step (no agent, or an agent that did not report) reads zero.  The
- * engine writes such a row once and remembers that it did, per observation buffer (pointer and row stride of the last call that
- * wrote rows: the same rule for pgd_reset / pgd_observe / pgd_step_packed); a caller that scribbles over rows it was handed must not
- * expect them to be zeroed again while it keeps passing the same buffer -- pass another buffer, or clear the rows itself. */
+ * engine writes such a row once and remembers that it did -- per env, together with the identity of the buffer (address and row
+ * stride) the marks describe; the kernel compares that identity itself, so eager calls with alternating buffers, HIP-graph replays
+ * and env groups on their own streams all see marks that belong to the buffer they write (the same rule for pgd_reset /
+ * pgd_observe / pgd_step_packed).  A caller that scribbles over rows it was handed (in-place normalisation, noise) must not expect
+ * them to be zeroed again while it keeps passing the same buffer: copy first, pass another buffer, or create the engine with
+ * PGD_NO_ROWZ=1 in the environment (every row that is not due is then zero-filled by every call). */
 int pgd_step(pgd_handle h, const float* d_actions /*[N,A,2]*/, float* d_obs /*[N,A,D]*/, float* d_reward /*[N,A]*/,
              uint8_t* d_done /*[N,A]*/, uint32_t* d_flags /*[N,A]*/);
 
@@ -276,7 +279,10 @@ int pgd_step_packed(pgd_handle h, const float* d_actions, float* d_rows /*[N,row
  * consecutive steps of different groups overlap on the GPU (a launch ends with its slowest wave; another group's step fills
  * that tail).  All pointers address the FULL [N, ...] arrays; only the group's rows are read / written.  pgd_group_stream
  * hands out the stream so that the caller can order its own kernels (the policy) with the group's steps; work submitted
- * through pgd_step / pgd_reset (engine stream) is NOT ordered against the group streams: synchronise when switching. */
+ * through pgd_step / pgd_reset (engine stream) is NOT ordered against the group streams: synchronise when switching.
+ * An engine in throughput mode (>= 32768 envs: three whole envs per wave) whose group size is not a whole number of such waves is
+ * switched back to one env per wave FOR THE REST OF ITS LIFE (same results, 6 - 18 % slower at that size); the switch happens only
+ * when the call succeeds (PGD_ERR_ARG leaves the engine unchanged) and pgd_describe_step reports it from then on. */
 int pgd_set_groups(pgd_handle h, int n_groups);   /* N % n_groups == 0; 1 = back to a single group */
 int pgd_step_group(pgd_handle h, int group, const float* d_actions /*[N,A,2]*/, float* d_obs /*[N,A,D]*/, float* d_reward,
                    uint8_t* d_done, uint32_t* d_flags);

@@ -14,6 +14,11 @@ oracle's bookkeeping with what the reference's classes answered.
   parking    ParkingLotSpawnManager: get_parking_space / after_vehicle_done / update_destination_for
              (marl_parking_lot.py:40-90): size of the free pool and who holds a space after every event (the reference
              draws WHICH free space from an unseeded stream, the engine from its counter RNG: the draw itself is not compared)
+  respawn    how many agents ONE env.step respawns: SpawnManager.get_available_respawn_places (spawn_manager.py:157-207) offers a
+             free place at most once per frame and MultiAgentPGDrive._respawn_vehicles / _respawn_single_vehicle
+             (multi_agent_pgdrive.py:180-213) take one place per call -- both run here on occupancy patterns (a stand-in
+             rect_region_detection answers from the pattern): newcomers of a frame, of a second call in the same frame and of
+             the next frame, and whether the chosen place was a free one
 """
 import gzip
 import json
@@ -236,12 +241,114 @@ def parking_reference(run):
     return out
 
 
+def respawn_reference():
+    """The reference's own respawn loop on occupancy patterns over P = 8 places (which places' 8 m x 3 m regions hold a vehicle)."""
+    from oracle import refstub
+    refstub.load()
+    import pgdrive.envs.marl_envs.marl_parking_lot  # noqa: F401  (the import order that avoids the reference's circular imports)
+    from pgdrive.manager import spawn_manager as sm_mod
+    from pgdrive.manager.spawn_manager import SpawnManager
+    from pgdrive.envs.marl_envs.multi_agent_pgdrive import MultiAgentPGDrive
+    from pgdrive.utils import Config
+
+    P = 8
+    occupied = set()
+
+    class _Hit:
+        def __init__(self, hit):
+            self._hit = hit
+
+        def hasHit(self):
+            return self._hit
+
+    class _Engine:
+        global_config = dict(debug=False, debug_physics_world=False)
+
+    def fake_region_detection(engine, position, heading, lon, lat, mask, *a, **k):
+        assert (lon, lat) == (SpawnManager.RESPAWN_REGION_LONGITUDE, SpawnManager.RESPAWN_REGION_LATERAL) == (8.0, 3.0)
+        return _Hit(int(round(position[0] / 100.0)) in occupied)  # place p sits at x = 100 p
+
+    sm_mod.rect_region_detection = fake_region_detection
+    sm_mod.get_engine = lambda: _Engine
+
+    def fresh_manager():
+        m = SpawnManager.__new__(SpawnManager)
+        m.spawn_places_used = []
+        m.safe_spawn_places = {
+            "place%d" % p: Config(dict(identifier="place%d" % p, config=dict(spawn_lane_index=("a", "b", p), spawn_longitude=4.0,
+                                                                           spawn_lateral=0.0),
+                                       spawn_point_position=(100.0 * p, 0.0), spawn_point_heading=0.0), unchangeable=False)
+            for p in range(P)}
+        m.update_destination_for = lambda agent_id, cfg: cfg
+        return m
+
+    class _Vehicle:
+        def __init__(self):
+            self.config = {}
+
+        def reset(self):
+            pass
+
+        def after_step(self):
+            pass
+
+    class _Obs:
+        def observe(self, v):
+            return "row"
+
+    class _AgentManager:
+        allow_respawn = True
+
+        def __init__(self):
+            self.count = 0
+
+        def propose_new_vehicle(self):
+            self.count += 1
+            return "agent%d" % (100 + self.count), _Vehicle()
+
+    class _Env:
+        _DEBUG_RANDOM_SEED = None
+        current_map = None
+        _respawn_single_vehicle = MultiAgentPGDrive._respawn_single_vehicle
+
+        def __init__(self, m):
+            self.engine = types.SimpleNamespace(spawn_manager=m)
+            self.agent_manager = _AgentManager()
+            self.dones = {}
+
+            class _D(dict):
+                def __missing__(self, k):
+                    return _Obs()
+            self.observations = _D()
+
+    cases = []
+    rng = np.random.RandomState(5)
+    patterns = [[], list(range(P)), [0], [1, 2, 3, 4, 5, 6, 7]] + [sorted(rng.choice(P, size=int(rng.randint(1, P)), replace=False).tolist())
+                                                                  for _ in range(20)]
+    for occ in patterns:
+        occupied.clear()
+        occupied.update(occ)
+        m = fresh_manager()
+        env = _Env(m)
+        first = MultiAgentPGDrive._respawn_vehicles(env, randomize_position=False)
+        chosen = [int(v.config["spawn_lane_index"][2]) for v in []]  # (the vehicles are not kept: read the places from the manager)
+        offered = [int(b[5:]) for b in m.spawn_places_used]
+        again = MultiAgentPGDrive._respawn_vehicles(env, randomize_position=False)   # same frame: every free place was offered already
+        SpawnManager.step(m)                                                          # next frame
+        nxt = MultiAgentPGDrive._respawn_vehicles(env, randomize_position=False)
+        cases.append(dict(places=P, occupied=list(occ), newcomers=len(first), offered_in_first_call=sorted(offered),
+                          newcomers_second_call_same_frame=len(again), newcomers_next_frame=len(nxt)))
+        del chosen
+    return cases
+
+
 def main():
     t = toll_run()
     tr = toll_reference(t)
     p = parking_run()
     pr = parking_reference(p)
-    out = dict(toll=dict(events=t["events"], reference=tr), parking=dict(events=p["events"], n_spaces=p["n_spaces"], reference=pr))
+    out = dict(toll=dict(events=t["events"], reference=tr), parking=dict(events=p["events"], n_spaces=p["n_spaces"], reference=pr),
+               respawn=respawn_reference())
     path = os.path.join(ROOT, "tests", "golden", "marl_rules_v0.json.gz")
     with gzip.open(path, "wt") as fh:
         json.dump(out, fh)

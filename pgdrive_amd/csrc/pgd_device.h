@@ -56,10 +56,13 @@ struct PgdDev {
   int dbg_exit;  // exit-profile builds only (PGD_EXITAT)
   int unit_off;  // first block unit of this launch (pgd_step_group); 0 for a whole-engine step
   int obs_g;     // multi-agent k_step with the fused observation: observers per pass (what fits the step's LDS)
-  // multi-agent engines: bit a of rowz[e] = row a of env e in the caller's observation buffer (the one the host tracks, see
-  // obs_rows_known) was written as zeros by an earlier call and has not been due since: not written again (40 agent slots, 6 - 30
-  // alive: the zero rows were 46 MB of stores per step at 4096 envs).  Null: every row that is not due is zero-filled.
-  unsigned long long* rowz;
+  // multi-agent engines: rowz[e] = (mask, tag).  Bit a of the mask = row a of env e in the observation buffer that `tag` names (its
+  // address mixed with the row stride, rowz_tag) was written as zeros by an earlier call and has not been due since: not written
+  // again (40 agent slots, 6 - 30 alive: the zero rows were 46 MB of stores per step at 4096 envs).  The buffer's identity lives HERE,
+  // per env, and is compared by the kernel itself: a HIP graph replayed after an eager call with another buffer, or env groups on
+  // their own streams, cannot get it wrong (round 4 kept it in a host-side cache: ADVICE r04).  Null (PGD_NO_ROWZ=1): every row that
+  // is not due is zero-filled by every call -- for callers that post-process the returned rows in place.
+  ulonglong2* rowz;
   uint8_t* bev_fill;  // [N] or null: the env was reset -- the top-down observation refills its history (pgd_topdown.h)
 };
 

@@ -694,35 +694,43 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     const bool allow = (gcf.marl_flags & PGD_MA_ALLOW_RESPAWN) && !(gcf.horizon > 0 && ep_steps >= gcf.horizon) &&
                        alive < gcf.agent_limit;
     if (allow) {
+      // get_available_respawn_places offers every place at most once per frame (spawn_places_used, spawn_manager.py:157-207) and
+      // _respawn_vehicles takes ONE of the offered places per call (multi_agent_pgdrive.py:180-213): the second call of the frame finds
+      // every free place already offered and stops -- at most one newcomer per step, on a random one of the free places
+      // (rounds 2 - 4 filled every free place in the same step)
       const pgd_spawn* rbase = d.spawns + (size_t)scen * d.sstride + V;
+      unsigned long long freem = 0ull;
       for (int p = 0; p < gcf.respawn_places; ++p) {
         const pgd_spawn& place = rbase[p * gcf.respawn_dests];
         const float2 phv = cold.spawn_hv[(size_t)scen * d.sstride + V + p * gcf.respawn_dests];
         const float pc = phv.x, ps = phv.y;
         const Obb region{place.x, place.y, pc, ps, 4.0f, 1.5f};  // RESPAWN_REGION 8 m x 3 m (spawn_manager.py:27-28)
         const bool blocks = lane < V && S.present[lane] && obb_overlap(region, snap_obb(S, lane));
-        if (__ballot(blocks) != 0ull) continue;
-        // lowest empty slot that did not report this step (its terminal row must survive)
-        unsigned long long em = __ballot(is_lead_agent && r.status == ST_EMPTY && !fresh && !(my_fl & PGD_F_REPORT));
-        if (em == 0ull) break;
+        if (__ballot(blocks) == 0ull) freem |= 1ull << p;
+      }
+      // lowest empty slot that did not report this step (its terminal row must survive)
+      const unsigned long long em = __ballot(is_lead_agent && r.status == ST_EMPTY && !(my_fl & PGD_F_REPORT));
+      // parking lot: a road place is offered only while a parking space is free (marl_parking_lot.py:176-190)
+      const unsigned pool = parking ? ((unsigned)s_aux & ((1u << gcf.respawn_dests) - 1u)) : 1u;
+      if (freem != 0ull && em != 0ull && __ballot(pool != 0u) != 0ull) {
+        int kth = (int)(pgd_rng(gcf.seed, (uint32_t)(gcf.env_base + e), 0x51ace5u, (uint32_t)next_agent) % (uint32_t)__popcll(freem));
+        unsigned long long fm = freem;
+        while (kth-- > 0) fm &= fm - 1ull;
+        const int p = __builtin_ffsll((long long)fm) - 1;
         const int src = __builtin_ffsll((long long)em) - 1;
         const int tslot = (src / d.sub) % V;
         int dest = (int)(pgd_rng(gcf.seed, (uint32_t)(gcf.env_base + e), 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
                          (uint32_t)gcf.respawn_dests);
-        if (parking) {  // get_parking_space: a random one of the free spaces; none -> nobody enters from a road
-          const unsigned mask = (unsigned)s_aux & ((1u << gcf.respawn_dests) - 1u);
-          if (__ballot(mask != 0u) == 0ull) break;
+        if (parking) {  // get_parking_space: a random one of the free spaces
           int pick = (int)(pgd_rng(gcf.seed, (uint32_t)(gcf.env_base + e), 0x0a9e47u + (uint32_t)p, (uint32_t)next_agent) %
-                           (uint32_t)__popc(mask));
+                           (uint32_t)__popc(pool));
           dest = 0;
           for (int b = 0; b < 32; ++b)
-            if (mask & (1u << b)) { if (pick-- == 0) { dest = b; break; } }
+            if (pool & (1u << b)) { if (pick-- == 0) { dest = b; break; } }
           step_sync();  // everybody has read the pool before lane 0 takes the space out
           if (lane == 0) s_aux &= ~(1 << dest);
         }
         if (valid && s == tslot) {
-          // only the choice is recorded here; the record itself is rebuilt once, after the loop (rewriting `r` inside it kept
-          // two copies of the 32 record registers alive around the place test: 139 VGPRs, 66 spilled)
           fresh_idx = V + p * gcf.respawn_dests + dest;
           fresh_id = next_agent;
           fresh = true;
@@ -1305,18 +1313,15 @@ struct pgd_engine {
   bool no_fix;       // PGD_NO_FIX: never pick the kernel specialised for the default configuration (A/B, debugging)
   bool no_fuse;      // PGD_NO_FUSE was set when the engine was created (debug: always run the stand-alone k_observe)
   bool prof_fused;
-  unsigned long long* rowz;  // multi-agent engines: PgdDev::rowz ...
-  const float* rowz_obs;     // ... describes THIS observation buffer (pointer and row stride of the last call that wrote rows); a
-  int rowz_stride;           // call with another buffer forgets what is known (a caller that alternates buffers pays the zero rows)
+  bool left_pack_mode;  // pgd_set_groups switched the engine from throughput mode back to one env per wave (reported by pgd_describe_step)
+  ulonglong2* rowz;  // multi-agent engines: PgdDev::rowz (zero-row marks + the tag of the buffer they describe, per env)
 };
 
-// the caller's observation buffer of this call: the zero-row marks hold for one buffer at a time (multi-agent engines)
-static int obs_rows_known(pgd_engine* h, const float* d_obs, int ostride, hipStream_t stream, bool env_rows) {
-  if (!h->rowz || !d_obs) return PGD_OK;
-  if (env_rows && d_obs == h->rowz_obs && ostride == h->rowz_stride) return PGD_OK;
-  HIPCHK(hipMemsetAsync(h->rowz, 0, sizeof(unsigned long long) * (size_t)h->d.N, stream));
-  h->rowz_obs = env_rows ? d_obs : nullptr;  // rows written by another kernel (k_observe): nothing is known afterwards
-  h->rowz_stride = ostride;
+// Rows written by a kernel that does not keep the zero-row marks (k_observe, one block per row): what the marks say about this
+// buffer may no longer hold -- forget them (a memset node when the stream is being captured: every replay forgets again).
+static int obs_rows_forget(pgd_engine* h, hipStream_t stream) {
+  if (!h->rowz) return PGD_OK;
+  HIPCHK(hipMemsetAsync(h->rowz, 0, sizeof(ulonglong2) * (size_t)h->d.N, stream));
   return PGD_OK;
 }
 
@@ -1415,7 +1420,7 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->n_groups = 1;
   const bool marl = (cfg->marl_flags & PGD_MA_ENABLED) != 0;
   // multi-agent engines have no IDM traffic; num_traffic slots may hold static bodies (toll booths, group PGD_GROUP_NEVER)
-  if (marl && (cfg->respawn_places < 0 || cfg->respawn_dests < 0)) return PGD_ERR_ARG;
+  if (marl && (cfg->respawn_places < 0 || cfg->respawn_places > 64 || cfg->respawn_dests < 0)) return PGD_ERR_ARG;  // (free places: one 64-bit mask)
   if (cfg->idm_agent && (marl || cfg->num_agents != 1)) return PGD_ERR_ARG;  // the agent's PID / routing fields double as multi-agent bookkeeping
   if (marl && cfg->horizon > 0x7fff) return PGD_ERR_ARG;  // the per-agent episode length is a 16-bit field of the record
   h->d.sstride = V + (marl ? cfg->respawn_places * cfg->respawn_dests : 0);
@@ -1446,9 +1451,12 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   HIPCHK(hipMemsetAsync(h->d.rec, 0, sizeof(VehRec) * nv, h->stream));
   HIPCHK(hipMemsetAsync(h->d.ei, 0, sizeof(int32_t) * (size_t)h->d.N * PGD_NEI, h->stream));
   if (marl) {
-    HIPCHK(hipMalloc(&h->rowz, sizeof(unsigned long long) * (size_t)h->d.N));
-    HIPCHK(hipMemsetAsync(h->rowz, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
-    h->d.rowz = h->rowz;
+    // PGD_NO_ROWZ=1: no marks -- every row that is not due is zero-filled by every call (callers that edit the returned rows in place)
+    if (!getenv("PGD_NO_ROWZ") || getenv("PGD_NO_ROWZ")[0] == '0') {
+      HIPCHK(hipMalloc(&h->rowz, sizeof(ulonglong2) * (size_t)h->d.N));
+      HIPCHK(hipMemsetAsync(h->rowz, 0, sizeof(ulonglong2) * (size_t)h->d.N, h->stream));
+      h->d.rowz = h->rowz;
+    }
   }
   HIPCHK(hipMalloc(&h->d.env_map, sizeof(pgd_map) * (size_t)h->d.N));
   HIPCHK(hipMemsetAsync(h->d.env_map, 0, sizeof(pgd_map) * (size_t)h->d.N, h->stream));
@@ -1670,7 +1678,6 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
     while (G > 1 && (size_t)nw * observe_env_words(G, NL, V, h->d.cfg.num_others) * 4 + oth_bytes > PGD_OBS_ENV_LDS) --G;
     const size_t dyn = (size_t)nw * observe_env_words(G, NL, V, h->d.cfg.num_others) * 4 + oth_bytes;
     if (dyn <= 49152) {
-      { int rc = obs_rows_known(h, d_obs, D.ostride, stream, true); if (rc) return rc; }
       const bool fix = !h->no_fix && !h->has_objects && fix_config_matches(D, true, FIXK_MARL);
       void (*ke)(PgdDev, float*, const uint32_t*, int) = four ? k_observe_env<4> : k_observe_env<1>;
       if (fix) ke = four ? k_observe_env<4, true> : k_observe_env<1, true>;
@@ -1679,7 +1686,7 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
       return PGD_OK;
     }
   }
-  { int rc = obs_rows_known(h, d_obs, D.ostride, stream, false); if (rc) return rc; }
+  { int rc = obs_rows_forget(h, stream); if (rc) return rc; }
   const bool wide = h->d.cfg.num_lasers > 128;  // up to 128 beams one wave does it in two rounds: 4x fewer waves than 256-thread blocks
   void (*kern)(PgdDev, float*, const uint32_t*, int) =
       wide ? (oth ? k_observe<256, true> : k_observe<256, false>) : (oth ? k_observe<64, true> : k_observe<64, false>);
@@ -1766,7 +1773,6 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   const bool timing = h->step_timing && !prof && !grouped && group < 0;
   if (prof || timing || g_open) HIPCHK(hipEventRecord((prof || g_open) ? pe[0] : h->ev0, h->stream));
   int blocks = (n_env_launch + h->d.epw - 1) / h->d.epw;
-  if (fuse_env) { int rc = obs_rows_known(h, d_obs, ostride, stream, true); if (rc) return rc; }
   if (marl && h->d.epw != 1) return PGD_ERR_STATE;  // the multi-agent tail needs the env in one wave (V >= 33 or SUB split)
   void (*kern)(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*, PgdCold) = k_step<false, false, false>;
   const char* kname = h->d.pack_obs ? "k_step: whole envs side by side in a wave, one vehicle per lane (throughput mode)"
@@ -1853,16 +1859,21 @@ int pgd_step_packed(pgd_handle h, const float* d_actions, float* d_rows, int row
 int pgd_set_groups(pgd_handle h, int n_groups) {
   if (!h || n_groups < 1 || n_groups > 64) return PGD_ERR_ARG;
   if (h->d.N % n_groups != 0) return PGD_ERR_ARG;  // equal groups
-  if ((h->d.N / n_groups) % h->d.epw != 0) {
+  int pack = h->d.pack_obs, sub = h->d.sub, epw = h->d.epw;
+  if ((h->d.N / n_groups) % epw != 0) {
     // groups are launched as whole waves.  Throughput mode (pgd_create picks it from 32768 envs on: three envs of 17 slots per
     // wave) does not divide a power-of-two group size: such an engine goes back to one env per wave -- the record, image and
-    // mask layouts do not depend on the lane mapping, so the switch is a change of launch geometry only
-    if (!h->d.pack_obs) return PGD_ERR_ARG;
-    h->d.pack_obs = 0;
-    h->d.sub = WAVE / h->d.V < 16 ? WAVE / h->d.V : 16;
-    h->d.epw = WAVE / (h->d.V * h->d.sub);
-    if ((h->d.N / n_groups) % h->d.epw != 0) return PGD_ERR_ARG;
+    // mask layouts do not depend on the lane mapping, so the switch is a change of launch geometry only.  The new geometry is
+    // worked out in locals and committed only when every check has passed (a refused call leaves the engine as it was), and the
+    // switch is reported: pgd_describe_step says so from then on (by the r03 sweep it costs 6 - 18 % at 32768 envs)
+    if (!pack) return PGD_ERR_ARG;
+    pack = 0;
+    sub = WAVE / h->d.V < 16 ? WAVE / h->d.V : 16;
+    epw = WAVE / (h->d.V * sub);
+    if ((h->d.N / n_groups) % epw != 0) return PGD_ERR_ARG;
   }
+  if (pack != h->d.pack_obs) h->left_pack_mode = true;
+  h->d.pack_obs = pack; h->d.sub = sub; h->d.epw = epw;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->gstreams) {
@@ -1897,7 +1908,8 @@ int pgd_group_sync(pgd_handle h, int group) {
 
 int pgd_describe_step(pgd_handle h, char* buf, int cap) {
   if (!h || !buf || cap <= 0) return PGD_ERR_ARG;
-  snprintf(buf, (size_t)cap, "%s", h->last_step_kernel ? h->last_step_kernel : "");
+  snprintf(buf, (size_t)cap, "%s%s", h->last_step_kernel ? h->last_step_kernel : "",
+           h->left_pack_mode ? " [throughput mode switched off by pgd_set_groups: the group size is not a whole number of three-env waves]" : "");
   return PGD_OK;
 }
 

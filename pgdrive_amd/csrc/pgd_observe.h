@@ -559,6 +559,10 @@ struct EnvInWave {
 // x / n for 0 <= x < 4096, n <= 128 without the integer division (~25 instructions): (x + 0.5) / n is at least 0.5 / n away from an
 // integer and the fp32 product is off by < 1e-3 of one
 DEV int div_small(const int x, const float inv_n) { return (int)(((float)x + 0.5f) * inv_n); }
+// identity of an observation buffer for the zero-row marks (PgdDev::rowz): its address mixed with the row stride
+DEV unsigned long long rowz_tag(const float* obs, int ostride) {
+  return (unsigned long long)(uintptr_t)obs ^ ((unsigned long long)(unsigned)ostride * 0x9E3779B97F4A7C15ull);
+}
 // OBJ = false: engines whose scenarios hold no traffic objects (no circles among the bodies)
 template <int NW, bool ALLOW_OTH = true, bool FUSED = false, bool OBJ = true>
 DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const uint32_t* flags, ObsEnvLds<NW>& M,
@@ -575,7 +579,10 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   const int LPA = WAVE * NW / A;  // lanes per agent in the state phase (A <= WAVE)
   const int sa = FUSED ? in_wave->slot : tid / LPA, st = FUSED ? in_wave->sub : tid - (tid / LPA) * LPA;
   const bool s_on = sa < A;
-  const unsigned long long known_zero = d.rowz ? d.rowz[e] : 0ull;  // (read by every wave before the first barrier, written behind it)
+  // (read by every wave before the first barrier, written behind it)
+  const unsigned long long rz_tag = rowz_tag(obs, d.ostride);
+  const ulonglong2 rz = d.rowz ? d.rowz[e] : make_ulonglong2(0ull, 0ull);
+  const unsigned long long known_zero = rz.y == rz_tag ? rz.x : 0ull;  // marks of another buffer say nothing about this one
   Veh me;
   Veh body;  // only the first 64 bytes are filled
   uint32_t f_me, f_body = 0u;
@@ -666,7 +673,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     float* zr = obs + (size_t)e * d.ostride + (size_t)__builtin_ctzll(zm) * D;
     for (int k = tid; k < D; k += WAVE * NW) zr[k] = 0.0f;
   }
-  if (d.rowz && tid == 0 && not_due != known_zero) d.rowz[e] = not_due;
+  if (d.rowz && tid == 0 && (not_due != known_zero || rz.y != rz_tag)) d.rowz[e] = make_ulonglong2(not_due, rz_tag);
   row_sync<true>();
   PHASE_MARK(20);  // env obs: loads, publish, state blocks, lists, zero rows
   if (NL <= 0) return;

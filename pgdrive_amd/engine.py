@@ -157,7 +157,11 @@ class Engine:
 
     def step(self, actions, want_obs=True, out=None):
         """actions: float32 cuda tensor [N, A, 2] (contiguous). Asynchronous on the engine stream.
-        `out` = (obs, reward, done, flags) tensors to write instead of the engine's own buffers."""
+        `out` = (obs, reward, done, flags) tensors to write instead of the engine's own buffers.
+        The returned obs IS the engine's buffer (or `out[0]`), not a copy.  Multi-agent engines zero the row of a seat that is not
+        due ONCE and remember it per buffer (include/pgdrive_hip.h, pgd_step): a caller that edits the returned rows in place
+        (normalisation, clamp_, noise) would see its edits persist in the rows of empty seats -- clone first, or create the engine
+        with PGD_NO_ROWZ=1 in the environment (the zero rows are then rewritten by every call)."""
         assert actions.is_cuda and actions.dtype == self.torch.float32 and actions.is_contiguous()
         assert actions.numel() == self.N * self.A * 2
         if out is None:  # the engine's own output buffers: their addresses never change

@@ -42,6 +42,7 @@ MA_DEFAULT_CONFIG = dict(
     out_of_road_penalty=10,
     crash_vehicle_penalty=10,
     crash_object_penalty=10,
+    crash_vehicle_cost=1, crash_object_cost=1, out_of_road_cost=0,  # cost_function (multi_agent_pgdrive.py:45-47): out of road is free
     driving_reward=1.0,
     speed_reward=0.1,
     use_lateral=False,
@@ -126,8 +127,18 @@ class MultiAgentRoundaboutVecEnv:
         self._rng = np.random.RandomState(c["seed"])
 
     def reset(self):
-        ids = self._rng.randint(0, len(self.scen_bank.scenarios), size=self.num_envs).astype(np.int32)
-        return self.engine.reset(ids)  # [N, A, D]; rows of empty slots are zero
+        """SpawnManager.reset draws the placement afresh every episode (spawn_manager.py:68-101); here an env is dealt one of the
+        `spawn_variants` pre-drawn placements -- never the one it was dealt at its last reset() (the reference's own
+        test_randomize_spawn_place expects every agent somewhere else after a reset).  Returns obs [N, A, D]; rows of empty seats are
+        zero, and a row that is not due stays as it was left: callers that post-process rows in place should copy first (see
+        Engine.step)."""
+        n = len(self.scen_bank.scenarios)
+        ids = self._rng.randint(0, n, size=self.num_envs).astype(np.int32)
+        if n > 1 and getattr(self, "_last_ids", None) is not None:
+            same = ids == self._last_ids
+            ids[same] = (ids[same] + 1 + self._rng.randint(0, n - 1, size=int(same.sum()))) % n
+        self._last_ids = ids.copy()
+        return self.engine.reset(ids)
 
     def step(self, actions):
         """actions [N, A, 2] cuda float32 (rows of slots without an active agent are ignored)."""
@@ -314,6 +325,15 @@ class MultiAgentRoundaboutEnv:
         cfg = dict(config or {})
         cfg["num_envs"] = 1
         cfg.setdefault("auto_reset", False)
+        # Seats.  The engine never re-uses a seat in the step in which its agent reported (the terminal row must survive), so with
+        # exactly num_agents seats a step in which EVERY agent finishes leaves nobody to respawn into and reads as `__all__` -- the
+        # reference respawns in that very step (multi_agent_pgdrive.py:126-150; its own tests finish both of two agents at once and
+        # expect the episode to go on).  The dict env therefore keeps spare seats unless told otherwise: as many as agents, bodies per
+        # env capped at 52 (the sub-step contact test of larger waves is coarser).  `num_agents` still bounds how
+        # many are alive at a time (agent_limit).
+        n = cfg.get("num_agents", self.VEC.DEFAULTS["num_agents"])
+        if cfg.get("max_agents") is None and n is not None and n > 0:
+            cfg["max_agents"] = min(2 * n, max(n, 44))
         self.vec = self.VEC(cfg)
         self.config = self.vec.config
         import torch
@@ -321,6 +341,11 @@ class MultiAgentRoundaboutEnv:
         self._slots = {}  # agent name -> slot
         self._static = set()  # slots frozen by VehicleHandle.set_static
         self.episode_steps = 0
+
+    @property
+    def num_agents(self):
+        """How many agents may be alive at a time (BaseEnv.num_agents)."""
+        return int(self.vec.scen_bank.num_agents)
 
     @property
     def vehicles(self):
@@ -378,7 +403,10 @@ class MultiAgentRoundaboutEnv:
                 crash_vehicle=bool(fl[s] & _abi.F_CRASH_VEHICLE), crash=bool(fl[s] & _abi.F_CRASH_VEHICLE),
                 crash_object=bool(fl[s] & _abi.F_CRASH_OBJECT), crash_building=bool(fl[s] & _abi.F_CRASH_BUILDING),
                 max_step=bool(fl[s] & _abi.F_MAX_STEP), step_reward=float(rew[s]),
-                cost=1 if (fl[s] & _abi.F_CRASH_VEHICLE and not fl[s] & _abi.F_OUT_OF_ROAD) else 0,
+                # cost_function (pgdrive_env.py:197-207): out of road, else crash_vehicle, else crash_object
+                cost=(self.config["out_of_road_cost"] if fl[s] & _abi.F_OUT_OF_ROAD else
+                      self.config["crash_vehicle_cost"] if fl[s] & _abi.F_CRASH_VEHICLE else
+                      self.config["crash_object_cost"] if fl[s] & _abi.F_CRASH_OBJECT else 0),
                 # _get_step_return (base_env.py:335-339) and BaseVehicle.after_step (base_vehicle.py:255-273)
                 episode_reward=float(f0[_abi.SF["EP_REWARD"], 0, s]) + float(rew[s]),
                 episode_length=int(i0[_abi.SI["RLANE"], 0, s]) + 1,

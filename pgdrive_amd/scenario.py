@@ -576,11 +576,15 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
     spawn_roads = MARL_SPAWN_ROADS[kind](desc) if spawn_roads is None else resolve_spawn_roads(desc, spawn_roads)
     slots, safe = spawn_slots(desc, spawn_roads)
     infinite = num_agents == -1  # "as many vehicles as possible" (base_env.py:25): every spawn slot, in slot order
-    if infinite:
-        num_agents = len(slots)
+    if infinite:  # ... as far as the seats go (`max_agents`): the first `capacity` slots
+        num_agents = min(len(slots), capacity or len(slots))
     A = capacity or num_agents
     if num_agents > len(slots) or num_agents > A:
         raise ValueError("Too many agents! We only accept %d agents" % min(len(slots), A))
+    for a in (fixed or {}):
+        if not 0 <= int(a) < num_agents:
+            raise KeyError("target_vehicle_configs: 'agent%d' is not one of the %d initial agents (agent0 .. agent%d)" % (
+                int(a), num_agents, num_agents - 1))
     auto = kind in MARL_AUTO_DEST
 
     def auto_dest(c):  # Navigation.update (navigation.py:99-121): last block's socket, first block's on a negative road
@@ -611,7 +615,7 @@ def build_marl_scenario(desc, map_index, rng, num_agents, capacity=None, vehicle
         r["ckpt_road"][0] = lane["road"]
         r["dest_lane"] = road["first_lane"] + road["n_lanes"] - 1
     # (spawn_manager.py:76-81: all slots in order when the number of agents is -1, else a draw without replacement)
-    pick = np.arange(len(slots)) if infinite else rng.choice(len(slots), num_agents, replace=False)
+    pick = np.arange(num_agents) if infinite else rng.choice(len(slots), num_agents, replace=False)
     lo, la = RESPAWN_REGION_LONGITUDE - MAX_VEHICLE_LENGTH, RESPAWN_REGION_LATERAL - MAX_VEHICLE_WIDTH
     for a, idx in enumerate(pick):
         c = slots[int(idx)]
@@ -677,7 +681,7 @@ def build_parking_scenario(desc, map_index, rng, num_agents, capacity=None, vehi
     recs["lane"] = -1
     recs["group"] = -1
     avail = list(range(S))
-    pick = np.arange(len(slots)) if infinite else rng.choice(len(slots), num_agents, replace=False)
+    pick = np.arange(num_agents) if infinite else rng.choice(len(slots), num_agents, replace=False)
     lo, la = RESPAWN_REGION_LONGITUDE - MAX_VEHICLE_LENGTH, RESPAWN_REGION_LATERAL - MAX_VEHICLE_WIDTH
     for a, idx in enumerate(pick):
         c = slots[int(idx)]

@@ -580,6 +580,68 @@ def test_step_captured_in_a_hip_graph_matches_eager():
     graphed.close()
 
 
+@pytest.mark.parametrize("agents", [8, 40])
+def test_zero_row_marks_follow_the_buffer_through_graph_replays(agents):
+    """a multi-agent step captured with buffer X in a HIP graph, an eager step with `out=` another buffer Y between the
+    replays, then X again by replay: the marks of the zero rows carry the identity of the buffer they describe (on the device, per
+    env), so every replay zeroes what its own buffer needs -- rows of seats that are not due read zero in X and in Y after every
+    step, while both buffers are filled with garbage wherever a row is NOT marked (8 seats: rows appended to k_step; 40 seats: the
+    four-wave k_observe_env)."""
+    import torch
+    from pgdrive_amd import marl_env, _abi
+    env = marl_env.MultiAgentRoundaboutVecEnv(dict(num_envs=64, num_agents=agents, seed=4, horizon=60, delay_done=5))
+    eng = env.engine
+    try:
+        env.reset()
+        N, A, D = 64, eng.A, eng.D
+        g = torch.Generator(device="cuda")
+        g.manual_seed(1)
+        a_static = torch.zeros((N, A, 2), device="cuda")
+        X = (eng.obs, eng.reward, eng.done, eng.flags)
+        Y = tuple(torch.empty_like(t) for t in X)
+        Y[0].fill_(7.0)  # garbage: every row that is not due must be cleared by the first call that writes Y
+
+        def draw():
+            a = torch.rand((N, A, 2), device="cuda", generator=g) * 2 - 1
+            a[..., 1] = a[..., 1].abs()
+            return a
+
+        def check(buf, flags, what):
+            torch.cuda.synchronize()
+            due = (flags.cpu().numpy().astype(np.uint32) & (_abi.F_REPORT | _abi.F_NEW)) != 0
+            rows = buf.cpu().numpy().reshape(N, A, D)
+            assert (rows[~due] == 0.0).all(), what
+            assert (np.abs(rows[due]).sum(axis=1) > 0).all(), what
+            return int((~due).sum())
+
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                a_static.copy_(draw())
+                eng.step(a_static)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eng.step(a_static)  # writes X
+        n_zero = 0
+        for k in range(90):
+            a_static.copy_(draw())
+            if k % 3 == 1:
+                eng.step(a_static, out=Y)  # eager, another buffer: the marks now describe Y
+                n_zero += check(Y[0], Y[3], "eager step into Y, step %d" % k)
+                Y[0].fill_(7.0)            # ... and the caller scribbles over Y afterwards
+            else:
+                graph.replay()             # X again, by replay: the kernel sees marks of another buffer and zeroes what X needs
+                n_zero += check(X[0], X[3], "replay into X, step %d" % k)
+                if k % 3 == 0:
+                    X[0].fill_(-3.0)       # garbage in X before the eager step: the next replay follows a call with another buffer
+        assert n_zero > 100
+    finally:
+        env.close()
+
+
 def test_env_groups_step_like_one_batch(descs):
     """pgd_set_groups / pgd_step_group: four asynchronous env groups of one handle, each stepped once per round on its own
     stream, produce exactly what a plain engine produces for the whole batch (envs do not interact), through auto-resets;

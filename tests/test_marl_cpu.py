@@ -65,9 +65,13 @@ def test_infinite_agents_fill_every_spawn_slot_in_order():
             assert np.hypot(per[v]["x"][a] - x, per[v]["y"][a] - y) <= np.hypot(0.5 * lo, 0.5 * la) + 1e-4
     big = scenario.MarlScenarioBank(d, num_agents=-1, capacity=60, n_variants=1)  # room to grow beyond the initial 48
     assert big.A == 60 and big.num_agents == 48 and (big.spawns["lane"][48:60] == -1).all()
+    # fewer seats than spawn slots (`max_agents`): the first seats' worth of slots, in slot order (this used to raise)
+    small = scenario.MarlScenarioBank(d, num_agents=-1, capacity=40, n_variants=2)
+    assert small.infinite and small.A == small.num_agents == 40
+    assert (small.spawns.reshape(2, -1)[1]["lane"][:40] == np.array([c["lane"] for c in slots[:40]])).all()
     import pytest
     with pytest.raises(ValueError, match="Too many agents"):
-        scenario.MarlScenarioBank(d, num_agents=-1, capacity=40, n_variants=1)
+        scenario.MarlScenarioBank(d, num_agents=50, capacity=50, n_variants=1)  # 48 spawn slots
 
 
 def test_target_vehicle_configs_pin_the_named_agents():
@@ -101,6 +105,8 @@ def test_target_vehicle_configs_pin_the_named_agents():
     import pytest
     with pytest.raises(KeyError):
         scenario.MarlScenarioBank([d], num_agents=4, n_variants=1, kind="pg", fixed={0: dict(destination_node="no such node")})
+    with pytest.raises(KeyError, match="agent99"):  # a name outside agent0 .. agent3 is refused, not silently ignored
+        scenario.MarlScenarioBank([d], num_agents=4, n_variants=1, kind="pg", fixed={99: dict(spawn_longitude=5.0)})
 
 
 def test_spawn_roads_override():

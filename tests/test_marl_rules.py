@@ -75,3 +75,49 @@ def test_parking_space_pool_matches_the_reference_spawn_manager(golden):
             n_done_held += ev["kind"] == "done" and ev["held"]
     print("parking rules: checks", n_check, "spaces handed out on respawn", n_take, "spaces returned", n_done_held)
     assert n_check > 1000 and n_take > 20 and n_done_held > 20
+
+
+def test_one_respawn_per_step_matches_the_reference_respawn_loop(golden):
+    """How many agents one env.step respawns.  The fixture holds what the reference's OWN SpawnManager.get_available_respawn_places +
+    MultiAgentPGDrive._respawn_vehicles do on 24 occupancy patterns of eight places (oracle/gen_marl_rules.py::respawn_reference):
+    a free place is offered once per frame, one offered place is taken per call -- ONE newcomer per step when any place is free,
+    none from a second call in the same frame, the next one in the next frame.  (Rounds 2 - 4 filled every free place in one step;
+    the re-stated reference invariants of tests/test_marl_invariants_gpu.py found it.)  The oracle is held to the same rule: with
+    ten seats emptied at once it brings back exactly one agent per step, each into a free place."""
+    import numpy as np
+    from oracle import orc
+    from pgdrive_amd import _abi
+    from tests import util
+    cases = golden["respawn"]
+    assert len(cases) >= 20
+    for c in cases:
+        n_free = c["places"] - len(c["occupied"])
+        assert c["newcomers"] == min(1, n_free) and c["newcomers_second_call_same_frame"] == 0
+        assert c["newcomers_next_frame"] == min(1, n_free)  # (the stand-in vehicles occupy nothing: the same places are free again)
+        assert c["offered_in_first_call"] == [p for p in range(c["places"]) if p not in c["occupied"]]
+    d, mb, sb = util.make_marl_banks(num_agents=40, n_variants=2, kind="roundabout")
+    n = 6
+    cfg = util.marl_config(n, sb, horizon=1000, delay_done=0)
+    ora = orc.Oracle(cfg, mb, sb)
+    ora.reset(np.arange(n) % 2)
+    f, i, ei = ora.get_state()
+    i[_abi.SI["STATUS"], :, :10] = _abi.ST_EMPTY  # ten agents leave at once: ten seats free, alive = 30 < 40
+    ora.set_state(f, i, ei)
+    act = np.zeros((n, 40, 2), np.float32)
+    act[..., 1] = 0.5  # everybody drives off: the road starts clear one after the other
+    back = np.zeros(n, int)
+    for t in range(60):
+        f0, i0, _ = ora.get_state()
+        obs, rew, done, flags = ora.step(act)
+        new = (flags & _abi.F_NEW) != 0
+        assert (new.sum(axis=1) <= 1).all(), "more than one newcomer in one env step"
+        f1, i1, _ = ora.get_state()
+        for e in range(n):
+            for a in np.nonzero(new[e])[0]:  # the newcomer stands clear of everybody who was there before it came
+                others = [(f0[_abi.SF["X"], e, b], f0[_abi.SF["Y"], e, b]) for b in range(40)
+                          if b != a and i0[_abi.SI["STATUS"], e, b] in (_abi.ST_ACTIVE, _abi.ST_DYING)]
+                dist = min(np.hypot(f1[_abi.SF["X"], e, a] - x, f1[_abi.SF["Y"], e, a] - y) for x, y in others)
+                assert dist > 3.0
+        back += new.sum(axis=1)
+    assert (back >= 6).all() and (back <= 60).all()  # one per step, and only while some place is free
+    ora.close()

@@ -72,8 +72,9 @@ def _compare_step(torch, eng, ora, act, stats):
                 off = sl + r_ * sl
                 fan[off:off + ks] = True
                 fan[off + (ks or 2) + 6:off + (ks or 2) + 6 + km] = True
+        tail = 2 if (eng.cfg.marl_flags & _abi.MA_TOLLGATE) else 0  # TollGateObservation appends its two floats BEHIND the lidar
         if nl:
-            fan[-nl:] = True
+            fan[d.shape[1] - tail - nl:d.shape[1] - tail] = True
         stats["obs"] = max(stats["obs"], float(d[:, ~fan].max()))
         stats["obs_state"] = max(stats.get("obs_state", 0.0), float(d[:, ~fan].max()))  # the non-ray columns on their own
         if ks + km:  # same treatment as the lidar beams below, plus origin-on-a-line-edge flips
@@ -87,7 +88,7 @@ def _compare_step(torch, eng, ora, act, stats):
         if nl:
             # a beam grazing a box corner can flip hit <-> miss between fp32 and fp64 (the slab test compares two
             # nearly equal parameters); such flips are counted and bounded, every other beam must agree to OBS_TOL
-            beams = d[:, -nl:]
+            beams = d[:, d.shape[1] - tail - nl:d.shape[1] - tail]
             graze = beams > OBS_TOL
             stats["beams"] = stats.get("beams", 0) + beams.size
             stats["grazing"] = stats.get("grazing", 0) + int(graze.sum())
