@@ -1,0 +1,129 @@
+"""What the kinematic bicycle does to the reference's IDM traffic (evidence, not a model change).
+
+The reference steers its traffic with a PID tuned on Bullet's raycast vehicle (policy/idm_policy.py:187-188,244-252: heading PID
+kp 1.7 / kd 3.5 fed by a lateral PID, one decision per 0.1 s).  On the bicycle model of this engine the same gains weave.  Bullet
+cannot run here, so nothing below is a parity statement: the test MEASURES, over the PGDrive-v0 map bank in trigger and in respawn
+mode, how far driving IDM vehicles stray from the axis of the lane they follow, how often their box reaches over the lane's edge,
+and how often the traffic manager removes a vehicle for having left its lane (manager/traffic_manager.py:98-108: `not v.on_lane`)
+somewhere else than at the end of its route -- and asserts the band the numbers were found in, so that a change of the dynamics or
+of the controller that moves them is seen.  The numbers are quoted in README.md ("unpinned semantics")."""
+import numpy as np
+import pytest
+
+from pgdrive_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _lane_tables(mb):
+    """Per map, padded to the largest lane count: type, start / centre, direction, length, width, road id."""
+    L = max(len(d["lanes"]) for d in mb.descs)
+    M = len(mb.descs)
+    t = dict(type=np.zeros((M, L), int), sx=np.zeros((M, L)), sy=np.zeros((M, L)), dx=np.zeros((M, L)), dy=np.zeros((M, L)),
+             length=np.zeros((M, L)), width=np.zeros((M, L)), nsucc=np.zeros((M, L), int))
+    for m, d in enumerate(mb.descs):
+        for k, l in enumerate(d["lanes"]):
+            t["type"][m, k] = l["type"]
+            t["length"][m, k], t["width"][m, k] = l["length"], l["width"]
+            if l["type"] == 0:
+                t["sx"][m, k], t["sy"][m, k] = l["start"]
+                t["dx"][m, k], t["dy"][m, k] = l["direction"]
+            road = d["roads"][l["road"]]
+            t["nsucc"][m, k] = sum(1 for r in d["roads"] if r["frm"] == road["to"])
+    return t
+
+
+@pytest.mark.parametrize("mode", ["trigger", "respawn"])
+def test_idm_traffic_lateral_behaviour_on_the_bicycle_model(descs, mode):
+    import torch
+    from pgdrive_amd import mapdata, scenario
+    from pgdrive_amd.engine import Engine
+    sel = list(descs[:100])
+    mb = mapdata.MapBank(sel)
+    sb = scenario.ScenarioBank(sel, [d["seed"] for d in sel], num_agents=1, num_traffic=16, traffic_mode=mode)
+    n = 400
+    cfg = _abi.make_config(n, num_agents=1, num_traffic=16, num_lasers=240, auto_reset=1, seed=17)
+    eng = Engine(cfg, mb, sb)
+    scen = np.arange(n) % len(sel)
+    eng.reset(scen)
+    T = _lane_tables(mb)
+    SF, SI = _abi.SF, _abi.SI
+    act = torch.zeros((n, 1, 2), dtype=torch.float32, device=eng.device)
+    steps = 700
+    lat_all, lat_settled, over_edge, veh_steps, straight_steps = [], [], 0, 0, 0
+    removed_mid = removed_end = 0
+    at_lock = flips = 0
+    prev = None
+    prev_steer = None
+    since = np.zeros((n, 16), int)  # steps a vehicle has been on its present lane (a lane change ends with a swing-in of its own)
+    for t in range(steps):
+        if mode == "trigger":  # the scripted ego keeps driving: the trigger traffic gets released, episodes end by arrival
+            eng.lane_keep_actions(act, t)
+        # (respawn mode: every vehicle drives from the first step; the ego stays parked -- a driving ego runs into the car the
+        # reference places 1 m ahead of it at once and the episode would restart every other step)
+        eng.step(act)
+        eng.sync()
+        f, i, ei = eng.get_state()
+        m_of = sb.scenarios["map"][ei[_abi.EI["SCEN"]]][:, None].repeat(16, axis=1)
+        st, lane, rl = i[SI["STATUS"]][:, 1:], i[SI["LANE"]][:, 1:], i[SI["RLANE"]][:, 1:]
+        x, y, sp = f[SF["X"]][:, 1:].astype(np.float64), f[SF["Y"]][:, 1:].astype(np.float64), f[SF["SPEED"]][:, 1:]
+        steer = f[SF["STEER"]][:, 1:]  # what IDMPolicy.act asked for (the physics clips it to the lock, +-1)
+        drv = (st == _abi.ST_ACTIVE) & (np.abs(sp) > 0.5)
+        veh_steps += int(drv.sum())
+        ln = np.clip(lane, 0, T["type"].shape[1] - 1)
+        # a vehicle that follows its lane (no lane change under way: the routing target is the lane it is on) on a straight lane
+        on_straight = drv & (T["type"][m_of, ln] == 0) & ((rl == lane) | (rl < 0))
+        ddx, ddy = x - T["sx"][m_of, ln], y - T["sy"][m_of, ln]
+        lat = ddx * -T["dy"][m_of, ln] + ddy * T["dx"][m_of, ln]
+        lon = ddx * T["dx"][m_of, ln] + ddy * T["dy"][m_of, ln]
+        inside = on_straight & (lon > 2.0) & (lon < T["length"][m_of, ln] - 2.0)  # (not in the junction mouths)
+        if prev is not None:
+            kept = (prev[1] == lane) & (prev[0] == _abi.ST_ACTIVE) & (st == _abi.ST_ACTIVE) & (ei[_abi.EI["EPISODES"]] == prev[4])[:, None]
+            since = np.where(kept, since + 1, 0)
+        straight_steps += int(inside.sum())
+        lat_all.append(lat[inside])
+        lat_settled.append(lat[inside & (since >= 30)])  # on this lane for 3 s and more: the controller's steady state
+        # chatter: the command at (or beyond) the lock, and with the opposite sign of the step before
+        at_lock += int((inside & (np.abs(steer) >= 1.0)).sum())
+        if prev_steer is not None:
+            flips += int((inside & (since >= 1) & (steer * prev_steer < 0.0) & (np.abs(steer) > 0.5) & (np.abs(prev_steer) > 0.5)).sum())
+        prev_steer = steer.copy()
+        # the box reaches over the lane's edge: |lateral| + half the car's width beyond half the lane's width
+        hw = 0.5 * sb.spawns["width"].reshape(len(sel), -1)[ei[_abi.EI["SCEN"]]][:, 1:17]
+        over_edge += int((inside & (np.abs(lat) + hw > 0.5 * T["width"][m_of, ln])).sum())
+        if prev is not None:
+            p_st, p_lane, p_lon, p_m, p_ep = prev
+            same_ep = (ei[_abi.EI["EPISODES"]] == p_ep)[:, None]
+            gone = same_ep & (p_st == _abi.ST_ACTIVE) & (st == _abi.ST_REMOVED)
+            # at the end of its route (the lane has no road behind it, or the car was within 8 m of its end) or in mid-road
+            pl = np.clip(p_lane, 0, T["type"].shape[1] - 1)
+            at_end = (T["nsucc"][p_m, pl] == 0) | (p_lon > T["length"][p_m, pl] - 8.0) | (T["type"][p_m, pl] != 0)
+            removed_end += int((gone & at_end).sum())
+            removed_mid += int((gone & ~at_end).sum())
+        prev = (st.copy(), lane.copy(), lon.copy(), m_of.copy(), ei[_abi.EI["EPISODES"]].copy())
+    lat_all, lat_settled = np.concatenate(lat_all), np.concatenate(lat_settled)
+    rms, p99, mx = float(np.sqrt((lat_all ** 2).mean())), float(np.quantile(np.abs(lat_all), 0.99)), float(np.abs(lat_all).max())
+    s_rms, s_p99 = float(np.sqrt((lat_settled ** 2).mean())), float(np.quantile(np.abs(lat_settled), 0.99))
+    edge_frac = over_edge / max(1, straight_steps)
+    mid_per_1k = 1000.0 * removed_mid / max(1, veh_steps)
+    lock_frac, flip_frac = at_lock / max(1, straight_steps), flips / max(1, straight_steps)
+    print("IDM traffic on the bicycle model, %s mode: %d driving vehicle-steps, %d of them lane-following on straight lanes: lateral "
+          "offset from the lane axis rms %.3f m, 99th percentile %.3f m, max %.3f m (3 s and longer on the lane, %d steps: rms %.3f m, 99th "
+          "percentile %.3f m); box over the lane edge in %.4f of those steps; steering command at the lock in %.3f of them, swinging from "
+          "one side to the other between consecutive decisions in %.3f; removed for leaving the lane: %d at a route / lane end, %d in "
+          "mid-road (%.3f per 1000 vehicle-steps)" % (
+              mode, veh_steps, straight_steps, rms, p99, mx, lat_settled.size, s_rms, s_p99, edge_frac, lock_frac, flip_frac,
+              removed_end, removed_mid, mid_per_1k))
+    assert straight_steps > 20000
+    # The band the numbers were found in (README.md, "unpinned semantics"; measured: rms 0.45 m, 99th percentile 1.7 m, box over the edge
+    # in 9 % of the steps, 0.01 mid-road removals per 1000 vehicle-steps, in both modes).  Said plainly: behind its first curve an IDM
+    # vehicle of this engine does NOT settle on the lane axis -- the reference's heading PID (kp 1.7, kd 3.5 per 0.1 s decision) is
+    # unstable on a vehicle without yaw inertia and ends in a two-step limit cycle, lock to lock, +-0.15 rad of heading around the
+    # lane's, a few decimetres beside the axis (the unbounded integrators hold the offset for hundreds of steps).  The cars keep to
+    # their roads (next to no mid-road removals), but they routinely reach over their lane's edge.  Bullet's raycast vehicle, which
+    # the gains were tuned on, cannot be run here: how much of this the reference's traffic shows is unknown.
+    assert rms < 0.7 and p99 < 2.2 and mx < 3.5
+    assert edge_frac < 0.15
+    assert mid_per_1k < 0.1
+    assert flip_frac < 0.8
+    eng.close()
