@@ -64,6 +64,12 @@ struct PgdDev {
   // is not due is zero-filled by every call -- for callers that post-process the returned rows in place.
   ulonglong2* rowz;
   uint8_t* bev_fill;  // [N] or null: the env was reset -- the top-down observation refills its history (pgd_topdown.h)
+  // multi-agent engines whose rows are written by k_observe_env after the step (many agent slots): the observation buffer of this
+  // step, or null.  k_step then writes the STATE BLOCK of every row that is due itself -- one lane per agent, from the record, the
+  // route context and the map view it holds in registers -- and k_observe_env<..., STATE = false> does the pairwise part only
+  // (round 5: the state phase of the four-wave kernel was 2.8 k of its 7.4 k instructions per env, every wave running the whole
+  // branch ladder for six lanes per agent after reading records, spawn records and lane tables back from memory).
+  float* state_rows;
 };
 
 // Device-side vehicle record = the per-lane register image of a vehicle (device-private; pgd_get_state / pgd_set_state

@@ -700,12 +700,19 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       // (rounds 2 - 4 filled every free place in the same step)
       const pgd_spawn* rbase = d.spawns + (size_t)scen * d.sstride + V;
       unsigned long long freem = 0ull;
+      // the places' poses: lane p reads place p, one round trip for all of them (read inside the loop, place after place, the two
+      // dependent reads per place were 5 k cycles of a step with 30 agents alive: profiles/r05_notes.md)
+      float plx = 0.0f, ply = 0.0f, plc = 1.0f, pls = 0.0f;
+      if (lane < gcf.respawn_places) {
+        const pgd_spawn& place = rbase[lane * gcf.respawn_dests];
+        const float2 phv = cold.spawn_hv[(size_t)scen * d.sstride + V + lane * gcf.respawn_dests];
+        plx = place.x; ply = place.y; plc = phv.x; pls = phv.y;
+      }
+      const Obb mine = snap_obb(S, lane < V ? lane : 0);
+      const bool here = lane < V && S.present[lane];
       for (int p = 0; p < gcf.respawn_places; ++p) {
-        const pgd_spawn& place = rbase[p * gcf.respawn_dests];
-        const float2 phv = cold.spawn_hv[(size_t)scen * d.sstride + V + p * gcf.respawn_dests];
-        const float pc = phv.x, ps = phv.y;
-        const Obb region{place.x, place.y, pc, ps, 4.0f, 1.5f};  // RESPAWN_REGION 8 m x 3 m (spawn_manager.py:27-28)
-        const bool blocks = lane < V && S.present[lane] && obb_overlap(region, snap_obb(S, lane));
+        const Obb region{__shfl(plx, p), __shfl(ply, p), __shfl(plc, p), __shfl(pls, p), 4.0f, 1.5f};  // RESPAWN_REGION 8 m x 3 m (spawn_manager.py:27-28)
+        const bool blocks = here && obb_overlap(region, mine);
         if (__ballot(blocks) == 0ull) freem |= 1ull << p;
       }
       // lowest empty slot that did not report this step (its terminal row must survive)
@@ -906,6 +913,22 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (lane == 0 && hint_next != ((near_env ? 1 : 0) | (trig_hint << 1))) d.ei[(size_t)e * PGD_NEI + EI_NEAR] = hint_next;
   }
   if (packed && obs == nullptr && valid && s == 0 && leader && !near_env) d.ei[(size_t)e * PGD_NEI + EI_NEAR] = 1;  // no row, no hint
+  // multi-agent engine with many agent slots (the rows are k_observe_env's, after this launch): the state block of every row that is
+  // due -- an agent that reported, a newcomer, or after a restart every active agent -- by the lane that holds the vehicle: its
+  // record, route context and map view are in registers here, where the four-wave kernel would read records, spawn records and
+  // lane tables back and run the float ladder in every wave (PgdDev::state_rows; same routine, one thread per row)
+  if (ONE_ENV && MARL && obs == nullptr && d.state_rows != nullptr && valid && leader && s < A) {
+    const bool due = resetting ? r.status == ST_ACTIVE : (my_fl & (PGD_F_REPORT | PGD_F_NEW)) != 0u;
+    if (due) {
+      AgentView ag;
+      ag.x = r.x; ag.y = r.y; ag.th = r.th; ag.hx = r.hx; ag.hy = r.hy; ag.dl = r.dl; ag.dr = r.dr; ag.v = r.v;
+      ag.steer = r.steer; ag.a0s = r.a0s; ag.a0t = r.a0t; ag.lhx = r.lasthx; ag.lhy = r.lasthy;
+      ag.cur_first = r.cur_first; ag.cur_n = r.cur_n; ag.next_first = r.next_first;
+      ag.blk = r.blk; ag.toll_time = r.php;
+      ag.env = e; ag.slot = s; ag.tick = steps_total;
+      state_block_one(d, mv, SPV, ag, d.state_rows + (size_t)e * d.ostride + (size_t)s * d.D);  // (state_in_step_ok: the plain row layout)
+    }
+  }
   // multi-agent engine: the rows of all agents, from the records and flags this wave has just written (the barrier makes
   // them visible to the whole workgroup); the step's LDS is free by now
   if (ONE_ENV && MARL && obs != nullptr) {
@@ -1239,13 +1262,14 @@ __global__ __launch_bounds__(BLOCK == WAVE ? WAVE * OBS_RPB : BLOCK) void k_obse
 // are at least four passes (A >= 4 * (WAVE / V)), else 1.
 // NW = 4 when the pair phase has at least four passes (A >= 4 * (WAVE / V)), else 1.
 // FIX: the engine runs the default multi-agent configuration (same constants as k_step's instantiation for it, PGD_FIXM_FIELDS)
-template <int NW, bool FIX = false>
+// STATE = false: k_step has written the state blocks of the rows that are due (PgdDev::state_rows): the pairwise part only
+template <int NW, bool FIX = false, bool STATE = true>
 __global__ __launch_bounds__(WAVE * NW) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags, int G) {
   if (FIX) write_fixed_config<true, true, false>(d);
   extern __shared__ unsigned s_minb_dyn[];
   __shared__ ObsEnvLds<NW> M;
   PHASE_INIT();  // (profile builds: the marks of observe_env_body count from here)
-  observe_env_body<NW, !FIX, false, !FIX>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);  // (the fixed-config kernel: no traffic objects)
+  observe_env_body<NW, !FIX, false, !FIX, STATE>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);  // (the fixed-config kernel: no traffic objects)
 }
 
 // scripted lane-keeping policy (pgd_lane_keep_actions): one thread per env
@@ -1313,6 +1337,7 @@ struct pgd_engine {
   bool no_fix;       // PGD_NO_FIX: never pick the kernel specialised for the default configuration (A/B, debugging)
   bool no_fuse;      // PGD_NO_FUSE was set when the engine was created (debug: always run the stand-alone k_observe)
   bool prof_fused;
+  bool no_state_in_step;  // PGD_NO_STATE_IN_STEP was set when the engine was created (A/B: the state blocks stay in k_observe_env)
   bool left_pack_mode;  // pgd_set_groups switched the engine from throughput mode back to one env per wave (reported by pgd_describe_step)
   ulonglong2* rowz;  // multi-agent engines: PgdDev::rowz (zero-row marks + the tag of the buffer they describe, per env)
 };
@@ -1409,6 +1434,7 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->no_fuse = getenv("PGD_NO_FUSE") != nullptr;
   h->no_fix = getenv("PGD_NO_FIX") != nullptr;
   h->row_observe = getenv("PGD_ROW_OBSERVE") != nullptr;
+  h->no_state_in_step = getenv("PGD_NO_STATE_IN_STEP") != nullptr;
   h->d.cfg = *cfg;
   h->d.N = cfg->num_envs; h->d.A = cfg->num_agents; h->d.T = cfg->num_traffic; h->d.V = V;
   h->d.D = pgd_obs_dim(cfg);
@@ -1662,8 +1688,18 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
 #ifndef PGD_OBS_ENV_LDS
 #define PGD_OBS_ENV_LDS 16384  // dynamic LDS a block of k_observe_env may take for its rounds of observers (40 slots x 72 beams: 53.2 us with 16 KB, 55.2 with 12, 55.8 with 48)
 #endif
+// The multi-agent observation after a step: is it the four-wave k_observe_env (many agent slots), and may k_step write the rows'
+// state blocks itself (PgdDev::state_rows)?  The latter for rows without detector fans, neighbour rows, toll floats or the
+// random-agent-model floats -- one lane per agent would cast the fans one beam after the other.  PGD_NO_STATE_IN_STEP=1: never (A/B).
+static bool env_observe_four(const pgd_engine* h);
+static bool state_in_step_ok(const pgd_engine* h) {
+  const pgd_config& c = h->d.cfg;
+  return env_observe_four(h) && c.side_lasers == 0 && c.lane_line_lasers == 0 && c.num_others == 0 && !c.random_agent_model &&
+         !(c.marl_flags & (PGD_MA_TOLLGATE | PGD_MA_OTHERS_STATE)) && c.num_lasers > 0 && !h->no_state_in_step;
+}
+
 static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, const PgdDev* dv = nullptr, hipStream_t stream = nullptr,
-                          int n_envs = 0) {
+                          int n_envs = 0, bool state_done = false) {
   const PgdDev& D = dv ? *dv : h->d;
   if (!stream) stream = h->stream;
   const int rows = (n_envs > 0 ? n_envs : h->d.N) * h->d.A;
@@ -1681,11 +1717,13 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
       const bool fix = !h->no_fix && !h->has_objects && fix_config_matches(D, true, FIXK_MARL);
       void (*ke)(PgdDev, float*, const uint32_t*, int) = four ? k_observe_env<4> : k_observe_env<1>;
       if (fix) ke = four ? k_observe_env<4, true> : k_observe_env<1, true>;
+      if (state_done && four) ke = fix ? k_observe_env<4, true, false> : k_observe_env<4, false, false>;
       hipLaunchKernelGGL(ke, dim3(envs), dim3(WAVE * nw), dyn, stream, D, d_obs, d_flags, G);
       HIPCHK(hipGetLastError());
       return PGD_OK;
     }
   }
+  if (state_done) return PGD_ERR_STATE;  // (state_in_step_ok promised the four-wave kernel: the same conditions as above)
   { int rc = obs_rows_forget(h, stream); if (rc) return rc; }
   const bool wide = h->d.cfg.num_lasers > 128;  // up to 128 beams one wave does it in two rounds: 4x fewer waves than 256-thread blocks
   void (*kern)(PgdDev, float*, const uint32_t*, int) =
@@ -1693,6 +1731,18 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
   hipLaunchKernelGGL(kern, dim3(wide ? rows : (rows + OBS_RPB - 1) / OBS_RPB), dim3(wide ? 256 : WAVE * OBS_RPB), 0, stream, D, d_obs, d_flags, rows);
   HIPCHK(hipGetLastError());
   return PGD_OK;
+}
+
+static bool env_observe_four(const pgd_engine* h) {  // (the conditions under which launch_observe takes k_observe_env<4>)
+  if (!(h->d.A > 1 && h->d.epw == 1 && !h->row_observe)) return false;
+  const int A = h->d.A, V = h->d.V, NL = h->d.cfg.num_lasers;
+  if (!(A >= 4 * (WAVE / V))) return false;
+  const bool oth = (h->d.cfg.marl_flags & PGD_MA_OTHERS_STATE) != 0 && h->d.cfg.num_others > 0;
+  const int per_wave = (A + 3) / 4;
+  int G = per_wave;
+  const size_t oth_bytes = (size_t)observe_env_oth_words(A, h->d.cfg.num_others, oth) * 4;
+  while (G > 1 && (size_t)4 * observe_env_words(G, NL, V, h->d.cfg.num_others) * 4 + oth_bytes > PGD_OBS_ENV_LDS) --G;
+  return (size_t)4 * observe_env_words(G, NL, V, h->d.cfg.num_others) * 4 + oth_bytes <= 49152;
 }
 
 int pgd_reset(pgd_handle h, const int32_t* env_ids, const int32_t* scen_ids, int n, float* d_obs) {
@@ -1812,6 +1862,9 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
       kname = "k_step: whole envs side by side in a wave (throughput mode), specialised for the default single-agent configuration";
     }
   }
+  // many agent slots: the rows come from k_observe_env after the step; the state blocks of the rows that are due are k_step's
+  const bool state_in_step = d_obs && !fuse && marl && state_in_step_ok(h);
+  dv.state_rows = state_in_step ? d_obs : nullptr;
   h->last_step_kernel = kname;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), 0, stream, dv, d_actions, d_reward, d_done,
                      d_flags, fuse ? d_obs : (float*)nullptr,
@@ -1820,7 +1873,7 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   if (prof || g_close) HIPCHK(hipEventRecord(pe[1], h->stream));
   if (g_close) h->prof_n += 1;
   if (d_obs && !fuse) {
-    int rc = launch_observe(h, d_obs, marl ? d_flags : (const uint32_t*)nullptr, &dv, stream, n_env_launch);
+    int rc = launch_observe(h, d_obs, marl ? d_flags : (const uint32_t*)nullptr, &dv, stream, n_env_launch, state_in_step);
     if (rc) return rc;
   }
   h->prof_fused = fuse;

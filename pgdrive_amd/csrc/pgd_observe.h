@@ -266,6 +266,40 @@ DEV void state_block(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const A
   }
 }
 
+// state_block for ONE thread and the plain row layout -- [2 lateral distances][6 ego floats][10 navigation floats], no detector fans,
+// no random-agent-model floats, no toll floats: the three table reads at once, the eighteen floats straight down (state_block's loop
+// would run its branch ladder once per float), nine 8-byte stores (a row starts at a multiple of D floats: D even -> 8-byte aligned,
+// else single stores).  Same expressions as state_block, float by float.
+template <class MV>
+DEV void state_block_one(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const AgentView& ag, float* __restrict__ row) {
+  const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
+  const pgd_lane ml = mv.lanes[state_lane_of(ag, 2)];
+  const LaneNav nv0 = mv.lnav()[state_lane_of(ag, 8)], nv1 = mv.lnav()[state_lane_of(ag, 13)];
+  float o[18];
+  o[0] = clipf(ag.dl / 18.0f, 0.0f, 1.0f);
+  o[1] = clipf(ag.dr / 18.0f, 0.0f, 1.0f);
+  o[2] = heading_diff(ml, px, py, hx, hy);
+  o[3] = clipf((speed_kmh(ag.v) + 1.0f) / (sp.max_speed + 1.0f), 0.0f, 1.0f);
+  o[4] = clipf((ag.steer / 60.0f + 1.0f) * 0.5f, 0.0f, 1.0f);
+  o[5] = clipf((ag.a0s + 1.0f) * 0.5f, 0.0f, 1.0f);
+  o[6] = clipf((ag.a0t + 1.0f) * 0.5f, 0.0f, 1.0f);
+  {
+    const float dot = hx * ag.lhx + hy * ag.lhy, cross = hx * ag.lhy - hy * ag.lhx;
+    const float z = dot > 0.0f ? fabsf(cross) / dot : 1.0f, q = z * z;
+    const float beta = z > 0.11f ? 1.0f : z * (1.0f + q * (-1.0f / 3.0f + q * 0.2f));
+    o[7] = clipf(beta / 0.1f, 0.0f, 1.0f);
+  }
+  navi_info_for(nv0, mv.lane_width(), ag.cur_n, px, py, hx, hy, o + 8);
+  navi_info_for(nv1, mv.lane_width(), ag.cur_n, px, py, hx, hy, o + 13);
+  if ((d.D & 1) == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) reinterpret_cast<float2*>(row)[k] = make_float2(o[2 * k], o[2 * k + 1]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 18; ++k) row[k] = o[k];
+  }
+}
+
 // the view of slot `o` of the env as an observed vehicle (the state vector a neighbour contributes to
 // LidarStateObservationMARound); its speed comes from the observer's snapshot
 DEV AgentView view_of_slot(const PgdDev& d, const MapView& mv, const VehRec* recs, const pgd_spawn* spb, int o, float spd_kmh,
@@ -564,7 +598,9 @@ DEV unsigned long long rowz_tag(const float* obs, int ostride) {
   return (unsigned long long)(uintptr_t)obs ^ ((unsigned long long)(unsigned)ostride * 0x9E3779B97F4A7C15ull);
 }
 // OBJ = false: engines whose scenarios hold no traffic objects (no circles among the bodies)
-template <int NW, bool ALLOW_OTH = true, bool FUSED = false, bool OBJ = true>
+// STATE = false: the state blocks of the rows that are due have been written by k_step (PgdDev::state_rows): no record of an
+// observer, no spawn record, no lane table is read here -- the bodies' poses and the step flags are all the routine needs
+template <int NW, bool ALLOW_OTH = true, bool FUSED = false, bool OBJ = true, bool STATE = true>
 DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const uint32_t* flags, ObsEnvLds<NW>& M,
                           unsigned* s_minb_all, const int G, const EnvInWave* in_wave = nullptr) {
   float (&bX)[WAVE] = M.bX; float (&bY)[WAVE] = M.bY; float (&bUX)[WAVE] = M.bUX; float (&bUY)[WAVE] = M.bUY;
@@ -594,21 +630,24 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     f_me = s_on ? in_wave->fl : 0u;
     scen = in_wave->scen; tick = in_wave->tick; mv = *in_wave->mv;
   } else {
-    load_rec(recs + (s_on ? sa : 0), me);
+    if (STATE) load_rec(recs + (s_on ? sa : 0), me);
 #pragma unroll
     for (int k = 0; k < 4; ++k) reinterpret_cast<uint4*>(&body)[k] = reinterpret_cast<const uint4*>(recs + (tid < V ? tid : 0))[k];
-    f_me = (flags && s_on) ? flags[(size_t)e * A + sa] : 0u;
+    f_me = (STATE && flags && s_on) ? flags[(size_t)e * A + sa] : 0u;
     f_body = (flags && tid < A) ? flags[(size_t)e * A + tid] : 0u;
     scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
     tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
-    mv = map_view_of(d, d.env_map + e);
+    if (STATE) mv = map_view_of(d, d.env_map + e);
   }
   const pgd_spawn* spb = d.spawns + (size_t)scen * d.sstride;
-  const pgd_spawn& msp = FUSED ? *in_wave->sp : spb[me.spawn];
+  const pgd_spawn& msp = FUSED ? *in_wave->sp : spb[STATE ? me.spawn : 0];
   // which slots get a row: after a multi-agent step the ones that reported or were (re)spawned, else the active ones
-  bool want = me.status == ST_ACTIVE;
-  if (flags) want = (f_me & PGD_F_RESET) ? want : (f_me & (PGD_F_REPORT | PGD_F_NEW)) != 0;
-  want = want && s_on;
+  bool want = false;  // (STATE = false: the rows' state blocks are there already; `aWant` comes from the bodies' own lanes below)
+  if (STATE) {
+    want = me.status == ST_ACTIVE;
+    if (flags) want = (f_me & PGD_F_RESET) ? want : (f_me & (PGD_F_REPORT | PGD_F_NEW)) != 0;
+    want = want && s_on;
+  }
   // ---- publish the bodies and the observers
   if (FUSED) {  // V == A: the first lane of every agent publishes its own vehicle
     if (s_on && st == 0) {
@@ -629,7 +668,14 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     bST[tid] = (int)body.status | (so_kind << 8);
     bFL[tid] = f_body;
   }
-  if (s_on && st == 0) { aMS[sa] = msp.max_speed; aWant[sa] = want ? 1 : 0; }
+  if (STATE) {
+    if (s_on && st == 0) { aMS[sa] = msp.max_speed; aWant[sa] = want ? 1 : 0; }
+  } else if (tid < A) {  // the same rule from the body's own status and flags (its lane holds both)
+    bool w = body.status == ST_ACTIVE;
+    if (flags) w = (f_body & PGD_F_RESET) ? w : (f_body & (PGD_F_REPORT | PGD_F_NEW)) != 0;
+    aWant[tid] = w ? 1 : 0;
+    aMS[tid] = 0.0f;  // (only read for neighbour rows, which the STATE = false kernels do not write)
+  }
   // ---- state blocks: every agent at once, LPA lanes each
   float* row = obs + (size_t)e * d.ostride + (size_t)(s_on ? sa : 0) * D;
   if (want) {
