@@ -218,8 +218,8 @@ class Engine:
 
     def describe_step(self):
         """Which step kernel the last step call launched (pgd_describe_step)."""
-        buf = C.create_string_buffer(256)
-        _chk(self.L.pgd_describe_step(self.h, buf, 256), "pgd_describe_step")
+        buf = C.create_string_buffer(512)
+        _chk(self.L.pgd_describe_step(self.h, buf, 512), "pgd_describe_step")
         return buf.value.decode()
 
     def lane_keep_actions(self, out, tick, obs=None, k_lat=1.0, k_head=2.0, v_target_kmh=30.0, noise=0.05):

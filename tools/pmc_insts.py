@@ -54,8 +54,13 @@ def summarise(kname):
     return out
 
 
-ks = [k for k in acc if "k_step" in k]
-ko = [k for k in acc if "k_observe_env" in k]
+def by_dispatches(names):  # the instantiation the steps launch (pgd_reset launches another one once)
+    names = [k for k in names if len(acc[k].get("SQ_WAVES", [])) >= 10]
+    return sorted(names, key=lambda k: -len(acc[k]["SQ_WAVES"]))
+
+
+ks = by_dispatches([k for k in acc if "k_step" in k])
+ko = by_dispatches([k for k in acc if "k_observe_env" in k])
 out = dict(envs=N, traffic=TRAFFIC, lasers=LASERS, actions=ACTIONS, traffic_mode=MODE, workload=WORKLOAD,
            agents=AGENTS if WORKLOAD == "c5" else 1,
            k_step=summarise(ks[0]) if ks else None, k_observe=summarise(ko[0]) if ko else None,

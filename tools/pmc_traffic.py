@@ -15,6 +15,7 @@ MODE = sys.argv[4] if len(sys.argv) > 4 else "trigger"         # bench.py --traf
 WORKLOAD = sys.argv[5] if len(sys.argv) > 5 else "c3"          # bench.py --workload
 AGENTS = int(sys.argv[6]) if len(sys.argv) > 6 else 1          # bench.py --agents (c5)
 LASERS = int(sys.argv[7]) if len(sys.argv) > 7 else (240 if WORKLOAD == "c3" else 72)
+TRAFFIC = int(sys.argv[8]) if len(sys.argv) > 8 else (16 if WORKLOAD == "c3" else 0)  # bench.py --traffic
 
 
 def pmc(d, steady_only=False):
@@ -35,7 +36,7 @@ rc_f = sum(cf["rec_copy"]) / len(cf["rec_copy"])
 rc_w = sum(cw["rec_copy"]) / len(cw["rec_copy"])
 rw_w = sum(cw["row_write"]) / len(cw["row_write"])
 c_f, c_w = rec_bytes / (rc_f * 1024.0), rec_bytes / (rc_w * 1024.0)
-out = dict(envs=N, traffic=16 if WORKLOAD == "c3" else 0, lasers=LASERS, actions=ACTIONS, traffic_mode=MODE, workload=WORKLOAD,
+out = dict(envs=N, traffic=TRAFFIC, lasers=LASERS, actions=ACTIONS, traffic_mode=MODE, workload=WORKLOAD,
            agents=AGENTS if WORKLOAD == "c5" else 1, kernel=kname, FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk,
            dispatches_averaged=len(steady(fetch[kname])),
            calibration=dict(rec_copy_bytes=rec_bytes, rec_copy_FETCH_SIZE_KB=rc_f, rec_copy_WRITE_SIZE_KB=rc_w, row_write_bytes=row_bytes,

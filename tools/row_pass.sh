@@ -6,6 +6,7 @@
 R=$GRAFT_REPO_ROOT; TAG=$1; WL=$2; N=$3; ACT=$4; MODE=$5; AG=$6; NL=$7; shift 7
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/$TAG; mkdir -p $O
+TR=16; [ "$WL" = "c5" ] && TR=0; prev=""; for a in "$@"; do case "$prev" in --traffic) TR=$a;; esac; prev=$a; done
 ARGS="--no-rows --no-cpu-baseline --workload $WL --envs $N --actions $ACT --traffic-mode $MODE --agents $AG --lasers $NL $@"
 [ -x /tmp/pgd_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/profiles/r01_calib.hip -o /tmp/pgd_calib 2>/dev/null
 timeout 600 python $R/bench.py $ARGS > $O/bench.json 2> $O/bench.err < /dev/null
@@ -19,12 +20,11 @@ if [ -z "$NO_INSTS" ]; then
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/insts_a -- python $R/bench.py $ARGS --exact --steps 200 --warmup 1500 --windows 1 > /dev/null 2> $O/insts.err < /dev/null
 timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH --kernel-trace --output-format csv -d $O/insts_b -- python $R/bench.py $ARGS --exact --steps 200 --warmup 1500 --windows 1 > /dev/null 2>> $O/insts.err < /dev/null
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/insts_c -- python $R/bench.py $ARGS --exact --steps 200 --warmup 1500 --windows 1 > /dev/null 2>> $O/insts.err < /dev/null
-TR=16; [ "$WL" = "c5" ] && TR=0; for a in "$@"; do case "$prev" in --traffic) TR=$a;; esac; prev=$a; done
 python $R/tools/pmc_insts.py $O $N $ACT $MODE $WL $AG $NL $TR > $O/pmc_insts.json; grep -E "insts_per_wave|waves_per_launch|share" $O/pmc_insts.json
 rm -rf $O/insts_a $O/insts_b $O/insts_c
 fi
 for f in $(find $O/stats -name "*kernel_stats.csv"); do cp $f $O/kernel_stats.csv; head -3 $f; done
-python $R/tools/pmc_traffic.py $O $N $ACT $MODE $WL $AG $NL > $O/pmc_traffic.json; grep -E "bytes_per_env_step|FETCH_SIZE_KB|WRITE_SIZE_KB|fetch_correction" $O/pmc_traffic.json
+python $R/tools/pmc_traffic.py $O $N $ACT $MODE $WL $AG $NL $TR > $O/pmc_traffic.json; grep -E "bytes_per_env_step|FETCH_SIZE_KB|WRITE_SIZE_KB|fetch_correction" $O/pmc_traffic.json
 tail -c 400 $O/bench.json; echo
 # keep only the summaries (the raw traces are large)
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -delete
