@@ -12,7 +12,14 @@
 //            px per metre (the crop of ObservationWindow: +-distance around the ego, ego heading up, top_down_obs_impl.py:30-82)
 //   ch 0     road_network: like the reference, the map is drawn ONCE -- a raster per scenario at TD_TEXEL = 0.25 m (the
 //            reference's background canvas: 2000 px over the map's extent + 20 m, i.e. 3-4 px / m), every texel classified
-//            analytically at its centre (k_topdown_raster) -- and the window samples its nearest texel:
+//            analytically at its centre (k_topdown_raster) -- and the window samples it.  Single RGB frame: the nearest texel.
+//            Multi-channel: the reference renders this channel at 2 R and halves it with pygame.transform.smoothscale
+//            (top_down_obs_multi_channel.py:214-217: for an exact halving an area average), after rotozoom has resampled the canvas
+//            bilinearly -- anti-aliased greys on the edges of lines and route lanes.  Here (round 5): the raster is PRE-AVERAGED at
+//            upload -- a half-resolution raster whose 0.5 m cell holds how many of its 2 x 2 texels are line / route lane
+//            (k_topdown_reduce) -- and a pixel takes the cell under its centre: value = (n_line * 35 + n_navi * 64) * 2 / 255 / 4,
+//            ONE gather per pixel (round 4 averaged four point samples a quarter pixel around the centre: four gathers, 138 -> 200 us;
+//            neither form is pygame's pixel -- that stays unpinned -- and both are the same analytic scene, area-averaged).  Classes:
 //            2 * 35/255 where the texel centre lies within 0.25 m (half of LANE_LINE_WIDTH = 0.5, or half a window pixel if
 //            that is more) of a lane-line box of the map (continuous and broken lines; LANE_LINE_COLOR (35,35,35)); else
 //            2 * 64/255 inside a lane (|lateral| <= width / 2, 0 <= longitudinal <= length) of a road on the ego's route
@@ -109,13 +116,37 @@ __global__ __launch_bounds__(256) void k_topdown_raster(PgdDev d, int scen, floa
   }
 }
 
+// Half-resolution raster of the multi-channel road channel: cell (x, y) covers the texels (2x .. 2x+1, 2y .. 2y+1) of the 0.25 m
+// raster; its byte = number of line texels | number of route-lane texels << 4 (texels beyond the raster count as nothing).
+__global__ __launch_bounds__(256) void k_topdown_reduce(const uint8_t* __restrict__ fine, uint8_t* __restrict__ coarse, int W, int H) {
+  const int W2 = (W + 1) >> 1, H2 = (H + 1) >> 1;
+  const int tbw = (W + 7) >> 3, tbw2 = (W2 + 7) >> 3, tbh2 = (H2 + 7) >> 3;
+  const long long n = (long long)tbw2 * tbh2 * 64;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
+    const long long tile = p >> 6;
+    const int in_t = (int)(p & 63), by = (int)(tile / tbw2), bx = (int)(tile - (long long)by * tbw2);
+    const int y2 = by * 8 + (in_t >> 3), x2 = bx * 8 + (in_t & 7);
+    int acc = 0;
+    if (x2 < W2 && y2 < H2)
+      for (int q = 0; q < 4; ++q) {
+        const int x = 2 * x2 + (q & 1), y = 2 * y2 + (q >> 1);
+        if (x < W && y < H) { const int c = fine[td_tiled(x, y, tbw)]; acc += c == 2 ? 1 : (c == 1 ? 16 : 0); }
+      }
+    coarse[p] = (uint8_t)acc;
+  }
+}
+
 #ifndef TD_OCC
 #define TD_OCC 1
 #endif
 #ifndef TD_NK
 #define TD_NK 4
 #endif
-__global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t, uint8_t* __restrict__ fill, float* __restrict__ img) {
+// RGB: the single RGB frame (TopDown::rgb) as a compile-time fact: the multi-channel kernel carries none of its branches
+template <bool RGB>
+__global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in, uint8_t* __restrict__ fill, float* __restrict__ img) {
+  TopDown t = t_in;
+  t.rgb = RGB ? 1 : 0;
   // dynamic LDS, sized by the engine's V instead of the 64-slot maximum (more blocks per CU: a block alternates between phases
   // that wait for reads and a phase that only writes, and the CU overlaps them across blocks):
   //   pose history after this step's insertion [n_frames][V] | per stacked frame the visible boxes [4][V] (centre, axis) | [4][V] half extents
@@ -206,18 +237,17 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t, ui
   const float4 eg0 = s_pose[0];
   const float m_ox = m.ox, m_oy = m.oy;
   const int tbw = (tw + 7) >> 3;
-  // texel class under pixel (pi, pj): the road network around the CURRENT ego pose (right = heading rotated by +90 deg in the
-  // engine's x / y frame), nearest texel of the scenario's raster
-  // (multi-channel mode: the reference renders the road channel at 2 R and pygame.transform.smoothscale halves it,
-  // top_down_obs_multi_channel.py:214-217 -- for an exact halving that filter is the 2 x 2 area average -- so a pixel is the mean of
-  // four samples at (+-1/4, +-1/4) pixel around its centre: anti-aliased greys on the edges of lines and route lanes instead of a
-  // three-valued channel.  The RGB frame is not rescaled upstream: one sample at the centre.)
-  auto texel_addr = [&](int pi, int pj, bool on, bool& in, float oi = 0.0f, float oj = 0.0f) -> long long {
-    const float fw = ((float)R * 0.5f - (float)pi - 0.5f - oi) * inv_s, rg = ((float)pj + 0.5f + oj - (float)R * 0.5f) * inv_s;
+  // raster entry under the centre of pixel (pi, pj): the road network around the CURRENT ego pose (right = heading rotated by
+  // +90 deg in the engine's x / y frame).  RGB frame: the nearest 0.25 m texel (its class).  Multi-channel: the 0.5 m cell of the
+  // pre-averaged raster that holds it (line / route-lane counts of the cell's 2 x 2 texels, k_topdown_reduce) -- the cell index is
+  // the texel index halved, and a centre whose texel lies beyond the raster reads nothing
+  const int tbw2 = (((tw + 1) >> 1) + 7) >> 3;
+  auto texel_addr = [&](int pi, int pj, bool on, bool& in) -> long long {
+    const float fw = ((float)R * 0.5f - (float)pi - 0.5f) * inv_s, rg = ((float)pj + 0.5f - (float)R * 0.5f) * inv_s;
     const float wx = eg0.x + fw * eg0.z - rg * eg0.w, wy = eg0.y + fw * eg0.w + rg * eg0.z;
     const int ix = (int)floorf((wx - m_ox) * (1.0f / TD_TEXEL)), iy = (int)floorf((wy - m_oy) * (1.0f / TD_TEXEL));
     in = on && ix >= 0 && iy >= 0 && ix < tw && iy < th;
-    return in ? td_tiled(ix, iy, tbw) : 0ll;
+    return in ? (RGB ? td_tiled(ix, iy, tbw) : td_tiled(ix >> 1, iy >> 1, tbw2)) : 0ll;
   };
   const int rows_c = min((TD_CHUNK / R) & ~7, (R + 7) & ~7);  // image rows per chunk
   for (int row0 = 0; row0 < R; row0 += rows_c) {
@@ -236,18 +266,8 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t, ui
           const int i = row0 + ty * 8 + (lane >> 3), j = tx * 8 + (lane & 7);
           const bool on = q < n_tiles && i < row1 && j < R;
           bool in;
-          if (t.rgb) {
-            v[u] = tex[texel_addr(i, j, on, in)];
-            if (!in) v[u] = 0;
-          } else {  // four sub-samples: low nibble = how many hit a line, high nibble = how many a route lane
-            int acc = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int c = tex[texel_addr(i, j, on, in, (q & 2) ? 0.25f : -0.25f, (q & 1) ? 0.25f : -0.25f)];
-              acc += !in ? 0 : (c == 2 ? 1 : (c == 1 ? 16 : 0));
-            }
-            v[u] = acc;
-          }
+          v[u] = tex[texel_addr(i, j, on, in)];  // RGB: the class; multi-channel: low nibble = line texels of the cell, high nibble = route-lane texels
+          if (!in) v[u] = 0;
           pix[u] = on ? i * R + j - c0 : -1;
         }
 #pragma unroll
@@ -357,26 +377,33 @@ static int topdown_build_rasters(pgd_engine* h) {
   const int n_scen = (int)h->h_scen->size();
   std::vector<long long> off((size_t)n_scen);
   long long total = 0;
+  const bool rgb = s->t.rgb != 0;  // RGB frame: the 0.25 m rasters themselves; multi-channel: their pre-averaged halves
+  long long fine_max = 0;
   for (int k = 0; k < n_scen; ++k) {
     const pgd_map& M = (*h->h_maps)[(size_t)(*h->h_scen)[(size_t)k].map];
     off[(size_t)k] = total;
     const long long W = (long long)((float)M.gx * M.cell / TD_TEXEL), H = (long long)((float)M.gy * M.cell / TD_TEXEL);
-    total += ((W + 7) / 8) * ((H + 7) / 8) * 64;
+    const long long fine = ((W + 7) / 8) * ((H + 7) / 8) * 64;
+    const long long W2 = (W + 1) / 2, H2 = (H + 1) / 2;
+    fine_max = std::max(fine_max, fine);
+    total += rgb ? fine : ((W2 + 7) / 8) * ((H2 + 7) / 8) * 64;
   }
   if (s->tex) { HIPCHK(hipFree(s->tex)); s->tex = nullptr; }
   if (s->tex_off) { HIPCHK(hipFree(s->tex_off)); s->tex_off = nullptr; }
-  {  // one raster per scenario, 16 bytes per square metre of map extent (1-2 MB per PGDrive-v0 map): a bank of a thousand
-     // scenarios is gigabytes -- refuse with a message instead of failing inside hipMalloc
+  {  // one raster per scenario, 16 bytes per square metre of map extent (1-2 MB per PGDrive-v0 map; a quarter of that pre-averaged):
+     // a bank of a thousand scenarios is gigabytes -- refuse with a message instead of failing inside hipMalloc
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    if ((size_t)total > free_b / 2) {
+    if ((size_t)(total + fine_max) > free_b / 2) {
       fprintf(stderr, "[pgdrive_hip] top-down rasters of %d scenarios need %.1f GB (%.1f GB free): use fewer scenarios per engine\n",
-              n_scen, (double)total / 1e9, (double)free_b / 1e9);
+              n_scen, (double)(total + fine_max) / 1e9, (double)free_b / 1e9);
       return PGD_ERR_STATE;
     }
   }
   HIPCHK(hipMalloc(&s->tex, (size_t)(total > 0 ? total : 1)));
   HIPCHK(hipMalloc(&s->tex_off, sizeof(long long) * (size_t)n_scen));
+  uint8_t* fine_tmp = nullptr;  // multi-channel: one scenario's 0.25 m raster at a time, reduced into its half-resolution raster
+  if (!rgb) HIPCHK(hipMalloc(&fine_tmp, (size_t)(fine_max > 0 ? fine_max : 1)));
   HIPCHK(hipMemcpyAsync(s->tex_off, off.data(), sizeof(long long) * (size_t)n_scen, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   for (int k = 0; k < n_scen; ++k) {
@@ -384,8 +411,15 @@ static int topdown_build_rasters(pgd_engine* h) {
     const int W = (int)((float)M.gx * M.cell / TD_TEXEL), H = (int)((float)M.gy * M.cell / TD_TEXEL);
     const long long n = (long long)((W + 7) / 8) * ((H + 7) / 8) * 64;
     const int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_topdown_raster, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, h->stream, h->d, k, s->t.line_r, s->tex + off[(size_t)k], W, H);
+    uint8_t* fine = rgb ? s->tex + off[(size_t)k] : fine_tmp;
+    hipLaunchKernelGGL(k_topdown_raster, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, h->stream, h->d, k, s->t.line_r, fine, W, H);
+    if (!rgb) {
+      const long long n2 = (long long)(((W + 1) / 2 + 7) / 8) * (((H + 1) / 2 + 7) / 8) * 64;
+      const int blocks2 = (int)std::min<long long>((n2 + 255) / 256, 8192);
+      hipLaunchKernelGGL(k_topdown_reduce, dim3(blocks2 > 0 ? blocks2 : 1), dim3(256), 0, h->stream, fine, s->tex + off[(size_t)k], W, H);
+    }
   }
+  if (fine_tmp) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipFree(fine_tmp)); }
   HIPCHK(hipGetLastError());
   s->t.tex = s->tex;
   s->t.tex_off = s->tex_off;
@@ -433,7 +467,8 @@ int pgd_observe_topdown(pgd_handle h, float* d_img) {
   HIPCHK(hipSetDevice(h->device));
   if (h->topdown->tex_dirty) { int rc = topdown_build_rasters(h); if (rc) return rc; }
   const size_t dyn = sizeof(float4) * ((size_t)h->topdown->t.n_frames + 4) * h->d.V + sizeof(float2) * 4 * (size_t)h->d.V;
-  hipLaunchKernelGGL(k_topdown, dim3(h->d.N), dim3(256), dyn, h->stream, h->d, h->topdown->t, h->d.bev_fill, d_img);
+  if (h->topdown->t.rgb) hipLaunchKernelGGL(k_topdown<true>, dim3(h->d.N), dim3(256), dyn, h->stream, h->d, h->topdown->t, h->d.bev_fill, d_img);
+  else hipLaunchKernelGGL(k_topdown<false>, dim3(h->d.N), dim3(256), dyn, h->stream, h->d, h->topdown->t, h->d.bev_fill, d_img);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }

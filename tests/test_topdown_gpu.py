@@ -26,15 +26,17 @@ def _setup(descs, n_envs, td=None, **kw):
 
 def test_topdown_parity_with_the_oracle(descs):
     """84 x 84 x 5 images (TopDownPGDriveEnv defaults) of 48 envs over 70 teacher-forced steps incl. auto-resets: every pixel is one
-    of the channel's two or three exact values, so the comparison is exact except where a pixel centre sits on an edge (fp32 vs
-    fp64 inside / outside); such pixels are counted."""
+    of the channel's few exact values, so the comparison is exact except where a pixel centre sits on an edge (fp32 vs fp64 inside
+    / outside); such pixels are counted.  Road channel (round 5: one 0.5 m cell of the pre-averaged raster per pixel): a centre
+    within an fp32 ulp of a cell border (1.5e-5 m at 200 m from the origin, two axes, 0.5 m cells) reads the neighbouring cell,
+    whose counts differ wherever a line or a lane edge is near: 1e-4 of the road channel's pixels, counted on their own."""
     n = 32
     torch, eng, ora, mb, sb = _setup(descs, n)
     ids = np.arange(n) % 8
     ora.reset(ids)
     eng.reset(ids)
     rng = np.random.default_rng(2)
-    tot = diff = 0
+    tot = diff = diff_road = 0
     seen = dict(line=0, navi=0, veh=0, past=0, old_frames=0, resets=0)
     # waiting traffic moved into view: a few vehicles around every ego (random offsets / headings), so that the traffic
     # channels have something to show from the first frame on
@@ -53,18 +55,19 @@ def test_topdown_parity_with_the_oracle(descs):
     eng.set_state(f32, i, ei)
 
     def compare():
-        nonlocal tot, diff
+        nonlocal tot, diff, diff_road
         g = eng.observe_topdown().cpu().numpy().astype(np.float64)
         o = ora.observe_topdown()
         assert g.shape == o.shape == (n, 84, 84, 5)
-        # road channel: the 2 x 2 area average of four samples, each line / route lane / nothing
+        # road channel: the mean over the 2 x 2 texels of the pre-averaged raster's cell, each line / route lane / nothing
         levels = {round((k * TD_LINE + j * TD_NAVI) / 4, 6) for k in range(5) for j in range(5 - k)}
         assert set(np.unique(np.round(g[..., 0], 6))) <= levels
         assert set(np.unique(g[..., 1])) <= {0.0, 1.0}
         assert set(np.unique(np.round(g[..., 2:], 6))) <= {0.0, round(TD_VEH, 6)}
         d = np.abs(g - o) > 1e-6
         tot += d.size
-        diff += int(d.sum())
+        diff += int(d[..., 1:].sum())
+        diff_road += int(d[..., 0].sum())
         seen["line"] += int((np.abs(o[..., 0] - TD_LINE) < 1e-9).sum()); seen["navi"] += int((np.abs(o[..., 0] - TD_NAVI) < 1e-9).sum())
         seen["edge"] = seen.get("edge", 0) + int(((o[..., 0] > 0) & (np.abs(o[..., 0] - TD_LINE) > 1e-9) & (np.abs(o[..., 0] - TD_NAVI) > 1e-9)).sum())
         seen["veh"] += int((o[..., 2] > 0).sum()); seen["past"] += int(o[..., 1].sum())
@@ -86,8 +89,8 @@ def test_topdown_parity_with_the_oracle(descs):
         ora.set_state(f32, i, ei)
         eng.set_state(f32, i, ei)
         compare()
-    print("top-down parity: pixels", tot, "edge pixels that differ", diff, seen)
-    assert diff <= 2e-5 * tot
+    print("top-down parity: pixels", tot, "edge pixels that differ: road channel", diff_road, "other channels", diff, seen)
+    assert diff <= 2e-5 * tot and diff_road <= 2.5e-4 * (tot / 5)
     assert seen["line"] > 20000 and seen["navi"] > 400000 and seen["edge"] > 100000 and seen["veh"] > 5000 and seen["past"] > 2000
     assert seen["old_frames"] > 100 and seen["resets"] > 5
     eng.close()
