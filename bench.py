@@ -386,6 +386,9 @@ ROWS = [
     ("c5_8x72", dict(workload="c5", agents=8, lasers=72, warmup=1000, steps=1024)),
     ("c5_40x72", dict(workload="c5", agents=40, lasers=72, warmup=1000, steps=2048)),
     ("c3_32768", dict(envs=32768, warmup=1500, steps=512)),
+    # the top-down image observation (TopDownPGDriveEnv: 84 x 84 x 5 floats per env and step instead of the 274-float row): pgd_step
+    # without the lidar + pgd_observe_topdown; a write-bound kernel of its own
+    ("c3_topdown", dict(topdown=True, lasers=0, warmup=600, steps=512)),
 ]
 
 XGMI_LINK_GBPS = 153.0  # per direction and link (MI355X_MICROARCH.md); 7 links per GPU, point to point
@@ -634,7 +637,11 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
             **({"open_loop": "pgd_step_n: %d steps of the action ring per call, one observation per call -- NOT the metric's closed "
                              "loop" % args.step_n} if args.step_n > 1 else {}),
             **({"observation": "top-down image 84 x 84 x 5 float32 (pgd_observe_topdown), %.1f MB written per step" % (
-                N * 84 * 84 * 5 * 4 / 1e6)} if args.topdown else {}),
+                N * 84 * 84 * 5 * 4 / 1e6),
+                # the image kernel's share of a step = step time - k_step's event time; its roofline is the HBM write rate
+                "topdown_us": (elapsed / timed * 1e3 - (((results.get("replicas") or {}).get("prof") or {}).get("k_step_ms") or 0.0)) * 1e3,
+                "topdown_write_frac_of_hbm_peak": (N * 84 * 84 * 5 * 4) / max(1e-9, (elapsed / timed - (((results.get("replicas") or {}).get("prof") or {}).get("k_step_ms") or 0.0) * 1e-3)) / 8e12}
+               if args.topdown else {}),
             "parallelism": par, "backend": (args.backend if world > 1 else "none"),
             "steady_state": "pre-roll %d steps, %d x %d timed steps (floors %d / %d%s)" % (
                 warm, n_win, timed, PREROLL_MIN, TIMED_MIN, ", off: --exact" if args.exact else ""),
@@ -821,7 +828,8 @@ def row_summary(name, line):
     r = line.get("roofline") or {}
     c = line["config"]
     keep = ("driving_traffic_mean", "envs_with_traffic_frac", "ego_speed_kmh_mean", "episode_step_mean", "active_agents_mean",
-            "present_agents_mean", "step_kernel", "obs_dim", "envs_per_gpu", "note")
+            "present_agents_mean", "step_kernel", "obs_dim", "envs_per_gpu", "note", "observation", "topdown_us",
+            "topdown_write_frac_of_hbm_peak")
     iss = r.get("issue") or None
     return {
         "row": name, "workload": c["workload"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],

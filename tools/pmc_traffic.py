@@ -27,7 +27,11 @@ def pmc(d, steady_only=False):
 
 
 fetch, write, cf, cw = pmc("fetch"), pmc("write"), pmc("cal_fetch"), pmc("cal_write")
-kname = [k for k in fetch if "k_step" in k][0]
+def most_dispatched(names, table):  # the instantiation the steps launch (pgd_reset launches another one once)
+    return sorted(names, key=lambda k: -len(table[k]))
+
+
+kname = most_dispatched([k for k in fetch if "k_step" in k], fetch)[0]
 steady = lambda v: v[len(v) * 3 // 4:]  # the last quarter of the dispatches: steady-state traffic (after the 1500-step pre-roll)
 fk = sum(steady(fetch[kname])) / len(steady(fetch[kname]))
 wk = sum(steady(write[kname])) / len(steady(write[kname]))
@@ -47,7 +51,7 @@ out = dict(envs=N, traffic=TRAFFIC, lasers=LASERS, actions=ACTIONS, traffic_mode
                 "(KB per dispatch, last quarter of the k_step dispatches = steady state). Corrections as MI355X_MICROARCH.md (HBM "
                 "section) prescribes, measured on the engine's own record pattern with profiles/r01_calib.hip.")
 # engines whose observation is a kernel of its own (multi-agent, many slots): the same figure for k_observe_env
-ko = [k for k in fetch if "k_observe_env" in k]
+ko = most_dispatched([k for k in fetch if "k_observe_env" in k and len(fetch[k]) >= 10], fetch)
 if ko and ko[0] in write:
     fo = sum(steady(fetch[ko[0]])) / len(steady(fetch[ko[0]]))
     wo = sum(steady(write[ko[0]])) / len(steady(write[ko[0]]))
