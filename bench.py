@@ -192,7 +192,7 @@ class Watchdog:
     rank arms a timer per transport pass; when it fires, rank 0 prints the line built from what was measured before the pass
     (`partial`, with `aborted`) and every rank leaves with os._exit(0) -- no clean-up of a communicator that no longer answers."""
     def __init__(self):
-        self.timer, self.partial, self.rank = None, None, 0
+        self.timer, self.partial, self.rank, self.label = None, None, 0, "the run"
 
     def arm(self, label, seconds):
         import threading
@@ -206,11 +206,36 @@ class Watchdog:
             self.timer.cancel()
             self.timer = None
 
+    def on_termination(self):
+        """A rank that dies hard (a memory fault under a transport that has never run between these devices) makes the launcher
+        send SIGTERM to the others.  Rank 0 then still prints what it has: Python's C-level handler writes the signal number to a
+        wake-up descriptor at once, even while the main thread sits inside a HIP / RCCL call, and a helper thread that reads the
+        descriptor prints the partial line and leaves."""
+        import signal
+        import threading
+        r, w = os.pipe()
+        os.set_blocking(w, False)
+        signal.signal(signal.SIGTERM, lambda *_: None)  # (installs the C-level handler that feeds the wake-up descriptor)
+        signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+
+        def watch():
+            os.read(r, 1)
+            sys.stderr.write("bench.py: rank %d: SIGTERM (another rank ended?) -- printing what was measured\n" % self.rank)
+            if self.rank == 0 and self.partial is not None:
+                line = dict(self.partial)
+                line["aborted"] = "terminated by the launcher (SIGTERM: another rank ended?) during " + self.label
+                print(json.dumps(line), flush=True)
+            os._exit(1)
+        t = threading.Thread(target=watch, daemon=True)
+        t.start()
+
     def _fire(self, label, seconds):
         sys.stderr.write("bench.py: rank %d: transport %s did not finish within %.0f s -- ending the run\n" % (self.rank, label, seconds))
         sys.stderr.flush()
         if self.rank == 0 and self.partial is not None:
-            print(json.dumps(self.partial), flush=True)
+            line = dict(self.partial)
+            line["aborted"] = "transport %s exceeded %.0f s" % (label, seconds)
+            print(json.dumps(line), flush=True)
         time.sleep(0.5)
         os._exit(0)
 
@@ -460,7 +485,9 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
     # N > 1: the replicas pass first (no collective inside its timed loop), then the passes with the per-step gather, one per
     # transport -- a transport that fails on hardware it has never run on leaves the line with the others and says why
     if args.transport == "all":
-        plan = [("root", False), ("root", True), ("peer", True), ("collective", False), ("peer", False), ("collective", True)]
+        # (the RCCL transports first: should the peer transport die hard between devices it has never met, the launcher's SIGTERM
+        # still finds a partial line with everything measured before it: Watchdog.on_termination)
+        plan = [("root", False), ("root", True), ("collective", False), ("collective", True), ("peer", True), ("peer", False)]
     else:
         plan = [(args.transport, bool(args.graph))]
 
@@ -746,11 +773,13 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
                 name = transport + ("+graph" if use_graph else "")
                 if watchdog is not None:
                     if rank == 0 and ("replicas" in results or any("elapsed" in r for r in by_transport.values())):
-                        watchdog.partial = make_line_ref[0](dict(by_transport), None, "transport %s exceeded %.0f s" % (name, args.transport_timeout))
+                        watchdog.partial = make_line_ref[0](dict(by_transport), None, None)
+                    watchdog.label = "transport " + name
                     watchdog.arm(name, args.transport_timeout)
                 by_transport[name] = run_transport(transport, use_graph)
                 if watchdog is not None:
                     watchdog.disarm()
+                    watchdog.label = "the work statistics after the transports"
                 # the ranks agree on what happened (an error on one rank is an error of the pass)
                 if world > 1:
                     bad = torch.tensor([1.0 if "error" in by_transport[name] else 0.0], dtype=torch.float64, device=dev)
@@ -863,6 +892,8 @@ def run_rank(args, rank, world, local_rank):
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
 
     WATCHDOG.rank = rank
+    if world > 1:
+        WATCHDOG.on_termination()
     out = measure(args, rank, world, local_rank)
     # the loaded rows, in the same invocation (N = 1, the default command only: any flag that changes the workload of the
     # headline -- other actions, env counts, groups ... -- is a single-workload run)

@@ -204,7 +204,7 @@ def test_bench_world_8_under_the_drivers_launcher():
     assert d["config"]["global_envs"] == 8 * 512 and d["config"]["envs_per_gpu"] == 512
     assert d["value_mode"].startswith("gather:") and d["value"] > 0 and d["value_replicas"] > 0
     t = d["value_by_transport"]
-    assert list(t) == ["root", "root+graph", "peer+graph", "collective", "peer", "collective+graph"]
+    assert list(t) == ["root", "root+graph", "collective", "collective+graph", "peer+graph", "peer"]  # (RCCL first, see bench.py)
     for name in ("root", "peer+graph", "collective", "peer"):  # the four that can run on this box
         e = t[name]
         assert e["gather_ok"] is True and e["gather_check"]["ranks_checked"] == 8 and e["gather_check"]["mismatched_ranks"] == [], (name, e)

@@ -139,3 +139,34 @@ def test_map_choice_short_and_long_form():
         resolve_map_choice(merge_config(DEFAULT_CONFIG, {"map_config": {"config": 7, "type": "block_sequence"}}))
     with pytest.raises(ValueError):
         resolve_map_choice(merge_config(DEFAULT_CONFIG, {"map": 2.5}))
+
+
+def test_bench_prints_what_it_has_when_the_launcher_terminates_it():
+    """N > 1: a rank that dies hard under a transport makes the launcher SIGTERM the others.  Rank 0 then still prints the line
+    measured so far -- even while its main thread sits in a blocking call (bench.py, Watchdog.on_termination: the C-level handler feeds
+    a wake-up descriptor, a helper thread prints and leaves)."""
+    import json
+    import os
+    import signal
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, time
+        sys.path.insert(0, %r)
+        import bench
+        bench.WATCHDOG.rank = 0
+        bench.WATCHDOG.partial = {"metric": "x", "value": 1.0, "value_by_transport": {"root": {"value": 1.0, "gather_ok": True}}}
+        bench.WATCHDOG.label = "transport peer+graph"
+        bench.WATCHDOG.on_termination()
+        print("armed", flush=True)
+        time.sleep(60)
+    """ % root)
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.stdout.readline().strip() == "armed"
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=30)
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["value"] == 1.0 and "peer+graph" in line["aborted"] and line["value_by_transport"]["root"]["gather_ok"] is True
+    assert p.returncode == 1
