@@ -12,10 +12,11 @@ maps (seeds 1000..1099, env e -> scenario e mod 100), actions uniform(-1,1) from
 on the device, auto-reset on done.  Weak scaling: each rank owns 4096 envs.
 
 Steady state.  The first ~1000 steps after a reset are cheaper than the rest (the trigger traffic is still parked), so a
-short run would report an early-episode number.  The bench therefore ALWAYS pre-rolls at least PREROLL_MIN steps before
-the timed region and times at least TIMED_MIN steps, whatever --warmup / --steps say; the JSON line carries the requested
-counts ("steps", "warmup") and the counts actually run ("steps_timed", "warmup_run"); `ms_per_step` and `value` refer to
-the timed steps.  --exact turns the floors off.
+short run would report an early-episode number.  The bench therefore ALWAYS pre-rolls and times at least the floors, whatever
+--warmup / --steps say: at N = 1 BASELINE.md section 4 to the letter -- 10 k warm-up steps, then three windows of 100 k timed steps,
+the median is the value (5.5 s of stepping) --, at N > 1 1500 + 3 x 4096 per pass (every transport gets its own windows); the JSON
+line carries the requested counts ("steps", "warmup") and the counts actually run ("steps_timed", "warmup_run"); `ms_per_step` and
+`value` refer to the timed steps of the median window.  --exact turns the floors off.
 
 Rows.  At N = 1 the same invocation also times the LOADED workloads next to the metric's (whose uniform(-1,1) stream leaves the
 ego crawling and most traffic parked): the scripted lane-keeping ego, respawn-mode traffic (every IDM vehicle drives), BASELINE
@@ -54,8 +55,10 @@ sys.path.insert(0, ROOT)
 HOST_THREADS = len(os.sched_getaffinity(0))  # read before any OpenMP runtime binds the main thread to one core (OMP_PROC_BIND)
 
 PROF_STRIDE = 64      # k_step launches per HIP-event group (an event pair costs a launch gap: 16 per group took 0.4 us off every step)
-PREROLL_MIN = 1500    # steps before the timed region (steady-state traffic)
-TIMED_MIN = 4096      # timed steps (>= 64 event groups of PROF_STRIDE launches)
+PREROLL_MIN = 1500    # steps before the timed region (steady-state traffic): N > 1 (every transport gets its own windows)
+TIMED_MIN = 4096      # timed steps per window (>= 64 event groups of PROF_STRIDE launches): N > 1
+PREROLL_HEAD = 10000  # N = 1, the metric's row: BASELINE.md section 4 to the letter -- "10 k warm-up, 100 k timed steps, median of 3"
+TIMED_HEAD = 100000   #   (three windows of 100 k steps: 5.3 s)
 
 
 # Algorithmic HBM bytes per env-step for this build's record layout:
@@ -477,8 +480,8 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
         acts[..., 1] = 1.0
     actions = torch.from_numpy(acts).to(dev)
 
-    warm = args.warmup if args.exact else max(args.warmup, PREROLL_MIN)
-    timed = args.steps if args.exact else max(args.steps, TIMED_MIN)
+    warm = args.warmup if args.exact else max(args.warmup, PREROLL_HEAD if world == 1 else PREROLL_MIN)
+    timed = args.steps if args.exact else max(args.steps, TIMED_HEAD if world == 1 else TIMED_MIN)
     n_win = args.windows
     want_replicas = world == 1 or args.mode in ("both", "replicas")
     want_gather = world > 1 and args.mode in ("both", "gather")
@@ -671,7 +674,8 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
                if args.topdown else {}),
             "parallelism": par, "backend": (args.backend if world > 1 else "none"),
             "steady_state": "pre-roll %d steps, %d x %d timed steps (floors %d / %d%s)" % (
-                warm, n_win, timed, PREROLL_MIN, TIMED_MIN, ", off: --exact" if args.exact else ""),
+                warm, n_win, timed, PREROLL_HEAD if world == 1 else PREROLL_MIN, TIMED_HEAD if world == 1 else TIMED_MIN,
+                ", off: --exact" if args.exact else ""),
         }
         out["roofline"] = make_roofline((results.get("replicas") or {}).get("prof"), (results.get("replicas") or {}).get("stride", 1),
                                         work, args, N, A, D)

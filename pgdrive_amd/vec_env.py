@@ -162,6 +162,8 @@ def merge_config(default, user, path=""):
                            "only: {}".format(path + k, sorted(out.keys())))
         if isinstance(out[k], dict) and isinstance(v, dict):
             out[k] = merge_config(out[k], v, path + k + ".")
+        elif isinstance(out[k], dict):  # a dict item overwritten by something that is not one (utils/config.py:143-152)
+            raise TypeError("Type error! The item {} has original type {} and updating type {}.".format(path + k, type(out[k]), type(v)))
         else:
             out[k] = v
     return out

@@ -250,6 +250,37 @@ def test_safe_env():
         env.close()
 
 
+def test_episode_release():
+    """tests/test_functionality/test_episode_release.py:5-25: SafePGDriveEnv over 100 maps with accidents and dense traffic, a few
+    steps, then two resets in a row, ten times over: every reset hands out a clean episode -- a valid first observation, episode
+    counters at zero, nothing of the previous episode's bodies left (no slot beyond what the new scenario's spawn table holds)."""
+    import warnings
+    from pgdrive_amd import _abi
+    from pgdrive_amd.env import SafePGDriveEnv
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # (density 0.5 exceeds the 16 traffic seats: the env says so)
+        env = SafePGDriveEnv({"environment_num": 100, "accident_prob": 0.8, "traffic_density": 0.5})
+    try:
+        env.reset()
+        for i in range(1, 10):
+            for _ in range(4):
+                o, r, d, info = env.step([1.0, 1.0])
+                assert env.observation_space.contains(o)
+            for _ in range(2):
+                o = env.reset()
+                assert env.observation_space.contains(o)
+                f, ii, ei = env.vec.engine.get_state()
+                assert ei[_abi.EI["EP_STEPS"], 0] == 0 and f[_abi.SF["EP_REWARD"], 0, 0] == 0.0 and f[_abi.SF["SPEED"], 0, 0] == 0.0
+                scen = int(ei[_abi.EI["SCEN"], 0])
+                sp = env.vec.scen_bank.spawns.reshape(len(env.vec.scen_bank.scenarios), -1)[scen]
+                filled = sp["lane"] >= 0
+                st = ii[_abi.SI["STATUS"], 0]
+                assert ((st != _abi.ST_EMPTY) == filled).all(), "a body of another episode survived the reset"
+                assert st[0] == _abi.ST_ACTIVE and not (ii[_abi.SI["VFLAGS"], 0, 0] & (_abi.F_CRASH_VEHICLE | _abi.F_CRASH_OBJECT))
+    finally:
+        env.close()
+
+
 def test_safe_env_cost_to_reward_and_object_contact():
     """cost_to_reward folds the costs into the penalties (safe_pgdrive_env.py:41-47); driving into a cone line gives
     crash_object exactly once per cone."""

@@ -170,3 +170,22 @@ def test_bench_prints_what_it_has_when_the_launcher_terminates_it():
     line = json.loads(out.strip().splitlines()[-1])
     assert line["value"] == 1.0 and "peer+graph" in line["aborted"] and line["value_by_transport"]["root"]["gather_ok"] is True
     assert p.returncode == 1
+
+
+def test_nested_config_update_rules():
+    """tests/test_functionality/test_nested_config.py:4-49 on the env surface's merge_config (a user config is merged like
+    Config.update(..., allow_add_new_key=False), base_env.py:100-107): nested values update in place, an unknown key at any depth is a
+    KeyError, a dict item replaced by a non-dict a TypeError, siblings keep their values."""
+    import pytest
+    from pgdrive_amd.vec_env import merge_config
+    base = {"aa": {"bb": {"cc": 100}}, "x": 1}
+    c = merge_config(base, {"aa": {"bb": {"cc": 101}}})
+    assert c["aa"]["bb"]["cc"] == 101 and c["x"] == 1 and base["aa"]["bb"]["cc"] == 100
+    with pytest.raises(TypeError):
+        merge_config(base, {"aa": {"bb": 102}})
+    with pytest.raises(KeyError):
+        merge_config(base, {"aa": {"bbd": 102}})
+    with pytest.raises(KeyError):
+        merge_config(base, {"aa": {"bb": {"dd": 101}}})
+    c = merge_config({"aa": {"bb": {"cc": 100, "dd": 1}}}, {"aa": {"bb": {"dd": 101}}})
+    assert c["aa"]["bb"] == {"cc": 100, "dd": 101}

@@ -9,8 +9,9 @@ O=$R/gpurun_out/$TAG; mkdir -p $O
 TR=16; [ "$WL" = "c5" ] && TR=0; prev=""; for a in "$@"; do case "$prev" in --traffic) TR=$a;; esac; prev=$a; done
 ARGS="--no-rows --no-cpu-baseline --workload $WL --envs $N --actions $ACT --traffic-mode $MODE --agents $AG --lasers $NL $@"
 [ -x /tmp/pgd_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/profiles/r01_calib.hip -o /tmp/pgd_calib 2>/dev/null
-timeout 600 python $R/bench.py $ARGS > $O/bench.json 2> $O/bench.err < /dev/null
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py $ARGS > $O/bench_under_rocprof.json 2> $O/stats.err < /dev/null
+# (1500 + 3 x 4096 steps: the default N = 1 run times 10 k + 3 x 100 k, too long a trace for the kernel statistics)
+timeout 600 python $R/bench.py $ARGS --exact --warmup 1500 --steps 4096 > $O/bench.json 2> $O/bench.err < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py $ARGS --exact --warmup 1500 --steps 4096 > $O/bench_under_rocprof.json 2> $O/stats.err < /dev/null
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python $R/bench.py $ARGS --exact --steps 200 --warmup 1500 --windows 1 > /dev/null 2> $O/fetch.err < /dev/null
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python $R/bench.py $ARGS --exact --steps 200 --warmup 1500 --windows 1 > /dev/null 2> $O/write.err < /dev/null
 timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_fetch -- /tmp/pgd_calib > $O/calib.txt 2> $O/cal.err < /dev/null
