@@ -900,6 +900,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       near_any = near_any || near_a;
       step_sync();
       PHASE_MARK(21);  // obs: compaction
+      XMARK(21);
       observe_agent<OBJ, STD, false, true, true>(d, mvo, d.spawns[(size_t)scen_now * d.sstride + a], ag, OL,
                                                  obs + (size_t)e * d.ostride + (size_t)a * d.D, lane, WAVE, nullptr, nullptr, &pre, lidar_minb(S));
       step_sync();

@@ -379,6 +379,7 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
     t2[1] = (in_toll && ag.toll_time > (float)d.cfg.min_pass_steps) ? 1.0f : 0.0f;
   }
   PHASE_MARK(22);  // obs: state + navi block
+  XMARK(22);
   if (NL <= 0) return;
   // get_surrounding_vehicles_info (lidar.py:55-77): rank by centre distance (stable), 4 floats per neighbour; the last
   // threads take this part so that it overlaps the state block of the first ones
@@ -431,6 +432,7 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
     }
   }
   PHASE_MARK(23);  // obs: neighbours
+  XMARK(23);
   // lidar (distance_detector.py:65-94, cutils.pyx:60-142): beam i at theta + i*2pi/N, nearest hit fraction
   // every lane of the row takes part in every round (the ballot below needs the body lanes), beams past the fan are not stored
   const int lane64 = tid & (WAVE - 1);
