@@ -141,7 +141,9 @@ class MultiAgentRoundaboutVecEnv:
         return self.engine.reset(ids)
 
     def step(self, actions):
-        """actions [N, A, 2] cuda float32 (rows of slots without an active agent are ignored)."""
+        """actions [N, A, 2] cuda float32 (rows of slots without an active agent are ignored).  Returns the engine's own buffers
+        (obs [N, A, D], reward, done, flags), not copies: the row of a seat that is not due reads zero and is written ONCE per
+        buffer (Engine.step) -- clone before editing rows in place, or create the env with PGD_NO_ROWZ=1 in the environment."""
         return self.engine.step(actions.contiguous())
 
     def slot_table(self):
