@@ -2,6 +2,13 @@
 // Part of the single translation unit pgd_engine.hip (included there, in this order, after pgd_device.h).
 #ifndef PGD_OBSERVE_H
 #define PGD_OBSERVE_H
+#ifdef PGD_NT_OBS
+#define OBS_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define OBS_ST(p, v) (*(p) = (v))
+#endif
+typedef float obs_f2 __attribute__((ext_vector_type(2)));
+typedef float obs_f4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------------------
 // observation: LidarStateObservation.observe (obs/state_obs.py:132-170) for one (env, agent)
@@ -250,7 +257,7 @@ DEV void state_block(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const A
       v = comp == 0 ? out[0] : comp == 1 ? out[1] : comp == 2 ? out[2] : comp == 3 ? out[3] : out[4];
       col = toll ? -1 : o_navi + (q - 8);
     }
-    if (col >= 0) row[col] = v;
+    if (col >= 0) OBS_ST(row + col, v);
   }
   // SideDetector / LaneLineDetector fans (distance_detector.py:137-152): beam i at theta + i*2pi/n + 90 deg, cast through
   // the map grid against the line boxes of the wanted kinds
@@ -262,7 +269,7 @@ DEV void state_block(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const A
                                 : ((1u << PGD_BOX_WHITE) | (1u << PGD_BOX_YELLOW) | (1u << PGD_BOX_BROKEN));
     float sn, cs;
     sincosf((float)i * (2.0f * PGD_PI / (float)n) + 0.5f * PGD_PI + ag.th, &sn, &cs);
-    row[side ? i : o_ego + 6 + i] = ray_grid(mv, px, py, dist * cs, dist * sn, kinds);
+    OBS_ST(row + (side ? i : o_ego + 6 + i), ray_grid(mv, px, py, dist * cs, dist * sn, kinds));
   }
 }
 
@@ -456,7 +463,7 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
       if (on && off < bcnt) best = fminf(best, shape_ray<OBJ>(box, px, py, dx, dy));
     }
     if (!STD) best = lidar_noise(d, ag.env, ag.slot, ag.tick, i, best);
-    if (on) row[o_oth + per_other * NO + i] = best;
+    if (on) OBS_ST(row + o_oth + per_other * NO + i, best);
   };
   // With several bodies in range a round of 64 beams runs the slab test of every body whose window meets its 96-degree sector for
   // ALL 64 beams, although a window is 10 - 20 beams wide: three quarters of those tests are masked off.  A row that one wave
@@ -523,7 +530,7 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
         if (i < NL) {
           float best = __uint_as_float(minb[i]);
           if (!STD) best = lidar_noise(d, ag.env, ag.slot, ag.tick, i, best);
-          row[o_oth + per_other * NO + i] = best;
+          OBS_ST(row + o_oth + per_other * NO + i, best);
         }
       }
       PHASE_MARK(24);  // obs: lidar
@@ -934,16 +941,16 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     if (pairs_ok && NL >= 2 * WAVE) {
       for (int qa = 0; qa < g1 - g0; ++qa) {
         const int ga = wList[g0 + qa];
-        float2* dst = reinterpret_cast<float2*>(obs + (size_t)e * d.ostride + (size_t)ga * D + o_lid);
-        const float2* src = reinterpret_cast<const float2*>(s_minb + qa * NL);
-        for (int i = lane; i < (NL >> 1); i += WAVE) dst[i] = src[i];
+        obs_f2* dst = reinterpret_cast<obs_f2*>(obs + (size_t)e * d.ostride + (size_t)ga * D + o_lid);
+        const obs_f2* src = reinterpret_cast<const obs_f2*>(s_minb + qa * NL);
+        for (int i = lane; i < (NL >> 1); i += WAVE) OBS_ST(dst + i, src[i]);
       }
     } else if (pairs_ok) {
       const int half = NL >> 1;
       const float inv_half = 1.0f / (float)half;
       for (int k = lane; k < (g1 - g0) * half; k += WAVE) {
         const int qa = div_small(k, inv_half), i = k - qa * half, ga = wList[g0 + qa];
-        reinterpret_cast<float2*>(obs + (size_t)e * d.ostride + (size_t)ga * D + o_lid)[i] = reinterpret_cast<const float2*>(s_minb)[k];
+        OBS_ST(reinterpret_cast<obs_f2*>(obs + (size_t)e * d.ostride + (size_t)ga * D + o_lid) + i, reinterpret_cast<const obs_f2*>(s_minb)[k]);
       }
     } else
     if (NL >= 2 * WAVE) {  // long fans observer by observer: no division per element (240 beams: 116 -> 123 M env-steps/s at 8 agents)

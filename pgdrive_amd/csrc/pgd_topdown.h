@@ -289,8 +289,8 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
         float* dst = out + (size_t)p0 * C;
         if (VEC) {  // 64 x C floats = at most 128 float4 (C <= 8): two predicated stores, no loop
           const int n4 = nf >> 2;
-          if (lane < n4) reinterpret_cast<float4*>(dst)[lane] = reinterpret_cast<const float4*>(so)[lane];
-          if (lane + 64 < n4) reinterpret_cast<float4*>(dst)[lane + 64] = reinterpret_cast<const float4*>(so)[lane + 64];
+          if (lane < n4) OBS_ST(reinterpret_cast<obs_f4*>(dst) + lane, reinterpret_cast<const obs_f4*>(so)[lane]);
+          if (lane + 64 < n4) OBS_ST(reinterpret_cast<obs_f4*>(dst) + lane + 64, reinterpret_cast<const obs_f4*>(so)[lane + 64]);
         } else {
           for (int k = lane; k < nf; k += 64) dst[k] = so[k];
         }
