@@ -14,6 +14,15 @@
 #define DEV __device__ __forceinline__
 #define DEV_HOST __host__ __device__ inline
 
+// One 16-byte piece of a vehicle record in memory (struct Veh below = eight pieces).  A BLOCK of n records -- the V slots of an env,
+// the slots of a scenario's reset image, a scenario's respawn records -- is stored as eight PLANES of n pieces: piece k of record s
+// lies (k * n + s) * 16 bytes behind the block's start (rec_block / load_rec / store_rec in pgd_vehicle.h).  The lanes of a wave hold
+// one vehicle each and read their records piece by piece: with a line per vehicle every one of those eight instructions touched as
+// many cache lines as the env has vehicles (17 ... 40), plane by plane it touches n / 8 of them.  Same bytes, same DRAM pages;
+// `tools/rec_layout.hip`: the 40 records of 4096 envs read and written back in 9.6 instead of 13.3 us, 17 records read 0.4 us sooner.
+// (An opaque type: nothing indexes a record as an array element any more.)
+struct RecPiece { uint4 q; };
+
 // ---------------------------------------------------------------------------------------------------------------------
 // device-side view of the engine
 // ---------------------------------------------------------------------------------------------------------------------
@@ -38,14 +47,14 @@ struct PgdDev {
   const pgd_spawn* spawns;
   const float2* spawn_hv;     // [n_scen * sstride] (cos, sin) of each spawn heading (k_spawn_hv at upload)
   int n_scen;
-  struct Veh* rec;  // [N*V] one 128-byte record per vehicle slot (device layout; the ABI blobs are field-major)
+  RecPiece* rec;  // [N] blocks of V records of 128 bytes, piece planes (above; device layout, the ABI blobs are field-major)
   int32_t* ei;         // [N][PGD_NEI]
   pgd_map* env_map;    // [N] copy of the map header of the env's running scenario (rewritten on reset): the map view of a
                        // step needs no env -> scenario -> header chain
   int use_imask;       // 0: every slot is read from the env's own record (small N: one dependent load level less)
   unsigned long long* imask;  // [N] bit s: slot s of the env still equals its scenario's reset image (never stored since)
-  const struct Veh* reset_img;  // [n_scen][V] every slot right after a reset of its scenario (k_reset_image)
-  const struct Veh* respawn_img;  // [n_scen][sstride - V] multi-agent: an agent right after it was spawned from respawn record V + k
+  const RecPiece* reset_img;  // [n_scen] blocks of V records: every slot right after a reset of its scenario (k_reset_image)
+  const RecPiece* respawn_img;  // [n_scen] blocks of sstride - V records (multi-agent): an agent right after it was spawned from respawn record V + k
   const float2* beam;  // [num_lasers] (cos, sin) of the beam angle i * 2 pi / num_lasers in the vehicle frame
   // output addressing of one launch: the observation row of (env e, agent a) starts at obs + e * ostride + a * D.
   // pgd_step: ostride = A * D (dense [N, A, D]).  pgd_step_packed: ostride = the caller's row stride and `prow` = the same
@@ -73,8 +82,9 @@ struct PgdDev {
 };
 
 // Device-side vehicle record = the per-lane register image of a vehicle (device-private; pgd_get_state / pgd_set_state
-// convert to the ABI's field-major blobs).  128 B = one cache line: a lane loads / stores its vehicle with 8 dwordx4
-// transactions, full-line writes, and no field shuffling -- the struct in registers IS the record.
+// convert to the ABI's field-major blobs).  128 B = eight 16-byte pieces: a lane loads / stores its vehicle with 8 dwordx4
+// transactions and no field shuffling -- the struct in registers IS the record; in memory its pieces lie in the planes of its
+// block (RecPiece above).
 // Besides the ABI fields of include/pgd_state_layout.h (SF_THROTTLE is not stored: the last applied throttle always equals
 // the newer entry of the action deque, SF_ACT1T; base_vehicle.py:343-349 sets both from the same action) the line carries
 // state DERIVED from them, kept from step to step instead of being recomputed through dependent table reads every step:

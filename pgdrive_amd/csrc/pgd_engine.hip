@@ -230,7 +230,7 @@ struct PgdCold {
   const pgd_map* scen_map;
   uint8_t* bev_fill;
   const float2* spawn_hv;
-  const struct Veh* respawn_img;
+  const RecPiece* respawn_img;
   int n_scen;
   uint32_t seed;
   int env_base;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   const bool packed = !ONE_ENV && d.pack_obs != 0;  // throughput mode: whole envs side by side in the wave, one vehicle per lane
   if ((ONE_ENV || (packed && valid)) && d.use_imask) im = d.imask[e];
   if (one_env || valid) scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
-  if (valid) load_rec(((ONE_ENV || packed) && ((im >> s) & 1ull)) ? d.reset_img + (size_t)scen * V + s : d.rec + (size_t)e * V + s, r);
+  if (valid) load_rec(((ONE_ENV || packed) && ((im >> s) & 1ull)) ? rec_block(d.reset_img, (size_t)scen, V) : rec_block(d.rec, (size_t)e, V), V, s, r);
   // the agent's action: its address follows from the block index as well -- read here, used by the policy phase (read there it cost
   // every wave a memory latency of its own right after the snapshot: 1.5 k cycles of the metric's row).  BEHIND the record's reads:
   // issued ahead of the mask / scenario / record chain it delays that chain (17.76 -> 17.99 us), and so does a speculative read
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (fresh) {  // the new agent's record, first localisation included, from the respawn image (k_respawn_image)
       sp = d.spawns + (size_t)scen * d.sstride + fresh_idx;
       if (REGSP) spawn_head_load(sp, sl);
-      load_rec(cold.respawn_img + (size_t)scen * (d.sstride - V) + (fresh_idx - V), r);
+      load_rec(rec_block(cold.respawn_img, (size_t)scen, d.sstride - V), d.sstride - V, fresh_idx - V, r);
       r.agent_id = (float)fresh_id;
     }
     PHASE_MARK(27);  // marl: respawn
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     if (REGSP) spawn_head_load(sp, sl);
     // the slot right after a reset is a function of the scenario alone (spawn pose, first localisation, side distances,
     // agent id): read from the image k_reset_image built at upload instead of localising every vehicle again
-    load_rec(d.reset_img + (size_t)scen * V + s, r);
+    load_rec(rec_block(d.reset_img, (size_t)scen, V), V, s, r);
     const unsigned long long am = __ballot(leader && s < A && r.status == ST_ACTIVE);
     if (marl && s < A && r.status == ST_ACTIVE) my_fl |= PGD_F_NEW;
     if (s == 0 && d.cfg.resample_scenario)  // the env's header copy follows the scenario (any number of sub-lanes)
@@ -1050,19 +1050,19 @@ DEV unsigned long long reset_slot(const PgdDev& d, const LaneMap& lm, int scen, 
 }
 
 // the reset image: one record per (scenario, slot), read by the auto-reset of k_step; same lane mapping, unit = scenario
-__global__ __launch_bounds__(WAVE) void k_reset_image(PgdDev d, VehRec* __restrict__ img) {
+__global__ __launch_bounds__(WAVE) void k_reset_image(PgdDev d, RecPiece* __restrict__ img) {
   const LaneMap lm = lane_map(d, blockIdx.x, d.n_scen);
   if (!lm.valid) return;
   Veh r;
   reset_slot(d, lm, lm.e, r);
-  if (lm.sub == 0) store_rec(img + (size_t)lm.e * d.V + lm.s, r);
+  if (lm.sub == 0) store_rec(rec_block(img, (size_t)lm.e, d.V), d.V, lm.s, r);
 }
 
 // multi-agent: the record of an agent right after it was (re)spawned from respawn record V + k of a scenario (spawn state, route
 // context, first localisation, side distances, line / sidewalk flags) is a function of the scenario alone: built once per
 // upload, one thread per record; the respawn of k_step copies it and sets the agent id (was: a second after_step + line test
 // inside the step whenever any agent of the env entered, 7 k cycles of the wave)
-__global__ __launch_bounds__(256) void k_respawn_image(PgdDev d, VehRec* __restrict__ img) {
+__global__ __launch_bounds__(256) void k_respawn_image(PgdDev d, RecPiece* __restrict__ img) {
   const int n_extra = d.sstride - d.V;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= d.n_scen * n_extra) return;
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(256) void k_respawn_image(PgdDev d, VehRec* __restr
     route_refresh(mv, *sp, r);
     after_step_vehicle(d.cfg, mv, g, *sp, *sp, r, true, true, ctx);
   }
-  store_rec(img + k, r);
+  store_rec(rec_block(img, (size_t)scen, n_extra), n_extra, k % n_extra, r);
 }
 
 // reset of selected envs; same lane mapping as k_step, unit = position in the id list
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(256) void k_derive(PgdDev d) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= d.NV) return;
   Veh r;
-  load_rec(d.rec + k, r);
+  load_rec(rec_block(d.rec, (size_t)(k / d.V), d.V), d.V, k % d.V, r);
   if (r.hx == 0.0f && r.hy == 0.0f) sincosf(r.th, &r.hy, &r.hx);  // a checkpoint carries the heading vector (SF_HX / SF_HY)
   r.lon = 0.0f;
   r.road_cur = 0; r.road_next = 0; r.blk = 0; r.cur_first = 0; r.next_first = 0; r.cur_n = 0; r.next_n = 0;
@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_derive(PgdDev d) {
     }
     if (r.ck0 < PGD_MAX_CKPT && r.ck1 < PGD_MAX_CKPT) route_refresh(mv, sp, r);
   }
-  store_rec(d.rec + k, r);
+  store_rec(rec_block(d.rec, (size_t)(k / d.V), d.V), d.V, k % d.V, r);
 }
 
 // engine.after_step on the current state (used after pgd_set_state)
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(BLOCK == WAVE ? WAVE * OBS_RPB : BLOCK) void k_obse
   ObsLds& L = Ls[WROW ? threadIdx.x / WAVE : 0];
   const int e = rowi / A + d.unit_off * d.epw, a = rowi % A;
   const int tid = WROW ? (int)(threadIdx.x % WAVE) : (int)threadIdx.x;
-  const VehRec* recs = d.rec + (size_t)e * V;  // the env's vehicle records
+  const RecPiece* recs = rec_block(d.rec, (size_t)e, V);  // the env's vehicle records
   float* row = obs + (size_t)e * d.ostride + (size_t)a * D;
   PHASE_INIT();
   // A row lives a few microseconds and almost all of that is load latency, so the reads go out in three batches instead of
@@ -1177,10 +1177,10 @@ __global__ __launch_bounds__(BLOCK == WAVE ? WAVE * OBS_RPB : BLOCK) void k_obse
   // of body `tid`'s record (pose, speed, status, spawn index, agent id), the step flags, the env's scenario and step count.
   const int ob = tid < V ? tid : 0;
   Veh me;
-  load_rec(recs + a, me);
+  load_rec(recs, V, a, me);
   uint4 bw[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) bw[k] = reinterpret_cast<const uint4*>(recs + ob)[k];
+  for (int k = 0; k < 4; ++k) bw[k] = recs[k * V + ob].q;
   const uint32_t fa = flags ? flags[(size_t)e * A + a] : 0u, fo = flags ? flags[(size_t)e * A + (tid < A ? tid : 0)] : 0u;
   const int scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
   const uint32_t tick = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
@@ -1315,8 +1315,8 @@ struct pgd_engine {
   float2* spawn_hv;
   pgd_map* scen_map;  // per scenario: copy of its map header (saves one dependent load per block)
   float2* beam;       // lidar beam directions in the vehicle frame
-  VehRec* reset_img;  // [n_scen][V], rebuilt after every map / scenario upload
-  VehRec* respawn_img;  // [n_scen][sstride - V] (multi-agent), rebuilt with it
+  RecPiece* reset_img;  // [n_scen] blocks of V records, rebuilt after every map / scenario upload
+  RecPiece* respawn_img;  // [n_scen] blocks of sstride - V records (multi-agent), rebuilt with it
   bool img_dirty;
   std::vector<pgd_map>* h_maps;
   std::vector<pgd_scenario>* h_scen;
@@ -1999,18 +1999,28 @@ int pgd_state_dims(pgd_handle h, int* nf, int* ni, int* nei) {
 
 // ABI order is field-major ([field][env*V + slot], [field][env]); the device keeps one 128 B record per vehicle and one
 // PGD_NEI-int row per env — converted on the host
+// host copies of the record array: record k = (env k / V, slot k % V) out of / into the piece planes of its env's block (RecPiece)
+static void record_from_planes(const RecPiece* raw, int V, size_t k, VehRec& t) {
+  const RecPiece* blk = raw + (k / (size_t)V) * (size_t)(8 * V);
+  for (int p = 0; p < 8; ++p) memcpy(reinterpret_cast<char*>(&t) + 16 * p, blk + (size_t)p * V + k % (size_t)V, 16);
+}
+static void record_to_planes(RecPiece* raw, int V, size_t k, const VehRec& t) {
+  RecPiece* blk = raw + (k / (size_t)V) * (size_t)(8 * V);
+  for (int p = 0; p < 8; ++p) memcpy(blk + (size_t)p * V + k % (size_t)V, reinterpret_cast<const char*>(&t) + 16 * p, 16);
+}
 extern "C" int pgd_get_state(pgd_handle h, float* f, int32_t* i, int32_t* ei) {
   if (!h || !f || !i || !ei) return PGD_ERR_ARG;
   const size_t nv = (size_t)h->d.NV;
   const int N = h->d.N;
   HIPCHK(hipSetDevice(h->device));
-  std::vector<VehRec> tr(nv);
+  std::vector<RecPiece> tr(nv * 8);
   std::vector<int32_t> te((size_t)N * PGD_NEI);
   HIPCHK(hipMemcpyAsync(tr.data(), h->d.rec, sizeof(VehRec) * nv, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(te.data(), h->d.ei, sizeof(int32_t) * te.size(), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   for (size_t k = 0; k < nv; ++k) {  // device record -> ABI fields (struct Veh in pgd_device.h)
-    const VehRec& t = tr[k];
+    VehRec t;
+    record_from_planes(tr.data(), h->d.V, k, t);
     const float fv[PGD_NF] = {t.x, t.y, t.th, t.v, t.steer, t.a1t /* SF_THROTTLE */, t.lastx, t.lasty, t.lasthx, t.lasthy, t.a0s, t.a0t,
                               t.a1s, t.a1t, t.php, t.phi, t.plp, t.pli, t.target, t.energy, t.dl, t.dr, t.eprew, t.agent_id, t.hx, t.hy};
     const int32_t iv[PGD_NI] = {(int32_t)t.status, (int32_t)t.lane, (int32_t)t.ck0, (int32_t)t.ck1, (int32_t)t.rlane, (int32_t)t.timer,
@@ -2026,10 +2036,10 @@ extern "C" int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, con
   if (!h || !f || !i || !ei) return PGD_ERR_ARG;
   const size_t nv = (size_t)h->d.NV;
   const int N = h->d.N;
-  std::vector<VehRec> tr(nv);
+  std::vector<RecPiece> tr(nv * 8);
   std::vector<int32_t> te((size_t)N * PGD_NEI);
   for (size_t k = 0; k < nv; ++k) {  // ABI fields -> device record; the derived part is rebuilt on the device (k_derive)
-    VehRec& t = tr[k];
+    VehRec t;
     memset(&t, 0, sizeof(t));
     auto F = [&](int q) { return f[(size_t)q * nv + k]; };
     auto I = [&](int q) { return i[(size_t)q * nv + k]; };
@@ -2052,6 +2062,7 @@ extern "C" int pgd_set_state(pgd_handle h, const float* f, const int32_t* i, con
       return PGD_ERR_ARG;
     t.lane = (uint32_t)lane; t.spawn = (uint32_t)spawn; t.rlane = rlane; t.timer = (uint32_t)std::min(timer, 0xffff);
     t.vflags = (uint32_t)vflags; t.status = (uint32_t)status; t.ck0 = (uint32_t)ck0; t.ck1 = (uint32_t)ck1;
+    record_to_planes(tr.data(), h->d.V, k, t);
   }
   for (int e = 0; e < N; ++e)
     for (int q = 0; q < PGD_NEI; ++q) te[(size_t)e * PGD_NEI + q] = q == EI_NEAR ? 1 : ei[(size_t)q * N + e];

@@ -7,6 +7,12 @@
 #else
 #define OBS_ST(p, v) (*(p) = (v))
 #endif
+// the fans of the multi-agent rows (written once per step from LDS, read by nobody on this chip's L2 again): streaming stores
+#ifdef PGD_PLAIN_FAN
+#define OBS_ST_FAN(p, v) (*(p) = (v))
+#else
+#define OBS_ST_FAN(p, v) __builtin_nontemporal_store((v), (p))
+#endif
 typedef float obs_f2 __attribute__((ext_vector_type(2)));
 typedef float obs_f4 __attribute__((ext_vector_type(4)));
 
@@ -309,9 +315,10 @@ DEV void state_block_one(const PgdDev& d, const MV& mv, const pgd_spawn& sp, con
 
 // the view of slot `o` of the env as an observed vehicle (the state vector a neighbour contributes to
 // LidarStateObservationMARound); its speed comes from the observer's snapshot
-DEV AgentView view_of_slot(const PgdDev& d, const MapView& mv, const VehRec* recs, const pgd_spawn* spb, int o, float spd_kmh,
+DEV AgentView view_of_slot(const PgdDev& d, const MapView& mv, const RecPiece* recs, const pgd_spawn* spb, int o, float spd_kmh,
                            int env, uint32_t tick) {
-  const VehRec& rc = recs[o];
+  Veh rc;
+  load_rec(recs, d.V, o, rc);
   AgentView ag;
   ag.x = rc.x; ag.y = rc.y; ag.th = rc.th;
   ag.hx = rc.hx; ag.hy = rc.hy;
@@ -358,7 +365,7 @@ DEV void row_sync() {
 // WAVE_ROW: see row_sync
 template <bool OBJ, bool STD = false, bool OTH = false, bool STATE = true, bool WAVE_ROW = false, class MV>
 DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const AgentView& ag, ObsLds& L,
-                       float* __restrict__ row, int tid, int nt, const VehRec* recs = nullptr, const pgd_spawn* spb = nullptr,
+                       float* __restrict__ row, int tid, int nt, const RecPiece* recs = nullptr, const pgd_spawn* spb = nullptr,
                        const ObsPre* pre = nullptr, unsigned* minb = nullptr) {
   const float px = ag.x, py = ag.y, hx = ag.hx, hy = ag.hy;
   const float R = d.cfg.lidar_dist;
@@ -411,7 +418,7 @@ DEV void observe_agent(const PgdDev& d, const MV& mv, const pgd_spawn& sp, const
         for (int q = tid; q < o_oth; q += nt) dst[q] = 0.0f;
       } else {
         const AgentView oa = view_of_slot(d, mv, recs, spb, o, L.rank_spd[r], ag.env, ag.tick);
-        state_block<STD>(d, mv, spb[recs[o].spawn], oa, dst, tid, nt);
+        state_block<STD>(d, mv, spb[rec_spawn(recs, d.V, o)], oa, dst, tid, nt);
       }
     }
   } else
@@ -618,7 +625,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   float (&pDist_all)[NW][WAVE] = M.pDist; int (&pPref_all)[NW][WAVE + 1] = M.pPref; int (&pI0_all)[NW][WAVE] = M.pI0;
   const int V = d.V, A = d.A, D = d.D, NL = d.cfg.num_lasers, NO = d.cfg.num_others;
   const int tid = threadIdx.x, wv = tid / WAVE, lane = tid % WAVE;
-  const VehRec* recs = d.rec + (size_t)e * V;
+  const RecPiece* recs = rec_block(d.rec, (size_t)e, V);
   // ---- loads whose addresses follow from the block index: body `lane` (first half of its record), the agent of this lane's
   // state group (whole record), step flags, scenario, step count, the env's map header
   const int LPA = WAVE * NW / A;  // lanes per agent in the state phase (A <= WAVE)
@@ -639,9 +646,8 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
     f_me = s_on ? in_wave->fl : 0u;
     scen = in_wave->scen; tick = in_wave->tick; mv = *in_wave->mv;
   } else {
-    if (STATE) load_rec(recs + (s_on ? sa : 0), me);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) reinterpret_cast<uint4*>(&body)[k] = reinterpret_cast<const uint4*>(recs + (tid < V ? tid : 0))[k];
+    if (STATE) load_rec(recs, V, s_on ? sa : 0, me);
+    load_rec_head(recs, V, tid < V ? tid : 0, body);
     f_me = (STATE && flags && s_on) ? flags[(size_t)e * A + sa] : 0u;
     f_body = (flags && tid < A) ? flags[(size_t)e * A + tid] : 0u;
     scen = d.ei[(size_t)(e) * PGD_NEI + EI_SCEN];
@@ -943,14 +949,14 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
         const int ga = wList[g0 + qa];
         obs_f2* dst = reinterpret_cast<obs_f2*>(obs + (size_t)e * d.ostride + (size_t)ga * D + o_lid);
         const obs_f2* src = reinterpret_cast<const obs_f2*>(s_minb + qa * NL);
-        for (int i = lane; i < (NL >> 1); i += WAVE) OBS_ST(dst + i, src[i]);
+        for (int i = lane; i < (NL >> 1); i += WAVE) OBS_ST_FAN(dst + i, src[i]);
       }
     } else if (pairs_ok) {
       const int half = NL >> 1;
       const float inv_half = 1.0f / (float)half;
       for (int k = lane; k < (g1 - g0) * half; k += WAVE) {
         const int qa = div_small(k, inv_half), i = k - qa * half, ga = wList[g0 + qa];
-        OBS_ST(reinterpret_cast<obs_f2*>(obs + (size_t)e * d.ostride + (size_t)ga * D + o_lid) + i, reinterpret_cast<const obs_f2*>(s_minb)[k]);
+        OBS_ST_FAN(reinterpret_cast<obs_f2*>(obs + (size_t)e * d.ostride + (size_t)ga * D + o_lid) + i, reinterpret_cast<const obs_f2*>(s_minb)[k]);
       }
     } else
     if (NL >= 2 * WAVE) {  // long fans observer by observer: no division per element (240 beams: 116 -> 123 M env-steps/s at 8 agents)
@@ -977,7 +983,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
           for (int k = st; k < o_oth; k += LPA) dst[k] = 0.0f;
         } else {
           const AgentView oa = view_of_slot(d, mv, recs, spb, o, nbSpd[sa * NO + rk], e, tick);
-          state_block<false>(d, mv, spb[recs[o].spawn], oa, dst, st, LPA);
+          state_block<false>(d, mv, spb[rec_spawn(recs, d.V, o)], oa, dst, st, LPA);
         }
       }
   }

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
   float4* s_pose = s_dyn4;                                  // [f * V + s]
   float4* s_vc = s_dyn4 + (size_t)t.n_frames * V;           // [f * V + k]: (forward, right) of the box centre, (forward, right) of its long axis
   float2* s_vh = reinterpret_cast<float2*>(s_vc + 4 * V);   // [f * V + k]: half extents
-  const VehRec* recs = d.rec + (size_t)e * V;
+  const RecPiece* recs = rec_block(d.rec, (size_t)e, V);
   const int scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
   const pgd_spawn* spb = d.spawns + (size_t)scen * d.sstride;
   const MapView mv = map_view_of(d, d.scen_map + scen);
@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
     const int f = k / V, s = k - f * V;
     float4 q;
     if (f == 0 || refill) {
-      const VehRec& rc = recs[s];
+      Veh rc;  // (the first 64 bytes: pose, heading vector, spawn index, status)
+      load_rec_head(recs, V, s, rc);
       const bool drawn = (rc.status == ST_PENDING || rc.status == ST_ACTIVE || rc.status == ST_DYING) && spb[rc.spawn].kind == PGD_OBJ_VEHICLE;
       float hx = rc.hx, hy = rc.hy;
       if (s != 0 && fabsf(rc.th) <= 2.0f * PGD_PI / 180.0f) { hx = 1.0f; hy = 0.0f; }  // the reference snaps small headings of the others
@@ -182,8 +183,8 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
     } else q = hp[(size_t)(f - 1) * V + s];
     s_pose[f * V + s] = q;
   }
-  for (int k = tid; k < t.n_pos; k += 256) s_pos[k] = (k == 0 || refill) ? make_float2(recs[0].x, recs[0].y) : pp[k - 1];
-  if (tid < V) { const pgd_spawn& so = spb[recs[tid].spawn]; s_hl[tid] = 0.5f * so.length; s_hw[tid] = 0.5f * so.width; }
+  for (int k = tid; k < t.n_pos; k += 256) s_pos[k] = (k == 0 || refill) ? make_float2(rec_float(recs, V, 0, RW_X), rec_float(recs, V, 0, RW_Y)) : pp[k - 1];
+  if (tid < V) { const pgd_spawn& so = spb[rec_spawn(recs, V, tid)]; s_hl[tid] = 0.5f * so.length; s_hw[tid] = 0.5f * so.width; }
   if (tid == 0) s_nhist = refill ? 1 : min(t.n_hist[e] + 1, t.n_pos);
   __syncthreads();
   for (int k = tid; k < t.n_frames * V; k += 256) hp[k] = s_pose[k];
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
   };
   if (t.rgb) {
     if (wv == 0 && !(eg0.z == 0.0f && eg0.w == 0.0f)) {
-      const bool snap = fabsf(recs[0].th) <= 2.0f * PGD_PI / 180.0f;
+      const bool snap = fabsf(rec_float(recs, V, 0, RW_TH)) <= 2.0f * PGD_PI / 180.0f;
       const float ax = snap ? eg0.z : 1.0f, ay = snap ? -eg0.w : 0.0f;  // (1, 0) turned into the window's frame; unsnapped: straight up
       const float hl = s_hl[0], hw = s_hw[0];
       const float rad = (hl + hw) * s_px + 1.5f, cc = (float)R * 0.5f - 0.5f;
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
     const int k = tid * t.frame_skip;
     if (k < s_nhist) {
       const float4 eg = s_pose[0];
-      const bool snap = fabsf(recs[0].th) <= 2.0f * PGD_PI / 180.0f;  // the reference rotates by the snapped ego heading here
+      const bool snap = fabsf(rec_float(recs, V, 0, RW_TH)) <= 2.0f * PGD_PI / 180.0f;  // the reference rotates by the snapped ego heading here
       const float ehx = snap ? 1.0f : eg.z, ehy = snap ? 0.0f : eg.w;
       const float dx = s_pos[k].x - eg.x, dy = s_pos[k].y - eg.y, sc = (float)R / t.distance;
       float u = (dy * ehx - dx * ehy) * sc + (float)R * 0.5f, vv = -(dx * ehx + dy * ehy) * sc + (float)R * 0.5f;

@@ -6,20 +6,33 @@
 // ---------------------------------------------------------------------------------------------------------------------
 // per-lane vehicle registers: struct Veh (pgd_device.h) is the record itself
 // ---------------------------------------------------------------------------------------------------------------------
-DEV void load_rec(const VehRec* rec, Veh& r) {
-  const uint4* src = reinterpret_cast<const uint4*>(rec);
+// records in memory: blocks of n records as eight planes of n pieces (RecPiece, pgd_device.h)
+DEV const RecPiece* rec_block(const RecPiece* base, size_t block, int n) { return base + block * (size_t)(8 * n); }
+DEV RecPiece* rec_block(RecPiece* base, size_t block, int n) { return base + block * (size_t)(8 * n); }
+DEV void load_rec(const RecPiece* blk, int n, int s, Veh& r) {
   uint4* dst = reinterpret_cast<uint4*>(&r);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) dst[k] = src[k];
+  for (int k = 0; k < 8; ++k) dst[k] = blk[k * n + s].q;
 }
-DEV void load_veh(const PgdDev& d, int e, int s, Veh& r) { load_rec(d.rec + (size_t)e * d.V + s, r); }
-DEV void store_rec(VehRec* rec, const Veh& r) {
-  uint4* dst = reinterpret_cast<uint4*>(rec);
+// the first 64 bytes: pose, speed, heading vector, lane | spawn, status / flags, route words (what an observer needs of a body)
+DEV void load_rec_head(const RecPiece* blk, int n, int s, Veh& r) {
+  uint4* dst = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dst[k] = blk[k * n + s].q;
+}
+DEV void store_rec(RecPiece* blk, int n, int s, const Veh& r) {
   const uint4* src = reinterpret_cast<const uint4*>(&r);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) dst[k] = src[k];
+  for (int k = 0; k < 8; ++k) blk[k * n + s].q = src[k];
 }
-DEV void store_veh(const PgdDev& d, int e, int s, const Veh& r) { store_rec(d.rec + (size_t)e * d.V + s, r); }
+// 32-bit word w (0 .. 31) of record s: struct Veh's fields by their word index
+DEV uint32_t rec_word(const RecPiece* blk, int n, int s, int w) { return reinterpret_cast<const uint32_t*>(blk + (w >> 2) * n + s)[w & 3]; }
+DEV float rec_float(const RecPiece* blk, int n, int s, int w) { return __uint_as_float(rec_word(blk, n, s, w)); }
+enum { RW_X = 0, RW_Y = 1, RW_TH = 2, RW_V = 3, RW_HX = 4, RW_HY = 5, RW_LANE_SPAWN = 8, RW_STATUS = 10 };
+DEV int rec_spawn(const RecPiece* blk, int n, int s) { return (int)(rec_word(blk, n, s, RW_LANE_SPAWN) >> 16); }
+DEV int rec_status(const RecPiece* blk, int n, int s) { return (int)((rec_word(blk, n, s, RW_STATUS) >> 16) & 15u); }
+DEV void load_veh(const PgdDev& d, int e, int s, Veh& r) { load_rec(rec_block(d.rec, (size_t)e, d.V), d.V, s, r); }
+DEV void store_veh(const PgdDev& d, int e, int s, const Veh& r) { store_rec(rec_block(d.rec, (size_t)e, d.V), d.V, s, r); }
 
 // base_vehicle.py:394-401; the magnitude: a reversing vehicle has a negative speed field, and BaseVehicle.velocity is this
 // magnitude times the FORWARD vector even then (base_vehicle.py:419-425)

@@ -1,0 +1,70 @@
+// Record layout of an env's vehicle block and what it costs at the start (loads) and at the end (stores) of a step's launch:
+// one wave per env, lane -> vehicle as k_step maps them (V = 17: three lanes per vehicle; V = 40: one), eight 16-byte pieces per
+// 128-byte record.  "line per vehicle" = piece k of slot s at (s * 8 + k) * 16 (an instruction touches V cache lines);
+// "piece planes" = piece k of slot s at (k * V + s) * 16 (an instruction touches V * 16 / 128 lines).  Same bytes, same DRAM pages.
+// hipcc --offload-arch=gfx950 -O2 -o rec_layout tools/rec_layout.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+struct Dev { int* ei; uint4* rec; unsigned long long* out; int planes; int V; int sub; int store; };
+__global__ __launch_bounds__(64, 4) void k(Dev d) {
+  const int e = blockIdx.x, lane = threadIdx.x, V = d.V;
+  long long t0 = clock64();
+  int scen = d.ei[e * 8];
+  const int s = lane / d.sub; const bool valid = s < V;
+  uint4 r[8];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (scen == 12345) return;
+  long long t1 = clock64();
+  const uint4* blk = d.rec + (size_t)e * V * 8 + (scen & 1);
+  const int ss = d.planes ? 1 : 8, ks = d.planes ? V : 1;
+  if (valid) {
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) r[k2] = blk[s * ss + k2 * ks];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  unsigned acc = 0;
+  if (valid) for (int k2 = 0; k2 < 8; ++k2) acc += r[k2].x ^ r[k2].w;
+  long long t2 = clock64();
+  if (acc == 0x12345678u) d.out[0] = 1;
+  // a stand-in for the step: ~6 us of dependent arithmetic
+  float f = (float)acc;
+  for (int i = 0; i < 600; ++i) f = __builtin_fmaf(f, 1.0001f, 0.5f);
+  if (f == 3.25f) d.out[1] = 1;
+  long long t3 = clock64();
+  if (d.store && valid && lane % d.sub == 0) {
+    uint4* w = d.rec + (size_t)e * V * 8;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) w[s * ss + k2 * ks] = r[k2];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  long long t4 = clock64();
+  if (lane == 0) {
+    d.ei[e * 8] = scen;
+    unsigned long long* o = d.out + 8 + e * 4;
+    o[0] += (unsigned long long)(t1 - t0); o[1] += (unsigned long long)(t2 - t1); o[2] += (unsigned long long)(t4 - t3);
+  }
+}
+int main() {
+  const int N = 4096;
+  Dev d{}; hipMalloc(&d.ei, N * 8 * 4); hipMalloc(&d.rec, (size_t)N * 40 * 128 + 64); hipMalloc(&d.out, 64 + N * 32);
+  hipMemset(d.ei, 0, N * 8 * 4); hipMemset(d.rec, 0, (size_t)N * 40 * 128 + 64);
+  for (int rep = 0; rep < 2; ++rep)
+  for (int V : {17, 40}) for (int waves : {4096, 256}) for (int store : {0, 1}) for (int planes : {0, 1}) {
+    d.planes = planes; d.V = V; d.sub = V == 17 ? 3 : 1; d.store = store;
+    for (int i = 0; i < 50; ++i) k<<<waves, 64>>>(d);
+    hipMemset(d.out, 0, 64 + N * 32);
+    const int n = 500;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    for (int i = 0; i < n; ++i) k<<<waves, 64>>>(d);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> ob(8 + N * 4); hipMemcpy(ob.data(), d.out, 64 + N * 32, hipMemcpyDeviceToHost);
+    unsigned long long o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < waves; ++b) { o[2] += ob[8 + b * 4]; o[3] += ob[9 + b * 4]; o[4] += ob[10 + b * 4]; }
+    printf("V %2d waves %4d %-16s %-9s: launch %6.2f us; env word after %5.0f cycles, records after another %5.0f, stores waited for %5.0f\n", V, waves,
+           planes ? "piece planes" : "line per vehicle", store ? "stores" : "no stores", ms / n * 1e3, (double)o[2] / n / waves, (double)o[3] / n / waves, (double)o[4] / n / waves);
+  }
+  return 0;
+}
