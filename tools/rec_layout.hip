@@ -6,21 +6,30 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
-struct Dev { int* ei; uint4* rec; unsigned long long* out; int planes; int V; int sub; int store; };
+struct Dev { int* ei; uint4* rec; unsigned long long* out; int planes; int V; int sub; int store; int lead; };
 __global__ __launch_bounds__(64, 4) void k(Dev d) {
   const int e = blockIdx.x, lane = threadIdx.x, V = d.V;
   long long t0 = clock64();
   int scen = d.ei[e * 8];
   const int s = lane / d.sub; const bool valid = s < V;
-  uint4 r[8];
+  uint4 r[8] = {};
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   if (scen == 12345) return;
   long long t1 = clock64();
   const uint4* blk = d.rec + (size_t)e * V * 8 + (scen & 1);
   const int ss = d.planes ? 1 : 8, ks = d.planes ? V : 1;
-  if (valid) {
+  // lead = 1: only the first lane of a vehicle's group reads; lead = 2: ... and hands the record to the group's other lanes (bpermute)
+  if (valid && (d.lead == 0 || lane % d.sub == 0)) {
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) r[k2] = blk[s * ss + k2 * ks];
+  }
+  if (d.lead == 2) {
+    const int src = (lane - lane % d.sub) * 4;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      r[k2].x = __builtin_amdgcn_ds_bpermute(src, r[k2].x); r[k2].y = __builtin_amdgcn_ds_bpermute(src, r[k2].y);
+      r[k2].z = __builtin_amdgcn_ds_bpermute(src, r[k2].z); r[k2].w = __builtin_amdgcn_ds_bpermute(src, r[k2].w);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   unsigned acc = 0;
@@ -50,8 +59,9 @@ int main() {
   Dev d{}; hipMalloc(&d.ei, N * 8 * 4); hipMalloc(&d.rec, (size_t)N * 40 * 128 + 64); hipMalloc(&d.out, 64 + N * 32);
   hipMemset(d.ei, 0, N * 8 * 4); hipMemset(d.rec, 0, (size_t)N * 40 * 128 + 64);
   for (int rep = 0; rep < 2; ++rep)
-  for (int V : {17, 40}) for (int waves : {4096, 256}) for (int store : {0, 1}) for (int planes : {0, 1}) {
-    d.planes = planes; d.V = V; d.sub = V == 17 ? 3 : 1; d.store = store;
+  for (int V : {17, 40}) for (int waves : {4096, 256}) for (int store : {0, 1}) for (int planes : {0, 1}) for (int lead : {0, 1, 2}) {
+    if (lead && (V != 17 || !planes)) continue;
+    d.planes = planes; d.V = V; d.sub = V == 17 ? 3 : 1; d.store = store; d.lead = lead;
     for (int i = 0; i < 50; ++i) k<<<waves, 64>>>(d);
     hipMemset(d.out, 0, 64 + N * 32);
     const int n = 500;
@@ -63,8 +73,8 @@ int main() {
     std::vector<unsigned long long> ob(8 + N * 4); hipMemcpy(ob.data(), d.out, 64 + N * 32, hipMemcpyDeviceToHost);
     unsigned long long o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = 0; b < waves; ++b) { o[2] += ob[8 + b * 4]; o[3] += ob[9 + b * 4]; o[4] += ob[10 + b * 4]; }
-    printf("V %2d waves %4d %-16s %-9s: launch %6.2f us; env word after %5.0f cycles, records after another %5.0f, stores waited for %5.0f\n", V, waves,
-           planes ? "piece planes" : "line per vehicle", store ? "stores" : "no stores", ms / n * 1e3, (double)o[2] / n / waves, (double)o[3] / n / waves, (double)o[4] / n / waves);
+    printf("V %2d waves %4d %-16s lead %d %-9s: launch %6.2f us; env word after %5.0f cycles, records after another %5.0f, stores waited for %5.0f\n", V, waves,
+           planes ? "piece planes" : "line per vehicle", lead, store ? "stores" : "no stores", ms / n * 1e3, (double)o[2] / n / waves, (double)o[3] / n / waves, (double)o[4] / n / waves);
   }
   return 0;
 }
