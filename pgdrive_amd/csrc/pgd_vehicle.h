@@ -28,9 +28,8 @@ DEV void store_rec(RecPiece* blk, int n, int s, const Veh& r) {
 // 32-bit word w (0 .. 31) of record s: struct Veh's fields by their word index
 DEV uint32_t rec_word(const RecPiece* blk, int n, int s, int w) { return reinterpret_cast<const uint32_t*>(blk + (w >> 2) * n + s)[w & 3]; }
 DEV float rec_float(const RecPiece* blk, int n, int s, int w) { return __uint_as_float(rec_word(blk, n, s, w)); }
-enum { RW_X = 0, RW_Y = 1, RW_TH = 2, RW_V = 3, RW_HX = 4, RW_HY = 5, RW_LANE_SPAWN = 8, RW_STATUS = 10 };
-DEV int rec_spawn(const RecPiece* blk, int n, int s) { return (int)(rec_word(blk, n, s, RW_LANE_SPAWN) >> 16); }
-DEV int rec_status(const RecPiece* blk, int n, int s) { return (int)((rec_word(blk, n, s, RW_STATUS) >> 16) & 15u); }
+enum { RW_X = 0, RW_Y = 1, RW_TH = 2, RW_LANE_SPAWN = 8 };
+DEV int rec_spawn(const RecPiece* blk, int n, int s) { return (int)(rec_word(blk, n, s, RW_LANE_SPAWN) >> 16); }  // Veh::spawn
 DEV void load_veh(const PgdDev& d, int e, int s, Veh& r) { load_rec(rec_block(d.rec, (size_t)e, d.V), d.V, s, r); }
 DEV void store_veh(const PgdDev& d, int e, int s, const Veh& r) { store_rec(rec_block(d.rec, (size_t)e, d.V), d.V, s, r); }
 
