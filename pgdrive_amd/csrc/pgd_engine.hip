@@ -108,12 +108,23 @@ DEV LaneMap lane_map(const PgdDev& d, int unit, int n_units) {
 #define FUSE_MAX_AGENTS 8
 // first 64 bytes of a spawn record (everything but the route arrays) into a local copy; the copy is only ever read by field, so it
 // lives in registers and the fields nobody reads cost nothing
-DEV void spawn_head_load(const pgd_spawn* sp, pgd_spawn& out) {
+template <bool SKIP_POSE> DEV void spawn_head_load(const pgd_spawn* sp, pgd_spawn& out) {
   static_assert(offsetof(pgd_spawn, ckpt) == 64 && sizeof(pgd_spawn) % 16 == 0, "spawn record head = 4 x 16 bytes");
+  static_assert(offsetof(pgd_spawn, length) == 12, "the first piece = spawn pose + length");
   const float4* q = reinterpret_cast<const float4*>(sp);
   float4* o = reinterpret_cast<float4*>(&out);
-  const float4 a = q[0], b = q[1], c = q[2], e = q[3];
-  o[0] = a; o[1] = b; o[2] = c; o[3] = e;
+  // (the spawn pose is only read where slots are (re)built from the record in memory -- the image kernels: a step reads the length
+  // alone from the first piece; as a whole piece it went through a temporary that the compiler waited for before it issued the
+  // last two reads in the kernels that are short of registers)
+  // (SKIP_POSE: the multi-agent kernels; the single-agent ones issue the four pieces together as they are)
+  if constexpr (SKIP_POSE) {
+    const float len = sp->length;
+    const float4 b = q[1], c = q[2], e = q[3];
+    o[0] = make_float4(0.0f, 0.0f, 0.0f, len); o[1] = b; o[2] = c; o[3] = e;
+  } else {
+    const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+    o[0] = a; o[1] = b; o[2] = c; o[3] = e;
+  }
 }
 template <bool REG> DEV const pgd_lane& dest_lane_ref(const pgd_lane& regs, const pgd_lane* lanes, int id) {
   if constexpr (REG) return regs; else return lanes[id];
@@ -181,7 +192,7 @@ DEV void step_sync() { row_sync<true>(); }
 // reference's 72 beams and BASELINE config 5's 240 run the same instantiation: as a constant the beam count gave the 72-beam row
 // 0.8 % and cost the 240-beam row 6 %, which then fell back to the general kernel).
 #define PGD_FIXM_FIELDS(F, d, c)                                                                                                    \
-  F(d.T, 0) F(d.epw, 1) F(d.pack_obs, 0)                                                                                 \
+  F(d.T, 0) F(d.epw, 1) F(d.pack_obs, 0) F(d.no_groups, 1) F(d.use_imask, 1)                                              \
   F(c.num_traffic, 0) F(c.num_others, 0) F(c.lidar_dist, 40.0f) F(c.dt, 0.02f) F(c.decision_repeat, 5)          \
   F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0) F(c.enable_reverse, 0)                                     \
   F(c.marl_flags, (PGD_MA_ENABLED | PGD_MA_CRASH_DONE | PGD_MA_OUT_ROAD_DONE | PGD_MA_ALLOW_RESPAWN)) F(c.use_lateral, 0)           \
@@ -304,7 +315,10 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // env's own record in HBM.  One env per wave only; the records in memory stay complete either way.
   unsigned long long im = 0ull;
   const bool packed = !ONE_ENV && d.pack_obs != 0;  // throughput mode: whole envs side by side in the wave, one vehicle per lane
-  if ((ONE_ENV || (packed && valid)) && d.use_imask) im = d.imask[e];
+  // (read whatever `use_imask` says and masked afterwards: behind a branch on a run-time switch the read sat in a block of its own,
+  // waited for on the spot, and the scenario's read went out a whole memory latency later -- the multi-agent kernels)
+  if (ONE_ENV || (packed && valid)) im = d.imask[e];
+  im = d.use_imask ? im : 0ull;
   if (one_env || valid) scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
   if (valid) load_rec(((ONE_ENV || packed) && ((im >> s) & 1ull)) ? rec_block(d.reset_img, (size_t)scen, V) : rec_block(d.rec, (size_t)e, V), V, s, r);
   // the agent's action: its address follows from the block index as well -- read here, used by the policy phase (read there it cost
@@ -330,7 +344,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   XMARK(13);
   if (valid) {
     sp = d.spawns + (size_t)scen * d.sstride + r.spawn;
-    if (REGSP) spawn_head_load(sp, sl);
+    if (REGSP) spawn_head_load<MARL>(sp, sl);
     // (0) AgentManager.before_step (agent_manager.py:191-199): finished agents count down, then leave the world
     if (marl && r.status == ST_DYING && --r.timer == 0) r.status = ST_EMPTY;
   }
@@ -338,6 +352,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // group.  One env per wave: a ballot over the wave's lanes (no trip through LDS); several envs per wave: a flag per env.
   bool on_trigger;
   if (ONE_ENV && !MARL && A == 1 && trig_hint != 0) on_trigger = valid && s < A && trig_hint == 2;
+  else if (MARL && d.no_groups) on_trigger = false;  // no scenario has a trigger group (engines without traffic slots: two dependent reads less)
   else on_trigger = valid && s < A && r.status == ST_ACTIVE && ng < sc->n_groups && mv.lanes[r.lane].road == sc->trigger_road[ng];
   bool trig;
   if (ONE_ENV) {
@@ -756,7 +771,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     }
     if (fresh) {  // the new agent's record, first localisation included, from the respawn image (k_respawn_image)
       sp = d.spawns + (size_t)scen * d.sstride + fresh_idx;
-      if (REGSP) spawn_head_load(sp, sl);
+      if (REGSP) spawn_head_load<MARL>(sp, sl);
       load_rec(rec_block(cold.respawn_img, (size_t)scen, d.sstride - V), d.sstride - V, fresh_idx - V, r);
       r.agent_id = (float)fresh_id;
     }
@@ -801,7 +816,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   if (valid && resetting) {
     sp = d.spawns + (size_t)scen * d.sstride + s;
-    if (REGSP) spawn_head_load(sp, sl);
+    if (REGSP) spawn_head_load<MARL>(sp, sl);
     // the slot right after a reset is a function of the scenario alone (spawn pose, first localisation, side distances,
     // agent id): read from the image k_reset_image built at upload instead of localising every vehicle again
     load_rec(rec_block(d.reset_img, (size_t)scen, V), V, s, r);
@@ -1672,6 +1687,9 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   }
   for (size_t k = 0; k < (size_t)n_scen * h->d.sstride; ++k)
     if (spawns[k].lane >= 0 && (!(spawns[k].max_steer <= 1.0f) || spawns[k].n_ckpt > PGD_MAX_CKPT)) return PGD_ERR_ARG;  // tan_small
+  h->d.no_groups = 1;
+  for (int k = 0; k < n_scen; ++k)
+    if (scen[k].n_groups > 0) { h->d.no_groups = 0; break; }
   h->has_objects = false;
   for (size_t k = 0; k < (size_t)n_scen * h->d.sstride; ++k)
     if (spawns[k].lane >= 0 && spawns[k].kind != PGD_OBJ_VEHICLE) { h->has_objects = true; break; }
