@@ -320,6 +320,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (ONE_ENV || (packed && valid)) im = d.imask[e];
   im = d.use_imask ? im : 0ull;
   if (one_env || valid) scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
+  // the kernel of the multi-agent defaults (no traffic slots, no trigger groups, no IDM policy: nothing before the reward needs the
+  // env's counters): EI_NEAR with the scenario id, the counters where they are first used -- below
+  constexpr bool LATE_WORDS = MARL && FIX != 0;
+  int hint_early = 0;
+  if (LATE_WORDS && (one_env || valid)) hint_early = d.ei[(size_t)e * PGD_NEI + EI_NEAR];
   if (valid) load_rec(((ONE_ENV || packed) && ((im >> s) & 1ull)) ? rec_block(d.reset_img, (size_t)scen, V) : rec_block(d.rec, (size_t)e, V), V, s, r);
   // the agent's action: its address follows from the block index as well -- read here, used by the policy phase (read there it cost
   // every wave a memory latency of its own right after the snapshot: 1.5 k cycles of the metric's row).  BEHIND the record's reads:
@@ -328,9 +333,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   float2 act_in = make_float2(0.0f, 0.0f);
   if (ONE_ENV && valid && s < A) act_in = *reinterpret_cast<const float2*>(act + ((size_t)e * A + s) * 2);
   const int key0 = valid ? (r.status ^ (r.vflags << 3)) : 0;  // what a vehicle that does not drive can change: status, flags
-  if (one_env || valid) {
-    sc = d.scen + scen;
-    mv = map_view_as<MV>(d, d.env_map + e);  // per-env header copy: address known at kernel start
+  // the env's counters.  The multi-agent kernels are out of scalar registers: read here, the compiler fetched the words one after the
+  // other through the same register -- three scalar-memory round trips in a row between the records and the spawn heads (a word that
+  // goes straight to a spill lane is waited for on the spot).  They take the near hint with the scenario id (above) and the counters
+  // where the step first needs them, behind after_step: the row is in the scalar cache by then.
+  auto env_words = [&]() {
     ng = d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP];
     ep_steps = d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS];
     steps_total = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
@@ -339,6 +346,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
       near_env = (hint & 1) != 0;
       trig_hint = (hint >> 1) & 3;
     }
+  };
+  if (one_env || valid) {
+    sc = d.scen + scen;
+    mv = map_view_as<MV>(d, d.env_map + e);  // per-env header copy: address known at kernel start
+    if (!LATE_WORDS) env_words();
   }
   PHASE_MARK(13);  // load: scenario + table staging
   XMARK(13);
@@ -348,6 +360,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // (0) AgentManager.before_step (agent_manager.py:191-199): finished agents count down, then leave the world
     if (marl && r.status == ST_DYING && --r.timer == 0) r.status = ST_EMPTY;
   }
+  if (LATE_WORDS && (ONE_ENV || packed)) { near_env = (hint_early & 1) != 0; trig_hint = (hint_early >> 1) & 3; }
   // (1) TrafficManager.before_step trigger (traffic_manager.py:76-85): an agent of the env stands on the trigger road of the next
   // group.  One env per wave: a ballot over the wave's lanes (no trip through LDS); several envs per wave: a flag per env.
   bool on_trigger;
@@ -631,6 +644,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   }
   PHASE_MARK(5);  // after_step
   XMARK(5);
+  if (LATE_WORDS && (one_env || valid)) {  // (not before this point: see env_words)
+    asm volatile("" ::: "memory");
+    ng = d.ei[(size_t)(e) * PGD_NEI + EI_NEXT_GROUP];
+    ep_steps = d.ei[(size_t)(e) * PGD_NEI + EI_EP_STEPS];
+    steps_total = (uint32_t)d.ei[(size_t)(e) * PGD_NEI + EI_STEPS_TOTAL];
+  }
   ep_steps += 1;
   steps_total += 1;
   // (7) reward / done (base_env.py:303-344).  "The env restarts": one env per wave -> a ballot over the lanes that ask for it;
