@@ -1702,3 +1702,58 @@ def test_idm_agent_parity_and_arrivals(descs, traffic_mode):
           "reward %.1f" % (done_n, arrive_n, mean_len, float(np.mean(ep_rewards))))
     assert mean_len > 100 and float(np.mean(ep_rewards)) > 40.0
     eng.close(); twin.close()
+
+
+def test_state_with_spawn_records_of_other_slots(descs):
+    """pgd_set_state may hand a slot the spawn record of another one (SI_SPAWN is a state field).  The single-agent kernels read the
+    head of a slot's OWN spawn record together with its vehicle record (the address follows from the scenario id) and fall back to
+    the record's spawn index when the two differ: two traffic vehicles with exchanged records (other dimensions and drive
+    parameters) must step like the oracle's."""
+    import torch
+    from oracle import orc
+    from pgdrive_amd.engine import Engine
+    mb, sb = util.make_banks(descs, n_maps=8, traffic_mode="respawn")  # every traffic vehicle drives from the first step
+    n = 64
+    cfg = _abi.make_config(n, num_agents=1, num_traffic=16, num_lasers=240, auto_reset=0, seed=5)
+    eng = Engine(cfg, mb, sb)
+    ora = orc.Oracle(cfg, mb, sb)
+    ids = np.arange(n) % 8
+    ora.reset(ids)
+    eng.reset(ids)
+    f, i, ei = ora.get_state()
+    sp = i[_abi.SI["SPAWN"]]
+    st = i[_abi.SI["STATUS"]]
+    swapped = 0
+    for e in range(n):  # exchange the spawn records of the first two driving traffic vehicles of different size
+        act = [s for s in range(1, 17) if st[e, s] == _abi.ST_ACTIVE]
+        for a in act:
+            for b in act:
+                la = sb.spawns["length"].reshape(len(sb.scenarios), -1)[ids[e], sp[e, a]]
+                lb = sb.spawns["length"].reshape(len(sb.scenarios), -1)[ids[e], sp[e, b]]
+                if a < b and la != lb:
+                    sp[e, a], sp[e, b] = sp[e, b], sp[e, a]
+                    swapped += 1
+                    break
+            else:
+                continue
+            break
+    assert swapped > n // 2
+    ora.set_state(f, i, ei)
+    eng.set_state(f, i, ei)
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for t in range(40):
+        act = util.driving_actions(rng, n)
+        oo, orw, od, ofl = ora.step(act, threads=16)
+        go, grw, gd, gfl = eng.step(torch.from_numpy(act).cuda())
+        eng.sync()
+        assert np.array_equal(gfl.cpu().numpy(), ofl)
+        d_obs = np.abs(go.cpu().numpy().astype(np.float64) - oo)
+        beams = d_obs[..., -240:]
+        beams[beams > OBS_TOL] = 0.0  # (grazing beams are counted by the parity tests proper)
+        worst = max(worst, float(d_obs.max()))
+        gf, gi, gei = eng.get_state()
+        assert np.array_equal(gi[_abi.SI["SPAWN"]], ora.get_state()[1][_abi.SI["SPAWN"]])
+        ora.set_state(*eng.get_state())  # teacher forcing
+    assert worst < OBS_TOL, worst
+    eng.close()
