@@ -51,7 +51,7 @@ struct PgdDev {
   int32_t* ei;         // [N][PGD_NEI]
   pgd_map* env_map;    // [N] copy of the map header of the env's running scenario (rewritten on reset): the map view of a
                        // step needs no env -> scenario -> header chain
-  int use_imask;       // 0: every slot is read from the env's own record (small N: one dependent load level less)
+  int use_imask;       // 0: every slot is read from the env's own record (one env per wave: one dependent load level less)
   int no_groups;       // no uploaded scenario has a traffic trigger group (pgd_upload_scenarios): the trigger test of a step is skipped
   unsigned long long* imask;  // [N] bit s: slot s of the env still equals its scenario's reset image (never stored since)
   const RecPiece* reset_img;  // [n_scen] blocks of V records: every slot right after a reset of its scenario (k_reset_image)

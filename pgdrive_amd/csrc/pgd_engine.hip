@@ -174,7 +174,7 @@ DEV void step_sync() { row_sync<true>(); }
 #define PGD_FIX_V 17
 // one list for the device (assignment) and the host (test): F(field, value)
 #define PGD_FIX_FIELDS(F, d, c, one_env)                                                                                            \
-  F(d.V, PGD_FIX_V) F(d.A, 1) F(d.T, PGD_FIX_V - 1) F(d.D, 274) F(d.sstride, PGD_FIX_V) F(d.use_imask, 1)                            \
+  F(d.V, PGD_FIX_V) F(d.A, 1) F(d.T, PGD_FIX_V - 1) F(d.D, 274) F(d.sstride, PGD_FIX_V) F(d.use_imask, (one_env ? 0 : 1))                      \
   F(d.sub, (one_env ? WAVE / PGD_FIX_V : 1)) F(d.epw, (one_env ? 1 : WAVE / PGD_FIX_V)) F(d.pack_obs, (one_env ? 0 : 1))             \
   F(c.num_agents, 1) F(c.num_traffic, PGD_FIX_V - 1) F(c.num_lasers, 240) F(c.num_others, 4) F(c.lidar_dist, 50.0f)                 \
   F(c.dt, 0.02f) F(c.decision_repeat, 5) F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0)                     \
@@ -192,7 +192,7 @@ DEV void step_sync() { row_sync<true>(); }
 // reference's 72 beams and BASELINE config 5's 240 run the same instantiation: as a constant the beam count gave the 72-beam row
 // 0.8 % and cost the 240-beam row 6 %, which then fell back to the general kernel).
 #define PGD_FIXM_FIELDS(F, d, c)                                                                                                    \
-  F(d.T, 0) F(d.epw, 1) F(d.pack_obs, 0) F(d.no_groups, 1) F(d.use_imask, 1)                                              \
+  F(d.T, 0) F(d.epw, 1) F(d.pack_obs, 0) F(d.no_groups, 1) F(d.use_imask, 0)                                              \
   F(c.num_traffic, 0) F(c.num_others, 0) F(c.lidar_dist, 40.0f) F(c.dt, 0.02f) F(c.decision_repeat, 5)          \
   F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0) F(c.enable_reverse, 0)                                     \
   F(c.marl_flags, (PGD_MA_ENABLED | PGD_MA_CRASH_DONE | PGD_MA_OUT_ROAD_DONE | PGD_MA_ALLOW_RESPAWN)) F(c.use_lateral, 0)           \
@@ -1379,6 +1379,7 @@ struct pgd_engine {
   bool no_fuse;      // PGD_NO_FUSE was set when the engine was created (debug: always run the stand-alone k_observe)
   bool prof_fused;
   bool no_state_in_step;  // PGD_NO_STATE_IN_STEP was set when the engine was created (A/B: the state blocks stay in k_observe_env)
+  int imask_env;        // PGD_NO_IMASK / PGD_IMASK: 0 / 1 force the reset-image reads off / on, -1 = by mode (PgdDev::use_imask)
   bool left_pack_mode;  // pgd_set_groups switched the engine from throughput mode back to one env per wave (reported by pgd_describe_step)
   ulonglong2* rowz;  // multi-agent engines: PgdDev::rowz (zero-row marks + the tag of the buffer they describe, per env)
 };
@@ -1528,9 +1529,13 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   HIPCHK(hipMalloc(&h->d.env_map, sizeof(pgd_map) * (size_t)h->d.N));
   HIPCHK(hipMemsetAsync(h->d.env_map, 0, sizeof(pgd_map) * (size_t)h->d.N, h->stream));
   // never-written slots are read from the scenario's reset image (cache resident, shared by every env of the scenario) instead
-  // of the env's own record: halves the HBM bytes of a step at any N (2.2 vs 4.5 KB per env-step at 4096 envs) and is worth
-  // +13 % at 262144 envs; at 4096 envs the step is latency bound and the time is the same either way (PGD_NO_IMASK: A/B switch)
-  h->d.use_imask = !getenv("PGD_NO_IMASK");
+  // of the env's own record: halves the HBM bytes of a step and is worth +13 % at 262144 envs.  THROUGHPUT MODE ONLY (several envs
+  // per wave, from 32768 envs on): with one env per wave the step is bound by its chain of memory round trips, and the mask is one
+  // of them -- mask + scenario id -> records -> ...; without it the records' reads go out at once (round 5: 4096 envs 17.38 -> 17.12 us,
+  // 16384 envs 47.3 -> 46.8, 8 agents 22.4 -> 22.1, 40 seats' step 27.7 -> 27.0; 32768 envs in throughput mode 77.2 -> 77.7 without
+  // the image).  PGD_NO_IMASK=1 / PGD_IMASK=1 force it off / on (A/B; the specialised kernels are compiled for the default).
+  h->imask_env = getenv("PGD_NO_IMASK") ? 0 : (getenv("PGD_IMASK") ? 1 : -1);
+  h->d.use_imask = h->imask_env >= 0 ? h->imask_env : (h->d.pack_obs ? 1 : 0);
   HIPCHK(hipMalloc(&h->d.imask, sizeof(unsigned long long) * (size_t)h->d.N));
   HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
   {
@@ -1971,8 +1976,13 @@ int pgd_set_groups(pgd_handle h, int n_groups) {
   }
   if (pack != h->d.pack_obs) h->left_pack_mode = true;
   h->d.pack_obs = pack; h->d.sub = sub; h->d.epw = epw;
+  const int use_imask = h->imask_env >= 0 ? h->imask_env : (pack ? 1 : 0);
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (use_imask != h->d.use_imask) {  // (the masks are only kept up while they are read: none is trusted across the switch)
+    HIPCHK(hipMemsetAsync(h->d.imask, 0, sizeof(unsigned long long) * (size_t)h->d.N, h->stream));
+    h->d.use_imask = use_imask;
+  }
   if (h->gstreams) {
     for (int g = 0; g < h->n_groups; ++g) { (void)hipStreamSynchronize(h->gstreams[g]); (void)hipStreamDestroy(h->gstreams[g]); }
     free(h->gstreams);

@@ -1059,16 +1059,19 @@ def test_throughput_mode_at_32768_envs_properties():
 
 
 @pytest.mark.parametrize("num_traffic", [16, 24, 40])  # 3, 2, 1 sub-lanes per vehicle slot
-def test_record_cache_matches_plain_records(descs, num_traffic):
+def test_record_cache_matches_plain_records(descs, num_traffic, monkeypatch):
     """The step kernel skips the write of a record that did not change and reads never-written slots from the scenario's
-    reset image.  Engine A runs freely with both short cuts; engine B gets A's complete state through get_state /
+    reset image (the throughput mode's default; with one env per wave the image reads are off by default since round 5 -- the mask
+    is a memory round trip in front of the records -- and PGD_IMASK=1 switches them on: this test).  Engine A runs freely with both short cuts; engine B gets A's complete state through get_state /
     set_state before every step (set_state drops the image marks, so B reads its own records).  Same kernel, same inputs:
     every output must be bit-identical, through terminations, auto-resets with re-drawn scenarios, a partial pgd_reset
     and a scenario re-upload in the middle of the run.  (A free-running env also keeps its own copy of the map header, which
     set_state rebuilds: with fewer than four sub-lanes per slot the copy used to follow a re-drawn scenario only in part.)"""
     n_envs = 96
+    monkeypatch.setenv("PGD_IMASK", "1")
     torch, eng_a, ora, cfg = _engines(descs, n_envs, seed=5, num_traffic=num_traffic, resample_scenario=1)
     _, eng_b, _, _ = _engines(descs, n_envs, seed=5, num_traffic=num_traffic, resample_scenario=1)
+    monkeypatch.delenv("PGD_IMASK")
     scen_ids = np.arange(n_envs) % 8
     eng_a.reset(scen_ids)
     eng_b.reset(scen_ids)
