@@ -315,10 +315,9 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // env's own record in HBM.  One env per wave only; the records in memory stay complete either way.
   unsigned long long im = 0ull;
   const bool packed = !ONE_ENV && d.pack_obs != 0;  // throughput mode: whole envs side by side in the wave, one vehicle per lane
-  // (read whatever `use_imask` says and masked afterwards: behind a branch on a run-time switch the read sat in a block of its own,
-  // waited for on the spot, and the scenario's read went out a whole memory latency later -- the multi-agent kernels)
-  if (ONE_ENV || (packed && valid)) im = d.imask[e];
-  im = d.use_imask ? im : 0ull;
+  // (a run-time switch in the general kernels: off with one env per wave -- the branch then skips the read; where it is on, the read
+  // sits in a block of its own and is waited for there, a memory latency in front of the scenario id's read)
+  if ((ONE_ENV || (packed && valid)) && d.use_imask) im = d.imask[e];
   if (one_env || valid) scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
   // the kernel of the multi-agent defaults (no traffic slots, no trigger groups, no IDM policy: nothing before the reward needs the
   // env's counters): EI_NEAR with the scenario id, the counters where they are first used -- below
@@ -335,7 +334,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // single-agent engines: a slot keeps the spawn record of its own index (only a multi-agent respawn hands a slot another one; a
   // state set by hand may: checked below) -- the head's address follows from the scenario id like the record's, and its reads travel
   // with the record's instead of waiting for them (17.48 -> 17.40 us on the metric's row, now that the records' reads are short)
-  if (!MARL && REGSP && valid) { sp = d.spawns + (size_t)scen * d.sstride + s; spawn_head_load<false>(sp, sl); }
+  constexpr bool EARLY_HEAD = !MARL && REGSP && FIX != 0;  // (the general kernels have no registers for it: 19.5 -> 19.9 us there)
+  if (EARLY_HEAD && valid) { sp = d.spawns + (size_t)scen * d.sstride + s; spawn_head_load<false>(sp, sl); }
   const int key0 = valid ? (r.status ^ (r.vflags << 3)) : 0;  // what a vehicle that does not drive can change: status, flags
   // the env's counters.  The multi-agent kernels are out of scalar registers: read here, the compiler fetched the words one after the
   // other through the same register -- three scalar-memory round trips in a row between the records and the spawn heads (a word that
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   PHASE_MARK(13);  // load: scenario + table staging
   XMARK(13);
   if (valid) {
-    if (MARL || !REGSP || (int)r.spawn != s) {
+    if (!EARLY_HEAD || (int)r.spawn != s) {
       sp = d.spawns + (size_t)scen * d.sstride + r.spawn;
       if (REGSP) spawn_head_load<MARL>(sp, sl);
     }
