@@ -317,6 +317,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   const bool packed = !ONE_ENV && d.pack_obs != 0;  // throughput mode: whole envs side by side in the wave, one vehicle per lane
   // (a run-time switch in the general kernels: off with one env per wave -- the branch then skips the read; where it is on, the read
   // sits in a block of its own and is waited for there, a memory latency in front of the scenario id's read)
+  // With the image off (a uniform switch) the records' addresses follow from the block index alone: their reads go out FIRST, the
+  // scenario id's behind them -- read in front, its round trip sat in the scalar wait that the records' base pointer needs (general
+  // kernels; the specialised ones fold the switch).
+  const bool own_first = FIX == 0 && ONE_ENV && !d.use_imask;  // (the specialised kernels already come out that way)
+  if (own_first && valid) load_rec(rec_block(d.rec, (size_t)e, V), V, s, r);
   if ((ONE_ENV || (packed && valid)) && d.use_imask) im = d.imask[e];
   if (one_env || valid) scen = d.ei[(size_t)e * PGD_NEI + EI_SCEN];
   // the kernel of the multi-agent defaults (no traffic slots, no trigger groups, no IDM policy: nothing before the reward needs the
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   constexpr bool LATE_WORDS = MARL && FIX != 0;
   int hint_early = 0;
   if (LATE_WORDS && (one_env || valid)) hint_early = d.ei[(size_t)e * PGD_NEI + EI_NEAR];
-  if (valid) load_rec(((ONE_ENV || packed) && ((im >> s) & 1ull)) ? rec_block(d.reset_img, (size_t)scen, V) : rec_block(d.rec, (size_t)e, V), V, s, r);
+  if (valid && !own_first) load_rec(((ONE_ENV || packed) && ((im >> s) & 1ull)) ? rec_block(d.reset_img, (size_t)scen, V) : rec_block(d.rec, (size_t)e, V), V, s, r);
   // the agent's action: its address follows from the block index as well -- read here, used by the policy phase (read there it cost
   // every wave a memory latency of its own right after the snapshot: 1.5 k cycles of the metric's row).  BEHIND the record's reads:
   // issued ahead of the mask / scenario / record chain it delays that chain (17.76 -> 17.99 us), and so does a speculative read
