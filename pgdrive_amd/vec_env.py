@@ -286,7 +286,7 @@ class PGDriveVecEnv:
             assert ok, "Input actions are not compatible with action space {}!".format(self.single_action_space)
         obs, rew, done, flags = self.engine.step(actions.contiguous().view(self.num_envs, 1, 2))
         if not getattr(self, "_kernel_reported", False):
-            # once: a configuration that is not one of the reference's defaults runs the general step kernel, measured 8 % behind
+            # once: a configuration that is not one of the reference's defaults runs the general step kernel, measured 12 % behind
             # the instantiations with the configuration compiled in -- say so instead of paying silently
             self._kernel_reported = True
             kname = self.engine.describe_step()
