@@ -293,7 +293,7 @@ class PGDriveVecEnv:
             if self.num_envs >= 1024 and "specialised" not in kname:
                 import warnings
                 warnings.warn("pgdrive_amd: this configuration runs the general step kernel (%s); the reference's default "
-                              "configurations run specialised instantiations that are about 8 %% faster" % kname)
+                              "configurations run specialised instantiations that are about 12 %% faster" % kname)
         if self.topdown:
             return self.engine.observe_topdown(), rew.view(-1), done.view(-1), flags.view(-1)
         return obs.view(self.num_envs, self.obs_dim), rew.view(-1), done.view(-1), flags.view(-1)
