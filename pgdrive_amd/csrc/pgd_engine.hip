@@ -202,7 +202,7 @@ DEV void step_sync() { row_sync<true>(); }
 // BASELINE config 2: the ego alone, no lidar (dynamics + reward + the 18-float state vector), otherwise the single-agent defaults --
 // four envs per wave, 16 sub-lanes per ego, the row written by k_step itself.
 #define PGD_FIXE_FIELDS(F, d, c)                                                                                                    \
-  F(d.V, 1) F(d.A, 1) F(d.T, 0) F(d.D, 18) F(d.sstride, 1) F(d.sub, 16) F(d.epw, 4) F(d.pack_obs, 0)                                 \
+  F(d.V, 1) F(d.A, 1) F(d.T, 0) F(d.D, 18) F(d.sstride, 1) F(d.sub, 16) F(d.epw, 4) F(d.pack_obs, 0) F(d.no_groups, 1)               \
   F(c.num_agents, 1) F(c.num_traffic, 0) F(c.num_lasers, 0) F(c.num_others, 0) F(c.dt, 0.02f) F(c.decision_repeat, 5)                \
   F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0) F(c.enable_reverse, 0) F(c.marl_flags, 0)                  \
   F(c.use_lateral, 0) F(c.out_of_route_done, 0) F(c.success_reward, 10.0f) F(c.out_of_road_penalty, 5.0f)                           \
@@ -283,7 +283,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // read ONCE, four 16-byte loads in one round trip, when the record's address is known; the phases used to fetch its fields one
   // by one where they needed them, each time for a whole memory latency (profiles/r03_notes.md).  Kernels with one env per wave
   // only: the multi-env instantiations have no registers to spare.
-  constexpr bool REGSP = ONE_ENV;
+  // the ego-only kernel (BASELINE config 2: four envs of one vehicle per wave) is small and far below its register budget: it takes
+  // the one-env kernels' short cuts -- spawn head in registers (read with the record), the action read in the first burst, no
+  // trigger test without trigger groups -- each of them a memory round trip of a step that is nothing but round trips
+  // (round 5: 1024 envs 11.12 -> 10.93 us, 65536 envs 1.40 -> 1.55 G env-steps/s)
+  constexpr bool FIXE_K = FIX != 0 && !ONE_ENV && !MARL && !STD;
+  constexpr bool REGSP = ONE_ENV || FIXE_K;
   pgd_spawn sl;
   pgd_lane FL;  // REGSP && FIX (registers to spare): the agent's destination lane record, read ahead
 #define SPV spawn_ref<REGSP>(sl, sp)
@@ -335,7 +340,8 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // issued ahead of the mask / scenario / record chain it delays that chain (17.76 -> 17.99 us), and so does a speculative read
   // of the slot's spawn record next to the vehicle record (18.4 us): the first burst of a wave stays as short as it can be
   float2 act_in = make_float2(0.0f, 0.0f);
-  if (ONE_ENV && valid && s < A) act_in = *reinterpret_cast<const float2*>(act + ((size_t)e * A + s) * 2);
+  constexpr bool ACT_EARLY = ONE_ENV || FIXE_K;
+  if (ACT_EARLY && valid && s < A) act_in = *reinterpret_cast<const float2*>(act + ((size_t)e * A + s) * 2);
   // single-agent engines: a slot keeps the spawn record of its own index (only a multi-agent respawn hands a slot another one; a
   // state set by hand may: checked below) -- the head's address follows from the scenario id like the record's, and its reads travel
   // with the record's instead of waiting for them (17.48 -> 17.40 us on the metric's row, now that the records' reads are short)
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // group.  One env per wave: a ballot over the wave's lanes (no trip through LDS); several envs per wave: a flag per env.
   bool on_trigger;
   if (ONE_ENV && !MARL && A == 1 && trig_hint != 0) on_trigger = valid && s < A && trig_hint == 2;
-  else if (MARL && d.no_groups) on_trigger = false;  // no scenario has a trigger group (engines without traffic slots: two dependent reads less)
+  else if ((MARL || FIXE_K) && d.no_groups) on_trigger = false;  // no scenario has a trigger group (engines without traffic slots: two dependent reads less)
   else on_trigger = valid && s < A && r.status == ST_ACTIVE && ng < sc->n_groups && mv.lanes[r.lane].road == sc->trigger_road[ng];
   bool trig;
   if (ONE_ENV) {
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   if (acting) {
     float st, tb;
     if (s < A && !idm_ego) {  // EnvInputPolicy.act (env_input_policy.py:17-26); NaN made harmless (test_ego_vehicle.py:78-84)
-      float a0 = ONE_ENV ? act_in.x : act[((size_t)e * A + s) * 2 + 0], a1 = ONE_ENV ? act_in.y : act[((size_t)e * A + s) * 2 + 1];
+      float a0 = ACT_EARLY ? act_in.x : act[((size_t)e * A + s) * 2 + 0], a1 = ACT_EARLY ? act_in.y : act[((size_t)e * A + s) * 2 + 1];
       if (a0 != a0) a0 = 0.0f;
       if (a1 != a1) a1 = 0.0f;
       st = clipf(a0, -1.0f, 1.0f);
