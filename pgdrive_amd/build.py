@@ -24,9 +24,12 @@ FAST_FP = ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals
 # -Os 22.92, -Os without SLP vectorisation (packed f32 VALU is slower than two scalar ops on this hardware) 22.72.  -Os hoists and
 # batches less: 105 instead of 126 VGPRs, 34.6 instead of 36.6 KB of code for the benchmark kernel; every other kernel is as fast
 # or faster with it (C5 +1 %, 32768 envs +1 %, dense traffic +1 %, top-down unchanged).
+# Round 5, after the records went into piece planes and the image mask out of the one-env kernels: -O2 is ahead again -- metric 17.12 ->
+# 17.08 us, respawn traffic 24.5 -> 24.1, 8 agents 22.1 -> 21.9, 32768 envs 77.1 -> 75.3, ego-only 1024 envs 10.7 -> 9.4 (the general
+# kernels lose 2.7 %; k_observe_env keeps size-optimised code by attribute): profiles/r05_notes.md.
 # SimplifyCFG folds `a && b` into one branch when b costs at most this many speculated instructions (default 1): the kernel spends a
 # fifth of its instructions on exec-mask bookkeeping of divergent branches (221 s_and_saveexec sites -> 195): another 0.9 %.
-OPT = ["-Os", "-fno-slp-vectorize", "-mllvm", "-bonus-inst-threshold=4"]
+OPT = ["-O2", "-fno-slp-vectorize", "-mllvm", "-bonus-inst-threshold=4"]
 
 
 def needs_build():

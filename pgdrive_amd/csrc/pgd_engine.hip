@@ -1316,7 +1316,13 @@ __global__ __launch_bounds__(BLOCK == WAVE ? WAVE * OBS_RPB : BLOCK) void k_obse
 // FIX: the engine runs the default multi-agent configuration (same constants as k_step's instantiation for it, PGD_FIXM_FIELDS)
 // STATE = false: k_step has written the state blocks of the rows that are due (PgdDev::state_rows): the pairwise part only
 template <int NW, bool FIX = false, bool STATE = true>
-__global__ __launch_bounds__(WAVE * NW) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags, int G) {
+// (the library is built at -O2 since the end of round 5; this kernel keeps the size-optimised code it had -- 30.0 against 30.7 us for the
+// 40 seats -- and its specialised instantiations seven waves per SIMD: 72 registers, what -Os gave them unasked; at -O2 they took 82 and
+// the observation 32.6 us)
+#ifndef PGD_KOE_ATTR
+#define PGD_KOE_ATTR __attribute__((minsize))
+#endif
+__global__ PGD_KOE_ATTR __launch_bounds__(WAVE * NW, (FIX ? 7 : 1)) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags, int G) {
   if (FIX) write_fixed_config<true, true, false>(d);
   extern __shared__ unsigned s_minb_dyn[];
   __shared__ ObsEnvLds<NW> M;
