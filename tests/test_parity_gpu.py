@@ -1001,7 +1001,7 @@ def test_throughput_mode_at_32768_envs_properties():
         e.reset(ids[lo:lo + n])
     rng = np.random.default_rng(14)
     n_done = 0
-    worst = 0.0
+    worst = worst_ray = 0.0
     ckpt, tail = None, []
     for t in range(90):
         a = rng.uniform(-1, 1, size=(N, 1, 2)).astype(np.float32)
@@ -1018,7 +1018,12 @@ def test_throughput_mode_at_32768_envs_properties():
             o2, r2, d2, f2 = e.step(act[lo:lo + n].contiguous())
             e.sync()
             assert torch.equal(d1[lo:lo + n], d2) and torch.equal(f1[lo:lo + n], f2), "flags differ from the default mode at step %d" % t
-            worst = max(worst, float((o1[lo:lo + n] - o2).abs().max()), float((r1[lo:lo + n] - r2).abs().max()) * 0.05)
+            dd = (o1[lo:lo + n] - o2).abs()
+            # (the two instantiations contract their multiply-adds differently: the state / navigation / neighbour columns agree to
+            # 2e-6; a ray column may differ by what the ray tolerance against the oracle allows -- since the -O2 build a few beams in
+            # a million do, by up to 1.4e-5 = 0.7 mm at the lidar's 50 m)
+            worst = max(worst, float(dd[..., :34].max()), float((r1[lo:lo + n] - r2).abs().max()) * 0.05)
+            worst_ray = max(worst_ray, float(dd[..., 34:].max()))
         fl = f1.cpu().numpy().astype(np.uint32)[:, 0]
         dn = d1.cpu().numpy()[:, 0]
         term = (fl & (_abi.F_ARRIVE | _abi.F_OUT_OF_ROAD | _abi.F_CRASH_VEHICLE | _abi.F_MAX_STEP)) != 0
@@ -1031,7 +1036,7 @@ def test_throughput_mode_at_32768_envs_properties():
             ckpt = big.get_state()
         if t > 50:
             tail.append((act, o1))
-    assert n_done > 3000 and worst < 2e-6, (n_done, worst)
+    assert n_done > 3000 and worst < 2e-6 and worst_ray < OBS_TOL, (n_done, worst, worst_ray)
     resumed = make(N)
     resumed.reset(ids)
     resumed.set_state(*ckpt)
@@ -1053,7 +1058,9 @@ def test_throughput_mode_at_32768_envs_properties():
     desc = twin.describe_step()
     assert desc.startswith("k_step: one env per wave") and "throughput mode switched off by pgd_set_groups" in desc
     assert "throughput" in big.describe_step() and "switched off" not in big.describe_step()
-    assert torch.equal(twin.done, d_ref) and torch.equal(twin.flags, f_ref) and float((twin.obs - o_ref).abs().max()) < 2e-6
+    dd = (twin.obs - o_ref).abs()
+    assert torch.equal(twin.done, d_ref) and torch.equal(twin.flags, f_ref)
+    assert float(dd[..., :34].max()) < 2e-6 and float(dd[..., 34:].max()) < OBS_TOL  # (state columns / ray columns, as above)
     for e in [big, twin, resumed] + small:
         e.close()
 
