@@ -73,11 +73,24 @@ def algorithmic_bytes(A, T, D):
     return k_step, k_obs, fused
 
 
+PROFILES_DIR = os.path.join(ROOT, "profiles")
+
+
+def library_sha():
+    """The loaded engine library's stamp (pgd_source_sha: sha256 over the sources it was compiled from, pgdrive_amd/build.py); an
+    experimental build outside build.py says "unstamped" and matches no committed profile."""
+    try:
+        from pgdrive_amd import engine
+        return engine.load_library().pgd_source_sha().decode()
+    except Exception:  # noqa: BLE001  (an older PGD_LIB build without the entry point)
+        return "unstamped"
+
+
 def _match_profile(pattern, N, args):
     """Newest profiles/<pattern> whose recorded workload equals this run's (envs / traffic / beams / actions / traffic mode /
-    workload / agents)."""
+    workload / agents).  The caller compares the record's `source_sha` with the loaded library's before it quotes a figure."""
     import glob
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+    for p in sorted(glob.glob(os.path.join(PROFILES_DIR, pattern)), reverse=True):
         try:
             t = json.load(open(p))
         except Exception:
@@ -110,7 +123,7 @@ def issue_model():
     return None, None
 
 
-def make_roofline(prof, stride, work, args, N, A, D):
+def make_roofline(prof, stride, work, args, N, A, D, lib_sha=None):
     """The `roofline` object of a line.  HBM: algorithmic bytes of the dominant kernel / its mean launch time from the HIP events
     (`frac`, the contract's figure) and the bytes the counters saw move (`frac_moved`).  `issue`: the instruction-issue bound of the
     same kernel from its committed SQ_INSTS_* pass and the measured issue rates of tools/issue_rate.hip.  `bound` names what the
@@ -128,6 +141,21 @@ def make_roofline(prof, stride, work, args, N, A, D):
     traffic, traffic_src, traffic_obs = load_traffic(N, args)
     if dom == "k_observe":
         traffic = traffic_obs  # the counters' figure of the observation kernel (multi-agent engines with many slots)
+    # Counter figures are only quoted for the binary they were measured on: every profile summary carries the source stamp of the
+    # library that ran under rocprofv3 (tools/pmc_traffic.py, tools/pmc_insts.py); a pass of another build is reported as stale --
+    # `traffic` / `issue` null -- instead of describing a kernel that is no longer the one timed here
+    lib_sha = lib_sha if lib_sha is not None else library_sha()
+    insts, insts_src = _match_profile("r*_pmc_insts.json", N, args)
+    t_rec, _ = _match_profile("r*_pmc_traffic.json", N, args)
+    prof_sha = (t_rec or {}).get("source_sha") if t_rec else None
+    insts_sha = (insts or {}).get("source_sha") if insts else None
+    stale_why = []
+    if t_rec is not None and prof_sha != lib_sha:
+        stale_why.append("%s was measured on source %s, the loaded library is %s" % (traffic_src, prof_sha or "(unstamped: before round 6)", lib_sha))
+        traffic, traffic_obs = None, None
+    if insts is not None and insts_sha != lib_sha:
+        stale_why.append("%s was measured on source %s, the loaded library is %s" % (insts_src, insts_sha or "(unstamped: before round 6)", lib_sha))
+        insts = None
     # bytes that MOVE per launch: the counters' figure when a pass of this workload is committed, else the formula
     # charged only for the records of vehicles that drove (waiting / removed slots are neither rewritten nor re-read
     # from HBM: reset image); the nominal formula charges all V records read + written
@@ -144,7 +172,6 @@ def make_roofline(prof, stride, work, args, N, A, D):
     # instruction issue: instructions per wave of the dominant kernel (committed SQ_INSTS_* pass of this workload) x waves per
     # SIMD x the time a SIMD needs per wave-instruction at that occupancy and VALU : SALU mix (tools/issue_rate.hip)
     issue = None
-    insts, insts_src = _match_profile("r*_pmc_insts.json", N, args)
     model, model_src = issue_model()
     if insts and model and dom_ms > 0:
         kk = insts.get("k_observe" if dom == "k_observe" else "k_step") or {}
@@ -169,7 +196,9 @@ def make_roofline(prof, stride, work, args, N, A, D):
                 "dependent chain (loads, LDS round trips, exec-dependent VALU) of its slowest waves plus the launch ramp" % (
                     100 * hbm_frac, 100 * issue["frac"])) if bound == "latency" else None
     else:
-        bound, note = "hbm", "no committed instruction pass of this workload: only the HBM figure is available"
+        bound, note = "hbm", ("the committed counter passes of this workload belong to another build (stale): only the HBM figure from "
+                              "this run's own HIP events is available" if stale_why else
+                              "no committed instruction pass of this workload: only the HBM figure is available")
     return {
         "bound": bound, **({"bound_note": note} if note else {}),
         "kernel": dom + (" (observation fused)" if fused else ""),
@@ -185,6 +214,9 @@ def make_roofline(prof, stride, work, args, N, A, D):
             "frac_active": (b_step - 2 * 128 * (args.traffic - work["driving_traffic_mean"])) * N / (dom_ms * 1e-3) / 8e12}
            if (work and "driving_traffic_mean" in work and dom == "k_step" and dom_ms > 0) else {}),
         "issue": issue,
+        # the binary the counter passes belong to against the binary timed here (equal, or `stale` says why the figures are null)
+        "source_sha": lib_sha, "profile_source_sha": prof_sha if t_rec is not None else insts_sha,
+        "stale": bool(stale_why), **({"stale_reason": "; ".join(stale_why)} if stale_why else {}),
         "k_step_ms": prof["k_step_ms"], "k_observe_ms": prof["k_observe_ms"], "events": prof["count"],
         "launches_per_event_group": stride if fused else 1,
     }
@@ -678,7 +710,7 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
                 ", off: --exact" if args.exact else ""),
         }
         out["roofline"] = make_roofline((results.get("replicas") or {}).get("prof"), (results.get("replicas") or {}).get("stride", 1),
-                                        work, args, N, A, D)
+                                        work, args, N, A, D, lib_sha=state.get("lib_sha"))
         return out
     make_line_ref = [make_line]
 
@@ -793,6 +825,10 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
 
     step_kernel = eng.describe_step()  # which k_step instantiation the timed launches were (pgd_describe_step)
     state["step_kernel"] = step_kernel
+    try:
+        state["lib_sha"] = eng.L.pgd_source_sha().decode()  # of the library THIS engine runs on (PGD_LIB builds included)
+    except AttributeError:
+        state["lib_sha"] = "unstamped"
     # how much work a step does at this point of the run: 5 snapshots of the state, 50 untimed steps apart
     work = None
     if args.workload == "c3" and N <= 65536:
@@ -870,7 +906,8 @@ def row_summary(name, line):
         "steps_timed": line["steps_timed"], "warmup_run": line["warmup_run"],
         **{k: c[k] for k in keep if k in c},
         "roofline": {**{k: r.get(k) for k in ("bound", "kernel", "achieved", "frac", "frac_moved", "moved_source", "frac_active", "traffic",
-                                              "traffic_source", "bytes_per_launch", "k_step_ms", "k_observe_ms")},
+                                              "traffic_source", "bytes_per_launch", "k_step_ms", "k_observe_ms", "source_sha",
+                                              "profile_source_sha", "stale")},
                      "issue": ({k: iss.get(k) for k in ("insts_per_wave", "waves_per_simd", "ns_per_inst_per_simd", "bound_us", "frac")}
                                if iss else None)} if r else None,
     }

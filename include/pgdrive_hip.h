@@ -335,6 +335,10 @@ int pgd_set_stream(pgd_handle h, void* hip_stream);
 int pgd_sync(pgd_handle h);
 int pgd_destroy(pgd_handle h);
 const char* pgd_version(void);
+/* Identity of the binary: sha256 (16 hex digits) over the sources it was compiled from, written in by pgdrive_amd/build.py
+ * ("unstamped" for any other build).  Profile summaries under profiles/ carry the same stamp; bench.py quotes a counter pass only
+ * when the stamps agree.  (No reference counterpart: the reference ships no native binary on this path.) */
+const char* pgd_source_sha(void);
 
 /* Top-down (bird's-eye) multi-channel observation: TopDownMultiChannel.observe (obs/top_down_obs_multi_channel.py:18-280) of
  * TopDownPGDriveEnv (envs/top_down_env.py:28-42) as a rasteriser kernel.  Image [N, R, R, 2 + frame_stack] float32 in [0, 1]:

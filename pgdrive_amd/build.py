@@ -32,6 +32,20 @@ FAST_FP = ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals
 OPT = ["-O2", "-fno-slp-vectorize", "-mllvm", "-bonus-inst-threshold=4"]
 
 
+def source_sha():
+    """What a binary of the engine is identified by: sha256 over the sources it is compiled from (csrc/*, include/*, and this file,
+    whose flags are part of the build), first 16 hex digits.  build() compiles it into the library (pgd_source_sha), the profile
+    passes of tools/ stamp their summaries with it, and bench.py only quotes a committed counter pass whose stamp equals the loaded
+    library's (a kernel change without a re-profile must not ship a line whose counters describe another binary)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(os.path.abspath(x) for x in DEPS):
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -50,7 +64,8 @@ def build(force=False, verbose=False, extra=()):
     # after_step, its only user -- compiles to the 9-instruction v_exp_f32 form (1 ulp of 2^x plus the input scaling) instead of
     # the 26-instruction library version; sinf / cosf / atan2f compile to the same code either way.  SF_ENERGY is held to
     # 2e-6 + 2e-5 rel against the fp64 oracle after every teacher-forced step (tests/util.py), measured 0.56 of that.
-    cmd = [hipcc(), "--offload-arch=gfx950", *OPT, "-std=c++17", *FAST_FP, "-shared", "-fPIC", "-o", LIB, SRC] + list(extra)
+    cmd = [hipcc(), "--offload-arch=gfx950", *OPT, "-std=c++17", *FAST_FP, "-shared", "-fPIC",
+           '-DPGD_SOURCE_SHA="%s"' % source_sha(), "-o", LIB, SRC] + list(extra)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1474,6 +1474,10 @@ static int build_reset_image(pgd_engine* h) {
 extern "C" {
 
 const char* pgd_version(void) { return "pgdrive_hip 0.1 (gfx950)"; }
+#ifndef PGD_SOURCE_SHA
+#define PGD_SOURCE_SHA "unstamped"  // (an experimental build outside pgdrive_amd/build.py: no committed counter pass is its own)
+#endif
+const char* pgd_source_sha(void) { return PGD_SOURCE_SHA; }
 
 int pgd_obs_dim(const pgd_config* c) {
   const int toll = (c->marl_flags & PGD_MA_TOLLGATE) != 0;

@@ -44,6 +44,7 @@ _SIGS = {
     "pgd_sync": (C.c_int, [C.c_void_p]),
     "pgd_destroy": (C.c_int, [C.c_void_p]),
     "pgd_version": (C.c_char_p, []),
+    "pgd_source_sha": (C.c_char_p, []),
     "pgd_gather_create": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_void_p)]),
     "pgd_gather_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "pgd_gather_export": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -1,4 +1,5 @@
 """Host-side mirror of the reference's env surface that does not need a GPU: config merging, spaces, gym ids, sharding."""
+import json
 import numpy as np
 import pytest
 
@@ -189,3 +190,52 @@ def test_nested_config_update_rules():
         merge_config(base, {"aa": {"bb": {"dd": 101}}})
     c = merge_config({"aa": {"bb": {"cc": 100, "dd": 1}}}, {"aa": {"bb": {"dd": 101}}})
     assert c["aa"]["bb"] == {"cc": 100, "dd": 101}
+
+
+def test_touched_source_makes_the_roofline_say_stale(tmp_path, monkeypatch):
+    """the counter figures of the bench line (`roofline.traffic`, `roofline.issue`) come from committed
+    rocprofv3 passes; every pass is stamped with the sha of the sources its binary was built from (pgdrive_amd/build.py
+    source_sha, compiled into the library as pgd_source_sha).  A pass whose stamp equals the library's is quoted; touch a source and
+    the same pass is reported as stale, figures null."""
+    import bench
+    from pgdrive_amd import build
+    src = tmp_path / "kernel.hip"
+    src.write_text("// step kernel, version 1\n")
+    monkeypatch.setattr(build, "DEPS", [str(src)])
+    sha1 = build.source_sha()
+    assert len(sha1) == 16 and sha1 == build.source_sha()
+    prof_dir = tmp_path / "profiles"
+    prof_dir.mkdir()
+    wl = dict(envs=4096, traffic=16, lasers=240, actions="uniform", traffic_mode="trigger", workload="c3", agents=1)
+    (prof_dir / "r06_head_pmc_traffic.json").write_text(json.dumps(dict(wl, bytes_per_launch=18.0e6, source_sha=sha1)))
+    (prof_dir / "r06_head_pmc_insts.json").write_text(json.dumps(dict(
+        wl, source_sha=sha1, k_step=dict(insts_per_wave=2000.0, waves_per_launch=4096, valu=1300.0, salu=650.0, lds=50.0, vmem=60.0, smem=40.0))))
+    (prof_dir / "r06_issue_rate.json").write_text(json.dumps(dict(
+        clock_ghz=2.4, mixes=[dict(name="2 VALU : 1 SALU", valu_per_salu=2.0, ns_per_inst_per_simd={"4": 0.885})])))
+    monkeypatch.setattr(bench, "PROFILES_DIR", str(prof_dir))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    args = bench.parse_args([])
+    prof = dict(k_step_ms=0.017, k_observe_ms=0.0, count=100)
+    r = bench.make_roofline(prof, 64, None, args, 4096, 1, 274, lib_sha=build.source_sha())
+    assert r["stale"] is False and r["traffic"] == 18.0e6 and r["issue"] is not None
+    assert r["source_sha"] == r["profile_source_sha"] == sha1 and r["frac_moved"] is not None
+    # a kernel change without a re-profile
+    src.write_text("// step kernel, version 2\n")
+    sha2 = build.source_sha()
+    assert sha2 != sha1
+    r2 = bench.make_roofline(prof, 64, None, args, 4096, 1, 274, lib_sha=sha2)
+    assert r2["stale"] is True and r2["traffic"] is None and r2["issue"] is None
+    assert r2["source_sha"] == sha2 and r2["profile_source_sha"] == sha1 and sha1 in r2["stale_reason"]
+    assert r2["frac"] == r["frac"]  # the contract's figure comes from this run's own HIP events either way
+    # a pass from before the stamps existed (rounds 1 - 5) is stale by construction
+    (prof_dir / "r06_head_pmc_traffic.json").write_text(json.dumps(dict(wl, bytes_per_launch=18.0e6)))
+    r3 = bench.make_roofline(prof, 64, None, args, 4096, 1, 274, lib_sha=sha2)
+    assert r3["stale"] is True and r3["traffic"] is None
+
+
+def test_the_built_library_carries_the_stamp_of_its_sources():
+    """pgd_source_sha of the in-tree library equals build.source_sha() of the tree it was built from (build() passes it as a
+    define); needs the library, not a GPU."""
+    from pgdrive_amd import build, engine
+    build.build()
+    assert engine.load_library().pgd_source_sha().decode() == build.source_sha()

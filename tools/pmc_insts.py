@@ -67,4 +67,9 @@ out = dict(envs=N, traffic=TRAFFIC, lasers=LASERS, actions=ACTIONS, traffic_mode
            note="rocprofv3 --pmc passes (SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES | SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM "
                 "SQ_INSTS_BRANCH | SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY) over `python bench.py --exact --steps 200 "
                 "--warmup 1500` of the row; per-dispatch sums, last quarter of the dispatches, divided by SQ_WAVES")
+# the binary these passes ran on (bench.py quotes the record only for a library with the same stamp)
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from pgdrive_amd import build as _build  # noqa: E402
+out["source_sha"] = os.environ.get("PGD_PROFILE_SHA") or _build.source_sha()
 print(json.dumps(out, indent=1))

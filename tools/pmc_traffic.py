@@ -57,4 +57,9 @@ if ko and ko[0] in write:
     wo = sum(steady(write[ko[0]])) / len(steady(write[ko[0]]))
     out.update(k_observe_kernel=ko[0], k_observe_FETCH_SIZE_KB=fo, k_observe_WRITE_SIZE_KB=wo,
                bytes_per_launch_k_observe=(fo * c_f + wo * out["calibration"]["write_correction_rows"]) * 1024.0)
+# the binary these passes ran on (bench.py quotes the record only for a library with the same stamp)
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from pgdrive_amd import build as _build  # noqa: E402
+out["source_sha"] = os.environ.get("PGD_PROFILE_SHA") or _build.source_sha()
 print(json.dumps(out, indent=1))

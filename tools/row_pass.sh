@@ -25,6 +25,8 @@ python $R/tools/pmc_insts.py $O $N $ACT $MODE $WL $AG $NL $TR > $O/pmc_insts.jso
 rm -rf $O/insts_a $O/insts_b $O/insts_c
 fi
 for f in $(find $O/stats -name "*kernel_stats.csv"); do cp $f $O/kernel_stats.csv; head -3 $f; done
+# the binary the passes ran on (sidecar of the kernel statistics; the pmc summaries carry the same stamp as `source_sha`)
+( cd $R && python -c "from pgdrive_amd import build; print(build.source_sha())" ) > $O/kernel_stats.source_sha
 python $R/tools/pmc_traffic.py $O $N $ACT $MODE $WL $AG $NL $TR > $O/pmc_traffic.json; grep -E "bytes_per_env_step|FETCH_SIZE_KB|WRITE_SIZE_KB|fetch_correction" $O/pmc_traffic.json
 tail -c 400 $O/bench.json; echo
 # keep only the summaries (the raw traces are large)
