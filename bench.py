@@ -618,7 +618,8 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
             if "error" in r:
                 e["error"] = r["error"]
             table[name] = e
-        good = [n for n, e in table.items() if e.get("gather_ok") and "error" not in e]
+        # (a peer pass forced onto coarse-grained memory -- PGD_GATHER_COARSE=1 -- is an A/B figure, never the headline: ADVICE r05)
+        good = [n for n, e in table.items() if e.get("gather_ok") and "error" not in e and e.get("gather_mem") != "coarse"]
         measured = [n for n, e in table.items() if "value" in e]
         best = max(good, key=lambda n: table[n]["value"]) if good else None
         # the headline: the best transport whose self-check passed; without one, a measured transport (gather_ok false says so);

@@ -335,6 +335,13 @@ int pgd_set_stream(pgd_handle h, void* hip_stream);
 int pgd_sync(pgd_handle h);
 int pgd_destroy(pgd_handle h);
 const char* pgd_version(void);
+/* Multi-agent engines remember, per env, which rows of the LAST observation buffer they were given already hold the zeros of a seat
+ * that is not due (identified by the buffer's address and row stride), and do not write them again.  A caller that hands pgd_step
+ * a buffer whose address a FORMER buffer had (a caching allocator re-using a freed block: torch.empty per step) calls this first:
+ * every row that is not due is then written once more.  Asynchronous on the engine's stream.  pgdrive_amd.Engine.step(out=...) calls
+ * it whenever `out` is a tensor it has not seen alive.  (No reference counterpart: the reference returns fresh numpy arrays,
+ * base_env.py:303-344.) */
+int pgd_forget_rows(pgd_handle h);
 /* Identity of the binary: sha256 (16 hex digits) over the sources it was compiled from, written in by pgdrive_amd/build.py
  * ("unstamped" for any other build).  Profile summaries under profiles/ carry the same stamp; bench.py quotes a counter pass only
  * when the stamps agree.  (No reference counterpart: the reference ships no native binary on this path.) */

@@ -2034,6 +2034,12 @@ int pgd_group_sync(pgd_handle h, int group) {
   return PGD_OK;
 }
 
+int pgd_forget_rows(pgd_handle h) {
+  if (!h) return PGD_ERR_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  return obs_rows_forget(h, h->stream);
+}
+
 int pgd_describe_step(pgd_handle h, char* buf, int cap) {
   if (!h || !buf || cap <= 0) return PGD_ERR_ARG;
   snprintf(buf, (size_t)cap, "%s%s", h->last_step_kernel ? h->last_step_kernel : "",

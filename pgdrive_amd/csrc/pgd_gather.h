@@ -122,13 +122,20 @@ int pgd_gather_create(int device, int world, int rank, int n_rows, int row_float
   // Peers write the rows and the flag / ack words of this block over xGMI while kernels of this device poll and read them:
   // fine-grained (device-coherent across agents) memory, as RCCL uses for its own buffers -- ordinary coarse-grained hipMalloc
   // memory is only guaranteed coherent at kernel boundaries, so a polling kernel could keep seeing a stale flag line.
-  // PGD_GATHER_COARSE=1 forces plain hipMalloc (A/B); a runtime that refuses the flag falls back to it as well.
-  // The fallback is REPORTED (pgd_gather_mem_kind; bench.py prints `gather_mem`), not silent.
+  // PGD_GATHER_COARSE=1 forces plain hipMalloc (A/B; reported by pgd_gather_mem_kind, bench.py prints `gather_mem`).
+  // A runtime that refuses the flag makes pgd_gather_create FAIL (PGD_ERR_HIP): polling kernels on coarse memory may hang or read
+  // stale rows, and a caller that can fall back has a better fallback than that (pgdrive_amd/dist.py: the RCCL transports).  Only
+  // the explicit switch runs the protocol on coarse memory (the fallback used to be silent but for `gather_mem`).
   g->fine = 1;
-  if (getenv("PGD_GATHER_COARSE") || hipExtMallocWithFlags((void**)&g->base, g->total_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-    (void)hipGetLastError();
+  if (getenv("PGD_GATHER_COARSE")) {
     g->fine = 0;
     HIPCHK(hipMalloc((void**)&g->base, g->total_bytes));
+  } else if (hipExtMallocWithFlags((void**)&g->base, g->total_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    fprintf(stderr, "pgd_gather_create: the runtime refused %zu bytes of fine-grained memory; the peer transport needs it "
+                    "(PGD_GATHER_COARSE=1 forces coarse-grained memory, at the caller's risk)\n", g->total_bytes);
+    free(g);
+    return PGD_ERR_HIP;
   }
   HIPCHK(hipMemset(g->base, 0, g->total_bytes));
   HIPCHK(hipMalloc((void**)&g->counters, sizeof(int) * 4 * PGD_GATHER_MAX_WORLD));

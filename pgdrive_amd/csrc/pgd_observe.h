@@ -304,7 +304,9 @@ DEV void state_block_one(const PgdDev& d, const MV& mv, const pgd_spawn& sp, con
   }
   navi_info_for(nv0, mv.lane_width(), ag.cur_n, px, py, hx, hy, o + 8);
   navi_info_for(nv1, mv.lane_width(), ag.cur_n, px, py, hx, hy, o + 13);
-  if ((d.D & 1) == 0) {
+  // 8-byte stores only where every row starts on an 8-byte boundary: even row width AND even row stride (pgd_step_packed takes any
+  // stride >= A * (D + 2)) AND an aligned buffer -- the same guard as the lidar fan's pairs_ok
+  if (((d.D | d.ostride) & 1) == 0 && (reinterpret_cast<uintptr_t>(row) & 7) == 0) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) reinterpret_cast<float2*>(row)[k] = make_float2(o[2 * k], o[2 * k + 1]);
   } else {

@@ -27,6 +27,7 @@ _SIGS = {
     "pgd_set_state": (C.c_int, [C.c_void_p] * 4),
     "pgd_observe": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pgd_describe_step": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "pgd_forget_rows": (C.c_int, [C.c_void_p]),
     "pgd_lane_keep_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32]),
     "pgd_topdown_channels": (C.c_int, [C.POINTER(_abi.TopDownConfig)]),
     "pgd_topdown_enable": (C.c_int, [C.c_void_p, C.POINTER(_abi.TopDownConfig)]),
@@ -136,6 +137,7 @@ class Engine:
         self.flags = torch.zeros((self.N, self.A), dtype=torch.int32, device=dev)
         self._bound_stream = self.stream.cuda_stream  # the stream pgd_create was given
         self._own_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in (self.obs, self.reward, self.done, self.flags))
+        self._seen_out = []  # caller-supplied observation tensors of the last steps, kept alive (see step)
         torch.cuda.synchronize(dev)
 
     # -- reference surface ------------------------------------------------------------------------------------------
@@ -162,9 +164,11 @@ class Engine:
         The returned obs IS the engine's buffer (or `out[0]`), not a copy.  Multi-agent engines zero the row of a seat that is not
         due ONCE and remember it per buffer (include/pgdrive_hip.h, pgd_step): a caller that edits the returned rows in place
         (normalisation, clamp_, noise) would see its edits persist in the rows of empty seats -- clone first, or create the engine
-        with PGD_NO_ROWZ=1 in the environment (the zero rows are then rewritten by every call)."""
+        with PGD_NO_ROWZ=1 in the environment (the zero rows are then rewritten by every call).  `out` tensors need not be long-lived
+        or zero-initialised: a tensor the engine has not seen alive makes it forget its marks (pgd_forget_rows) before the step."""
         assert actions.is_cuda and actions.dtype == self.torch.float32 and actions.is_contiguous()
         assert actions.numel() == self.N * self.A * 2
+        forget_first = False
         if out is None:  # the engine's own output buffers: their addresses never change
             obs, reward, done, flags = self.obs, self.reward, self.done, self.flags
             p_obs, p_rew, p_done, p_flags = self._own_ptrs
@@ -172,12 +176,22 @@ class Engine:
             obs, reward, done, flags = out
             p_obs, p_rew, p_done, p_flags = (C.c_void_p(obs.data_ptr()), C.c_void_p(reward.data_ptr()),
                                              C.c_void_p(done.data_ptr()), C.c_void_p(flags.data_ptr()))
+            # The zero-row marks of a multi-agent engine name a buffer by its address: a NEW tensor may sit where a freed one sat
+            # (torch's caching allocator; `out=torch.empty(...)` per step) and would inherit "known zero" marks for rows that hold
+            # anything.  Tensors seen before are kept alive here (their memory cannot be handed out again); any other tensor makes
+            # the engine forget its marks first.
+            if want_obs and self.A > 1 and not any(t is obs for t in self._seen_out):
+                forget_first = True
+                self._seen_out.append(obs)
+                del self._seen_out[:-4]
         # the engine follows the caller's current stream (like a torch op): no events, no cross-stream waits per step;
         # pgd_set_stream orders the hand-over when the stream changes
         cur = self.torch.cuda.current_stream(self.device).cuda_stream
         if cur != self._bound_stream:
             _chk(self.L.pgd_set_stream(self.h, C.c_void_p(cur)), "pgd_set_stream")
             self._bound_stream = cur
+        if forget_first:
+            _chk(self.L.pgd_forget_rows(self.h), "pgd_forget_rows")
         _chk(
             self.L.pgd_step(self.h, C.c_void_p(actions.data_ptr()), p_obs if want_obs else None, p_rew, p_done, p_flags),
             "pgd_step"

@@ -216,6 +216,9 @@ def test_bench_world_8_under_the_drivers_launcher():
     # (one launch per 64 steps against several per step: normally 1 - 2 us against 30 - 120 us of host time per step.  Printed, not
     # asserted: eight ranks share this box's 16 CPUs with their launcher, and a replay behind a descheduled rank has read 122 us)
     print("host enqueue per step: peer+graph %.1f us, peer %.1f us" % (t["peer+graph"]["host_enqueue_us_per_step"], t["peer"]["host_enqueue_us_per_step"]))
+    # ... and a generous bound that a broken replay path (a graph re-instantiated or re-captured per step) would still trip
+    # (the strict comparison had to go, a bound need not)
+    assert t["peer+graph"]["host_enqueue_us_per_step"] <= max(2.0 * t["peer"]["host_enqueue_us_per_step"], 250.0)
     assert d["gather_ok"] is True and d["transport_chosen"] in t and d["gather_mem"] in ("fine", "coarse")
     assert d["value"] == max(e["value"] for e in t.values() if e.get("gather_ok"))
 

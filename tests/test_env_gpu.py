@@ -673,6 +673,40 @@ def test_zero_row_marks_follow_the_buffer_through_graph_replays(agents):
         env.close()
 
 
+@pytest.mark.parametrize("agents", [8, 40])
+def test_zero_row_marks_do_not_survive_a_reused_address(agents):
+    """`Engine.step(out=torch.empty(...))` per step -- torch's caching allocator hands a freed block out again, so a NEW
+    buffer can have the address (and row stride) the marks name.  Engine.step forgets the marks (pgd_forget_rows) for every tensor
+    it has not seen alive: rows of seats that are not due read zero in every fresh, garbage-filled buffer."""
+    import torch
+    from pgdrive_amd import marl_env, _abi
+    env = marl_env.MultiAgentRoundaboutVecEnv(dict(num_envs=64, num_agents=agents, seed=5, horizon=60, delay_done=5))
+    eng = env.engine
+    try:
+        env.reset()
+        N, A, D = 64, eng.A, eng.D
+        g = torch.Generator(device="cuda")
+        g.manual_seed(2)
+        addresses, n_zero = set(), 0
+        for k in range(60):
+            a = torch.rand((N, A, 2), device="cuda", generator=g) * 2 - 1
+            a[..., 1] = a[..., 1].abs()
+            Y = tuple(torch.empty_like(t) for t in (eng.obs, eng.reward, eng.done, eng.flags))
+            Y[0].fill_(7.0)
+            addresses.add(Y[0].data_ptr())
+            obs, _, _, fl = eng.step(a, out=Y)
+            torch.cuda.synchronize()
+            due = (fl.cpu().numpy().astype(np.uint32) & (_abi.F_REPORT | _abi.F_NEW)) != 0
+            rows = obs.cpu().numpy().reshape(N, A, D)
+            assert (rows[~due] == 0.0).all(), "step %d: a row that is not due kept the garbage of a fresh buffer" % k
+            n_zero += int((~due).sum())
+            del Y, obs
+        assert len(addresses) < 60, "the allocator never re-used an address: the test did not exercise the hazard"
+        assert n_zero > 100
+    finally:
+        env.close()
+
+
 def test_env_groups_step_like_one_batch(descs):
     """pgd_set_groups / pgd_step_group: four asynchronous env groups of one handle, each stepped once per round on its own
     stream, produce exactly what a plain engine produces for the whole batch (envs do not interact), through auto-resets;

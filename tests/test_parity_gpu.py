@@ -1002,6 +1002,7 @@ def test_throughput_mode_at_32768_envs_properties():
     rng = np.random.default_rng(14)
     n_done = 0
     worst = worst_ray = 0.0
+    n_ray = n_ray_over = 0
     ckpt, tail = None, []
     for t in range(90):
         a = rng.uniform(-1, 1, size=(N, 1, 2)).astype(np.float32)
@@ -1024,6 +1025,8 @@ def test_throughput_mode_at_32768_envs_properties():
             # a million do, by up to 1.4e-5 = 0.7 mm at the lidar's 50 m)
             worst = max(worst, float(dd[..., :34].max()), float((r1[lo:lo + n] - r2).abs().max()) * 0.05)
             worst_ray = max(worst_ray, float(dd[..., 34:].max()))
+            n_ray += int(dd[..., 34:].numel())
+            n_ray_over += int((dd[..., 34:] > 2e-6).sum())
         fl = f1.cpu().numpy().astype(np.uint32)[:, 0]
         dn = d1.cpu().numpy()[:, 0]
         term = (fl & (_abi.F_ARRIVE | _abi.F_OUT_OF_ROAD | _abi.F_CRASH_VEHICLE | _abi.F_MAX_STEP)) != 0
@@ -1037,6 +1040,9 @@ def test_throughput_mode_at_32768_envs_properties():
         if t > 50:
             tail.append((act, o1))
     assert n_done > 3000 and worst < 2e-6 and worst_ray < OBS_TOL, (n_done, worst, worst_ray)
+    # ... and not only a maximum: the beams on which the two instantiations differ by more than rounding stay a few in a million
+    # (measured 26 of 3.4 M = 7.6e-6 with the -O2 build)
+    assert n_ray > 3_000_000 and n_ray_over <= 2e-5 * n_ray, (n_ray_over, n_ray)
     resumed = make(N)
     resumed.reset(ids)
     resumed.set_state(*ckpt)
