@@ -5,6 +5,11 @@ Importing the package does not touch the GPU; `PGDriveVecEnv` / `PGDriveEnv` / `
 """
 __version__ = "0.1.0"
 
+# pgdrive/__init__.py:1 imports pgdrive.register: the gym ids exist once the package is imported (a no-op without gym)
+from .spaces import register_gym_ids as _register_gym_ids  # noqa: E402
+
+_register_gym_ids()
+
 
 def __getattr__(name):
     if name == "PGDriveVecEnv":

@@ -10,6 +10,7 @@ terminal observation is returned and the user calls reset() — exactly the refe
 import numpy as np
 
 from . import _abi
+from .spaces import EnvBase
 from .vec_env import PGDriveVecEnv
 
 # register.py:5-38
@@ -25,7 +26,7 @@ ENV_IDS = {
 }
 
 
-class PGDriveEnv:
+class PGDriveEnv(EnvBase):  # gym.Env when gym is importable (base_env.py:93), else object: pgdrive_amd/spaces.py
     metadata = {"render.modes": []}
 
     def __init__(self, config=None):

@@ -14,7 +14,7 @@ places at the road starts while fewer than `num_agents` are alive and the episod
 import numpy as np
 
 from . import _abi, bank, mapdata, scenario
-from .spaces import Box, Dict
+from .spaces import Box, Dict, EnvBase
 from .vec_env import merge_config, resolve_map_choice, strip_reference_only_keys
 
 # MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG + MARoundaboutConfig (multi_agent_pgdrive.py:12-55, marl_inout_roundabout.py:15-28)
@@ -319,7 +319,7 @@ class VehicleHandle:
             self._env._static.discard(self.slot)
 
 
-class MultiAgentRoundaboutEnv:
+class MultiAgentRoundaboutEnv(EnvBase):  # (gym.Env when gym is importable, like the reference's MultiAgentPGDrive)
     """Dict protocol of the reference: keys "agent{k}"; done has "__all__" (multi_agent_pgdrive.py:126-150)."""
     VEC = MultiAgentRoundaboutVecEnv
 

@@ -917,3 +917,40 @@ def test_reference_line_contact_and_sidewalk():
         assert first_done is not None and first_done["out_of_road"]
     finally:
         env.close()
+
+
+@pytest.mark.gpu
+def test_gym_make_returns_the_reference_shapes(tmp_path):
+    """VERDICT r05 item 7, on the GPU: with a `gym` on the path (tests/util.py write_fake_gym: this image has none),
+    `gym.make("PGDrive-v0")` builds pgdrive_amd.env.PGDriveEnv with register.py's config, the env is a gym.Env, its spaces are
+    gym's Box(274) / Box(2), and reset / step have the reference's call shapes (base_env.py:184-193, 269-290)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests import util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = util.write_fake_gym(tmp_path)
+    code = """
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+import gym
+import pgdrive_amd
+env = gym.make("PGDrive-v0")
+o = env.reset()
+o2, r, d, info = env.step(np.array([0.0, 1.0], dtype=np.float32))
+print(json.dumps(dict(is_env=isinstance(env, gym.Env), cls=type(env).__name__, seeds=[env.config["start_seed"], env.config["environment_num"]],
+                      obs_space=[type(env.observation_space).__module__, list(env.observation_space.shape)],
+                      act_space=[type(env.action_space).__module__, list(env.action_space.shape)],
+                      o=[list(o.shape), str(o.dtype)], o2=[list(o2.shape), str(o2.dtype)], r=type(r).__name__, d=type(d).__name__,
+                      info=sorted(info)[:3], in_space=bool(env.observation_space.contains(o2)))))
+env.close()
+""" % root
+    env = dict(os.environ, PYTHONPATH=fake + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["is_env"] and d["cls"] == "PGDriveEnv" and d["seeds"] == [1000, 100]
+    assert d["obs_space"] == ["gym.spaces", [274]] and d["act_space"] == ["gym.spaces", [2]]
+    assert d["o"] == [[274], "float32"] and d["o2"] == [[274], "float32"] and d["r"] == "float" and d["d"] == "bool" and d["in_space"]

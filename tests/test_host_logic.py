@@ -239,3 +239,69 @@ def test_the_built_library_carries_the_stamp_of_its_sources():
     from pgdrive_amd import build, engine
     build.build()
     assert engine.load_library().pgd_source_sha().decode() == build.source_sha()
+
+
+_GYM_PROBE = """
+import json, sys
+sys.path.insert(0, %r)
+import gym
+import pgdrive_amd
+from pgdrive_amd import spaces, env, marl_env, vec_env
+reg = gym.envs.registration.registry
+out = dict(
+    gym_found=spaces.GYM is gym,
+    single=issubclass(env.PGDriveEnv, gym.Env) and issubclass(env.SafePGDriveEnv, gym.Env) and issubclass(env.TopDownPGDriveEnv, gym.Env),
+    marl=all(issubclass(getattr(marl_env, n), gym.Env) for n in ("MultiAgentRoundaboutEnv", "MultiAgentIntersectionEnv",
+             "MultiAgentBottleneckEnv", "MultiAgentTollgateEnv", "MultiAgentParkingLotEnv", "MultiAgentPGDrive")),
+    spaces=(spaces.Box is gym.spaces.Box) and (spaces.MultiDiscrete is gym.spaces.MultiDiscrete) and (spaces.Dict is gym.spaces.Dict),
+    ids={k: [str(getattr(v, "entry_point", None) or v["entry_point"]), (getattr(v, "kwargs", None) or v["kwargs"])["config"]]
+         for k, v in (getattr(reg, "env_specs", reg)).items() if k.startswith("PGDrive-")},
+    again=pgdrive_amd.spaces.register_gym_ids(),
+)
+print(json.dumps(out))
+"""
+
+
+def _check_gym_probe(d):
+    assert d["gym_found"] and d["single"] and d["marl"] and d["spaces"]
+    # pgdrive/register.py:5-41: eight ids, each PGDriveEnv(config=dict(start_seed, environment_num))
+    assert d["ids"] == {k: ["pgdrive_amd.env:PGDriveEnv", dict(v)] for k, v in penv.ENV_IDS.items()} and len(d["ids"]) == 8
+    assert d["ids"]["PGDrive-v0"][1] == dict(start_seed=1000, environment_num=100)
+    assert d["again"] == []  # importing twice / calling again registers nothing twice
+
+
+def test_gym_identity_with_a_gym_on_the_path(tmp_path):
+    """with `gym` importable the envs ARE gym.Env subclasses (envs/base_env.py:93), their spaces are gym's, and
+    the eight ids of pgdrive/register.py:5-41 are registered at `import pgdrive_amd`.  This image has no gym: a minimal package of
+    that name (tests/util.py write_fake_gym) goes on the PYTHONPATH of a subprocess -- the decision is made at import."""
+    import os
+    import subprocess
+    import sys
+    from tests import util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = util.write_fake_gym(tmp_path)
+    env = dict(os.environ, PYTHONPATH=fake + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-c", _GYM_PROBE % root], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    _check_gym_probe(json.loads(out.stdout.strip().splitlines()[-1]))
+
+
+def test_gym_identity_with_the_real_gym():
+    """The same with a real gym, where one is installed (skipped here)."""
+    pytest.importorskip("gym")
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _GYM_PROBE % root], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    _check_gym_probe(json.loads(out.stdout.strip().splitlines()[-1]))
+
+
+def test_without_gym_the_stand_ins_keep_the_surface():
+    """No gym on the path (this image): the stand-in spaces, plain classes, nothing registered -- the env surface is unchanged."""
+    if spaces.GYM is not None:
+        pytest.skip("gym is installed")
+    assert penv.PGDriveEnv.__mro__[1] is object and spaces.register_gym_ids() == []
+    b = spaces.Box(-1.0, 1.0, (2, ), np.float32)
+    assert b.contains(np.zeros(2, np.float32)) and not b.contains(np.full(2, 2.0, np.float32))

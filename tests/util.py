@@ -119,3 +119,35 @@ def compare_state(gf, f, mask, worst, skip=()):
 
 def state_failures(worst):
     return {k: round(v, 3) for k, v in worst.items() if v > 1.0}
+
+
+def write_fake_gym(root):
+    """A minimal `gym` package (Env, spaces.Box / MultiDiscrete / Dict, envs.registration.register / make / registry) under `root`:
+    this image has no gym, and the env surface's gym identity (pgdrive_amd/spaces.py) is decided at import -- the tests run a
+    subprocess with `root` on PYTHONPATH.  Not a stand-in for gym's behaviour: just enough surface to see what the package does
+    with a gym it finds."""
+    import os
+    g = os.path.join(str(root), "gym")
+    os.makedirs(os.path.join(g, "envs"), exist_ok=True)
+    open(os.path.join(g, "__init__.py"), "w").write(
+        "class Env:\n    metadata = {}\n    def reset(self):\n        raise NotImplementedError\n"
+        "    def step(self, action):\n        raise NotImplementedError\n"
+        "from . import spaces, envs\nfrom .envs.registration import make, register\n__version__ = '0.0-fake'\n")
+    open(os.path.join(g, "spaces.py"), "w").write(
+        "import numpy as np\n"
+        "class Space:\n    pass\n"
+        "class Box(Space):\n    def __init__(self, low, high, shape=None, dtype=np.float32):\n"
+        "        self.low = np.full(shape, low, dtype=dtype); self.high = np.full(shape, high, dtype=dtype)\n"
+        "        self.shape = tuple(shape); self.dtype = np.dtype(dtype)\n"
+        "    def contains(self, x):\n        x = np.asarray(x); return x.shape == self.shape and bool((x >= self.low).all() and (x <= self.high).all())\n"
+        "class MultiDiscrete(Space):\n    def __init__(self, nvec):\n        self.nvec = np.asarray(nvec); self.shape = self.nvec.shape\n"
+        "class Dict(Space):\n    def __init__(self, spaces):\n        self.spaces = dict(spaces)\n"
+        "    def keys(self):\n        return self.spaces.keys()\n    def __getitem__(self, k):\n        return self.spaces[k]\n")
+    open(os.path.join(g, "envs", "__init__.py"), "w").write("from .registration import registry, register, make\n")
+    open(os.path.join(g, "envs", "registration.py"), "w").write(
+        "import importlib\nregistry = {}\n"
+        "def register(id, entry_point=None, kwargs=None, **more):\n    registry[id] = dict(entry_point=entry_point, kwargs=dict(kwargs or {}))\n"
+        "def make(id, **kw):\n    spec = registry[id]; ep = spec['entry_point']\n"
+        "    if isinstance(ep, str):\n        mod, attr = ep.split(':'); ep = getattr(importlib.import_module(mod), attr)\n"
+        "    return ep(**dict(spec['kwargs'], **kw))\n")
+    return str(root)
