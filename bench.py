@@ -442,9 +442,11 @@ ROWS = [
     ("c3_expert", dict(actions="expert")),
     ("c3_respawn", dict(traffic_mode="respawn")),
     ("c3_expert_respawn", dict(actions="expert", traffic_mode="respawn")),
-    ("c5_8x240", dict(workload="c5", agents=8, lasers=240, warmup=1000, steps=1024)),
-    ("c5_8x72", dict(workload="c5", agents=8, lasers=72, warmup=1000, steps=1024)),
-    ("c5_40x72", dict(workload="c5", agents=40, lasers=72, warmup=1000, steps=2048)),
+    # (the multi-agent rows: windows of 2000 steps = two whole 1000-step agent horizons, so that the three windows see the same mix of
+    # the population's phases -- with 1024-step windows they differed by 10 - 12 %)
+    ("c5_8x240", dict(workload="c5", agents=8, lasers=240, warmup=1000, steps=2000)),
+    ("c5_8x72", dict(workload="c5", agents=8, lasers=72, warmup=1000, steps=2000)),
+    ("c5_40x72", dict(workload="c5", agents=40, lasers=72, warmup=1000, steps=2000)),
     ("c3_32768", dict(envs=32768, warmup=1500, steps=512)),
     # the top-down image observation (TopDownPGDriveEnv: 84 x 84 x 5 floats per env and step instead of the 274-float row): pgd_step
     # without the lidar + pgd_observe_topdown; a write-bound kernel of its own
@@ -893,6 +895,140 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
     return out
 
 
+def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
+    """The closed loop an RL user runs: observation -> policy network -> action -> pgd_step, nothing pre-generated.
+    Policy = the 274-256-256-2 tanh MLP of examples/graph_rollout.py in torch fp32 (hipBLASLt GEMMs + elementwise kernels: the user's
+    code, not the engine's), random weights (seed 0), C3 workload.  Three ways to drive it, same engine configuration:
+      eager        one Python iteration per step: 6 torch launches + pgd_step, 4096 envs
+      graph        4 iterations captured in ONE HIP graph (torch.cuda.graphs), replayed: one host call per 4 steps, 4096 envs
+      groups+graph two env groups of 4096 (pgd_set_groups / pgd_step_group, 8192 envs in the handle), each group's policy + step on
+                   the group's own stream, both captured in one HIP graph: the policy of one group overlaps the step of the other
+    Reported: env-steps/s (median of `windows` windows), us per iteration, the host's enqueue time per step."""
+    import torch
+    from pgdrive_amd import _abi, bank, mapdata, scenario
+    from pgdrive_amd.engine import Engine
+    dev = torch.device("cuda", local_rank)
+    descs = bank.get_descriptions(range(1000, 1000 + args.maps))
+    mb = mapdata.MapBank(descs)
+    sb = scenario.ScenarioBank(descs, [d["seed"] for d in descs], num_agents=1, num_traffic=16, traffic_mode="trigger")
+    torch.manual_seed(0)
+    lin = [torch.nn.Linear(274, 256), torch.nn.Linear(256, 256), torch.nn.Linear(256, 2)]
+    W = [l.weight.detach().t().contiguous().to(dev) for l in lin]
+    B = [l.bias.detach().to(dev) for l in lin]
+
+    def policy(obs2d, act_out2d):  # tanh MLP; the last activation is written straight into the action buffer the step reads
+        h = torch.tanh(torch.addmm(B[0], obs2d, W[0]))
+        h = torch.tanh(torch.addmm(B[1], h, W[1]))
+        torch.tanh(torch.addmm(B[2], h, W[2]), out=act_out2d)
+
+    def engine(n):
+        cfg = _abi.make_config(n, num_agents=1, num_traffic=16, num_lasers=240, auto_reset=1, seed=1234)
+        e = Engine(cfg, mb, sb, device=local_rank)
+        e.reset(np.arange(n) % len(descs))
+        return e
+
+    def timed(run_window, n_env_steps_per_window):
+        wins, enq = [], []
+        for w in range(windows):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            run_window()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            wins.append(t2 - t0)
+            enq.append(t1 - t0)
+        med = int(np.argsort(wins)[len(wins) // 2])
+        return dict(value=n_env_steps_per_window / wins[med], windows=[n_env_steps_per_window / w for w in wins],
+                    window_spread=(max(wins) - min(wins)) / wins[med], us_per_iteration=wins[med] / steps * 1e6,
+                    host_enqueue_us_per_step=enq[med] / steps * 1e6)
+
+    N = 4096
+    out = {"row": "c3_policy", "workload": "C3 closed loop: %d envs x (1 ego + 16 IDM traffic slots) x 240 beams, actions = tanh MLP 274-256-256-2 "
+                                           "(torch fp32, random weights) of the last observation, auto-reset" % N,
+           "unit": "env-steps/s", "steps_timed": steps, "warmup_run": warm, "policy": "torch fp32: 3 x addmm (hipBLASLt) + 3 x tanh per step"}
+    UNROLL = 4
+    try:
+        with torch.no_grad():
+            eng = engine(N)
+            act = torch.zeros((N, 1, 2), dtype=torch.float32, device=dev)
+            obs2d, act2d = eng.obs.view(N, -1), act.view(N, 2)
+
+            def iteration():
+                policy(obs2d, act2d)
+                eng.step(act)
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for _ in range(warm):
+                    iteration()
+                torch.cuda.synchronize(dev)
+                out["eager"] = timed(lambda: [iteration() for _ in range(steps)], N * steps)
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize(dev)
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(UNROLL):
+                    iteration()
+            torch.cuda.synchronize(dev)
+            for _ in range(8):
+                g.replay()
+            out["graph"] = dict(timed(lambda: [g.replay() for _ in range(steps // UNROLL)], N * steps), steps_per_replay=UNROLL)
+            f_, i_, _e = eng.get_state()
+            out["ego_speed_kmh_mean"] = float(np.abs(f_[_abi.SF["SPEED"]][:, 0]).mean() * 3.6)
+            out["driving_traffic_mean"] = float((i_[_abi.SI["STATUS"]][:, 1:] == _abi.ST_ACTIVE).sum(axis=1).mean())
+            out["step_kernel"] = eng.describe_step()
+            del g
+            eng.close()
+    except Exception as ex:  # noqa: BLE001
+        out["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+    try:
+        with torch.no_grad():
+            G = 2
+            eng = engine(G * N)
+            eng.set_groups(G)
+            act = torch.zeros((G * N, 1, 2), dtype=torch.float32, device=dev)
+            views = [(eng.obs[eng.group_slice(k)].view(N, -1), act[eng.group_slice(k)].view(N, 2)) for k in range(G)]
+            gs = eng.group_streams
+
+            def iteration_groups():
+                for k in range(G):
+                    with torch.cuda.stream(gs[k]):
+                        policy(*views[k])
+                        eng.step_group(k, act)
+
+            def join(cur):
+                for k in range(G):
+                    cur.wait_stream(gs[k])
+            cur = torch.cuda.current_stream(dev)
+            for k in range(G):
+                gs[k].wait_stream(cur)
+            for _ in range(warm):
+                iteration_groups()
+            join(cur)
+            torch.cuda.synchronize(dev)
+            s = torch.cuda.Stream(device=dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                for k in range(G):  # fork: the group streams join the capture
+                    gs[k].wait_stream(s)
+                for _ in range(UNROLL):
+                    iteration_groups()
+                join(s)
+            torch.cuda.synchronize(dev)
+            for _ in range(8):
+                g.replay()
+            out["groups_graph"] = dict(timed(lambda: [g.replay() for _ in range(steps // UNROLL)], G * N * steps), steps_per_replay=UNROLL,
+                                       env_groups=G, envs=G * N,
+                                       note="one iteration = both groups stepped once (%d env-steps)" % (G * N))
+            del g
+            eng.close()
+    except Exception as ex:  # noqa: BLE001
+        out["groups_graph"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+    best = max((out[k]["value"] for k in ("eager", "graph", "groups_graph") if isinstance(out.get(k), dict) and "value" in out[k]), default=None)
+    out["value"] = best
+    return out
+
+
 def row_summary(name, line):
     """The part of a row's line that goes into `rows` of the headline."""
     r = line.get("roofline") or {}
@@ -956,6 +1092,12 @@ def run_rank(args, rank, world, local_rank):
                 rows.append(row_summary(name, measure(ra, 0, 1, local_rank, with_cpu_baseline=False)))
             except Exception as ex:  # noqa: BLE001  (a row that fails must not take the metric's line with it)
                 rows.append({"row": name, "error": "%s: %s" % (type(ex).__name__, str(ex)[:200])})
+        # the closed loop with a policy network in it (not a `measure` workload: the actions come from the observation)
+        if want is None or "c3_policy" in want:
+            try:
+                rows.append(measure_policy(args, local_rank))
+            except Exception as ex:  # noqa: BLE001
+                rows.append({"row": "c3_policy", "error": "%s: %s" % (type(ex).__name__, str(ex)[:200])})
         out["rows"] = rows
     if rank == 0:
         print(json.dumps(out), flush=True)

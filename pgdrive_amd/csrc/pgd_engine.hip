@@ -172,17 +172,33 @@ DEV void step_sync() { row_sync<true>(); }
 // use -- the scalar registers are full, and a fetch right before its use costs its whole latency (profiles/r03_notes.md).
 // pgd_step picks the instantiation only when fix_config_matches() holds, so its results are those of the general kernel.
 #define PGD_FIX_V 17
+// The single-agent instantiations differ in a handful of values: what varies lives in a FixSpec, one per FIX number (round 6: the
+// configurations the shipped env classes produce no longer fall back to the general kernel, 12 % behind -- VERDICT r05 item 3).
+//   FIX 1  PGDriveEnv defaults (pgdrive_env.py:22-109), default reward scheme folded
+//   FIX 2  the same geometry, reward scheme read at run time
+//   FIX 3  the top-down envs (envs/top_down_env.py:8-72: "Remove lidar" -- no beams, no neighbour block: the row = the 18 state floats), default reward
+//   FIX 4  SafePGDriveEnv (envs/safe_pgdrive_env.py:9-26): 16 traffic + 40 object slots, one lane per slot, crashes are costs
+//          (safe_rl_env), reward scheme at run time (cost_to_reward moves the penalties)
+struct FixSpec {
+  int V, lasers, others, D, safe;
+  bool reward;   // the default reward scheme is folded as well
+  bool lidar50;  // the lidar reaches 50 m (folded only where there is a lidar)
+};
+constexpr FixSpec fix_spec(int fix) {
+  // (lidar off: LidarStateObservation leaves out the neighbour block with the cloud, state_obs.py:124-130 -- the row is the 18 state floats)
+  return fix == 3 ? FixSpec{PGD_FIX_V, 0, 0, 18, 0, true, false}
+         : fix == 4 ? FixSpec{1 + 16 + 40, 240, 4, 274, 1, false, true}
+         : FixSpec{PGD_FIX_V, 240, 4, 274, 0, fix == 1, true};
+}
 // one list for the device (assignment) and the host (test): F(field, value)
-#define PGD_FIX_FIELDS(F, d, c, one_env)                                                                                            \
-  F(d.V, PGD_FIX_V) F(d.A, 1) F(d.T, PGD_FIX_V - 1) F(d.D, 274) F(d.sstride, PGD_FIX_V) F(d.use_imask, (one_env ? 0 : 1))                      \
-  F(d.sub, (one_env ? WAVE / PGD_FIX_V : 1)) F(d.epw, (one_env ? 1 : WAVE / PGD_FIX_V)) F(d.pack_obs, (one_env ? 0 : 1))             \
-  F(c.num_agents, 1) F(c.num_traffic, PGD_FIX_V - 1) F(c.num_lasers, 240) F(c.num_others, 4) F(c.lidar_dist, 50.0f)                 \
-  F(c.dt, 0.02f) F(c.decision_repeat, 5) F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0)                     \
+#define PGD_FIX_FIELDS(F, d, c, one_env, SP)                                                                                        \
+  F(d.V, SP.V) F(d.A, 1) F(d.T, SP.V - 1) F(d.D, SP.D) F(d.sstride, SP.V) F(d.use_imask, (one_env ? 0 : 1))                      \
+  F(d.sub, (one_env ? WAVE / SP.V : 1)) F(d.epw, (one_env ? 1 : WAVE / SP.V)) F(d.pack_obs, (one_env ? 0 : 1))             \
+  F(c.num_agents, 1) F(c.num_traffic, SP.V - 1) F(c.num_lasers, SP.lasers) F(c.num_others, SP.others)                                     \
+  F(c.dt, 0.02f) F(c.decision_repeat, 5) F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, SP.safe)               \
   F(c.enable_reverse, 0) F(c.marl_flags, 0) F(c.side_lasers, 0) F(c.lane_line_lasers, 0)                                            \
   F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f) F(c.idm_agent, 0)
-// ... and the default reward scheme (pgdrive_env.py:91-101).  Engines that keep the default geometry but train on their own
-// reward run the instantiation with only the list above compiled in (FIX == 2: 2 % slower than the full one, 6 % faster than the
-// general kernel).
+#define PGD_FIX_LIDAR_FIELDS(F, c) F(c.lidar_dist, 50.0f)
 #define PGD_FIX_REWARD_FIELDS(F, c)                                                                                                 \
   F(c.use_lateral, 0) F(c.out_of_route_done, 0) F(c.success_reward, 10.0f) F(c.out_of_road_penalty, 5.0f)                           \
   F(c.crash_vehicle_penalty, 5.0f) F(c.crash_object_penalty, 5.0f) F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f)
@@ -208,7 +224,8 @@ DEV void step_sync() { row_sync<true>(); }
   F(c.use_lateral, 0) F(c.out_of_route_done, 0) F(c.success_reward, 10.0f) F(c.out_of_road_penalty, 5.0f)                           \
   F(c.crash_vehicle_penalty, 5.0f) F(c.crash_object_penalty, 5.0f) F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f)               \
   F(c.side_lasers, 0) F(c.lane_line_lasers, 0) F(c.random_agent_model, 0) F(c.idm_agent, 0)
-enum { FIXK_DEFAULT = 0, FIXK_MARL = 1, FIXK_EGO_ONLY = 2, FIXK_GEOMETRY = 3 };
+enum { FIXK_DEFAULT = 0, FIXK_MARL = 1, FIXK_EGO_ONLY = 2, FIXK_GEOMETRY = 3, FIXK_NO_LIDAR = 4, FIXK_SAFE = 5 };
+constexpr int fix_of_kind(int kind) { return kind == FIXK_GEOMETRY ? 2 : kind == FIXK_NO_LIDAR ? 3 : kind == FIXK_SAFE ? 4 : 1; }
 template <bool ONE_ENV, bool MARL, bool STD, int FIX = 1>
 DEV void write_fixed_config(PgdDev& d) {
   pgd_config& c = d.cfg;
@@ -216,8 +233,10 @@ DEV void write_fixed_config(PgdDev& d) {
   if (MARL) { PGD_FIXM_FIELDS(PGD_F_SET, d, c) }
   else if (!ONE_ENV && !STD) { PGD_FIXE_FIELDS(PGD_F_SET, d, c) }
   else {
-    PGD_FIX_FIELDS(PGD_F_SET, d, c, ONE_ENV)
-    if (FIX == 1) { PGD_FIX_REWARD_FIELDS(PGD_F_SET, c) }
+    constexpr FixSpec SP = fix_spec(FIX);
+    PGD_FIX_FIELDS(PGD_F_SET, d, c, ONE_ENV, SP)
+    if (SP.lidar50) { PGD_FIX_LIDAR_FIELDS(PGD_F_SET, c) }
+    if (SP.reward) { PGD_FIX_REWARD_FIELDS(PGD_F_SET, c) }
   }
 #undef PGD_F_SET
 }
@@ -228,8 +247,10 @@ static bool fix_config_matches(const PgdDev& d, bool one_env, int kind = FIXK_DE
   if (kind == FIXK_MARL) { PGD_FIXM_FIELDS(PGD_F_TEST, d, c) }
   else if (kind == FIXK_EGO_ONLY) { PGD_FIXE_FIELDS(PGD_F_TEST, d, c) }
   else {
-    PGD_FIX_FIELDS(PGD_F_TEST, d, c, one_env)
-    if (kind != FIXK_GEOMETRY) { PGD_FIX_REWARD_FIELDS(PGD_F_TEST, c) }
+    const FixSpec SP = fix_spec(fix_of_kind(kind));
+    PGD_FIX_FIELDS(PGD_F_TEST, d, c, one_env, SP)
+    if (SP.lidar50) { PGD_FIX_LIDAR_FIELDS(PGD_F_TEST, c) }
+    if (SP.reward) { PGD_FIX_REWARD_FIELDS(PGD_F_TEST, c) }
   }
 #undef PGD_F_TEST
   return ok;
@@ -276,7 +297,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   XMARK(99);
   Veh r;
   RouteCtx ctx{0.0f, 1.0f, 0, -1};  // of this lane's vehicle if it is an agent: refreshed by every after_step_vehicle
-  using MV = typename std::conditional<FIX != 0, MapViewPre, MapView>::type;
+  using MV = typename std::conditional<FIX != 0 && !OBJ, MapViewPre, MapView>::type;
   MV mv;
   const pgd_spawn* sp = nullptr;
   // The scalar part of the slot's spawn record (dimensions, drive parameters, trigger group, destination: its first 64 bytes) is
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // single-agent engines: a slot keeps the spawn record of its own index (only a multi-agent respawn hands a slot another one; a
   // state set by hand may: checked below) -- the head's address follows from the scenario id like the record's, and its reads travel
   // with the record's instead of waiting for them (17.48 -> 17.40 us on the metric's row, now that the records' reads are short)
-  constexpr bool EARLY_HEAD = !MARL && REGSP && FIX != 0;  // (the general kernels have no registers for it: 19.5 -> 19.9 us there)
+  constexpr bool EARLY_HEAD = !MARL && REGSP && FIX != 0 && !OBJ;  // (the general kernels have no registers for it: 19.5 -> 19.9 us there; nor has the object kernel)
   if (EARLY_HEAD && valid) { sp = d.spawns + (size_t)scen * d.sstride + s; spawn_head_load<false>(sp, sl); }
   const int key0 = valid ? (r.status ^ (r.vflags << 3)) : 0;  // what a vehicle that does not drive can change: status, flags
   // the env's counters.  The multi-agent kernels are out of scalar registers: read here, the compiler fetched the words one after the
@@ -613,7 +634,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     // several agents: the line / sidewalk test runs as a phase of its own (below), where the localisation's boxes and lane
     // records are no longer live -- inside after_step it pushed the multi-agent kernel 66 registers over the 128 it may use
     // the destination lane of an agent (arrive test of reward_done) is known from its spawn record: read before the localisation
-    if (REGSP && FIX && s < A) FL = mv.lanes[SPV.dest_lane];
+    if (REGSP && FIX && !OBJ && s < A) FL = mv.lanes[SPV.dest_lane];
     after_step_vehicle<ONE_ENV>(d.cfg, mv, g, *sp, SPV, r, s < A, !one_env, ctx);
     if (s >= A && (r.vflags & PGD_F_OFF_LANE)) r.status = ST_REMOVED;
   }
@@ -683,7 +704,7 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   float my_rew = 0.0f;
   const bool was_active = acting;  // status at the start of the step (after the delay-done countdown)
   if (valid && s < A && !marl) {
-    if (r.status == ST_ACTIVE) my_rew = reward_done<false>(d, mv, SPV, dest_lane_ref<REGSP && FIX != 0>(FL, mv.lanes, SPV.dest_lane), r, ctx, my_fl, my_dn);
+    if (r.status == ST_ACTIVE) my_rew = reward_done<false>(d, mv, SPV, dest_lane_ref<REGSP && FIX != 0 && !OBJ>(FL, mv.lanes, SPV.dest_lane), r, ctx, my_fl, my_dn);
     if (d.cfg.horizon > 0 && ep_steps >= d.cfg.horizon) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }
     if (sc->max_steps > 0 && ep_steps >= sc->max_steps) { my_dn = true; my_fl |= PGD_F_MAX_STEP; }  // auto_termination
     r.eprew += my_rew;
@@ -1909,6 +1930,13 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
     const bool std_obs = c.side_lasers == 0 && c.lane_line_lasers == 0 && !c.random_agent_model &&
                          c.lidar_gaussian_noise <= 0.0f && c.lidar_dropout_prob <= 0.0f;
     kern = h->has_objects ? k_step<true, false, true> : (std_obs ? k_step<true, false, false, true> : k_step<true, false, false>);
+    if (h->has_objects && std_obs && !h->no_fix && fix_config_matches(dv, true, FIXK_SAFE)) {
+      kern = k_step<true, false, true, true, 4>;
+      kname = "k_step: one env per wave, specialised for the SafePGDriveEnv configuration (16 traffic + 40 object slots, run-time reward scheme)";
+    } else if (!h->has_objects && std_obs && !h->no_fix && fix_config_matches(dv, true, FIXK_NO_LIDAR)) {
+      kern = k_step<true, false, false, true, 3>;
+      kname = "k_step: one env per wave, specialised for the top-down envs' configuration (single agent, lidar off)";
+    } else
     if (!h->has_objects && std_obs && !h->no_fix && fix_config_matches(dv, true)) {
       kern = k_step<true, false, false, true, 1>;
       kname = "k_step: one env per wave, specialised for the default single-agent configuration";

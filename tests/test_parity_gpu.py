@@ -198,6 +198,60 @@ def test_default_configuration_kernel_matches_the_general_kernel(descs, monkeypa
     assert ("throughput mode" in fix.describe_step()) == (pack == "1")
 
 
+@pytest.mark.parametrize("variant", ["top_down", "safe"])
+def test_env_class_instantiations_match_the_general_kernel(descs, monkeypatch, variant):
+    """Round 6: the configurations the shipped env classes produce besides the default one have their own
+    instantiations of k_step -- the top-down envs' (envs/top_down_env.py:8-72: lidar off, the row is the 18 state floats)
+    and SafePGDriveEnv's (envs/safe_pgdrive_env.py:9-26: 16 traffic + 40 object slots, crashes are costs).  Same protocol as the
+    default configuration's test: against the general kernel (PGD_NO_FIX=1) from the same state with the same actions, flags / done /
+    integer state bit-identical, floats to rounding; pgd_describe_step names the instantiation; a neighbouring configuration (another
+    slot count) still gets the general kernel."""
+    n_envs = 65
+    kw = dict(seed=3, resample_scenario=1)
+    if variant == "top_down":
+        kw.update(num_lasers=0)
+        other_kw = dict(kw, num_traffic=12)
+        name = "specialised for the top-down envs"
+    else:
+        kw.update(num_traffic=56, accident_prob=0.8, safe_rl_env=True, density=0.05, use_lateral=False)
+        other_kw = dict(kw, num_traffic=46)
+        name = "specialised for the SafePGDriveEnv"
+    monkeypatch.delenv("PGD_NO_FIX", raising=False)
+    torch, fix, _, _ = _engines(descs, n_envs, n_maps=16, **kw)
+    _, other, _, _ = _engines(descs, n_envs, n_maps=16, **other_kw)
+    monkeypatch.setenv("PGD_NO_FIX", "1")
+    _, gen, _, _ = _engines(descs, n_envs, n_maps=16, **kw)
+    ids = np.arange(n_envs) % 16
+    fix.reset(ids); gen.reset(ids); other.reset(ids)
+    rng = np.random.default_rng(22)
+    n_done = n_obj = 0
+    for t in range(300):
+        act = util.driving_actions(rng, n_envs)
+        if t % 4 == 0:
+            act[::3, 0, :] = 1.0
+        f, i, ei = gen.get_state()
+        fix.set_state(f, i, ei)
+        a = torch.from_numpy(act).to(gen.device)
+        o1, r1, d1, f1 = [x.clone() for x in gen.step(a)]
+        o2, r2, d2, f2 = [x.clone() for x in fix.step(a)]
+        gen.sync(); fix.sync()
+        assert torch.equal(d1, d2) and torch.equal(f1, f2), "flags differ at step %d" % t
+        assert float((o1 - o2).abs().max()) < 2e-6 and float((r1 - r2).abs().max()) < 2e-5
+        g1, i1, e1 = gen.get_state()
+        g2, i2, e2 = fix.get_state()
+        assert (i1 == i2).all() and (e1 == e2).all(), "integer state differs at step %d" % t
+        assert np.abs(g1 - g2).max() < 1e-4
+        n_done += int(d1.sum())
+        n_obj += int(((f1 & _abi.F_CRASH_OBJECT) != 0).sum())
+    assert n_done > 10 and (variant != "safe" or n_obj > 0)
+    other.step(torch.from_numpy(util.driving_actions(rng, n_envs)).to(other.device)); other.sync()
+    assert name in fix.describe_step(), fix.describe_step()
+    assert "specialised" not in gen.describe_step() and "specialised" not in other.describe_step()
+    assert fix.D == (18 if variant == "top_down" else 274)
+    for e in (fix, gen, other):
+        e.close()
+
+
 def test_default_multi_agent_kernel_matches_the_general_kernel(monkeypatch):
     """Multi-agent engines with the scalar fields of MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG get their own instantiation of k_step (those
     fields are compile-time constants in it; agent count, spawn places and horizon stay run-time values).  Against the general
