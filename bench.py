@@ -897,13 +897,17 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
 
 def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
     """The closed loop an RL user runs: observation -> policy network -> action -> pgd_step, nothing pre-generated.
-    Policy = the 274-256-256-2 tanh MLP of examples/graph_rollout.py in torch fp32 (hipBLASLt GEMMs + elementwise kernels: the user's
-    code, not the engine's), random weights (seed 0), C3 workload.  Three ways to drive it, same engine configuration:
-      eager        one Python iteration per step: 6 torch launches + pgd_step, 4096 envs
+    Policy = the 274-256-256-2 tanh MLP of examples/graph_rollout.py (the shape of the reference's PPO expert,
+    examples/ppo_expert/numpy_expert.py), random weights (seed 0), C3 workload.  Two implementations of the same network --
+      torch   fp32 torch ops (3 x addmm on hipBLASLt + 3 x tanh: six dependent launches per step; the user's unchanged code)
+      fused   pgd_mlp_policy: the engine's one-launch MLP (f32 matrix cores, activations in LDS: pgdrive_amd/csrc/pgd_policy.h)
+    -- and three ways to drive them, same engine configuration:
+      eager        one Python iteration per step, 4096 envs
       graph        4 iterations captured in ONE HIP graph (torch.cuda.graphs), replayed: one host call per 4 steps, 4096 envs
-      groups+graph two env groups of 4096 (pgd_set_groups / pgd_step_group, 8192 envs in the handle), each group's policy + step on
-                   the group's own stream, both captured in one HIP graph: the policy of one group overlaps the step of the other
-    Reported: env-steps/s (median of `windows` windows), us per iteration, the host's enqueue time per step."""
+      groups_graph two env groups of 4096 (pgd_set_groups / pgd_step_group, 8192 envs in the handle), each group's policy + step
+                   captured in its own single-stream HIP graph on the group's stream and replayed side by side: the policy of one
+                   group overlaps the step of the other (one graph over both streams costs HIP 4 us of host time per node: measured)
+    Reported per variant: env-steps/s (median of `windows` windows), us per iteration, the host's enqueue time per step."""
     import torch
     from pgdrive_amd import _abi, bank, mapdata, scenario
     from pgdrive_amd.engine import Engine
@@ -914,9 +918,10 @@ def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
     torch.manual_seed(0)
     lin = [torch.nn.Linear(274, 256), torch.nn.Linear(256, 256), torch.nn.Linear(256, 2)]
     W = [l.weight.detach().t().contiguous().to(dev) for l in lin]
-    B = [l.bias.detach().to(dev) for l in lin]
+    B = [l.bias.detach().contiguous().to(dev) for l in lin]
+    weights = (W[0], B[0], W[1], B[1], W[2], B[2])
 
-    def policy(obs2d, act_out2d):  # tanh MLP; the last activation is written straight into the action buffer the step reads
+    def policy_torch(obs2d, act_out2d):  # tanh MLP; the last activation is written straight into the action buffer the step reads
         h = torch.tanh(torch.addmm(B[0], obs2d, W[0]))
         h = torch.tanh(torch.addmm(B[1], h, W[1]))
         torch.tanh(torch.addmm(B[2], h, W[2]), out=act_out2d)
@@ -943,89 +948,96 @@ def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
                     window_spread=(max(wins) - min(wins)) / wins[med], us_per_iteration=wins[med] / steps * 1e6,
                     host_enqueue_us_per_step=enq[med] / steps * 1e6)
 
-    N = 4096
+    N, UNROLL, G = 4096, 4, 2
     out = {"row": "c3_policy", "workload": "C3 closed loop: %d envs x (1 ego + 16 IDM traffic slots) x 240 beams, actions = tanh MLP 274-256-256-2 "
-                                           "(torch fp32, random weights) of the last observation, auto-reset" % N,
-           "unit": "env-steps/s", "steps_timed": steps, "warmup_run": warm, "policy": "torch fp32: 3 x addmm (hipBLASLt) + 3 x tanh per step"}
-    UNROLL = 4
-    try:
-        with torch.no_grad():
-            eng = engine(N)
-            act = torch.zeros((N, 1, 2), dtype=torch.float32, device=dev)
-            obs2d, act2d = eng.obs.view(N, -1), act.view(N, 2)
+                                           "(fp32, random weights) of the last observation, auto-reset" % N,
+           "unit": "env-steps/s", "steps_timed": steps, "warmup_run": warm,
+           "policy": {"torch": "3 x addmm (hipBLASLt) + 3 x tanh per step, fp32", "fused": "pgd_mlp_policy: one launch, f32 MFMA (v_mfma_f32_16x16x4_f32)"}}
+    for impl in ("torch", "fused"):
+        res = {}
+        try:  # one engine of 4096 envs: eager, then 4 iterations per HIP graph
+            with torch.no_grad():
+                eng = engine(N)
+                act = torch.zeros((N, 1, 2), dtype=torch.float32, device=dev)
+                obs2d, act2d = eng.obs.view(N, -1), act.view(N, 2)
 
-            def iteration():
-                policy(obs2d, act2d)
-                eng.step(act)
-            s = torch.cuda.Stream(device=dev)
-            s.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(s):
-                for _ in range(warm):
-                    iteration()
-                torch.cuda.synchronize(dev)
-                out["eager"] = timed(lambda: [iteration() for _ in range(steps)], N * steps)
+                def iteration():
+                    if impl == "torch":
+                        policy_torch(obs2d, act2d)
+                    else:
+                        eng.mlp_policy(weights, act, final_tanh=True)
+                    eng.step(act)
+                s = torch.cuda.Stream(device=dev)
+                s.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(s):
+                    for _ in range(warm):
+                        iteration()
+                    torch.cuda.synchronize(dev)
+                    res["eager"] = timed(lambda: [iteration() for _ in range(steps)], N * steps)
+                    torch.cuda.synchronize(dev)
                 g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    for _ in range(UNROLL):
+                        iteration()
                 torch.cuda.synchronize(dev)
-            with torch.cuda.graph(g, stream=s):
-                for _ in range(UNROLL):
-                    iteration()
-            torch.cuda.synchronize(dev)
-            for _ in range(8):
-                g.replay()
-            out["graph"] = dict(timed(lambda: [g.replay() for _ in range(steps // UNROLL)], N * steps), steps_per_replay=UNROLL)
-            f_, i_, _e = eng.get_state()
-            out["ego_speed_kmh_mean"] = float(np.abs(f_[_abi.SF["SPEED"]][:, 0]).mean() * 3.6)
-            out["driving_traffic_mean"] = float((i_[_abi.SI["STATUS"]][:, 1:] == _abi.ST_ACTIVE).sum(axis=1).mean())
-            out["step_kernel"] = eng.describe_step()
-            del g
-            eng.close()
-    except Exception as ex:  # noqa: BLE001
-        out["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
-    try:
-        with torch.no_grad():
-            G = 2
-            eng = engine(G * N)
-            eng.set_groups(G)
-            act = torch.zeros((G * N, 1, 2), dtype=torch.float32, device=dev)
-            views = [(eng.obs[eng.group_slice(k)].view(N, -1), act[eng.group_slice(k)].view(N, 2)) for k in range(G)]
-            gs = eng.group_streams
+                for _ in range(8):
+                    g.replay()
+                res["graph"] = dict(timed(lambda: [g.replay() for _ in range(steps // UNROLL)], N * steps), steps_per_replay=UNROLL)
+                if impl == "torch":
+                    f_, i_, _e = eng.get_state()
+                    out["ego_speed_kmh_mean"] = float(np.abs(f_[_abi.SF["SPEED"]][:, 0]).mean() * 3.6)
+                    out["driving_traffic_mean"] = float((i_[_abi.SI["STATUS"]][:, 1:] == _abi.ST_ACTIVE).sum(axis=1).mean())
+                    out["step_kernel"] = eng.describe_step()
+                del g
+                eng.close()
+        except Exception as ex:  # noqa: BLE001
+            res["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+        try:  # two env groups of 4096: a single-stream graph per group, replayed on the group's stream
+            with torch.no_grad():
+                eng = engine(G * N)
+                eng.set_groups(G)
+                act = torch.zeros((G * N, 1, 2), dtype=torch.float32, device=dev)
+                views = [(eng.obs[eng.group_slice(k)].view(N, -1), act[eng.group_slice(k)].view(N, 2)) for k in range(G)]
+                gs = eng.group_streams
 
-            def iteration_groups():
+                def group_iteration(k):  # (on the group's stream)
+                    if impl == "torch":
+                        policy_torch(*views[k])
+                    else:
+                        eng.mlp_policy(weights, act, group=k, final_tanh=True)
+                    eng.step_group(k, act)
+                cur = torch.cuda.current_stream(dev)
+                graphs = []
                 for k in range(G):
+                    gs[k].wait_stream(cur)
                     with torch.cuda.stream(gs[k]):
-                        policy(*views[k])
-                        eng.step_group(k, act)
-
-            def join(cur):
+                        for _ in range(warm):
+                            group_iteration(k)
+                torch.cuda.synchronize(dev)
                 for k in range(G):
-                    cur.wait_stream(gs[k])
-            cur = torch.cuda.current_stream(dev)
-            for k in range(G):
-                gs[k].wait_stream(cur)
-            for _ in range(warm):
-                iteration_groups()
-            join(cur)
-            torch.cuda.synchronize(dev)
-            s = torch.cuda.Stream(device=dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s):
-                for k in range(G):  # fork: the group streams join the capture
-                    gs[k].wait_stream(s)
-                for _ in range(UNROLL):
-                    iteration_groups()
-                join(s)
-            torch.cuda.synchronize(dev)
-            for _ in range(8):
-                g.replay()
-            out["groups_graph"] = dict(timed(lambda: [g.replay() for _ in range(steps // UNROLL)], G * N * steps), steps_per_replay=UNROLL,
-                                       env_groups=G, envs=G * N,
-                                       note="one iteration = both groups stepped once (%d env-steps)" % (G * N))
-            del g
-            eng.close()
-    except Exception as ex:  # noqa: BLE001
-        out["groups_graph"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
-    best = max((out[k]["value"] for k in ("eager", "graph", "groups_graph") if isinstance(out.get(k), dict) and "value" in out[k]), default=None)
-    out["value"] = best
+                    gk = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gk, stream=gs[k]):
+                        for _ in range(UNROLL):
+                            group_iteration(k)
+                    graphs.append(gk)
+                torch.cuda.synchronize(dev)
+
+                def replay_all():
+                    for k in range(G):
+                        with torch.cuda.stream(gs[k]):
+                            graphs[k].replay()
+                for _ in range(8):
+                    replay_all()
+                res["groups_graph"] = dict(timed(lambda: [replay_all() for _ in range(steps // UNROLL)], G * N * steps), steps_per_replay=UNROLL,
+                                           env_groups=G, envs=G * N, note="one iteration = both groups stepped once (%d env-steps)" % (G * N))
+                del graphs
+                eng.close()
+        except Exception as ex:  # noqa: BLE001
+            res["groups_graph"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+        out[impl] = res
+    vals = [(out[i][k]["value"], "%s/%s" % (i, k)) for i in ("torch", "fused") for k in ("eager", "graph", "groups_graph")
+            if isinstance(out.get(i, {}).get(k), dict) and "value" in out[i][k]]
+    out["value"], out["value_variant"] = max(vals) if vals else (None, None)
     return out
 
 

@@ -335,6 +335,19 @@ int pgd_set_stream(pgd_handle h, void* hip_stream);
 int pgd_sync(pgd_handle h);
 int pgd_destroy(pgd_handle h);
 const char* pgd_version(void);
+/* The policy network of a closed loop in one launch: actions[r][0..1] = MLP(obs row r) for every (env, agent) row of the engine
+ * (group < 0: all rows, on the engine's stream; group >= 0: the rows of that env group on the group's stream, the twin of
+ * pgd_step_group).  Replaces pgdrive/examples/ppo_expert/numpy_expert.py:25-44 (`expert(obs)`: x = tanh(obs @ fc_1 + b);
+ * x = tanh(x @ fc_2 + b); out = x @ fc_out + b, the action = the first two outputs) evaluated row by row in numpy, and the
+ * policy(obs) call of any rollout loop whose policy is such a network.  Weights: fp32 device arrays, row-major [in][out] as the
+ * reference's `kernel` arrays (w1 [in_dim][hidden], w2 [hidden][hidden], w3 [hidden][out_cols]; only columns 0 and 1 of w3 / b3 are
+ * used); hidden must be 256.  d_obs: rows of obs_stride floats, the first in_dim are the network's input (normally the buffer and
+ * row width pgd_step writes).  final_tanh != 0 squashes the two outputs (numpy_expert.py does not; the env clips).
+ * d_actions: [rows][2] floats, the layout pgd_step reads.  Asynchronous; may be captured in a HIP graph with the step.
+ * Arithmetic: fp32 throughout (the 256-wide layers on the f32 matrix cores: a k-ordered fma chain). */
+int pgd_mlp_policy(pgd_handle h, int group, const float* d_obs, int obs_stride, int in_dim, int hidden, const float* d_w1,
+                   const float* d_b1, const float* d_w2, const float* d_b2, const float* d_w3, const float* d_b3, int out_cols,
+                   int final_tanh, float* d_actions);
 /* Multi-agent engines remember, per env, which rows of the LAST observation buffer they were given already hold the zeros of a seat
  * that is not due (identified by the buffer's address and row stride), and do not write them again.  A caller that hands pgd_step
  * a buffer whose address a FORMER buffer had (a caching allocator re-using a freed block: torch.empty per step) calls this first:

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "pgd_engine.hip")
 DEPS = [SRC] + [os.path.join(HERE, "csrc", h) for h in ("pgd_device.h", "pgd_vehicle.h", "pgd_localize.h", "pgd_idm.h",
-                                                         "pgd_dynamics.h", "pgd_observe.h", "pgd_gather.h", "pgd_topdown.h")] + \
+                                                         "pgd_dynamics.h", "pgd_observe.h", "pgd_gather.h", "pgd_topdown.h", "pgd_policy.h")] + \
     [os.path.join(HERE, "..", "include", "pgdrive_hip.h"), os.path.join(HERE, "..", "include", "pgd_state_layout.h"),
      os.path.abspath(__file__)]  # the flags below are part of the build: a change of this file rebuilds
 LIB = os.path.join(HERE, "libpgdrive_hip.so")

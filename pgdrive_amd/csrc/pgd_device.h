@@ -80,6 +80,10 @@ struct PgdDev {
   // (round 5: the state phase of the four-wave kernel was 2.8 k of its 7.4 k instructions per env, every wave running the whole
   // branch ladder for six lanes per agent after reading records, spawn records and lane tables back from memory).
   float* state_rows;
+  // Every body of every uploaded scenario is a vehicle box of ONE size (the multi-agent defaults: one vehicle model, no traffic
+  // objects; pgd_upload_scenarios compares the spawn records): its length and width, else 0.  The multi-agent observation kernel then
+  // publishes the bodies without the spawn record of each -- a second memory round trip behind the records (round 6).
+  float uni_len, uni_wid;
 };
 
 // Device-side vehicle record = the per-lane register image of a vehicle (device-private; pgd_get_state / pgd_set_state

@@ -80,6 +80,7 @@ __shared__ long long s_prof_t0, s_prof_w0;
 #include "pgd_idm.h"
 #include "pgd_dynamics.h"
 #include "pgd_observe.h"
+#include "pgd_policy.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_step: one env.step() for every environment (base_env.py:184-224)
@@ -1670,6 +1671,13 @@ int pgd_upload_maps(pgd_handle h, const pgd_map* maps, int n_maps, const pgd_lan
         }
       }
       for (int k = 0; k < maps[m].n_lanes; ++k) memcpy(&dl[(size_t)maps[m].lane_off + k].ey, &rel[(size_t)k], 4);
+      // device-private use of `pad`: the from-node of the lane's road -- what Navigation._update_target_checkpoints looks up in the
+      // route (navigation.py:262-282); with it in the lane record the checkpoint test needs no lane -> road table chain (two
+      // dependent reads per vehicle on every step of the first five metres of a lane: round 6)
+      for (int k = 0; k < maps[m].n_lanes; ++k) {
+        pgd_lane& L = dl[(size_t)maps[m].lane_off + k];
+        L.pad = (L.road >= 0 && L.road < maps[m].n_roads) ? roads[(size_t)maps[m].road_off + L.road].from : (int16_t)-1;
+      }
     }
     if ((rc = upload(&h->lanes, dl.data(), n_lanes, h->stream))) return rc;
     std::vector<LaneNav> nav((size_t)(n_lanes > 0 ? n_lanes : 1));
@@ -1747,7 +1755,17 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   HIPCHK(hipSetDevice(h->device));
   int rc;
   if ((rc = upload(&h->scen, scen, n_scen, h->stream))) return rc;
-  if ((rc = upload(&h->spawns, spawns, (size_t)n_scen * h->d.sstride, h->stream))) return rc;
+  {
+    // device-private form of the routes: PGD_CKPT_END from a route's last node on (update_checkpoints: a match on the last node
+    // alone changes nothing, navigation.py:270-277 -- the search stops at the mark instead of reading the route length first)
+    std::vector<pgd_spawn> dsp(spawns, spawns + (size_t)n_scen * h->d.sstride);
+    for (pgd_spawn& q : dsp) {
+      const int n = q.n_ckpt < 0 ? 0 : (q.n_ckpt > PGD_MAX_CKPT ? PGD_MAX_CKPT : q.n_ckpt);
+      for (int k = n > 0 ? n - 1 : 0; k < PGD_MAX_CKPT; ++k) q.ckpt[k] = (int16_t)PGD_CKPT_END;
+    }
+    if ((rc = upload(&h->spawns, dsp.data(), dsp.size(), h->stream))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));  // (the staging vector goes out of scope)
+  }
   h->d.scen = h->scen; h->d.spawns = h->spawns; h->d.n_scen = n_scen;
   {
     const size_t ns = (size_t)n_scen * h->d.sstride;
@@ -1765,6 +1783,17 @@ int pgd_upload_scenarios(pgd_handle h, const pgd_scenario* scen, int n_scen, con
   h->has_objects = false;
   for (size_t k = 0; k < (size_t)n_scen * h->d.sstride; ++k)
     if (spawns[k].lane >= 0 && spawns[k].kind != PGD_OBJ_VEHICLE) { h->has_objects = true; break; }
+  {  // one body size for the whole upload?  (unused slots -- lane < 0 -- never enter a world)
+    float ul = 0.0f, uw = 0.0f;
+    bool uni = !h->has_objects && getenv("PGD_NO_UNI") == nullptr;
+    for (size_t k = 0; uni && k < (size_t)n_scen * h->d.sstride; ++k) {
+      if (spawns[k].lane < 0) continue;
+      if (ul == 0.0f) { ul = spawns[k].length; uw = spawns[k].width; }
+      uni = spawns[k].length == ul && spawns[k].width == uw && ul > 0.0f && uw > 0.0f;
+    }
+    h->d.uni_len = uni ? ul : 0.0f;
+    h->d.uni_wid = uni ? uw : 0.0f;
+  }
   if (!h->h_scen) h->h_scen = new std::vector<pgd_scenario>();
   h->h_scen->assign(scen, scen + n_scen);
   if ((rc = build_scen_map(h))) return rc;
@@ -2059,6 +2088,34 @@ int pgd_group_stream(pgd_handle h, int group, void** hip_stream) {
 int pgd_group_sync(pgd_handle h, int group) {
   if (!h || group < 0 || group >= h->n_groups || !h->gstreams) return PGD_ERR_ARG;
   HIPCHK(hipStreamSynchronize(h->gstreams[group]));
+  return PGD_OK;
+}
+
+int pgd_mlp_policy(pgd_handle h, int group, const float* d_obs, int obs_stride, int in_dim, int hidden, const float* d_w1, const float* d_b1,
+                   const float* d_w2, const float* d_b2, const float* d_w3, const float* d_b3, int out_cols, int final_tanh,
+                   float* d_actions) {
+  if (!h || !d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_w3 || !d_b3 || !d_actions) return PGD_ERR_ARG;
+  if (hidden != MLP_H || in_dim < 4 || in_dim > 4096 || obs_stride < in_dim || out_cols < 2) return PGD_ERR_ARG;
+  const size_t lds = mlp_lds_bytes(in_dim);
+  if (lds > 65536) return PGD_ERR_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t stream = h->stream;
+  int rows = h->d.N * h->d.A, row0 = 0;
+  if (group >= 0) {  // the rows of one env group, on the group's stream (pgd_step_group's twin)
+    if (group >= h->n_groups || !h->gstreams) return PGD_ERR_ARG;
+    rows = (h->d.N / h->n_groups) * h->d.A;
+    row0 = group * rows;
+    stream = h->gstreams[group];
+  }
+  auto kern = final_tanh ? k_mlp_policy<true> : k_mlp_policy<false>;
+  static bool attr_set[2] = {false, false};
+  if (lds > 49152 && !attr_set[final_tanh ? 1 : 0]) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    attr_set[final_tanh ? 1 : 0] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((rows + MLP_ROWS - 1) / MLP_ROWS), dim3(WAVE * MLP_WAVES), lds, stream, d_obs, row0, rows, obs_stride, in_dim,
+                     d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, out_cols, d_actions);
+  HIPCHK(hipGetLastError());
   return PGD_OK;
 }
 

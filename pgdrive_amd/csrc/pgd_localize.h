@@ -116,29 +116,47 @@ DEV void route_refresh(const MapView& mv, const pgd_spawn& sp, Veh& r) {
 }
 
 // Navigation._update_target_checkpoints (navigation.py:262-282)
-DEV void update_checkpoints(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, float lon) {
+// `start_node`: from-node of the road of the vehicle's lane (the device lane copy carries it: pgd_lane::pad, pgd_upload_maps).
+// The device copy of a spawn record holds PGD_CKPT_END in the route from its LAST node on (pgd_upload_scenarios): the search below --
+// checkpoints[ck1:].index(start_node) with index < len - 1 (navigation.py:270-277) -- then needs neither the route length nor the
+// lane -> road table chain in front of its reads: one memory round trip on every step of the first five metres of a lane where
+// rounds 1 - 5 made three dependent ones (lane record, road record, route; PGD_CKPT_CHAIN keeps that form for A/B).
+#define PGD_CKPT_END (-32768)
+DEV void update_checkpoints(const MapView& mv, const Grp& g, const pgd_spawn& sp, Veh& r, float lon, const int start_node) {
   if (r.ck0 == r.ck1) return;
   if (!(lon < 5.0f)) return;
-  int n = sp.n_ckpt;
-  int start_node = mv.roads()[mv.lanes[r.lane].road].from;
-  // checkpoints[ck1:].index(start_node) with index < len - 1 (navigation.py:270-277): the first match decides, and a match
-  // on the last node alone changes nothing.  The sub-lanes of the vehicle split the tail, four independent reads each per
-  // round (a whole route in one round trip), and take the lowest hit.
+  // The first match decides, and a match on the last node alone changes nothing.  The sub-lanes of the vehicle split the tail,
+  // four independent reads each per round (a whole route in one round trip), and take the lowest hit.
   unsigned hit = 0xffffffffu;
   const int step = g.SUB;
+#ifdef PGD_CKPT_CHAIN
+  const int n = sp.n_ckpt;
+  const int start_node_ = mv.roads()[mv.lanes[r.lane].road].from;
   for (int k = r.ck1 + g.sub; k < n - 1; k += 4 * step) {
     int v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = sp.ckpt[min(k + j * step, n - 2)];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (k + j * step < n - 1 && v[j] == start_node) hit = min(hit, (unsigned)(k + j * step));
+      if (k + j * step < n - 1 && v[j] == start_node_) hit = min(hit, (unsigned)(k + j * step));
   }
+#else
+  for (int k = r.ck1 + g.sub; k < PGD_MAX_CKPT; k += 4 * step) {
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = sp.ckpt[min(k + j * step, PGD_MAX_CKPT - 1)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k + j * step < PGD_MAX_CKPT && v[j] == start_node) hit = min(hit, (unsigned)(k + j * step));
+    if (v[3] == PGD_CKPT_END) break;  // (the end marks are contiguous: this sub-lane's later entries are marks as well)
+  }
+#endif
   hit = group_min(hit, g);
   if (hit == 0xffffffffu) return;
   const int idx = (int)hit;
+  const int n_nodes = sp.n_ckpt;  // (a checkpoint was passed: once per road)
   r.ck0 = idx;
-  r.ck1 = (idx + 1 == n - 1) ? idx : idx + 1;
+  r.ck1 = (idx + 1 == n_nodes - 1) ? idx : idx + 1;
   route_refresh(mv, sp, r);
 }
 
@@ -198,10 +216,15 @@ DEV void update_localization(const MV& mv, const Grp& g, const pgd_spawn& sp, Ve
   bool on_lane = lane >= 0;
   if (!on_lane) lane = r.lane;
   r.lane = lane;
-  if (!stay) lane_local(mv.lanes[lane], r.x, r.y, lon, lat);
+  int from_node = PL.pad;  // (the lane of the previous step, still the vehicle's when it stays)
+  if (!stay) {
+    const pgd_lane& NL = mv.lanes[lane];
+    from_node = NL.pad;
+    lane_local(NL, r.x, r.y, lon, lat);
+  }
   lon_out = lon; lat_out = lat;
   r.lon = lon;
-  update_checkpoints(mv, g, sp, r, lon);
+  update_checkpoints(mv, g, sp, r, lon, from_node);
   r.vflags = on_lane ? (r.vflags & ~PGD_F_OFF_LANE) : (r.vflags | PGD_F_OFF_LANE);
   PHASE_MARK(18);  // after_step: lane_local + checkpoints
 }

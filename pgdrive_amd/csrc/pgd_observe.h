@@ -676,9 +676,15 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
       bFL[sa] = f_me;
     }
   } else if (tid < V) {
-    const pgd_spawn& so = spb[body.spawn];
-    const float so_len = so.length, so_wid = so.width;
-    const int so_kind = so.kind;
+    // (one body size for the whole engine -- PgdDev::uni_len, a kernel argument: no spawn record is read, the publish follows the
+    // records' arrival directly; a wave-uniform branch)
+    float so_len, so_wid;
+    int so_kind;
+    if (!OBJ && d.uni_len > 0.0f) { so_len = d.uni_len; so_wid = d.uni_wid; so_kind = PGD_OBJ_VEHICLE; }
+    else {
+      const pgd_spawn& so = spb[body.spawn];
+      so_len = so.length; so_wid = so.width; so_kind = so.kind;
+    }
     bX[tid] = body.x; bY[tid] = body.y; bUX[tid] = body.hx; bUY[tid] = body.hy;
     bHL[tid] = 0.5f * so_len; bHW[tid] = so_kind == PGD_OBJ_CYLINDER ? -1.0f : 0.5f * so_wid;
     bV[tid] = body.v; bAID[tid] = body.agent_id;

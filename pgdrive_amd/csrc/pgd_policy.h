@@ -1,0 +1,156 @@
+// pgd_policy.h -- the policy network of the closed loop as ONE launch: actions = MLP(observation rows).
+// Part of the single translation unit pgd_engine.hip.
+//
+// What it mirrors: pgdrive/examples/ppo_expert/numpy_expert.py:25-44 (`expert(obs)`): a three-layer tanh MLP
+//   x = tanh(obs @ fc_1/kernel + fc_1/bias); x = tanh(x @ fc_2/kernel + fc_2/bias); out = x @ fc_out/kernel + fc_out/bias
+// with 256 hidden units, the action = the first two outputs (the mean of the Gaussian head) -- the policy the reference's own
+// closed-loop tests drive the env with (tests/test_functionality/test_expert_performance.py:48-85) and the shape of a PPO / SAC
+// rollout policy in general.  As torch ops the three layers are six dependent launches of GEMMs far too small to fill the chip
+// (4096 x 274 x 256): 35 us per step next to a 17 us env step (profiles/r06_notes.md).  Here: one workgroup per 16 observation rows,
+// the rows and both hidden activations stay in LDS, the two 256-wide layers run on the f32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact f32, a k-ordered fma chain -- the result is what a per-thread fmaf loop gives), the 2-wide head on
+// the vector ALU.  This is the one GEMM-shaped piece of the closed loop, hence the one place MFMA is used; the step itself stays
+// branch / latency bound scalar geometry.
+//
+// Layout: weights row-major [in][out] exactly as numpy_expert.py's `kernel` arrays (x @ kernel), fp32, on the device.
+// Work split: 8 waves per workgroup; wave w owns hidden columns [32 w, 32 w + 32) = two 16 x 16 accumulator tiles.
+//   A fragment (activations, LDS):  lane l -> row l & 15, k = k0 + (l >> 4)
+//   B fragment (weights, global, L2-resident: 545 KB for 274-256-256-2):  lane l -> k = k0 + (l >> 4), column c0 + (l & 15)
+//   C / D: register i of lane l -> row 4 (l >> 4) + i, column l & 15
+// LDS row strides are = 2 (mod 32) words: the 32 lanes of a half-wave (16 rows x 2 k) then hit 32 different banks.
+#ifndef PGD_POLICY_H
+#define PGD_POLICY_H
+
+#define MLP_ROWS 16
+#define MLP_H 256
+#define MLP_WAVES 8
+#define MLP_HS (MLP_H + 2)  // 258 = 2 (mod 32)
+typedef float mlp_f32x4 __attribute__((ext_vector_type(4)));
+
+DEV_HOST int mlp_x_stride(int in_dim) {
+  const int kp = (in_dim + 3) & ~3;
+  return kp + ((2 - kp) % 32 + 32) % 32;
+}
+DEV_HOST size_t mlp_lds_bytes(int in_dim) { return sizeof(float) * (size_t)MLP_ROWS * ((size_t)mlp_x_stride(in_dim) + 2 * MLP_HS); }
+
+// one 256-wide layer for the wave's two column tiles: acc += A[16 x K] (LDS, row stride a_ld) * W[K x 256] (global), K = kp (a multiple of
+// four; rows of W at or beyond k_real read as zero)
+DEV void mlp_layer(const float* __restrict__ A, const int a_ld, const float* __restrict__ W, const int kp, const int k_real, const int lane,
+                   const int c0, mlp_f32x4& acc0, mlp_f32x4& acc1) {
+  const int arow = lane & 15, kq = lane >> 4;
+  const float* ap = A + arow * a_ld + kq;
+  const float* wp = W + (size_t)kq * MLP_H + c0 + (lane & 15);
+  // Eight k-steps (32 rows of W) per round: their sixteen weight reads and eight LDS reads go out together, then sixteen matrix
+  // instructions (512 cycles of the matrix pipe).  Two register sets, ping and pong: the reads of round r + 1 are issued BEFORE the
+  // matrix instructions of round r -- a round at a time the wave waited a whole L2 latency per round (17 rounds x ~2 k cycles:
+  // 18 us for 4096 rows, measured; two waves per SIMD cannot hide it).
+  constexpr int U = 8;
+  const int k_last = k_real - 1 - kq;  // (k_real >= 4: the caller checks in_dim)
+  auto load = [&](const int k0, float (&a)[U], float (&b0)[U], float (&b1)[U]) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      // rows at or beyond k_real (the padding of the last round): the reads go to the last real row instead -- unconditional reads
+      // keep the round one basic block, so that the wait in front of a round's matrix instructions counts only its own reads --
+      // and the activation is replaced by zero (a finite weight times zero)
+      const int k = k0 + 4 * j;
+      const bool in = k + kq < k_real;
+      const int kc = in ? k : k_last;
+      const float av = ap[kc];
+      a[j] = in ? av : 0.0f;
+      b0[j] = wp[(size_t)kc * MLP_H];
+      b1[j] = wp[(size_t)kc * MLP_H + 16];
+    }
+  };
+  auto mma = [&](const float (&a)[U], const float (&b0)[U], const float (&b1)[U]) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b0[j], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b1[j], acc1, 0, 0, 0);
+    }
+  };
+  float aP[U], b0P[U], b1P[U], aQ[U], b0Q[U], b1Q[U];
+  // (rounds come in pairs and every read is unconditional: a straight-line loop body, so that the wait in front of a round's matrix
+  // instructions leaves the sixteen reads of the round after it in flight; a round past the end multiplies zeros: <= 512 cycles)
+  const int pairs = (kp + 8 * U - 1) / (8 * U);
+  load(0, aP, b0P, b1P);
+  for (int p = 0; p < pairs; ++p) {
+    const int k0 = p * 8 * U;
+    // (scheduling barriers: left to itself the instruction scheduler sinks the reads of the next round in between the matrix
+    // instructions of this one and the wait pass then drains the read queue -- vmcnt(0) -- in the middle of a round)
+    load(k0 + 4 * U, aQ, b0Q, b1Q);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(aP, b0P, b1P);
+    __builtin_amdgcn_sched_barrier(0);
+    load(k0 + 8 * U, aP, b0P, b1P);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(aQ, b0Q, b1Q);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// tanh in fp32 through one exponential: tanh(x) = 1 - 2 / (e^{2x} + 1), |error| of a few ulp for |x| < 9, saturating beyond
+DEV float mlp_tanh(const float x) {
+  const float e = __expf(2.0f * fminf(fmaxf(x, -10.0f), 10.0f));
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+
+// bias + tanh of the wave's two tiles into the next layer's LDS tile
+DEV void mlp_store_hidden(float* __restrict__ H, const float* __restrict__ bias, const int lane, const int c0, const mlp_f32x4& acc0,
+                          const mlp_f32x4& acc1) {
+  const int col = c0 + (lane & 15), r4 = (lane >> 4) * 4;
+  const float bb0 = bias[col], bb1 = bias[col + 16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    H[(r4 + i) * MLP_HS + col] = mlp_tanh(acc0[i] + bb0);
+    H[(r4 + i) * MLP_HS + col + 16] = mlp_tanh(acc1[i] + bb1);
+  }
+}
+
+// rows [row0, row0 + n_rows) of `obs` (row stride obs_stride floats, in_dim used) -> act[row][0..1]
+template <bool TANH_OUT>
+__global__ __launch_bounds__(WAVE * MLP_WAVES) void k_mlp_policy(const float* __restrict__ obs, const int row0, const int n_rows,
+                                                                 const int obs_stride, const int in_dim, const float* __restrict__ W1,
+                                                                 const float* __restrict__ b1, const float* __restrict__ W2,
+                                                                 const float* __restrict__ b2, const float* __restrict__ W3,
+                                                                 const float* __restrict__ b3, const int out_cols, float* __restrict__ act) {
+  extern __shared__ float mlp_lds[];
+  const int kp = (in_dim + 3) & ~3, xs = mlp_x_stride(in_dim);
+  float* X = mlp_lds;
+  float* H1 = X + MLP_ROWS * xs;
+  float* H2 = H1 + MLP_ROWS * MLP_HS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r0 = (int)blockIdx.x * MLP_ROWS;  // (relative to row0)
+  // the 16 observation rows: whole rows, coalesced (a row is contiguous in memory); padding columns and rows past the end read zero
+  for (int r = wave; r < MLP_ROWS; r += MLP_WAVES) {
+    const bool row_in = r0 + r < n_rows;
+    const float* src = obs + (size_t)(row0 + r0 + (row_in ? r : 0)) * obs_stride;
+    for (int k = lane; k < kp; k += WAVE) X[r * xs + k] = (row_in && k < in_dim) ? src[k] : 0.0f;
+  }
+  __syncthreads();
+  const int c0 = wave * 32;
+  mlp_f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  mlp_layer(X, xs, W1, kp, in_dim, lane, c0, a0, a1);
+  mlp_store_hidden(H1, b1, lane, c0, a0, a1);
+  __syncthreads();
+  a0 = mlp_f32x4{0.0f, 0.0f, 0.0f, 0.0f}; a1 = mlp_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  mlp_layer(H1, MLP_HS, W2, MLP_H, MLP_H, lane, c0, a0, a1);
+  mlp_store_hidden(H2, b2, lane, c0, a0, a1);
+  __syncthreads();
+  // the head: 16 rows x 2 outputs = 32 dot products of 256, sixteen lanes each (the first 512 threads = all of them)
+  {
+    const int dot = tid >> 4, part = tid & 15, r = dot >> 1, o = dot & 1;
+    float s = 0.0f;
+#pragma unroll 4
+    for (int k = part; k < MLP_H; k += 16) s = fmaf(H2[r * MLP_HS + k], W3[(size_t)k * out_cols + o], s);
+    s += __shfl_xor(s, 8);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 1);
+    if (part == 0 && r0 + r < n_rows) {
+      const float v = s + b3[o];
+      act[(size_t)(row0 + r0 + r) * 2 + o] = TANH_OUT ? mlp_tanh(v) : v;
+    }
+  }
+}
+
+#endif

@@ -954,3 +954,71 @@ env.close()
     assert d["is_env"] and d["cls"] == "PGDriveEnv" and d["seeds"] == [1000, 100]
     assert d["obs_space"] == ["gym.spaces", [274]] and d["act_space"] == ["gym.spaces", [2]]
     assert d["o"] == [[274], "float32"] and d["o2"] == [[274], "float32"] and d["r"] == "float" and d["d"] == "bool" and d["in_space"]
+
+
+def _mlp_numpy(x, w1, b1, w2, b2, w3, b3, final_tanh):
+    """pgdrive/examples/ppo_expert/numpy_expert.py:25-44 re-stated in float64 (the checker)."""
+    h = np.tanh(x.astype(np.float64) @ w1.astype(np.float64) + b1)
+    h = np.tanh(h @ w2.astype(np.float64) + b2)
+    o = (h @ w3.astype(np.float64) + b3)[:, :2]
+    return np.tanh(o) if final_tanh else o
+
+
+@pytest.mark.parametrize("case", ["expert_weights", "random_274", "groups"])
+def test_mlp_policy_matches_the_numpy_expert(descs, case):
+    """pgd_mlp_policy (pgdrive_amd/csrc/pgd_policy.h: the policy network of the closed loop in one launch, f32 matrix cores) against
+    the reference's numpy expert: (a) the reference's own PPO weights (examples/ppo_expert/expert_weights.npz, kept as a fixture:
+    275 inputs, 4 outputs of which the first two are the action) on random observation rows of a wider buffer, a row count that is
+    not a multiple of the kernel's 16-row tile; (b) random 274-256-256-2 weights on the engine's own observation buffer, with the
+    final tanh; (c) the same per env group on the groups' streams.  fp32 against a float64 restatement: 2e-5."""
+    import torch
+    from pgdrive_amd import _abi
+    from pgdrive_amd.engine import Engine
+    from tests import util
+    mb, sb = util.make_banks(descs, n_maps=8)
+    rng = np.random.default_rng(3)
+    n = 100 if case != "groups" else 96
+    eng = Engine(_abi.make_config(n, seed=2), mb, sb)
+    try:
+        eng.reset(np.arange(n) % 8)
+        if case == "expert_weights":
+            Wz = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "expert_weights.npz"))
+            w = [Wz["default_policy/fc_1/kernel"], Wz["default_policy/fc_1/bias"], Wz["default_policy/fc_2/kernel"],
+                 Wz["default_policy/fc_2/bias"], Wz["default_policy/fc_out/kernel"], Wz["default_policy/fc_out/bias"]]
+            assert w[0].shape == (275, 256) and w[4].shape == (256, 4)
+            x = np.clip(rng.normal(0.5, 1.0, size=(n, 288)), 0.0, 1.0).astype(np.float32)  # (numpy_expert.py's own self-test input)
+            x[:, 275:] = np.nan  # columns beyond in_dim are never read
+            obs, in_dim, ft = torch.from_numpy(x).cuda(), 275, False
+        else:
+            w = [rng.normal(0, 0.08, size=(274, 256)), rng.normal(0, 0.1, size=256), rng.normal(0, 0.08, size=(256, 256)),
+                 rng.normal(0, 0.1, size=256), rng.normal(0, 0.1, size=(256, 2)), rng.normal(0, 0.1, size=2)]
+            a = torch.from_numpy(util.driving_actions(rng, n)).cuda()
+            for _ in range(5):
+                eng.step(a)
+            eng.sync()
+            obs, in_dim, ft = None, 274, True
+            x = eng.obs.view(n, -1).cpu().numpy()
+        w = [np.ascontiguousarray(v, dtype=np.float32) for v in w]
+        wt = tuple(torch.from_numpy(v).cuda() for v in w)
+        out = torch.full((n, 1, 2), 7.0, dtype=torch.float32, device="cuda")
+        if case == "groups":
+            eng.set_groups(4)
+            for g in range(4):
+                eng.mlp_policy(wt, out, group=g, final_tanh=ft)
+            for g in range(4):
+                eng.group_sync(g)
+        else:
+            eng.mlp_policy(wt, out, obs=obs, final_tanh=ft, in_dim=in_dim)
+            eng.sync()
+        want = _mlp_numpy(x[:, :in_dim], *w, ft)
+        got = out.view(n, 2).cpu().numpy()
+        assert np.isfinite(got).all() and np.abs(got - want).max() < 2e-5, np.abs(got - want).max()
+        assert np.abs(want).max() > 0.05  # (not a trivially small network output)
+        # the arguments the library refuses: another hidden width, a row stride below the input width
+        import ctypes as C
+        p = [C.c_void_p(t.data_ptr()) for t in wt]
+        o2 = eng.obs.view(n, -1)
+        assert eng.L.pgd_mlp_policy(eng.h, -1, C.c_void_p(o2.data_ptr()), 274, 274, 128, *p, 2, 0, C.c_void_p(out.data_ptr())) == 1
+        assert eng.L.pgd_mlp_policy(eng.h, -1, C.c_void_p(o2.data_ptr()), 100, 274, 256, *p, 2, 0, C.c_void_p(out.data_ptr())) == 1
+    finally:
+        eng.close()
