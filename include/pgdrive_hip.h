@@ -341,7 +341,7 @@ const char* pgd_version(void);
  * x = tanh(x @ fc_2 + b); out = x @ fc_out + b, the action = the first two outputs) evaluated row by row in numpy, and the
  * policy(obs) call of any rollout loop whose policy is such a network.  Weights: fp32 device arrays, row-major [in][out] as the
  * reference's `kernel` arrays (w1 [in_dim][hidden], w2 [hidden][hidden], w3 [hidden][out_cols]; only columns 0 and 1 of w3 / b3 are
- * used); hidden must be 256.  d_obs: rows of obs_stride floats, the first in_dim are the network's input (normally the buffer and
+ * used); hidden must be 256; w1, w2, b1, b2 16-byte aligned.  d_obs: rows of obs_stride floats, the first in_dim are the network's input (normally the buffer and
  * row width pgd_step writes).  final_tanh != 0 squashes the two outputs (numpy_expert.py does not; the env clips).
  * d_actions: [rows][2] floats, the layout pgd_step reads.  Asynchronous; may be captured in a HIP graph with the step.
  * Arithmetic: fp32 throughout (the 256-wide layers on the f32 matrix cores: a k-ordered fma chain). */

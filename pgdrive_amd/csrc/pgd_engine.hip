@@ -2096,6 +2096,7 @@ int pgd_mlp_policy(pgd_handle h, int group, const float* d_obs, int obs_stride, 
                    float* d_actions) {
   if (!h || !d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_w3 || !d_b3 || !d_actions) return PGD_ERR_ARG;
   if (hidden != MLP_H || in_dim < 4 || in_dim > 4096 || obs_stride < in_dim || out_cols < 2) return PGD_ERR_ARG;
+  if ((((uintptr_t)d_w1 | (uintptr_t)d_w2 | (uintptr_t)d_b1 | (uintptr_t)d_b2) & 15u) != 0u) return PGD_ERR_ARG;  // 16-byte reads
   const size_t lds = mlp_lds_bytes(in_dim);
   if (lds > 65536) return PGD_ERR_ARG;
   HIPCHK(hipSetDevice(h->device));

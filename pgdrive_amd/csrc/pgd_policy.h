@@ -13,17 +13,21 @@
 // branch / latency bound scalar geometry.
 //
 // Layout: weights row-major [in][out] exactly as numpy_expert.py's `kernel` arrays (x @ kernel), fp32, on the device.
-// Work split: 8 waves per workgroup; wave w owns hidden columns [32 w, 32 w + 32) = two 16 x 16 accumulator tiles.
+// Work split: 4 waves per workgroup; wave w owns hidden columns [64 w, 64 w + 64) as FOUR 16 x 16 accumulator tiles whose columns
+// interleave: tile t = columns { 64 w + 4 n + t : n = 0 .. 15 }.  Any 16 columns make a tile; with this choice the four weights a lane
+// needs for one k-step -- one per tile -- are four CONSECUTIVE floats of a row of W: one 16-byte read feeds four matrix
+// instructions.  (First version, round 6: tiles of 16 consecutive columns, one 4-byte read per tile and k-step: 2,176 read
+// instructions per CU and launch, 21.4 us for 4096 rows -- a third of the matrix pipe's rate, bound by the issue of its reads.)
 //   A fragment (activations, LDS):  lane l -> row l & 15, k = k0 + (l >> 4)
-//   B fragment (weights, global, L2-resident: 545 KB for 274-256-256-2):  lane l -> k = k0 + (l >> 4), column c0 + (l & 15)
-//   C / D: register i of lane l -> row 4 (l >> 4) + i, column l & 15
+//   B fragment (weights, global, L2-resident: 545 KB for 274-256-256-2):  lane l -> k = k0 + (l >> 4), columns c0 + 4 (l & 15) + t
+//   C / D of tile t: register i of lane l -> row 4 (l >> 4) + i, column c0 + 4 (l & 15) + t
 // LDS row strides are = 2 (mod 32) words: the 32 lanes of a half-wave (16 rows x 2 k) then hit 32 different banks.
 #ifndef PGD_POLICY_H
 #define PGD_POLICY_H
 
 #define MLP_ROWS 16
 #define MLP_H 256
-#define MLP_WAVES 8
+#define MLP_WAVES 4
 #define MLP_HS (MLP_H + 2)  // 258 = 2 (mod 32)
 typedef float mlp_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -33,20 +37,19 @@ DEV_HOST int mlp_x_stride(int in_dim) {
 }
 DEV_HOST size_t mlp_lds_bytes(int in_dim) { return sizeof(float) * (size_t)MLP_ROWS * ((size_t)mlp_x_stride(in_dim) + 2 * MLP_HS); }
 
-// one 256-wide layer for the wave's two column tiles: acc += A[16 x K] (LDS, row stride a_ld) * W[K x 256] (global), K = kp (a multiple of
-// four; rows of W at or beyond k_real read as zero)
+// one 256-wide layer for the wave's four column tiles: acc[t] += A[16 x K] (LDS, row stride a_ld) * W[K x 256] (global), K = kp (a
+// multiple of four; rows of W at or beyond k_real contribute zero)
 DEV void mlp_layer(const float* __restrict__ A, const int a_ld, const float* __restrict__ W, const int kp, const int k_real, const int lane,
-                   const int c0, mlp_f32x4& acc0, mlp_f32x4& acc1) {
+                   const int c0, mlp_f32x4 (&acc)[4]) {
   const int arow = lane & 15, kq = lane >> 4;
   const float* ap = A + arow * a_ld + kq;
-  const float* wp = W + (size_t)kq * MLP_H + c0 + (lane & 15);
-  // Eight k-steps (32 rows of W) per round: their sixteen weight reads and eight LDS reads go out together, then sixteen matrix
-  // instructions (512 cycles of the matrix pipe).  Two register sets, ping and pong: the reads of round r + 1 are issued BEFORE the
-  // matrix instructions of round r -- a round at a time the wave waited a whole L2 latency per round (17 rounds x ~2 k cycles:
-  // 18 us for 4096 rows, measured; two waves per SIMD cannot hide it).
+  const float4* wp = reinterpret_cast<const float4*>(W + (size_t)kq * MLP_H + c0 + 4 * (lane & 15));  // (16-byte aligned: c0, 4 n, 256 k)
+  // Eight k-steps (32 rows of W) per round: eight 16-byte weight reads and eight LDS reads go out together, then 32 matrix
+  // instructions (1,024 cycles of the matrix pipe).  Two register sets, ping and pong: the reads of round r + 1 are issued BEFORE the
+  // matrix instructions of round r (one wave per SIMD: nothing else hides an L2 latency).
   constexpr int U = 8;
   const int k_last = k_real - 1 - kq;  // (k_real >= 4: the caller checks in_dim)
-  auto load = [&](const int k0, float (&a)[U], float (&b0)[U], float (&b1)[U]) {
+  auto load = [&](const int k0, float (&a)[U], float4 (&b)[U]) {
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       // rows at or beyond k_real (the padding of the last round): the reads go to the last real row instead -- unconditional reads
@@ -57,33 +60,35 @@ DEV void mlp_layer(const float* __restrict__ A, const int a_ld, const float* __r
       const int kc = in ? k : k_last;
       const float av = ap[kc];
       a[j] = in ? av : 0.0f;
-      b0[j] = wp[(size_t)kc * MLP_H];
-      b1[j] = wp[(size_t)kc * MLP_H + 16];
+      b[j] = wp[(size_t)kc * (MLP_H / 4)];
     }
   };
-  auto mma = [&](const float (&a)[U], const float (&b0)[U], const float (&b1)[U]) {
+  auto mma = [&](const float (&a)[U], const float4 (&b)[U]) {
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b0[j], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b1[j], acc1, 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j].z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j].w, acc[3], 0, 0, 0);
     }
   };
-  float aP[U], b0P[U], b1P[U], aQ[U], b0Q[U], b1Q[U];
+  float aP[U], aQ[U];
+  float4 bP[U], bQ[U];
   // (rounds come in pairs and every read is unconditional: a straight-line loop body, so that the wait in front of a round's matrix
-  // instructions leaves the sixteen reads of the round after it in flight; a round past the end multiplies zeros: <= 512 cycles)
+  // instructions leaves the reads of the round after it in flight; a round past the end multiplies zeros: <= 1,024 cycles)
   const int pairs = (kp + 8 * U - 1) / (8 * U);
-  load(0, aP, b0P, b1P);
+  load(0, aP, bP);
   for (int p = 0; p < pairs; ++p) {
     const int k0 = p * 8 * U;
     // (scheduling barriers: left to itself the instruction scheduler sinks the reads of the next round in between the matrix
     // instructions of this one and the wait pass then drains the read queue -- vmcnt(0) -- in the middle of a round)
-    load(k0 + 4 * U, aQ, b0Q, b1Q);
+    load(k0 + 4 * U, aQ, bQ);
     __builtin_amdgcn_sched_barrier(0);
-    mma(aP, b0P, b1P);
+    mma(aP, bP);
     __builtin_amdgcn_sched_barrier(0);
-    load(k0 + 8 * U, aP, b0P, b1P);
+    load(k0 + 8 * U, aP, bP);
     __builtin_amdgcn_sched_barrier(0);
-    mma(aQ, b0Q, b1Q);
+    mma(aQ, bQ);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -94,15 +99,15 @@ DEV float mlp_tanh(const float x) {
   return 1.0f - 2.0f / (e + 1.0f);
 }
 
-// bias + tanh of the wave's two tiles into the next layer's LDS tile
-DEV void mlp_store_hidden(float* __restrict__ H, const float* __restrict__ bias, const int lane, const int c0, const mlp_f32x4& acc0,
-                          const mlp_f32x4& acc1) {
-  const int col = c0 + (lane & 15), r4 = (lane >> 4) * 4;
-  const float bb0 = bias[col], bb1 = bias[col + 16];
+// bias + tanh of the wave's four tiles into the next layer's LDS tile: a lane holds four consecutive columns of each of its four rows
+DEV void mlp_store_hidden(float* __restrict__ H, const float* __restrict__ bias, const int lane, const int c0, const mlp_f32x4 (&acc)[4]) {
+  const int col = c0 + 4 * (lane & 15), r4 = (lane >> 4) * 4;
+  const float4 bb = *reinterpret_cast<const float4*>(bias + col);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    H[(r4 + i) * MLP_HS + col] = mlp_tanh(acc0[i] + bb0);
-    H[(r4 + i) * MLP_HS + col + 16] = mlp_tanh(acc1[i] + bb1);
+    float* h = H + (r4 + i) * MLP_HS + col;  // (8-byte aligned: the row stride is even)
+    reinterpret_cast<float2*>(h)[0] = make_float2(mlp_tanh(acc[0][i] + bb.x), mlp_tanh(acc[1][i] + bb.y));
+    reinterpret_cast<float2*>(h)[1] = make_float2(mlp_tanh(acc[2][i] + bb.z), mlp_tanh(acc[3][i] + bb.w));
   }
 }
 
@@ -127,22 +132,24 @@ __global__ __launch_bounds__(WAVE * MLP_WAVES) void k_mlp_policy(const float* __
     for (int k = lane; k < kp; k += WAVE) X[r * xs + k] = (row_in && k < in_dim) ? src[k] : 0.0f;
   }
   __syncthreads();
-  const int c0 = wave * 32;
-  mlp_f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
-  mlp_layer(X, xs, W1, kp, in_dim, lane, c0, a0, a1);
-  mlp_store_hidden(H1, b1, lane, c0, a0, a1);
+  const int c0 = wave * 64;
+  mlp_f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = mlp_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  mlp_layer(X, xs, W1, kp, in_dim, lane, c0, acc);
+  mlp_store_hidden(H1, b1, lane, c0, acc);
   __syncthreads();
-  a0 = mlp_f32x4{0.0f, 0.0f, 0.0f, 0.0f}; a1 = mlp_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  mlp_layer(H1, MLP_HS, W2, MLP_H, MLP_H, lane, c0, a0, a1);
-  mlp_store_hidden(H2, b2, lane, c0, a0, a1);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = mlp_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  mlp_layer(H1, MLP_HS, W2, MLP_H, MLP_H, lane, c0, acc);
+  mlp_store_hidden(H2, b2, lane, c0, acc);
   __syncthreads();
-  // the head: 16 rows x 2 outputs = 32 dot products of 256, sixteen lanes each (the first 512 threads = all of them)
+  // the head: 16 rows x 2 outputs = 32 dot products of 256, eight lanes each
   {
-    const int dot = tid >> 4, part = tid & 15, r = dot >> 1, o = dot & 1;
+    const int dot = tid >> 3, part = tid & 7, r = dot >> 1, o = dot & 1;
     float s = 0.0f;
 #pragma unroll 4
-    for (int k = part; k < MLP_H; k += 16) s = fmaf(H2[r * MLP_HS + k], W3[(size_t)k * out_cols + o], s);
-    s += __shfl_xor(s, 8);
+    for (int k = part; k < MLP_H; k += 8) s = fmaf(H2[r * MLP_HS + k], W3[(size_t)k * out_cols + o], s);
     s += __shfl_xor(s, 4);
     s += __shfl_xor(s, 2);
     s += __shfl_xor(s, 1);
