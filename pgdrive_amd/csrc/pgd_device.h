@@ -214,7 +214,14 @@ DEV float wrap_to_pi(float x) {  // ((x + pi) % (2 pi)) - pi with Python's sign-
   return r - PGD_PI;
 }
 // BaseVehicle.heading_theta (base_vehicle.py:411-416): (-getH() - 90) deg with getH in (-180, 180]: [-3 pi / 2, pi / 2)
-DEV float heading_wrap(float th) { return wrap_to_pi(th + 0.5f * PGD_PI) - 0.5f * PGD_PI; }
+DEV float heading_wrap(float th) {
+  // (no re-association across the inlined wrap: `(th + pi / 2) + pi` must not become `th + 3 pi / 2` in one instantiation of k_step
+  // and stay as written in another -- tools/mode_diff.py found THETA one ulp apart in 39 of 6.3 M vehicle-steps, round 6)
+#pragma clang fp contract(off)
+#pragma clang fp reassociate(off)
+  const float shifted = th + 0.5f * PGD_PI;
+  return wrap_to_pi(shifted) - 0.5f * PGD_PI;
+}
 DEV float not_zero(float x, float eps) { return fabsf(x) > eps ? x : (x > 0.0f ? eps : -eps); }
 
 // counter RNG (IDM timer reseed idm_policy.py:239, scenario resampling base_env.py:451-458)

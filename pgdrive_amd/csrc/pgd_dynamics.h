@@ -3,12 +3,21 @@
 #ifndef PGD_DYNAMICS_H
 #define PGD_DYNAMICS_H
 
+// Fused multiply-adds are WRITTEN OUT in this file's arithmetic (`fmaf`) and the compiler's own contraction / re-association is
+// switched off inside these routines: the instantiations of k_step (one env per wave, several envs per wave, specialised, general) inline
+// the same source, and left to itself the compiler fuses `a * b + c * d` one way here and the other way there -- a heading vector
+// that differs in the last bit after one step, poses that drift apart by ulps per step, and ray columns of the two modes that
+// differed by up to 1.4e-5 after ninety steps (tools/mode_diff.py, profiles/r06_notes.md).  Same instruction
+// count as the fused forms the compiler chose; every instantiation now produces the same bits from the same state.
+
 // tan on |x| <= 1 rad (steering locks are 35-50 deg; pgd_upload_scenarios rejects max_steer > 1) as sin / cos from their
 // Taylor polynomials (truncation < 2e-10): the error is the fp32 rounding of the quotient, at a sixth of tanf's instructions
 DEV float tan_small(float x) {
+#pragma clang fp contract(off)
+#pragma clang fp reassociate(off)
   const float q = x * x;
-  const float sn = x * (1.0f + q * (-1.0f / 6.0f + q * (1.0f / 120.0f + q * (-1.0f / 5040.0f + q * (1.0f / 362880.0f + q * (-1.0f / 39916800.0f))))));
-  const float cs = 1.0f + q * (-0.5f + q * (1.0f / 24.0f + q * (-1.0f / 720.0f + q * (1.0f / 40320.0f + q * (-1.0f / 3628800.0f + q * (1.0f / 479001600.0f))))));
+  const float sn = x * fmaf(q, fmaf(q, fmaf(q, fmaf(q, fmaf(q, -1.0f / 39916800.0f, 1.0f / 362880.0f), -1.0f / 5040.0f), 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
+  const float cs = fmaf(q, fmaf(q, fmaf(q, fmaf(q, fmaf(q, fmaf(q, 1.0f / 479001600.0f, -1.0f / 3628800.0f), 1.0f / 40320.0f), -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
   return sn / cs;
 }
 
@@ -18,6 +27,8 @@ DEV float tan_small(float x) {
 // contact test of this step.  ONE compiled body for both cases: two instantiations would contract their multiply-adds
 // differently and an env would not step bit-identically with and without the bookkeeping.
 DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse, const float thr, struct SubPose* sub, int slot, const bool keep) {
+#pragma clang fp contract(off)
+#pragma clang fp reassociate(off)
   float dt = d.cfg.dt;
   float force = 0.0f, brake = 0.0f;
   if (thr >= 0.0f) {
@@ -31,25 +42,26 @@ DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse, con
   float delta = -clipf(r.steer, -1.0f, 1.0f) * p.max_steer;
   // beta = atan(t), t = tan(delta)/2  ->  cos(beta) = 1/sqrt(1+t^2), sin(beta) = t/sqrt(1+t^2)
   float t = 0.5f * tan_small(delta);
-  float cb = 1.0f / sqrtf(1.0f + t * t), sb = t * cb;
+  float cb = 1.0f / sqrtf(fmaf(t, t, 1.0f)), sb = t * cb;
   // unit vector of the motion direction th + beta, advanced by exact small-angle rotations instead of sincos per sub-step
-  float cd = r.hx * cb - r.hy * sb, sd = r.hy * cb + r.hx * sb;
+  float cd = fmaf(r.hx, cb, -(r.hy * sb)), sd = fmaf(r.hy, cb, r.hx * sb);
   float inv_half_base = 2.0f / p.wheelbase;
-  float dv_brake = fminf(4.0f * brake / p.mass, p.friction * 9.81f * dt);
-  float dv_engine = 4.0f * force / p.mass * dt;
+  float dv_brake = fminf((4.0f * brake) / p.mass, (p.friction * 9.81f) * dt);
+  float dv_engine = ((4.0f * force) / p.mass) * dt;
   float trav = 0.0f;
   const int n_mid = (keep && d.cfg.decision_repeat <= PGD_MAX_SUB) ? d.cfg.decision_repeat - 1 : 0;  // sub-step poses kept
   for (int k = 0; k < d.cfg.decision_repeat; ++k) {
-    trav += fabsf(r.v) * dt;
-    r.x += r.v * cd * dt;
-    r.y += r.v * sd * dt;
-    float dth = r.v * sb * inv_half_base * dt;  // |dth| < 0.25 rad at 80 km/h and full lock
+    trav = fmaf(fabsf(r.v), dt, trav);
+    const float vd = r.v * dt;  // distance of the sub-step
+    r.x = fmaf(vd, cd, r.x);
+    r.y = fmaf(vd, sd, r.y);
+    float dth = (vd * sb) * inv_half_base;  // |dth| < 0.25 rad at 80 km/h and full lock
     r.th += dth;
     float q = dth * dth;
-    float sn = dth * (1.0f + q * (-1.0f / 6.0f + q * (1.0f / 120.0f + q * (-1.0f / 5040.0f))));
-    float cs = 1.0f + q * (-0.5f + q * (1.0f / 24.0f + q * (-1.0f / 720.0f + q * (1.0f / 40320.0f))));
-    float ncd = cd * cs - sd * sn;
-    sd = sd * cs + cd * sn;
+    float sn = dth * fmaf(q, fmaf(q, fmaf(q, -1.0f / 5040.0f, 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
+    float cs = fmaf(q, fmaf(q, fmaf(q, fmaf(q, 1.0f / 40320.0f, -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
+    float ncd = fmaf(cd, cs, -(sd * sn));
+    sd = fmaf(sd, cs, cd * sn);
     cd = ncd;
     if (force != 0.0f) r.v += dv_engine;
     else r.v = r.v >= 0.0f ? fmaxf(0.0f, r.v - dv_brake) : fminf(0.0f, r.v + dv_brake);
@@ -62,8 +74,8 @@ DEV void dynamics(const PgdDev& d, const pgd_spawn& p, Veh& r, bool reverse, con
     if (sub) { sub->trav[slot] = trav; sub->beta[slot] = make_float2(cb, sb); }
   }
   // heading unit vector = motion direction rotated back by beta, renormalised
-  float hx = cd * cb + sd * sb, hy = sd * cb - cd * sb;
-  float inv = 1.0f / sqrtf(hx * hx + hy * hy);
+  float hx = fmaf(cd, cb, sd * sb), hy = fmaf(sd, cb, -(cd * sb));
+  float inv = 1.0f / sqrtf(fmaf(hx, hx, hy * hy));
   r.hx = hx * inv;
   r.hy = hy * inv;
   // heading_theta as the reference reports it; keeps the fp32 angle exact to an ulp of pi however often the car has turned

@@ -35,7 +35,9 @@ DEV_HOST int mlp_x_stride(int in_dim) {
   const int kp = (in_dim + 3) & ~3;
   return kp + ((2 - kp) % 32 + 32) % 32;
 }
-DEV_HOST size_t mlp_lds_bytes(int in_dim) { return sizeof(float) * (size_t)MLP_ROWS * ((size_t)mlp_x_stride(in_dim) + 2 * MLP_HS); }
+DEV_HOST size_t mlp_lds_bytes(int in_dim) {  // X tile | H1 | H2 | the head's weights [2][256]
+  return sizeof(float) * ((size_t)MLP_ROWS * ((size_t)mlp_x_stride(in_dim) + 2 * MLP_HS) + 2 * MLP_H);
+}
 
 // one 256-wide layer for the wave's four column tiles: acc[t] += A[16 x K] (LDS, row stride a_ld) * W[K x 256] (global), K = kp (a
 // multiple of four; rows of W at or beyond k_real contribute zero)
@@ -113,7 +115,7 @@ DEV void mlp_store_hidden(float* __restrict__ H, const float* __restrict__ bias,
 
 // rows [row0, row0 + n_rows) of `obs` (row stride obs_stride floats, in_dim used) -> act[row][0..1]
 template <bool TANH_OUT>
-__global__ __launch_bounds__(WAVE * MLP_WAVES) void k_mlp_policy(const float* __restrict__ obs, const int row0, const int n_rows,
+__global__ __launch_bounds__(WAVE * MLP_WAVES, 4) void k_mlp_policy(const float* __restrict__ obs, const int row0, const int n_rows,
                                                                  const int obs_stride, const int in_dim, const float* __restrict__ W1,
                                                                  const float* __restrict__ b1, const float* __restrict__ W2,
                                                                  const float* __restrict__ b2, const float* __restrict__ W3,
@@ -125,11 +127,50 @@ __global__ __launch_bounds__(WAVE * MLP_WAVES) void k_mlp_policy(const float* __
   float* H2 = H1 + MLP_ROWS * MLP_HS;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r0 = (int)blockIdx.x * MLP_ROWS;  // (relative to row0)
-  // the 16 observation rows: whole rows, coalesced (a row is contiguous in memory); padding columns and rows past the end read zero
+  // the head's weights (256 x 2 of W3, its first two columns) go to LDS with the observation rows: read in the head itself, 32 strided
+  // reads per lane behind the last barrier were 2 us of a launch that has nothing else to do by then
+  float* W3s = H2 + MLP_ROWS * MLP_HS;  // [2][256]
+  float w3v[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + q * WAVE * MLP_WAVES;  // 0 .. 511: (k = idx >> 1, o = idx & 1)
+    w3v[q] = W3[(size_t)(idx >> 1) * out_cols + (idx & 1)];
+  }
+  // the 16 observation rows: whole rows, coalesced (a row is contiguous in memory); padding columns and rows past the end read zero.
+  // Every read of the wave's four rows goes out before the first LDS store (rows of up to 320 floats: five chunks of 64 per row) --
+  // as a read-then-store loop the prologue was twenty memory round trips in a row, a third of the launch (round 6)
+  constexpr int XCH = 5;
+  if (kp <= WAVE * XCH) {
+    float v[MLP_ROWS / MLP_WAVES][XCH];
+#pragma unroll
+    for (int i = 0; i < MLP_ROWS / MLP_WAVES; ++i) {
+      const int r = wave + i * MLP_WAVES;
+      const bool row_in = r0 + r < n_rows;
+      const float* src = obs + (size_t)(row0 + r0 + (row_in ? r : 0)) * obs_stride;
+#pragma unroll
+      for (int j = 0; j < XCH; ++j) {
+        const int k = lane + WAVE * j;
+        v[i][j] = src[k < in_dim ? k : in_dim - 1];
+        if (!(row_in && k < in_dim)) v[i][j] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MLP_ROWS / MLP_WAVES; ++i)
+#pragma unroll
+      for (int j = 0; j < XCH; ++j) {
+        const int k = lane + WAVE * j;
+        if (k < kp) X[(wave + i * MLP_WAVES) * xs + k] = v[i][j];
+      }
+  } else
   for (int r = wave; r < MLP_ROWS; r += MLP_WAVES) {
     const bool row_in = r0 + r < n_rows;
     const float* src = obs + (size_t)(row0 + r0 + (row_in ? r : 0)) * obs_stride;
     for (int k = lane; k < kp; k += WAVE) X[r * xs + k] = (row_in && k < in_dim) ? src[k] : 0.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + q * WAVE * MLP_WAVES;
+    W3s[(idx & 1) * MLP_H + (idx >> 1)] = w3v[q];
   }
   __syncthreads();
   const int c0 = wave * 64;
@@ -149,7 +190,7 @@ __global__ __launch_bounds__(WAVE * MLP_WAVES) void k_mlp_policy(const float* __
     const int dot = tid >> 3, part = tid & 7, r = dot >> 1, o = dot & 1;
     float s = 0.0f;
 #pragma unroll 4
-    for (int k = part; k < MLP_H; k += 8) s = fmaf(H2[r * MLP_HS + k], W3[(size_t)k * out_cols + o], s);
+    for (int k = part; k < MLP_H; k += 8) s = fmaf(H2[r * MLP_HS + k], W3s[o * MLP_H + k], s);
     s += __shfl_xor(s, 4);
     s += __shfl_xor(s, 2);
     s += __shfl_xor(s, 1);

@@ -1074,9 +1074,9 @@ def test_throughput_mode_at_32768_envs_properties():
             e.sync()
             assert torch.equal(d1[lo:lo + n], d2) and torch.equal(f1[lo:lo + n], f2), "flags differ from the default mode at step %d" % t
             dd = (o1[lo:lo + n] - o2).abs()
-            # (the two instantiations contract their multiply-adds differently: the state / navigation / neighbour columns agree to
-            # 2e-6; a ray column may differ by what the ray tolerance against the oracle allows -- since the -O2 build a few beams in
-            # a million do, by up to 1.4e-5 = 0.7 mm at the lidar's 50 m)
+            # (round 6: the dynamics spell their fused multiply-adds out -- pgd_dynamics.h -- so the two instantiations carry bit-identical
+            # poses from step to step; what is left is the last bit of a few observation columns, not a drift: every column, the ray
+            # columns included, agrees to 2e-6 again.  With the -O2 build of round 5 a few beams in a million differed by up to 1.4e-5.)
             worst = max(worst, float(dd[..., :34].max()), float((r1[lo:lo + n] - r2).abs().max()) * 0.05)
             worst_ray = max(worst_ray, float(dd[..., 34:].max()))
             n_ray += int(dd[..., 34:].numel())
@@ -1093,10 +1093,8 @@ def test_throughput_mode_at_32768_envs_properties():
             ckpt = big.get_state()
         if t > 50:
             tail.append((act, o1))
-    assert n_done > 3000 and worst < 2e-6 and worst_ray < OBS_TOL, (n_done, worst, worst_ray)
-    # ... and not only a maximum: the beams on which the two instantiations differ by more than rounding stay a few in a million
-    # (measured 26 of 3.4 M = 7.6e-6 with the -O2 build)
-    assert n_ray > 3_000_000 and n_ray_over <= 2e-5 * n_ray, (n_ray_over, n_ray)
+    assert n_done > 3000 and worst < 2e-6 and worst_ray < 2e-6, (n_done, worst, worst_ray)
+    assert n_ray > 3_000_000 and n_ray_over == 0, (n_ray_over, n_ray)
     resumed = make(N)
     resumed.reset(ids)
     resumed.set_state(*ckpt)
@@ -1120,7 +1118,7 @@ def test_throughput_mode_at_32768_envs_properties():
     assert "throughput" in big.describe_step() and "switched off" not in big.describe_step()
     dd = (twin.obs - o_ref).abs()
     assert torch.equal(twin.done, d_ref) and torch.equal(twin.flags, f_ref)
-    assert float(dd[..., :34].max()) < 2e-6 and float(dd[..., 34:].max()) < OBS_TOL  # (state columns / ray columns, as above)
+    assert float(dd.max()) < 2e-6  # (every column, as above)
     for e in [big, twin, resumed] + small:
         e.close()
 
