@@ -948,7 +948,7 @@ def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
                     window_spread=(max(wins) - min(wins)) / wins[med], us_per_iteration=wins[med] / steps * 1e6,
                     host_enqueue_us_per_step=enq[med] / steps * 1e6)
 
-    N, UNROLL, G = 4096, 4, 2
+    N, UNROLL = 4096, 4
     out = {"row": "c3_policy", "workload": "C3 closed loop: %d envs x (1 ego + 16 IDM traffic slots) x 240 beams, actions = tanh MLP 274-256-256-2 "
                                            "(fp32, random weights) of the last observation, auto-reset" % N,
            "unit": "env-steps/s", "steps_timed": steps, "warmup_run": warm,
@@ -992,51 +992,55 @@ def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
                 eng.close()
         except Exception as ex:  # noqa: BLE001
             res["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
-        try:  # two env groups of 4096: a single-stream graph per group, replayed on the group's stream
-            with torch.no_grad():
-                eng = engine(G * N)
-                eng.set_groups(G)
-                act = torch.zeros((G * N, 1, 2), dtype=torch.float32, device=dev)
-                views = [(eng.obs[eng.group_slice(k)].view(N, -1), act[eng.group_slice(k)].view(N, 2)) for k in range(G)]
-                gs = eng.group_streams
+        # env groups (pgd_set_groups): a single-stream graph per group, replayed on the group's stream -- 2 x 4096 (the verdict's
+        # variant), and smaller groups, which leave register file for the policy's waves next to the other group's step
+        for Gn, Ng in ((2, N), (2, N // 2), (4, N // 2)):
+            key = "groups_graph" if (Gn, Ng) == (2, N) else "groups_graph_%dx%d" % (Gn, Ng)
+            try:
+                with torch.no_grad():
+                    eng = engine(Gn * Ng)
+                    eng.set_groups(Gn)
+                    act = torch.zeros((Gn * Ng, 1, 2), dtype=torch.float32, device=dev)
+                    views = [(eng.obs[eng.group_slice(k)].view(Ng, -1), act[eng.group_slice(k)].view(Ng, 2)) for k in range(Gn)]
+                    gs = eng.group_streams
 
-                def group_iteration(k):  # (on the group's stream)
-                    if impl == "torch":
-                        policy_torch(*views[k])
-                    else:
-                        eng.mlp_policy(weights, act, group=k, final_tanh=True)
-                    eng.step_group(k, act)
-                cur = torch.cuda.current_stream(dev)
-                graphs = []
-                for k in range(G):
-                    gs[k].wait_stream(cur)
-                    with torch.cuda.stream(gs[k]):
-                        for _ in range(warm):
-                            group_iteration(k)
-                torch.cuda.synchronize(dev)
-                for k in range(G):
-                    gk = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gk, stream=gs[k]):
-                        for _ in range(UNROLL):
-                            group_iteration(k)
-                    graphs.append(gk)
-                torch.cuda.synchronize(dev)
-
-                def replay_all():
-                    for k in range(G):
+                    def group_iteration(k):  # (on the group's stream)
+                        if impl == "torch":
+                            policy_torch(*views[k])
+                        else:
+                            eng.mlp_policy(weights, act, group=k, final_tanh=True)
+                        eng.step_group(k, act)
+                    cur = torch.cuda.current_stream(dev)
+                    graphs = []
+                    for k in range(Gn):
+                        gs[k].wait_stream(cur)
                         with torch.cuda.stream(gs[k]):
-                            graphs[k].replay()
-                for _ in range(8):
-                    replay_all()
-                res["groups_graph"] = dict(timed(lambda: [replay_all() for _ in range(steps // UNROLL)], G * N * steps), steps_per_replay=UNROLL,
-                                           env_groups=G, envs=G * N, note="one iteration = both groups stepped once (%d env-steps)" % (G * N))
-                del graphs
-                eng.close()
-        except Exception as ex:  # noqa: BLE001
-            res["groups_graph"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+                            for _ in range(warm):
+                                group_iteration(k)
+                    torch.cuda.synchronize(dev)
+                    for k in range(Gn):
+                        gk = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gk, stream=gs[k]):
+                            for _ in range(UNROLL):
+                                group_iteration(k)
+                        graphs.append(gk)
+                    torch.cuda.synchronize(dev)
+
+                    def replay_all():
+                        for k in range(Gn):
+                            with torch.cuda.stream(gs[k]):
+                                graphs[k].replay()
+                    for _ in range(8):
+                        replay_all()
+                    res[key] = dict(timed(lambda: [replay_all() for _ in range(steps // UNROLL)], Gn * Ng * steps), steps_per_replay=UNROLL,
+                                    env_groups=Gn, envs=Gn * Ng, note="one iteration = every group stepped once (%d env-steps)" % (Gn * Ng))
+                    del graphs
+                    eng.close()
+            except Exception as ex:  # noqa: BLE001
+                res[key] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
         out[impl] = res
-    vals = [(out[i][k]["value"], "%s/%s" % (i, k)) for i in ("torch", "fused") for k in ("eager", "graph", "groups_graph")
-            if isinstance(out.get(i, {}).get(k), dict) and "value" in out[i][k]]
+    vals = [(v["value"], "%s/%s" % (i, k)) for i in ("torch", "fused") for k, v in (out.get(i) or {}).items()
+            if isinstance(v, dict) and "value" in v]
     out["value"], out["value_variant"] = max(vals) if vals else (None, None)
     return out
 

@@ -76,9 +76,10 @@ DEV void mlp_layer(const float* __restrict__ A, const int a_ld, const float* __r
   };
   float aP[U], aQ[U];
   float4 bP[U], bQ[U];
-  // (rounds come in pairs and every read is unconditional: a straight-line loop body, so that the wait in front of a round's matrix
-  // instructions leaves the reads of the round after it in flight; a round past the end multiplies zeros: <= 1,024 cycles)
-  const int pairs = (kp + 8 * U - 1) / (8 * U);
+  // (every read is unconditional and the loop body is straight-line -- two rounds, ping then pong --, so that the wait in front of a
+  // round's matrix instructions leaves the reads of the round after it in flight; an odd last round runs behind the loop: its reads
+  // were the loop's last; the partial last round multiplies zeros for the k-steps past the end)
+  const int rounds = (kp + 4 * U - 1) / (4 * U), pairs = rounds >> 1;
   load(0, aP, bP);
   for (int p = 0; p < pairs; ++p) {
     const int k0 = p * 8 * U;
@@ -93,6 +94,7 @@ DEV void mlp_layer(const float* __restrict__ A, const int a_ld, const float* __r
     mma(aQ, bQ);
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (rounds & 1) mma(aP, bP);
 }
 
 // tanh in fp32 through one exponential: tanh(x) = 1 - 2 / (e^{2x} + 1), |error| of a few ulp for |x| < 9, saturating beyond
