@@ -296,6 +296,13 @@ int pgd_group_sync(pgd_handle h, int group);
  *   steering = clip(k_lat * 18 * (o[0] - o[1]) / 10 + k_head * (2 o[2] - 1) + noise * n1, -1, 1)
  *   throttle = clip(0.3 * (v_target_kmh - v_kmh) + noise * n2, -1, 1)      n1, n2 ~ U(-1, 1) from the counter RNG (seed, env, tick)
  * d_actions [N, 1, 2] is then handed to pgd_step.  Not part of the reference's env.step: a convenience of this library. */
+/* The same policy evaluated by the step itself: pgd_step_lane_keep = pgd_lane_keep_actions on the rows in d_obs (what the previous
+ * pgd_step / pgd_reset / pgd_step_lane_keep wrote there) followed by pgd_step with those actions, d_obs rewritten -- as ONE launch on
+ * engines with one env per wave (the step kernel reads the four floats where it would read the caller's action; the same arithmetic,
+ * the same bits), as the two launches otherwise.  Closed-loop driving without a second launch per step (the policy kernel alone
+ * was a fifth of an iteration: its launch floor). */
+int pgd_step_lane_keep(pgd_handle h, float k_lat, float k_head, float v_target_kmh, float noise, uint32_t tick, float* d_obs /*[N,1,D]*/,
+                       float* d_reward, uint8_t* d_done, uint32_t* d_flags);
 int pgd_lane_keep_actions(pgd_handle h, const float* d_obs /*[N,1,D]*/, float* d_actions /*[N,1,2]*/, float k_lat, float k_head,
                           float v_target_kmh, float noise, uint32_t tick);
 

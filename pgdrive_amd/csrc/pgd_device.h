@@ -214,14 +214,11 @@ DEV float wrap_to_pi(float x) {  // ((x + pi) % (2 pi)) - pi with Python's sign-
   return r - PGD_PI;
 }
 // BaseVehicle.heading_theta (base_vehicle.py:411-416): (-getH() - 90) deg with getH in (-180, 180]: [-3 pi / 2, pi / 2)
-DEV float heading_wrap(float th) {
-  // (no re-association across the inlined wrap: `(th + pi / 2) + pi` must not become `th + 3 pi / 2` in one instantiation of k_step
-  // and stay as written in another -- tools/mode_diff.py found THETA one ulp apart in 39 of 6.3 M vehicle-steps, round 6)
-#pragma clang fp contract(off)
-#pragma clang fp reassociate(off)
-  const float shifted = th + 0.5f * PGD_PI;
-  return wrap_to_pi(shifted) - 0.5f * PGD_PI;
-}
+// (Not pinned like wrap_to_pi itself: with contraction / re-association switched off HERE the metric's kernel ran 0.1 us slower --
+// 17.00 -> 17.12 us, three interleaved repetitions -- for a different schedule of the same arithmetic.  Left as it is, SF_THETA of the
+// throughput-mode and the one-env kernels differs by one ulp in 40 - 60 of 6.3 M vehicle-steps (`(th + pi / 2) + pi` folded in one of
+// them, tools/mode_diff.py); every pose, heading vector and ray column is bit-identical either way: profiles/r06_notes.md.)
+DEV float heading_wrap(float th) { return wrap_to_pi(th + 0.5f * PGD_PI) - 0.5f * PGD_PI; }
 DEV float not_zero(float x, float eps) { return fabsf(x) > eps ? x : (x > 0.0f ? eps : -eps); }
 
 // counter RNG (IDM timer reseed idm_policy.py:239, scenario resampling base_env.py:451-458)
@@ -373,6 +370,20 @@ DEV void projection(float hx, float hy, float vx, float vy, float& ph, float& ps
   ph = (vx * hx + vy * hy) / (l + 1e-6f);
   float sx = -hy / l, sy = hx / l;
   ps = (vx * sx + vy * sy) / (norm2(sx, sy) + 1e-6f);
+}
+
+// the scripted lane-keeping policy (pgd_lane_keep_actions / pgd_step_lane_keep; include/pgdrive_hip.h): ONE arithmetic for the
+// stand-alone kernel and the copy inside k_step (fused multiply-adds written out, no contraction: the two must give the same bits)
+DEV float2 lane_keep_action(const uint32_t seed, const int env_global, const float o0, const float o1, const float o2, const float o3, const float k_lat,
+                            const float k_head, const float v_target, const float noise, const uint32_t tick) {
+#pragma clang fp contract(off)
+#pragma clang fp reassociate(off)
+  const uint32_t r = pgd_rng(seed ^ 0x1a7e5eedu, (uint32_t)env_global, 0x900dcafeu, tick);
+  const float n1 = fmaf((float)(r & 0xffffu), 2.0f / 65535.0f, -1.0f), n2 = fmaf((float)(r >> 16), 2.0f / 65535.0f, -1.0f);
+  const float v_kmh = fmaf(o3, 81.0f, -1.0f);  // state_obs.py:82: (speed + 1) / (max_speed + 1), max_speed 80 km/h
+  const float st = fmaf(noise, n1, fmaf(k_head, fmaf(2.0f, o2, -1.0f), (k_lat * 1.8f) * (o0 - o1)));
+  const float tb = fmaf(noise, n2, 0.3f * (v_target - v_kmh));
+  return make_float2(clipf(st, -1.0f, 1.0f), clipf(tb, -1.0f, 1.0f));
 }
 
 DEV float pid_update(float& p, float& i, float kp, float ki, float kd, float err) {  // PID_controller.py:10-17

@@ -267,8 +267,17 @@ struct PgdCold {
   int n_scen;
   uint32_t seed;
   int env_base;
+  // pgd_step_lane_keep: the scripted lane-keeping policy evaluated by k_step itself, from the observation row the PREVIOUS step wrote
+  // (null: the actions come from the caller's buffer).  One launch per closed-loop step instead of two (k_lane_keep was 4.9 us of a
+  // 23.5 us iteration: the launch floor of a 16-block kernel, profiles/r06_expert_kernel_stats.csv).  Here, not in PgdDev: these
+  // fields are read once, at the head of the kernel, and must not cost the specialised kernels scalar registers for the whole step.
+  const float* lk_obs;
+  float lk_klat, lk_khead, lk_vt, lk_noise;
+  uint32_t lk_tick;
 };
-template <bool ONE_ENV, bool MARL, bool OBJ, bool STD = false, int FIX = 0>
+// LK: the scripted lane-keeping policy inside the step (pgd_step_lane_keep): an instantiation of its own -- as a run-time branch at
+// the head of every kernel it cost the metric's row 0.09 us (17.03 -> 17.12)
+template <bool ONE_ENV, bool MARL, bool OBJ, bool STD = false, int FIX = 0, bool LK = false>
 __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, const float* __restrict__ act, float* __restrict__ reward,
                                                 uint8_t* __restrict__ done, uint32_t* __restrict__ flags,
                                                 float* __restrict__ obs, const PgdCold cold) {
@@ -363,7 +372,13 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
   // of the slot's spawn record next to the vehicle record (18.4 us): the first burst of a wave stays as short as it can be
   float2 act_in = make_float2(0.0f, 0.0f);
   constexpr bool ACT_EARLY = ONE_ENV || FIXE_K;
-  if (ACT_EARLY && valid && s < A) act_in = *reinterpret_cast<const float2*>(act + ((size_t)e * A + s) * 2);
+  if (ACT_EARLY && valid && s < A) {
+    if (LK) {  // pgd_step_lane_keep: the action from the row the previous step wrote -- the same round trip as the caller's action
+      const float* o = cold.lk_obs + ((size_t)e * A + s) * d.D;
+      const float2 q0 = *reinterpret_cast<const float2*>(o), q1 = *reinterpret_cast<const float2*>(o + 2);  // (rows are 8-byte aligned: D even)
+      act_in = lane_keep_action(cold.seed, cold.env_base + e, q0.x, q0.y, q1.x, q1.y, cold.lk_klat, cold.lk_khead, cold.lk_vt, cold.lk_noise, cold.lk_tick);
+    } else act_in = *reinterpret_cast<const float2*>(act + ((size_t)e * A + s) * 2);
+  }
   // single-agent engines: a slot keeps the spawn record of its own index (only a multi-agent respawn hands a slot another one; a
   // state set by hand may: checked below) -- the head's address follows from the scenario id like the record's, and its reads travel
   // with the record's instead of waiting for them (17.48 -> 17.40 us on the metric's row, now that the records' reads are short)
@@ -1358,18 +1373,11 @@ __global__ __launch_bounds__(256) void k_lane_keep(PgdDev d, const float* __rest
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.N) return;
   const float* o = obs + (size_t)e * d.D;
-  const float o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3];
-  const uint32_t r = pgd_rng(d.cfg.seed ^ 0x1a7e5eedu, (uint32_t)(d.cfg.env_base + e), 0x900dcafeu, tick);
-  const float n1 = (float)(r & 0xffffu) * (2.0f / 65535.0f) - 1.0f, n2 = (float)(r >> 16) * (2.0f / 65535.0f) - 1.0f;
-  const float v_kmh = o3 * 81.0f - 1.0f;  // state_obs.py:82: (speed + 1) / (max_speed + 1), max_speed 80 km/h
-  act[(size_t)e * 2 + 0] = clipf(k_lat * 1.8f * (o0 - o1) + k_head * (2.0f * o2 - 1.0f) + noise * n1, -1.0f, 1.0f);
-  act[(size_t)e * 2 + 1] = clipf(0.3f * (v_target - v_kmh) + noise * n2, -1.0f, 1.0f);
+  const float2 a = lane_keep_action(d.cfg.seed, d.cfg.env_base + e, o[0], o[1], o[2], o[3], k_lat, k_head, v_target, noise, tick);
+  act[(size_t)e * 2 + 0] = a.x;
+  act[(size_t)e * 2 + 1] = a.y;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// host side
-// ---------------------------------------------------------------------------------------------------------------------
-// the env hint words back to "test contacts, trigger verdict unknown" (upload calls: maps / scenarios of running envs changed)
 __global__ void k_clear_hints(int32_t* ei, int n) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) ei[(size_t)e * PGD_NEI + EI_NEAR] = 1;
@@ -1421,6 +1429,8 @@ struct pgd_engine {
   int imask_env;        // PGD_NO_IMASK / PGD_IMASK: 0 / 1 force the reset-image reads off / on, -1 = by mode (PgdDev::use_imask)
   bool left_pack_mode;  // pgd_set_groups switched the engine from throughput mode back to one env per wave (reported by pgd_describe_step)
   ulonglong2* rowz;  // multi-agent engines: PgdDev::rowz (zero-row marks + the tag of the buffer they describe, per env)
+  struct { const float* obs; float k_lat, k_head, v_target, noise; uint32_t tick; } lk;  // pgd_step_lane_keep: this launch's scripted policy (obs null: none)
+  float* lk_act;     // pgd_step_lane_keep on engines that cannot take the policy into the step kernel: the actions in between
 };
 
 // Rows written by a kernel that does not keep the zero-row marks (k_observe, one block per row): what the marks say about this
@@ -1959,6 +1969,10 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
     const bool std_obs = c.side_lasers == 0 && c.lane_line_lasers == 0 && !c.random_agent_model &&
                          c.lidar_gaussian_noise <= 0.0f && c.lidar_dropout_prob <= 0.0f;
     kern = h->has_objects ? k_step<true, false, true> : (std_obs ? k_step<true, false, false, true> : k_step<true, false, false>);
+    if (h->lk.obs) {  // (pgd_step_lane_keep checked lane_keep_in_step: the default configuration's instantiation with the policy in it)
+      kern = k_step<true, false, false, true, 1, true>;
+      kname = "k_step: one env per wave, specialised for the default single-agent configuration, scripted lane-keeping policy inside";
+    } else
     if (h->has_objects && std_obs && !h->no_fix && fix_config_matches(dv, true, FIXK_SAFE)) {
       kern = k_step<true, false, true, true, 4>;
       kname = "k_step: one env per wave, specialised for the SafePGDriveEnv configuration (16 traffic + 40 object slots, run-time reward scheme)";
@@ -1995,7 +2009,8 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   h->last_step_kernel = kname;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), 0, stream, dv, d_actions, d_reward, d_done,
                      d_flags, fuse ? d_obs : (float*)nullptr,
-                     PgdCold{dv.scen_map, dv.bev_fill, dv.spawn_hv, dv.respawn_img, dv.n_scen, dv.cfg.seed, dv.cfg.env_base});
+                     PgdCold{dv.scen_map, dv.bev_fill, dv.spawn_hv, dv.respawn_img, dv.n_scen, dv.cfg.seed, dv.cfg.env_base,
+                             h->lk.obs, h->lk.k_lat, h->lk.k_head, h->lk.v_target, h->lk.noise, h->lk.tick});
   HIPCHK(hipGetLastError());
   if (prof || g_close) HIPCHK(hipEventRecord(pe[1], h->stream));
   if (g_close) h->prof_n += 1;
@@ -2131,6 +2146,34 @@ int pgd_describe_step(pgd_handle h, char* buf, int cap) {
   snprintf(buf, (size_t)cap, "%s%s", h->last_step_kernel ? h->last_step_kernel : "",
            h->left_pack_mode ? " [throughput mode switched off by pgd_set_groups: the group size is not a whole number of three-env waves]" : "");
   return PGD_OK;
+}
+
+// the engines whose step kernel has an instantiation with the scripted policy inside: the reference's default single-agent configuration
+static bool lane_keep_in_step(const pgd_engine* h) {
+  const pgd_config& c = h->d.cfg;
+  const bool std_obs = c.side_lasers == 0 && c.lane_line_lasers == 0 && !c.random_agent_model && c.lidar_gaussian_noise <= 0.0f &&
+                       c.lidar_dropout_prob <= 0.0f;
+  return h->d.epw == 1 && !(c.marl_flags & PGD_MA_ENABLED) && !h->has_objects && std_obs && !h->no_fix && !h->no_fuse &&
+         fix_config_matches(h->d, true);
+}
+
+int pgd_step_lane_keep(pgd_handle h, float k_lat, float k_head, float v_target_kmh, float noise, uint32_t tick, float* d_obs,
+                       float* d_reward, uint8_t* d_done, uint32_t* d_flags) {
+  if (!h || !d_obs || !d_reward || !d_done || !d_flags) return PGD_ERR_ARG;
+  if (h->d.A != 1 || h->d.cfg.side_lasers != 0 || h->d.D < 4) return PGD_ERR_STATE;  // reads columns 0..3 of the default layout
+  if (lane_keep_in_step(h) && (reinterpret_cast<uintptr_t>(d_obs) & 7u) == 0u) {
+    // one launch: k_step reads the row of the previous step where it would read the caller's action
+    h->lk = {d_obs, k_lat, k_head, v_target_kmh, noise, tick};
+    const int rc = step_impl(h, d_obs /* (never read: the kernel takes the scripted action) */, d_obs, d_reward, d_done, d_flags,
+                             h->d.A * h->d.D, false);
+    h->lk.obs = nullptr;
+    return rc;
+  }
+  // any other engine: the policy as a launch of its own
+  if (!h->lk_act) HIPCHK(hipMalloc((void**)&h->lk_act, sizeof(float) * 2 * (size_t)h->d.N));
+  const int rc = pgd_lane_keep_actions(h, d_obs, h->lk_act, k_lat, k_head, v_target_kmh, noise, tick);
+  if (rc) return rc;
+  return step_impl(h, h->lk_act, d_obs, d_reward, d_done, d_flags, h->d.A * h->d.D, false);
 }
 
 int pgd_lane_keep_actions(pgd_handle h, const float* d_obs, float* d_actions, float k_lat, float k_head, float v_target_kmh,
@@ -2357,7 +2400,7 @@ int pgd_sync(pgd_handle h) {
 int pgd_destroy(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   (void)hipStreamSynchronize(h->stream);
-  void* bufs[] = {h->rowz, h->d.rec, h->d.ei, h->d.imask, h->d.env_map, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
+  void* bufs[] = {h->lk_act, h->rowz, h->d.rec, h->d.ei, h->d.imask, h->d.env_map, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
                   h->cell_items, h->cell_boxes, h->cell_ext, h->lane_nav, h->scen_map, h->scen, h->spawns, h->spawn_hv, h->beam, h->reset_img, h->respawn_img};
   for (void* b : bufs)
     if (b) (void)hipFree(b);

@@ -29,6 +29,7 @@ _SIGS = {
     "pgd_describe_step": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "pgd_forget_rows": (C.c_int, [C.c_void_p]),
     "pgd_mlp_policy": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
+    "pgd_step_lane_keep": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32] + [C.c_void_p] * 4),
     "pgd_lane_keep_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32]),
     "pgd_topdown_channels": (C.c_int, [C.POINTER(_abi.TopDownConfig)]),
     "pgd_topdown_enable": (C.c_int, [C.c_void_p, C.POINTER(_abi.TopDownConfig)]),
@@ -276,6 +277,19 @@ class Engine:
                                    C.c_void_p(w3.data_ptr()), C.c_void_p(b3.data_ptr()), int(w3.shape[1]), int(bool(final_tanh)),
                                    C.c_void_p(out.data_ptr())), "pgd_mlp_policy")
         return out
+
+    def step_lane_keep(self, tick, k_lat=1.0, k_head=2.0, v_target_kmh=30.0, noise=0.05):
+        """One closed-loop step under the scripted lane-keeping policy (pgd_step_lane_keep): the policy reads the engine's own
+        observation buffer (what the previous step / reset wrote), the step rewrites it -- one launch on engines with one env per
+        wave.  Same results as lane_keep_actions(...) followed by step(...)."""
+        cur = self.torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self._bound_stream:
+            _chk(self.L.pgd_set_stream(self.h, C.c_void_p(cur)), "pgd_set_stream")
+            self._bound_stream = cur
+        p_obs, p_rew, p_done, p_flags = self._own_ptrs
+        _chk(self.L.pgd_step_lane_keep(self.h, k_lat, k_head, v_target_kmh, noise, int(tick) & 0xffffffff, p_obs, p_rew, p_done, p_flags),
+             "pgd_step_lane_keep")
+        return self.obs, self.reward, self.done, self.flags
 
     # -- top-down observation (obs/top_down_obs_multi_channel.py) -----------------------------------------------------------
     def enable_topdown(self, td_cfg=None):

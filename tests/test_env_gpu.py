@@ -1022,3 +1022,35 @@ def test_mlp_policy_matches_the_numpy_expert(descs, case):
         assert eng.L.pgd_mlp_policy(eng.h, -1, C.c_void_p(o2.data_ptr()), 100, 274, 256, *p, 2, 0, C.c_void_p(out.data_ptr())) == 1
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("pack", ["0", "1"])
+def test_step_lane_keep_equals_policy_then_step(descs, monkeypatch, pack):
+    """pgd_step_lane_keep (round 6: the scripted lane-keeping policy evaluated by the step kernel itself, from the row the previous
+    step wrote) against pgd_lane_keep_actions + pgd_step: the same arithmetic compiled into both kernels (fused multiply-adds written
+    out), so every output is BIT-identical over 300 closed-loop steps with auto-resets -- with one env per wave (one launch) and with
+    several envs per wave (PGD_PACK=1: the call falls back to the two launches itself)."""
+    import torch
+    from pgdrive_amd import _abi
+    from pgdrive_amd.engine import Engine
+    from tests import util
+    monkeypatch.setenv("PGD_PACK", pack)
+    mb, sb = util.make_banks(descs, n_maps=8)
+    n = 99
+    a, b = Engine(_abi.make_config(n, auto_reset=1, seed=5), mb, sb), Engine(_abi.make_config(n, auto_reset=1, seed=5), mb, sb)
+    try:
+        ids = np.arange(n) % 8
+        a.reset(ids); b.reset(ids)
+        act = torch.zeros((n, 1, 2), device="cuda")
+        n_done = 0
+        for t in range(300):
+            a.lane_keep_actions(act, t)
+            o1, r1, d1, f1 = [x.clone() for x in a.step(act)]
+            o2, r2, d2, f2 = b.step_lane_keep(t)
+            a.sync(); b.sync()
+            assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(f1, f2), "step %d" % t
+            n_done += int(d1.sum())
+        assert n_done > 5 and float(a.get_state()[0][_abi.SF["SPEED"]][:, 0].mean()) > 2.0  # (the egos drive)
+        assert ("throughput" in b.describe_step()) == (pack == "1")
+    finally:
+        a.close(); b.close()
