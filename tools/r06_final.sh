@@ -28,3 +28,5 @@ TRAFFIC=respawn timeout 600 python tools/wave_life.py uniform 4096 24 > $O/wave_
 timeout 600 python tools/wave_life.py expert 4096 24 > $O/wave_life_expert.txt 2>&1; head -6 $O/wave_life_expert.txt
 timeout 600 python tools/wave_life.py uniform 4096 24 > $O/wave_life_metric.txt 2>&1; head -6 $O/wave_life_metric.txt
 timeout 300 python tools/mlp_bench.py 4096 2>&1 | grep -v amdgpu.ids | tee $O/mlp_bench.txt
+( time timeout 3000 python tests/parity_campaign.py ) > $O/campaign.log 2>&1; tail -6 $O/campaign.log | cut -c1-200; cp gpurun_out/campaign.json $O/campaign.json
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
