@@ -444,9 +444,11 @@ ROWS = [
     ("c3_expert_respawn", dict(actions="expert", traffic_mode="respawn")),
     # (the multi-agent rows: windows of 2000 steps = two whole 1000-step agent horizons, so that the three windows see the same mix of
     # the population's phases -- with 1024-step windows they differed by 10 - 12 %)
-    ("c5_8x240", dict(workload="c5", agents=8, lasers=240, warmup=1000, steps=2000)),
-    ("c5_8x72", dict(workload="c5", agents=8, lasers=72, warmup=1000, steps=2000)),
-    ("c5_40x72", dict(workload="c5", agents=40, lasers=72, warmup=1000, steps=2000)),
+    # (and a pre-roll of 6000 steps: with 1000 the three windows still FELL -- 83.1 / 79.4 / 77.2 M at 40 seats: the roundabout's
+    # population was still growing -- and the median overstated the steady state; round 6)
+    ("c5_8x240", dict(workload="c5", agents=8, lasers=240, warmup=6000, steps=2000)),
+    ("c5_8x72", dict(workload="c5", agents=8, lasers=72, warmup=6000, steps=2000)),
+    ("c5_40x72", dict(workload="c5", agents=40, lasers=72, warmup=6000, steps=2000)),
     ("c3_32768", dict(envs=32768, warmup=1500, steps=512)),
     # the top-down image observation (TopDownPGDriveEnv: 84 x 84 x 5 floats per env and step instead of the 274-float row): pgd_step
     # without the lidar + pgd_observe_topdown; a write-bound kernel of its own

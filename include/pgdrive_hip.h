@@ -200,6 +200,14 @@ typedef struct pgd_config {
                                / GPUs reproduce the single-engine run env for env */
   int32_t idm_agent;        /* IDM_agent (base_env.py:30, agent_manager.py:79): the ego is driven by IDMPolicy along its route,
                                the actions handed to pgd_step are ignored.  Single-agent engines only */
+  float idm_steer_lag;      /* NOT in the reference; 0 (the default) = the reference's behaviour.  > 0: time constant [s] of a
+                               first-order lag between the steering IDMPolicy commands (idm_policy.py:244-252) and the steering an
+                               IDM-driven vehicle applies: steer += (clip(cmd) - steer) * T / (lag + T), T = dt * decision_repeat.
+                               The reference's heading PID (kp 1.7, kd 3.5 per 0.1 s decision) was tuned on Bullet's raycast
+                               vehicle; on the kinematic bicycle (no yaw inertia) the same gains end in a two-step limit cycle,
+                               steering lock to lock (tests/test_traffic_band_gpu.py).  The lag stands in for the yaw dynamics the
+                               bicycle lacks: an OPT-IN for users who train against traffic; unpinned like the bicycle itself.
+                               Controlled agents are never lagged.  0.2 s settles the traffic on its lane axis */
 } pgd_config;
 
 #define PGD_MA_ENABLED        1  /* MultiAgentPGDrive semantics: per-agent done, delay-done queue, respawn, __all__ */

@@ -17,6 +17,7 @@ class PgdConfig(C.Structure):
         ("safe_rl_env", C.c_int32), ("overspeed_penalty", C.c_float), ("min_pass_steps", C.c_int32),
         ("enable_reverse", C.c_int32), ("lidar_gaussian_noise", C.c_float), ("lidar_dropout_prob", C.c_float),
         ("random_agent_model", C.c_int32), ("env_base", C.c_int32), ("idm_agent", C.c_int32),
+        ("idm_steer_lag", C.c_float),
     ]
 
 
@@ -40,7 +41,7 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
                 discrete_action=False, discrete_steering_dim=5, discrete_throttle_dim=5, increment_steering=False,
                 safe_rl_env=False, plain_reward=False, cross_yellow_line_done=True, tollgate=False, overspeed_penalty=0.5,
                 min_pass_steps=30, enable_reverse=False, parking=False, others_state=False, random_agent_model=False,
-                lidar_gaussian_noise=0.0, lidar_dropout_prob=0.0, env_base=0, idm_agent=False):
+                lidar_gaussian_noise=0.0, lidar_dropout_prob=0.0, env_base=0, idm_agent=False, idm_steer_lag=0.0):
     """Defaults mirror PGDriveEnv_DEFAULT_CONFIG / BASE_DEFAULT_CONFIG (pgdrive_env.py:22-109, base_env.py:19-90)."""
     c = PgdConfig()
     c.num_envs, c.num_agents, c.num_traffic = num_envs, num_agents, num_traffic
@@ -58,6 +59,7 @@ def make_config(num_envs, num_agents=1, num_traffic=16, num_lasers=240, num_othe
     c.safe_rl_env = int(bool(safe_rl_env))
     c.env_base = int(env_base)
     c.idm_agent = int(bool(idm_agent))
+    c.idm_steer_lag = float(idm_steer_lag)  # (an extension, default off: include/pgdrive_hip.h)
     c.enable_reverse = int(bool(enable_reverse))
     c.random_agent_model = int(bool(random_agent_model))
     c.lidar_gaussian_noise, c.lidar_dropout_prob = float(lidar_gaussian_noise), float(lidar_dropout_prob)

@@ -198,7 +198,8 @@ constexpr FixSpec fix_spec(int fix) {
   F(c.num_agents, 1) F(c.num_traffic, SP.V - 1) F(c.num_lasers, SP.lasers) F(c.num_others, SP.others)                                     \
   F(c.dt, 0.02f) F(c.decision_repeat, 5) F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, SP.safe)               \
   F(c.enable_reverse, 0) F(c.marl_flags, 0) F(c.side_lasers, 0) F(c.lane_line_lasers, 0)                                            \
-  F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f) F(c.idm_agent, 0)
+  F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f) F(c.idm_agent, 0)              \
+  F(c.idm_steer_lag, 0.0f)
 #define PGD_FIX_LIDAR_FIELDS(F, c) F(c.lidar_dist, 50.0f)
 #define PGD_FIX_REWARD_FIELDS(F, c)                                                                                                 \
   F(c.use_lateral, 0) F(c.out_of_route_done, 0) F(c.success_reward, 10.0f) F(c.out_of_road_penalty, 5.0f)                           \
@@ -215,7 +216,8 @@ constexpr FixSpec fix_spec(int fix) {
   F(c.marl_flags, (PGD_MA_ENABLED | PGD_MA_CRASH_DONE | PGD_MA_OUT_ROAD_DONE | PGD_MA_ALLOW_RESPAWN)) F(c.use_lateral, 0)           \
   F(c.out_of_route_done, 0) F(c.success_reward, 10.0f) F(c.out_of_road_penalty, 10.0f) F(c.crash_vehicle_penalty, 10.0f)            \
   F(c.crash_object_penalty, 10.0f) F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f) F(c.side_lasers, 0) F(c.lane_line_lasers, 0)   \
-  F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f) F(c.delay_done, 25) F(c.idm_agent, 0)
+  F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f) F(c.delay_done, 25) F(c.idm_agent, 0)   \
+  F(c.idm_steer_lag, 0.0f)
 // BASELINE config 2: the ego alone, no lidar (dynamics + reward + the 18-float state vector), otherwise the single-agent defaults --
 // four envs per wave, 16 sub-lanes per ego, the row written by k_step itself.
 #define PGD_FIXE_FIELDS(F, d, c)                                                                                                    \
@@ -224,7 +226,7 @@ constexpr FixSpec fix_spec(int fix) {
   F(c.discrete_action, 0) F(c.increment_steering, 0) F(c.safe_rl_env, 0) F(c.enable_reverse, 0) F(c.marl_flags, 0)                  \
   F(c.use_lateral, 0) F(c.out_of_route_done, 0) F(c.success_reward, 10.0f) F(c.out_of_road_penalty, 5.0f)                           \
   F(c.crash_vehicle_penalty, 5.0f) F(c.crash_object_penalty, 5.0f) F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f)               \
-  F(c.side_lasers, 0) F(c.lane_line_lasers, 0) F(c.random_agent_model, 0) F(c.idm_agent, 0)
+  F(c.side_lasers, 0) F(c.lane_line_lasers, 0) F(c.random_agent_model, 0) F(c.idm_agent, 0) F(c.idm_steer_lag, 0.0f)
 enum { FIXK_DEFAULT = 0, FIXK_MARL = 1, FIXK_EGO_ONLY = 2, FIXK_GEOMETRY = 3, FIXK_NO_LIDAR = 4, FIXK_SAFE = 5 };
 constexpr int fix_of_kind(int kind) { return kind == FIXK_GEOMETRY ? 2 : kind == FIXK_NO_LIDAR ? 3 : kind == FIXK_SAFE ? 4 : 1; }
 template <bool ONE_ENV, bool MARL, bool STD, int FIX = 1>
@@ -507,7 +509,11 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
     r.a0s = r.a1s; r.a0t = r.a1t;
     r.a1s = st; r.a1t = tb;
     // _set_action / _set_incremental_action (base_vehicle.py:343-358)
-    r.steer = (s < A && d.cfg.increment_steering) ? clipf(r.steer + st * 0.05f, -1.0f, 1.0f) : st;
+    r.steer = (s < A && d.cfg.increment_steering) ? clipf(r.steer + st * 0.05f, -1.0f, 1.0f)
+              // pgd_config::idm_steer_lag (an opt-in, 0 in every kernel specialised for a reference configuration): IDM-driven vehicles only
+              : ((d.cfg.idm_steer_lag > 0.0f && (s >= A || idm_ego))
+                     ? r.steer + (clipf(st, -1.0f, 1.0f) - r.steer) * ((d.cfg.dt * (float)d.cfg.decision_repeat) / (d.cfg.idm_steer_lag + d.cfg.dt * (float)d.cfg.decision_repeat))
+                     : st);
     // (4) physics
     dynamics(d, SPV, r, s < A && d.cfg.enable_reverse != 0, tb, leader ? &SUBP : nullptr, slot, near_env && sub_ok && n_mid_enabled);
     PHASE_MARK(3);  // dynamics

@@ -68,6 +68,9 @@ DEFAULT_CONFIG = dict(
     # obs/top_down_obs_multi_channel.py); pgdrive_amd/csrc/pgd_topdown.h states what exactly is drawn
     use_topdown=False, frame_stack=3, post_stack=5, frame_skip=5, resolution_size=84, distance=30, rgb_clip=True,
     topdown_single_frame=False,  # TopDownObservation instead of TopDownMultiChannel: one RGB frame (TopDownSingleFramePGDriveEnv)
+    idm_steer_lag=0.0,  # NOT a reference key (an opt-in of this build, default off): time constant [s] of a first-order lag on the steering
+                        # IDM-driven vehicles apply -- stands in for the yaw dynamics the kinematic bicycle lacks (include/pgdrive_hip.h
+                        # pgd_config::idm_steer_lag; 0.2 settles the traffic on its lane axis).  Such an engine runs the general step kernel
     IDM_agent=False,  # the ego is driven by IDMPolicy along its route, step()'s actions are ignored (base_env.py:30, agent_manager.py:79)
     map_bank=None,  # path of a pre-generated description bank; None -> generate with our BIG (pgdrive_amd/mapgen.py)
 )
@@ -233,7 +236,8 @@ class PGDriveVecEnv:
             discrete_action=c["discrete_action"], discrete_steering_dim=c["discrete_steering_dim"],
             discrete_throttle_dim=c["discrete_throttle_dim"], increment_steering=vc["increment_steering"],
             safe_rl_env=c["safe_rl_env"], random_agent_model=c["random_agent_model"], enable_reverse=vc["enable_reverse"],
-            lidar_gaussian_noise=lid["gaussian_noise"], lidar_dropout_prob=lid["dropout_prob"], idm_agent=bool(c["IDM_agent"])
+            lidar_gaussian_noise=lid["gaussian_noise"], lidar_dropout_prob=lid["dropout_prob"], idm_agent=bool(c["IDM_agent"]),
+            idm_steer_lag=float(c["idm_steer_lag"])
         )
         from .engine import Engine
         self.engine = Engine(self.cfg, self.map_bank, self.scen_bank, device=c["device"])

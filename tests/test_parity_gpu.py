@@ -38,7 +38,7 @@ def _engines(descs, n_envs, n_maps=8, **kw):
                            resample_scenario=kw.get("resample_scenario", 0), decision_repeat=kw.get("decision_repeat", 5),
                            lidar_dist=kw.get("lidar_dist", 50.0),
                            **{k: kw[k] for k in ("success_reward", "use_lateral", "speed_reward", "driving_reward", "out_of_road_penalty",
-                                                 "idm_agent") if k in kw})
+                                                 "idm_agent", "idm_steer_lag") if k in kw})
     eng = Engine(cfg, mb, sb)
     ora = orc.Oracle(cfg, mb, sb)
     ora.map_bank, ora.scen_bank = mb, sb
@@ -102,6 +102,46 @@ def _compare_step(torch, eng, ora, act, stats):
 def test_teacher_forced_parity(descs, num_traffic, num_lasers):
     """Each step starts from the same fp32-rounded state on both sides; outputs and the next state must agree."""
     _teacher_forced(descs, num_traffic, num_lasers)
+
+
+@pytest.mark.parametrize("idm_agent", [False, True])
+def test_idm_steer_lag_parity(descs, idm_agent):
+    """pgd_config::idm_steer_lag (an opt-in of this build, not a reference key: a first-order lag on the steering IDM-driven vehicles
+    apply; 0 = the reference's behaviour, which every other test runs): engine and oracle implement the same rule -- teacher-forced
+    parity with the lag on, respawn traffic (every IDM vehicle drives), with and without the ego under the IDM policy; the applied
+    steering (SF_STEER) stays inside [-1, 1] and differs from the raw command of the action deque (SF_ACT1S)."""
+    n_envs = 96
+    torch, eng, ora, cfg = _engines(descs, n_envs, n_maps=16, seed=4, traffic_mode="respawn", idm_steer_lag=0.2, idm_agent=int(idm_agent))
+    assert "specialised" not in (eng.describe_step() or "")
+    ids = np.arange(n_envs) % 16
+    assert np.abs(eng.reset(ids).cpu().numpy() - ora.reset(ids)).max() < OBS_TOL
+    rng = np.random.default_rng(31)
+    stats = dict(steps=0, flag_mismatch=0, obs=0.0, rew=0.0)
+    worst = {}
+    lagged = 0
+    for t in range(250):
+        act = util.driving_actions(rng, n_envs) * (0.0 if not idm_agent else 1.0)  # (a parked ego keeps the respawn jam from restarting the env every step)
+        _compare_step(torch, eng, ora, act, stats)
+        f, i, ei = ora.get_state()
+        gf, gi, gei = eng.get_state()
+        agree = (gi == i).all(axis=0) & (gei == ei).all(axis=0)[:, None]
+        tie = util.idm_tie(gf, f)
+        util.compare_state(gf, f, agree & ~tie, worst)
+        assert (~agree).sum() == 0
+        drv = gi[_abi.SI["STATUS"]] == _abi.ST_ACTIVE
+        drv[:, 0] &= bool(idm_agent)
+        st, cmd = gf[_abi.SF["STEER"]][drv], gf[_abi.SF["ACT1S"]][drv]
+        assert (np.abs(st) <= 1.0 + 1e-6).all()
+        lagged += int((np.abs(st - np.clip(cmd, -1, 1)) > 1e-3).sum())
+        f32 = util.round_state_f32(f)
+        ora.set_state(f32, i, ei)
+        eng.set_state(f32, i, ei)
+    print("steer lag parity:", stats, {k: round(v, 3) for k, v in worst.items()})
+    assert "specialised" not in eng.describe_step()
+    assert stats["obs"] < OBS_TOL and stats["rew"] < REW_TOL and stats["flag_mismatch"] == 0
+    assert not util.state_failures(worst), util.state_failures(worst)
+    assert lagged > 1000
+    eng.close()
 
 
 def test_throughput_mode_parity(descs, monkeypatch):
