@@ -350,6 +350,18 @@ int pgd_set_stream(pgd_handle h, void* hip_stream);
 int pgd_sync(pgd_handle h);
 int pgd_destroy(pgd_handle h);
 const char* pgd_version(void);
+/* Run-time specialisation of the step kernel (no reference counterpart).  The library ships instantiations of k_step with the
+ * configurations of the reference's env classes compiled in; any OTHER configuration runs the general kernel, 12 - 17 % behind.
+ * pgdrive_amd/jit.py builds, with the same hipcc and flags as the library, a code object that holds k_step with THIS handle's
+ * configuration and geometry as literals (every pgd_config field; pgd_step_geometry reports the derived values:
+ * N, A, T, V, D, NV, epw, sub, pack_obs, sstride, use_imask, flags: bit 0 objects among the bodies, bit 1 default row layout, bit 2
+ * the engine can take such a kernel -- single-agent, one env per wave, scenarios uploaded), and pgd_set_step_module loads it:
+ * pgd_step then launches it wherever it would have launched a general kernel, while the engine's geometry and object flag are what
+ * the module was built for (pgd_set_groups, a scenario upload that adds objects: back to the library's kernels).  Null path: unload.
+ * Results are those of the general kernel to rounding (constant folding re-orders a few fp32 operations), flags and integer state
+ * bit-identical: tests/test_parity_gpu.py::test_run_time_kernel_matches_the_general_kernel. */
+int pgd_step_geometry(pgd_handle h, int32_t* out12);
+int pgd_set_step_module(pgd_handle h, const char* code_object_path, int built_with_objects, int built_with_std_rows);
 /* The policy network of a closed loop in one launch: actions[r][0..1] = MLP(obs row r) for every (env, agent) row of the engine
  * (group < 0: all rows, on the engine's stream; group >= 0: the rows of that env group on the group's stream, the twin of
  * pgd_step_group).  Replaces pgdrive/examples/ppo_expert/numpy_expert.py:25-44 (`expert(obs)`: x = tanh(obs @ fc_1 + b);

@@ -235,6 +235,12 @@ DEV void write_fixed_config(PgdDev& d) {
 #define PGD_F_SET(f, v) f = v;
   if (MARL) { PGD_FIXM_FIELDS(PGD_F_SET, d, c) }
   else if (!ONE_ENV && !STD) { PGD_FIXE_FIELDS(PGD_F_SET, d, c) }
+#ifdef PGD_JIT
+  // FIX 9: a code object built at run time for ONE handle (pgdrive_amd/jit.py, pgd_set_step_module): every immutable field of its
+  // configuration and geometry is a literal of the generated header (PGD_JIT_FIELDS) -- what the AOT instantiations do for the
+  // configurations of the reference's env classes, for any configuration (the JIT alternative)
+  else if (FIX == 9) { PGD_JIT_FIELDS(PGD_F_SET, d, c) }
+#endif
   else {
     constexpr FixSpec SP = fix_spec(FIX);
     PGD_FIX_FIELDS(PGD_F_SET, d, c, ONE_ENV, SP)
@@ -1116,6 +1122,12 @@ __global__ __launch_bounds__(WAVE, PGD_WAVES_PER_SIMD) void k_step(PgdDev d, con
 
 #undef SPV
 
+#ifdef PGD_JIT
+// The run-time build (hipcc --genco -DPGD_JIT -include <generated header>): this translation unit up to here plus ONE instantiation
+// of the step kernel; the other kernels and the host side exist in the library only.
+template __global__ void k_step<true, false, PGD_JIT_OBJ, PGD_JIT_STD, 9, false>(PgdDev, const float*, float*, uint8_t*, uint32_t*, float*, PgdCold);
+#else
+
 // heading vectors of the spawn poses, once per upload (the restart of a vehicle then evaluates no sincosf)
 __global__ void k_spawn_hv(const pgd_spawn* __restrict__ sp, float2* __restrict__ hv, size_t n) {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1428,6 +1440,13 @@ struct pgd_engine {
   bool step_timing;  // record ev0 / ev1 around every step (pgd_last_step_ms)
   bool row_observe;  // PGD_ROW_OBSERVE was set when the engine was created (debug / A-B: k_observe per row instead of k_observe_env)
   const char* last_step_kernel;  // what the last pgd_step* call launched (pgd_describe_step)
+  // a step kernel built at run time for this handle's configuration (pgd_set_step_module): launched instead of the general kernel
+  // while the engine's geometry and object flag are what it was built for
+  hipModule_t jit_mod;
+  hipFunction_t jit_fn;
+  bool jit_obj;
+  int jit_geom[4];   // sub, epw, pack_obs, use_imask at the time of the build
+  char jit_name[96];
   bool no_fix;       // PGD_NO_FIX: never pick the kernel specialised for the default configuration (A/B, debugging)
   bool no_fuse;      // PGD_NO_FUSE was set when the engine was created (debug: always run the stand-alone k_observe)
   bool prof_fused;
@@ -2012,11 +2031,23 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   // many agent slots: the rows come from k_observe_env after the step; the state blocks of the rows that are due are k_step's
   const bool state_in_step = d_obs && !fuse && marl && state_in_step_ok(h);
   dv.state_rows = state_in_step ? d_obs : nullptr;
-  h->last_step_kernel = kname;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), 0, stream, dv, d_actions, d_reward, d_done,
-                     d_flags, fuse ? d_obs : (float*)nullptr,
-                     PgdCold{dv.scen_map, dv.bev_fill, dv.spawn_hv, dv.respawn_img, dv.n_scen, dv.cfg.seed, dv.cfg.env_base,
-                             h->lk.obs, h->lk.k_lat, h->lk.k_head, h->lk.v_target, h->lk.noise, h->lk.tick});
+  PgdCold cold_arg{dv.scen_map, dv.bev_fill, dv.spawn_hv, dv.respawn_img, dv.n_scen, dv.cfg.seed, dv.cfg.env_base,
+                   h->lk.obs, h->lk.k_lat, h->lk.k_head, h->lk.v_target, h->lk.noise, h->lk.tick};
+  float* obs_arg = fuse ? d_obs : (float*)nullptr;
+  // a kernel built for this handle at run time takes the place of a GENERAL kernel only (the AOT instantiations are what it would be),
+  // and only while the engine is what it was built for
+  const bool general = strstr(kname, "specialised") == nullptr;
+  const bool use_jit = h->jit_fn && general && !marl && h->d.epw == 1 && !h->no_fix && !h->lk.obs && h->jit_obj == h->has_objects &&
+                       h->jit_geom[0] == h->d.sub && h->jit_geom[1] == h->d.epw && h->jit_geom[2] == h->d.pack_obs &&
+                       h->jit_geom[3] == h->d.use_imask;
+  if (use_jit) {
+    h->last_step_kernel = h->jit_name;
+    void* kargs[] = {&dv, &d_actions, &d_reward, &d_done, &d_flags, &obs_arg, &cold_arg};
+    HIPCHK(hipModuleLaunchKernel(h->jit_fn, (unsigned)blocks, 1, 1, WAVE, 1, 1, 0, stream, kargs, nullptr));
+  } else {
+    h->last_step_kernel = kname;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), 0, stream, dv, d_actions, d_reward, d_done, d_flags, obs_arg, cold_arg);
+  }
   HIPCHK(hipGetLastError());
   if (prof || g_close) HIPCHK(hipEventRecord(pe[1], h->stream));
   if (g_close) h->prof_n += 1;
@@ -2138,6 +2169,47 @@ int pgd_mlp_policy(pgd_handle h, int group, const float* d_obs, int obs_stride, 
   hipLaunchKernelGGL(kern, dim3((rows + MLP_ROWS - 1) / MLP_ROWS), dim3(WAVE * MLP_WAVES), lds, stream, d_obs, row0, rows, obs_stride, in_dim,
                      d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, out_cols, d_actions);
   HIPCHK(hipGetLastError());
+  return PGD_OK;
+}
+
+/* ---- run-time specialisation (pgdrive_amd/jit.py builds the code object with hipcc; see include/pgdrive_hip.h) -------------- */
+int pgd_step_geometry(pgd_handle h, int32_t* out12) {
+  if (!h || !out12) return PGD_ERR_ARG;
+  const pgd_config& c = h->d.cfg;
+  const bool std_obs = c.side_lasers == 0 && c.lane_line_lasers == 0 && !c.random_agent_model && c.lidar_gaussian_noise <= 0.0f &&
+                       c.lidar_dropout_prob <= 0.0f;
+  const bool marl = (c.marl_flags & PGD_MA_ENABLED) != 0;
+  const int v[12] = {h->d.N, h->d.A, h->d.T, h->d.V, h->d.D, h->d.NV, h->d.epw, h->d.sub, h->d.pack_obs, h->d.sstride, h->d.use_imask,
+                     // bit 0: objects among the bodies; bit 1: default row layout; bit 2: the engine can take a run-time kernel at all
+                     (h->has_objects ? 1 : 0) | (std_obs ? 2 : 0) | ((!marl && h->d.epw == 1 && !h->d.pack_obs && h->have_scen) ? 4 : 0)};
+  for (int k = 0; k < 12; ++k) out12[k] = v[k];
+  return PGD_OK;
+}
+
+int pgd_set_step_module(pgd_handle h, const char* code_object_path, int built_with_objects, int built_with_std_rows) {
+  if (!h) return PGD_ERR_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  if (h->jit_mod) {  // (a module in use by launches in flight must outlive them)
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->jit_fn = nullptr;
+    (void)hipModuleUnload(h->jit_mod);
+    h->jit_mod = nullptr;
+  }
+  if (!code_object_path) return PGD_OK;  // (null: back to the library's own kernels)
+  const bool marl = (h->d.cfg.marl_flags & PGD_MA_ENABLED) != 0;
+  if (marl || h->d.epw != 1 || h->d.pack_obs) return PGD_ERR_STATE;
+  hipModule_t mod = nullptr;
+  if (hipModuleLoad(&mod, code_object_path) != hipSuccess) { (void)hipGetLastError(); return PGD_ERR_HIP; }
+  char name[160];
+  snprintf(name, sizeof(name), "_Z6k_stepILb1ELb0ELb%dELb%dELi9ELb0EEv6PgdDevPKfPfPhPjS3_7PgdCold", built_with_objects ? 1 : 0,
+           built_with_std_rows ? 1 : 0);
+  hipFunction_t fn = nullptr;
+  if (hipModuleGetFunction(&fn, mod, name) != hipSuccess) { (void)hipGetLastError(); (void)hipModuleUnload(mod); return PGD_ERR_HIP; }
+  h->jit_mod = mod;
+  h->jit_obj = built_with_objects != 0;
+  h->jit_geom[0] = h->d.sub; h->jit_geom[1] = h->d.epw; h->jit_geom[2] = h->d.pack_obs; h->jit_geom[3] = h->d.use_imask;
+  snprintf(h->jit_name, sizeof(h->jit_name), "k_step: one env per wave, specialised for this engine's configuration at run time");
+  h->jit_fn = fn;  // (published last: a step on another thread sees either no module or a complete one)
   return PGD_OK;
 }
 
@@ -2406,6 +2478,7 @@ int pgd_sync(pgd_handle h) {
 int pgd_destroy(pgd_handle h) {
   if (!h) return PGD_ERR_ARG;
   (void)hipStreamSynchronize(h->stream);
+  if (h->jit_mod) { (void)hipModuleUnload(h->jit_mod); h->jit_mod = nullptr; h->jit_fn = nullptr; }
   void* bufs[] = {h->lk_act, h->rowz, h->d.rec, h->d.ei, h->d.imask, h->d.env_map, h->d_ids, h->maps, h->lanes, h->roads, h->boxes, h->cell_start,
                   h->cell_items, h->cell_boxes, h->cell_ext, h->lane_nav, h->scen_map, h->scen, h->spawns, h->spawn_hv, h->beam, h->reset_img, h->respawn_img};
   for (void* b : bufs)
@@ -2436,3 +2509,4 @@ int pgd_destroy(pgd_handle h) {
 
 #include "pgd_topdown.h"
 #include "pgd_gather.h"
+#endif  // !PGD_JIT

@@ -28,6 +28,8 @@ _SIGS = {
     "pgd_observe": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pgd_describe_step": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "pgd_forget_rows": (C.c_int, [C.c_void_p]),
+    "pgd_step_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "pgd_set_step_module": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "pgd_mlp_policy": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "pgd_step_lane_keep": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32] + [C.c_void_p] * 4),
     "pgd_lane_keep_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32]),
@@ -232,6 +234,13 @@ class Engine:
         _chk(self.L.pgd_step_n(self.h, C.c_void_p(action_ring.data_ptr()), int(action_ring.shape[0]), int(first), int(n_steps), p_obs,
                                C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(flags.data_ptr())), "pgd_step_n")
         return (self.obs if want_obs else None), rew, done, flags
+
+    def specialise(self, wait=True, verbose=False):
+        """Build (hipcc, cached) and load a step kernel with THIS engine's configuration compiled in (pgdrive_amd/jit.py):
+        configurations the library has no instantiation for then step as fast as the reference's defaults.  wait=False: in a
+        background thread, the general kernel steps meanwhile."""
+        from . import jit
+        return jit.specialise(self, wait=wait, verbose=verbose)
 
     def describe_step(self):
         """Which step kernel the last step call launched (pgd_describe_step)."""

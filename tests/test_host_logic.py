@@ -305,3 +305,23 @@ def test_without_gym_the_stand_ins_keep_the_surface():
     assert penv.PGDriveEnv.__mro__[1] is object and spaces.register_gym_ids() == []
     b = spaces.Box(-1.0, 1.0, (2, ), np.float32)
     assert b.contains(np.zeros(2, np.float32)) and not b.contains(np.full(2, 2.0, np.float32))
+
+
+def test_run_time_kernel_builds_without_a_gpu(tmp_path, monkeypatch):
+    """pgdrive_amd/jit.py: the code object of a step kernel with one configuration compiled in is built by hipcc (a cross-compile: no
+    GPU), holds the kernel under the name pgd_set_step_module looks up, and is found in the cache the second time."""
+    import time
+    from pgdrive_amd import jit
+    monkeypatch.setenv("PGD_JIT_DIR", str(tmp_path))
+    cfg = _abi.make_config(512, num_traffic=12, num_lasers=72, num_others=2, discrete_action=True)
+    geom = dict(N=512, A=1, T=12, V=13, D=_abi.obs_dim(cfg), NV=512 * 13, epw=1, sub=4, pack_obs=0, sstride=13, use_imask=0)
+    text = jit.header_text(cfg, geom, False, True)
+    assert "F(d.V, 13)" in text and "F(c.num_lasers, 72)" in text and "F(c.discrete_action, 1)" in text and "PGD_JIT_STD true" in text
+    assert "F(c.lidar_dist, 0x1.9000000000000p+5f)" in text  # 50.0 as an exact hexadecimal float literal
+    path = jit.build_module(cfg, geom, False, True)
+    blob = open(path, "rb").read()
+    assert b"_Z6k_stepILb1ELb0ELb0ELb1ELi9ELb0EEv6PgdDevPKfPfPhPjS3_7PgdCold" in blob
+    t0 = time.time()
+    assert jit.build_module(cfg, geom, False, True) == path and time.time() - t0 < 0.5  # (cached)
+    cfg2 = _abi.make_config(512, num_traffic=12, num_lasers=96, num_others=2, discrete_action=True)
+    assert jit.header_text(cfg2, dict(geom, D=_abi.obs_dim(cfg2)), False, True) != text

@@ -292,6 +292,87 @@ def test_env_class_instantiations_match_the_general_kernel(descs, monkeypatch, v
         e.close()
 
 
+@pytest.mark.parametrize("variant", ["lasers72_traffic12", "discrete_fans_noise", "objects"])
+def test_run_time_kernel_matches_the_general_kernel(descs, monkeypatch, tmp_path, variant):
+    """pgdrive_amd/jit.py + pgd_set_step_module (round 6): a step kernel with ONE engine's configuration compiled in, built with hipcc at
+    run time, for configurations the library has no instantiation for -- another beam / traffic / neighbour count; discrete actions with
+    side and lane-line detector fans and lidar noise (the general row layout); traffic objects among the bodies.  Same protocol as the
+    AOT instantiations' tests: against the general kernel from the same state with the same actions, flags / done / integer state
+    bit-identical, floats to rounding, through auto-resets with re-drawn scenarios; pgd_describe_step names it; unloading the module
+    (null path) puts the general kernel back."""
+    import ctypes as C
+    monkeypatch.setenv("PGD_JIT_DIR", str(tmp_path))
+    monkeypatch.delenv("PGD_NO_FIX", raising=False)
+    n_envs = 65
+    kw = dict(seed=3, resample_scenario=1)
+    if variant == "lasers72_traffic12":
+        kw.update(num_traffic=12, num_lasers=72, num_others=2, lidar_dist=40.0, success_reward=20.0)
+    elif variant == "discrete_fans_noise":
+        kw.update(discrete_action=True, side_lasers=4, lane_line_lasers=2, lidar_gaussian_noise=0.02, lidar_dropout_prob=0.05, horizon=150)
+    else:
+        kw.update(num_traffic=30, accident_prob=0.8, density=0.05)
+    torch, jit_eng, _, _ = _engines(descs, n_envs, n_maps=16, **kw)
+    _, gen, _, _ = _engines(descs, n_envs, n_maps=16, **kw)
+    assert jit_eng.specialise(wait=True) is True
+    assert any(f.endswith(".hsaco") for f in os.listdir(str(tmp_path)))
+    ids = np.arange(n_envs) % 16
+    jit_eng.reset(ids); gen.reset(ids)
+    rng = np.random.default_rng(23)
+    n_done = 0
+    for t in range(300):
+        act = util.driving_actions(rng, n_envs)
+        if variant == "discrete_fans_noise":
+            act = rng.integers(0, 5, size=(n_envs, 1, 2)).astype(np.float32)
+            act[:, 0, 1] = np.maximum(act[:, 0, 1], 2.0)
+        elif t % 4 == 0:
+            act[::3, 0, :] = 1.0
+        f, i, ei = gen.get_state()
+        jit_eng.set_state(f, i, ei)
+        a = torch.from_numpy(act).to(gen.device)
+        o1, r1, d1, f1 = [x.clone() for x in gen.step(a)]
+        o2, r2, d2, f2 = [x.clone() for x in jit_eng.step(a)]
+        gen.sync(); jit_eng.sync()
+        assert torch.equal(d1, d2) and torch.equal(f1, f2), "flags differ at step %d" % t
+        assert float((o1 - o2).abs().max()) < 2e-6 and float((r1 - r2).abs().max()) < 2e-5
+        g1, i1, e1 = gen.get_state()
+        g2, i2, e2 = jit_eng.get_state()
+        assert (i1 == i2).all() and (e1 == e2).all(), "integer state differs at step %d" % t
+        assert np.abs(g1 - g2).max() < 1e-4
+        n_done += int(d1.sum())
+    assert n_done > 10
+    assert "at run time" in jit_eng.describe_step() and "specialised" not in gen.describe_step()
+    assert jit_eng.L.pgd_set_step_module(jit_eng.h, None, 0, 0) == 0
+    jit_eng.step(a); jit_eng.sync()
+    assert "specialised" not in jit_eng.describe_step()
+    for e in (jit_eng, gen):
+        e.close()
+
+
+def test_run_time_kernel_is_refused_where_it_does_not_apply(descs, monkeypatch, tmp_path):
+    """Engines that cannot take a run-time kernel say so (specialise() returns False, nothing is built): multi-agent engines and
+    throughput mode; an engine whose configuration the library already has an instantiation for keeps that instantiation even with a
+    module loaded (the module only ever replaces a GENERAL kernel)."""
+    monkeypatch.setenv("PGD_JIT_DIR", str(tmp_path))
+    import torch
+    from pgdrive_amd.engine import Engine
+    d, mb, sb = util.make_marl_banks(num_agents=8, capacity=12, kind="roundabout")
+    marl = Engine(util.marl_config(16, sb, horizon=120), mb, sb)
+    assert marl.specialise() is False
+    marl.close()
+    monkeypatch.setenv("PGD_PACK", "1")
+    _, pack, _, _ = _engines(descs, 66, seed=1)
+    assert pack.specialise() is False
+    pack.close()
+    monkeypatch.setenv("PGD_PACK", "0")
+    _, dflt, _, _ = _engines(descs, 64, seed=1)
+    assert dflt.specialise() is True  # (built and loaded ...)
+    dflt.reset(np.arange(64) % 8)
+    dflt.step(torch.zeros((64, 1, 2), device="cuda")); dflt.sync()
+    assert "specialised for the default single-agent configuration" in dflt.describe_step()  # (... and not used: the AOT instantiation runs)
+    dflt.close()
+    assert len([f for f in os.listdir(str(tmp_path)) if f.endswith(".hsaco")]) == 1
+
+
 def test_default_multi_agent_kernel_matches_the_general_kernel(monkeypatch):
     """Multi-agent engines with the scalar fields of MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG get their own instantiation of k_step (those
     fields are compile-time constants in it; agent count, spawn places and horizon stay run-time values).  Against the general
