@@ -1444,7 +1444,7 @@ struct pgd_engine {
   // while the engine's geometry and object flag are what it was built for
   hipModule_t jit_mod;
   hipFunction_t jit_fn;
-  bool jit_obj;
+  bool jit_obj, jit_force;
   int jit_geom[4];   // sub, epw, pack_obs, use_imask at the time of the build
   char jit_name[96];
   bool no_fix;       // PGD_NO_FIX: never pick the kernel specialised for the default configuration (A/B, debugging)
@@ -1553,6 +1553,7 @@ int pgd_create(const pgd_config* cfg, int device, void* hip_stream, pgd_handle* 
   h->device = device;
   h->no_fuse = getenv("PGD_NO_FUSE") != nullptr;
   h->no_fix = getenv("PGD_NO_FIX") != nullptr;
+  h->jit_force = getenv("PGD_JIT_FORCE") != nullptr;
   h->row_observe = getenv("PGD_ROW_OBSERVE") != nullptr;
   h->no_state_in_step = getenv("PGD_NO_STATE_IN_STEP") != nullptr;
   h->d.cfg = *cfg;
@@ -2036,7 +2037,7 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
   float* obs_arg = fuse ? d_obs : (float*)nullptr;
   // a kernel built for this handle at run time takes the place of a GENERAL kernel only (the AOT instantiations are what it would be),
   // and only while the engine is what it was built for
-  const bool general = strstr(kname, "specialised") == nullptr;
+  const bool general = strstr(kname, "specialised") == nullptr || h->jit_force;  // (PGD_JIT_FORCE=1, A/B only: also in place of an AOT instantiation)
   const bool use_jit = h->jit_fn && general && !marl && h->d.epw == 1 && !h->no_fix && !h->lk.obs && h->jit_obj == h->has_objects &&
                        h->jit_geom[0] == h->d.sub && h->jit_geom[1] == h->d.epw && h->jit_geom[2] == h->d.pack_obs &&
                        h->jit_geom[3] == h->d.use_imask;

@@ -301,7 +301,8 @@ class PGDriveVecEnv:
             if self.num_envs >= 1024 and "specialised" not in kname:
                 import warnings
                 warnings.warn("pgdrive_amd: this configuration runs the general step kernel (%s); the reference's default "
-                              "configurations run specialised instantiations that are about 12 %% faster" % kname)
+                              "configurations run specialised instantiations that are 12 - 17 %% faster -- jit_step_kernel=True (or "
+                              "engine.specialise()) builds one for this configuration at run time" % kname)
         if self.topdown:
             return self.engine.observe_topdown(), rew.view(-1), done.view(-1), flags.view(-1)
         return obs.view(self.num_envs, self.obs_dim), rew.view(-1), done.view(-1), flags.view(-1)
