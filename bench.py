@@ -414,6 +414,9 @@ def parse_args(argv=None):
     ap.add_argument("--topdown", action="store_true",
                     help="c3 with the top-down image observation (TopDownPGDriveEnv: 84 x 84 x 5, lidar off): pgd_step + "
                          "pgd_observe_topdown per step; reported next to the metric, never as the metric")
+    ap.add_argument("--jit", action="store_true",
+                    help="build and load a step kernel with this run's configuration compiled in (pgdrive_amd/jit.py, Engine.specialise): for "
+                         "configurations the library has no instantiation for; reported as rows, never as the metric")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="plumbing tests: allow more ranks than GPUs (ranks share devices; needs --backend gloo)")
@@ -453,6 +456,10 @@ ROWS = [
     # the top-down image observation (TopDownPGDriveEnv: 84 x 84 x 5 floats per env and step instead of the 274-float row): pgd_step
     # without the lidar + pgd_observe_topdown; a write-bound kernel of its own
     ("c3_topdown", dict(topdown=True, lasers=0, warmup=600, steps=512)),
+    # a configuration the library has no instantiation for (72 beams, 12 traffic slots): the general kernel, and the same engine with a
+    # step kernel built for it at run time (pgdrive_amd/jit.py; round 6)
+    ("c3_72x12_general", dict(lasers=72, traffic=12)),
+    ("c3_72x12_run_time_kernel", dict(lasers=72, traffic=12, jit=True)),
 ]
 
 XGMI_LINK_GBPS = 153.0  # per direction and link (MI355X_MICROARCH.md); 7 links per GPU, point to point
@@ -495,6 +502,11 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
         n_scen = len(descs)
     eng = Engine(cfg, mb, sb, device=local_rank)
     D = eng.D
+    jit_s = None
+    if getattr(args, "jit", False):  # (2 s of hipcc the first time, cached by configuration)
+        t_j = time.perf_counter()
+        jit_ok = eng.specialise(wait=True)
+        jit_s = (time.perf_counter() - t_j) if jit_ok else None
     eng.reset((np.arange(N) + rank * N) % n_scen)
     extra = []  # --engines E: E - 1 more engines with their own streams, seeds and scenario offsets
     for j in range(1, max(1, args.engines)):
@@ -698,6 +710,7 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
             **({"active_vehicles_mean": 1.0 + work["driving_traffic_mean"]} if work and "driving_traffic_mean" in work else {}),
             **(work or {}),
             "step_kernel": state.get("step_kernel"),
+            **({"run_time_kernel_build_s": jit_s} if getattr(args, "jit", False) else {}),
             "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
             "engines_per_gpu": max(1, args.engines), "env_groups": args.groups,
             **({"open_loop": "pgd_step_n: %d steps of the action ring per call, one observation per call -- NOT the metric's closed "
@@ -1052,7 +1065,7 @@ def row_summary(name, line):
     c = line["config"]
     keep = ("driving_traffic_mean", "envs_with_traffic_frac", "ego_speed_kmh_mean", "episode_step_mean", "active_agents_mean",
             "present_agents_mean", "step_kernel", "obs_dim", "envs_per_gpu", "note", "observation", "topdown_us",
-            "topdown_write_frac_of_hbm_peak")
+            "topdown_write_frac_of_hbm_peak", "run_time_kernel_build_s")
     iss = r.get("issue") or None
     return {
         "row": name, "workload": c["workload"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
@@ -1094,7 +1107,7 @@ def run_rank(args, rank, world, local_rank):
     # headline -- other actions, env counts, groups ... -- is a single-workload run)
     default_cmd = (args.workload == "c3" and args.actions == "uniform" and args.traffic_mode == "trigger" and args.envs == 4096 and
                    args.traffic == 16 and args.lasers == 240 and args.maps == 100 and args.groups == 1 and args.engines == 1 and
-                   args.step_n == 1 and not args.topdown and not args.exact)
+                   args.step_n == 1 and not args.topdown and not args.exact and not args.jit)
     if world == 1 and rank == 0 and not args.no_rows and (default_cmd or args.rows):
         want = None if not args.rows else set(args.rows.split(","))
         rows = []

@@ -1445,6 +1445,7 @@ struct pgd_engine {
   hipModule_t jit_mod;
   hipFunction_t jit_fn;
   bool jit_obj, jit_force;
+  bool mlp_attr[2];  // pgd_mlp_policy: the kernel's dynamic LDS limit has been raised on this engine's device
   int jit_geom[4];   // sub, epw, pack_obs, use_imask at the time of the build
   char jit_name[96];
   bool no_fix;       // PGD_NO_FIX: never pick the kernel specialised for the default configuration (A/B, debugging)
@@ -2162,10 +2163,9 @@ int pgd_mlp_policy(pgd_handle h, int group, const float* d_obs, int obs_stride, 
     stream = h->gstreams[group];
   }
   auto kern = final_tanh ? k_mlp_policy<true> : k_mlp_policy<false>;
-  static bool attr_set[2] = {false, false};
-  if (lds > 49152 && !attr_set[final_tanh ? 1 : 0]) {
+  if (lds > 49152 && !h->mlp_attr[final_tanh ? 1 : 0]) {  // (per engine = per device: a process may hold engines on several GPUs)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    attr_set[final_tanh ? 1 : 0] = true;
+    h->mlp_attr[final_tanh ? 1 : 0] = true;
   }
   hipLaunchKernelGGL(kern, dim3((rows + MLP_ROWS - 1) / MLP_ROWS), dim3(WAVE * MLP_WAVES), lds, stream, d_obs, row0, rows, obs_stride, in_dim,
                      d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, out_cols, d_actions);

@@ -387,6 +387,9 @@ class Engine:
         _chk(self.L.pgd_set_state(self.h, _np_p(f), _np_p(i), _np_p(ei)), "pgd_set_state")
 
     def close(self):
+        t = getattr(self, "_jit_thread", None)
+        if t is not None and t.is_alive():  # a run-time kernel still being built (specialise(wait=False))
+            t.join(timeout=120)
         if getattr(self, "h", None):
             self.L.pgd_destroy(self.h)
             self.h = None
