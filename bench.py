@@ -913,8 +913,9 @@ def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
     """The closed loop an RL user runs: observation -> policy network -> action -> pgd_step, nothing pre-generated.
     Policy = the 274-256-256-2 tanh MLP of examples/graph_rollout.py (the shape of the reference's PPO expert,
     examples/ppo_expert/numpy_expert.py), random weights (seed 0), C3 workload.  Two implementations of the same network --
-      torch   fp32 torch ops (3 x addmm on hipBLASLt + 3 x tanh: six dependent launches per step; the user's unchanged code)
-      fused   pgd_mlp_policy: the engine's one-launch MLP (f32 matrix cores, activations in LDS: pgdrive_amd/csrc/pgd_policy.h)
+      torch         fp32 torch ops (3 x addmm on hipBLASLt + 3 x tanh: six dependent launches per step; the user's unchanged code)
+      fused         pgd_mlp_policy: the engine's one-launch MLP (f32 matrix cores, exact f32, activations in LDS: pgdrive_amd/csrc/pgd_policy.h)
+      fused_bf16x3  pgd_mlp_policy_prepared: the same launch with split bf16 operands on prepared weights (3 bf16 matrix instructions per product)
     -- and three ways to drive them, same engine configuration:
       eager        one Python iteration per step, 4096 envs
       graph        4 iterations captured in ONE HIP graph (torch.cuda.graphs), replayed: one host call per 4 steps, 4096 envs
@@ -966,8 +967,10 @@ def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
     out = {"row": "c3_policy", "workload": "C3 closed loop: %d envs x (1 ego + 16 IDM traffic slots) x 240 beams, actions = tanh MLP 274-256-256-2 "
                                            "(fp32, random weights) of the last observation, auto-reset" % N,
            "unit": "env-steps/s", "steps_timed": steps, "warmup_run": warm,
-           "policy": {"torch": "3 x addmm (hipBLASLt) + 3 x tanh per step, fp32", "fused": "pgd_mlp_policy: one launch, f32 MFMA (v_mfma_f32_16x16x4_f32)"}}
-    for impl in ("torch", "fused"):
+           "policy": {"torch": "3 x addmm (hipBLASLt) + 3 x tanh per step, fp32", "fused": "pgd_mlp_policy: one launch, f32 MFMA (v_mfma_f32_16x16x4_f32), exact f32",
+                      "fused_bf16x3": "pgd_mlp_policy_prepared: one launch, every operand split hi + lo into two bf16, three v_mfma_f32_16x16x32_bf16 "
+                                      "per product, f32 accumulation: ~3e-5 on an action (the exact kernel: ~1e-6)"}}
+    for impl in ("torch", "fused", "fused_bf16x3"):
         res = {}
         try:  # one engine of 4096 envs: eager, then 4 iterations per HIP graph
             with torch.no_grad():
@@ -975,11 +978,13 @@ def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
                 act = torch.zeros((N, 1, 2), dtype=torch.float32, device=dev)
                 obs2d, act2d = eng.obs.view(N, -1), act.view(N, 2)
 
+                prep = eng.mlp_prepare(weights) if impl == "fused_bf16x3" else None  # (once per policy update; here: once)
+
                 def iteration():
                     if impl == "torch":
                         policy_torch(obs2d, act2d)
                     else:
-                        eng.mlp_policy(weights, act, final_tanh=True)
+                        eng.mlp_policy(weights, act, final_tanh=True, prepared=prep)
                     eng.step(act)
                 s = torch.cuda.Stream(device=dev)
                 s.wait_stream(torch.cuda.current_stream(dev))
@@ -1008,7 +1013,7 @@ def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
             res["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
         # env groups (pgd_set_groups): a single-stream graph per group, replayed on the group's stream -- 2 x 4096 (the verdict's
         # variant), and smaller groups, which leave register file for the policy's waves next to the other group's step
-        for Gn, Ng in (((2, N), (2, N // 2), (4, N // 2)) if impl == "fused" else ((2, N), )):  # (the smaller groups: the engine's policy only)
+        for Gn, Ng in (((2, N), (2, N // 2), (4, N // 2)) if impl == "fused" else ((2, N), )):  # (the smaller groups: the exact engine policy only)
             key = "groups_graph" if (Gn, Ng) == (2, N) else "groups_graph_%dx%d" % (Gn, Ng)
             try:
                 with torch.no_grad():
@@ -1017,12 +1022,14 @@ def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
                     act = torch.zeros((Gn * Ng, 1, 2), dtype=torch.float32, device=dev)
                     views = [(eng.obs[eng.group_slice(k)].view(Ng, -1), act[eng.group_slice(k)].view(Ng, 2)) for k in range(Gn)]
                     gs = eng.group_streams
+                    prep = eng.mlp_prepare(weights) if impl == "fused_bf16x3" else None
+                    eng.sync()
 
                     def group_iteration(k):  # (on the group's stream)
                         if impl == "torch":
                             policy_torch(*views[k])
                         else:
-                            eng.mlp_policy(weights, act, group=k, final_tanh=True)
+                            eng.mlp_policy(weights, act, group=k, final_tanh=True, prepared=prep)
                         eng.step_group(k, act)
                     cur = torch.cuda.current_stream(dev)
                     graphs = []
@@ -1053,7 +1060,7 @@ def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
             except Exception as ex:  # noqa: BLE001
                 res[key] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
         out[impl] = res
-    vals = [(v["value"], "%s/%s" % (i, k)) for i in ("torch", "fused") for k, v in (out.get(i) or {}).items()
+    vals = [(v["value"], "%s/%s" % (i, k)) for i in ("torch", "fused", "fused_bf16x3") for k, v in (out.get(i) or {}).items()
             if isinstance(v, dict) and "value" in v]
     out["value"], out["value_variant"] = max(vals) if vals else (None, None)
     return out

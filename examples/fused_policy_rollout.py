@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--weights", default=None)
     ap.add_argument("--graph", action="store_true", help="capture 4 iterations in one HIP graph and replay it")
+    ap.add_argument("--bf16x3", action="store_true",
+                    help="the split-bf16 kernel on prepared weights (pgd_mlp_prepare / pgd_mlp_policy_prepared): 16 bits of mantissa, "
+                         "a third of the exact kernel's time")
     args = ap.parse_args()
     env = PGDriveVecEnv(dict(num_envs=args.envs, start_seed=1000, environment_num=100, auto_reset=True))
     eng, D = env.engine, env.obs_dim
@@ -38,12 +41,13 @@ def main():
         w = [rng.normal(0, D ** -0.5, (D, 256)), np.zeros(256), rng.normal(0, 1 / 16, (256, 256)), np.zeros(256),
              rng.normal(0, 1 / 16, (256, 2)), np.array([0.0, 0.5])]  # (a bias towards the throttle: the cars drive)
     weights = tuple(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda() for v in w)
+    prepared = eng.mlp_prepare(weights) if args.bf16x3 else None  # (once per policy update)
     act = torch.zeros((args.envs, 1, 2), device="cuda")
     ret = torch.zeros(1, device="cuda")
     env.reset()
 
     def iteration():
-        eng.mlp_policy(weights, act, final_tanh=True)  # reads the engine's observation buffer, writes the action buffer
+        eng.mlp_policy(weights, act, final_tanh=True, prepared=prepared)  # reads the engine's observation buffer, writes the action buffer
         _, rew, _, _ = eng.step(act)
         ret.add_(rew.sum())
 

@@ -350,6 +350,16 @@ int pgd_set_stream(pgd_handle h, void* hip_stream);
 int pgd_sync(pgd_handle h);
 int pgd_destroy(pgd_handle h);
 const char* pgd_version(void);
+/* The same network with SPLIT bf16 operands on the bf16 matrix cores (every f32 value = hi + lo, two bf16; a product = three matrix
+ * instructions; f32 accumulation): 1/5 of the exact form's matrix time, ~3e-5 of error on an action in [-1, 1] instead of ~1e-6.  The
+ * weights are prepared ONCE per policy update into a device buffer of pgd_mlp_prepared_bytes(in_dim) bytes (16-byte aligned):
+ * pgd_mlp_prepare splits them and lays them out in the kernel's fragment order (asynchronous on the engine's stream);
+ * pgd_mlp_policy_prepared then evaluates the network like pgd_mlp_policy (same rows, groups, action layout). */
+size_t pgd_mlp_prepared_bytes(int in_dim);
+int pgd_mlp_prepare(pgd_handle h, int in_dim, int hidden, const float* d_w1, const float* d_b1, const float* d_w2, const float* d_b2,
+                    const float* d_w3, const float* d_b3, int out_cols, void* d_prepared);
+int pgd_mlp_policy_prepared(pgd_handle h, int group, const float* d_obs, int obs_stride, int in_dim, const void* d_prepared, int final_tanh,
+                            float* d_actions);
 /* Run-time specialisation of the step kernel (no reference counterpart).  The library ships instantiations of k_step with the
  * configurations of the reference's env classes compiled in; any OTHER configuration runs the general kernel, 12 - 17 % behind.
  * pgdrive_amd/jit.py builds, with the same hipcc and flags as the library, a code object that holds k_step with THIS handle's

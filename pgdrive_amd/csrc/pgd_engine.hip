@@ -1445,7 +1445,7 @@ struct pgd_engine {
   hipModule_t jit_mod;
   hipFunction_t jit_fn;
   bool jit_obj, jit_force;
-  bool mlp_attr[2];  // pgd_mlp_policy: the kernel's dynamic LDS limit has been raised on this engine's device
+  bool mlp_attr[4];  // pgd_mlp_policy / pgd_mlp_policy_prepared: the kernel's dynamic LDS limit has been raised on this engine's device
   int jit_geom[4];   // sub, epw, pack_obs, use_imask at the time of the build
   char jit_name[96];
   bool no_fix;       // PGD_NO_FIX: never pick the kernel specialised for the default configuration (A/B, debugging)
@@ -2169,6 +2169,47 @@ int pgd_mlp_policy(pgd_handle h, int group, const float* d_obs, int obs_stride, 
   }
   hipLaunchKernelGGL(kern, dim3((rows + MLP_ROWS - 1) / MLP_ROWS), dim3(WAVE * MLP_WAVES), lds, stream, d_obs, row0, rows, obs_stride, in_dim,
                      d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, out_cols, d_actions);
+  HIPCHK(hipGetLastError());
+  return PGD_OK;
+}
+
+/* ---- the policy network with split bf16 operands (pgd_policy.h, second half): weights prepared once per policy update ------------ */
+size_t pgd_mlp_prepared_bytes(int in_dim) { return in_dim >= 4 && in_dim <= 4096 ? mlp_prepared_bytes(in_dim) : 0; }
+
+int pgd_mlp_prepare(pgd_handle h, int in_dim, int hidden, const float* d_w1, const float* d_b1, const float* d_w2, const float* d_b2,
+                    const float* d_w3, const float* d_b3, int out_cols, void* d_prepared) {
+  if (!h || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_w3 || !d_b3 || !d_prepared) return PGD_ERR_ARG;
+  if (hidden != MLP_H || in_dim < 4 || in_dim > 4096 || out_cols < 2 || (reinterpret_cast<uintptr_t>(d_prepared) & 15u) != 0u) return PGD_ERR_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  const int n = (mlp_chunks(in_dim) + mlp_chunks(MLP_H)) * MLP_WAVES * 4 * WAVE;
+  hipLaunchKernelGGL(k_mlp_prepare, dim3((n + 255) / 256), dim3(256), 0, h->stream, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, in_dim, out_cols,
+                     reinterpret_cast<uint4*>(d_prepared));
+  HIPCHK(hipGetLastError());
+  return PGD_OK;
+}
+
+int pgd_mlp_policy_prepared(pgd_handle h, int group, const float* d_obs, int obs_stride, int in_dim, const void* d_prepared, int final_tanh,
+                            float* d_actions) {
+  if (!h || !d_obs || !d_prepared || !d_actions) return PGD_ERR_ARG;
+  if (in_dim < 4 || in_dim > 4096 || obs_stride < in_dim || (reinterpret_cast<uintptr_t>(d_prepared) & 15u) != 0u) return PGD_ERR_ARG;
+  const size_t lds = mlp_bf_lds_bytes(in_dim);
+  if (lds > 65536) return PGD_ERR_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t stream = h->stream;
+  int rows = h->d.N * h->d.A, row0 = 0;
+  if (group >= 0) {
+    if (group >= h->n_groups || !h->gstreams) return PGD_ERR_ARG;
+    rows = (h->d.N / h->n_groups) * h->d.A;
+    row0 = group * rows;
+    stream = h->gstreams[group];
+  }
+  auto kern = final_tanh ? k_mlp_policy_bf<true> : k_mlp_policy_bf<false>;
+  if (lds > 49152 && !h->mlp_attr[2 + (final_tanh ? 1 : 0)]) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    h->mlp_attr[2 + (final_tanh ? 1 : 0)] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((rows + MLP_ROWS - 1) / MLP_ROWS), dim3(WAVE * MLP_WAVES), lds, stream, d_obs, row0, rows, obs_stride, in_dim,
+                     reinterpret_cast<const uint4*>(d_prepared), d_actions);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }

@@ -203,4 +203,203 @@ __global__ __launch_bounds__(WAVE * MLP_WAVES, 4) void k_mlp_policy(const float*
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same network on the bf16 matrix cores with SPLIT operands (pgd_mlp_prepare + pgd_mlp_policy_prepared; `precision 1`).
+// Every f32 value is carried as hi + lo, two bf16 numbers (hi = the value rounded to bf16, lo = the rounded remainder: 16 bits of
+// mantissa together), and a product a * b is formed as a_hi b_hi + a_hi b_lo + a_lo b_hi on `v_mfma_f32_16x16x32_bf16` (f32
+// accumulation; the dropped a_lo b_lo is 2^-16 of the product).  Three matrix instructions of 16 cycles cover K = 32 where the exact
+// f32 form needs eight of 32 cycles: the matrix pipe's share of the launch drops from 7.7 to 1.5 us, and the launch is bound by what
+// streams the weights through the CU's L1 (same bytes as f32: 2 x 2 instead of 4 per value).  Error against float64: ~3e-5 on an
+// action in [-1, 1] (test_mlp_policy_matches_the_numpy_expert holds 1e-4); the exact-f32 kernel above stays the default.
+// Weights are PREPARED once per policy update (k_mlp_prepare): split, and re-laid out so that a lane's B fragment of a tile and a
+// 32-row chunk -- eight values of one column -- is one 16-byte read:  [layer][chunk c][wave w][tile t][plane hi / lo][lane] x 16 B,
+// lane l = (column 64 w + 16 t + (l & 15), rows 32 c + 8 (l >> 4) .. + 7); behind the two layers: b1, b2, the head's 2 x 256
+// weights and b3 as f32.  (Which K index the hardware gives element j of lane group g does not matter: A and B fragments put the
+// SAME k into the same (g, j) slot.)
+typedef __bf16 mlp_bf16x8 __attribute__((ext_vector_type(8)));
+DEV unsigned mlp_bf16_rne(const float x) {  // round to nearest even; finite inputs
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+DEV float mlp_bf16_f(const unsigned b) { return __uint_as_float(b << 16); }
+DEV void mlp_split(const float x, unsigned& hi, unsigned& lo) {
+  hi = mlp_bf16_rne(x);
+  lo = mlp_bf16_rne(x - mlp_bf16_f(hi));
+}
+DEV_HOST int mlp_chunks(int k) { return (k + 31) / 32; }
+DEV_HOST size_t mlp_prepared_layer_bytes(int k) { return (size_t)mlp_chunks(k) * MLP_WAVES * 4 * 2 * WAVE * 16; }
+DEV_HOST size_t mlp_prepared_bytes(int in_dim) {
+  return mlp_prepared_layer_bytes(in_dim) + mlp_prepared_layer_bytes(MLP_H) + sizeof(float) * (2 * MLP_H + 2 * MLP_H + 4);
+}
+DEV_HOST int mlp_bf_stride(int kp) { return kp + 8; }  // bf16 elements per LDS row: (kp / 2 + 4) words = 4 (odd) -> 16 rows x 16 B hit 64 banks
+DEV_HOST size_t mlp_bf_lds_bytes(int in_dim) {
+  return 2 * (size_t)MLP_ROWS * (2 * (size_t)mlp_bf_stride(32 * mlp_chunks(in_dim)) + 4 * (size_t)mlp_bf_stride(MLP_H)) + sizeof(float) * 2 * MLP_H;
+}
+
+// one thread per (layer, chunk, wave, tile, lane): eight weights of one column, split and packed
+__global__ __launch_bounds__(256) void k_mlp_prepare(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                                                     const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3,
+                                                     const int in_dim, const int out_cols, uint4* __restrict__ prep) {
+  const int c1 = mlp_chunks(in_dim), c2 = mlp_chunks(MLP_H);
+  const int per_chunk = MLP_WAVES * 4 * WAVE;
+  const int n_frag = (c1 + c2) * per_chunk;
+  const int id = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x;
+  if (id < n_frag) {
+    const bool second = id >= c1 * per_chunk;
+    const int q = second ? id - c1 * per_chunk : id;
+    const int c = q / per_chunk, r = q - c * per_chunk, w = r / (4 * WAVE), t = (r / WAVE) & 3, l = r & (WAVE - 1);
+    const float* W = second ? W2 : W1;
+    const int kreal = second ? MLP_H : in_dim;
+    const int col = 64 * w + 16 * t + (l & 15), k0 = 32 * c + 8 * (l >> 4);
+    unsigned h[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mlp_split(k0 + j < kreal ? W[(size_t)(k0 + j) * MLP_H + col] : 0.0f, h[j], lo[j]);
+    uint4* dst = prep + (second ? mlp_prepared_layer_bytes(in_dim) / 16 : 0) + ((size_t)((c * MLP_WAVES + w) * 4 + t) * 2) * WAVE + l;
+    dst[0] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    dst[WAVE] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+  }
+  float* tail = reinterpret_cast<float*>(reinterpret_cast<char*>(prep) + mlp_prepared_layer_bytes(in_dim) + mlp_prepared_layer_bytes(MLP_H));
+  if (id < MLP_H) {
+    tail[id] = b1[id];
+    tail[MLP_H + id] = b2[id];
+    tail[2 * MLP_H + id] = W3[(size_t)id * out_cols];          // head, output 0
+    tail[3 * MLP_H + id] = W3[(size_t)id * out_cols + 1];      // head, output 1
+  }
+  if (id < 2) tail[4 * MLP_H + id] = b3[id];
+}
+
+// one 256-wide layer, split operands: A planes in LDS (row stride a_ld bf16 elements), B fragments from the prepared buffer
+DEV void mlp_layer_bf(const unsigned short* __restrict__ AH, const unsigned short* __restrict__ AL, const int a_ld, const uint4* __restrict__ Bp,
+                      const int chunks, const int lane, const int wave, mlp_f32x4 (&acc)[4]) {
+  const int arow = lane & 15, g = lane >> 4;
+  const uint4* ah = reinterpret_cast<const uint4*>(AH + arow * a_ld + 8 * g);  // (16-byte aligned: a_ld and the chunk offsets are multiples of 8)
+  const uint4* al = reinterpret_cast<const uint4*>(AL + arow * a_ld + 8 * g);
+  const uint4* bp = Bp + (size_t)wave * 4 * 2 * WAVE + lane;
+  auto load = [&](const int c, uint4 (&a)[2], uint4 (&b)[8]) {
+    const int cc = c < chunks ? c : chunks - 1;  // (a read past the last chunk repeats it: unconditional reads, never used)
+    a[0] = ah[cc * 4];  // 32 bf16 = 4 x 16 B per chunk
+    a[1] = al[cc * 4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b[q] = bp[((size_t)cc * MLP_WAVES * 4 * 2 + q) * WAVE];  // q = 2 t + plane
+  };
+  auto mma = [&](const uint4 (&a)[2], const uint4 (&b)[8]) {
+    const mlp_bf16x8 aH = __builtin_bit_cast(mlp_bf16x8, a[0]), aL = __builtin_bit_cast(mlp_bf16x8, a[1]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const mlp_bf16x8 bH = __builtin_bit_cast(mlp_bf16x8, b[2 * t]), bL = __builtin_bit_cast(mlp_bf16x8, b[2 * t + 1]);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aL, bH, acc[t], 0, 0, 0);  // (the small terms first)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aH, bL, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aH, bH, acc[t], 0, 0, 0);
+    }
+  };
+  uint4 aP[2], aQ[2], bP[8], bQ[8];
+  const int pairs = chunks >> 1;
+  load(0, aP, bP);
+  for (int p = 0; p < pairs; ++p) {
+    load(2 * p + 1, aQ, bQ);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(aP, bP);
+    __builtin_amdgcn_sched_barrier(0);
+    load(2 * p + 2, aP, bP);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(aQ, bQ);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (chunks & 1) mma(aP, bP);
+}
+
+DEV void mlp_store_hidden_bf(unsigned short* __restrict__ HH, unsigned short* __restrict__ HL, const float* __restrict__ bias, const int lane,
+                             const int wave, const mlp_f32x4 (&acc)[4]) {
+  const int n = lane & 15, r4 = (lane >> 4) * 4, hs = mlp_bf_stride(MLP_H);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = 64 * wave + 16 * t + n;
+    const float bb = bias[col];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned hi, lo;
+      mlp_split(mlp_tanh(acc[t][i] + bb), hi, lo);
+      HH[(r4 + i) * hs + col] = (unsigned short)hi;
+      HL[(r4 + i) * hs + col] = (unsigned short)lo;
+    }
+  }
+}
+
+template <bool TANH_OUT>
+__global__ __launch_bounds__(WAVE * MLP_WAVES, 4) void k_mlp_policy_bf(const float* __restrict__ obs, const int row0, const int n_rows,
+                                                                       const int obs_stride, const int in_dim, const uint4* __restrict__ prep,
+                                                                       float* __restrict__ act) {
+  extern __shared__ float mlp_lds[];
+  const int c1 = mlp_chunks(in_dim), kp = 32 * c1, xs = mlp_bf_stride(kp), hs = mlp_bf_stride(MLP_H);
+  unsigned short* XH = reinterpret_cast<unsigned short*>(mlp_lds);
+  unsigned short* XL = XH + MLP_ROWS * xs;
+  unsigned short* H1H = XL + MLP_ROWS * xs;
+  unsigned short* H1L = H1H + MLP_ROWS * hs;
+  unsigned short* H2H = H1L + MLP_ROWS * hs;
+  unsigned short* H2L = H2H + MLP_ROWS * hs;
+  float* W3s = reinterpret_cast<float*>(H2L + MLP_ROWS * hs);  // [2][256] (the stride terms are multiples of 8 elements: 4-byte aligned)
+  const float* tail = reinterpret_cast<const float*>(reinterpret_cast<const char*>(prep) + mlp_prepared_layer_bytes(in_dim) + mlp_prepared_layer_bytes(MLP_H));
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r0 = (int)blockIdx.x * MLP_ROWS;
+  float w3v[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) w3v[q] = tail[2 * MLP_H + tid + q * WAVE * MLP_WAVES];
+  // the observation rows, split on their way into LDS (all reads of the wave's four rows before the first store; rows of up to 320 floats)
+  constexpr int XCH = 5;
+  for (int i = 0; i < MLP_ROWS / MLP_WAVES; ++i) {
+    const int r = wave + i * MLP_WAVES;
+    const bool row_in = r0 + r < n_rows;
+    const float* src = obs + (size_t)(row0 + r0 + (row_in ? r : 0)) * obs_stride;
+    if (kp <= WAVE * XCH) {
+      float v[XCH];
+#pragma unroll
+      for (int j = 0; j < XCH; ++j) {
+        const int k = lane + WAVE * j;
+        v[j] = src[k < in_dim ? k : in_dim - 1];
+        if (!(row_in && k < in_dim)) v[j] = 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < XCH; ++j) {
+        const int k = lane + WAVE * j;
+        if (k < kp) { unsigned hi, lo; mlp_split(v[j], hi, lo); XH[r * xs + k] = (unsigned short)hi; XL[r * xs + k] = (unsigned short)lo; }
+      }
+    } else {
+      for (int k = lane; k < kp; k += WAVE) {
+        unsigned hi, lo;
+        mlp_split((row_in && k < in_dim) ? src[k] : 0.0f, hi, lo);
+        XH[r * xs + k] = (unsigned short)hi; XL[r * xs + k] = (unsigned short)lo;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) W3s[tid + q * WAVE * MLP_WAVES] = w3v[q];
+  __syncthreads();
+  mlp_f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = mlp_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  mlp_layer_bf(XH, XL, xs, prep, c1, lane, wave, acc);
+  mlp_store_hidden_bf(H1H, H1L, tail, lane, wave, acc);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = mlp_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  mlp_layer_bf(H1H, H1L, hs, prep + mlp_prepared_layer_bytes(in_dim) / 16, mlp_chunks(MLP_H), lane, wave, acc);
+  mlp_store_hidden_bf(H2H, H2L, tail + MLP_H, lane, wave, acc);
+  __syncthreads();
+  {
+    const int dot = tid >> 3, part = tid & 7, r = dot >> 1, o = dot & 1;
+    float s = 0.0f;
+#pragma unroll 4
+    for (int k = part; k < MLP_H; k += 8) s = fmaf(mlp_bf16_f(H2H[r * hs + k]) + mlp_bf16_f(H2L[r * hs + k]), W3s[o * MLP_H + k], s);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 1);
+    if (part == 0 && r0 + r < n_rows) {
+      const float v = s + tail[4 * MLP_H + o];
+      act[(size_t)(row0 + r0 + r) * 2 + o] = TANH_OUT ? mlp_tanh(v) : v;
+    }
+  }
+}
+
 #endif

@@ -28,6 +28,9 @@ _SIGS = {
     "pgd_observe": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pgd_describe_step": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "pgd_forget_rows": (C.c_int, [C.c_void_p]),
+    "pgd_mlp_prepared_bytes": (C.c_size_t, [C.c_int]),
+    "pgd_mlp_prepare": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
+    "pgd_mlp_policy_prepared": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pgd_step_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "pgd_set_step_module": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "pgd_mlp_policy": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
@@ -235,6 +238,26 @@ class Engine:
                                C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(flags.data_ptr())), "pgd_step_n")
         return (self.obs if want_obs else None), rew, done, flags
 
+    def mlp_prepare(self, weights):
+        """The policy network's weights in the split-bf16 kernel's own layout (pgd_mlp_prepare): call once per policy update, hand the
+        returned buffer to mlp_policy(prepared=...).  `weights` as for mlp_policy."""
+        t = self.torch
+        w1, b1, w2, b2, w3, b3 = weights
+        for w in weights:
+            assert w.is_cuda and w.dtype == t.float32 and w.is_contiguous()
+        k = int(w1.shape[0])
+        assert w1.shape == (k, 256) and w2.shape == (256, 256) and w3.shape[0] == 256 and w3.shape[1] >= 2
+        buf = t.empty(int(self.L.pgd_mlp_prepared_bytes(k)), dtype=t.uint8, device=self.device)
+        cur = t.cuda.current_stream(self.device).cuda_stream
+        if cur != self._bound_stream:
+            _chk(self.L.pgd_set_stream(self.h, C.c_void_p(cur)), "pgd_set_stream")
+            self._bound_stream = cur
+        _chk(self.L.pgd_mlp_prepare(self.h, k, 256, C.c_void_p(w1.data_ptr()), C.c_void_p(b1.data_ptr()), C.c_void_p(w2.data_ptr()),
+                                    C.c_void_p(b2.data_ptr()), C.c_void_p(w3.data_ptr()), C.c_void_p(b3.data_ptr()), int(w3.shape[1]),
+                                    C.c_void_p(buf.data_ptr())), "pgd_mlp_prepare")
+        buf._pgd_in_dim = k
+        return buf
+
     def specialise(self, wait=True, verbose=False):
         """Build (hipcc, cached) and load a step kernel with THIS engine's configuration compiled in (pgdrive_amd/jit.py):
         configurations the library has no instantiation for then step as fast as the reference's defaults.  wait=False: in a
@@ -261,12 +284,27 @@ class Engine:
                                           v_target_kmh, noise, int(tick) & 0xffffffff), "pgd_lane_keep_actions")
         return out
 
-    def mlp_policy(self, weights, out, obs=None, group=-1, final_tanh=False, in_dim=None):
+    def mlp_policy(self, weights, out, obs=None, group=-1, final_tanh=False, in_dim=None, prepared=None):
         """actions = tanh-MLP(observation rows) in one launch (pgd_mlp_policy; the network of examples/ppo_expert/numpy_expert.py).
         `weights` = (w1 [in, 256], b1, w2 [256, 256], b2, w3 [256, >= 2], b3): contiguous float32 cuda tensors, row-major [in][out].
         `obs`: [rows, stride] float32 cuda (default: the engine's own observation buffer); `out`: float32 cuda [N, A, 2].
         group >= 0: only the rows of that env group, on the group's stream (then `obs` / `out` are still the FULL buffers)."""
         t = self.torch
+        if prepared is not None:  # split-bf16 kernel on weights prepared by mlp_prepare (`weights` is then ignored)
+            o = self.obs if obs is None else obs
+            o2 = o.view(-1, o.shape[-1])
+            assert o2.is_cuda and o2.dtype == t.float32 and o2.stride(1) == 1 and o2.shape[0] == self.N * self.A
+            assert out.is_cuda and out.dtype == t.float32 and out.is_contiguous() and out.numel() == self.N * self.A * 2
+            k = int(in_dim if in_dim is not None else prepared._pgd_in_dim)
+            if group < 0:
+                cur = t.cuda.current_stream(self.device).cuda_stream
+                if cur != self._bound_stream:
+                    _chk(self.L.pgd_set_stream(self.h, C.c_void_p(cur)), "pgd_set_stream")
+                    self._bound_stream = cur
+            _chk(self.L.pgd_mlp_policy_prepared(self.h, int(group), C.c_void_p(o2.data_ptr()), int(o2.stride(0)), k,
+                                                C.c_void_p(prepared.data_ptr()), int(bool(final_tanh)), C.c_void_p(out.data_ptr())),
+                 "pgd_mlp_policy_prepared")
+            return out
         w1, b1, w2, b2, w3, b3 = weights
         o = self.obs if obs is None else obs
         o2 = o.view(-1, o.shape[-1])

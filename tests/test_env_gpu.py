@@ -1014,6 +1014,23 @@ def test_mlp_policy_matches_the_numpy_expert(descs, case):
         got = out.view(n, 2).cpu().numpy()
         assert np.isfinite(got).all() and np.abs(got - want).max() < 2e-5, np.abs(got - want).max()
         assert np.abs(want).max() > 0.05  # (not a trivially small network output)
+        # the same network with split bf16 operands on prepared weights (pgd_mlp_prepare / pgd_mlp_policy_prepared): every value as
+        # hi + lo, a product as three bf16 matrix instructions -- 16 bits of mantissa, not 24: held to 1e-4 (measured ~3e-5)
+        prep = eng.mlp_prepare(wt)
+        assert prep.numel() == eng.L.pgd_mlp_prepared_bytes(in_dim)
+        out2 = torch.full((n, 1, 2), 7.0, dtype=torch.float32, device="cuda")
+        if case == "groups":
+            for g in range(4):
+                eng.mlp_policy(None, out2, group=g, final_tanh=ft, prepared=prep)
+            for g in range(4):
+                eng.group_sync(g)
+        else:
+            eng.mlp_policy(None, out2, obs=obs, final_tanh=ft, in_dim=in_dim, prepared=prep)
+            eng.sync()
+        got2 = out2.view(n, 2).cpu().numpy()
+        err2 = float(np.abs(got2 - want).max())
+        print("split-bf16 policy, %s: max |action - float64| = %.2e (exact-f32 kernel: %.2e)" % (case, err2, float(np.abs(got - want).max())))
+        assert np.isfinite(got2).all() and err2 < 1e-4, err2
         # the arguments the library refuses: another hidden width, a row stride below the input width
         import ctypes as C
         p = [C.c_void_p(t.data_ptr()) for t in wt]

@@ -27,7 +27,11 @@ def torch_policy():
     torch.tanh(torch.addmm(B[2], h, W[2]), out=act.view(N, 2))
 
 
-for name, fn in (("pgd_mlp_policy", lambda: eng.mlp_policy(w, act, final_tanh=True)), ("torch 3 x addmm + 3 x tanh", torch_policy)):
+prep = eng.mlp_prepare(w)
+eng.sync()
+for name, fn in (("pgd_mlp_policy", lambda: eng.mlp_policy(w, act, final_tanh=True)),
+                 ("pgd_mlp_policy_prepared (bf16 x 3)", lambda: eng.mlp_policy(None, act, final_tanh=True, prepared=prep)),
+                 ("torch 3 x addmm + 3 x tanh", torch_policy)):
     with torch.no_grad(), torch.cuda.stream(eng.stream):
         for _ in range(20):
             fn()
@@ -47,5 +51,5 @@ for name, fn in (("pgd_mlp_policy", lambda: eng.mlp_policy(w, act, final_tanh=Tr
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 400
     flops = 2.0 * N * (274 * 256 + 256 * 256 + 256 * 2)
-    print("%-28s %d rows: %.2f us per call back to back (%.1f TFLOP/s fp32; f32 MFMA peak 157)" % (name, N, us, flops / us / 1e6))
+    print("%-36s %d rows: %.2f us per call back to back (%.1f TFLOP/s fp32; f32 MFMA peak 157)" % (name, N, us, flops / us / 1e6))
 eng.close()
