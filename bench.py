@@ -1013,7 +1013,7 @@ def measure_policy(args, local_rank, steps=2048, warm=1500, windows=3):
             res["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
         # env groups (pgd_set_groups): a single-stream graph per group, replayed on the group's stream -- 2 x 4096 (the verdict's
         # variant), and smaller groups, which leave register file for the policy's waves next to the other group's step
-        for Gn, Ng in (((2, N), (2, N // 2), (4, N // 2)) if impl == "fused" else ((2, N), )):  # (the smaller groups: the exact engine policy only)
+        for Gn, Ng in {"fused": ((2, N), (2, N // 2), (4, N // 2)), "fused_bf16x3": ((2, N), (2, N // 2))}.get(impl, ((2, N), )):
             key = "groups_graph" if (Gn, Ng) == (2, N) else "groups_graph_%dx%d" % (Gn, Ng)
             try:
                 with torch.no_grad():

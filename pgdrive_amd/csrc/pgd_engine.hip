@@ -2231,8 +2231,9 @@ int pgd_step_geometry(pgd_handle h, int32_t* out12) {
 int pgd_set_step_module(pgd_handle h, const char* code_object_path, int built_with_objects, int built_with_std_rows) {
   if (!h) return PGD_ERR_ARG;
   HIPCHK(hipSetDevice(h->device));
-  if (h->jit_mod) {  // (a module in use by launches in flight must outlive them)
+  if (h->jit_mod) {  // (a module in use by launches in flight must outlive them: the engine's stream and every env group's)
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (int g = 0; h->gstreams && g < h->n_groups; ++g) HIPCHK(hipStreamSynchronize(h->gstreams[g]));
     h->jit_fn = nullptr;
     (void)hipModuleUnload(h->jit_mod);
     h->jit_mod = nullptr;
