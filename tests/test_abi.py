@@ -125,3 +125,14 @@ def test_field_offsets_match_c():
             assert int(out["%s.%s" % (st, name)]) == off, (st, name, out["%s.%s" % (st, name)], off)
             n += 1
     assert n > 100
+
+
+def test_prepared_policy_buffer_size_is_a_pure_function():
+    """pgd_mlp_prepared_bytes (no GPU needed): two layers of 32-row chunks x 4 waves x 4 tiles x 2 planes x 64 lanes x 16 bytes, then
+    b1, b2, the head's 2 x 256 weights and b3 (4 floats reserved); 0 for an input width the kernels refuse."""
+    from pgdrive_amd import engine
+    L = engine.load_library()
+    chunk = 4 * 4 * 2 * 64 * 16
+    assert L.pgd_mlp_prepared_bytes(274) == (9 + 8) * chunk + 4 * (4 * 256 + 4)
+    assert L.pgd_mlp_prepared_bytes(256) == (8 + 8) * chunk + 4 * (4 * 256 + 4)
+    assert L.pgd_mlp_prepared_bytes(3) == 0 and L.pgd_mlp_prepared_bytes(5000) == 0
