@@ -218,6 +218,13 @@ constexpr FixSpec fix_spec(int fix) {
   F(c.crash_object_penalty, 10.0f) F(c.driving_reward, 1.0f) F(c.speed_reward, 0.1f) F(c.side_lasers, 0) F(c.lane_line_lasers, 0)   \
   F(c.random_agent_model, 0) F(c.lidar_gaussian_noise, 0.0f) F(c.lidar_dropout_prob, 0.0f) F(c.delay_done, 25) F(c.idm_agent, 0)   \
   F(c.idm_steer_lag, 0.0f)
+// ... and, on top of that list, the engine's SEAT COUNT for the two geometries the reference's default agent counts produce here:
+// 40 seats (MultiAgentRoundaboutEnv's 40 agents, marl_inout_roundabout.py:26: the vec env and bench.py's c5_40x72 row) and 44 (the
+// dict-keyed envs keep spare seats: pgdrive_amd/marl_env.py) with the reference's 72 beams (multi_agent_pgdrive.py:38).  FIX = the seat
+// count.  With V, A, the lanes per seat, the row width and the beam count literals the 40-seat step runs at 115 registers instead of
+// 128 and 23 scalar spills instead of 77: k_step 28.4 -> 26.3 us, k_observe_env 30.2 -> 29.5 us (64 registers), the row 76.8 -> 81.1 M
+// (round 6, profiles/r06_notes.md).  The respawn table's shape and the horizon stay run-time values (they differ between the maps).
+#define PGD_FIXM_SEAT_FIELDS(F, d, c, S) F(d.V, S) F(d.A, S) F(d.sub, (WAVE / (S))) F(d.D, 90) F(c.num_agents, S) F(c.num_lasers, 72)
 // BASELINE config 2: the ego alone, no lidar (dynamics + reward + the 18-float state vector), otherwise the single-agent defaults --
 // four envs per wave, 16 sub-lanes per ego, the row written by k_step itself.
 #define PGD_FIXE_FIELDS(F, d, c)                                                                                                    \
@@ -233,7 +240,10 @@ template <bool ONE_ENV, bool MARL, bool STD, int FIX = 1>
 DEV void write_fixed_config(PgdDev& d) {
   pgd_config& c = d.cfg;
 #define PGD_F_SET(f, v) f = v;
-  if (MARL) { PGD_FIXM_FIELDS(PGD_F_SET, d, c) }
+  if (MARL) {
+    PGD_FIXM_FIELDS(PGD_F_SET, d, c)
+    if (FIX > 1 && FIX != 9) { PGD_FIXM_SEAT_FIELDS(PGD_F_SET, d, c, (FIX > 1 ? FIX : WAVE)) }
+  }
   else if (!ONE_ENV && !STD) { PGD_FIXE_FIELDS(PGD_F_SET, d, c) }
 #ifdef PGD_JIT
   // FIX 9: a code object built at run time for ONE handle (pgdrive_amd/jit.py, pgd_set_step_module): every immutable field of its
@@ -263,6 +273,17 @@ static bool fix_config_matches(const PgdDev& d, bool one_env, int kind = FIXK_DE
   }
 #undef PGD_F_TEST
   return ok;
+}
+// the multi-agent instantiations with the seat count folded: which one (0 = none) an engine that passed FIXK_MARL can run
+static int marl_fix_seats(const PgdDev& d) {
+  for (int S : {40, 44}) {
+    bool ok = true;
+#define PGD_F_TEST(f, v) ok = ok && (f == v);
+    PGD_FIXM_SEAT_FIELDS(PGD_F_TEST, d, d.cfg, S)
+#undef PGD_F_TEST
+    if (ok) return S;
+  }
+  return 0;
 }
 // What only the rare paths of a step read (an env restarting, a multi-agent respawn): a second by-value argument that is never
 // written, so its fields are fetched from the argument segment where they are used -- in the specialised kernels `d` is a local
@@ -1370,7 +1391,7 @@ __global__ __launch_bounds__(BLOCK == WAVE ? WAVE * OBS_RPB : BLOCK) void k_obse
 // NW = 4 when the pair phase has at least four passes (A >= 4 * (WAVE / V)), else 1.
 // FIX: the engine runs the default multi-agent configuration (same constants as k_step's instantiation for it, PGD_FIXM_FIELDS)
 // STATE = false: k_step has written the state blocks of the rows that are due (PgdDev::state_rows): the pairwise part only
-template <int NW, bool FIX = false, bool STATE = true>
+template <int NW, bool FIX = false, bool STATE = true, int SEATS = 0>  // SEATS: the seat count folded as well (PGD_FIXM_SEAT_FIELDS)
 // (the library is built at -O2 since the end of round 5; this kernel keeps the size-optimised code it had -- 30.0 against 30.7 us for the
 // 40 seats -- and its specialised instantiations seven waves per SIMD: 72 registers, what -Os gave them unasked; at -O2 they took 82 and
 // the observation 32.6 us)
@@ -1378,7 +1399,7 @@ template <int NW, bool FIX = false, bool STATE = true>
 #define PGD_KOE_ATTR __attribute__((minsize))
 #endif
 __global__ PGD_KOE_ATTR __launch_bounds__(WAVE * NW, (FIX ? 7 : 1)) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags, int G) {
-  if (FIX) write_fixed_config<true, true, false>(d);
+  if (FIX) write_fixed_config<true, true, false, (SEATS ? SEATS : 1)>(d);
   extern __shared__ unsigned s_minb_dyn[];
   __shared__ ObsEnvLds<NW> M;
   PHASE_INIT();  // (profile builds: the marks of observe_env_body count from here)
@@ -1875,6 +1896,9 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
       void (*ke)(PgdDev, float*, const uint32_t*, int) = four ? k_observe_env<4> : k_observe_env<1>;
       if (fix) ke = four ? k_observe_env<4, true> : k_observe_env<1, true>;
       if (state_done && four) ke = fix ? k_observe_env<4, true, false> : k_observe_env<4, false, false>;
+      const int seats = (fix && four) ? marl_fix_seats(D) : 0;
+      if (seats == 40) ke = state_done ? k_observe_env<4, true, false, 40> : k_observe_env<4, true, true, 40>;
+      if (seats == 44) ke = state_done ? k_observe_env<4, true, false, 44> : k_observe_env<4, true, true, 44>;
       hipLaunchKernelGGL(ke, dim3(envs), dim3(WAVE * nw), dyn, stream, D, d_obs, d_flags, G);
       HIPCHK(hipGetLastError());
       return PGD_OK;
@@ -1989,6 +2013,9 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
     if (!h->has_objects && !h->no_fix && fix_config_matches(dv, true, FIXK_MARL) && dv.V == dv.A && dv.sub == WAVE / dv.A) {
       kern = k_step<true, true, false, false, 1>;
       kname = "k_step: one env per wave, specialised for the default multi-agent configuration";
+      const int seats = marl_fix_seats(dv);
+      if (seats == 40) { kern = k_step<true, true, false, false, 40>; kname = "k_step: one env per wave, specialised for the default multi-agent configuration with 40 agent seats x 72 beams"; }
+      if (seats == 44) { kern = k_step<true, true, false, false, 44>; kname = "k_step: one env per wave, specialised for the default multi-agent configuration with 44 agent seats x 72 beams"; }
     }
   }
   else if (h->d.epw == 1) {

@@ -373,13 +373,16 @@ def test_run_time_kernel_is_refused_where_it_does_not_apply(descs, monkeypatch, 
     assert len([f for f in os.listdir(str(tmp_path)) if f.endswith(".hsaco")]) == 1
 
 
-def test_default_multi_agent_kernel_matches_the_general_kernel(monkeypatch):
+@pytest.mark.parametrize("agents,seats", [(8, 12), (40, 40), (40, 44)])
+def test_default_multi_agent_kernel_matches_the_general_kernel(monkeypatch, agents, seats):
     """Multi-agent engines with the scalar fields of MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG get their own instantiation of k_step (those
-    fields are compile-time constants in it; agent count, spawn places and horizon stay run-time values).  Against the general
-    kernel (PGD_NO_FIX=1) from the same state with the same actions: flags, done, integer state identical, floats to rounding."""
+    fields are compile-time constants in it; agent count, spawn places and horizon stay run-time values) -- and, round 6, the seat
+    counts the reference's default agent number produces (40: the vec env; 44: the dict-keyed envs' spare seats) instantiations with
+    the seat count, the row width and the 72 beams folded as well, in the step AND in the four-wave observation kernel.  Against the
+    general kernels (PGD_NO_FIX=1) from the same state with the same actions: flags, done, integer state identical, floats to rounding."""
     import torch
     from pgdrive_amd.engine import Engine
-    d, mb, sb = util.make_marl_banks(num_agents=8, capacity=12, kind="roundabout")
+    d, mb, sb = util.make_marl_banks(num_agents=agents, capacity=seats, kind="roundabout")
     n_envs = 32
     cfg = util.marl_config(n_envs, sb, horizon=120)
     monkeypatch.delenv("PGD_NO_FIX", raising=False)
@@ -390,7 +393,7 @@ def test_default_multi_agent_kernel_matches_the_general_kernel(monkeypatch):
     ids = np.arange(n_envs) % 8
     fix.reset(ids); gen.reset(ids); other.reset(ids)
     rng = np.random.default_rng(5)
-    n_done = n_new = 0
+    n_done = n_new = n_graze = 0
     for t in range(300):
         act = util.marl_actions(rng, n_envs, sb.A)
         f, i, ei = gen.get_state()
@@ -401,15 +404,25 @@ def test_default_multi_agent_kernel_matches_the_general_kernel(monkeypatch):
         gen.sync(); fix.sync()
         assert torch.equal(d1, d2) and torch.equal(f1, f2), "flags differ at step %d" % t
         rep = ((f1 & (_abi.F_REPORT | _abi.F_NEW)) != 0)
-        assert float(((o1 - o2).abs() * rep[..., None]).max()) < 2e-6 and float(((r1 - r2).abs() * rep).max()) < 2e-5
+        dd = (o1 - o2).abs() * rep[..., None]
+        # (a beam that grazes a box corner is a hit in one instantiation and a miss in the other -- the slab test compares two nearly
+        # equal parameters, and the two kernels round them differently: seen once in 300 steps x 32 envs at 44 seats, beam 70 of a row,
+        # 0.16 against 1.0.  Such flips are counted, like the grazing beams of the oracle comparisons; everything else agrees to 2e-6)
+        flip = (dd[..., 18:] > 2e-6) & ((o1[..., 18:] == 1.0) | (o2[..., 18:] == 1.0))
+        n_graze += int(flip.sum())
+        dd[..., 18:][flip] = 0.0
+        assert float(dd.max()) < 2e-6 and float(((r1 - r2).abs() * rep).max()) < 2e-5
         g1, i1, e1 = gen.get_state()
         g2, i2, e2 = fix.get_state()
         assert (i1 == i2).all() and (e1 == e2).all(), "integer state differs at step %d" % t
         n_done += int(d1.sum()); n_new += int(((f1 & _abi.F_NEW) != 0).sum())
-    assert n_done > 20 and n_new > 20
+    assert n_done > 20 and n_new > 20 and n_graze <= 3, n_graze
     other.step(torch.from_numpy(util.marl_actions(rng, n_envs, sb.A)).to(other.device)); other.sync()
     assert "specialised for the default multi-agent" in fix.describe_step()
+    assert ("%d agent seats x 72 beams" % seats in fix.describe_step()) == (seats in (40, 44)), fix.describe_step()
     assert "specialised" not in gen.describe_step() and "specialised" not in other.describe_step()
+    for e in (fix, gen, other):
+        e.close()
 
 
 @pytest.mark.parametrize("traffic_mode", ["trigger", "hybrid"])
