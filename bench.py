@@ -452,6 +452,9 @@ ROWS = [
     ("c5_8x240", dict(workload="c5", agents=8, lasers=240, warmup=6000, steps=2000)),
     ("c5_8x72", dict(workload="c5", agents=8, lasers=72, warmup=6000, steps=2000)),
     ("c5_40x72", dict(workload="c5", agents=40, lasers=72, warmup=6000, steps=2000)),
+    # the same 4096 envs as two asynchronous env groups of 2048 (pgd_set_groups / pgd_step_group, each on its own stream): the step
+    # kernel of one group -- one wave per env, waiting for memory half of its life -- runs beside the observation kernel of the other
+    ("c5_40x72_two_groups", dict(workload="c5", agents=40, lasers=72, warmup=6000, steps=2000, groups=2)),
     ("c3_32768", dict(envs=32768, warmup=1500, steps=512)),
     # the top-down image observation (TopDownPGDriveEnv: 84 x 84 x 5 floats per env and step instead of the 274-float row): pgd_step
     # without the lidar + pgd_observe_topdown; a write-bound kernel of its own

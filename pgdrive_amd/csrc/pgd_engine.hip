@@ -1401,9 +1401,10 @@ template <int NW, bool FIX = false, bool STATE = true, int SEATS = 0>  // SEATS:
 __global__ PGD_KOE_ATTR __launch_bounds__(WAVE * NW, (FIX ? 7 : 1)) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags, int G) {
   if (FIX) write_fixed_config<true, true, false, (SEATS ? SEATS : 1)>(d);
   extern __shared__ unsigned s_minb_dyn[];
-  __shared__ ObsEnvLds<NW> M;
+  constexpr int CAP = SEATS ? (SEATS + 15) / 16 * 16 : WAVE;
+  __shared__ ObsEnvLds<NW, CAP> M;
   PHASE_INIT();  // (profile builds: the marks of observe_env_body count from here)
-  observe_env_body<NW, !FIX, false, !FIX, STATE>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);  // (the fixed-config kernel: no traffic objects)
+  observe_env_body<NW, !FIX, false, !FIX, STATE, CAP>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);  // (the fixed-config kernel: no traffic objects)
 }
 
 // scripted lane-keeping policy (pgd_lane_keep_actions): one thread per env

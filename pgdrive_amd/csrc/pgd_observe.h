@@ -579,16 +579,19 @@ DEV_HOST int observe_env_words(int g, int num_lasers, int V, int num_others) {
 // ... and behind the waves' areas, with PGD_MA_OTHERS_STATE: slot and speed of every observer's ranked neighbours
 DEV_HOST int observe_env_oth_words(int A, int num_others, bool oth) { return oth ? 2 * A * num_others : 0; }
 
-template <int NW>
+// CAP: slots the body / observer tables hold (WAVE, or the seat count rounded up to 16 in the instantiations that fold it: with 48
+// instead of 64 and the beam start packed into the pair word a block of the 40-seat kernel takes 20.2 instead of 22.0 KB, and the
+// eighth block fits the CU's 160 KB)
+template <int NW, int CAP = WAVE>
 struct ObsEnvLds {
-  float bX[WAVE], bY[WAVE], bUX[WAVE], bUY[WAVE], bHL[WAVE], bHW[WAVE], bV[WAVE], bAID[WAVE];
-  int bST[WAVE];       // status | kind << 8
-  uint32_t bFL[WAVE];  // step flags of agent slot o (0 beyond A or without flags)
-  float aMS[WAVE];     // observer: max_speed of its vehicle
-  int aWant[WAVE];
-  unsigned char wList[WAVE], bList[WAVE];  // the observers that get a row / the bodies that can be seen by one, ascending
-  float pDist[NW][WAVE];
-  int pPref[NW][WAVE + 1], pI0[NW][WAVE];
+  float bX[CAP], bY[CAP], bUX[CAP], bUY[CAP], bHL[CAP], bHW[CAP], bV[CAP], bAID[CAP];
+  int bST[CAP];       // status | kind << 8
+  uint32_t bFL[CAP];  // step flags of agent slot o (0 beyond A or without flags)
+  float aMS[CAP];     // observer: max_speed of its vehicle
+  int aWant[CAP];
+  unsigned char wList[CAP], bList[CAP];  // the observers that get a row / the bodies that can be seen by one, ascending
+  float pDist[NW][WAVE];  // (as ints: first beam of the window << 16 | observer of the round << 8 | body, per lane of the pass)
+  int pPref[NW][WAVE + 1];
   unsigned long long pMask[NW][32];  // per round of 64 incidences: the positions at which a pair's window starts
 };
 // `G` observers per round of a wave (as many as the LDS holds, see observe_env_words);
@@ -618,13 +621,13 @@ DEV unsigned long long rowz_tag(const float* obs, int ostride) {
 // OBJ = false: engines whose scenarios hold no traffic objects (no circles among the bodies)
 // STATE = false: the state blocks of the rows that are due have been written by k_step (PgdDev::state_rows): no record of an
 // observer, no spawn record, no lane table is read here -- the bodies' poses and the step flags are all the routine needs
-template <int NW, bool ALLOW_OTH = true, bool FUSED = false, bool OBJ = true, bool STATE = true>
-DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const uint32_t* flags, ObsEnvLds<NW>& M,
+template <int NW, bool ALLOW_OTH = true, bool FUSED = false, bool OBJ = true, bool STATE = true, int CAP = WAVE>
+DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const uint32_t* flags, ObsEnvLds<NW, CAP>& M,
                           unsigned* s_minb_all, const int G, const EnvInWave* in_wave = nullptr) {
-  float (&bX)[WAVE] = M.bX; float (&bY)[WAVE] = M.bY; float (&bUX)[WAVE] = M.bUX; float (&bUY)[WAVE] = M.bUY;
-  float (&bHL)[WAVE] = M.bHL; float (&bHW)[WAVE] = M.bHW; float (&bV)[WAVE] = M.bV; float (&bAID)[WAVE] = M.bAID;
-  int (&bST)[WAVE] = M.bST; uint32_t (&bFL)[WAVE] = M.bFL; float (&aMS)[WAVE] = M.aMS; int (&aWant)[WAVE] = M.aWant;
-  float (&pDist_all)[NW][WAVE] = M.pDist; int (&pPref_all)[NW][WAVE + 1] = M.pPref; int (&pI0_all)[NW][WAVE] = M.pI0;
+  float (&bX)[CAP] = M.bX; float (&bY)[CAP] = M.bY; float (&bUX)[CAP] = M.bUX; float (&bUY)[CAP] = M.bUY;
+  float (&bHL)[CAP] = M.bHL; float (&bHW)[CAP] = M.bHW; float (&bV)[CAP] = M.bV; float (&bAID)[CAP] = M.bAID;
+  int (&bST)[CAP] = M.bST; uint32_t (&bFL)[CAP] = M.bFL; float (&aMS)[CAP] = M.aMS; int (&aWant)[CAP] = M.aWant;
+  float (&pDist_all)[NW][WAVE] = M.pDist; int (&pPref_all)[NW][WAVE + 1] = M.pPref;
   const int V = d.V, A = d.A, D = d.D, NL = d.cfg.num_lasers, NO = d.cfg.num_others;
   const int tid = threadIdx.x, wv = tid / WAVE, lane = tid % WAVE;
   const RecPiece* recs = rec_block(d.rec, (size_t)e, V);
@@ -728,9 +731,10 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   // are compacted into two ascending lists, and everything below works on observers x bodies of the LISTS, 64 pairs at a time.
   // (Every wave builds the same lists: identical bytes to identical places.)
   unsigned char* wList = M.wList; unsigned char* bList = M.bList;
-  const bool w_l = lane < A && aWant[lane] != 0;
-  const int st_l = bST[lane] & 0xff;
-  const bool b_l = lane < V && (st_l == ST_PENDING || st_l == ST_ACTIVE || st_l == ST_DYING || (lane < A && (bFL[lane] & PGD_F_REPORT) != 0u));
+  const int tl = (CAP < WAVE && lane >= CAP) ? 0 : lane;  // (lanes beyond the tables: V, A <= CAP, their verdicts are false anyway)
+  const bool w_l = lane < A && aWant[tl] != 0;
+  const int st_l = bST[tl] & 0xff;
+  const bool b_l = lane < V && (st_l == ST_PENDING || st_l == ST_ACTIVE || st_l == ST_DYING || (lane < A && (bFL[tl] & PGD_F_REPORT) != 0u));
   const unsigned long long wm = __ballot(w_l), bm = __ballot(b_l);
   const int nW = __popcll(wm), nB = __popcll(bm);
   if (w_l) wList[__popcll(wm & ((1ull << lane) - 1ull))] = (unsigned char)lane;
@@ -768,9 +772,8 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
   unsigned short* cand = reinterpret_cast<unsigned short*>(s_minb + (size_t)G * NL);
   float* rDist = reinterpret_cast<float*>(s_minb + (size_t)G * (NL + (V + 1) / 2));  // (the last two only with neighbour rows)
   float* rSpd = rDist + (size_t)G * V;
-  int* pAO = reinterpret_cast<int*>(pDist_all[wv]);  // (observer of the round << 8) | body, per lane of the pass
+  int* pAO = reinterpret_cast<int*>(pDist_all[wv]);  // first beam << 16 | (observer of the round << 8) | body, per lane of the pass
   int* pPref = pPref_all[wv];
-  int* pI0 = pI0_all[wv];
   for (int g0 = a_lo; g0 < a_hi; g0 += G) {
     const int g1 = min(g0 + G, a_hi);
     const int P = (g1 - g0) * nB;
@@ -861,8 +864,8 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
       const int T = __shfl(inc, WAVE - 1);
       const int R = (T + WAVE - 1) / WAVE;  // rounds of 64 incidences
       // lidar (distance_detector.py:65-94, cutils.pyx:60-142): incidence t belongs to the pair whose window covers it
-      auto cast = [&](const int ao, const int i0w, const int start, const int t) {
-        const int qa = ao >> 8, qo = ao & 0xff, ga = wList[g0 + qa];
+      auto cast = [&](const int ao, const int start, const int t) {
+        const int i0w = ao >> 16, qa = (ao >> 8) & 0xff, qo = ao & 0xff, ga = wList[g0 + qa];
         int i = i0w + (t - start);
         i -= i >= NL ? NL : 0;
         const float ax = bX[ga], ay = bY[ga], ahx = bUX[ga], ahy = bUY[ga];
@@ -883,8 +886,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
         if (cnt > 0) {
           const int k = __popcll(nz & ((1ull << lane) - 1ull));
           const int start = inc - cnt;
-          pAO[k] = (al << 8) | o;
-          pI0[k] = i0;
+          pAO[k] = (i0 << 16) | (al << 8) | o;
           pPref[k] = start;
           atomicOr(&pMask[start >> 6], 1ull << (start & 63));
         }
@@ -895,11 +897,10 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
           const int t = r * WAVE + lane;
           const int k = before + __popcll(m & ((2ull << lane) - 1ull)) - 1;
           before += __popcll(m);
-          if (t < T) cast(pAO[k], pI0[k], pPref[k], t);
+          if (t < T) cast(pAO[k], pPref[k], t);
         }
       } else {
-        pAO[lane] = (al << 8) | o;
-        pI0[lane] = i0;
+        pAO[lane] = (i0 << 16) | (al << 8) | o;
         pPref[lane + 1] = inc;
         if (lane == 0) pPref[0] = 0;
         row_sync<true>();
@@ -908,7 +909,7 @@ DEV void observe_env_body(const PgdDev& d, int e, float* __restrict__ obs, const
 #pragma unroll
           for (int sh = WAVE / 2; sh > 0; sh >>= 1)
             if (pPref[pl + sh] <= t) pl += sh;
-          cast(pAO[pl], pI0[pl], pPref[pl], t);
+          cast(pAO[pl], pPref[pl], t);
         }
       }
       row_sync<true>();

@@ -373,6 +373,40 @@ def test_run_time_kernel_is_refused_where_it_does_not_apply(descs, monkeypatch, 
     assert len([f for f in os.listdir(str(tmp_path)) if f.endswith(".hsaco")]) == 1
 
 
+def test_multi_agent_env_groups_step_like_one_batch():
+    """The 40-seat engine as two asynchronous env groups (pgd_set_groups / pgd_step_group; bench.py's row c5_40x72_two_groups): the step
+    kernel and the four-wave observation kernel of a group run on the group's stream over the group's envs only -- and leave, group
+    by group and in any order, exactly the bytes one launch over the whole batch leaves, through finishes and respawns."""
+    import torch
+    from pgdrive_amd.engine import Engine
+    d, mb, sb = util.make_marl_banks(num_agents=40, capacity=40, kind="roundabout")
+    n_envs = 64
+    cfg = util.marl_config(n_envs, sb, horizon=120)
+    one, two = Engine(cfg, mb, sb), Engine(cfg, mb, sb)
+    ids = np.arange(n_envs) % 8
+    one.reset(ids); two.reset(ids)
+    two.set_groups(2)
+    rng = np.random.default_rng(11)
+    n_done = n_new = 0
+    for t in range(260):
+        a = torch.from_numpy(util.marl_actions(rng, n_envs, sb.A)).to(one.device)
+        o, r, dn, fl = [x.clone() for x in one.step(a)]
+        one.sync()
+        for g in ((1, 0) if t % 2 else (0, 1)):
+            two.step_group(g, a)
+        for g in range(2):
+            two.group_sync(g)
+        assert torch.equal(two.flags, fl) and torch.equal(two.done, dn), "flags differ at step %d" % t
+        assert torch.equal(two.obs, o) and torch.equal(two.reward, r), "rows differ at step %d" % t
+        n_done += int(dn.sum()); n_new += int(((fl & _abi.F_NEW) != 0).sum())
+    assert n_done > 40 and n_new > 40
+    assert "40 agent seats" in one.describe_step() and "40 agent seats" in two.describe_step()
+    f1, i1, e1 = one.get_state()
+    f2, i2, e2 = two.get_state()
+    assert (i1 == i2).all() and (e1 == e2).all() and np.array_equal(f1, f2)
+    one.close(); two.close()
+
+
 @pytest.mark.parametrize("agents,seats", [(8, 12), (40, 40), (40, 44)])
 def test_default_multi_agent_kernel_matches_the_general_kernel(monkeypatch, agents, seats):
     """Multi-agent engines with the scalar fields of MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG get their own instantiation of k_step (those
