@@ -411,9 +411,14 @@ def parse_args(argv=None):
     ap.add_argument("--step-n", type=int, default=1,
                     help="open-loop variant: K steps of the action ring per pgd_step_n call (observation only for the last state of "
                          "each call); reported next to the metric, never as the metric (the metric is the closed loop)")
+    ap.add_argument("--groups-graph", dest="groups_graph", type=int, default=0,
+                    help="with --groups G: capture U steps of every group in a HIP graph on the group's stream (one graph per group) and "
+                         "replay the graphs every U steps -- G host calls per U steps instead of 2 launches x G per step")
     ap.add_argument("--topdown", action="store_true",
                     help="c3 with the top-down image observation (TopDownPGDriveEnv: 84 x 84 x 5, lidar off): pgd_step + "
                          "pgd_observe_topdown per step; reported next to the metric, never as the metric")
+    ap.add_argument("--topdown-u8", dest="topdown_u8", action="store_true",
+                    help="with --topdown: the image as bytes in [0, 255] (the reference's rgb_clip=False; pgd_observe_topdown_u8)")
     ap.add_argument("--jit", action="store_true",
                     help="build and load a step kernel with this run's configuration compiled in (pgdrive_amd/jit.py, Engine.specialise): for "
                          "configurations the library has no instantiation for; reported as rows, never as the metric")
@@ -454,11 +459,16 @@ ROWS = [
     ("c5_40x72", dict(workload="c5", agents=40, lasers=72, warmup=6000, steps=2000)),
     # the same 4096 envs as two asynchronous env groups of 2048 (pgd_set_groups / pgd_step_group, each on its own stream): the step
     # kernel of one group -- one wave per env, waiting for memory half of its life -- runs beside the observation kernel of the other
-    ("c5_40x72_two_groups", dict(workload="c5", agents=40, lasers=72, warmup=6000, steps=2000, groups=2)),
+    # (a HIP graph of 64 steps per group -- the whole cycle of the action ring, the same action sequence as the eager launches: as eager
+    # launches the row needs four launches from the host inside 43 us, which one GPU box of the round's measurements did not manage --
+    # 56 M there against 94 M; `--groups 2` without `--groups-graph` is the eager form)
+    ("c5_40x72_two_groups", dict(workload="c5", agents=40, lasers=72, warmup=6000, steps=2048, groups=2, groups_graph=64)),
     ("c3_32768", dict(envs=32768, warmup=1500, steps=512)),
     # the top-down image observation (TopDownPGDriveEnv: 84 x 84 x 5 floats per env and step instead of the 274-float row): pgd_step
     # without the lidar + pgd_observe_topdown; a write-bound kernel of its own
     ("c3_topdown", dict(topdown=True, lasers=0, warmup=600, steps=512)),
+    # the same image as bytes (the reference's rgb_clip=False: pgd_observe_topdown_u8): a quarter of the float image's writes
+    ("c3_topdown_u8", dict(topdown=True, topdown_u8=True, lasers=0, warmup=600, steps=512)),
     # a configuration the library has no instantiation for (72 beams, 12 traffic slots): the general kernel, and the same engine with a
     # step kernel built for it at run time (pgdrive_amd/jit.py; round 6)
     ("c3_72x12_general", dict(lasers=72, traffic=12)),
@@ -548,7 +558,7 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
     if args.groups > 1:
         eng.set_groups(args.groups)
     if args.topdown:
-        eng.enable_topdown()
+        eng.enable_topdown(uint8=bool(getattr(args, "topdown_u8", False)))
 
     expert = args.actions == "expert"
     if expert and (A != 1 or args.groups > 1 or args.step_n > 1 or args.engines > 1 or args.topdown or want_gather):
@@ -560,6 +570,12 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
             eng.step_lane_keep(k)  # launched the policy as a kernel of its own: 4.9 us of a 23.5 us iteration)
             return
         if args.groups > 1:
+            if state.get("group_graphs"):  # a single-stream graph of U steps per group, replayed on the group's stream
+                if k % args.groups_graph == 0:
+                    for g in range(args.groups):
+                        with torch.cuda.stream(eng.group_streams[g]):
+                            state["group_graphs"][g].replay()
+                return
             for g in range(args.groups):  # each group on its own internal stream: the launches overlap
                 eng.step_group(g, actions[(k + 5 * g) % CYC])
             return
@@ -660,6 +676,8 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
         }
         if aborted:
             out["aborted"] = aborted
+        if world == 1 and head is None and "replicas" in results:  # the host's share of a step: launches enqueued, not yet run
+            out["host_enqueue_us_per_step"] = results["replicas"]["host_enqueue_s"] / timed * 1e6
         if world > 1:
             out["value_mode"] = ("gather:" + head) if head is not None else "replicas"
             if "replicas" in results:
@@ -695,6 +713,7 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
         else:
             par = "env-sharded dp%d, no data-path collective" % world
         c2 = args.workload == "c3" and args.traffic == 0 and args.lasers == 0
+        TD_BYTES = 1 if getattr(args, "topdown_u8", False) else 4
         out["config"] = {
             "workload": (("C2: %d envs/GPU x 1 ego, no traffic, no lidar (state observation only), PGDrive-v0 maps seeds 1000-1099, "
                           "%s actions, auto-reset" % (N, args.actions)) if c2 else
@@ -716,13 +735,14 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
             **({"run_time_kernel_build_s": jit_s} if getattr(args, "jit", False) else {}),
             "envs_per_gpu": N * max(1, args.engines), "global_envs": N * world * max(1, args.engines), "obs_dim": D,
             "engines_per_gpu": max(1, args.engines), "env_groups": args.groups,
+            **({"env_groups_graph_steps": args.groups_graph} if args.groups > 1 and getattr(args, "groups_graph", 0) > 1 else {}),
             **({"open_loop": "pgd_step_n: %d steps of the action ring per call, one observation per call -- NOT the metric's closed "
                              "loop" % args.step_n} if args.step_n > 1 else {}),
-            **({"observation": "top-down image 84 x 84 x 5 float32 (pgd_observe_topdown), %.1f MB written per step" % (
-                N * 84 * 84 * 5 * 4 / 1e6),
+            **({"observation": "top-down image 84 x 84 x 5 %s, %.1f MB written per step" % (
+                "uint8 (pgd_observe_topdown_u8)" if TD_BYTES == 1 else "float32 (pgd_observe_topdown)", N * 84 * 84 * 5 * TD_BYTES / 1e6),
                 # the image kernel's share of a step = step time - k_step's event time; its roofline is the HBM write rate
                 "topdown_us": (elapsed / timed * 1e3 - (((results.get("replicas") or {}).get("prof") or {}).get("k_step_ms") or 0.0)) * 1e3,
-                "topdown_write_frac_of_hbm_peak": (N * 84 * 84 * 5 * 4) / max(1e-9, (elapsed / timed - (((results.get("replicas") or {}).get("prof") or {}).get("k_step_ms") or 0.0) * 1e-3)) / 8e12}
+                "topdown_write_frac_of_hbm_peak": (N * 84 * 84 * 5 * TD_BYTES) / max(1e-9, (elapsed / timed - (((results.get("replicas") or {}).get("prof") or {}).get("k_step_ms") or 0.0) * 1e-3)) / 8e12}
                if args.topdown else {}),
             "parallelism": par, "backend": (args.backend if world > 1 else "none"),
             "steady_state": "pre-roll %d steps, %d x %d timed steps (floors %d / %d%s)" % (
@@ -747,6 +767,22 @@ def measure(args, rank, world, local_rank, with_cpu_baseline=True):
             # launch duration is group time / PROF_STRIDE (two event packets around EVERY launch leave the command processor
             # idle between back-to-back kernels and slow the thing being measured)
             profiled = args.step_n == 1  # (the open-loop variant mixes launches with and without the observation)
+            if args.groups > 1 and getattr(args, "groups_graph", 0) > 1:
+                # the groups' steps from here on come out of graphs: U steps of group g with the actions of steps 0 .. U - 1 (+ 5 g), captured
+                # on the group's stream after the pre-roll (the launches inside a graph carry no event pairs: no k_step event time)
+                profiled = False
+                fence()
+                U = args.groups_graph
+                graphs = []
+                for g in range(args.groups):
+                    gk = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gk, stream=eng.group_streams[g]):
+                        for j in range(U):
+                            eng.step_group(g, actions[(j + 5 * g) % CYC])
+                    graphs.append(gk)
+                torch.cuda.synchronize(dev)
+                state["group_graphs"] = graphs
+                state["counter"] = (state["counter"] + U - 1) // U * U
             # short --exact runs (tests, sweeps of a few hundred steps): smaller groups, so that several of them complete
             stride = PROF_STRIDE if timed >= 8 * PROF_STRIDE else (16 if timed >= 16 else 1)
             if profiled:
@@ -1075,12 +1111,12 @@ def row_summary(name, line):
     c = line["config"]
     keep = ("driving_traffic_mean", "envs_with_traffic_frac", "ego_speed_kmh_mean", "episode_step_mean", "active_agents_mean",
             "present_agents_mean", "step_kernel", "obs_dim", "envs_per_gpu", "note", "observation", "topdown_us",
-            "topdown_write_frac_of_hbm_peak", "run_time_kernel_build_s")
+            "topdown_write_frac_of_hbm_peak", "run_time_kernel_build_s", "env_groups", "env_groups_graph_steps")
     iss = r.get("issue") or None
     return {
         "row": name, "workload": c["workload"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
         "windows": line.get("windows"), "window_spread": line.get("window_spread"),
-        "steps_timed": line["steps_timed"], "warmup_run": line["warmup_run"],
+        "steps_timed": line["steps_timed"], "warmup_run": line["warmup_run"], "host_enqueue_us_per_step": line.get("host_enqueue_us_per_step"),
         **{k: c[k] for k in keep if k in c},
         "roofline": {**{k: r.get(k) for k in ("bound", "kernel", "achieved", "frac", "frac_moved", "moved_source", "frac_active", "traffic",
                                               "traffic_source", "bytes_per_launch", "k_step_ms", "k_observe_ms", "source_sha",

@@ -417,6 +417,12 @@ typedef struct pgd_topdown_config {
 int pgd_topdown_channels(const pgd_topdown_config* cfg);
 int pgd_topdown_enable(pgd_handle h, const pgd_topdown_config* cfg);
 int pgd_observe_topdown(pgd_handle h, float* d_img /*[N,R,R,C]*/);
+/* The same image as bytes in [0, 255]: the reference's `rgb_clip=False` (pgdrive_env.py:133-141; top_down_obs_multi_channel.py:208-211,
+ * 253-256, 277-280 return the uint8 pygame values instead of float32 / 255).  byte = (int)(float value x 255): (line texels x 35 + route
+ * texels x 64) / 2 of the pixel's 2 x 2 cell on the road channel, 255 at a past position, 176 inside a vehicle box; RGB frame: lines 35,
+ * the ego (50, 200, 0), the others (100, 200, 255).  A quarter of the bytes of the float image (a write-bound kernel: DESIGN.md
+ * section 14).  `d_img` 16-byte aligned.  One call advances the pose history like pgd_observe_topdown: call ONE of the two per step. */
+int pgd_observe_topdown_u8(pgd_handle h, uint8_t* d_img /*[N,R,R,C]*/);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Per-step gather by direct peer writes (multi-GPU, one process per GPU).  The reference has no distributed layer (one env

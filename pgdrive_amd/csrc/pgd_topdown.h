@@ -139,12 +139,20 @@ __global__ __launch_bounds__(256) void k_topdown_reduce(const uint8_t* __restric
 #ifndef TD_OCC
 #define TD_OCC 1
 #endif
+#ifndef TD_OCC_U8
+#define TD_OCC_U8 6  /* the byte kernel: six waves per SIMD (80 registers, five of them spilled) against five without the bound: 77.4 -> 71.5 us; seven: 70.7 us with twenty spilled */
+#endif
 #ifndef TD_NK
 #define TD_NK 4
 #endif
 // RGB: the single RGB frame (TopDown::rgb) as a compile-time fact: the multi-channel kernel carries none of its branches
-template <bool RGB>
-__global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in, uint8_t* __restrict__ fill, float* __restrict__ img) {
+// U8: the image as bytes in [0, 255] -- the reference's `rgb_clip=False` (top_down_obs_multi_channel.py:208-211, 253-256, 277-280: the
+// uint8 pygame values themselves instead of float32 / 255): a quarter of the bytes of a kernel that is bound by its writes.  The byte
+// of a pixel is the float image's value x 255, truncated like numpy's astype(uint8): (lines x 35 + route texels x 64) / 2 on the
+// road channel, 255 on the past positions, 176 in a vehicle box; 35 / (50, 200, 0) / (100, 200, 255) in the RGB frame.
+template <bool RGB, bool U8 = false>
+__global__ __launch_bounds__(256, (U8 ? TD_OCC_U8 : TD_OCC)) void k_topdown(PgdDev d, TopDown t_in, uint8_t* __restrict__ fill, void* __restrict__ img_v) {
+  using PX = typename std::conditional<U8, uint8_t, float>::type;
   TopDown t = t_in;
   t.rgb = RGB ? 1 : 0;
   // dynamic LDS, sized by the engine's V instead of the 64-slot maximum (more blocks per CU: a block alternates between phases
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
   const pgd_map& m = *mv.m;
   const int tw = (int)((float)m.gx * m.cell / TD_TEXEL), th = (int)((float)m.gy * m.cell / TD_TEXEL);
   const uint8_t* tex = t.tex + t.tex_off[scen];
-  float* out = img + (size_t)e * R * R * C;
+  PX* out = reinterpret_cast<PX*>(img_v) + (size_t)e * R * R * C;
   // The image is almost empty outside channel 0: the code below writes the road channel and zeros, then the few pixels the
   // vehicles cover are set.  Loads and stores share one completion counter on this hardware and complete out of order with
   // respect to each other, so a wave that waits for a texel also waits for every store it has in flight: the texel classes
@@ -232,9 +240,11 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
   // that follows contains no global read at all -- each wave streams its batches of 64 consecutive pixels out of its own
   // staging area and never waits for memory or for the other three waves.
   const int wv = tid >> 6, lane = tid & 63, n_pix = R * R;
-  float* so = s_out + wv * 64 * 8;  // the wave's staging area: 64 pixels x C (<= 6) floats, then written out linearly
-  for (int k = lane; k < 64 * 8; k += 64) so[k] = 0.0f;  // channels 1.. stay zero: only ch 0 is rewritten per batch
-  const bool vec_ok = ((n_pix * C) & 3) == 0 && ((64 * C) & 3) == 0;  // every batch is then a whole number of float4
+  // the wave's staging area: 64 pixels x C (<= 6) floats -- or 256 pixels x C bytes: the same 2 KB --, then written out linearly
+  PX* so = reinterpret_cast<PX*>(s_out) + wv * (U8 ? 256 * 8 : 64 * 8);
+  for (int k = lane; k < 64 * 8; k += 64) s_out[wv * 64 * 8 + k] = 0.0f;  // channels 1.. stay zero: only ch 0 is rewritten per batch
+  // every batch is then a whole number of 16-byte stores but for the image's last one (bytes: every env's image starts on a 16-byte boundary)
+  const bool vec_ok = U8 ? ((n_pix * C) & 15) == 0 : (((n_pix * C) & 3) == 0 && ((64 * C) & 3) == 0);
   const float4 eg0 = s_pose[0];
   const float m_ox = m.ox, m_oy = m.oy;
   const int tbw = (tw + 7) >> 3;
@@ -258,12 +268,20 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
     {
       const int txn = (R + 7) >> 3, n_tiles = ((row1 - row0 + 7) >> 3) * txn;
       constexpr int NK = TD_NK;
-      for (int q0 = wv; q0 < n_tiles; q0 += 4 * NK) {
+      // (the tile walk in scalar registers: tile q = ty * txn + tx of the band, wave w takes q = w, w + 4, ...; the quotient and the
+      // remainder advance by additions -- as `q / txn` per lane and tile the division was a third of the loop's vector instructions,
+      // and the loop is bound by them: 45 of the byte image's 89 us)
+      const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+      int ty_s = 0, tx_s = wv_s;
+      while (tx_s >= txn) { tx_s -= txn; ++ty_s; }
+      for (int q0 = wv_s; q0 < n_tiles; q0 += 4 * NK) {
         int v[NK], pix[NK];
 #pragma unroll
         for (int u = 0; u < NK; ++u) {
           const int q = q0 + 4 * u;
-          const int ty = q / txn, tx = q - ty * txn;
+          const int ty = ty_s, tx = tx_s;
+          tx_s += 4;
+          while (tx_s >= txn) { tx_s -= txn; ++ty_s; }
           const int i = row0 + ty * 8 + (lane >> 3), j = tx * 8 + (lane & 7);
           const bool on = q < n_tiles && i < row1 && j < R;
           bool in;
@@ -283,11 +301,21 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
       for (int p0 = c0 + wv * 64; p0 < c1; p0 += 256) {
         const int n_here = min(64, c1 - p0);
         const int cls = lane < n_here ? (int)s_cls[p0 - c0 + lane] : 0;
-        if (t.rgb) { const float g = cls == 2 ? TD_RGB_LINE : 0.0f; so[lane * 3] = g; so[lane * 3 + 1] = g; so[lane * 3 + 2] = g; }
-        else so[lane * C] = (float)(cls & 15) * (0.25f * TD_LINE) + (float)(cls >> 4) * (0.25f * TD_NAVI);
+        if (U8) {
+          if (t.rgb) { const PX g = (PX)(cls == 2 ? 35 : 0); so[lane * 3] = g; so[lane * 3 + 1] = g; so[lane * 3 + 2] = g; }
+          else so[lane * C] = (PX)(((cls & 15) * 35 + (cls >> 4) * 64) >> 1);
+        } else
+        if (t.rgb) { const float g = cls == 2 ? TD_RGB_LINE : 0.0f; so[lane * 3] = (PX)g; so[lane * 3 + 1] = (PX)g; so[lane * 3 + 2] = (PX)g; }
+        else so[lane * C] = (PX)((float)(cls & 15) * (0.25f * TD_LINE) + (float)(cls >> 4) * (0.25f * TD_NAVI));
         row_sync<true>();  // the wave's own LDS traffic only
         const int nf = n_here * C;
-        float* dst = out + (size_t)p0 * C;
+        PX* dst = out + (size_t)p0 * C;
+        if (U8) {  // 64 x C bytes = at most 32 sixteen-byte pieces: one predicated store, the tail of the image's last batch byte by byte
+          const int n16 = VEC ? nf >> 4 : 0;
+          if (lane < n16) OBS_ST(reinterpret_cast<obs_f4*>(dst) + lane, reinterpret_cast<const obs_f4*>(so)[lane]);
+  #pragma unroll 1
+        for (int k = (n16 << 4) + lane; k < nf; k += 64) dst[k] = so[k];
+        } else
         if (VEC) {  // 64 x C floats = at most 128 float4 (C <= 8): two predicated stores, no loop
           const int n4 = nf >> 2;
           if (lane < n4) OBS_ST(reinterpret_cast<obs_f4*>(dst) + lane, reinterpret_cast<const obs_f4*>(so)[lane]);
@@ -298,6 +326,29 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
         row_sync<true>();
       }
     };
+    // bytes: 64 pixels are 320 bytes, twenty lanes' worth of a store -- the rounds above were what the byte image's stream-out cost
+    // (27 of 89 us).  A wave takes 256 consecutive pixels per round instead: four classes per lane into the staging area, then up to 96
+    // sixteen-byte pieces in two stores per lane; a quarter of the rounds and of their LDS round trips.
+    if (U8 && vec_ok && (rows_c >= R || ((rows_c * R * C) & 15) == 0)) {  // (every band starts on a 16-byte boundary)
+      for (int p0 = c0 + wv * 256; p0 < c1; p0 += 1024) {
+        const int n_here = min(256, c1 - p0);
+#pragma unroll 1
+        for (int u = 0; u < 4; ++u) {
+          const int k = u * 64 + lane;
+          const int cls = k < n_here ? (int)s_cls[p0 - c0 + k] : 0;
+          if (RGB) { const PX g = (PX)(cls == 2 ? 35 : 0); so[k * 3] = g; so[k * 3 + 1] = g; so[k * 3 + 2] = g; }
+          else so[k * C] = (PX)(((cls & 15) * 35 + (cls >> 4) * 64) >> 1);
+        }
+        row_sync<true>();
+        const int nf = n_here * C, n16 = nf >> 4;
+        PX* dst = out + (size_t)p0 * C;
+        if (lane < n16) OBS_ST(reinterpret_cast<obs_f4*>(dst) + lane, reinterpret_cast<const obs_f4*>(so)[lane]);
+        if (lane + 64 < n16) OBS_ST(reinterpret_cast<obs_f4*>(dst) + lane + 64, reinterpret_cast<const obs_f4*>(so)[lane + 64]);
+#pragma unroll 1
+        for (int k = (n16 << 4) + lane; k < nf; k += 64) dst[k] = so[k];
+        row_sync<true>();
+      }
+    } else
     if (vec_ok) store_loop(std::true_type{});
     else store_loop(std::false_type{});
     __syncthreads();
@@ -308,9 +359,14 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
   // pixel of slack), 8 x 8 at a time, with the exact point-in-box test.
   // (RGB frame: the ego first -- VehicleGraphics.GREEN, its heading snapped below 2 degrees like everybody's while the window
   // turns with the true one -- then the others over it, VehicleGraphics.BLUE; obs/top_down_obs.py:150-166)
-  auto paint = [&](float* px, int f) {
-    if (!t.rgb) { px[2 + f] = TD_VEH; return; }
-    px[0] = f < 0 ? 50.0f / 255.0f : 100.0f / 255.0f; px[1] = 200.0f / 255.0f; px[2] = f < 0 ? 0.0f : 1.0f;
+  auto paint = [&](PX* px, int f) {
+    if (U8) {
+      if (!t.rgb) { px[2 + f] = (PX)176; return; }  // (int)(TD_VEH * 255) = (int)176.37
+      px[0] = (PX)(f < 0 ? 50 : 100); px[1] = (PX)200; px[2] = (PX)(f < 0 ? 0 : 255);
+      return;
+    }
+    if (!t.rgb) { px[2 + f] = (PX)TD_VEH; return; }
+    px[0] = (PX)(f < 0 ? 50.0f / 255.0f : 100.0f / 255.0f); px[1] = (PX)(200.0f / 255.0f); px[2] = (PX)(f < 0 ? 0.0f : 1.0f);
   };
   if (t.rgb) {
     if (wv == 0 && !(eg0.z == 0.0f && eg0.w == 0.0f)) {
@@ -359,7 +415,7 @@ __global__ __launch_bounds__(256, TD_OCC) void k_topdown(PgdDev d, TopDown t_in,
       float u = (dy * ehx - dx * ehy) * sc + (float)R * 0.5f, vv = -(dx * ehx + dy * ehy) * sc + (float)R * 0.5f;
       u = clipf(u, -(float)R, (float)R); vv = clipf(vv, -(float)R, (float)R);
       const int jj = (int)floorf(u), ii = (int)floorf(vv);
-      if (ii >= 0 && jj >= 0 && ii < R && jj < R) out[((size_t)ii * R + jj) * C + 1] = 1.0f;
+      if (ii >= 0 && jj >= 0 && ii < R && jj < R) out[((size_t)ii * R + jj) * C + 1] = U8 ? (PX)255 : (PX)1;
     }
   }
 }
@@ -462,17 +518,21 @@ int pgd_topdown_enable(pgd_handle h, const pgd_topdown_config* c) {
   return PGD_OK;
 }
 
-int pgd_observe_topdown(pgd_handle h, float* d_img) {
+static int observe_topdown_impl(pgd_handle h, void* d_img, bool u8) {
   if (!h || !d_img) return PGD_ERR_ARG;
   if (!h->topdown || !h->have_maps || !h->have_scen) return PGD_ERR_STATE;
+  if (u8 && (reinterpret_cast<uintptr_t>(d_img) & 15u)) return PGD_ERR_ARG;  // (the byte image is written sixteen bytes at a time)
   HIPCHK(hipSetDevice(h->device));
   if (h->topdown->tex_dirty) { int rc = topdown_build_rasters(h); if (rc) return rc; }
   const size_t dyn = sizeof(float4) * ((size_t)h->topdown->t.n_frames + 4) * h->d.V + sizeof(float2) * 4 * (size_t)h->d.V;
-  if (h->topdown->t.rgb) hipLaunchKernelGGL(k_topdown<true>, dim3(h->d.N), dim3(256), dyn, h->stream, h->d, h->topdown->t, h->d.bev_fill, d_img);
-  else hipLaunchKernelGGL(k_topdown<false>, dim3(h->d.N), dim3(256), dyn, h->stream, h->d, h->topdown->t, h->d.bev_fill, d_img);
+  void (*k)(PgdDev, TopDown, uint8_t*, void*) = h->topdown->t.rgb ? (u8 ? k_topdown<true, true> : k_topdown<true, false>)
+                                                                 : (u8 ? k_topdown<false, true> : k_topdown<false, false>);
+  hipLaunchKernelGGL(k, dim3(h->d.N), dim3(256), dyn, h->stream, h->d, h->topdown->t, h->d.bev_fill, d_img);
   HIPCHK(hipGetLastError());
   return PGD_OK;
 }
+int pgd_observe_topdown(pgd_handle h, float* d_img) { return observe_topdown_impl(h, d_img, false); }
+int pgd_observe_topdown_u8(pgd_handle h, uint8_t* d_img) { return observe_topdown_impl(h, d_img, true); }
 
 }  // extern "C"
 

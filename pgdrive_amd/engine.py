@@ -39,6 +39,7 @@ _SIGS = {
     "pgd_topdown_channels": (C.c_int, [C.POINTER(_abi.TopDownConfig)]),
     "pgd_topdown_enable": (C.c_int, [C.c_void_p, C.POINTER(_abi.TopDownConfig)]),
     "pgd_observe_topdown": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pgd_observe_topdown_u8": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pgd_set_groups": (C.c_int, [C.c_void_p, C.c_int]),
     "pgd_step_group": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5),
     "pgd_group_stream": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
@@ -339,21 +340,27 @@ class Engine:
         return self.obs, self.reward, self.done, self.flags
 
     # -- top-down observation (obs/top_down_obs_multi_channel.py) -----------------------------------------------------------
-    def enable_topdown(self, td_cfg=None):
-        """Switch on the bird's-eye multi-channel observation; `td_cfg` = _abi.make_topdown_config(...)."""
+    def enable_topdown(self, td_cfg=None, uint8=False):
+        """Switch on the bird's-eye observation; `td_cfg` = _abi.make_topdown_config(...).  `uint8`: the engine's own image buffer holds
+        bytes in [0, 255] (the reference's rgb_clip=False) instead of float32 in [0, 1]."""
         self.td_cfg = td_cfg or _abi.make_topdown_config()
         _chk(self.L.pgd_topdown_enable(self.h, C.byref(self.td_cfg)), "pgd_topdown_enable")
         R, Cn = self.td_cfg.resolution, self.L.pgd_topdown_channels(C.byref(self.td_cfg))
-        self.img = self.torch.zeros((self.N, R, R, Cn), dtype=self.torch.float32, device=self.device)
+        self.img = self.torch.zeros((self.N, R, R, Cn), dtype=self.torch.uint8 if uint8 else self.torch.float32, device=self.device)
 
     def observe_topdown(self, out=None):
-        """Image [N, R, R, C] of the present state; call once after every step / reset (it advances the frame history)."""
+        """Image [N, R, R, C] of the present state -- float32 in [0, 1], or bytes in [0, 255] when the buffer (`out`, else the engine's
+        own) is a uint8 tensor; call once after every step / reset (it advances the frame history)."""
         img = self.img if out is None else out
+        assert img.is_cuda and img.is_contiguous() and img.dtype in (self.torch.float32, self.torch.uint8) and img.numel() == self.img.numel()
         cur = self.torch.cuda.current_stream(self.device).cuda_stream
         if cur != self._bound_stream:
             _chk(self.L.pgd_set_stream(self.h, C.c_void_p(cur)), "pgd_set_stream")
             self._bound_stream = cur
-        _chk(self.L.pgd_observe_topdown(self.h, C.c_void_p(img.data_ptr())), "pgd_observe_topdown")
+        if img.dtype == self.torch.uint8:
+            _chk(self.L.pgd_observe_topdown_u8(self.h, C.c_void_p(img.data_ptr())), "pgd_observe_topdown_u8")
+        else:
+            _chk(self.L.pgd_observe_topdown(self.h, C.c_void_p(img.data_ptr())), "pgd_observe_topdown")
         return img
 
     # -- asynchronous env groups ----------------------------------------------------------------------------------------

@@ -248,17 +248,17 @@ class PGDriveVecEnv:
         self._jit_thread = self.engine.specialise(wait=False) if c["jit_step_kernel"] else None  # (join() it to wait for the module)
         self.topdown = bool(c["use_topdown"])
         if self.topdown:
-            if not c["rgb_clip"]:
-                raise NotImplementedError("use_topdown with rgb_clip=False (uint8 images) is not built: images are float32 in [0, 1]")
+            # rgb_clip=False (pgdrive_env.py:133-141): the images as uint8 in [0, 255] (pgd_observe_topdown_u8) instead of float32 / 255
             # (the single-frame observation is built without a `resolution` argument upstream: TopDownObservation.RESOLUTION = 200,
             # top_down_env.py:23-26, top_down_obs.py:27)
             self.engine.enable_topdown(_abi.make_topdown_config(200 if c["topdown_single_frame"] else c["resolution_size"], c["distance"],
                                                                 c["frame_stack"], c["post_stack"], c["frame_skip"],
-                                                                mode=1 if c["topdown_single_frame"] else 0))
+                                                                mode=1 if c["topdown_single_frame"] else 0), uint8=not c["rgb_clip"])
         # spaces (base_vehicle.py:720-727, state_obs.py:124-130)
         self.single_observation_space = Box(-0.0, 1.0, (self.obs_dim, ), np.float32)
         if self.topdown:
-            self.single_observation_space = Box(-0.0, 1.0, tuple(self.engine.img.shape[1:]), np.float32)
+            self.single_observation_space = Box(-0.0, 1.0, tuple(self.engine.img.shape[1:]), np.float32) if c["rgb_clip"] else \
+                Box(0, 255, tuple(self.engine.img.shape[1:]), np.uint8)  # (top_down_obs_multi_channel.py:277-280)
         self.single_action_space = MultiDiscrete([c["discrete_steering_dim"], c["discrete_throttle_dim"]]) \
             if c["discrete_action"] else Box(-1.0, 1.0, (2, ), np.float32)
         self.observation_space = self.single_observation_space

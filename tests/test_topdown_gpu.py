@@ -266,3 +266,81 @@ def test_topdown_rgb_single_frame(descs):
         assert env.observation_space.shape == (84, 84, 5) and env.reset().shape == (84, 84, 5)
     finally:
         env.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_topdown_uint8_images(descs, mode):
+    """rgb_clip=False (pgdrive_env.py:133-141; top_down_obs_multi_channel.py:208-211, 277-280): the image as the uint8 pygame values
+    instead of float32 / 255 -- pgd_observe_topdown_u8.  Two engines through the same 60 steps with auto-resets, one with float images,
+    one with bytes: every byte is the float value x 255 truncated (numpy's astype(uint8)), every pixel of every image; the values
+    are the few the definition allows; the image of a reset env is refilled like the float one."""
+    import torch
+    from pgdrive_amd.engine import Engine
+    n = 40
+    mb, sb = util.make_banks(descs, n_maps=8)
+    cfg = _abi.make_config(n, num_agents=1, num_traffic=16, num_lasers=0, auto_reset=1, seed=3)
+    td = _abi.make_topdown_config(resolution=200, distance=30.0, mode=1) if mode else _abi.make_topdown_config()
+    a, b = Engine(cfg, mb, sb), Engine(cfg, mb, sb)
+    a.enable_topdown(td)
+    b.enable_topdown(td, uint8=True)
+    assert b.img.dtype == torch.uint8 and b.img.shape == a.img.shape
+    ids = np.arange(n) % 8
+    a.reset(ids); b.reset(ids)
+    rng = np.random.default_rng(2)
+    f, i, ei = a.get_state()
+    SF, SI = _abi.SF, _abi.SI
+    for k in range(1, 5):  # some waiting traffic moved into the window
+        th = f[SF["THETA"], :, 0]
+        fw, lt = rng.uniform(6, 26, n), rng.uniform(-9, 9, n)
+        f[SF["X"], :, k] = f[SF["X"], :, 0] + fw * np.cos(th) - lt * np.sin(th)
+        f[SF["Y"], :, k] = f[SF["Y"], :, 0] + fw * np.sin(th) + lt * np.cos(th)
+        f[SF["THETA"], :, k] = th + rng.uniform(-3.0, 3.0, n) * (k % 2)
+        f[SF["HX"], :, k] = f[SF["HY"], :, k] = 0.0
+        i[SI["STATUS"], :, k] = _abi.ST_PENDING
+    f32 = util.round_state_f32(f)
+    a.set_state(f32, i, ei); b.set_state(f32, i, ei)
+    n_done = 0
+    seen = set()
+    for t in range(60):
+        if t:
+            act = util.driving_actions(rng, n)
+            act[::3, 0, 1] = 1.0
+            at = torch.from_numpy(act).to(a.device)
+            _, _, dn, _ = a.step(at)
+            b.step(at)
+            n_done += int(dn.sum())
+        f = a.observe_topdown().cpu().numpy()
+        u = b.observe_topdown().cpu().numpy()
+        assert u.dtype == np.uint8
+        want = np.floor(f.astype(np.float64) * 255.0 + 1e-3).astype(np.uint8)
+        assert np.array_equal(u, want), "step %d: %d bytes differ" % (t, int((u != want).sum()))
+        seen |= set(np.unique(u).tolist())
+    assert n_done > 5
+    if mode:
+        assert seen <= {0, 35, 50, 100, 200, 255} and {35, 50, 200} <= seen
+    else:  # road channel: (lines x 35 + route texels x 64) / 2 of a 2 x 2 cell, truncated; past positions 255; vehicle boxes 176
+        road = {(nl * 35 + nn * 64) >> 1 for nl in range(5) for nn in range(5) if nl + nn <= 4}
+        assert seen <= road | {255, 176} and {255, 176, 128} <= seen and len(seen & road) >= 5
+    # a caller's own byte buffer, and the float image into a float buffer of the caller's, from the same handle
+    own = torch.zeros_like(b.img)
+    b.step(at)
+    a.step(at)
+    assert torch.equal(b.observe_topdown(out=own), own) and own.any()
+    f = a.observe_topdown().cpu().numpy()
+    assert np.array_equal(own.cpu().numpy(), np.floor(f.astype(np.float64) * 255.0 + 1e-3).astype(np.uint8))
+    a.close(); b.close()
+
+
+def test_topdown_env_uint8():
+    """TopDownPGDriveEnv(dict(rgb_clip=False)): Box(0, 255, uint8) observations (top_down_obs_multi_channel.py:277-280)."""
+    from pgdrive_amd.env import TopDownPGDriveEnv
+    env = TopDownPGDriveEnv(dict(start_seed=1000, environment_num=4, rgb_clip=False))
+    try:
+        assert env.observation_space.shape == (84, 84, 5) and env.observation_space.dtype == np.uint8
+        o = env.reset()
+        assert o.shape == (84, 84, 5) and o.dtype == np.uint8 and o.max() == 255
+        for t in range(12):
+            o, r, d, info = env.step([0.0, 1.0])
+            assert o.dtype == np.uint8 and env.observation_space.contains(o) and o[..., 0].max() > 0 and o[..., 1].max() == 255
+    finally:
+        env.close()

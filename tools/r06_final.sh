@@ -19,6 +19,8 @@ bash tools/row_pass.sh $TAG/c5_40x72 c5 4096 uniform trigger 40 72
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/td -- python $R/bench.py --no-rows --no-cpu-baseline --topdown --exact --warmup 300 --steps 400 --windows 1 > $O/topdown_bench_under_rocprof.json 2> /dev/null < /dev/null
 for f in $(find $O/td -name "*kernel_stats.csv"); do cp $f $O/topdown_kernel_stats.csv; head -4 $f; done; rm -rf $O/td
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/td8 -- python $R/bench.py --no-rows --no-cpu-baseline --topdown --topdown-u8 --exact --warmup 300 --steps 400 --windows 1 > $O/topdown_u8_bench_under_rocprof.json 2> /dev/null < /dev/null
+for f in $(find $O/td8 -name "*kernel_stats.csv"); do cp $f $O/topdown_u8_kernel_stats.csv; head -3 $f; done; rm -rf $O/td8
 ( cd $R && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pol -- python tools/mlp_bench.py 4096 ) > $O/mlp_bench_under_rocprof.txt 2> /dev/null < /dev/null
 for f in $(find $O/pol -name "*kernel_stats.csv"); do cp $f $O/policy_kernel_stats.csv; head -4 $f; done; rm -rf $O/pol
 cd $R
