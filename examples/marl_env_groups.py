@@ -9,6 +9,11 @@ step kernel of one half runs beside the observation kernel of the other (bench.p
 94 M env-steps/s at 4096 envs).  Envs do not interact, so the halves leave exactly the bytes the single batch leaves
 (tests/test_parity_gpu.py::test_multi_agent_env_groups_step_like_one_batch); a learner that consumes group A's rows while group
 B steps gets the overlap for free.  Work that reads a group's rows belongs on `engine.group_streams[g]`.
+
+As eager launches the two halves need four kernel launches from the host inside ~43 us per iteration; a slow or busy host turns the
+gain into a loss (one box of the round's measurements: 56 M with two groups against 92 M with one).  A rollout that keeps its
+policy on the GPU captures `policy -> step_group` of each group in a HIP graph on the group's stream instead
+(examples/fused_policy_rollout.py; bench.py --groups 2 --groups-graph 64): one host call per group and replay.
 """
 import argparse
 import os
