@@ -52,6 +52,7 @@ struct TopDown {
   // road-network raster, one per scenario (the route is the scenario's): texel = TD_TEXEL m, value 0 / 1 (route lane) / 2 (line)
   const uint8_t* tex;        // all rasters back to back
   const long long* tex_off;  // [n_scen] offset of the scenario's raster
+  const uint8_t* occ;        // per 64-byte line of `tex` (an 8 x 8 tile of texels / cells): 1 = something is drawn in it (null: not built)
   float line_r;
   int rgb;  // pgd_topdown_config.mode == 1: one RGB frame (C = 3): lines grey, the ego green, the others blue; no route, no history
 };
@@ -136,6 +137,18 @@ __global__ __launch_bounds__(256) void k_topdown_reduce(const uint8_t* __restric
   }
 }
 
+// One byte per 64-byte line of the rasters (a tile of 8 x 8 texels, or of 8 x 8 half-resolution cells): is anything drawn in it.  Two
+// thirds of the 8 x 8 pixel tiles of a window see no road at all; k_topdown asks these bytes before it computes 64 raster addresses.
+__global__ __launch_bounds__(256) void k_topdown_occ(const uint8_t* __restrict__ tex, uint8_t* __restrict__ occ, long long n_lines) {
+  for (long long l = (long long)blockIdx.x * 256 + threadIdx.x; l < n_lines; l += (long long)gridDim.x * 256) {
+    const uint4* q = reinterpret_cast<const uint4*>(tex + l * 64);
+    unsigned any = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint4 v = q[k]; any |= v.x | v.y | v.z | v.w; }
+    occ[l] = any ? 1 : 0;
+  }
+}
+
 #ifndef TD_OCC
 #define TD_OCC 1
 #endif
@@ -164,7 +177,9 @@ __global__ __launch_bounds__(256, (U8 ? TD_OCC_U8 : TD_OCC)) void k_topdown(PgdD
   __shared__ int s_nhist;
   // per stacked frame: the vehicles that can show up in the window, already in the ego frame of that time
   __shared__ int s_nvis[4];
-  __shared__ uint8_t s_cls[TD_CHUNK];  // texel classes of a chunk of pixels: gathered first, then the chunk is written out
+  __shared__ __attribute__((aligned(16))) uint8_t s_cls[TD_CHUNK];  // texel classes of a chunk of pixels: gathered first, then the chunk is written out
+  __shared__ unsigned short s_tl[256];  // the band's 8 x 8 pixel tiles that can see something of the raster: row of tiles << 8 | column
+  __shared__ int s_ntl;
   __shared__ float s_out[256 * 8];   // one batch of 256 pixels x C channels, written out linearly (coalesced)
   const int e = blockIdx.x, tid = threadIdx.x, V = d.V;
   float4* s_pose = s_dyn4;                                  // [f * V + s]
@@ -264,26 +279,58 @@ __global__ __launch_bounds__(256, (U8 ? TD_OCC_U8 : TD_OCC)) void k_topdown(PgdD
   for (int row0 = 0; row0 < R; row0 += rows_c) {
     const int row1 = min(row0 + rows_c, R);
     const int c0 = row0 * R, c1 = row1 * R;
-    // ---- gather: the waves take the 8 x 8 pixel tiles of the band in turn, lane = pixel of the tile, 4 tiles in flight (80 VGPRs: 6 blocks per CU; 8 in flight cost a block)
+    // ---- which tiles: an 8 x 8 pixel tile of the window is gathered only if the bounding box of its pixel centres (the window map is
+    // affine: the box of the four corner centres, a texel of slack on every side) touches a raster line in which something is drawn
+    // (TopDown::occ); the classes of the other tiles are zero.  One tile per thread.
+    const int txn = (R + 7) >> 3, n_tiles = ((row1 - row0 + 7) >> 3) * txn;
     {
-      const int txn = (R + 7) >> 3, n_tiles = ((row1 - row0 + 7) >> 3) * txn;
+      const uint8_t* occ = t.occ ? t.occ + (t.tex_off[scen] >> 6) : nullptr;
+      const int lw = RGB ? tbw : tbw2, lh = RGB ? ((th + 7) >> 3) : ((((th + 1) >> 1) + 7) >> 3);  // raster lines per row / rows of lines
+      if (tid == 0) s_ntl = 0;
+      for (int k = tid; k < ((c1 - c0 + 3) >> 2); k += 256) reinterpret_cast<uint32_t*>(s_cls)[k] = 0u;
+      __syncthreads();
+      for (int q = tid; q < n_tiles; q += 256) {
+        const int ty = q / txn, tx = q - ty * txn;
+        bool take = true;
+        if (occ) {
+          const int i0 = row0 + ty * 8, i1 = min(i0 + 7, row1 - 1), j0 = tx * 8, j1 = min(j0 + 7, R - 1);
+          float u0 = 3.0e38f, u1 = -3.0e38f, v0 = 3.0e38f, v1 = -3.0e38f;
+#pragma unroll
+          for (int cnr = 0; cnr < 4; ++cnr) {
+            const int pi = (cnr & 1) ? i1 : i0, pj = (cnr & 2) ? j1 : j0;
+            const float fw = ((float)R * 0.5f - (float)pi - 0.5f) * inv_s, rg = ((float)pj + 0.5f - (float)R * 0.5f) * inv_s;
+            const float wx = eg0.x + fw * eg0.z - rg * eg0.w, wy = eg0.y + fw * eg0.w + rg * eg0.z;
+            const float u = (wx - m_ox) * (1.0f / TD_TEXEL), v = (wy - m_oy) * (1.0f / TD_TEXEL);
+            u0 = fminf(u0, u); u1 = fmaxf(u1, u); v0 = fminf(v0, v); v1 = fmaxf(v1, v);
+          }
+          const int sh = RGB ? 3 : 4;  // texel index -> line index (multi-channel: cells of two texels, lines of eight cells)
+          const int lx0 = max((int)floorf(u0 - 1.0f) >> sh, 0), lx1 = min((int)floorf(u1 + 1.0f) >> sh, lw - 1);
+          const int ly0 = max((int)floorf(v0 - 1.0f) >> sh, 0), ly1 = min((int)floorf(v1 + 1.0f) >> sh, lh - 1);
+          int any = 0;
+          for (int ly = ly0; ly <= ly1; ++ly)
+            for (int lx = lx0; lx <= lx1; ++lx) any |= (int)occ[(long long)ly * lw + lx];
+          take = any != 0;
+        }
+        if (take) s_tl[atomicAdd(&s_ntl, 1)] = (unsigned short)((ty << 8) | tx);
+      }
+      __syncthreads();
+    }
+    // ---- gather: the waves take the listed tiles in turn, lane = pixel of the tile, 4 tiles in flight (80 VGPRs: 6 blocks per CU; 8 in flight cost a block)
+    {
+      const int n_tl = s_ntl;
       constexpr int NK = TD_NK;
-      // (the tile walk in scalar registers: tile q = ty * txn + tx of the band, wave w takes q = w, w + 4, ...; the quotient and the
-      // remainder advance by additions -- as `q / txn` per lane and tile the division was a third of the loop's vector instructions,
-      // and the loop is bound by them: 45 of the byte image's 89 us)
+      // (the tile's row and column come out of the list as scalars: as `q / txn` per lane and tile the division was a third of the
+      // loop's vector instructions, and the loop is bound by them: 45 of the byte image's 89 us)
       const int wv_s = __builtin_amdgcn_readfirstlane(wv);
-      int ty_s = 0, tx_s = wv_s;
-      while (tx_s >= txn) { tx_s -= txn; ++ty_s; }
-      for (int q0 = wv_s; q0 < n_tiles; q0 += 4 * NK) {
+      for (int n0 = wv_s; n0 < n_tl; n0 += 4 * NK) {
         int v[NK], pix[NK];
 #pragma unroll
         for (int u = 0; u < NK; ++u) {
-          const int q = q0 + 4 * u;
-          const int ty = ty_s, tx = tx_s;
-          tx_s += 4;
-          while (tx_s >= txn) { tx_s -= txn; ++ty_s; }
+          const int n = n0 + 4 * u;
+          const int code = __builtin_amdgcn_readfirstlane((int)s_tl[min(n, n_tl - 1)]);
+          const int ty = code >> 8, tx = code & 255;
           const int i = row0 + ty * 8 + (lane >> 3), j = tx * 8 + (lane & 7);
-          const bool on = q < n_tiles && i < row1 && j < R;
+          const bool on = n < n_tl && i < row1 && j < R;
           bool in;
           v[u] = tex[texel_addr(i, j, on, in)];  // RGB: the class; multi-channel: low nibble = line texels of the cell, high nibble = route-lane texels
           if (!in) v[u] = 0;
@@ -424,6 +471,7 @@ struct pgd_topdown_state {
   TopDown t;
   uint8_t* tex;          // device rasters
   long long* tex_off;    // device offsets
+  uint8_t* occ;          // device: one byte per 64-byte line of `tex`
   bool tex_dirty;        // maps / scenarios were uploaded since the rasters were built
 };
 
@@ -447,6 +495,7 @@ static int topdown_build_rasters(pgd_engine* h) {
   }
   if (s->tex) { HIPCHK(hipFree(s->tex)); s->tex = nullptr; }
   if (s->tex_off) { HIPCHK(hipFree(s->tex_off)); s->tex_off = nullptr; }
+  if (s->occ) { HIPCHK(hipFree(s->occ)); s->occ = nullptr; }
   {  // one raster per scenario, 16 bytes per square metre of map extent (1-2 MB per PGDrive-v0 map; a quarter of that pre-averaged):
      // a bank of a thousand scenarios is gigabytes -- refuse with a message instead of failing inside hipMalloc
     size_t free_b = 0, total_b = 0;
@@ -477,6 +526,13 @@ static int topdown_build_rasters(pgd_engine* h) {
     }
   }
   if (fine_tmp) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipFree(fine_tmp)); }
+  s->t.occ = nullptr;
+  if (total > 0 && !getenv("PGD_TD_NO_OCC")) {  // (PGD_TD_NO_OCC=1, tests and A/B: every tile of a window is gathered)
+    const long long n_lines = total / 64;  // (every raster is a whole number of 64-byte lines)
+    HIPCHK(hipMalloc(&s->occ, (size_t)n_lines));
+    hipLaunchKernelGGL(k_topdown_occ, dim3((unsigned)std::min<long long>((n_lines + 255) / 256, 8192)), dim3(256), 0, h->stream, s->tex, s->occ, n_lines);
+    s->t.occ = s->occ;
+  }
   HIPCHK(hipGetLastError());
   s->t.tex = s->tex;
   s->t.tex_off = s->tex_off;
@@ -503,7 +559,7 @@ int pgd_topdown_enable(pgd_handle h, const pgd_topdown_config* c) {
   pgd_topdown_state* s = h->topdown;
   if (s->t.pos) { (void)hipFree(s->t.pos); (void)hipFree(s->t.pose); (void)hipFree(s->t.n_hist); }
   s->t = TopDown{c->resolution, rgb ? 3 : 2 + c->frame_stack, rgb ? 1 : c->frame_stack, rgb ? 1 : c->post_stack, rgb ? 1 : c->frame_skip,
-                 n_pos, n_frames, c->distance, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, rgb ? 1 : 0};
+                 n_pos, n_frames, c->distance, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, rgb ? 1 : 0};
   s->t.line_r = fmaxf(0.25f, 0.5f * (2.0f * c->distance) / (float)c->resolution);
   s->tex_dirty = true;
   const size_t N = (size_t)h->d.N;
@@ -543,6 +599,7 @@ static void topdown_free(pgd_engine* h) {
   if (h->topdown->t.pos) { (void)hipFree(h->topdown->t.pos); (void)hipFree(h->topdown->t.pose); (void)hipFree(h->topdown->t.n_hist); }
   if (h->topdown->tex) (void)hipFree(h->topdown->tex);
   if (h->topdown->tex_off) (void)hipFree(h->topdown->tex_off);
+  if (h->topdown->occ) (void)hipFree(h->topdown->occ);
   if (h->d.bev_fill) (void)hipFree(h->d.bev_fill);
   free(h->topdown);
   h->topdown = nullptr;

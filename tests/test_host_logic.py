@@ -325,3 +325,22 @@ def test_run_time_kernel_builds_without_a_gpu(tmp_path, monkeypatch):
     assert jit.build_module(cfg, geom, False, True) == path and time.time() - t0 < 0.5  # (cached)
     cfg2 = _abi.make_config(512, num_traffic=12, num_lasers=96, num_others=2, discrete_action=True)
     assert jit.header_text(cfg2, dict(geom, D=_abi.obs_dim(cfg2)), False, True) != text
+
+
+def test_bench_rows_are_well_formed():
+    """bench.py's ROWS: names unique, every override names an option parse_args knows (a typo would silently time the default
+    workload), and a row that replays per-group HIP graphs times a whole number of replays per window."""
+    import bench
+    base = vars(bench.parse_args([]))
+    names = [n for n, _ in bench.ROWS]
+    assert len(names) == len(set(names)) and "c5_40x72" in names and "c5_40x72_two_groups" in names and "c3_topdown_u8" in names
+    for name, over in bench.ROWS:
+        for k in over:
+            assert k in base, "row %s overrides %r, which is not an option of bench.py" % (name, k)
+        gg = over.get("groups_graph", 0)
+        if gg:
+            assert over.get("groups", 1) > 1 and over["steps"] % gg == 0, name
+        if over.get("topdown_u8"):
+            assert over.get("topdown")
+    a = bench.parse_args(["--groups", "2", "--groups-graph", "64", "--topdown", "--topdown-u8"])
+    assert a.groups == 2 and a.groups_graph == 64 and a.topdown_u8 and a.lasers == 0

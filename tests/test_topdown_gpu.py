@@ -268,7 +268,7 @@ def test_topdown_rgb_single_frame(descs):
         env.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_topdown_uint8_images(descs, mode):
     """rgb_clip=False (pgdrive_env.py:133-141; top_down_obs_multi_channel.py:208-211, 277-280): the image as the uint8 pygame values
     instead of float32 / 255 -- pgd_observe_topdown_u8.  Two engines through the same 60 steps with auto-resets, one with float images,
@@ -279,10 +279,15 @@ def test_topdown_uint8_images(descs, mode):
     n = 40
     mb, sb = util.make_banks(descs, n_maps=8)
     cfg = _abi.make_config(n, num_agents=1, num_traffic=16, num_lasers=0, auto_reset=1, seed=3)
-    td = _abi.make_topdown_config(resolution=200, distance=30.0, mode=1) if mode else _abi.make_topdown_config()
+    # mode 2: an odd resolution (85 x 85 x 5 bytes per image: no image starts on a 16-byte boundary, the byte-by-byte stream-out);
+    # mode 3: 96 x 96 x 4 at 25 m (two stacked frames; an image of two bands of rows: the band loop of the gather and of the stream-out)
+    td = {0: _abi.make_topdown_config(), 1: _abi.make_topdown_config(resolution=200, distance=30.0, mode=1),
+          2: _abi.make_topdown_config(resolution=85), 3: _abi.make_topdown_config(96, 25.0, 2, 3, 4)}[mode]
     a, b = Engine(cfg, mb, sb), Engine(cfg, mb, sb)
     a.enable_topdown(td)
     b.enable_topdown(td, uint8=True)
+    if mode >= 2:
+        assert b.img.shape == {2: (n, 85, 85, 5), 3: (n, 96, 96, 4)}[mode]
     assert b.img.dtype == torch.uint8 and b.img.shape == a.img.shape
     ids = np.arange(n) % 8
     a.reset(ids); b.reset(ids)
@@ -316,7 +321,7 @@ def test_topdown_uint8_images(descs, mode):
         assert np.array_equal(u, want), "step %d: %d bytes differ" % (t, int((u != want).sum()))
         seen |= set(np.unique(u).tolist())
     assert n_done > 5
-    if mode:
+    if mode == 1:
         assert seen <= {0, 35, 50, 100, 200, 255} and {35, 50, 200} <= seen
     else:  # road channel: (lines x 35 + route texels x 64) / 2 of a 2 x 2 cell, truncated; past positions 255; vehicle boxes 176
         road = {(nl * 35 + nn * 64) >> 1 for nl in range(5) for nn in range(5) if nl + nn <= 4}
@@ -344,3 +349,49 @@ def test_topdown_env_uint8():
             assert o.dtype == np.uint8 and env.observation_space.contains(o) and o[..., 0].max() > 0 and o[..., 1].max() == 255
     finally:
         env.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_topdown_tile_occupancy_changes_nothing(descs, monkeypatch, mode):
+    """k_topdown gathers an 8 x 8 pixel tile of the window only if the bounding box of its pixel centres touches a raster line in which
+    something is drawn (TopDown::occ, one byte per 64-byte line, built with the rasters); PGD_TD_NO_OCC=1 gathers every tile.  Same
+    images, every pixel, over 50 steps with resets on all eight maps -- float and byte images, both modes -- and most of what the
+    occupancy skips is there to be skipped (the mean image is mostly empty)."""
+    import torch
+    from pgdrive_amd.engine import Engine
+    n = 48
+    mb, sb = util.make_banks(descs, n_maps=8)
+    cfg = _abi.make_config(n, num_agents=1, num_traffic=16, num_lasers=0, auto_reset=1, seed=5)
+    td = _abi.make_topdown_config(resolution=200, distance=30.0, mode=1) if mode else _abi.make_topdown_config()
+    monkeypatch.delenv("PGD_TD_NO_OCC", raising=False)
+    a, a8 = Engine(cfg, mb, sb), Engine(cfg, mb, sb)
+    a.enable_topdown(td); a8.enable_topdown(td, uint8=True)
+    ids = np.arange(n) % 8
+    for e in (a, a8):
+        e.reset(ids)
+        e.observe_topdown()  # (the rasters and their occupancy bytes are built by the first image)
+    monkeypatch.setenv("PGD_TD_NO_OCC", "1")
+    b, b8 = Engine(cfg, mb, sb), Engine(cfg, mb, sb)
+    b.enable_topdown(td); b8.enable_topdown(td, uint8=True)
+    for e in (b, b8):
+        e.reset(ids)
+        e.observe_topdown()
+    monkeypatch.delenv("PGD_TD_NO_OCC", raising=False)
+    assert torch.equal(a.img, b.img) and torch.equal(a8.img, b8.img)
+    rng = np.random.default_rng(8)
+    n_done = 0
+    filled = 0.0
+    for t in range(50):
+        act = util.driving_actions(rng, n)
+        act[::2, 0, 1] = 1.0
+        at = torch.from_numpy(act).to(a.device)
+        for e in (a, a8, b, b8):
+            _, _, dn, _ = e.step(at)
+        n_done += int(dn.sum())
+        ia, ib, ia8, ib8 = a.observe_topdown(), b.observe_topdown(), a8.observe_topdown(), b8.observe_topdown()
+        assert torch.equal(ia, ib), "step %d: %d float pixels differ" % (t, int((ia != ib).sum()))
+        assert torch.equal(ia8, ib8), "step %d: %d bytes differ" % (t, int((ia8 != ib8).sum()))
+        filled += float((ia[..., 0] > 0).float().mean())
+    assert n_done > 5 and 0.02 < filled / 50 < 0.6
+    for e in (a, a8, b, b8):
+        e.close()
