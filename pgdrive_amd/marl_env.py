@@ -146,6 +146,25 @@ class MultiAgentRoundaboutVecEnv:
         buffer (Engine.step) -- clone before editing rows in place, or create the env with PGD_NO_ROWZ=1 in the environment."""
         return self.engine.step(actions.contiguous())
 
+    # -- asynchronous env groups (pgd_set_groups / pgd_step_group): a multi-agent step is two launches, a step kernel that waits for
+    # memory half of its life and an observation kernel; as two halves on two streams the step of one half runs beside the observation of
+    # the other (40 seats, 4096 envs: 81 -> 93 M env-steps/s, bench.py row c5_40x72_two_groups; examples/marl_env_groups.py) ----------
+    def set_groups(self, n_groups):
+        """Split the envs into `n_groups` equal contiguous groups with their own streams (`engine.group_streams`)."""
+        self.engine.set_groups(n_groups)
+
+    def step_group(self, g, actions):
+        """Step the envs of group g only, asynchronously on the group's stream; `actions` is the full [N, A, 2] tensor (the group reads
+        its own rows).  Returns views of the group's rows of the engine's buffers: (obs, reward, done, flags) -- work that reads them
+        belongs on `engine.group_streams[g]`, or behind `group_sync(g)`."""
+        return self.engine.step_group(g, actions.contiguous())
+
+    def group_sync(self, g):
+        self.engine.group_sync(g)
+
+    def group_slice(self, g):
+        return self.engine.group_slice(g)
+
     def slot_table(self):
         """Host copy of (status, agent id) per slot: ([N, A] int, [N, A] int)."""
         f, i, _ = self.engine.get_state()

@@ -401,6 +401,20 @@ def test_multi_agent_env_groups_step_like_one_batch():
         n_done += int(dn.sum()); n_new += int(((fl & _abi.F_NEW) != 0).sum())
     assert n_done > 40 and n_new > 40
     assert "40 agent seats" in one.describe_step() and "40 agent seats" in two.describe_step()
+    # the same from the env surface (MultiAgent*VecEnv.set_groups / step_group / group_sync)
+    from pgdrive_amd import MultiAgentRoundaboutVecEnv
+    e1, e2 = (MultiAgentRoundaboutVecEnv(dict(num_envs=16, num_agents=40, seed=3)) for _ in range(2))
+    e1.reset(); e2.reset()
+    e2.set_groups(2)
+    for t in range(40):
+        a = torch.from_numpy(util.marl_actions(rng, 16, e1.A)).to(e1.engine.device)
+        o, r, dn, fl = [x.clone() for x in e1.step(a)]
+        for g in (0, 1):
+            og, rg, dg, fg = e2.step_group(g, a)
+            e2.group_sync(g)
+            sl = e2.group_slice(g)
+            assert torch.equal(og, o[sl]) and torch.equal(rg, r[sl]) and torch.equal(dg, dn[sl]) and torch.equal(fg, fl[sl])
+    e1.close(); e2.close()
     f1, i1, e1 = one.get_state()
     f2, i2, e2 = two.get_state()
     assert (i1 == i2).all() and (e1 == e2).all() and np.array_equal(f1, f2)
