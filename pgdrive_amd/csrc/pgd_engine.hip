@@ -220,11 +220,13 @@ constexpr FixSpec fix_spec(int fix) {
   F(c.idm_steer_lag, 0.0f)
 // ... and, on top of that list, the engine's SEAT COUNT for the two geometries the reference's default agent counts produce here:
 // 40 seats (MultiAgentRoundaboutEnv's 40 agents, marl_inout_roundabout.py:26: the vec env and bench.py's c5_40x72 row) and 44 (the
-// dict-keyed envs keep spare seats: pgdrive_amd/marl_env.py) with the reference's 72 beams (multi_agent_pgdrive.py:38).  FIX = the seat
-// count.  With V, A, the lanes per seat, the row width and the beam count literals the 40-seat step runs at 115 registers instead of
+// dict-keyed envs keep spare seats: pgdrive_amd/marl_env.py) with the reference's 72 beams (multi_agent_pgdrive.py:38) -- and the 8 seats of
+// BASELINE.json's multi-agent configuration ("4096 envs x 8 controlled agents, multi-agent roundabout"), with the 72 beams of the
+// multi-agent default and with the 240 of the metric (bench.py's c5_8x72 / c5_8x240 rows).  FIX = seats x 1000 + beams.  With V, A, the lanes per seat, the row width and the beam count literals the 40-seat step runs at 115 registers instead of
 // 128 and 23 scalar spills instead of 77: k_step 28.4 -> 26.3 us, k_observe_env 30.2 -> 29.5 us (64 registers), the row 76.8 -> 81.1 M
 // (round 6, profiles/r06_notes.md).  The respawn table's shape and the horizon stay run-time values (they differ between the maps).
-#define PGD_FIXM_SEAT_FIELDS(F, d, c, S) F(d.V, S) F(d.A, S) F(d.sub, (WAVE / (S))) F(d.D, 90) F(c.num_agents, S) F(c.num_lasers, 72)
+#define PGD_FIXM_SEAT_FIELDS(F, d, c, S, NL) F(d.V, S) F(d.A, S) F(d.sub, (WAVE / (S))) F(d.D, (18 + (NL))) F(c.num_agents, S) F(c.num_lasers, NL)
+#define PGD_FIXM_SEAT_CODES {40072, 44072, 8072, 8240}
 // BASELINE config 2: the ego alone, no lidar (dynamics + reward + the 18-float state vector), otherwise the single-agent defaults --
 // four envs per wave, 16 sub-lanes per ego, the row written by k_step itself.
 #define PGD_FIXE_FIELDS(F, d, c)                                                                                                    \
@@ -242,7 +244,7 @@ DEV void write_fixed_config(PgdDev& d) {
 #define PGD_F_SET(f, v) f = v;
   if (MARL) {
     PGD_FIXM_FIELDS(PGD_F_SET, d, c)
-    if (FIX > 1 && FIX != 9) { PGD_FIXM_SEAT_FIELDS(PGD_F_SET, d, c, (FIX > 1 ? FIX : WAVE)) }
+    if (FIX >= 1000) { PGD_FIXM_SEAT_FIELDS(PGD_F_SET, d, c, (FIX >= 1000 ? FIX / 1000 : WAVE), (FIX % 1000)) }
   }
   else if (!ONE_ENV && !STD) { PGD_FIXE_FIELDS(PGD_F_SET, d, c) }
 #ifdef PGD_JIT
@@ -275,13 +277,14 @@ static bool fix_config_matches(const PgdDev& d, bool one_env, int kind = FIXK_DE
   return ok;
 }
 // the multi-agent instantiations with the seat count folded: which one (0 = none) an engine that passed FIXK_MARL can run
-static int marl_fix_seats(const PgdDev& d) {
-  for (int S : {40, 44}) {
+static int marl_fix_seats(const PgdDev& d) {  // (the code seats x 1000 + beams, or 0)
+  for (int code : PGD_FIXM_SEAT_CODES) {
+    const int S = code / 1000, NL = code % 1000;
     bool ok = true;
 #define PGD_F_TEST(f, v) ok = ok && (f == v);
-    PGD_FIXM_SEAT_FIELDS(PGD_F_TEST, d, d.cfg, S)
+    PGD_FIXM_SEAT_FIELDS(PGD_F_TEST, d, d.cfg, S, NL)
 #undef PGD_F_TEST
-    if (ok) return S;
+    if (ok) return code;
   }
   return 0;
 }
@@ -1401,7 +1404,7 @@ template <int NW, bool FIX = false, bool STATE = true, int SEATS = 0>  // SEATS:
 __global__ PGD_KOE_ATTR __launch_bounds__(WAVE * NW, (FIX ? 7 : 1)) void k_observe_env(PgdDev d, float* __restrict__ obs, const uint32_t* __restrict__ flags, int G) {
   if (FIX) write_fixed_config<true, true, false, (SEATS ? SEATS : 1)>(d);
   extern __shared__ unsigned s_minb_dyn[];
-  constexpr int CAP = SEATS ? (SEATS + 15) / 16 * 16 : WAVE;
+  constexpr int CAP = SEATS ? (SEATS / 1000 + 15) / 16 * 16 : WAVE;
   __shared__ ObsEnvLds<NW, CAP> M;
   PHASE_INIT();  // (profile builds: the marks of observe_env_body count from here)
   observe_env_body<NW, !FIX, false, !FIX, STATE, CAP>(d, (int)blockIdx.x + d.unit_off * d.epw, obs, flags, M, s_minb_dyn, G);  // (the fixed-config kernel: no traffic objects)
@@ -1898,8 +1901,8 @@ static int launch_observe(pgd_handle h, float* d_obs, const uint32_t* d_flags, c
       if (fix) ke = four ? k_observe_env<4, true> : k_observe_env<1, true>;
       if (state_done && four) ke = fix ? k_observe_env<4, true, false> : k_observe_env<4, false, false>;
       const int seats = (fix && four) ? marl_fix_seats(D) : 0;
-      if (seats == 40) ke = state_done ? k_observe_env<4, true, false, 40> : k_observe_env<4, true, true, 40>;
-      if (seats == 44) ke = state_done ? k_observe_env<4, true, false, 44> : k_observe_env<4, true, true, 44>;
+      if (seats == 40072) ke = state_done ? k_observe_env<4, true, false, 40072> : k_observe_env<4, true, true, 40072>;
+      if (seats == 44072) ke = state_done ? k_observe_env<4, true, false, 44072> : k_observe_env<4, true, true, 44072>;
       hipLaunchKernelGGL(ke, dim3(envs), dim3(WAVE * nw), dyn, stream, D, d_obs, d_flags, G);
       HIPCHK(hipGetLastError());
       return PGD_OK;
@@ -2015,8 +2018,10 @@ static int step_impl(pgd_handle h, const float* d_actions, float* d_obs, float* 
       kern = k_step<true, true, false, false, 1>;
       kname = "k_step: one env per wave, specialised for the default multi-agent configuration";
       const int seats = marl_fix_seats(dv);
-      if (seats == 40) { kern = k_step<true, true, false, false, 40>; kname = "k_step: one env per wave, specialised for the default multi-agent configuration with 40 agent seats x 72 beams"; }
-      if (seats == 44) { kern = k_step<true, true, false, false, 44>; kname = "k_step: one env per wave, specialised for the default multi-agent configuration with 44 agent seats x 72 beams"; }
+      if (seats == 40072) { kern = k_step<true, true, false, false, 40072>; kname = "k_step: one env per wave, specialised for the default multi-agent configuration with 40 agent seats x 72 beams"; }
+      if (seats == 44072) { kern = k_step<true, true, false, false, 44072>; kname = "k_step: one env per wave, specialised for the default multi-agent configuration with 44 agent seats x 72 beams"; }
+      if (seats == 8072) { kern = k_step<true, true, false, false, 8072>; kname = "k_step: one env per wave, specialised for the default multi-agent configuration with 8 agent seats x 72 beams"; }
+      if (seats == 8240) { kern = k_step<true, true, false, false, 8240>; kname = "k_step: one env per wave, specialised for the default multi-agent configuration with 8 agent seats x 240 beams"; }
     }
   }
   else if (h->d.epw == 1) {

@@ -421,21 +421,22 @@ def test_multi_agent_env_groups_step_like_one_batch():
     one.close(); two.close()
 
 
-@pytest.mark.parametrize("agents,seats", [(8, 12), (40, 40), (40, 44)])
-def test_default_multi_agent_kernel_matches_the_general_kernel(monkeypatch, agents, seats):
+@pytest.mark.parametrize("agents,seats,beams", [(8, 12, 72), (40, 40, 72), (40, 44, 72), (8, 8, 72), (8, 8, 240)])
+def test_default_multi_agent_kernel_matches_the_general_kernel(monkeypatch, agents, seats, beams):
     """Multi-agent engines with the scalar fields of MULTI_AGENT_PGDRIVE_DEFAULT_CONFIG get their own instantiation of k_step (those
     fields are compile-time constants in it; agent count, spawn places and horizon stay run-time values) -- and, round 6, the seat
     counts the reference's default agent number produces (40: the vec env; 44: the dict-keyed envs' spare seats) instantiations with
-    the seat count, the row width and the 72 beams folded as well, in the step AND in the four-wave observation kernel.  Against the
+    the seat count, the row width and the 72 beams folded as well, in the step AND in the four-wave observation kernel; and the 8 seats
+    of BASELINE.json's multi-agent configuration with 72 and with 240 beams (the observation fused into the step).  Against the
     general kernels (PGD_NO_FIX=1) from the same state with the same actions: flags, done, integer state identical, floats to rounding."""
     import torch
     from pgdrive_amd.engine import Engine
     d, mb, sb = util.make_marl_banks(num_agents=agents, capacity=seats, kind="roundabout")
     n_envs = 32
-    cfg = util.marl_config(n_envs, sb, horizon=120)
+    cfg = util.marl_config(n_envs, sb, horizon=120, num_lasers=beams)
     monkeypatch.delenv("PGD_NO_FIX", raising=False)
     fix = Engine(cfg, mb, sb)
-    other = Engine(util.marl_config(n_envs, sb, horizon=120, delay_done=10), mb, sb)
+    other = Engine(util.marl_config(n_envs, sb, horizon=120, delay_done=10, num_lasers=beams), mb, sb)
     monkeypatch.setenv("PGD_NO_FIX", "1")
     gen = Engine(cfg, mb, sb)
     ids = np.arange(n_envs) % 8
@@ -469,7 +470,7 @@ def test_default_multi_agent_kernel_matches_the_general_kernel(monkeypatch, agen
     assert n_done > 20 and n_new > 20 and n_graze <= 3, n_graze
     other.step(torch.from_numpy(util.marl_actions(rng, n_envs, sb.A)).to(other.device)); other.sync()
     assert "specialised for the default multi-agent" in fix.describe_step()
-    assert ("%d agent seats x 72 beams" % seats in fix.describe_step()) == (seats in (40, 44)), fix.describe_step()
+    assert ("%d agent seats x %d beams" % (seats, beams) in fix.describe_step()) == (seats in (40, 44, 8)), fix.describe_step()
     assert "specialised" not in gen.describe_step() and "specialised" not in other.describe_step()
     for e in (fix, gen, other):
         e.close()
