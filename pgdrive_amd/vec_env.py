@@ -307,6 +307,26 @@ class PGDriveVecEnv:
             return self.engine.observe_topdown(), rew.view(-1), done.view(-1), flags.view(-1)
         return obs.view(self.num_envs, self.obs_dim), rew.view(-1), done.view(-1), flags.view(-1)
 
+    # -- asynchronous env groups (pgd_set_groups / pgd_step_group; double-buffered sampling: the policy of one group runs while the other
+    # steps -- bench.py's closed-loop rows, examples/fused_policy_rollout.py).  Lidar observations only (the top-down image is one launch
+    # over every env of the handle).
+    def set_groups(self, n_groups):
+        self.engine.set_groups(n_groups)
+
+    def step_group(self, g, actions):
+        """Step the envs of group g only, asynchronously on `engine.group_streams[g]`; `actions` is the full [N, 2] tensor.  Returns views
+        of the group's rows (obs [n, D], reward, done, flags)."""
+        if self.topdown:
+            raise NotImplementedError("step_group with the top-down observation")
+        obs, rew, done, flags = self.engine.step_group(g, actions.contiguous().view(self.num_envs, 1, 2))
+        return obs.view(-1, self.obs_dim), rew.view(-1), done.view(-1), flags.view(-1)
+
+    def group_sync(self, g):
+        self.engine.group_sync(g)
+
+    def group_slice(self, g):
+        return self.engine.group_slice(g)
+
     def info_from_flags(self, flags):
         """Host-side decode of the flag bit-field into the reference's info keys (pgdrive_env.py:165-194)."""
         fl = np.asarray(flags.cpu() if hasattr(flags, "cpu") else flags).astype(np.uint32)

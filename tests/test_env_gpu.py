@@ -756,6 +756,20 @@ def test_env_groups_step_like_one_batch(descs):
     assert torch.equal(b.obs[others], before[others])  # the other groups' rows were not touched
     a.close()
     b.close()
+    # the same from the env surface (PGDriveVecEnv.set_groups / step_group / group_sync / group_slice)
+    from pgdrive_amd import PGDriveVecEnv
+    e1, e2 = (PGDriveVecEnv(dict(num_envs=64, start_seed=1000, environment_num=8, seed=2)) for _ in range(2))
+    e1.reset(); e2.reset()
+    e2.set_groups(2)
+    for t in range(30):
+        act = torch.from_numpy(util.driving_actions(rng, 64)).to(e1.engine.device).view(64, 2)
+        o, r, dn, fl = [x.clone() for x in e1.step(act)]
+        for g in (1, 0):
+            og, rg, dg, fg = e2.step_group(g, act)
+            e2.group_sync(g)
+            s2 = e2.group_slice(g)
+            assert torch.equal(og, o[s2]) and torch.equal(rg, r[s2]) and torch.equal(dg, dn[s2]) and torch.equal(fg, fl[s2])
+    e1.close(); e2.close()
 
 
 @pytest.mark.gpu
