@@ -1,4 +1,5 @@
-"""The seat-folded multi-agent kernels (40 / 44 seats x 72 beams: k_step<..., 40 | 44> + k_observe_env<4, ..., 40 | 44>) against the general
+"""The seat-folded multi-agent kernels (40 / 44 seats x 72 beams: k_step<..., 40072 | 44072> + k_observe_env<4, ..., 40072 | 44072>; 8 seats x
+72 / 240 beams: k_step<..., 8072 | 8240> with the observation fused) against the general
 kernels (PGD_NO_FIX=1) over a long run: every step both engines start from the general engine's state and take the same actions
 (tests/test_parity_gpu.py::test_default_multi_agent_kernel_matches_the_general_kernel, 300 steps x 32 envs there).  Reports flag / done /
 integer-state differences, the largest float differences of the rows that are due, and the corner-grazing beam flips.
@@ -17,9 +18,9 @@ from tests import util  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 n_envs = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-for seats in (40, 44):
-    d, mb, sb = util.make_marl_banks(num_agents=40, capacity=seats, kind="roundabout")
-    cfg = util.marl_config(n_envs, sb, horizon=300)
+for seats, beams in ((40, 72), (44, 72), (8, 72), (8, 240)):
+    d, mb, sb = util.make_marl_banks(num_agents=min(seats, 40), capacity=seats, kind="roundabout")
+    cfg = util.marl_config(n_envs, sb, horizon=300, num_lasers=beams)
     os.environ.pop("PGD_NO_FIX", None)
     fix = Engine(cfg, mb, sb)
     os.environ["PGD_NO_FIX"] = "1"
@@ -55,8 +56,8 @@ for seats in (40, 44):
         n_int += int((i1 != i2).sum()) + int((e1 != e2).sum())
         worst_state = max(worst_state, float(np.abs(g1 - g2).max()))
         n_done += int(d1.sum()); n_new += int(((f1 & _abi.F_NEW) != 0).sum())
-    print("%d seats: %d steps x %d envs, %d rows due, %d finishes, %d (re)spawns | flag/done differences %d, integer-state differences %d, "
+    print("%d seats x %d beams: %d steps x %d envs, %d rows due, %d finishes, %d (re)spawns | flag/done differences %d, integer-state differences %d, "
           "corner-grazing beam flips %d of %d beams, worst |obs| %.2e, |reward| %.2e, |state| %.2e  [%s]" %
-          (seats, steps, n_envs, rows_due, n_done, n_new, n_flag, n_int, n_graze, rows_due * 72, worst_obs, worst_rew, worst_state,
+          (seats, beams, steps, n_envs, rows_due, n_done, n_new, n_flag, n_int, n_graze, rows_due * beams, worst_obs, worst_rew, worst_state,
            fix.describe_step()), flush=True)
     fix.close(); gen.close()
